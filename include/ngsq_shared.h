@@ -1,0 +1,249 @@
+/*
+ * ngsq_shared.h -- pure integer functions compiled identically for the host
+ * (C / C++) and the device (HIP): the pinned GC-window offset and the
+ * synthetic record generator of SURVEY.md 8(d) ("Value distributions").
+ *
+ * Everything here is integer arithmetic on counter-based hashes keyed by
+ * (seed, record index, field), so any shard regenerates its slice and host
+ * and device produce identical bytes.  No floating point, no libm.
+ */
+#ifndef NGSQ_SHARED_H
+#define NGSQ_SHARED_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NGSQ_HD __host__ __device__ static inline
+#else
+#define NGSQ_HD static inline
+#endif
+
+/* splitmix64 finalizer (Steele, Lea, Flood 2014): a bijective 64-bit mix */
+NGSQ_HD uint64_t ngsq_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/*
+ * GC window start.  Reference: gc_content.rs:69-74
+ *     offset = if 100 < len { rng.gen_range(0..len-100) } else { 0 }
+ * Same support (upper bound exclusive), but a pure function of the record's
+ * index in the file so that results are reproducible and shard-invariant.
+ */
+NGSQ_HD uint32_t ngsq_gc_offset_fn(uint64_t gc_seed, uint64_t record_index, uint32_t l_seq) {
+    if (l_seq <= 100u) return 0u;
+    return (uint32_t)(ngsq_mix64(gc_seed ^ record_index) % (uint64_t)(l_seq - 100u));
+}
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic records.                                        */
+/* ------------------------------------------------------------------------ */
+
+#define NGSQ_SYNTH_FIXED 0u /* every read `read_len` bases, CIGAR lM (configs 1-4)          */
+#define NGSQ_SYNTH_MIXED 1u /* l ~ U{min_len..max_len}, soft-clip/indel/skip CIGARs (cfg 5) */
+
+#define NGSQ_SYNTH_MAX_OPS 3u
+
+typedef struct ngsq_synth_config {
+    uint64_t seed;      /* default 0x4E4753 ("NGS")                                   */
+    uint64_t n_total;   /* records in the whole synthetic file (sets the pos spacing)  */
+    uint32_t mode;      /* NGSQ_SYNTH_FIXED / NGSQ_SYNTH_MIXED                         */
+    uint32_t read_len;  /* FIXED: read length (150)                                    */
+    uint32_t min_len;   /* MIXED: 50                                                   */
+    uint32_t max_len;   /* MIXED: 300                                                  */
+    uint32_t ref_len;   /* length of reference 0 (chr1 = 248 956 422)                  */
+    uint32_t n_refs;    /* 1, or 2 (reference 1 only ever appears as a mate reference) */
+} ngsq_synth_config;
+
+/* fixed-width part of one synthetic record */
+typedef struct ngsq_synth_record {
+    uint16_t flag;
+    uint8_t mapq;
+    uint8_t n_cigar;
+    int32_t ref_id;
+    int32_t pos; /* 0-based */
+    int32_t mate_ref_id;
+    int32_t tlen;
+    uint32_t l_seq;
+    uint32_t cigar[NGSQ_SYNTH_MAX_OPS]; /* len<<4|op */
+} ngsq_synth_record;
+
+/* field keys of the counter-based hash */
+#define NGSQ_KEY_FLAG 1ull
+#define NGSQ_KEY_MAPQ 2ull
+#define NGSQ_KEY_POS 3ull
+#define NGSQ_KEY_TLEN 4ull
+#define NGSQ_KEY_LEN 5ull
+#define NGSQ_KEY_CIGAR 6ull
+#define NGSQ_KEY_SEQ 7ull
+#define NGSQ_KEY_QUAL 8ull
+
+NGSQ_HD uint64_t ngsq_synth_hash(uint64_t seed, uint64_t i, uint64_t key, uint64_t word) {
+    return ngsq_mix64(ngsq_mix64(seed ^ (key << 56) ^ i) + word);
+}
+
+NGSQ_HD uint32_t ngsq_synth_len(const ngsq_synth_config *c, uint64_t i) {
+    if (c->mode == NGSQ_SYNTH_FIXED) return c->read_len;
+    uint64_t h = ngsq_synth_hash(c->seed, i, NGSQ_KEY_LEN, 0);
+    return c->min_len + (uint32_t)(h % (uint64_t)(c->max_len - c->min_len + 1u));
+}
+
+/* The fixed-width fields of record i. */
+NGSQ_HD void ngsq_synth_record_at(const ngsq_synth_config *c, uint64_t i, ngsq_synth_record *r) {
+    const uint64_t hf = ngsq_synth_hash(c->seed, i, NGSQ_KEY_FLAG, 0);
+    /* ten independent 16-bit draws out of two hashes */
+    const uint64_t hf2 = ngsq_synth_hash(c->seed, i, NGSQ_KEY_FLAG, 1);
+    const uint32_t d_paired = (uint32_t)(hf & 0xFFFF), d_proper = (uint32_t)((hf >> 16) & 0xFFFF),
+                   d_unmapped = (uint32_t)((hf >> 32) & 0xFFFF),
+                   d_mate_unmapped = (uint32_t)((hf >> 48) & 0xFFFF);
+    const uint32_t d_dup = (uint32_t)(hf2 & 0xFFFF), d_sec = (uint32_t)((hf2 >> 16) & 0xFFFF),
+                   d_sup = (uint32_t)((hf2 >> 32) & 0xFFFF), d_rev = (uint32_t)((hf2 >> 48) & 0xFFFF);
+
+    uint32_t flag = 0;
+    const int paired = d_paired < 64225u; /* 98 % */
+    const int unmapped = d_unmapped < 655u; /* 1 % */
+    if (paired) {
+        flag |= 0x1u;
+        flag |= (i & 1ull) ? 0x80u : 0x40u; /* read 1 / read 2 alternate */
+        if (d_mate_unmapped < 1311u) flag |= 0x8u; /* 2 % */
+        if (!unmapped && !(flag & 0x8u) && d_proper < 60948u) flag |= 0x2u; /* 93 % */
+    }
+    if (unmapped) flag |= 0x4u;
+    if (d_dup < 3277u) flag |= 0x400u; /* 5 % */
+    if (d_sec < 655u) flag |= 0x100u;  /* 1 % */
+    if (d_sup < 328u) flag |= 0x800u;  /* 0.5 % */
+    if (d_rev < 32768u) flag |= 0x10u; /* 50 % */
+    r->flag = (uint16_t)flag;
+
+    /* mapq: 255 w.p. 0.001, else 60 w.p. 0.8, else uniform 0..59 */
+    const uint64_t hm = ngsq_synth_hash(c->seed, i, NGSQ_KEY_MAPQ, 0);
+    const uint32_t m0 = (uint32_t)(hm & 0xFFFF), m1 = (uint32_t)((hm >> 16) & 0xFFFF);
+    if (m0 < 66u)
+        r->mapq = 255u;
+    else if (m1 < 52429u)
+        r->mapq = 60u;
+    else
+        r->mapq = (uint8_t)((hm >> 32) % 60ull);
+
+    /* position: coordinate-sorted by construction, never within 5300 of the end */
+    const uint64_t room = (c->ref_len > 5400u) ? (uint64_t)(c->ref_len - 5300u) : 100ull;
+    const uint64_t n = c->n_total ? c->n_total : 1ull;
+    const uint64_t step = room / n;
+    uint64_t start = 2ull + (i * room) / n; /* 1-based; >= 2 so placed-unmapped reads stay legal */
+    if (step > 0) start += ngsq_synth_hash(c->seed, i, NGSQ_KEY_POS, 0) % step;
+    r->ref_id = 0;
+    r->pos = (int32_t)(start - 1ull);
+
+    /* mate reference: same, except 1 % on reference 1 when it exists; none when unpaired */
+    const uint64_t hp = ngsq_synth_hash(c->seed, i, NGSQ_KEY_POS, 1);
+    if (!paired)
+        r->mate_ref_id = -1;
+    else if (c->n_refs >= 2u && (hp & 0xFFFF) < 655u)
+        r->mate_ref_id = 1;
+    else
+        r->mate_ref_id = 0;
+
+    /* template length: read 1 ~ 350 +- 50 (sum of four U{0..86}), read 2 negative,
+       0.5 % far out of range, 0 when unpaired */
+    const uint64_t ht = ngsq_synth_hash(c->seed, i, NGSQ_KEY_TLEN, 0);
+    int32_t t = 178 + (int32_t)((ht & 0xFFFF) % 87u) + (int32_t)(((ht >> 16) & 0xFFFF) % 87u) +
+                (int32_t)(((ht >> 32) & 0xFFFF) % 87u) + (int32_t)(((ht >> 48) & 0xFFFF) % 87u);
+    const uint64_t ht2 = ngsq_synth_hash(c->seed, i, NGSQ_KEY_TLEN, 1);
+    if ((ht2 & 0xFFFF) < 328u) t = 1025 + (int32_t)((ht2 >> 16) % 4000ull);
+    if (!paired)
+        t = 0;
+    else if (i & 1ull)
+        t = -t;
+    r->tlen = t;
+
+    const uint32_t l = ngsq_synth_len(c, i);
+    r->l_seq = l;
+
+    /* CIGAR */
+    r->cigar[0] = r->cigar[1] = r->cigar[2] = 0;
+    if (unmapped) {
+        r->n_cigar = 0;
+    } else if (c->mode == NGSQ_SYNTH_FIXED) {
+        r->n_cigar = 1;
+        r->cigar[0] = (l << 4) | 0u;
+    } else {
+        const uint64_t hc = ngsq_synth_hash(c->seed, i, NGSQ_KEY_CIGAR, 0);
+        const uint32_t kind = (uint32_t)(hc & 0xFFFF);
+        const uint32_t side = (uint32_t)((hc >> 16) & 1ull);
+        const uint32_t r1 = (uint32_t)((hc >> 24) & 0xFFFF), r2 = (uint32_t)((hc >> 40) & 0xFFFF);
+        if (kind < 45875u) { /* 70 %  lM */
+            r->n_cigar = 1;
+            r->cigar[0] = (l << 4) | 0u;
+        } else if (kind < 55706u) { /* 15 %  aS bM | bM aS, a in 1..30 */
+            const uint32_t a = 1u + r1 % 30u, b = l - a;
+            r->n_cigar = 2;
+            if (side) {
+                r->cigar[0] = (a << 4) | 4u;
+                r->cigar[1] = (b << 4) | 0u;
+            } else {
+                r->cigar[0] = (b << 4) | 0u;
+                r->cigar[1] = (a << 4) | 4u;
+            }
+        } else if (kind < 62259u) { /* 10 %  aM dD bM | aM iI bM, d,i in 1..10 */
+            const uint32_t g = 1u + r1 % 10u;
+            r->n_cigar = 3;
+            if (side) { /* deletion: read bases = a + b = l */
+                const uint32_t a = 1u + r2 % (l - 1u), b = l - a;
+                r->cigar[0] = (a << 4) | 0u;
+                r->cigar[1] = (g << 4) | 2u;
+                r->cigar[2] = (b << 4) | 0u;
+            } else { /* insertion: a + g + b = l, l >= 50 > g + 2 */
+                const uint32_t a = 1u + r2 % (l - g - 1u), b = l - g - a;
+                r->cigar[0] = (a << 4) | 0u;
+                r->cigar[1] = (g << 4) | 1u;
+                r->cigar[2] = (b << 4) | 0u;
+            }
+        } else { /* 5 %  aM nN bM, n in 100..5000 */
+            const uint32_t g = 100u + r1 % 4901u;
+            const uint32_t a = 1u + r2 % (l - 1u), b = l - a;
+            r->n_cigar = 3;
+            r->cigar[0] = (a << 4) | 0u;
+            r->cigar[1] = (g << 4) | 3u;
+            r->cigar[2] = (b << 4) | 0u;
+        }
+    }
+}
+
+/* 4-bit base code from a 16-bit draw: N 0.1 %, A/T 29.47 % each, C/G 20.48 % each */
+NGSQ_HD uint32_t ngsq_synth_base_code(uint32_t r16) {
+    if (r16 < 66u) return 15u;    /* N */
+    if (r16 < 19380u) return 1u;  /* A */
+    if (r16 < 32801u) return 2u;  /* C */
+    if (r16 < 46222u) return 4u;  /* G */
+    return 8u;                    /* T */
+}
+
+/* packed sequence byte j (bases 2j, 2j+1; high nibble first) of record i */
+NGSQ_HD uint8_t ngsq_synth_seq_byte(const ngsq_synth_config *c, uint64_t i, uint32_t l_seq,
+                                    uint32_t j) {
+    /* one hash feeds four 16-bit draws = two bytes */
+    const uint64_t h = ngsq_synth_hash(c->seed, i, NGSQ_KEY_SEQ, (uint64_t)(j >> 1));
+    const uint32_t sh = (j & 1u) * 32u;
+    const uint32_t hi = ngsq_synth_base_code((uint32_t)((h >> sh) & 0xFFFF));
+    uint32_t lo = ngsq_synth_base_code((uint32_t)((h >> (sh + 16u)) & 0xFFFF));
+    if (2u * j + 1u >= l_seq) lo = 0u; /* pad nibble of an odd-length read */
+    return (uint8_t)((hi << 4) | lo);
+}
+
+/* Phred score of cycle j (0-based) of record i:
+   P(37) = 0.9 - 0.3 j/l, remainder split .5/.3/.2 over 25/11/2 */
+NGSQ_HD uint8_t ngsq_synth_qual_byte(const ngsq_synth_config *c, uint64_t i, uint32_t l_seq,
+                                     uint32_t j) {
+    const uint64_t h = ngsq_synth_hash(c->seed, i, NGSQ_KEY_QUAL, (uint64_t)(j >> 2));
+    const uint32_t r = (uint32_t)((h >> ((j & 3u) * 16u)) & 0xFFFF);
+    const uint32_t t37 = 58982u - (19661u * j) / l_seq;
+    if (r < t37) return 37u;
+    const uint32_t rem = 65536u - t37, x = r - t37;
+    if (x * 10u < rem * 5u) return 25u;
+    if (x * 10u < rem * 8u) return 11u;
+    return 2u;
+}
+
+#endif /* NGSQ_SHARED_H */

@@ -1,0 +1,36 @@
+/*
+ * ngsq_synth.h -- synthetic record batches of SURVEY.md 8(d) for tests and
+ * bench.py (the reference's `ngs generate` makes FASTQ from a FASTA with an
+ * unseeded RNG, src/generate/command.rs:59-131, and cannot produce these).
+ * Records are a pure function of (seed, index): see ngsq_shared.h.
+ */
+#ifndef NGSQ_SYNTH_H
+#define NGSQ_SYNTH_H
+
+#include "ngsq.h"
+#include "ngsq_shared.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Byte / op totals of records [first, first+n): sizes of the seq, qual and cigar
+ * columns.  FIXED mode uses fixed strides ((l+1)/2, l, 1 op); MIXED uses offsets. */
+int ngsq_synth_sizes(const ngsq_synth_config *cfg, uint64_t first, uint64_t n, uint64_t *seq_bytes,
+                     uint64_t *qual_bytes, uint64_t *cigar_ops);
+
+/* Fill caller-allocated HOST columns of `batch` (the const is cast away: the
+ * pointers must be writable).  For MIXED mode seq_off/qual_off/cigar_off must
+ * point to n+1 entries; for FIXED mode they must be NULL and the strides set. */
+int ngsq_synth_fill_host(const ngsq_synth_config *cfg, uint64_t first, uint64_t n,
+                         const ngsq_batch *batch);
+
+/* Same on the context's device with DEVICE column pointers, generated in place
+ * by a HIP kernel (bit-identical to ngsq_synth_fill_host). */
+int ngsq_synth_fill_device(ngsq_ctx *ctx, const ngsq_synth_config *cfg, uint64_t first, uint64_t n,
+                           const ngsq_batch *batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,777 @@
+// context.cpp -- the C ABI of include/ngsq.h: context lifecycle, batch staging,
+// kernel sequencing on one HIP stream, teardown and integer result download.
+//
+// Host-side mirror of the reference driver's facet lifecycle
+// (src/qc/command.rs:288-418): process (batches) -> summarize/teardown ->
+// aggregate.  There is NO CPU fallback: without a usable GPU ngsq_create fails
+// with NGSQ_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ngsq.h"
+#include "../../include/ngsq_shared.h"
+#include "context.h"
+
+using namespace ngsq;
+
+static thread_local std::string g_err;
+
+static int fail(ngsq_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c)
+        c->err = buf;
+    else
+        g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), NGSQ_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+static const char *const KERNEL_NAMES[K_COUNT] = {"flags_tlen", "cigar_cov", "gc",       "qual",
+                                                  "edits",      "cov_scan",  "edits_vaf", "h2d"};
+
+extern "C" {
+
+uint32_t ngsq_abi_version(void) { return NGSQ_ABI_VERSION; }
+
+int ngsq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ngsq_facet_name(uint32_t bit) {
+    switch (bit) {
+    case NGSQ_FACET_GENERAL: return "General";
+    case NGSQ_FACET_TEMPLATE_LENGTH: return "Template Length";
+    case NGSQ_FACET_GC_CONTENT: return "GC Content";
+    case NGSQ_FACET_QUALITY_SCORE: return "Quality Score";
+    case NGSQ_FACET_COVERAGE: return "Coverage";
+    case NGSQ_FACET_EDITS: return "Edits";
+    default: return nullptr;
+    }
+}
+
+const char *ngsq_last_global_error(void) { return g_err.c_str(); }
+const char *ngsq_last_error(const ngsq_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+uint32_t ngsq_gc_offset(uint64_t seed, uint64_t idx, uint32_t l) { return ngsq_gc_offset_fn(seed, idx, l); }
+
+static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
+    if (!cfg || !out) return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(ngsq_config))
+        return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "ngsq_config.struct_size %u != %zu",
+                    cfg->struct_size, sizeof(ngsq_config));
+    if (cfg->n_refs && !cfg->ref_len)
+        return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "ref_len is null");
+    if (cfg->facets & ~(NGSQ_FACETS_RECORD_BASED | NGSQ_FACETS_SEQUENCE_BASED))
+        return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "unknown facet bits 0x%x", cfg->facets);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NGSQ_ERR_NO_DEVICE,
+                    "no HIP device available (%s); the ngs qc hot path has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", cfg->device,
+                    ndev - 1);
+
+    ngsq_ctx *c = new ngsq_ctx();
+    c->cfg = *cfg;
+    if (!c->cfg.bin_size) c->cfg.bin_size = 50000;
+    if (!c->cfg.tlen_cap) c->cfg.tlen_cap = 1024;
+    if (!c->cfg.cov_cap) c->cfg.cov_cap = 2048;
+    if (!c->cfg.max_read_len) c->cfg.max_read_len = 512;
+    if (c->cfg.max_read_len > NGSQ_MAX_READ_LEN_LIMIT || c->cfg.tlen_cap > 15000 || c->cfg.cov_cap > 15000) {
+        delete c;
+        return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "max_read_len/tlen_cap/cov_cap too large");
+    }
+    const uint32_t nr = cfg->n_refs;
+    c->ref_len.assign(cfg->ref_len, cfg->ref_len + nr);
+    c->primary.resize(nr);
+    for (uint32_t r = 0; r < nr; r++) c->primary[r] = cfg->ref_is_primary ? cfg->ref_is_primary[r] : 1;
+    c->cfg.ref_len = nullptr;
+    c->cfg.ref_is_primary = nullptr;
+    c->cfg.ref_bases = nullptr;
+    c->device = cfg->device;
+
+#define CTX_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            int rc_ = fail(nullptr, NGSQ_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            ngsq_destroy(c);                                                                   \
+            return rc_;                                                                        \
+        }                                                                                      \
+    } while (0)
+
+    CTX_TRY(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    CTX_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->li.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+        c->own_stream = false;
+    } else {
+        CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    CTX_TRY(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+
+    // ---- counters block
+    DeviceState &st = c->st;
+    st.tlen_cap = c->cfg.tlen_cap;
+    st.max_read_len = c->cfg.max_read_len;
+    st.n_refs = nr;
+    st.cov_cap = c->cfg.cov_cap;
+    st.gc_seed = c->cfg.gc_seed;
+    st.off_tlen = OFF_TLEN_HIST;
+    st.off_qual = (uint32_t)round_up(st.off_tlen + st.tlen_cap + 1, 8);
+    st.off_edits1 = st.off_qual + st.max_read_len * QUAL_BINS;
+    st.off_edits2 = st.off_edits1 + (uint32_t)round_up(NGSQ_EDITS_BINS, 8);
+    st.off_seen = st.off_edits2 + (uint32_t)round_up(NGSQ_EDITS_BINS, 8);
+    c->n_counters = round_up((uint64_t)st.off_seen + nr, 8);
+    CTX_TRY(hipMalloc((void **)&st.counters, c->n_counters * 8));
+    CTX_TRY(hipMemsetAsync(st.counters, 0, c->n_counters * 8, c->stream));
+    c->h_counters.assign(c->n_counters, 0);
+
+    // ---- per-sequence tables
+    std::vector<uint64_t> depth_off(nr, NO_DEPTH), edits_off(nr, NO_DEPTH), bases_off(nr, NO_DEPTH);
+    uint64_t nd = 0, ne = 0, nbases = 0;
+    c->bin_off.assign(nr + 1, 0);
+    uint64_t max_len = 0;
+    for (uint32_t r = 0; r < nr; r++) {
+        const uint64_t L = c->ref_len[r];
+        if (L > max_len) max_len = L;
+        if ((c->cfg.facets & NGSQ_FACET_COVERAGE) && c->primary[r]) {
+            depth_off[r] = nd;
+            nd += round_up(L + 2, 4);
+        }
+        const uint64_t nb = 1 + L / c->cfg.bin_size + (L % c->cfg.bin_size != 0);
+        c->bin_off[r + 1] = c->bin_off[r] + ((c->cfg.facets & NGSQ_FACET_COVERAGE) && c->primary[r] ? nb : 0);
+        if ((c->cfg.facets & NGSQ_FACET_EDITS) && cfg->ref_bases && cfg->ref_bases[r]) {
+            edits_off[r] = ne;
+            ne += round_up(2 * (L + 1), 4);
+            bases_off[r] = nbases;
+            nbases += round_up(L, 16);
+        }
+    }
+    c->depth_off = depth_off;
+    c->edits_off = edits_off;
+    c->n_depth = nd;
+    c->n_edits = ne;
+    if (nr) {
+        CTX_TRY(hipMalloc((void **)&c->d_ref_len, nr * 4));
+        CTX_TRY(hipMemcpy(c->d_ref_len, c->ref_len.data(), nr * 4, hipMemcpyHostToDevice));
+        CTX_TRY(hipMalloc((void **)&c->d_depth_off, nr * 8));
+        CTX_TRY(hipMemcpy(c->d_depth_off, depth_off.data(), nr * 8, hipMemcpyHostToDevice));
+        CTX_TRY(hipMalloc((void **)&c->d_edits_off, nr * 8));
+        CTX_TRY(hipMemcpy(c->d_edits_off, edits_off.data(), nr * 8, hipMemcpyHostToDevice));
+        CTX_TRY(hipMalloc((void **)&c->d_bases_off, nr * 8));
+        CTX_TRY(hipMemcpy(c->d_bases_off, bases_off.data(), nr * 8, hipMemcpyHostToDevice));
+    }
+    st.ref_len = c->d_ref_len;
+    st.ref_depth_off = c->d_depth_off;
+    st.ref_edits_off = c->d_edits_off;
+    st.ref_bases_off = c->d_bases_off;
+    if (nd) {
+        CTX_TRY(hipMalloc((void **)&st.depth, nd * 4));
+        CTX_TRY(hipMemsetAsync(st.depth, 0, nd * 4, c->stream));
+        const uint64_t chunks = (max_len + 2 + cov_scan_chunk_elems() - 1) / cov_scan_chunk_elems();
+        CTX_TRY(hipMalloc((void **)&c->d_chunk_sums, (chunks + 1) * 4));
+        c->n_cov_hist = (uint64_t)nr * (c->cfg.cov_cap + 2);
+        CTX_TRY(hipMalloc((void **)&c->d_cov_hist, c->n_cov_hist * 8));
+        CTX_TRY(hipMemsetAsync(c->d_cov_hist, 0, c->n_cov_hist * 8, c->stream));
+        CTX_TRY(hipMalloc((void **)&c->d_bin_totals, (c->bin_off[nr] + 1) * 8));
+        CTX_TRY(hipMemsetAsync(c->d_bin_totals, 0, (c->bin_off[nr] + 1) * 8, c->stream));
+        c->h_cov_hist.assign(c->n_cov_hist, 0);
+        c->h_bin_totals.assign(c->bin_off[nr] + 1, 0);
+    }
+    if (ne) {
+        CTX_TRY(hipMalloc((void **)&st.edits, ne * 4));
+        CTX_TRY(hipMemsetAsync(st.edits, 0, ne * 4, c->stream));
+        uint8_t *bases = nullptr;
+        CTX_TRY(hipMalloc((void **)&bases, nbases));
+        st.ref_bases = bases;
+        c->d_ref_bases = bases;
+        for (uint32_t r = 0; r < nr; r++)
+            if (bases_off[r] != NO_DEPTH)
+                CTX_TRY(hipMemcpy(bases + bases_off[r], cfg->ref_bases[r], c->ref_len[r], hipMemcpyHostToDevice));
+    }
+    if (c->cfg.facets & NGSQ_FACET_EDITS) {
+        CTX_TRY(hipMalloc((void **)&c->d_vaf, NGSQ_VAF_BINS * 8));
+        CTX_TRY(hipMemsetAsync(c->d_vaf, 0, NGSQ_VAF_BINS * 8, c->stream));
+    }
+    c->h_vaf.assign(NGSQ_VAF_BINS, 0);
+    for (int k = 0; k < K_COUNT; k++) c->timing[k] = {KERNEL_NAMES[k], 0, 0.0, 0};
+    CTX_TRY(hipStreamSynchronize(c->stream));
+#undef CTX_TRY
+    *out = c;
+    return NGSQ_OK;
+}
+
+void ngsq_destroy(ngsq_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto &ev : c->event_pool) (void)hipEventDestroy(ev);
+    for (int k = 0; k < 2; k++) {
+        if (c->stage[k].buf) (void)hipFree(c->stage[k].buf);
+        if (c->stage[k].done) (void)hipEventDestroy(c->stage[k].done);
+    }
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    (void)hipFree(c->st.counters);
+    (void)hipFree(c->st.depth);
+    (void)hipFree(c->st.edits);
+    (void)hipFree(c->d_ref_bases);
+    (void)hipFree(c->d_ref_len);
+    (void)hipFree(c->d_depth_off);
+    (void)hipFree(c->d_edits_off);
+    (void)hipFree(c->d_bases_off);
+    (void)hipFree(c->d_chunk_sums);
+    (void)hipFree(c->d_cov_hist);
+    (void)hipFree(c->d_bin_totals);
+    (void)hipFree(c->d_vaf);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---- kernel timing brackets -------------------------------------------------
+
+static hipEvent_t get_event(ngsq_ctx *c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Bracket {
+    ngsq_ctx *c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    Bracket(ngsq_ctx *c_, int id_, uint64_t bytes) : c(c_), id(id_) {
+        c->timing[id].launches += 1;
+        c->timing[id].algo_bytes += bytes;
+        if (c->cfg.timing) {
+            a = get_event(c);
+            b = get_event(c);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~Bracket() {
+        if (c->cfg.timing) {
+            (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({id, a, b});
+        }
+    }
+};
+
+static void resolve_timing(ngsq_ctx *c) {
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->timing[p.id].total_ms += ms;
+        c->event_pool.push_back(p.a);
+        c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+// ---- batches ----------------------------------------------------------------
+
+static int check_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t facets) {
+    if (b->struct_size != sizeof(ngsq_batch))
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "ngsq_batch.struct_size %u != %zu", b->struct_size,
+                    sizeof(ngsq_batch));
+    if (b->location != NGSQ_MEM_HOST && b->location != NGSQ_MEM_DEVICE)
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "bad batch location %u", b->location);
+    if (!b->n_records) return NGSQ_OK;
+    if (!b->flag) return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "flag column is null");
+    if ((facets & NGSQ_FACET_GENERAL) && (!b->mapq || !b->ref_id || !b->mate_ref_id || !b->n_cigar))
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "General needs mapq, ref_id, mate_ref_id, n_cigar");
+    if ((facets & NGSQ_FACET_TEMPLATE_LENGTH) && !b->tlen)
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Template Length needs tlen");
+    if ((facets & (NGSQ_FACET_GC_CONTENT | NGSQ_FACET_EDITS)) && (!b->l_seq || !b->seq))
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "GC Content / Edits need l_seq and seq");
+    if ((facets & NGSQ_FACET_QUALITY_SCORE) && (!b->qual || (!b->qual_off && !b->l_seq)))
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Quality Score needs qual (+ l_seq or qual_off)");
+    if ((facets & (NGSQ_FACET_COVERAGE | NGSQ_FACET_EDITS)) && (!b->ref_id || !b->pos || !b->n_cigar))
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Coverage / Edits need ref_id, pos, n_cigar");
+    return NGSQ_OK;
+}
+
+// bump allocator over one staging buffer
+struct Bump {
+    uint8_t *base;
+    uint64_t off = 0;
+    explicit Bump(uint8_t *b) : base(b) {}
+    uint8_t *take(uint64_t n) {
+        uint8_t *p = base + off;
+        off += round_up(n ? n : 1, 256);
+        return p;
+    }
+};
+
+struct ColumnSizes {
+    uint64_t seq_bytes, qual_bytes, cigar_ops;
+};
+
+static int column_sizes(ngsq_ctx *c, const ngsq_batch *b, ColumnSizes *cs) {
+    const uint64_t n = b->n_records;
+    const bool host = b->location == NGSQ_MEM_HOST;
+    cs->seq_bytes = b->seq_bytes;
+    cs->qual_bytes = b->qual_bytes;
+    cs->cigar_ops = b->cigar_ops;
+    if (!b->seq) cs->seq_bytes = 0;
+    else if (!b->seq_off) cs->seq_bytes = n * b->seq_stride;
+    else if (host) cs->seq_bytes = b->seq_off[n];
+    if (!b->qual) cs->qual_bytes = 0;
+    else if (!b->qual_off) cs->qual_bytes = n * b->qual_stride;
+    else if (host) cs->qual_bytes = b->qual_off[n];
+    if (!b->cigar) cs->cigar_ops = 0;
+    else if (!b->cigar_off) cs->cigar_ops = n * b->cigar_stride;
+    else if (host) cs->cigar_ops = b->cigar_off[n];
+    (void)c;
+    return NGSQ_OK;
+}
+
+static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs, uint32_t pass_mask) {
+    const uint32_t facets = c->cfg.facets;
+    const uint64_t n = db.n;
+    const uint32_t rec_f = (pass_mask & NGSQ_PASS_RECORD) ? (facets & NGSQ_FACETS_RECORD_BASED) : 0;
+    const uint32_t seq_f = (pass_mask & NGSQ_PASS_SEQUENCE) ? (facets & NGSQ_FACETS_SEQUENCE_BASED) : 0;
+    if (rec_f & (NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH)) {
+        Bracket br(c, K_FLAGS_TLEN, n * 15);
+        HIP_TRY(c, launch_flags_tlen(c->li, c->st, db, rec_f, c->stream));
+    }
+    if ((rec_f & NGSQ_FACET_GENERAL) || (seq_f & NGSQ_FACET_COVERAGE)) {
+        Bracket br(c, K_CIGAR_COV, n * 12 + cs.cigar_ops * 4);
+        HIP_TRY(c, launch_cigar_cov(c->li, c->st, db,
+                                    (rec_f & NGSQ_FACET_GENERAL) | (seq_f & NGSQ_FACET_COVERAGE), c->stream));
+    }
+    if (rec_f & NGSQ_FACET_GC_CONTENT) {
+        Bracket br(c, K_GC, n * 6 + cs.seq_bytes);
+        HIP_TRY(c, launch_gc(c->li, c->st, db, c->stream));
+    }
+    if (rec_f & NGSQ_FACET_QUALITY_SCORE) {
+        Bracket br(c, K_QUAL, cs.qual_bytes);
+        HIP_TRY(c, launch_qual(c->li, c->st, db, c->stream));
+    }
+    if (seq_f & NGSQ_FACET_EDITS) {
+        Bracket br(c, K_EDITS, n * 16 + cs.cigar_ops * 4 + cs.seq_bytes);
+        HIP_TRY(c, launch_edits(c->li, c->st, db, c->stream));
+    }
+    return NGSQ_OK;
+}
+
+int ngsq_process_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
+    if (!c || !b) return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (c->finalized) return fail(c, NGSQ_ERR_STATE, "context already finalized; call ngsq_reset");
+    const uint32_t facets = c->cfg.facets;
+    int rc = check_batch(c, b, facets);
+    if (rc != NGSQ_OK) return rc;
+    const uint64_t n = b->n_records;
+    if (!n) return NGSQ_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ColumnSizes cs;
+    column_sizes(c, b, &cs);
+
+    DeviceBatch db{};
+    db.n = n;
+    db.first_record_index = b->first_record_index;
+    db.seq_stride = b->seq_stride;
+    db.qual_stride = b->qual_stride;
+    db.cigar_stride = b->cigar_stride;
+
+    if (b->location == NGSQ_MEM_DEVICE) {
+        db.flag = b->flag;
+        db.mapq = b->mapq;
+        db.ref_id = b->ref_id;
+        db.pos = b->pos;
+        db.mate_ref_id = b->mate_ref_id;
+        db.tlen = b->tlen;
+        db.l_seq = b->l_seq;
+        db.n_cigar = b->n_cigar;
+        db.seq = b->seq;
+        db.seq_off = b->seq_off;
+        db.qual = b->qual;
+        db.qual_off = b->qual_off;
+        db.cigar = b->cigar;
+        db.cigar_off = b->cigar_off;
+        return launch_all(c, db, cs, pass_mask);
+    }
+
+    // host batch: copy the columns into one of two device staging buffers
+    const uint64_t need = round_up(n * 2, 256) + round_up(n, 256) + 5 * round_up(n * 4, 256) +
+                          round_up(n * 2, 256) + round_up(cs.seq_bytes + 16, 256) +
+                          round_up(cs.qual_bytes + 16, 256) + round_up(cs.cigar_ops * 4 + 16, 256) +
+                          3 * round_up((n + 1) * 8, 256) + 4096;
+    Staging &sg = c->stage[c->stage_next];
+    c->stage_next ^= 1;
+    if (sg.done) HIP_TRY(c, hipEventSynchronize(sg.done)); // kernels of its previous batch finished
+    if (sg.cap < need) {
+        if (sg.buf) HIP_TRY(c, hipFree(sg.buf));
+        sg.buf = nullptr;
+        sg.cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&sg.buf, need));
+        sg.cap = need;
+    }
+    if (!sg.done) HIP_TRY(c, hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+    Bump bump(sg.buf);
+    uint64_t copied = 0;
+    {
+        Bracket br(c, K_H2D, 0);
+#define STAGE(field, type, count)                                                             \
+    do {                                                                                      \
+        if (b->field) {                                                                       \
+            const uint64_t bytes_ = (uint64_t)(count) * sizeof(type);                         \
+            type *d_ = (type *)bump.take(bytes_);                                             \
+            if (bytes_) HIP_TRY(c, hipMemcpyAsync(d_, b->field, bytes_, hipMemcpyHostToDevice, c->stream)); \
+            db.field = d_;                                                                    \
+            copied += bytes_;                                                                 \
+        }                                                                                     \
+    } while (0)
+        STAGE(flag, uint16_t, n);
+        STAGE(mapq, uint8_t, n);
+        STAGE(ref_id, int32_t, n);
+        STAGE(pos, int32_t, n);
+        STAGE(mate_ref_id, int32_t, n);
+        STAGE(tlen, int32_t, n);
+        STAGE(l_seq, uint32_t, n);
+        STAGE(n_cigar, uint16_t, n);
+        STAGE(seq, uint8_t, cs.seq_bytes);
+        STAGE(seq_off, uint64_t, n + 1);
+        STAGE(qual, uint8_t, cs.qual_bytes);
+        STAGE(qual_off, uint64_t, n + 1);
+        STAGE(cigar, uint32_t, cs.cigar_ops);
+        STAGE(cigar_off, uint64_t, n + 1);
+#undef STAGE
+        c->timing[K_H2D].algo_bytes += copied;
+    }
+    HIP_TRY(c, hipEventRecord(c->copy_done, c->stream));
+    rc = launch_all(c, db, cs, pass_mask);
+    if (rc != NGSQ_OK) return rc;
+    HIP_TRY(c, hipEventRecord(sg.done, c->stream));
+    // the caller may reuse its (possibly pinned) buffers once the copies have landed
+    HIP_TRY(c, hipEventSynchronize(c->copy_done));
+    return NGSQ_OK;
+}
+
+int ngsq_synchronize(ngsq_ctx *c) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    resolve_timing(c);
+    return NGSQ_OK;
+}
+
+void *ngsq_stream(ngsq_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int ngsq_finalize(ngsq_ctx *c) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    if (c->finalized) return fail(c, NGSQ_ERR_STATE, "already finalized");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t facets = c->cfg.facets;
+    const uint32_t nr = c->st.n_refs;
+    // which sequences have a coverage entry (coverage.rs:187-193)?
+    std::vector<unsigned long long> seen(nr ? nr : 1, 0);
+    if ((facets & NGSQ_FACET_COVERAGE) && nr) {
+        HIP_TRY(c, hipMemcpyAsync(seen.data(), c->st.counters + c->st.off_seen, nr * 8, hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (uint32_t r = 0; r < nr; r++) {
+            if (!seen[r] || c->depth_off[r] == NO_DEPTH) continue;
+            CovScanArgs a{};
+            a.diff = c->st.depth + c->depth_off[r];
+            a.ref_len = c->ref_len[r];
+            a.bin_size = c->cfg.bin_size;
+            a.cov_cap = c->cfg.cov_cap;
+            a.hist = c->d_cov_hist + (uint64_t)r * (c->cfg.cov_cap + 2);
+            a.bin_totals = c->d_bin_totals + c->bin_off[r];
+            a.chunk_sums = c->d_chunk_sums;
+            a.reset = 1;
+            Bracket br(c, K_COV_SCAN, ((uint64_t)a.ref_len + 2) * 8);
+            HIP_TRY(c, launch_cov_scan(c->li, a, c->stream));
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->h_cov_hist.data(), c->d_cov_hist, c->n_cov_hist * 8, hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_bin_totals.data(), c->d_bin_totals, c->bin_off[nr] * 8 + 8,
+                                  hipMemcpyDeviceToHost, c->stream));
+    }
+    if (facets & NGSQ_FACET_EDITS) {
+        for (uint32_t r = 0; r < nr; r++) {
+            if (c->edits_off[r] == NO_DEPTH) continue;
+            const uint32_t *refs = c->st.edits + c->edits_off[r];
+            Bracket br(c, K_EDITS_VAF, ((uint64_t)c->ref_len[r] + 1) * 8);
+            HIP_TRY(c, launch_edits_vaf(c->li, refs, refs + (uint64_t)c->ref_len[r] + 1, c->ref_len[r], c->d_vaf,
+                                        c->stream));
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->h_vaf.data(), c->d_vaf, NGSQ_VAF_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters.data(), c->st.counters, c->n_counters * 8, hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    resolve_timing(c);
+    c->finalized = true;
+    const unsigned long long *err = c->h_counters.data() + C_ERR;
+    for (int k = 0; k < 8; k++)
+        if (err[k])
+            return fail(c, NGSQ_ERR_MALFORMED_RECORD,
+                        "malformed record(s): the reference would abort this run "
+                        "(missing_ref_id=%llu bad_quality=%llu read_too_long=%llu edits_bad_ref=%llu "
+                        "edits_record_short=%llu edits_not_consumed=%llu edits_too_many=%llu bad_cigar_op=%llu)",
+                        err[0], err[1], err[2], err[3], err[4], err[5], err[6], err[7]);
+    return NGSQ_OK;
+}
+
+int ngsq_reset(ngsq_ctx *c) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->st.counters, 0, c->n_counters * 8, c->stream));
+    if (c->n_depth) {
+        // a finalized context has already zeroed the difference arrays behind the scan
+        if (!c->finalized) HIP_TRY(c, hipMemsetAsync(c->st.depth, 0, c->n_depth * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_cov_hist, 0, c->n_cov_hist * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_bin_totals, 0, (c->bin_off[c->st.n_refs] + 1) * 8, c->stream));
+    }
+    if (c->n_edits) HIP_TRY(c, hipMemsetAsync(c->st.edits, 0, c->n_edits * 4, c->stream));
+    if (c->d_vaf) HIP_TRY(c, hipMemsetAsync(c->d_vaf, 0, NGSQ_VAF_BINS * 8, c->stream));
+    c->finalized = false;
+    return NGSQ_OK;
+}
+
+// ---- getters ------------------------------------------------------------------
+
+#define NEED_FINAL(c)                                                                         \
+    do {                                                                                      \
+        if (!(c)) return NGSQ_ERR_INVALID_ARGUMENT;                                           \
+        if (!(c)->finalized) return NGSQ_ERR_STATE;                                           \
+    } while (0)
+
+int ngsq_get_error_counts(const ngsq_ctx *c, ngsq_error_counts *out) {
+    NEED_FINAL(c);
+    memcpy(out, c->h_counters.data() + C_ERR, sizeof *out);
+    return NGSQ_OK;
+}
+
+int ngsq_get_general(const ngsq_ctx *c, ngsq_general_metrics *out) {
+    NEED_FINAL(c);
+    static_assert(sizeof(ngsq_general_metrics) == (16 + 18) * 8, "layout");
+    memcpy(out, c->h_counters.data() + C_GENERAL, sizeof *out);
+    return NGSQ_OK;
+}
+
+int ngsq_get_template_length(const ngsq_ctx *c, uint64_t *hist, size_t n_bins, uint64_t *processed,
+                             uint64_t *ignored) {
+    NEED_FINAL(c);
+    if (n_bins < (size_t)c->st.tlen_cap + 1) return NGSQ_ERR_BUFFER_TOO_SMALL;
+    memcpy(hist, c->h_counters.data() + c->st.off_tlen, ((size_t)c->st.tlen_cap + 1) * 8);
+    *processed = c->h_counters[C_TLEN_PROCESSED];
+    *ignored = c->h_counters[C_TLEN_IGNORED];
+    return NGSQ_OK;
+}
+
+int ngsq_get_gc_content(const ngsq_ctx *c, ngsq_gc_metrics *out) {
+    NEED_FINAL(c);
+    memcpy(out->histogram, c->h_counters.data() + OFF_GC_HIST, sizeof out->histogram);
+    out->total_gc_count = c->h_counters[C_GC_GC];
+    out->total_at_count = c->h_counters[C_GC_AT];
+    out->total_other_count = c->h_counters[C_GC_OTHER];
+    out->processed = c->h_counters[C_GC_PROCESSED];
+    out->ignored_flags = c->h_counters[C_GC_IGN_FLAGS];
+    out->ignored_too_short = c->h_counters[C_GC_IGN_SHORT];
+    return NGSQ_OK;
+}
+
+int ngsq_get_quality_scores(const ngsq_ctx *c, uint64_t *scores, size_t n_rows) {
+    NEED_FINAL(c);
+    if (n_rows < c->st.max_read_len) return NGSQ_ERR_BUFFER_TOO_SMALL;
+    memcpy(scores, c->h_counters.data() + c->st.off_qual, (size_t)c->st.max_read_len * QUAL_BINS * 8);
+    return NGSQ_OK;
+}
+
+uint32_t ngsq_n_refs(const ngsq_ctx *c) { return c ? c->st.n_refs : 0; }
+uint32_t ngsq_max_read_len(const ngsq_ctx *c) { return c ? c->st.max_read_len : 0; }
+uint32_t ngsq_tlen_bins(const ngsq_ctx *c) { return c ? c->st.tlen_cap + 1 : 0; }
+uint32_t ngsq_cov_bins(const ngsq_ctx *c) { return c ? c->st.cov_cap + 1 : 0; }
+
+uint64_t ngsq_coverage_n_bins(const ngsq_ctx *c, uint32_t ref) {
+    if (!c || ref >= c->st.n_refs) return 0;
+    const uint64_t L = c->ref_len[ref], b = c->cfg.bin_size;
+    return 1 + L / b + (L % b != 0);
+}
+
+int ngsq_get_coverage_sequence(const ngsq_ctx *c, uint32_t ref, int *seen, uint64_t *hist, size_t n_hist_bins,
+                               uint64_t *ignored, uint64_t *bin_totals, size_t n_bins) {
+    NEED_FINAL(c);
+    if (ref >= c->st.n_refs) return NGSQ_ERR_INVALID_ARGUMENT;
+    const bool has = (c->cfg.facets & NGSQ_FACET_COVERAGE) && c->depth_off[ref] != NO_DEPTH &&
+                     c->h_counters[c->st.off_seen + ref] != 0;
+    *seen = has ? 1 : 0;
+    *ignored = 0;
+    if (!has) return NGSQ_OK;
+    const uint64_t nb = ngsq_coverage_n_bins(c, ref);
+    if (n_hist_bins < (size_t)c->st.cov_cap + 1 || n_bins < nb) return NGSQ_ERR_BUFFER_TOO_SMALL;
+    const unsigned long long *h = c->h_cov_hist.data() + (uint64_t)ref * (c->st.cov_cap + 2);
+    memcpy(hist, h, ((size_t)c->st.cov_cap + 1) * 8);
+    *ignored = h[c->st.cov_cap + 1];
+    memcpy(bin_totals, c->h_bin_totals.data() + c->bin_off[ref], nb * 8);
+    return NGSQ_OK;
+}
+
+int ngsq_get_coverage_nonsensical(const ngsq_ctx *c, uint64_t *n) {
+    NEED_FINAL(c);
+    *n = c->h_counters[C_COV_NONSENSICAL];
+    return NGSQ_OK;
+}
+
+int ngsq_get_edits(const ngsq_ctx *c, uint64_t *r1, uint64_t *r2, size_t n_edit_bins, uint64_t *vaf,
+                   size_t n_vaf_bins) {
+    NEED_FINAL(c);
+    if (n_edit_bins < NGSQ_EDITS_BINS || n_vaf_bins < NGSQ_VAF_BINS) return NGSQ_ERR_BUFFER_TOO_SMALL;
+    memcpy(r1, c->h_counters.data() + c->st.off_edits1, NGSQ_EDITS_BINS * 8);
+    memcpy(r2, c->h_counters.data() + c->st.off_edits2, NGSQ_EDITS_BINS * 8);
+    memcpy(vaf, c->h_vaf.data(), NGSQ_VAF_BINS * 8);
+    return NGSQ_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------
+
+int ngsq_kernel_timing_count(const ngsq_ctx *c) { return c ? K_COUNT : 0; }
+
+int ngsq_kernel_timing(const ngsq_ctx *c, int index, ngsq_kernel_time *out) {
+    if (!c || index < 0 || index >= K_COUNT || !out) return NGSQ_ERR_INVALID_ARGUMENT;
+    *out = c->timing[index];
+    return NGSQ_OK;
+}
+
+int ngsq_kernel_timing_reset(ngsq_ctx *c) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    resolve_timing(c);
+    for (int k = 0; k < K_COUNT; k++) c->timing[k] = {KERNEL_NAMES[k], 0, 0.0, 0};
+    return NGSQ_OK;
+}
+
+// ---- multi-GPU exchange points ---------------------------------------------------
+
+int ngsq_state_counters(ngsq_ctx *c, void **p, uint64_t *n) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    *p = c->st.counters;
+    *n = c->n_counters;
+    return NGSQ_OK;
+}
+int ngsq_state_depth(ngsq_ctx *c, void **p, uint64_t *n) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    *p = c->st.depth;
+    *n = c->n_depth;
+    return NGSQ_OK;
+}
+int ngsq_state_edits(ngsq_ctx *c, void **p, uint64_t *n) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    *p = c->st.edits;
+    *n = c->n_edits;
+    return NGSQ_OK;
+}
+
+static int state_block(ngsq_ctx *c, int which, void **p, uint64_t *bytes) {
+    switch (which) {
+    case 0: *p = c->st.counters; *bytes = c->n_counters * 8; return NGSQ_OK;
+    case 1: *p = c->st.depth; *bytes = c->n_depth * 4; return NGSQ_OK;
+    case 2: *p = c->st.edits; *bytes = c->n_edits * 4; return NGSQ_OK;
+    default: return NGSQ_ERR_INVALID_ARGUMENT;
+    }
+}
+
+int ngsq_state_download(ngsq_ctx *c, int which, void *dst, uint64_t n_bytes) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    void *p;
+    uint64_t bytes;
+    int rc = state_block(c, which, &p, &bytes);
+    if (rc) return rc;
+    if (n_bytes != bytes) return fail(c, NGSQ_ERR_BUFFER_TOO_SMALL, "state block is %llu bytes", (unsigned long long)bytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NGSQ_OK;
+}
+
+int ngsq_state_upload(ngsq_ctx *c, int which, const void *src, uint64_t n_bytes) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    void *p;
+    uint64_t bytes;
+    int rc = state_block(c, which, &p, &bytes);
+    if (rc) return rc;
+    if (n_bytes != bytes) return fail(c, NGSQ_ERR_BUFFER_TOO_SMALL, "state block is %llu bytes", (unsigned long long)bytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NGSQ_OK;
+}
+
+// ---- device memory helpers -------------------------------------------------------
+
+int ngsq_device_malloc(ngsq_ctx *c, uint64_t n, void **p) {
+    if (!c || !p) return NGSQ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(p, n ? n : 1));
+    return NGSQ_OK;
+}
+int ngsq_device_free(ngsq_ctx *c, void *p) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(p));
+    return NGSQ_OK;
+}
+int ngsq_memcpy_h2d(ngsq_ctx *c, void *d, const void *h, uint64_t n) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n) HIP_TRY(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NGSQ_OK;
+}
+int ngsq_memcpy_d2h(ngsq_ctx *c, void *h, const void *d, uint64_t n) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n) HIP_TRY(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NGSQ_OK;
+}
+int ngsq_host_malloc_pinned(uint64_t n, void **p) {
+    if (!p) return NGSQ_ERR_INVALID_ARGUMENT;
+    hipError_t e = hipHostMalloc(p, n ? n : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(nullptr, NGSQ_ERR_DEVICE, "hipHostMalloc: %s", hipGetErrorString(e));
+    return NGSQ_OK;
+}
+int ngsq_host_free_pinned(void *p) {
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) return fail(nullptr, NGSQ_ERR_DEVICE, "hipHostFree: %s", hipGetErrorString(e));
+    return NGSQ_OK;
+}
+
+} // extern "C"

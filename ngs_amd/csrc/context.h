@@ -1,0 +1,54 @@
+// context.h -- private definition of ngsq_ctx (shared by context.cpp, results.cpp, synth.hip)
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ngsq.h"
+#include "kernels.h"
+
+namespace ngsq {
+
+enum KernelId { K_FLAGS_TLEN = 0, K_CIGAR_COV, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_COUNT };
+
+struct PendingTime {
+    int id;
+    hipEvent_t a, b;
+};
+
+struct Staging {
+    uint8_t *buf = nullptr;
+    uint64_t cap = 0;
+    hipEvent_t done = nullptr;
+};
+
+} // namespace ngsq
+
+struct ngsq_ctx {
+    ngsq_config cfg{};
+    std::vector<uint32_t> ref_len;
+    std::vector<uint8_t> primary;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t copy_done = nullptr;
+    ngsq::LaunchInfo li{};
+    ngsq::DeviceState st{};
+    uint64_t n_counters = 0, n_depth = 0, n_edits = 0, n_cov_hist = 0;
+    std::vector<uint64_t> depth_off, edits_off, bin_off;
+    uint32_t *d_ref_len = nullptr;
+    uint64_t *d_depth_off = nullptr, *d_edits_off = nullptr, *d_bases_off = nullptr;
+    uint8_t *d_ref_bases = nullptr;
+    uint32_t *d_chunk_sums = nullptr;
+    unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
+    std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;
+    bool finalized = false;
+    ngsq::Staging stage[2];
+    int stage_next = 0;
+    ngsq_kernel_time timing[ngsq::K_COUNT]{};
+    std::vector<ngsq::PendingTime> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::string err;
+};

@@ -1,0 +1,154 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (kernels.hip) and the
+// layout of the device-resident accumulator blocks they update.
+//
+// Layout of the packed uint64 "counters" block (one per context).  Every entry is
+// a sum of per-record contributions, so blocks of different shards add
+// element-wise:
+//
+//   [C_GENERAL .. +16)      RecordMetrics, order of ngsq_general_metrics
+//   [C_CIGAR1  .. +9)       read_one_cigar_ops by BAM op code
+//   [C_CIGAR2  .. +9)       read_two_cigar_ops
+//   C_TLEN_PROCESSED, C_TLEN_IGNORED
+//   C_GC_GC, C_GC_AT, C_GC_OTHER, C_GC_PROCESSED, C_GC_IGN_FLAGS, C_GC_IGN_SHORT
+//   C_COV_NONSENSICAL
+//   [C_ERR .. +8)           ngsq_error_counts
+//   [OFF_GC_HIST .. +101)   GC histogram
+//   [off_tlen .. +tlen_cap+1)
+//   [off_qual .. +max_read_len*94)   per-cycle quality table, row = 0-based cycle
+//   [off_edits1 .. +513) [off_edits2 .. +513)   per-read edit-count histograms
+//   [off_seen .. +n_refs)   records Coverage processed per sequence (entry exists iff > 0)
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/ngsq.h"
+
+namespace ngsq {
+
+enum : uint32_t {
+    C_GENERAL = 0,
+    C_CIGAR1 = 16,
+    C_CIGAR2 = 25,
+    C_TLEN_PROCESSED = 34,
+    C_TLEN_IGNORED = 35,
+    C_GC_GC = 36,
+    C_GC_AT = 37,
+    C_GC_OTHER = 38,
+    C_GC_PROCESSED = 39,
+    C_GC_IGN_FLAGS = 40,
+    C_GC_IGN_SHORT = 41,
+    C_COV_NONSENSICAL = 42,
+    C_ERR = 43,
+    E_MISSING_REF = 0,
+    E_BAD_QUAL = 1,
+    E_READ_TOO_LONG = 2,
+    E_EDITS_BAD_REF = 3,
+    E_EDITS_SHORT = 4,
+    E_EDITS_NOT_CONSUMED = 5,
+    E_EDITS_TOO_MANY = 6,
+    E_BAD_CIGAR = 7,
+    OFF_GC_HIST = 64,
+    OFF_TLEN_HIST = 168,
+};
+
+constexpr uint32_t QUAL_BINS = NGSQ_MAX_SCORE + 1; // 94
+constexpr uint32_t QUAL_LDS_MAX_ROWS = 320;        // cycles kept in the LDS table
+constexpr uint64_t NO_DEPTH = ~0ull;
+
+// device view of the context shared by all kernels
+struct DeviceState {
+    unsigned long long *counters; // packed block above
+    uint32_t off_tlen, off_qual, off_edits1, off_edits2, off_seen;
+    uint32_t tlen_cap, max_read_len, n_refs, cov_cap;
+    uint32_t *depth;               // coverage difference arrays, all primary sequences
+    const uint64_t *ref_depth_off; // [n_refs] element offset into depth, NO_DEPTH if not primary
+    const uint32_t *ref_len;       // [n_refs]
+    uint32_t *edits;               // refs/alts per position, all sequences with bases
+    const uint64_t *ref_edits_off; // [n_refs] element offset of refs[]; alts follow at +L+1
+    const uint8_t *ref_bases;      // concatenated 4-bit codes, one per byte
+    const uint64_t *ref_bases_off; // [n_refs] byte offset, NO_DEPTH if absent
+    uint64_t gc_seed;
+};
+
+// device view of one batch (all pointers device memory)
+struct DeviceBatch {
+    uint64_t n;
+    uint64_t first_record_index;
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const int32_t *ref_id;
+    const int32_t *pos;
+    const int32_t *mate_ref_id;
+    const int32_t *tlen;
+    const uint32_t *l_seq;
+    const uint16_t *n_cigar;
+    const uint8_t *seq;
+    const uint64_t *seq_off;
+    const uint8_t *qual;
+    const uint64_t *qual_off;
+    const uint32_t *cigar;
+    const uint64_t *cigar_off;
+    uint32_t seq_stride, qual_stride, cigar_stride;
+};
+
+struct LaunchInfo {
+    int n_cu; // compute units of the device
+};
+
+// General flag tallies + Template Length (general.rs:31-100, template_length.rs:79-87)
+hipError_t launch_flags_tlen(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                             uint32_t facets, hipStream_t s);
+// General CIGAR-op tallies (general.rs:103-121) + Coverage range-add (coverage.rs:148-180)
+hipError_t launch_cigar_cov(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                            uint32_t facets, hipStream_t s);
+// GC Content (gc_content.rs:38-100)
+hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                     hipStream_t s);
+// Quality Score (quality_scores.rs:37-49)
+hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                       hipStream_t s);
+// Edits process (edits.rs:217-303)
+hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                        hipStream_t s);
+
+// Coverage teardown for one sequence (coverage.rs:182-246): prefix-sum the
+// difference array, histogram the depths, integer bin totals; zeroes the
+// difference array behind itself when `reset` is set.
+struct CovScanArgs {
+    uint32_t *diff;      // L+2 entries (positions 0..L, sentinel L+1)
+    uint32_t ref_len;    // L
+    uint32_t bin_size;
+    uint32_t cov_cap;
+    unsigned long long *hist;       // [cov_cap+2]; last entry = positions with depth > cov_cap
+    unsigned long long *bin_totals; // [1 + L/bin + (L%bin!=0)]
+    uint32_t *chunk_sums;           // scratch [n_chunks]
+    int reset;
+};
+uint32_t cov_scan_chunk_elems();
+hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream_t s);
+
+// Edits teardown for one sequence (edits.rs:320-341): VAF histogram from refs/alts
+hipError_t launch_edits_vaf(const LaunchInfo &li, const uint32_t *refs, const uint32_t *alts,
+                            uint32_t ref_len, unsigned long long *vaf_hist, hipStream_t s);
+
+// synthetic records generated in place on the device (include/ngsq_shared.h)
+struct SynthColumns {
+    uint16_t *flag;
+    uint8_t *mapq;
+    int32_t *ref_id;
+    int32_t *pos;
+    int32_t *mate_ref_id;
+    int32_t *tlen;
+    uint32_t *l_seq;
+    uint16_t *n_cigar;
+    uint8_t *seq;
+    uint64_t *seq_off;
+    uint8_t *qual;
+    uint64_t *qual_off;
+    uint32_t *cigar;
+    uint64_t *cigar_off;
+    uint32_t seq_stride, qual_stride, cigar_stride;
+};
+
+} // namespace ngsq

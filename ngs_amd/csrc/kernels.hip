@@ -1,0 +1,699 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the `ngs qc` record scan.
+//
+// Every kernel is an HBM-bound integer scan over SoA columns: coalesced column
+// loads, per-thread register tallies, per-block LDS histograms, one flush of
+// non-zero bins per block into the packed uint64 counter block with
+// device-scope atomics.  No MFMA anywhere.
+#include <hip/hip_runtime.h>
+
+#include "../../include/ngsq_shared.h"
+#include "kernels.h"
+
+namespace ngsq {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Sum N per-thread tallies over the block and add them to global counters
+// dst[idx[k]].  s_acc: N u64 in LDS, zeroed before the call and barrier'd.
+template <int N>
+__device__ __forceinline__ void block_flush(const uint32_t (&v)[N], u64 *s_acc, u64 *dst,
+                                            const uint32_t (&idx)[N]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        uint32_t r = wave_sum(v[k]);
+        if (lane == 0 && r) atomicAdd(&s_acc[k], (u64)r);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        u64 r = s_acc[k];
+        if (r) atomicAdd(&dst[idx[k]], r);
+    }
+}
+
+// contiguous slice of [0, n) owned by this block (keeps coordinate-sorted
+// records of one block in one coordinate window)
+__device__ __forceinline__ void block_slice(uint64_t n, uint64_t &lo, uint64_t &hi) {
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    lo = per * blockIdx.x;
+    hi = lo + per;
+    if (lo > n) lo = n;
+    if (hi > n) hi = n;
+}
+
+// ---------------------------------------------------------------------------
+// General flag tallies + Template Length
+// reference: general.rs:31-100, template_length.rs:79-87
+// reads 15 B/record: flag 2, mapq 1, ref_id 4, mate_ref_id 4, tlen 4
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flags_tlen(DeviceState st, DeviceBatch b, uint32_t facets) {
+    extern __shared__ uint32_t s_tlen[]; // tlen_cap + 1 bins
+    __shared__ u64 s_acc[19];
+    const uint32_t nb = st.tlen_cap + 1;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_tlen[i] = 0;
+    if (threadIdx.x < 19) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+
+    const bool do_general = facets & NGSQ_FACET_GENERAL;
+    const bool do_tlen = facets & NGSQ_FACET_TEMPLATE_LENGTH;
+    uint32_t c[19];
+#pragma unroll
+    for (int k = 0; k < 19; k++) c[k] = 0;
+
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
+        if (do_general) {
+            const uint32_t f = b.flag[i];
+            const uint32_t unmapped = (f >> 2) & 1u, dup = (f >> 10) & 1u;
+            c[0] += 1;       // total            general.rs:33
+            c[1] += unmapped; // :37-39
+            c[2] += dup;      // :41-43
+            if (f & 0x100u) { // :45-46
+                c[4] += 1;
+            } else if (f & 0x800u) { // :47-48
+                c[5] += 1;
+            } else {
+                c[3] += 1;             // primary :50
+                c[6] += unmapped ^ 1u; // primary_mapped :52-54
+                c[7] += dup;           // primary_duplicate :56-58
+                if (f & 0x1u) {        // :60
+                    c[8] += 1;
+                    c[9] += (f >> 6) & 1u;  // read_1 :63-65
+                    c[10] += (f >> 7) & 1u; // read_2 :67-69
+                    if (!unmapped) {        // :71
+                        c[11] += (f >> 1) & 1u; // proper_pair :72-74
+                        if (f & 0x8u) {
+                            c[12] += 1; // singleton :76-77
+                        } else {
+                            c[13] += 1; // mate_mapped :79
+                            const int32_t r = b.ref_id[i], m = b.mate_ref_id[i];
+                            if (r < 0 || m < 0) {
+                                c[16] += 1; // :81-83 unwrap() on None
+                            } else if (r != m) {
+                                c[14] += 1; // :85-86
+                                if (b.mapq[i] >= 5) c[15] += 1; // :88-95 (255 = missing counts)
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (do_tlen) {
+            // template_length.rs:80  `as usize`: negatives wrap above any capacity
+            const int32_t t = b.tlen[i];
+            if (t >= 0 && (uint32_t)t <= st.tlen_cap) {
+                atomicAdd(&s_tlen[t], 1u);
+                c[17] += 1; // processed
+            } else {
+                c[18] += 1; // ignored
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
+        uint32_t v = s_tlen[i];
+        if (v) atomicAdd(&st.counters[st.off_tlen + i], (u64)v);
+    }
+    const uint32_t idx[19] = {C_GENERAL + 0,  C_GENERAL + 1,  C_GENERAL + 2,  C_GENERAL + 3,
+                              C_GENERAL + 4,  C_GENERAL + 5,  C_GENERAL + 6,  C_GENERAL + 7,
+                              C_GENERAL + 8,  C_GENERAL + 9,  C_GENERAL + 10, C_GENERAL + 11,
+                              C_GENERAL + 12, C_GENERAL + 13, C_GENERAL + 14, C_GENERAL + 15,
+                              C_ERR + E_MISSING_REF, C_TLEN_PROCESSED, C_TLEN_IGNORED};
+    block_flush<19>(c, s_acc, st.counters, idx);
+}
+
+// ---------------------------------------------------------------------------
+// CIGAR walk: General op tallies + Coverage range-add
+// reference: general.rs:103-121, coverage.rs:148-180, noodles query()
+// reads per record: flag 2, n_cigar 2, ref_id 4, pos 4, cigar 4*ops
+//
+// Coverage is accumulated as a DIFFERENCE array: +1 at alignment_start, -1 at
+// alignment_end+1 (uint32 wrap-around arithmetic), prefix-summed at teardown.
+// Two atomics per record replace `span` bounds-checked increments.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cigar_cov(DeviceState st, DeviceBatch b, uint32_t facets) {
+    __shared__ u64 s_acc[20];
+    if (threadIdx.x < 20) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    const bool do_general = facets & NGSQ_FACET_GENERAL;
+    const bool do_cov = facets & NGSQ_FACET_COVERAGE;
+
+    uint32_t one[9], two[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) one[k] = two[k] = 0;
+    uint32_t bad_op = 0;
+    u64 nonsensical = 0;
+    int32_t seen_ref = -1; // run-length tally of `seen` per sequence
+    uint32_t seen_cnt = 0;
+
+    uint64_t lo, hi;
+    block_slice(b.n, lo, hi);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t n_ops = b.n_cigar[i];
+        const uint64_t base = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
+        const uint32_t r1 = do_general ? (((uint32_t)b.flag[i] >> 6) & 1u) : 0u; // 0x40
+        uint64_t span = 0;
+        for (uint32_t k = 0; k < n_ops; k++) {
+            const uint32_t cg = b.cigar[base + k];
+            const uint32_t op = cg & 0xFu, len = cg >> 4;
+            if (op > 8u) {
+                bad_op += 1;
+                continue;
+            }
+            // utils/cigar.rs:6-11  M D N = X consume the reference
+            if ((0x18Du >> op) & 1u) span += len;
+            if (do_general) {
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const uint32_t hit = (op == (uint32_t)q);
+                    one[q] += hit & r1;
+                    two[q] += hit & (r1 ^ 1u);
+                }
+            }
+        }
+        if (do_cov) {
+            const int32_t ref = b.ref_id[i];
+            const int32_t pos = b.pos[i];
+            if (ref >= 0 && (uint32_t)ref < st.n_refs && pos >= 0) {
+                const uint64_t off = st.ref_depth_off[ref];
+                const uint64_t L = st.ref_len[ref];
+                const uint64_t s = (uint64_t)pos + 1, e = s + span - 1;
+                // noodles query(): end must be Some (>= 1) and [s,e] must meet [1,L]
+                if (off != NO_DEPTH && e != 0 && s <= L) {
+                    if (ref != seen_ref) {
+                        if (seen_cnt) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+                        seen_ref = ref;
+                        seen_cnt = 0;
+                    }
+                    seen_cnt += 1;
+                    const uint64_t ec = e < L ? e : L;
+                    nonsensical += e - ec; // coverage.rs:163-176, one per position > L
+                    if (s <= ec) {
+                        atomicAdd(&st.depth[off + s], 1u);
+                        atomicAdd(&st.depth[off + ec + 1], 0xFFFFFFFFu);
+                    }
+                }
+            }
+        }
+    }
+    if (seen_cnt) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+    u64 ns = wave_sum64(nonsensical);
+    if ((threadIdx.x & 63) == 0 && ns) atomicAdd(&st.counters[C_COV_NONSENSICAL], ns);
+
+    uint32_t v[19];
+    uint32_t idx[19];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        v[k] = one[k];
+        idx[k] = C_CIGAR1 + k;
+        v[9 + k] = two[k];
+        idx[9 + k] = C_CIGAR2 + k;
+    }
+    v[18] = bad_op;
+    idx[18] = C_ERR + E_BAD_CIGAR;
+    block_flush<19>(v, s_acc, st.counters, idx);
+}
+
+// ---------------------------------------------------------------------------
+// GC Content, one thread per record (general path: any length, any layout)
+// reference: gc_content.rs:38-100
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void gc_classify(uint32_t code, uint32_t &gc, uint32_t &at, uint32_t &other) {
+    // BAM codes: A=1 C=2 G=4 T=8 (gc_content.rs:79-86)
+    const uint32_t is_gc = (code == 2u) | (code == 4u);
+    const uint32_t is_at = (code == 1u) | (code == 8u);
+    gc += is_gc;
+    at += is_at;
+    other += (is_gc | is_at) ^ 1u;
+}
+
+__global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b) {
+    __shared__ uint32_t s_hist[NGSQ_GC_BINS];
+    __shared__ u64 s_acc[6];
+    if (threadIdx.x < NGSQ_GC_BINS) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 6) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t c[6] = {0, 0, 0, 0, 0, 0}; // gc, at, other, processed, ign_flags, ign_short
+
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
+        const uint32_t f = b.flag[i];
+        if (f & 0x500u) { // duplicate | secondary  gc_content.rs:41-45
+            c[4] += 1;
+            continue;
+        }
+        const uint32_t l = b.l_seq[i];
+        if (l < NGSQ_GC_WINDOW) { // :59-62
+            c[5] += 1;
+            continue;
+        }
+        const uint32_t off = ngsq_gc_offset_fn(st.gc_seed, b.first_record_index + i, l);
+        const uint8_t *s = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
+        uint32_t gc = 0, at = 0, other = 0;
+        const uint32_t first = off, last = off + NGSQ_GC_WINDOW - 1; // inclusive base indices
+        for (uint32_t j = first >> 1; j <= (last >> 1); j++) {
+            const uint32_t byte = s[j];
+            if (2 * j >= first) gc_classify(byte >> 4, gc, at, other);
+            if (2 * j + 1 >= first && 2 * j + 1 <= last) gc_classify(byte & 0xFu, gc, at, other);
+        }
+        c[0] += gc;
+        c[1] += at;
+        c[2] += other;
+        c[3] += 1;
+        atomicAdd(&s_hist[gc], 1u); // :91-96 round(gc/100*100) == gc
+    }
+    __syncthreads();
+    if (threadIdx.x < NGSQ_GC_BINS) {
+        uint32_t v = s_hist[threadIdx.x];
+        if (v) atomicAdd(&st.counters[OFF_GC_HIST + threadIdx.x], (u64)v);
+    }
+    const uint32_t idx[6] = {C_GC_GC, C_GC_AT, C_GC_OTHER, C_GC_PROCESSED, C_GC_IGN_FLAGS, C_GC_IGN_SHORT};
+    block_flush<6>(c, s_acc, st.counters, idx);
+}
+
+// ---------------------------------------------------------------------------
+// Quality Score, general path: one wave per record, lane = cycle (mod 64)
+// reference: quality_scores.rs:37-49
+// LDS table [rows][94] u32; cycles >= rows go straight to global atomics.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBatch b, uint32_t lds_rows) {
+    extern __shared__ uint32_t s_q[]; // lds_rows * 94
+    __shared__ u64 s_acc[2];
+    const uint32_t nbins = lds_rows * QUAL_BINS;
+    for (uint32_t i = threadIdx.x; i < nbins; i += blockDim.x) s_q[i] = 0;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t c[2] = {0, 0}; // bad quality, read too long
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    uint64_t lo, hi;
+    block_slice(b.n, lo, hi);
+    for (uint64_t i = lo + wave; i < hi; i += waves) {
+        uint64_t q0;
+        uint32_t nq;
+        if (b.qual_off) {
+            q0 = b.qual_off[i];
+            nq = (uint32_t)(b.qual_off[i + 1] - q0);
+        } else {
+            q0 = i * (uint64_t)b.qual_stride;
+            nq = b.l_seq[i];
+        }
+        if (nq > st.max_read_len) {
+            if (lane == 0) c[1] += 1;
+            nq = st.max_read_len;
+        }
+        const uint8_t *q = b.qual + q0;
+        for (uint32_t cyc = lane; cyc < nq; cyc += 64) {
+            const uint32_t v = q[cyc];
+            if (v > NGSQ_MAX_SCORE) {
+                c[0] += 1;
+            } else if (cyc < lds_rows) {
+                atomicAdd(&s_q[cyc * QUAL_BINS + v], 1u);
+            } else {
+                atomicAdd(&st.counters[st.off_qual + (uint64_t)cyc * QUAL_BINS + v], 1ull);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += blockDim.x) {
+        uint32_t v = s_q[i];
+        if (v) atomicAdd(&st.counters[st.off_qual + i], (u64)v);
+    }
+    const uint32_t idx[2] = {C_ERR + E_BAD_QUAL, C_ERR + E_READ_TOO_LONG};
+    block_flush<2>(c, s_acc, st.counters, idx);
+}
+
+// ---------------------------------------------------------------------------
+// Edits process, one thread per record
+// reference: edits.rs:217-303, utils/alignment.rs:48-107, utils/cigar.rs
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edits(DeviceState st, DeviceBatch b) {
+    __shared__ uint32_t s_h1[NGSQ_EDITS_BINS], s_h2[NGSQ_EDITS_BINS];
+    __shared__ u64 s_acc[4];
+    for (uint32_t i = threadIdx.x; i < NGSQ_EDITS_BINS; i += blockDim.x) s_h1[i] = s_h2[i] = 0;
+    if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t c[4] = {0, 0, 0, 0}; // bad_ref, record_short, not_consumed, too_many
+
+    uint64_t lo, hi;
+    block_slice(b.n, lo, hi);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t f = b.flag[i];
+        const int32_t ref = b.ref_id[i];
+        const int32_t pos = b.pos[i];
+        if (ref < 0 || (uint32_t)ref >= st.n_refs || pos < 0) continue;
+        const uint32_t n_ops = b.n_cigar[i];
+        const uint64_t cbase = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
+        uint64_t span = 0;
+        for (uint32_t k = 0; k < n_ops; k++) {
+            const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu;
+            if (op <= 8u && ((0x18Du >> op) & 1u)) span += cg >> 4;
+        }
+        const uint64_t L = st.ref_len[ref];
+        const uint64_t s = (uint64_t)pos + 1, e = s + span - 1;
+        if (e == 0 || s > L) continue;  // not yielded by query()
+        if (f & 0x404u) continue;       // unmapped | duplicate  edits.rs:227-229
+        const uint64_t boff = st.ref_bases_off[ref];
+        if (boff == NO_DEPTH || s + span - 1 > L) { // edits.rs:245-261
+            c[0] += 1;
+            continue;
+        }
+        const uint8_t *rb = st.ref_bases + boff + (s - 1);
+        uint32_t *refs = st.edits + st.ref_edits_off[ref];
+        uint32_t *alts = refs + (L + 1);
+        const uint8_t *sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
+        const uint32_t l = b.l_seq[i];
+        uint64_t rp = 0;  // reference_ptr
+        uint32_t qp = 0;  // record_ptr
+        uint32_t edits = 0;
+        int err = 0;
+        for (uint32_t k = 0; k < n_ops && !err; k++) {
+            const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu, len = cg >> 4;
+            if (op > 8u) continue;
+            const bool c_ref = (0x18Du >> op) & 1u;  // M D N = X
+            const bool c_seq = (0x193u >> op) & 1u;  // M I S = X
+            if (op == 0u) { // only Kind::Match compares (edits.rs:277)
+                for (uint32_t j = 0; j < len; j++) {
+                    if (qp >= l) { // alignment.rs:84-87
+                        err = 2;
+                        break;
+                    }
+                    const uint32_t byte = sq[qp >> 1];
+                    const uint32_t rec = (qp & 1u) ? (byte & 0xFu) : (byte >> 4);
+                    const uint32_t rbase = rb[rp];
+                    if (rbase != rec) {
+                        edits += 1;
+                        atomicAdd(&alts[s + rp], 1u);
+                    } else {
+                        atomicAdd(&refs[s + rp], 1u);
+                    }
+                    rp += 1;
+                    qp += 1;
+                }
+            } else {
+                if (c_seq) {
+                    if ((uint64_t)qp + len > l) {
+                        err = 2;
+                        break;
+                    }
+                    qp += len;
+                }
+                if (c_ref) rp += len;
+            }
+        }
+        // NOTE: like the reference, positions visited before an error stay counted;
+        // the error aborts the run anyway.
+        if (err == 2) {
+            c[1] += 1;
+            continue;
+        }
+        if (qp != l) { // alignment.rs:102-103 (reference side is consumed by construction)
+            c[2] += 1;
+            continue;
+        }
+        if (edits > 512u) { // edits.rs:296-300 unwrap()
+            c[3] += 1;
+            continue;
+        }
+        if (f & 0x40u)
+            atomicAdd(&s_h1[edits], 1u);
+        else
+            atomicAdd(&s_h2[edits], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < NGSQ_EDITS_BINS; i += blockDim.x) {
+        uint32_t v = s_h1[i];
+        if (v) atomicAdd(&st.counters[st.off_edits1 + i], (u64)v);
+        v = s_h2[i];
+        if (v) atomicAdd(&st.counters[st.off_edits2 + i], (u64)v);
+    }
+    const uint32_t idx[4] = {C_ERR + E_EDITS_BAD_REF, C_ERR + E_EDITS_SHORT, C_ERR + E_EDITS_NOT_CONSUMED,
+                             C_ERR + E_EDITS_TOO_MANY};
+    block_flush<4>(c, s_acc, st.counters, idx);
+}
+
+// ---------------------------------------------------------------------------
+// Coverage teardown (coverage.rs:182-246) as a three-phase scan of the
+// difference array of one sequence:
+//   A  per-chunk sums of diff              (read  4 B/position)
+//   B  exclusive scan of the chunk sums    (tiny)
+//   C  per-chunk prefix sums -> depth; depth histogram in LDS; integer bin
+//      totals; optional zeroing of the array (read 4 B + write 4 B/position)
+// ---------------------------------------------------------------------------
+constexpr uint32_t SCAN_THREADS = 256;
+constexpr uint32_t SCAN_PER_THREAD = 16;
+constexpr uint32_t SCAN_CHUNK = SCAN_THREADS * SCAN_PER_THREAD; // 4096 positions
+
+uint32_t cov_scan_chunk_elems() { return SCAN_CHUNK; }
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_cov_chunk_sums(const uint32_t *diff, uint64_t n,
+                                                                uint32_t *chunk_sums) {
+    __shared__ uint32_t s_w[SCAN_THREADS / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * 4;
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < SCAN_PER_THREAD / 4; r++) {
+        const uint64_t j = base + (uint64_t)r * (SCAN_THREADS * 4);
+        if (j + 3 < n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(diff + j);
+            sum += v.x + v.y + v.z + v.w;
+        } else {
+            for (uint64_t t = j; t < n && t < j + 4; t++) sum += diff[t];
+        }
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < SCAN_THREADS / 64; w++) t += s_w[w];
+        chunk_sums[blockIdx.x] = t;
+    }
+}
+
+// single block: exclusive scan of chunk sums in place
+__global__ __launch_bounds__(1024) void k_cov_scan_chunks(uint32_t *chunk_sums, uint32_t n_chunks) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n_chunks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_chunks ? chunk_sums[i] : 0;
+        uint32_t inc = v; // inclusive scan within the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o, 64);
+            if ((int)lane >= o) inc += t;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (uint32_t w = 0; w < wave; w++) wave_off += s_w[w];
+        const uint32_t carry = s_carry;
+        if (i < n_chunks) chunk_sums[i] = carry + wave_off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_cov_depth_hist(CovScanArgs a) {
+    extern __shared__ uint32_t s_hist[]; // cov_cap + 2
+    __shared__ uint32_t s_w[SCAN_THREADS / 64];
+    const uint32_t nb = a.cov_cap + 2;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+
+    const uint64_t n = (uint64_t)a.ref_len + 2; // entries of diff
+    const uint64_t L = a.ref_len;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // each thread owns 16 CONSECUTIVE positions so that its prefix is local
+    const uint64_t j0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    uint32_t d[SCAN_PER_THREAD];
+#pragma unroll
+    for (uint32_t r = 0; r < SCAN_PER_THREAD / 4; r++) {
+        const uint64_t j = j0 + r * 4;
+        if (j + 3 < n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.diff + j);
+            d[r * 4 + 0] = v.x;
+            d[r * 4 + 1] = v.y;
+            d[r * 4 + 2] = v.z;
+            d[r * 4 + 3] = v.w;
+            if (a.reset) *reinterpret_cast<uint4 *>(a.diff + j) = make_uint4(0, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++) {
+                d[r * 4 + t] = (j + t < n) ? a.diff[j + t] : 0u;
+                if (a.reset && j + t < n) a.diff[j + t] = 0u;
+            }
+        }
+    }
+    uint32_t tsum = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < SCAN_PER_THREAD; t++) tsum += d[t];
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t run = a.chunk_sums[blockIdx.x] + inc - tsum;
+    for (uint32_t w = 0; w < wave; w++) run += s_w[w];
+
+    // depth of each position -> histogram + bin totals
+    // bin of position i: 0 for i == 0, else 1 + (i-1)/bin_size  (coverage.rs:206-230)
+    u64 bin_sum = 0;
+    uint64_t cur_bin = ~0ull;
+#pragma unroll
+    for (uint32_t t = 0; t < SCAN_PER_THREAD; t++) {
+        run += d[t];
+        const uint64_t i = j0 + t;
+        if (i <= L) {
+            const uint32_t depth = run;
+            atomicAdd(&s_hist[depth <= a.cov_cap ? depth : a.cov_cap + 1], 1u);
+            const uint64_t bin = i == 0 ? 0 : 1 + (i - 1) / a.bin_size;
+            if (bin != cur_bin) {
+                if (bin_sum) atomicAdd(&a.bin_totals[cur_bin], bin_sum);
+                cur_bin = bin;
+                bin_sum = 0;
+            }
+            bin_sum += depth;
+        }
+    }
+    // wave-aggregate the common case: the whole wave lies in one bin
+    const uint64_t b0 = __shfl(cur_bin, 0, 64);
+    if (__all(cur_bin == b0)) {
+        u64 s = wave_sum64(bin_sum);
+        if (lane == 0 && s && b0 != ~0ull) atomicAdd(&a.bin_totals[b0], s);
+    } else if (bin_sum) {
+        atomicAdd(&a.bin_totals[cur_bin], bin_sum);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
+        uint32_t v = s_hist[i];
+        if (v) atomicAdd(&a.hist[i], (u64)v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Edits teardown (edits.rs:320-341): one VAF histogram increment per covered position.
+// f32 arithmetic exactly as the reference: alts as f32 / total as f32, * 100.0, truncate.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edits_vaf(const uint32_t *refs, const uint32_t *alts, uint32_t ref_len,
+                                                   u64 *vaf_hist) {
+    __shared__ uint32_t s_h[NGSQ_VAF_BINS];
+    if (threadIdx.x < NGSQ_VAF_BINS) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t n = (uint64_t)ref_len + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t r = refs[i], a = alts[i];
+        const uint64_t total = (uint64_t)r + a;
+        if (total == 0) continue;
+        const float vaf = __fdiv_rn((float)a, (float)total);
+        const float scaled = __fmul_rn(vaf, 100.0f);
+        atomicAdd(&s_h[(uint32_t)scaled], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < NGSQ_VAF_BINS) {
+        uint32_t v = s_h[threadIdx.x];
+        if (v) atomicAdd(&vaf_hist[threadIdx.x], (u64)v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline uint32_t grid_for(uint64_t n, uint32_t per_block, uint32_t max_blocks) {
+    uint64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (uint32_t)g;
+}
+
+hipError_t launch_flags_tlen(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                             uint32_t facets, hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    const uint32_t grid = grid_for(b.n, 256 * 4, li.n_cu * 8);
+    const size_t lds = (size_t)(st.tlen_cap + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_flags_tlen, dim3(grid), dim3(256), lds, s, st, b, facets);
+    return hipGetLastError();
+}
+
+hipError_t launch_cigar_cov(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                            uint32_t facets, hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    const uint32_t grid = grid_for(b.n, 256 * 4, li.n_cu * 8);
+    hipLaunchKernelGGL(k_cigar_cov, dim3(grid), dim3(256), 0, s, st, b, facets);
+    return hipGetLastError();
+}
+
+hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    const uint32_t grid = grid_for(b.n, 256 * 2, li.n_cu * 8);
+    hipLaunchKernelGGL(k_gc, dim3(grid), dim3(256), 0, s, st, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    uint32_t rows = b.qual_off ? st.max_read_len : b.qual_stride;
+    if (rows > st.max_read_len) rows = st.max_read_len;
+    if (rows > QUAL_LDS_MAX_ROWS) rows = QUAL_LDS_MAX_ROWS;
+    if (rows < 1) rows = 1;
+    const size_t lds = (size_t)rows * QUAL_BINS * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_general),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           QUAL_LDS_MAX_ROWS * QUAL_BINS * sizeof(uint32_t));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t per_cu = lds <= 72 * 1024 ? 2 : 1;
+    const uint32_t grid = grid_for(b.n, 1024, li.n_cu * per_cu);
+    hipLaunchKernelGGL(k_qual_general, dim3(grid), dim3(1024), lds, s, st, b, rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    const uint32_t grid = grid_for(b.n, 256, li.n_cu * 8);
+    hipLaunchKernelGGL(k_edits, dim3(grid), dim3(256), 0, s, st, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream_t s) {
+    (void)li;
+    const uint64_t n = (uint64_t)a.ref_len + 2;
+    const uint32_t n_chunks = (uint32_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    hipLaunchKernelGGL(k_cov_chunk_sums, dim3(n_chunks), dim3(SCAN_THREADS), 0, s, a.diff, n, a.chunk_sums);
+    hipLaunchKernelGGL(k_cov_scan_chunks, dim3(1), dim3(1024), 0, s, a.chunk_sums, n_chunks);
+    const size_t lds = (size_t)(a.cov_cap + 2) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_cov_depth_hist, dim3(n_chunks), dim3(SCAN_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_edits_vaf(const LaunchInfo &li, const uint32_t *refs, const uint32_t *alts,
+                            uint32_t ref_len, unsigned long long *vaf_hist, hipStream_t s) {
+    const uint32_t grid = grid_for((uint64_t)ref_len + 1, 256 * 8, li.n_cu * 8);
+    hipLaunchKernelGGL(k_edits_vaf, dim3(grid), dim3(256), 0, s, refs, alts, ref_len, vaf_hist);
+    return hipGetLastError();
+}
+
+} // namespace ngsq

@@ -1,0 +1,246 @@
+"""ctypes declarations of the C ABI in include/ngsq.h and include/ngsq_synth.h.
+
+This module is a binding only: structures, constants and function prototypes.
+The product is the shared library ``ngs_amd/libngsq.so`` (HIP kernels + C++
+host code); Python is the test / benchmark harness around it.  Loading fails
+loudly when the library has not been built -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libngsq.so")
+
+ABI_VERSION = 1
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_DEVICE = -2
+ERR_NO_DEVICE = -3
+ERR_MALFORMED_RECORD = -4
+ERR_STATE = -5
+ERR_BUFFER_TOO_SMALL = -6
+ERR_UNSUPPORTED = -7
+
+FACET_GENERAL = 0x01
+FACET_TEMPLATE_LENGTH = 0x02
+FACET_GC_CONTENT = 0x04
+FACET_QUALITY_SCORE = 0x08
+FACET_COVERAGE = 0x10
+FACET_EDITS = 0x20
+FACETS_RECORD_BASED = 0x0F
+FACETS_SEQUENCE_BASED = 0x30
+FACETS_DEFAULT = 0x1F
+
+N_CIGAR_KINDS = 9
+MAX_SCORE = 93
+GC_BINS = 101
+EDITS_BINS = 513
+VAF_BINS = 101
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+PASS_RECORD = 1
+PASS_SEQUENCE = 2
+PASS_BOTH = 3
+
+SYNTH_FIXED = 0
+SYNTH_MIXED = 1
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("facets", C.c_uint32),
+        ("device", C.c_int32),
+        ("n_refs", C.c_uint32),
+        ("ref_len", u32p),
+        ("ref_is_primary", u8p),
+        ("bin_size", C.c_uint32),
+        ("tlen_cap", C.c_uint32),
+        ("cov_cap", C.c_uint32),
+        ("max_read_len", C.c_uint32),
+        ("gc_seed", C.c_uint64),
+        ("ref_bases", C.POINTER(u8p)),
+        ("stream", C.c_void_p),
+        ("timing", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("location", C.c_uint32),
+        ("n_records", C.c_uint64),
+        ("first_record_index", C.c_uint64),
+        ("flag", C.c_void_p),
+        ("mapq", C.c_void_p),
+        ("ref_id", C.c_void_p),
+        ("pos", C.c_void_p),
+        ("mate_ref_id", C.c_void_p),
+        ("tlen", C.c_void_p),
+        ("l_seq", C.c_void_p),
+        ("n_cigar", C.c_void_p),
+        ("seq", C.c_void_p),
+        ("seq_off", C.c_void_p),
+        ("qual", C.c_void_p),
+        ("qual_off", C.c_void_p),
+        ("cigar", C.c_void_p),
+        ("cigar_off", C.c_void_p),
+        ("seq_stride", C.c_uint32),
+        ("qual_stride", C.c_uint32),
+        ("cigar_stride", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("seq_bytes", C.c_uint64),
+        ("qual_bytes", C.c_uint64),
+        ("cigar_ops", C.c_uint64),
+    ]
+
+
+GENERAL_FIELDS = [
+    "total", "unmapped", "duplicate", "primary", "secondary", "supplementary", "primary_mapped",
+    "primary_duplicate", "paired", "read_1", "read_2", "proper_pair", "singleton", "mate_mapped",
+    "mate_reference_sequence_id_mismatch", "mate_reference_sequence_id_mismatch_hq",
+]
+
+
+class GeneralMetrics(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in GENERAL_FIELDS] + [
+        ("read_one_cigar_ops", C.c_uint64 * N_CIGAR_KINDS),
+        ("read_two_cigar_ops", C.c_uint64 * N_CIGAR_KINDS),
+    ]
+
+
+class GcMetrics(C.Structure):
+    _fields_ = [
+        ("histogram", C.c_uint64 * GC_BINS),
+        ("total_gc_count", C.c_uint64),
+        ("total_at_count", C.c_uint64),
+        ("total_other_count", C.c_uint64),
+        ("processed", C.c_uint64),
+        ("ignored_flags", C.c_uint64),
+        ("ignored_too_short", C.c_uint64),
+    ]
+
+
+ERROR_FIELDS = [
+    "missing_reference_id", "bad_quality_score", "read_too_long", "edits_bad_reference",
+    "edits_record_short", "edits_not_consumed", "edits_too_many", "bad_cigar_op",
+]
+
+
+class ErrorCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ERROR_FIELDS]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("launches", C.c_uint64),
+        ("total_ms", C.c_double),
+        ("algo_bytes", C.c_uint64),
+    ]
+
+
+class SynthConfig(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("n_total", C.c_uint64),
+        ("mode", C.c_uint32),
+        ("read_len", C.c_uint32),
+        ("min_len", C.c_uint32),
+        ("max_len", C.c_uint32),
+        ("ref_len", C.c_uint32),
+        ("n_refs", C.c_uint32),
+    ]
+
+
+ctx_p = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/ngsq.h and include/ngsq_synth.h declare
+PROTOTYPES = {
+    "ngsq_abi_version": (C.c_uint32, []),
+    "ngsq_device_count": (C.c_int, []),
+    "ngsq_facet_name": (C.c_char_p, [C.c_uint32]),
+    "ngsq_last_global_error": (C.c_char_p, []),
+    "ngsq_create": (C.c_int, [C.POINTER(Config), C.POINTER(ctx_p)]),
+    "ngsq_destroy": (None, [ctx_p]),
+    "ngsq_last_error": (C.c_char_p, [ctx_p]),
+    "ngsq_process_batch": (C.c_int, [ctx_p, C.POINTER(Batch), C.c_uint32]),
+    "ngsq_finalize": (C.c_int, [ctx_p]),
+    "ngsq_reset": (C.c_int, [ctx_p]),
+    "ngsq_synchronize": (C.c_int, [ctx_p]),
+    "ngsq_stream": (C.c_void_p, [ctx_p]),
+    "ngsq_get_error_counts": (C.c_int, [ctx_p, C.POINTER(ErrorCounts)]),
+    "ngsq_get_general": (C.c_int, [ctx_p, C.POINTER(GeneralMetrics)]),
+    "ngsq_get_template_length": (C.c_int, [ctx_p, u64p, C.c_size_t, u64p, u64p]),
+    "ngsq_get_gc_content": (C.c_int, [ctx_p, C.POINTER(GcMetrics)]),
+    "ngsq_get_quality_scores": (C.c_int, [ctx_p, u64p, C.c_size_t]),
+    "ngsq_n_refs": (C.c_uint32, [ctx_p]),
+    "ngsq_max_read_len": (C.c_uint32, [ctx_p]),
+    "ngsq_tlen_bins": (C.c_uint32, [ctx_p]),
+    "ngsq_cov_bins": (C.c_uint32, [ctx_p]),
+    "ngsq_coverage_n_bins": (C.c_uint64, [ctx_p, C.c_uint32]),
+    "ngsq_get_coverage_sequence": (
+        C.c_int, [ctx_p, C.c_uint32, C.POINTER(C.c_int), u64p, C.c_size_t, u64p, u64p, C.c_size_t]),
+    "ngsq_get_coverage_nonsensical": (C.c_int, [ctx_p, u64p]),
+    "ngsq_get_edits": (C.c_int, [ctx_p, u64p, u64p, C.c_size_t, u64p, C.c_size_t]),
+    "ngsq_results_json": (C.c_int64, [ctx_p, C.POINTER(C.c_char_p), C.c_char_p, C.c_size_t]),
+    "ngsq_kernel_timing_count": (C.c_int, [ctx_p]),
+    "ngsq_kernel_timing": (C.c_int, [ctx_p, C.c_int, C.POINTER(KernelTime)]),
+    "ngsq_kernel_timing_reset": (C.c_int, [ctx_p]),
+    "ngsq_state_counters": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
+    "ngsq_state_depth": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
+    "ngsq_state_edits": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
+    "ngsq_state_download": (C.c_int, [ctx_p, C.c_int, C.c_void_p, C.c_uint64]),
+    "ngsq_state_upload": (C.c_int, [ctx_p, C.c_int, C.c_void_p, C.c_uint64]),
+    "ngsq_device_malloc": (C.c_int, [ctx_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ngsq_device_free": (C.c_int, [ctx_p, C.c_void_p]),
+    "ngsq_memcpy_h2d": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ngsq_memcpy_d2h": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ngsq_host_malloc_pinned": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ngsq_host_free_pinned": (C.c_int, [C.c_void_p]),
+    "ngsq_gc_offset": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32]),
+    "ngsq_synth_sizes": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, u64p, u64p, u64p]),
+    "ngsq_synth_fill_host": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
+    "ngsq_synth_fill_device": (
+        C.c_int, [ctx_p, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
+}
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load libngsq.so and attach prototypes.  Raises LibraryNotBuilt when absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise LibraryNotBuilt(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or python -m ngs_amd.build).  There is no CPU fallback for the ngs qc hot path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError = missing export, let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ngsq_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libngsq.so ABI {lib.ngsq_abi_version()} != binding ABI {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib

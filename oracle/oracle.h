@@ -1,0 +1,96 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may build, load or run it, and only as the checker / reported baseline.
+ *
+ * CPU restatement (plain C, single thread, record at a time, two passes) of
+ * the reference's `ngs qc` facet loop.  Each function cites the reference
+ * file:line it follows (paths relative to /root/reference).
+ *
+ * PINNING STATUS
+ *   - Histogram (histogram.c) and the CIGAR/reference walk (orc_stepthrough)
+ *     are pinned against every known-answer test the reference holds for
+ *     them (src/utils/histogram.rs:405-523, src/utils/alignment.rs:134-202,
+ *     src/qc/record_based/gc_content.rs:145-151): tests/test_oracle_kat.py.
+ *   - The facets' process/summarize/teardown/aggregate have NO tests, golden
+ *     files or fixtures in the reference, and the
+ *     reference is Rust, which cannot be built here (no cargo/rustc, crates
+ *     not vendored, no network): for them this oracle is PARITY UNPINNED --
+ *     a line-by-line restatement checked only against hand-derived goldens
+ *     (tests/golden/).
+ *   - The record decode the reference delegates to noodles-bam 0.28.0 /
+ *     noodles-sam 0.25.0 (Cargo.lock:902-905,1057-1059) is not in the tree;
+ *     the accessor semantics used here are restated from the SAM/BAM
+ *     specification and listed in DESIGN.md.
+ */
+#ifndef ORC_ORACLE_H
+#define ORC_ORACLE_H
+
+#include "../include/ngsq.h"
+#include "histogram.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ctx orc_ctx;
+
+/* a decoded record as the facets see it (noodles sam::alignment::Record accessors) */
+typedef struct orc_record {
+    uint16_t flag;
+    uint8_t mapq;
+    int32_t ref_id;
+    int32_t pos;
+    int32_t mate_ref_id;
+    int32_t tlen;
+    uint32_t l_seq;
+    const uint8_t *seq;  /* packed 4-bit */
+    uint32_t n_qual;     /* l_seq, or 0 when qualities are missing */
+    const uint8_t *qual;
+    uint32_t n_cigar;
+    const uint32_t *cigar;
+    uint64_t index;      /* index of the record in the file (GC offset fn) */
+} orc_record;
+
+orc_ctx *orc_create(const ngsq_config *cfg);
+void orc_destroy(orc_ctx *ctx);
+const char *orc_last_error(const orc_ctx *ctx);
+
+/* command.rs:305-316 (pass 1) and :356-397 (pass 2) over one SoA batch */
+int orc_process_batch(orc_ctx *ctx, const ngsq_batch *batch, uint32_t pass_mask);
+/* summarize (command.rs:328-330), teardown per sequence (:392-396), aggregate (:406-414) */
+int orc_finalize(orc_ctx *ctx);
+
+int orc_get_error_counts(const orc_ctx *ctx, ngsq_error_counts *out);
+int orc_get_general(const orc_ctx *ctx, ngsq_general_metrics *out);
+int orc_get_template_length(const orc_ctx *ctx, uint64_t *histogram, size_t n_bins,
+                            uint64_t *processed, uint64_t *ignored);
+int orc_get_gc_content(const orc_ctx *ctx, ngsq_gc_metrics *out);
+int orc_get_quality_scores(const orc_ctx *ctx, uint64_t *scores, size_t n_rows);
+uint64_t orc_coverage_n_bins(const orc_ctx *ctx, uint32_t ref);
+int orc_get_coverage_sequence(const orc_ctx *ctx, uint32_t ref, int *seen, uint64_t *histogram,
+                              size_t n_hist_bins, uint64_t *ignored, double *bin_means,
+                              size_t n_bins);
+int orc_get_coverage_nonsensical(const orc_ctx *ctx, uint64_t *nonsensical_records);
+int orc_get_edits(const orc_ctx *ctx, uint64_t *read_one_edits, uint64_t *read_two_edits,
+                  size_t n_edit_bins, uint64_t *vaf_histogram, size_t n_vaf_bins);
+int64_t orc_results_json(const orc_ctx *ctx, const char *const *ref_names, char *buf, size_t cap);
+
+/* alignment.rs:48-107 + :113-125: edits between a reference slice and a record
+ * (bases as 4-bit codes, one per byte).  Returns 0 and *edits, or
+ * 1 = "...consume a reference base...", 2 = "...consume a record base...",
+ * 3 = "reference sequence was not fully consumed",
+ * 4 = "record sequence was not fully consumed". */
+int orc_stepthrough_edits(const uint8_t *reference, size_t n_reference, const uint8_t *record,
+                          size_t n_record, const uint32_t *cigar, size_t n_cigar,
+                          uint64_t *edits);
+const char *orc_stepthrough_error_message(int code);
+
+/* timing helper for bench.py's cpu_baseline leg: seconds of CPU work spent in
+ * orc_process_batch + orc_finalize since orc_create */
+double orc_elapsed_seconds(const orc_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
