@@ -1,0 +1,118 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/*.h declares; structure layouts match the
+binding; and without a GPU the product fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from ngs_amd import ffi, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in ("ngsq.h", "ngsq_synth.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(ngsq_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_every_declared_symbol_is_exported(lib):
+    decl = declared_symbols()
+    assert len(decl) >= 40
+    for name in sorted(decl):
+        assert hasattr(lib, name), f"libngsq.so does not export {name}"
+    # and the binding covers exactly the declared surface
+    assert decl == set(ffi.PROTOTYPES), decl ^ set(ffi.PROTOTYPES)
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """Compile a C probe against include/ngsq.h and compare sizeof/offsetof with ctypes."""
+    src = tmp_path / "probe.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "ngsq.h"
+#include "ngsq_synth.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ngsq_config), sizeof(ngsq_batch), sizeof(ngsq_general_metrics),
+         sizeof(ngsq_gc_metrics), sizeof(ngsq_error_counts), sizeof(ngsq_kernel_time), sizeof(ngsq_synth_config));
+  printf("%zu %zu %zu %zu\n", offsetof(ngsq_config, gc_seed), offsetof(ngsq_config, stream),
+         offsetof(ngsq_batch, seq_stride), offsetof(ngsq_batch, cigar_ops));
+  return 0;
+}''')
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    sizes = [int(x) for x in out]
+    assert sizes[:7] == [C.sizeof(ffi.Config), C.sizeof(ffi.Batch), C.sizeof(ffi.GeneralMetrics),
+                         C.sizeof(ffi.GcMetrics), C.sizeof(ffi.ErrorCounts), C.sizeof(ffi.KernelTime),
+                         C.sizeof(ffi.SynthConfig)]
+    assert sizes[7:] == [ffi.Config.gc_seed.offset, ffi.Config.stream.offset, ffi.Batch.seq_stride.offset,
+                         ffi.Batch.cigar_ops.offset]
+
+
+def test_abi_version_and_pure_functions(lib):
+    assert lib.ngsq_abi_version() == ffi.ABI_VERSION
+    # gc_content.rs:69-74: offset 0 when l_seq <= 100, else in 0..l_seq-100 (exclusive)
+    assert lib.ngsq_gc_offset(1, 2, 100) == 0 and lib.ngsq_gc_offset(1, 2, 50) == 0
+    offs = {lib.ngsq_gc_offset(7, i, 150) for i in range(2000)}
+    assert offs == set(range(50))
+    assert {lib.ngsq_gc_offset(7, i, 101) for i in range(50)} == {0}
+
+
+@pytest.mark.skipif(ffi.load_library().ngsq_device_count() > 0, reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(lib):
+    with pytest.raises(host.NgsqError) as ei:
+        host.QcContext([1000])
+    assert ei.value.code == ffi.ERR_NO_DEVICE
+    assert "no CPU fallback" in ei.value.message
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(ffi.LibraryNotBuilt):
+        ffi.load_library(str(tmp_path / "libngsq.so"))
+
+
+def test_synthetic_host_generator_is_a_pure_function_of_the_index(lib):
+    """Any shard regenerates its slice: records [a,b) generated alone equal the
+    slice of a larger generation, in both modes."""
+    for mode in (ffi.SYNTH_FIXED, ffi.SYNTH_MIXED):
+        cfg = host.synth_config(5000, mode=mode, ref_len=200_000)
+        whole = host.synth_host_batch(cfg, 0, 3000, lib)
+        part = host.synth_host_batch(cfg, 1000, 500, lib)
+        sl = whole.slice(1000, 1500)
+        for k, a in part.cols.items():
+            if a is None:
+                assert sl.cols[k] is None
+            else:
+                np.testing.assert_array_equal(a, sl.cols[k], err_msg=k)
+        # coordinate-sorted by construction, inside the reference
+        pos = whole.cols["pos"]
+        assert (np.diff(pos.astype(np.int64)) >= 0).all() and pos.min() >= 1 and pos.max() < 200_000 - 5000
+
+
+def test_synthetic_distributions(lib):
+    cfg = host.synth_config(200_000, ref_len=10_000_000)
+    hb = host.synth_host_batch(cfg, 0, 200_000, lib)
+    f = hb.cols["flag"]
+    frac = lambda m: float(((f & m) != 0).mean())
+    assert abs(frac(0x1) - 0.98) < 0.005 and abs(frac(0x4) - 0.01) < 0.003
+    assert abs(frac(0x400) - 0.05) < 0.005 and abs(frac(0x100) - 0.01) < 0.003
+    q = hb.cols["qual"].reshape(-1, 150)
+    assert set(np.unique(q)) == {2, 11, 25, 37}
+    assert abs((q[:, 0] == 37).mean() - 0.9) < 0.01 and abs((q[:, 149] == 37).mean() - 0.6) < 0.01
+    s = hb.cols["seq"]
+    hi, lo = s >> 4, s & 15
+    codes = np.concatenate([hi, lo])
+    assert set(np.unique(codes)) == {1, 2, 4, 8, 15}
+    assert abs(((codes == 2) | (codes == 4)).mean() - 0.41) < 0.01
+    t = hb.cols["tlen"][(f & 0x41) == 0x41]
+    t = t[(t > 0) & (t <= 1024)]
+    assert abs(t.mean() - 350) < 2 and abs(t.std() - 50) < 2

@@ -1,0 +1,286 @@
+"""Parity tests proper: the HIP path through the C ABI vs the CPU oracle on the same
+seeded inputs.  Bit-exact on every integer array; parsed-JSON equal on the
+`Results` document (the reference's HashMap order is random).
+Run on the GPU box with `pytest -m gpu`.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ngs_amd import ffi, host
+from tests.util import (batch_from_records, compare_contexts, json_equal, make_edit_friendly, random_batch,
+                        random_ref_bases)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hand_six_records.json")
+
+
+def run_both(oracle_mod, lib, batches, ref_len, primary=None, facets=ffi.FACETS_DEFAULT, bin_size=1000,
+             max_read_len=320, gc_seed=7, ref_bases=None, on_device=False, allow_malformed=True, names=None):
+    kw = dict(facets=facets, bin_size=bin_size, max_read_len=max_read_len, gc_seed=gc_seed, ref_bases=ref_bases)
+    orc = oracle_mod.Oracle(ref_len, primary, **kw)
+    gpu = host.QcContext(ref_len, primary, lib=lib, **kw)
+    for hb in batches:
+        orc.process_batch(hb)
+        if on_device:
+            db = gpu.upload(hb)
+            gpu.process_batch(db)
+        else:
+            gpu.process_batch(hb)
+    rc_o = orc.finalize(allow_malformed=allow_malformed)
+    rc_g = gpu.finalize(allow_malformed=allow_malformed)
+    assert rc_o == rc_g
+    compare_contexts(gpu, orc, len(ref_len), facets, bin_size, ref_len)
+    names = names or [f"chr{i + 1}" for i in range(len(ref_len))]
+    json_equal(gpu.results(names), orc.results(names))
+    return gpu, orc
+
+
+def test_hand_golden(gpu_lib, oracle_mod):
+    g = json.load(open(GOLD))
+    cfg = g["config"]
+    hb = batch_from_records(g["records"])
+    gpu = host.QcContext(cfg["ref_len"], cfg["ref_is_primary"], facets=cfg["facets"], bin_size=cfg["bin_size"],
+                         max_read_len=cfg["max_read_len"], lib=gpu_lib)
+    gpu.process_batch(hb)
+    gpu.finalize()
+    json_equal(gpu.results(cfg["ref_names"]), g["expected"])
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_synthetic_fixed_150bp(gpu_lib, oracle_mod, on_device):
+    """configs[1]/[2] shape at a size the oracle finishes in seconds."""
+    n, L = 200_000, 500_000
+    cfg = host.synth_config(n, ref_len=L, n_refs=2)
+    hb = host.synth_host_batch(cfg, 0, n, gpu_lib)
+    run_both(oracle_mod, gpu_lib, [hb], [L, 300_000], bin_size=50_000, max_read_len=150, on_device=on_device,
+             allow_malformed=False)
+
+
+def test_synthetic_mixed_lengths_and_cigars(gpu_lib, oracle_mod):
+    """configs[4] shape: 50-300 bp, soft clips / indels / skips."""
+    n, L = 100_000, 400_000
+    cfg = host.synth_config(n, mode=ffi.SYNTH_MIXED, ref_len=L, n_refs=2)
+    hb = host.synth_host_batch(cfg, 0, n, gpu_lib)
+    gpu, _ = run_both(oracle_mod, gpu_lib, [hb], [L, 1000], bin_size=50_000, max_read_len=300,
+                      allow_malformed=False)
+    ops = gpu.general()["read_one_cigar_ops"]
+    assert ops[0] and ops[1] and ops[2] and ops[3] and ops[4]  # M I D N S all present
+
+
+def test_device_generator_matches_host_generator(gpu_lib):
+    for mode in (ffi.SYNTH_FIXED, ffi.SYNTH_MIXED):
+        cfg = host.synth_config(50_000, mode=mode, ref_len=1_000_000)
+        hb = host.synth_host_batch(cfg, 10_000, 20_000, gpu_lib)
+        with host.QcContext([1_000_000, 1000], lib=gpu_lib) as gpu:
+            db = gpu.synth_device_batch(cfg, 10_000, 20_000)
+            for name, a in hb.cols.items():
+                if a is None:
+                    continue
+                got = gpu.download_column(db, name, a.size)
+                np.testing.assert_array_equal(got, a, err_msg=f"mode {mode} column {name}")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_edge_cases(gpu_lib, oracle_mod, seed):
+    """Ragged, empty, unplaced, out-of-range, every flag bit, every CIGAR op."""
+    rng = np.random.default_rng(seed)
+    ref_len = [5000, 1, 777, 30_000]
+    primary = [1, 1, 0, 1]
+    hb = random_batch(rng, 20_000, ref_len)
+    run_both(oracle_mod, gpu_lib, [hb], ref_len, primary, bin_size=[1000, 7, 50_000][seed - 1], max_read_len=320)
+
+
+def test_many_batches_equal_one_batch(gpu_lib, oracle_mod):
+    rng = np.random.default_rng(11)
+    ref_len = [20_000, 9000]
+    hb = random_batch(rng, 30_000, ref_len, weird=True)
+    cuts = [0, 1, 2, 4097, 4098, 12_345, 29_999, 30_000]
+    parts = [hb.slice(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    gpu_parts, orc = run_both(oracle_mod, gpu_lib, parts, ref_len, bin_size=512)
+    gpu_one, _ = run_both(oracle_mod, gpu_lib, [hb], ref_len, bin_size=512)
+    json_equal(gpu_parts.results(["a", "b"]), gpu_one.results(["a", "b"]))
+
+
+def test_empty_and_tiny_batches(gpu_lib, oracle_mod):
+    ref_len = [1000]
+    empty = batch_from_records([])
+    one = batch_from_records([dict(flag=0, mapq=9, ref_id=0, pos=0, cigar="3M", seq="ACG", qual=[0, 93, 5])])
+    run_both(oracle_mod, gpu_lib, [empty], ref_len)
+    run_both(oracle_mod, gpu_lib, [empty, one, empty], ref_len)
+
+
+def test_no_records_gives_null_summaries(gpu_lib, oracle_mod):
+    gpu, _ = run_both(oracle_mod, gpu_lib, [], [1000, 2000])
+    r = gpu.results(["a", "b"])
+    assert r["general"]["summary"]["mapped_pct"] is None and r["quality_scores"] == {"scores": {}}
+
+
+def test_facet_subsets(gpu_lib, oracle_mod):
+    """`--only FACET` (qc.rs:101-123): every other top-level key is null."""
+    rng = np.random.default_rng(5)
+    ref_len = [8000]
+    hb = random_batch(rng, 5000, ref_len)
+    for facets in (ffi.FACET_GENERAL, ffi.FACET_TEMPLATE_LENGTH, ffi.FACET_GC_CONTENT, ffi.FACET_QUALITY_SCORE,
+                   ffi.FACET_COVERAGE, ffi.FACET_QUALITY_SCORE | ffi.FACET_GC_CONTENT | ffi.FACET_TEMPLATE_LENGTH):
+        gpu, _ = run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=facets)
+        r = gpu.results(["s"])
+        for key, bit in (("general", 1), ("template_length", 2), ("gc_content", 4), ("quality_scores", 8),
+                         ("coverage", 16), ("edits", 32)):
+            assert (r[key] is None) == (not facets & bit), (facets, key)
+
+
+def test_pass_masks(gpu_lib, oracle_mod):
+    """The two passes of the driver can be fed different record subsets (-n semantics)."""
+    rng = np.random.default_rng(8)
+    ref_len = [6000]
+    hb = random_batch(rng, 4000, ref_len)
+    orc = oracle_mod.Oracle(ref_len, bin_size=100, max_read_len=320)
+    gpu = host.QcContext(ref_len, bin_size=100, max_read_len=320, lib=gpu_lib)
+    a, b = hb.slice(0, 1000), hb.slice(500, 4000)
+    for c in (orc, gpu):
+        c.process_batch(a, ffi.PASS_RECORD)
+        c.process_batch(b, ffi.PASS_SEQUENCE)
+        c.finalize(allow_malformed=True)
+    compare_contexts(gpu, orc, 1, ffi.FACETS_DEFAULT, 100, ref_len)
+
+
+def test_malformed_records_are_reported_not_hidden(gpu_lib, oracle_mod):
+    recs = [dict(flag=0x1, mapq=9, ref_id=-1, pos=5, mate_ref_id=0, cigar="3M", seq="ACG", qual=[1, 2, 3]),  # unwrap on None
+            dict(flag=0, mapq=9, ref_id=0, pos=5, cigar="3M", seq="ACG", qual=[1, 94, 255])]               # score > 93
+    hb = batch_from_records(recs)
+    gpu = host.QcContext([100], lib=gpu_lib)
+    gpu.process_batch(hb)
+    with pytest.raises(host.NgsqError) as ei:
+        gpu.finalize()
+    assert ei.value.code == ffi.ERR_MALFORMED_RECORD
+    assert gpu.error_counts()["missing_reference_id"] == 1 and gpu.error_counts()["bad_quality_score"] == 2
+    run_both(oracle_mod, gpu_lib, [hb], [100])
+
+
+def test_reset_makes_the_context_reusable(gpu_lib, oracle_mod):
+    rng = np.random.default_rng(21)
+    ref_len = [10_000, 400]
+    hb1, hb2 = random_batch(rng, 6000, ref_len), random_batch(rng, 3000, ref_len)
+    gpu = host.QcContext(ref_len, bin_size=300, max_read_len=320, lib=gpu_lib)
+    gpu.process_batch(hb1)
+    gpu.finalize(allow_malformed=True)
+    first = gpu.results(["a", "b"])
+    gpu.reset()
+    gpu.process_batch(hb2)
+    gpu.finalize(allow_malformed=True)
+    orc = oracle_mod.Oracle(ref_len, bin_size=300, max_read_len=320)
+    orc.process_batch(hb2)
+    orc.finalize(allow_malformed=True)
+    json_equal(gpu.results(["a", "b"]), orc.results(["a", "b"]))
+    gpu.reset()
+    gpu.process_batch(hb1)
+    gpu.finalize(allow_malformed=True)
+    json_equal(gpu.results(["a", "b"]), first)  # idempotent
+
+
+def test_pileup_too_large_and_large_depth(gpu_lib, oracle_mod):
+    """depth > cov_cap is `ignored` (coverage.rs:211-213) but still in the bin means."""
+    recs = [dict(flag=0, ref_id=0, pos=10, cigar="20M", seq="A" * 20, qual=[5] * 20)] * 70 + \
+           [dict(flag=0, ref_id=0, pos=15, cigar="2M", seq="AC", qual=[5] * 2)] * 10
+    hb = batch_from_records(recs)
+    gpu, _ = run_both(oracle_mod, gpu_lib, [hb], [100], bin_size=16, facets=ffi.FACET_COVERAGE)
+    orc = oracle_mod.Oracle([100], facets=ffi.FACET_COVERAGE, bin_size=16, cov_cap=64)
+    g2 = host.QcContext([100], facets=ffi.FACET_COVERAGE, bin_size=16, cov_cap=64, lib=gpu_lib)
+    for c in (orc, g2):
+        c.process_batch(hb)
+        c.finalize()
+    assert g2.coverage_sequence(0)[2] == 20  # 20 positions at depth 70/80 > 64
+    json_equal(g2.results(["s"]), orc.results(["s"]))
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_edits_facet(gpu_lib, oracle_mod, seed):
+    rng = np.random.default_rng(seed)
+    ref_len = [6000, 2500]
+    bases = random_ref_bases(rng, ref_len)
+    hb = make_edit_friendly(random_batch(rng, 8000, ref_len, weird=False, min_len=1), rng, bases, ref_len)
+    gpu, _ = run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=ffi.FACETS_DEFAULT | ffi.FACET_EDITS,
+                      ref_bases=bases, bin_size=500)
+    r1, r2, vaf = gpu.edits()
+    assert r1.sum() + r2.sum() > 1000 and vaf.sum() > 1000
+    # malformed walks (random CIGARs) must be counted identically
+    hb2 = random_batch(rng, 4000, ref_len)
+    run_both(oracle_mod, gpu_lib, [hb2], ref_len, facets=ffi.FACET_EDITS, ref_bases=bases)
+    # sequence without bases in the FASTA
+    run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=ffi.FACET_EDITS, ref_bases=[bases[0], None])
+
+
+def test_vaf_f32_rounding_exhaustive_small_totals(gpu_lib, oracle_mod):
+    """Every (alts, total) with total <= 128 through both VAF paths (f32 divide, multiply, truncate)."""
+    T = 128
+    L = T * (T + 1) // 2 + T
+    ref = np.full(L, 1, dtype=np.uint8)
+    recs, p = [], 0
+    for total in range(1, T + 1):
+        for alts in range(0, total + 1, max(1, total // 16)):
+            recs += [dict(flag=0, ref_id=0, pos=p, cigar="1M", seq="C", qual=[1])] * alts
+            recs += [dict(flag=0, ref_id=0, pos=p, cigar="1M", seq="A", qual=[1])] * (total - alts)
+            p += 1
+    assert p <= L
+    run_both(oracle_mod, gpu_lib, [batch_from_records(recs)], [L], facets=ffi.FACET_EDITS, ref_bases=[ref])
+
+
+def test_sharded_state_sums_to_single_context(gpu_lib, oracle_mod):
+    """shard the records over contexts, add the exchange blocks, finalize once."""
+    rng = np.random.default_rng(31)
+    ref_len = [40_000, 3000]
+    hb = random_batch(rng, 24_000, ref_len, weird=True)
+    kw = dict(bin_size=700, max_read_len=320, gc_seed=3)
+    shards = [hb.slice(0, 9000), hb.slice(9000, 9001), hb.slice(9001, 24_000)]
+    blocks = None
+    for sh in shards:
+        with host.QcContext(ref_len, lib=gpu_lib, **kw) as c:
+            c.process_batch(sh)
+            c.synchronize()
+            got = [c.state_download(w) for w in (0, 1)]
+        blocks = got if blocks is None else [a + b for a, b in zip(blocks, got)]
+    total = host.QcContext(ref_len, lib=gpu_lib, **kw)
+    total.state_upload(0, blocks[0])
+    total.state_upload(1, blocks[1])
+    total.finalize(allow_malformed=True)
+    orc = oracle_mod.Oracle(ref_len, **kw)
+    orc.process_batch(hb)
+    orc.finalize(allow_malformed=True)
+    compare_contexts(total, orc, 2, ffi.FACETS_DEFAULT, 700, ref_len)
+    json_equal(total.results(["a", "b"]), orc.results(["a", "b"]))
+
+
+def test_full_size_properties(gpu_lib):
+    """At a size the oracle cannot reach quickly: size-independent invariants on
+    4 M generated-in-HBM records over a chr1-sized sequence."""
+    n, L = 4_000_000, 248_956_422
+    cfg = host.synth_config(n, ref_len=L, n_refs=2)
+    with host.QcContext([L, 242_193_529], max_read_len=150, timing=True, lib=gpu_lib) as gpu:
+        db = gpu.synth_device_batch(cfg, 0, n)
+        gpu.process_batch(db)
+        gpu.finalize()
+        g = gpu.general()
+        assert g["total"] == n and g["primary"] + g["secondary"] + g["supplementary"] == n
+        q = gpu.quality_scores()
+        assert (q.sum(axis=1) == n).all()  # every record reaches every cycle exactly once
+        h, processed, ignored = gpu.template_length()
+        assert processed + ignored == n and h.sum() == processed
+        gc = gpu.gc_content()
+        assert gc["processed"] + gc["ignored_flags"] + gc["ignored_too_short"] == n
+        assert gc["histogram"].sum() == gc["processed"]
+        assert gc["total_gc_count"] + gc["total_at_count"] + gc["total_other_count"] == 100 * gc["processed"]
+        seen, hist, ign, bins = gpu.coverage_sequence(0)
+        assert seen and hist.sum() + ign == L + 1
+        mapped = n - g["unmapped"]
+        assert bins.sum() == 150 * mapped  # every mapped read adds 150 to the depth total
+        assert gpu.coverage_nonsensical() == 0
+        assert not gpu.coverage_sequence(1)[0]
+        first = gpu.results(["chr1", "chr2"])
+        gpu.reset()
+        gpu.process_batch(db)
+        gpu.finalize()
+        json_equal(gpu.results(["chr1", "chr2"]), first)  # deterministic
