@@ -108,8 +108,11 @@ typedef struct ngsq_config {
  *   tlen        record.template_length()             template_length.rs:80
  *   l_seq       sequence length in bases
  *   seq         packed 4-bit bases "=ACMGRSVTWYHKDBN", high nibble first, (l_seq+1)/2 bytes
- *   qual        Phred bytes; a record with missing qualities has ZERO qual bytes
- *               (noodles yields an empty QualityScores for 0xFF-filled BAM quals)
+ *   qual        Phred bytes.  With qual_off: a record with missing qualities has ZERO
+ *               qual bytes (noodles yields an empty QualityScores for 0xFF-filled BAM
+ *               quals).  With a fixed stride: each row holds qual_stride bytes and the
+ *               byte 0xFF means "no score at this cycle" (row padding beyond l_seq, or a
+ *               whole 0xFF row = missing qualities, exactly BAM's own encoding)
  *   cigar       BAM encoding len<<4|op, op in 0..8 = MIDNSHP=X
  * Variable-length columns are addressed either by an offsets array
  * (`*_off[i] .. *_off[i+1]`, n_records+1 entries, units: bytes for seq/qual,
@@ -132,7 +135,7 @@ typedef struct ngsq_batch {
     const uint8_t *seq;
     const uint64_t *seq_off;    /* NULL -> fixed stride */
     const uint8_t *qual;
-    const uint64_t *qual_off;   /* NULL -> fixed stride; then every record has l_seq quals */
+    const uint64_t *qual_off;   /* NULL -> fixed stride rows, 0xFF = absent               */
     const uint32_t *cigar;
     const uint64_t *cigar_off;  /* NULL -> fixed stride (ops per record) */
     uint32_t seq_stride;        /* bytes per record when seq_off == NULL  */

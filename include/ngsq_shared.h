@@ -31,10 +31,13 @@ NGSQ_HD uint64_t ngsq_mix64(uint64_t z) {
  *     offset = if 100 < len { rng.gen_range(0..len-100) } else { 0 }
  * Same support (upper bound exclusive), but a pure function of the record's
  * index in the file so that results are reproducible and shard-invariant.
+ * The range reduction is the widening multiply rand 0.8.5's gen_range itself
+ * uses (high half of a 32x32 product): one v_mul_hi_u32 on the device.
  */
 NGSQ_HD uint32_t ngsq_gc_offset_fn(uint64_t gc_seed, uint64_t record_index, uint32_t l_seq) {
     if (l_seq <= 100u) return 0u;
-    return (uint32_t)(ngsq_mix64(gc_seed ^ record_index) % (uint64_t)(l_seq - 100u));
+    const uint64_t h32 = ngsq_mix64(gc_seed ^ record_index) >> 32;
+    return (uint32_t)((h32 * (uint64_t)(l_seq - 100u)) >> 32);
 }
 
 /* ------------------------------------------------------------------------ */

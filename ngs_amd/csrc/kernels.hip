@@ -207,7 +207,19 @@ __global__ __launch_bounds__(256) void k_cigar_cov(DeviceState st, DeviceBatch b
             }
         }
     }
-    if (seen_cnt) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+    // flush the per-thread run: one atomic per wave when the wave saw one sequence
+    {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long active = __ballot(seen_cnt != 0);
+        if (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int32_t r0 = __shfl(seen_ref, leader, 64);
+            const bool same = seen_cnt != 0 && seen_ref == r0;
+            const uint32_t s = wave_sum(same ? seen_cnt : 0u);
+            if (lane == 0) atomicAdd(&st.counters[st.off_seen + r0], (u64)s);
+            if (seen_cnt != 0 && !same) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+        }
+    }
     u64 ns = wave_sum64(nonsensical);
     if ((threadIdx.x & 63) == 0 && ns) atomicAdd(&st.counters[C_COV_NONSENSICAL], ns);
 
@@ -307,15 +319,21 @@ __global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBat
             nq = (uint32_t)(b.qual_off[i + 1] - q0);
         } else {
             q0 = i * (uint64_t)b.qual_stride;
-            nq = b.l_seq[i];
-        }
-        if (nq > st.max_read_len) {
-            if (lane == 0) c[1] += 1;
-            nq = st.max_read_len;
+            nq = b.qual_stride;
         }
         const uint8_t *q = b.qual + q0;
+        const bool fixed_row = b.qual_off == nullptr;
+        if (nq > st.max_read_len) {
+            // reads longer than the table: an error unless the excess is row padding
+            uint32_t over = 0;
+            for (uint32_t cyc = st.max_read_len + lane; cyc < nq; cyc += 64)
+                over |= (!fixed_row || q[cyc] != 0xFFu);
+            if (__any(over) && lane == 0) c[1] += 1;
+            nq = st.max_read_len;
+        }
         for (uint32_t cyc = lane; cyc < nq; cyc += 64) {
             const uint32_t v = q[cyc];
+            if (fixed_row && v == 0xFFu) continue; // no score at this cycle (ngsq.h)
             if (v > NGSQ_MAX_SCORE) {
                 c[0] += 1;
             } else if (cyc < lds_rows) {
@@ -332,6 +350,253 @@ __global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBat
     }
     const uint32_t idx[2] = {C_ERR + E_BAD_QUAL, C_ERR + E_READ_TOO_LONG};
     block_flush<2>(c, s_acc, st.counters, idx);
+}
+
+// ---------------------------------------------------------------------------
+// Quality Score, fast path: dense fixed-stride rows read as ONE byte stream.
+// reference: quality_scores.rs:37-49
+//
+// Thread = one 16-byte chunk (global_load_dwordx4, fully coalesced: a wave reads
+// 1 KiB contiguous).  Byte j of the stream is cycle j mod l of record j / l, so
+// no per-record bookkeeping is needed.  The per-block LDS table is laid out
+// [rho(cycle)][95] with rho(c) = (c mod 16) * R + c / 16, R = ceil(l/16):
+// lanes k, k+1 of one ds_add hold cycles 16 apart, i.e. CONSECUTIVE rows, and the
+// odd row pitch (95 words) walks them through consecutive banks when their
+// scores are equal (the common case on real data) -- conflict-free where the
+// natural [cycle][94] layout would put all 64 lanes on two banks.
+// ---------------------------------------------------------------------------
+constexpr uint32_t QF_PITCH = 95;
+
+__device__ __forceinline__ void qf_dword(uint32_t w, uint32_t cyc, uint32_t l, uint32_t R, uint32_t *s_q,
+                                         uint32_t &bad) {
+    // any byte >= 94 (incl. 0xFF padding)?  low-7-bits + 34 carries into bit 7, or bit 7 set
+    const uint32_t hi = (((w & 0x7F7F7F7Fu) + 0x22222222u) | w) & 0x80808080u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t q = (w >> (8 * k)) & 0xFFu;
+        uint32_t c = cyc + k;
+        c = min(c, c - l); // wrap into the next record's cycle 0.. (unsigned: c-l is huge unless c >= l)
+        const uint32_t row = (c & 15u) * R + (c >> 4);
+        if (hi == 0u) {
+            atomicAdd(&s_q[row * QF_PITCH + q], 1u);
+        } else if (q <= NGSQ_MAX_SCORE) {
+            atomicAdd(&s_q[row * QF_PITCH + q], 1u);
+        } else if (q != 0xFFu) {
+            bad += 1; // 0xFF = no score at this cycle (ngsq.h); 94..254 is a decode error
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_qual_fixed(DeviceState st, const uint8_t *__restrict__ qual,
+                                                     uint64_t n_bytes, uint32_t l, uint32_t R) {
+    extern __shared__ uint32_t s_q[]; // 16*R rows x QF_PITCH
+    __shared__ u64 s_acc[1];
+    const uint32_t nb = 16u * R * QF_PITCH;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_q[i] = 0;
+    if (threadIdx.x == 0) s_acc[0] = 0;
+    __syncthreads();
+
+    const uint64_t n_chunks = (n_bytes + 15) / 16;
+    const uint64_t per = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = min(per * blockIdx.x, n_chunks), hi = min(lo + per, n_chunks);
+    const uint64_t full = n_bytes / 16; // chunks that are entirely inside the stream
+    uint32_t cyc = (uint32_t)(((lo + threadIdx.x) * 16) % l);
+    const uint32_t step = (16u * blockDim.x) % l;
+    uint32_t bad[1] = {0};
+    const uint4 *src = reinterpret_cast<const uint4 *>(qual);
+
+    uint64_t g = lo + threadIdx.x;
+    // two chunks in flight per thread
+    for (; g + blockDim.x < hi && g + blockDim.x < full; g += 2 * (uint64_t)blockDim.x) {
+        const uint4 w0 = src[g];
+        const uint4 w1 = src[g + blockDim.x];
+        uint32_t c1 = cyc + step;
+        c1 = min(c1, c1 - l);
+        qf_dword(w0.x, cyc, l, R, s_q, bad[0]);
+        qf_dword(w0.y, cyc + 4, l, R, s_q, bad[0]);
+        qf_dword(w0.z, cyc + 8, l, R, s_q, bad[0]);
+        qf_dword(w0.w, cyc + 12, l, R, s_q, bad[0]);
+        qf_dword(w1.x, c1, l, R, s_q, bad[0]);
+        qf_dword(w1.y, c1 + 4, l, R, s_q, bad[0]);
+        qf_dword(w1.z, c1 + 8, l, R, s_q, bad[0]);
+        qf_dword(w1.w, c1 + 12, l, R, s_q, bad[0]);
+        cyc = c1 + step;
+        cyc = min(cyc, cyc - l);
+    }
+    for (; g < hi; g += blockDim.x) {
+        uint4 w;
+        if (g < full) {
+            w = src[g];
+        } else { // the last, partial chunk: absent bytes read as 0xFF
+            uint32_t t[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            for (uint64_t j = g * 16; j < n_bytes; j++) {
+                const uint32_t k = (uint32_t)(j - g * 16);
+                t[k >> 2] = (t[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)qual[j] << (8 * (k & 3)));
+            }
+            w = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        qf_dword(w.x, cyc, l, R, s_q, bad[0]);
+        qf_dword(w.y, cyc + 4, l, R, s_q, bad[0]);
+        qf_dword(w.z, cyc + 8, l, R, s_q, bad[0]);
+        qf_dword(w.w, cyc + 12, l, R, s_q, bad[0]);
+        cyc += step;
+        cyc = min(cyc, cyc - l);
+    }
+    __syncthreads();
+    const uint32_t n_out = l * QUAL_BINS;
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) {
+        const uint32_t c = i / QUAL_BINS, q = i - c * QUAL_BINS;
+        const uint32_t v = s_q[((c & 15u) * R + (c >> 4)) * QF_PITCH + q];
+        if (v) atomicAdd(&st.counters[st.off_qual + i], (u64)v);
+    }
+    const uint32_t idx[1] = {C_ERR + E_BAD_QUAL};
+    block_flush<1>(bad, s_acc, st.counters, idx);
+}
+
+// ---------------------------------------------------------------------------
+// GC Content, fast path: dense fixed-stride packed rows read as one stream.
+// reference: gc_content.rs:38-100
+//
+// A block walks tiles of GCF_TILE records (tile start a multiple of 16 records,
+// so the tile's first byte is 16-byte aligned for any row pitch):
+//   phase 0  thread per record : flag / length filters, window offset -> LDS
+//   phase 1  thread per 16-byte chunk of the tile's byte stream (coalesced
+//            dwordx4): nibble-parallel classification of its 32 bases, masked
+//            to the 100-base window of the one or two records it spans;
+//            per-record G/C count accumulated in LDS
+//   phase 2  thread per record : histogram of the per-record G/C count
+// ---------------------------------------------------------------------------
+constexpr uint32_t GCF_TILE = 1024;
+constexpr uint32_t GCF_SKIP = 0xFFFFFFFFu;
+
+// bit 4e of the result is set iff base e (0..7, stream order) of the dword is G/C (resp. A/T)
+__device__ __forceinline__ void gcf_classify(uint32_t x, uint32_t &gc, uint32_t &at) {
+    // put base order = nibble order: the first base of a byte is its HIGH nibble
+    const uint32_t sw = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
+    const uint32_t M = 0x11111111u;
+    const uint32_t b0 = sw & M, b1 = (sw >> 1) & M, b2 = (sw >> 2) & M, b3 = (sw >> 3) & M;
+    gc = (b1 ^ b2) & ~(b0 | b3); // 0010 (C) or 0100 (G)
+    at = (b0 ^ b3) & ~(b1 | b2); // 0001 (A) or 1000 (T)
+}
+
+__device__ __forceinline__ uint32_t gcf_prefix(int n) { // nibble-LSB mask of the first n bases of a dword
+    return n <= 0 ? 0u : (n >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * n)) - 1u)));
+}
+
+// G/C and A/T counts of chunk nibbles [a, b) (0 <= a <= b <= 32)
+__device__ __forceinline__ void gcf_count(const uint32_t (&gcb)[4], const uint32_t (&atb)[4], int a, int b,
+                                          uint32_t &gc, uint32_t &at) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t m = gcf_prefix(b - 8 * d) & ~gcf_prefix(a - 8 * d);
+        gc += __popc(gcb[d] & m);
+        at += __popc(atb[d] & m);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gc_fixed(DeviceState st, DeviceBatch b, uint32_t sb, uint32_t magic) {
+    __shared__ uint32_t s_hist[NGSQ_GC_BINS];
+    __shared__ u64 s_acc[6];
+    __shared__ uint32_t s_off[GCF_TILE];
+    __shared__ uint32_t s_cnt[GCF_TILE];
+    if (threadIdx.x < NGSQ_GC_BINS) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 6) s_acc[threadIdx.x] = 0;
+    uint32_t c[6] = {0, 0, 0, 0, 0, 0}; // gc, at, other, processed, ign_flags, ign_short
+    const uint64_t n_tiles = (b.n + GCF_TILE - 1) / GCF_TILE;
+    const uint64_t total_bytes = b.n * (uint64_t)sb;
+
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * GCF_TILE;
+        const uint32_t nrec = (uint32_t)min((uint64_t)GCF_TILE, b.n - t0);
+        __syncthreads(); // previous tile's phase 2 has read s_off / s_cnt
+        // ---- phase 0
+        for (uint32_t r = threadIdx.x; r < nrec; r += blockDim.x) {
+            const uint32_t f = b.flag[t0 + r];
+            const uint32_t l = b.l_seq[t0 + r];
+            uint32_t off = GCF_SKIP;
+            if (f & 0x500u) {
+                c[4] += 1; // duplicate | secondary  gc_content.rs:41-45
+            } else if (l < NGSQ_GC_WINDOW) {
+                c[5] += 1; // :59-62
+            } else {
+                off = ngsq_gc_offset_fn(st.gc_seed, b.first_record_index + t0 + r, l);
+            }
+            s_off[r] = off;
+            s_cnt[r] = 0;
+        }
+        __syncthreads();
+        // ---- phase 1
+        const uint32_t tile_bytes = nrec * sb;
+        const uint32_t n_chunks = (tile_bytes + 15) / 16;
+        const uint64_t base = t0 * (uint64_t)sb;
+        for (uint32_t g = threadIdx.x; g < n_chunks; g += blockDim.x) {
+            const uint32_t B = g * 16;
+            uint4 w;
+            if (base + B + 16 <= total_bytes) {
+                w = *reinterpret_cast<const uint4 *>(b.seq + base + B);
+            } else {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (uint64_t j = base + B; j < total_bytes; j++) {
+                    const uint32_t k = (uint32_t)(j - base - B);
+                    t[k >> 2] |= (uint32_t)b.seq[j] << (8 * (k & 3));
+                }
+                w = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            uint32_t gcb[4], atb[4];
+            gcf_classify(w.x, gcb[0], atb[0]);
+            gcf_classify(w.y, gcb[1], atb[1]);
+            gcf_classify(w.z, gcb[2], atb[2]);
+            gcf_classify(w.w, gcb[3], atb[3]);
+            const uint32_t rec = __umulhi(B, magic);       // B / sb (exact for B < 2^19, sb < 2^9)
+            const uint32_t r0 = B - rec * sb;              // first byte of the chunk inside its row
+            const int e0 = (int)min(16u, sb - r0);         // chunk bytes that belong to `rec`
+            // part A: record `rec`, row bases [2*r0, 2*(r0+e0))
+            {
+                const uint32_t off = s_off[rec];
+                if (off != GCF_SKIP) {
+                    const int lo_b = max((int)off, (int)(2 * r0)), hi_b = min((int)off + 100, (int)(2 * (r0 + e0)));
+                    if (hi_b > lo_b) {
+                        uint32_t gc = 0, at = 0;
+                        gcf_count(gcb, atb, lo_b - 2 * (int)r0, hi_b - 2 * (int)r0, gc, at);
+                        c[0] += gc;
+                        c[1] += at;
+                        c[2] += (uint32_t)(hi_b - lo_b) - gc - at;
+                        if (gc) atomicAdd(&s_cnt[rec], gc);
+                    }
+                }
+            }
+            // part B: record rec+1 (same tile), row bases [0, 2*(16-e0))
+            if (e0 < 16 && rec + 1 < nrec) {
+                const uint32_t off = s_off[rec + 1];
+                if (off != GCF_SKIP) {
+                    const int lo_b = (int)off, hi_b = min((int)off + 100, 2 * (16 - e0));
+                    if (hi_b > lo_b) {
+                        uint32_t gc = 0, at = 0;
+                        gcf_count(gcb, atb, lo_b + 2 * e0, hi_b + 2 * e0, gc, at);
+                        c[0] += gc;
+                        c[1] += at;
+                        c[2] += (uint32_t)(hi_b - lo_b) - gc - at;
+                        if (gc) atomicAdd(&s_cnt[rec + 1], gc);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2
+        for (uint32_t r = threadIdx.x; r < nrec; r += blockDim.x) {
+            if (s_off[r] != GCF_SKIP) {
+                atomicAdd(&s_hist[s_cnt[r]], 1u); // :91-96 round(gc/100*100) == gc
+                c[3] += 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NGSQ_GC_BINS) {
+        const uint32_t v = s_hist[threadIdx.x];
+        if (v) atomicAdd(&st.counters[OFF_GC_HIST + threadIdx.x], (u64)v);
+    }
+    const uint32_t idx[6] = {C_GC_GC, C_GC_AT, C_GC_OTHER, C_GC_PROCESSED, C_GC_IGN_FLAGS, C_GC_IGN_SHORT};
+    block_flush<6>(c, s_acc, st.counters, idx);
 }
 
 // ---------------------------------------------------------------------------
@@ -645,6 +910,14 @@ hipError_t launch_cigar_cov(const LaunchInfo &li, const DeviceState &st, const D
 
 hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
     if (!b.n) return hipSuccess;
+    // fast path: dense fixed-pitch rows, 16-byte aligned stream, pitch in [16, 512)
+    if (!b.seq_off && b.seq_stride >= 16 && b.seq_stride < 512 && ((uintptr_t)b.seq & 15) == 0) {
+        const uint32_t sb = b.seq_stride;
+        const uint32_t magic = (uint32_t)(((1ull << 32) + sb - 1) / sb);
+        const uint32_t grid = grid_for((b.n + GCF_TILE - 1) / GCF_TILE, 1, li.n_cu * 8);
+        hipLaunchKernelGGL(k_gc_fixed, dim3(grid), dim3(256), 0, s, st, b, sb, magic);
+        return hipGetLastError();
+    }
     const uint32_t grid = grid_for(b.n, 256 * 2, li.n_cu * 8);
     hipLaunchKernelGGL(k_gc, dim3(grid), dim3(256), 0, s, st, b);
     return hipGetLastError();
@@ -652,6 +925,25 @@ hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBa
 
 hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
     if (!b.n) return hipSuccess;
+    // fast path: dense fixed-pitch rows no longer than the table, 16-byte aligned stream
+    if (!b.qual_off && b.qual_stride >= 16 && b.qual_stride <= st.max_read_len &&
+        b.qual_stride <= QUAL_LDS_MAX_ROWS && ((uintptr_t)b.qual & 15) == 0) {
+        const uint32_t l = b.qual_stride, R = (l + 15) / 16;
+        const size_t lds = (size_t)16 * R * QF_PITCH * sizeof(uint32_t);
+        static bool attr_fixed = false;
+        if (!attr_fixed) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_fixed),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               16 * ((QUAL_LDS_MAX_ROWS + 15) / 16) * QF_PITCH * sizeof(uint32_t));
+            if (e != hipSuccess) return e;
+            attr_fixed = true;
+        }
+        const uint32_t per_cu = lds <= 76 * 1024 ? 2 : 1;
+        const uint64_t n_bytes = b.n * (uint64_t)l;
+        const uint32_t grid = grid_for((n_bytes + 15) / 16, 1024, li.n_cu * per_cu);
+        hipLaunchKernelGGL(k_qual_fixed, dim3(grid), dim3(1024), lds, s, st, b.qual, n_bytes, l, R);
+        return hipGetLastError();
+    }
     uint32_t rows = b.qual_off ? st.max_read_len : b.qual_stride;
     if (rows > st.max_read_len) rows = st.max_read_len;
     if (rows > QUAL_LDS_MAX_ROWS) rows = QUAL_LDS_MAX_ROWS;

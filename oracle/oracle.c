@@ -328,6 +328,9 @@ static void gc_summarize(orc_ctx *c) {
 
 static void quality_process(orc_ctx *c, const orc_record *r) {
     for (uint32_t i = 0; i < r->n_qual; i++) {
+        /* fixed-stride rows (ngsq.h): 0xFF = no score at this cycle (BAM's own
+           encoding of absent qualities; noodles yields no score for them) */
+        if (r->qual_fixed_row && r->qual[i] == 0xFF) continue;
         if (i >= c->cfg.max_read_len) {
             c->errors.read_too_long += 1;
             break;
@@ -594,6 +597,7 @@ static int fetch_record(const ngsq_batch *b, uint64_t i, orc_record *r) {
     r->mate_ref_id = b->mate_ref_id ? b->mate_ref_id[i] : -1;
     r->tlen = b->tlen ? b->tlen[i] : 0;
     r->l_seq = b->l_seq ? b->l_seq[i] : 0;
+    r->qual_fixed_row = 0;
     r->seq = b->seq ? b->seq + (b->seq_off ? b->seq_off[i] : i * (uint64_t)b->seq_stride) : NULL;
     if (b->qual) {
         if (b->qual_off) {
@@ -601,7 +605,8 @@ static int fetch_record(const ngsq_batch *b, uint64_t i, orc_record *r) {
             r->n_qual = (uint32_t)(b->qual_off[i + 1] - b->qual_off[i]);
         } else {
             r->qual = b->qual + i * (uint64_t)b->qual_stride;
-            r->n_qual = r->l_seq;
+            r->n_qual = b->qual_stride;
+            r->qual_fixed_row = 1;
         }
     } else {
         r->qual = NULL;

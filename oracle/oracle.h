@@ -47,6 +47,7 @@ typedef struct orc_record {
     const uint8_t *seq;  /* packed 4-bit */
     uint32_t n_qual;     /* l_seq, or 0 when qualities are missing */
     const uint8_t *qual;
+    int qual_fixed_row;  /* row of a fixed-stride batch: 0xFF bytes are absent scores */
     uint32_t n_cigar;
     const uint32_t *cigar;
     uint64_t index;      /* index of the record in the file (GC offset fn) */

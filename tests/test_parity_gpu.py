@@ -11,7 +11,7 @@ import pytest
 
 from ngs_amd import ffi, host
 from tests.util import (batch_from_records, compare_contexts, json_equal, make_edit_friendly, random_batch,
-                        random_ref_bases)
+                        random_ref_bases, to_fixed_stride)
 
 pytestmark = pytest.mark.gpu
 
@@ -92,6 +92,33 @@ def test_random_edge_cases(gpu_lib, oracle_mod, seed):
     primary = [1, 1, 0, 1]
     hb = random_batch(rng, 20_000, ref_len)
     run_both(oracle_mod, gpu_lib, [hb], ref_len, primary, bin_size=[1000, 7, 50_000][seed - 1], max_read_len=320)
+
+
+@pytest.mark.parametrize("max_len", [16, 31, 37, 100, 149, 150, 151, 255, 300])
+@pytest.mark.parametrize("on_device", [False, True])
+def test_fixed_pitch_rows_with_padding(gpu_lib, oracle_mod, max_len, on_device):
+    """The fast (dense byte-stream) kernels: ragged reads in fixed-pitch rows, 0xFF
+    quality padding, all-0xFF rows (missing qualities), odd pitches, and the same
+    records through the offsets layout must give identical results."""
+    rng = np.random.default_rng(max_len)
+    ref_len = [9000, 2000]
+    var = random_batch(rng, 7001, ref_len, max_len=max_len, min_len=0, weird=max_len >= 101)
+    fixed = to_fixed_stride(var, min_len=max_len)
+    g_fixed, _ = run_both(oracle_mod, gpu_lib, [fixed], ref_len, bin_size=333, max_read_len=320,
+                          on_device=on_device)
+    g_var, _ = run_both(oracle_mod, gpu_lib, [var], ref_len, bin_size=333, max_read_len=320, on_device=on_device)
+    json_equal(g_fixed.results(["a", "b"]), g_var.results(["a", "b"]))
+
+
+def test_fixed_pitch_row_longer_than_table(gpu_lib, oracle_mod):
+    """qual pitch > max_read_len: padding beyond the table is fine, real scores are an error."""
+    rng = np.random.default_rng(77)
+    var = random_batch(rng, 500, [5000], max_len=60, weird=False)
+    fixed = to_fixed_stride(var, min_len=80)
+    run_both(oracle_mod, gpu_lib, [fixed], [5000], max_read_len=64, facets=ffi.FACET_QUALITY_SCORE)
+    fixed2 = to_fixed_stride(random_batch(rng, 500, [5000], max_len=80, min_len=70, weird=False))
+    g, _ = run_both(oracle_mod, gpu_lib, [fixed2], [5000], max_read_len=64, facets=ffi.FACET_QUALITY_SCORE)
+    assert g.error_counts()["read_too_long"] == 500
 
 
 def test_many_batches_equal_one_batch(gpu_lib, oracle_mod):

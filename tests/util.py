@@ -248,3 +248,32 @@ def json_equal(a, b, path=""):
             json_equal(x, y, f"{path}[{i}]")
     else:
         assert a == b and type(a) is type(b), f"{path}: {a!r} vs {b!r}"
+
+
+def to_fixed_stride(hb: HostBatch, min_len: int = 0) -> HostBatch:
+    """Re-lay a variable-length batch as fixed-pitch rows (ngsq.h): seq rows padded
+    with zero nibbles, qual rows padded with 0xFF (a record with missing qualities
+    becomes an all-0xFF row, BAM's own encoding), cigar rows padded with zeros."""
+    n = hb.n
+    l_seq = hb.cols["l_seq"]
+    maxl = max(int(l_seq.max()) if n else 0, min_len, 1)
+    sb, qb = (maxl + 1) // 2, maxl
+    cs = max(int(hb.cols["n_cigar"].max()) if n else 0, 1)
+    seq = np.zeros((n, sb), dtype=np.uint8)
+    qual = np.full((n, qb), 0xFF, dtype=np.uint8)
+    cigar = np.zeros((n, cs), dtype=np.uint32)
+    so, qo, co = hb.cols["seq_off"], hb.cols["qual_off"], hb.cols["cigar_off"]
+    for i in range(n):
+        a, b = int(so[i]), int(so[i + 1])
+        seq[i, :b - a] = hb.cols["seq"][a:b]
+        a, b = int(qo[i]), int(qo[i + 1])
+        qual[i, :b - a] = hb.cols["qual"][a:b]
+        a, b = int(co[i]), int(co[i + 1])
+        cigar[i, :b - a] = hb.cols["cigar"][a:b]
+    cols = {k: hb.cols[k] for k in FIXED_COLS}
+    cols.update(seq=seq.reshape(-1), qual=qual.reshape(-1), cigar=cigar.reshape(-1), seq_off=None, qual_off=None,
+                cigar_off=None)
+    return HostBatch(n, cols, sb, qb, cs, hb.first_record_index)
+
+
+FIXED_COLS = ["flag", "mapq", "ref_id", "pos", "mate_ref_id", "tlen", "l_seq", "n_cigar"]
