@@ -54,6 +54,7 @@ enum : uint32_t {
 
 constexpr uint32_t QUAL_BINS = NGSQ_MAX_SCORE + 1; // 94
 constexpr uint32_t QUAL_LDS_MAX_ROWS = 320;        // cycles kept in the LDS table
+constexpr uint32_t QUAL_WIN_MAX_R = 20;            // 16-byte windows per row the fast path is built for
 constexpr uint64_t NO_DEPTH = ~0ull;
 
 // device view of the context shared by all kernels
@@ -108,6 +109,10 @@ hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBa
 // Quality Score (quality_scores.rs:37-49)
 hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                        hipStream_t s);
+// Quality Score fast path for fixed-pitch rows (qual_kernel.hip)
+bool qual_window_supported(const DeviceState &st, const DeviceBatch &b);
+hipError_t launch_qual_window(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint32_t nrot,
+                              hipStream_t s);
 // Edits process (edits.rs:217-303)
 hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                         hipStream_t s);

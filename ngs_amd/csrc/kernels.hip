@@ -6,6 +6,8 @@
 // device-scope atomics.  No MFMA anywhere.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/ngsq_shared.h"
 #include "kernels.h"
 
@@ -350,107 +352,6 @@ __global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBat
     }
     const uint32_t idx[2] = {C_ERR + E_BAD_QUAL, C_ERR + E_READ_TOO_LONG};
     block_flush<2>(c, s_acc, st.counters, idx);
-}
-
-// ---------------------------------------------------------------------------
-// Quality Score, fast path: dense fixed-stride rows read as ONE byte stream.
-// reference: quality_scores.rs:37-49
-//
-// Thread = one 16-byte chunk (global_load_dwordx4, fully coalesced: a wave reads
-// 1 KiB contiguous).  Byte j of the stream is cycle j mod l of record j / l, so
-// no per-record bookkeeping is needed.  The per-block LDS table is laid out
-// [rho(cycle)][95] with rho(c) = (c mod 16) * R + c / 16, R = ceil(l/16):
-// lanes k, k+1 of one ds_add hold cycles 16 apart, i.e. CONSECUTIVE rows, and the
-// odd row pitch (95 words) walks them through consecutive banks when their
-// scores are equal (the common case on real data) -- conflict-free where the
-// natural [cycle][94] layout would put all 64 lanes on two banks.
-// ---------------------------------------------------------------------------
-constexpr uint32_t QF_PITCH = 95;
-
-__device__ __forceinline__ void qf_dword(uint32_t w, uint32_t cyc, uint32_t l, uint32_t R, uint32_t *s_q,
-                                         uint32_t &bad) {
-    // any byte >= 94 (incl. 0xFF padding)?  low-7-bits + 34 carries into bit 7, or bit 7 set
-    const uint32_t hi = (((w & 0x7F7F7F7Fu) + 0x22222222u) | w) & 0x80808080u;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t q = (w >> (8 * k)) & 0xFFu;
-        uint32_t c = cyc + k;
-        c = min(c, c - l); // wrap into the next record's cycle 0.. (unsigned: c-l is huge unless c >= l)
-        const uint32_t row = (c & 15u) * R + (c >> 4);
-        if (hi == 0u) {
-            atomicAdd(&s_q[row * QF_PITCH + q], 1u);
-        } else if (q <= NGSQ_MAX_SCORE) {
-            atomicAdd(&s_q[row * QF_PITCH + q], 1u);
-        } else if (q != 0xFFu) {
-            bad += 1; // 0xFF = no score at this cycle (ngsq.h); 94..254 is a decode error
-        }
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_qual_fixed(DeviceState st, const uint8_t *__restrict__ qual,
-                                                     uint64_t n_bytes, uint32_t l, uint32_t R) {
-    extern __shared__ uint32_t s_q[]; // 16*R rows x QF_PITCH
-    __shared__ u64 s_acc[1];
-    const uint32_t nb = 16u * R * QF_PITCH;
-    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_q[i] = 0;
-    if (threadIdx.x == 0) s_acc[0] = 0;
-    __syncthreads();
-
-    const uint64_t n_chunks = (n_bytes + 15) / 16;
-    const uint64_t per = (n_chunks + gridDim.x - 1) / gridDim.x;
-    const uint64_t lo = min(per * blockIdx.x, n_chunks), hi = min(lo + per, n_chunks);
-    const uint64_t full = n_bytes / 16; // chunks that are entirely inside the stream
-    uint32_t cyc = (uint32_t)(((lo + threadIdx.x) * 16) % l);
-    const uint32_t step = (16u * blockDim.x) % l;
-    uint32_t bad[1] = {0};
-    const uint4 *src = reinterpret_cast<const uint4 *>(qual);
-
-    uint64_t g = lo + threadIdx.x;
-    // two chunks in flight per thread
-    for (; g + blockDim.x < hi && g + blockDim.x < full; g += 2 * (uint64_t)blockDim.x) {
-        const uint4 w0 = src[g];
-        const uint4 w1 = src[g + blockDim.x];
-        uint32_t c1 = cyc + step;
-        c1 = min(c1, c1 - l);
-        qf_dword(w0.x, cyc, l, R, s_q, bad[0]);
-        qf_dword(w0.y, cyc + 4, l, R, s_q, bad[0]);
-        qf_dword(w0.z, cyc + 8, l, R, s_q, bad[0]);
-        qf_dword(w0.w, cyc + 12, l, R, s_q, bad[0]);
-        qf_dword(w1.x, c1, l, R, s_q, bad[0]);
-        qf_dword(w1.y, c1 + 4, l, R, s_q, bad[0]);
-        qf_dword(w1.z, c1 + 8, l, R, s_q, bad[0]);
-        qf_dword(w1.w, c1 + 12, l, R, s_q, bad[0]);
-        cyc = c1 + step;
-        cyc = min(cyc, cyc - l);
-    }
-    for (; g < hi; g += blockDim.x) {
-        uint4 w;
-        if (g < full) {
-            w = src[g];
-        } else { // the last, partial chunk: absent bytes read as 0xFF
-            uint32_t t[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            for (uint64_t j = g * 16; j < n_bytes; j++) {
-                const uint32_t k = (uint32_t)(j - g * 16);
-                t[k >> 2] = (t[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((uint32_t)qual[j] << (8 * (k & 3)));
-            }
-            w = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-        qf_dword(w.x, cyc, l, R, s_q, bad[0]);
-        qf_dword(w.y, cyc + 4, l, R, s_q, bad[0]);
-        qf_dword(w.z, cyc + 8, l, R, s_q, bad[0]);
-        qf_dword(w.w, cyc + 12, l, R, s_q, bad[0]);
-        cyc += step;
-        cyc = min(cyc, cyc - l);
-    }
-    __syncthreads();
-    const uint32_t n_out = l * QUAL_BINS;
-    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) {
-        const uint32_t c = i / QUAL_BINS, q = i - c * QUAL_BINS;
-        const uint32_t v = s_q[((c & 15u) * R + (c >> 4)) * QF_PITCH + q];
-        if (v) atomicAdd(&st.counters[st.off_qual + i], (u64)v);
-    }
-    const uint32_t idx[1] = {C_ERR + E_BAD_QUAL};
-    block_flush<1>(bad, s_acc, st.counters, idx);
 }
 
 // ---------------------------------------------------------------------------
@@ -925,24 +826,14 @@ hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBa
 
 hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
     if (!b.n) return hipSuccess;
-    // fast path: dense fixed-pitch rows no longer than the table, 16-byte aligned stream
-    if (!b.qual_off && b.qual_stride >= 16 && b.qual_stride <= st.max_read_len &&
-        b.qual_stride <= QUAL_LDS_MAX_ROWS && ((uintptr_t)b.qual & 15) == 0) {
-        const uint32_t l = b.qual_stride, R = (l + 15) / 16;
-        const size_t lds = (size_t)16 * R * QF_PITCH * sizeof(uint32_t);
-        static bool attr_fixed = false;
-        if (!attr_fixed) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_fixed),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               16 * ((QUAL_LDS_MAX_ROWS + 15) / 16) * QF_PITCH * sizeof(uint32_t));
-            if (e != hipSuccess) return e;
-            attr_fixed = true;
+    // fast path: fixed-pitch rows no longer than the table (qual_kernel.hip)
+    if (qual_window_supported(st, b)) {
+        static int nrot = -1;
+        if (nrot < 0) {
+            const char *e = getenv("NGSQ_QUAL_NROT"); // measurement knob; default 4
+            nrot = e ? atoi(e) : 4;
         }
-        const uint32_t per_cu = lds <= 76 * 1024 ? 2 : 1;
-        const uint64_t n_bytes = b.n * (uint64_t)l;
-        const uint32_t grid = grid_for((n_bytes + 15) / 16, 1024, li.n_cu * per_cu);
-        hipLaunchKernelGGL(k_qual_fixed, dim3(grid), dim3(1024), lds, s, st, b.qual, n_bytes, l, R);
-        return hipGetLastError();
+        return launch_qual_window(li, st, b, (uint32_t)nrot, s);
     }
     uint32_t rows = b.qual_off ? st.max_read_len : b.qual_stride;
     if (rows > st.max_read_len) rows = st.max_read_len;
