@@ -318,6 +318,8 @@ static int check_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t facets) {
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Template Length needs tlen");
     if ((facets & (NGSQ_FACET_GC_CONTENT | NGSQ_FACET_EDITS)) && (!b->l_seq || !b->seq))
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "GC Content / Edits need l_seq and seq");
+    if ((facets & NGSQ_FACET_GC_CONTENT) && b->location == NGSQ_MEM_DEVICE && b->seq_off && !b->seq_bytes)
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "device batch with seq_off needs seq_bytes");
     if ((facets & NGSQ_FACET_QUALITY_SCORE) && (!b->qual || (!b->qual_off && !b->l_seq)))
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Quality Score needs qual (+ l_seq or qual_off)");
     if ((facets & (NGSQ_FACET_COVERAGE | NGSQ_FACET_EDITS)) && (!b->ref_id || !b->pos || !b->n_cigar))
@@ -376,7 +378,7 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
     }
     if (rec_f & NGSQ_FACET_GC_CONTENT) {
         Bracket br(c, K_GC, n * 6 + cs.seq_bytes);
-        HIP_TRY(c, launch_gc(c->li, c->st, db, c->stream));
+        HIP_TRY(c, launch_gc(c->li, c->st, db, cs.seq_bytes, c->stream));
     }
     if (rec_f & NGSQ_FACET_QUALITY_SCORE) {
         Bracket br(c, K_QUAL, cs.qual_bytes);

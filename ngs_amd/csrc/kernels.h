@@ -105,7 +105,7 @@ hipError_t launch_cigar_cov(const LaunchInfo &li, const DeviceState &st, const D
                             uint32_t facets, hipStream_t s);
 // GC Content (gc_content.rs:38-100)
 hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
-                     hipStream_t s);
+                     uint64_t seq_bytes, hipStream_t s);
 // Quality Score (quality_scores.rs:37-49)
 hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                        hipStream_t s);

@@ -240,28 +240,38 @@ __global__ __launch_bounds__(256) void k_cigar_cov(DeviceState st, DeviceBatch b
 }
 
 // ---------------------------------------------------------------------------
-// GC Content, one thread per record (general path: any length, any layout)
+// GC Content: one thread per record, gathering only the 100-base window.
 // reference: gc_content.rs:38-100
+//
+// The window [off, off+100) of a record occupies 50 or 51 bytes of its packed
+// row starting at byte off/2.  Each lane loads exactly those bytes (3 x
+// unaligned dwordx4 + 1 x dword from its own row; neighbouring lanes' rows share
+// cache lines, so every fetched line is used) and the window then sits at a
+// FIXED place in 13 registers: only the parity of `off` (one leading nibble)
+// varies.  Classification is nibble-parallel (8 bases per bit-op) with
+// compile-time masks, ~150 VALU operations per record, no LDS staging and no
+// dependence on the row layout: the same kernel serves fixed-pitch rows and the
+// offsets layout.
+// BAM base codes: A=1 C=2 G=4 T=8, anything else is "other" (gc_content.rs:79-86).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void gc_classify(uint32_t code, uint32_t &gc, uint32_t &at, uint32_t &other) {
-    // BAM codes: A=1 C=2 G=4 T=8 (gc_content.rs:79-86)
-    const uint32_t is_gc = (code == 2u) | (code == 4u);
-    const uint32_t is_at = (code == 1u) | (code == 8u);
-    gc += is_gc;
-    at += is_at;
-    other += (is_gc | is_at) ^ 1u;
+__device__ __forceinline__ void gc_dword(uint32_t x, uint32_t mask, uint32_t &gc, uint32_t &at) {
+    const uint32_t y = x >> 1, z = x >> 2, u = x >> 3;
+    gc += __popc((y ^ z) & ~(x | u) & mask); // nibble == 0010 or 0100
+    at += __popc((x ^ u) & ~(y | z) & mask); // nibble == 0001 or 1000
 }
 
-__global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b) {
+__global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b, uint64_t seq_bytes) {
     __shared__ uint32_t s_hist[NGSQ_GC_BINS];
     __shared__ u64 s_acc[6];
     if (threadIdx.x < NGSQ_GC_BINS) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 6) s_acc[threadIdx.x] = 0;
     __syncthreads();
     uint32_t c[6] = {0, 0, 0, 0, 0, 0}; // gc, at, other, processed, ign_flags, ign_short
+    constexpr uint32_t M = 0x11111111u;
 
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
+    uint64_t lo, hi;
+    block_slice(b.n, lo, hi);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t f = b.flag[i];
         if (f & 0x500u) { // duplicate | secondary  gc_content.rs:41-45
             c[4] += 1;
@@ -272,18 +282,39 @@ __global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b) {
             c[5] += 1;
             continue;
         }
-        const uint32_t off = ngsq_gc_offset_fn(st.gc_seed, b.first_record_index + i, l);
-        const uint8_t *s = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
-        uint32_t gc = 0, at = 0, other = 0;
-        const uint32_t first = off, last = off + NGSQ_GC_WINDOW - 1; // inclusive base indices
-        for (uint32_t j = first >> 1; j <= (last >> 1); j++) {
-            const uint32_t byte = s[j];
-            if (2 * j >= first) gc_classify(byte >> 4, gc, at, other);
-            if (2 * j + 1 >= first && 2 * j + 1 <= last) gc_classify(byte & 0xFu, gc, at, other);
+        const uint32_t off = ngsq_gc_offset_fn(st.gc_seed, b.first_record_index + i, l); // :68-74
+        const uint64_t row = b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride;
+        const uint64_t p = row + (off >> 1);
+        const uint32_t odd = off & 1u;
+        uint32_t x[13];
+        if (p + 52 <= seq_bytes) {
+            uint4 v0, v1, v2;
+            __builtin_memcpy(&v0, b.seq + p, 16);
+            __builtin_memcpy(&v1, b.seq + p + 16, 16);
+            __builtin_memcpy(&v2, b.seq + p + 32, 16);
+            __builtin_memcpy(&x[12], b.seq + p + 48, 4);
+            x[0] = v0.x, x[1] = v0.y, x[2] = v0.z, x[3] = v0.w;
+            x[4] = v1.x, x[5] = v1.y, x[6] = v1.z, x[7] = v1.w;
+            x[8] = v2.x, x[9] = v2.y, x[10] = v2.z, x[11] = v2.w;
+        } else { // the last rows of the buffer: never read past its end
+#pragma unroll
+            for (uint32_t d = 0; d < 13; d++) {
+                uint32_t t = 0;
+                for (uint32_t k = 0; k < 4; k++)
+                    if (p + 4 * d + k < seq_bytes) t |= (uint32_t)b.seq[p + 4 * d + k] << (8 * k);
+                x[d] = t;
+            }
         }
+        uint32_t gc = 0, at = 0;
+        // byte j of the gathered run holds bases (high nibble, low nibble).  off odd: the run
+        // starts one nibble early (drop the high nibble of byte 0) and ends in the high nibble of byte 50.
+        gc_dword(x[0], odd ? (M & ~0x10u) : M, gc, at);
+#pragma unroll
+        for (uint32_t d = 1; d < 12; d++) gc_dword(x[d], M, gc, at);
+        gc_dword(x[12], odd ? 0x00101111u : 0x00001111u, gc, at);
         c[0] += gc;
         c[1] += at;
-        c[2] += other;
+        c[2] += NGSQ_GC_WINDOW - gc - at;
         c[3] += 1;
         atomicAdd(&s_hist[gc], 1u); // :91-96 round(gc/100*100) == gc
     }
@@ -352,152 +383,6 @@ __global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBat
     }
     const uint32_t idx[2] = {C_ERR + E_BAD_QUAL, C_ERR + E_READ_TOO_LONG};
     block_flush<2>(c, s_acc, st.counters, idx);
-}
-
-// ---------------------------------------------------------------------------
-// GC Content, fast path: dense fixed-stride packed rows read as one stream.
-// reference: gc_content.rs:38-100
-//
-// A block walks tiles of GCF_TILE records (tile start a multiple of 16 records,
-// so the tile's first byte is 16-byte aligned for any row pitch):
-//   phase 0  thread per record : flag / length filters, window offset -> LDS
-//   phase 1  thread per 16-byte chunk of the tile's byte stream (coalesced
-//            dwordx4): nibble-parallel classification of its 32 bases, masked
-//            to the 100-base window of the one or two records it spans;
-//            per-record G/C count accumulated in LDS
-//   phase 2  thread per record : histogram of the per-record G/C count
-// ---------------------------------------------------------------------------
-constexpr uint32_t GCF_TILE = 1024;
-constexpr uint32_t GCF_SKIP = 0xFFFFFFFFu;
-
-// bit 4e of the result is set iff base e (0..7, stream order) of the dword is G/C (resp. A/T)
-__device__ __forceinline__ void gcf_classify(uint32_t x, uint32_t &gc, uint32_t &at) {
-    // put base order = nibble order: the first base of a byte is its HIGH nibble
-    const uint32_t sw = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
-    const uint32_t M = 0x11111111u;
-    const uint32_t b0 = sw & M, b1 = (sw >> 1) & M, b2 = (sw >> 2) & M, b3 = (sw >> 3) & M;
-    gc = (b1 ^ b2) & ~(b0 | b3); // 0010 (C) or 0100 (G)
-    at = (b0 ^ b3) & ~(b1 | b2); // 0001 (A) or 1000 (T)
-}
-
-__device__ __forceinline__ uint32_t gcf_prefix(int n) { // nibble-LSB mask of the first n bases of a dword
-    return n <= 0 ? 0u : (n >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * n)) - 1u)));
-}
-
-// G/C and A/T counts of chunk nibbles [a, b) (0 <= a <= b <= 32)
-__device__ __forceinline__ void gcf_count(const uint32_t (&gcb)[4], const uint32_t (&atb)[4], int a, int b,
-                                          uint32_t &gc, uint32_t &at) {
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const uint32_t m = gcf_prefix(b - 8 * d) & ~gcf_prefix(a - 8 * d);
-        gc += __popc(gcb[d] & m);
-        at += __popc(atb[d] & m);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_gc_fixed(DeviceState st, DeviceBatch b, uint32_t sb, uint32_t magic) {
-    __shared__ uint32_t s_hist[NGSQ_GC_BINS];
-    __shared__ u64 s_acc[6];
-    __shared__ uint32_t s_off[GCF_TILE];
-    __shared__ uint32_t s_cnt[GCF_TILE];
-    if (threadIdx.x < NGSQ_GC_BINS) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x < 6) s_acc[threadIdx.x] = 0;
-    uint32_t c[6] = {0, 0, 0, 0, 0, 0}; // gc, at, other, processed, ign_flags, ign_short
-    const uint64_t n_tiles = (b.n + GCF_TILE - 1) / GCF_TILE;
-    const uint64_t total_bytes = b.n * (uint64_t)sb;
-
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t t0 = tile * GCF_TILE;
-        const uint32_t nrec = (uint32_t)min((uint64_t)GCF_TILE, b.n - t0);
-        __syncthreads(); // previous tile's phase 2 has read s_off / s_cnt
-        // ---- phase 0
-        for (uint32_t r = threadIdx.x; r < nrec; r += blockDim.x) {
-            const uint32_t f = b.flag[t0 + r];
-            const uint32_t l = b.l_seq[t0 + r];
-            uint32_t off = GCF_SKIP;
-            if (f & 0x500u) {
-                c[4] += 1; // duplicate | secondary  gc_content.rs:41-45
-            } else if (l < NGSQ_GC_WINDOW) {
-                c[5] += 1; // :59-62
-            } else {
-                off = ngsq_gc_offset_fn(st.gc_seed, b.first_record_index + t0 + r, l);
-            }
-            s_off[r] = off;
-            s_cnt[r] = 0;
-        }
-        __syncthreads();
-        // ---- phase 1
-        const uint32_t tile_bytes = nrec * sb;
-        const uint32_t n_chunks = (tile_bytes + 15) / 16;
-        const uint64_t base = t0 * (uint64_t)sb;
-        for (uint32_t g = threadIdx.x; g < n_chunks; g += blockDim.x) {
-            const uint32_t B = g * 16;
-            uint4 w;
-            if (base + B + 16 <= total_bytes) {
-                w = *reinterpret_cast<const uint4 *>(b.seq + base + B);
-            } else {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (uint64_t j = base + B; j < total_bytes; j++) {
-                    const uint32_t k = (uint32_t)(j - base - B);
-                    t[k >> 2] |= (uint32_t)b.seq[j] << (8 * (k & 3));
-                }
-                w = make_uint4(t[0], t[1], t[2], t[3]);
-            }
-            uint32_t gcb[4], atb[4];
-            gcf_classify(w.x, gcb[0], atb[0]);
-            gcf_classify(w.y, gcb[1], atb[1]);
-            gcf_classify(w.z, gcb[2], atb[2]);
-            gcf_classify(w.w, gcb[3], atb[3]);
-            const uint32_t rec = __umulhi(B, magic);       // B / sb (exact for B < 2^19, sb < 2^9)
-            const uint32_t r0 = B - rec * sb;              // first byte of the chunk inside its row
-            const int e0 = (int)min(16u, sb - r0);         // chunk bytes that belong to `rec`
-            // part A: record `rec`, row bases [2*r0, 2*(r0+e0))
-            {
-                const uint32_t off = s_off[rec];
-                if (off != GCF_SKIP) {
-                    const int lo_b = max((int)off, (int)(2 * r0)), hi_b = min((int)off + 100, (int)(2 * (r0 + e0)));
-                    if (hi_b > lo_b) {
-                        uint32_t gc = 0, at = 0;
-                        gcf_count(gcb, atb, lo_b - 2 * (int)r0, hi_b - 2 * (int)r0, gc, at);
-                        c[0] += gc;
-                        c[1] += at;
-                        c[2] += (uint32_t)(hi_b - lo_b) - gc - at;
-                        if (gc) atomicAdd(&s_cnt[rec], gc);
-                    }
-                }
-            }
-            // part B: record rec+1 (same tile), row bases [0, 2*(16-e0))
-            if (e0 < 16 && rec + 1 < nrec) {
-                const uint32_t off = s_off[rec + 1];
-                if (off != GCF_SKIP) {
-                    const int lo_b = (int)off, hi_b = min((int)off + 100, 2 * (16 - e0));
-                    if (hi_b > lo_b) {
-                        uint32_t gc = 0, at = 0;
-                        gcf_count(gcb, atb, lo_b + 2 * e0, hi_b + 2 * e0, gc, at);
-                        c[0] += gc;
-                        c[1] += at;
-                        c[2] += (uint32_t)(hi_b - lo_b) - gc - at;
-                        if (gc) atomicAdd(&s_cnt[rec + 1], gc);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- phase 2
-        for (uint32_t r = threadIdx.x; r < nrec; r += blockDim.x) {
-            if (s_off[r] != GCF_SKIP) {
-                atomicAdd(&s_hist[s_cnt[r]], 1u); // :91-96 round(gc/100*100) == gc
-                c[3] += 1;
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < NGSQ_GC_BINS) {
-        const uint32_t v = s_hist[threadIdx.x];
-        if (v) atomicAdd(&st.counters[OFF_GC_HIST + threadIdx.x], (u64)v);
-    }
-    const uint32_t idx[6] = {C_GC_GC, C_GC_AT, C_GC_OTHER, C_GC_PROCESSED, C_GC_IGN_FLAGS, C_GC_IGN_SHORT};
-    block_flush<6>(c, s_acc, st.counters, idx);
 }
 
 // ---------------------------------------------------------------------------
@@ -809,18 +694,11 @@ hipError_t launch_cigar_cov(const LaunchInfo &li, const DeviceState &st, const D
     return hipGetLastError();
 }
 
-hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint64_t seq_bytes,
+                     hipStream_t s) {
     if (!b.n) return hipSuccess;
-    // fast path: dense fixed-pitch rows, 16-byte aligned stream, pitch in [16, 512)
-    if (!b.seq_off && b.seq_stride >= 16 && b.seq_stride < 512 && ((uintptr_t)b.seq & 15) == 0) {
-        const uint32_t sb = b.seq_stride;
-        const uint32_t magic = (uint32_t)(((1ull << 32) + sb - 1) / sb);
-        const uint32_t grid = grid_for((b.n + GCF_TILE - 1) / GCF_TILE, 1, li.n_cu * 8);
-        hipLaunchKernelGGL(k_gc_fixed, dim3(grid), dim3(256), 0, s, st, b, sb, magic);
-        return hipGetLastError();
-    }
-    const uint32_t grid = grid_for(b.n, 256 * 2, li.n_cu * 8);
-    hipLaunchKernelGGL(k_gc, dim3(grid), dim3(256), 0, s, st, b);
+    const uint32_t grid = grid_for(b.n, 256 * 4, li.n_cu * 8);
+    hipLaunchKernelGGL(k_gc, dim3(grid), dim3(256), 0, s, st, b, seq_bytes);
     return hipGetLastError();
 }
 
