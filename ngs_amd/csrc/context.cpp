@@ -42,8 +42,7 @@ static int fail(ngsq_ctx *c, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-static const char *const KERNEL_NAMES[K_COUNT] = {"flags_tlen", "cigar_cov", "gc",       "qual",
-                                                  "edits",      "cov_scan",  "edits_vaf", "h2d"};
+static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits", "cov_scan", "edits_vaf", "h2d"};
 
 extern "C" {
 
@@ -312,6 +311,12 @@ static int check_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t facets) {
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "bad batch location %u", b->location);
     if (!b->n_records) return NGSQ_OK;
     if (!b->flag) return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "flag column is null");
+    if (b->location == NGSQ_MEM_DEVICE) {
+        const void *cols[] = {b->flag, b->mapq, b->ref_id, b->pos, b->mate_ref_id, b->tlen, b->l_seq, b->n_cigar, b->cigar};
+        for (const void *p : cols)
+            if (((uintptr_t)p & 15) != 0)
+                return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "device batch columns must be 16-byte aligned");
+    }
     if ((facets & NGSQ_FACET_GENERAL) && (!b->mapq || !b->ref_id || !b->mate_ref_id || !b->n_cigar))
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "General needs mapq, ref_id, mate_ref_id, n_cigar");
     if ((facets & NGSQ_FACET_TEMPLATE_LENGTH) && !b->tlen)
@@ -367,14 +372,10 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
     const uint64_t n = db.n;
     const uint32_t rec_f = (pass_mask & NGSQ_PASS_RECORD) ? (facets & NGSQ_FACETS_RECORD_BASED) : 0;
     const uint32_t seq_f = (pass_mask & NGSQ_PASS_SEQUENCE) ? (facets & NGSQ_FACETS_SEQUENCE_BASED) : 0;
-    if (rec_f & (NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH)) {
-        Bracket br(c, K_FLAGS_TLEN, n * 15);
-        HIP_TRY(c, launch_flags_tlen(c->li, c->st, db, rec_f, c->stream));
-    }
-    if ((rec_f & NGSQ_FACET_GENERAL) || (seq_f & NGSQ_FACET_COVERAGE)) {
-        Bracket br(c, K_CIGAR_COV, n * 12 + cs.cigar_ops * 4);
-        HIP_TRY(c, launch_cigar_cov(c->li, c->st, db,
-                                    (rec_f & NGSQ_FACET_GENERAL) | (seq_f & NGSQ_FACET_COVERAGE), c->stream));
+    if ((rec_f & (NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH)) || (seq_f & NGSQ_FACET_COVERAGE)) {
+        const bool walk = (rec_f & NGSQ_FACET_GENERAL) || (seq_f & NGSQ_FACET_COVERAGE);
+        Bracket br(c, K_FIELDS, n * 25 + (walk ? cs.cigar_ops * 4 : 0));
+        HIP_TRY(c, launch_fields(c->li, c->st, db, rec_f, (seq_f & NGSQ_FACET_COVERAGE) != 0, c->stream));
     }
     if (rec_f & NGSQ_FACET_GC_CONTENT) {
         Bracket br(c, K_GC, n * 6 + cs.seq_bytes);

@@ -11,7 +11,7 @@
 
 namespace ngsq {
 
-enum KernelId { K_FLAGS_TLEN = 0, K_CIGAR_COV, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_COUNT };
+enum KernelId { K_FIELDS = 0, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_COUNT };
 
 struct PendingTime {
     int id;

@@ -1,0 +1,391 @@
+// fields_kernel.hip -- one pass over the fixed-width record columns and the CIGARs:
+//   General flag tallies        general.rs:31-100
+//   General CIGAR-op tallies    general.rs:103-121
+//   Template Length             template_length.rs:79-87
+//   Coverage range-add          coverage.rs:148-180 behind noodles' query() filter
+// Reads every fixed-width column exactly once (25 B/record) plus 4 B per CIGAR op.
+//
+// Layout of the work: a block walks TILES of 1024 consecutive records; thread t
+// owns records 4t..4t+3 of the tile, so each column is fetched with one vector
+// load per thread (8 or 16 bytes) and a wave covers 256 consecutive records.
+//
+// Coverage is accumulated as a DIFFERENCE array (+1 at alignment_start, -1 at
+// alignment_end+1, uint32 wrap-around; prefix-summed at teardown).  In a
+// coordinate-sorted file the 1024 records of a tile start inside a few thousand
+// positions, so the block keeps an LDS WINDOW of the reference axis anchored at
+// the tile's first record: both updates of a record are LDS atomics, and the
+// touched part of the window is then flushed with coalesced global atomics
+// (one wave instruction = 256 contiguous bytes).  Records that do not fit the
+// window (unsorted input, other sequence, long skips) fall back to direct
+// global atomics -- always correct, just slower.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace ngsq {
+
+typedef unsigned long long u64;
+
+constexpr uint32_t FT_THREADS = 256;
+constexpr uint32_t FT_PER_THREAD = 4;
+constexpr uint32_t FT_TILE = FT_THREADS * FT_PER_THREAD; // records per tile
+constexpr uint32_t FT_WINDOW = 4096;                     // positions in one LDS window (two are kept)
+constexpr uint32_t FT_NSLOT = 16 + 3 + 18 + 1;           // block tallies: see slot_counter()
+
+__device__ __forceinline__ uint32_t ft_wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+struct FieldsArgs {
+    uint32_t do_general, do_tlen, do_cov;
+};
+
+// the raw columns of the four records of one thread
+struct FtRaw {
+    uint2 flag, ncig;
+    uint32_t mapq;
+    int4 ref, mate, tlen, pos;
+    uint4 cig;
+};
+
+// number of lanes of the wave for which `c` holds: a wave-uniform value (SALU)
+__device__ __forceinline__ uint32_t ft_count(bool c) { return (uint32_t)__popcll(__ballot(c)); }
+
+__device__ __forceinline__ uint32_t slot_counter(uint32_t slot) {
+    return slot < 16    ? C_GENERAL + slot
+           : slot == 16 ? C_ERR + E_MISSING_REF
+           : slot == 17 ? C_TLEN_PROCESSED
+           : slot == 18 ? C_TLEN_IGNORED
+           : slot < 28  ? C_CIGAR1 + (slot - 19)
+           : slot < 37  ? C_CIGAR2 + (slot - 28)
+                        : C_ERR + E_BAD_CIGAR;
+}
+
+__global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, DeviceBatch b, FieldsArgs a) {
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t *const s_tlen = s_dyn;                                 // tlen_cap + 1
+    uint32_t *const s_win = s_dyn + ((st.tlen_cap + 1 + 3) & ~3u);  // 2 x FT_WINDOW
+    __shared__ u64 s_acc[FT_NSLOT];
+    __shared__ uint32_t s_max[2]; // highest window index touched, per window buffer
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t i = tid; i <= st.tlen_cap; i += FT_THREADS) s_tlen[i] = 0;
+    if (a.do_cov)
+        for (uint32_t i = tid; i < 2 * FT_WINDOW; i += FT_THREADS) s_win[i] = 0;
+    if (tid < FT_NSLOT) s_acc[tid] = 0;
+    if (tid < 2) s_max[tid] = 0;
+    __syncthreads();
+
+    // wave-uniform tallies (ballot + popcount): 16 RecordMetrics, missing ref, tlen processed/ignored
+    uint32_t g[19];
+#pragma unroll
+    for (int k = 0; k < 19; k++) g[k] = 0;
+    uint32_t one[9], two[9]; // per-lane CIGAR-op tallies
+#pragma unroll
+    for (int k = 0; k < 9; k++) one[k] = two[k] = 0;
+    uint32_t bad_op = 0;
+    u64 nonsensical = 0;
+    int32_t seen_ref = -1; // run-length tally of records Coverage processed, per sequence
+    uint32_t seen_cnt = 0;
+
+    const uint64_t n_tiles = (b.n + FT_TILE - 1) / FT_TILE;
+    const bool cigar_vec = b.cigar_off == nullptr && b.cigar_stride == 1;
+
+    auto load_tile = [&](uint64_t tile) -> FtRaw {
+        // full tiles only: every column with one aligned vector load per thread
+        const uint64_t r0 = tile * FT_TILE + (uint64_t)tid * FT_PER_THREAD;
+        FtRaw r;
+        r.flag = *reinterpret_cast<const uint2 *>(b.flag + r0);
+        r.ncig = make_uint2(0, 0);
+        r.mapq = 0;
+        r.ref = r.mate = r.tlen = r.pos = make_int4(0, 0, 0, 0);
+        r.cig = make_uint4(0, 0, 0, 0);
+        if (a.do_general || a.do_cov) {
+            r.ref = *reinterpret_cast<const int4 *>(b.ref_id + r0);
+            r.ncig = *reinterpret_cast<const uint2 *>(b.n_cigar + r0);
+            if (cigar_vec) r.cig = *reinterpret_cast<const uint4 *>(b.cigar + r0);
+        }
+        if (a.do_general) {
+            r.mapq = *reinterpret_cast<const uint32_t *>(b.mapq + r0);
+            r.mate = *reinterpret_cast<const int4 *>(b.mate_ref_id + r0);
+        }
+        if (a.do_tlen) r.tlen = *reinterpret_cast<const int4 *>(b.tlen + r0);
+        if (a.do_cov) r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
+        return r;
+    };
+    auto load_tail = [&](uint64_t tile, uint32_t &nrec) -> FtRaw {
+        // the last, partial tile: scalar loads, absent records read as zeros
+        const uint64_t r0 = tile * FT_TILE + (uint64_t)tid * FT_PER_THREAD;
+        uint32_t flag[4] = {0, 0, 0, 0}, ncig[4] = {0, 0, 0, 0}, mapq[4] = {0, 0, 0, 0}, cig[4] = {0, 0, 0, 0};
+        int32_t ref[4] = {0, 0, 0, 0}, mate[4] = {0, 0, 0, 0}, tlen[4] = {0, 0, 0, 0}, pos[4] = {0, 0, 0, 0};
+        nrec = 0;
+        for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
+            if (r0 + j >= b.n) break;
+            nrec = j + 1;
+            flag[j] = b.flag[r0 + j];
+            if (a.do_general || a.do_cov) {
+                ref[j] = b.ref_id[r0 + j];
+                ncig[j] = b.n_cigar[r0 + j];
+                if (cigar_vec) cig[j] = b.cigar[r0 + j];
+            }
+            if (a.do_general) {
+                mapq[j] = b.mapq[r0 + j];
+                mate[j] = b.mate_ref_id[r0 + j];
+            }
+            if (a.do_tlen) tlen[j] = b.tlen[r0 + j];
+            if (a.do_cov) pos[j] = b.pos[r0 + j];
+        }
+        FtRaw r;
+        r.flag = make_uint2(flag[0] | (flag[1] << 16), flag[2] | (flag[3] << 16));
+        r.ncig = make_uint2(ncig[0] | (ncig[1] << 16), ncig[2] | (ncig[3] << 16));
+        r.mapq = mapq[0] | (mapq[1] << 8) | (mapq[2] << 16) | (mapq[3] << 24);
+        r.ref = make_int4(ref[0], ref[1], ref[2], ref[3]);
+        r.mate = make_int4(mate[0], mate[1], mate[2], mate[3]);
+        r.tlen = make_int4(tlen[0], tlen[1], tlen[2], tlen[3]);
+        r.pos = make_int4(pos[0], pos[1], pos[2], pos[3]);
+        r.cig = make_uint4(cig[0], cig[1], cig[2], cig[3]);
+        return r;
+    };
+
+    uint32_t it = 0; // tile counter of this block: selects the window buffer
+    auto process = [&](const FtRaw &raw, uint64_t tile, uint32_t nrec) {
+        const uint64_t t0 = tile * FT_TILE;
+        const uint64_t r0 = t0 + (uint64_t)tid * FT_PER_THREAD;
+        const uint32_t flag[4] = {raw.flag.x & 0xFFFFu, raw.flag.x >> 16, raw.flag.y & 0xFFFFu, raw.flag.y >> 16};
+        const uint32_t ncig[4] = {raw.ncig.x & 0xFFFFu, raw.ncig.x >> 16, raw.ncig.y & 0xFFFFu, raw.ncig.y >> 16};
+        const int32_t ref[4] = {raw.ref.x, raw.ref.y, raw.ref.z, raw.ref.w};
+        const int32_t mate[4] = {raw.mate.x, raw.mate.y, raw.mate.z, raw.mate.w};
+        const int32_t tlen[4] = {raw.tlen.x, raw.tlen.y, raw.tlen.z, raw.tlen.w};
+        const int32_t pos[4] = {raw.pos.x, raw.pos.y, raw.pos.z, raw.pos.w};
+        const uint32_t cig1[4] = {raw.cig.x, raw.cig.y, raw.cig.z, raw.cig.w};
+
+        // ---- coverage window of this tile: anchored at the tile's first record (block-uniform
+        // loads; no LDS round trip).  Not placed / not covered => no window for this tile.
+        uint32_t *const win = s_win + (it & 1u) * FT_WINDOW;
+        int32_t win_ref = -1;
+        uint32_t win_base = 0;
+        uint64_t win_off = NO_DEPTH, win_L = 0;
+        if (a.do_cov) {
+            const int32_t fr = b.ref_id[t0], fp = b.pos[t0];
+            if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
+                win_off = st.ref_depth_off[fr];
+                win_L = st.ref_len[fr];
+                if (win_off != NO_DEPTH) {
+                    win_ref = fr;
+                    win_base = (uint32_t)fp & ~3u; // <= alignment_start of that record
+                }
+            }
+        }
+        uint32_t my_max = 0;
+
+#pragma unroll
+        for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
+            const bool live = j < nrec;
+            const uint32_t f = flag[j];
+            if (a.do_general) {
+                // general.rs:31-100 as mask tests; every tally is a ballot popcount (SALU)
+                const bool prim = live && !(f & 0x900u);             // neither secondary nor supplementary
+                const bool pair = prim && (f & 0x1u);                // :60
+                const bool pmap = pair && !(f & 0x4u);               // :71
+                const bool mm = pmap && !(f & 0x8u);                 // :79 mate mapped
+                const bool noid = mm && (ref[j] < 0 || mate[j] < 0); // :81-83 unwrap() on None
+                const bool mis = mm && !noid && ref[j] != mate[j];   // :85-86
+                const uint32_t mq = (raw.mapq >> (8 * j)) & 0xFFu;
+                g[0] += ft_count(live);                        // total :33
+                g[1] += ft_count(live && (f & 0x4u));          // unmapped :37-39
+                g[2] += ft_count(live && (f & 0x400u));        // duplicate :41-43
+                g[3] += ft_count(prim);                        // :50
+                g[4] += ft_count(live && (f & 0x100u));        // secondary :45-46
+                g[5] += ft_count(live && (f & 0x900u) == 0x800u); // supplementary :47-48
+                g[6] += ft_count(prim && !(f & 0x4u));         // primary_mapped :52-54
+                g[7] += ft_count(prim && (f & 0x400u));        // primary_duplicate :56-58
+                g[8] += ft_count(pair);                        // paired
+                g[9] += ft_count(pair && (f & 0x40u));         // read_1 :63-65
+                g[10] += ft_count(pair && (f & 0x80u));        // read_2 :67-69
+                g[11] += ft_count(pmap && (f & 0x2u));         // proper_pair :72-74
+                g[12] += ft_count(pmap && (f & 0x8u));         // singleton :76-77
+                g[13] += ft_count(mm);                         // mate_mapped
+                g[14] += ft_count(mis);                        // mismatch
+                g[15] += ft_count(mis && mq >= 5u);            // :88-95 (255 = missing counts as HQ)
+                g[16] += ft_count(noid);
+            }
+            if (a.do_tlen) {
+                // template_length.rs:80  `as usize`: negatives wrap above any capacity
+                const int32_t t = tlen[j];
+                const bool inr = live && t >= 0 && (uint32_t)t <= st.tlen_cap;
+                if (inr) atomicAdd(&s_tlen[t], 1u);
+                g[17] += ft_count(inr);
+                g[18] += ft_count(live && !inr);
+            }
+            if ((a.do_general || a.do_cov) && live) {
+                // ---- CIGAR walk: op tallies (general.rs:103-121) and the alignment span
+                const uint32_t n_ops = ncig[j];
+                const uint32_t r1 = (f >> 6) & 1u; // first segment -> "read one"
+                uint64_t span = 0;
+                const uint64_t cbase = b.cigar_off ? b.cigar_off[r0 + j] : (r0 + j) * (uint64_t)b.cigar_stride;
+                for (uint32_t k = 0; k < n_ops; k++) {
+                    const uint32_t cg = (cigar_vec && k == 0) ? cig1[j] : b.cigar[cbase + k];
+                    const uint32_t op = cg & 0xFu, len = cg >> 4;
+                    if (op > 8u) {
+                        bad_op += 1;
+                        continue;
+                    }
+                    if ((0x18Du >> op) & 1u) span += len; // utils/cigar.rs:6-11  M D N = X
+                    if (a.do_general) {
+                        const uint32_t o1 = r1 ? op : 15u, o2 = r1 ? 15u : op;
+#pragma unroll
+                        for (int q = 0; q < 9; q++) {
+                            one[q] += (o1 == (uint32_t)q);
+                            two[q] += (o2 == (uint32_t)q);
+                        }
+                    }
+                }
+                if (a.do_cov) {
+                    const int32_t rf = ref[j];
+                    const int32_t ps = pos[j];
+                    if (rf >= 0 && (uint32_t)rf < st.n_refs && ps >= 0) {
+                        uint64_t off = win_off, L = win_L;
+                        if (rf != win_ref) {
+                            off = st.ref_depth_off[rf];
+                            L = st.ref_len[rf];
+                        }
+                        const uint64_t s = (uint64_t)ps + 1, e = s + span - 1;
+                        // noodles query(): alignment_end must be Some (>= 1) and [s,e] must meet [1,L]
+                        if (off != NO_DEPTH && e != 0 && s <= L) {
+                            if (rf != seen_ref) {
+                                if (seen_cnt) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+                                seen_ref = rf;
+                                seen_cnt = 0;
+                            }
+                            seen_cnt += 1;
+                            const uint64_t ec = e < L ? e : L;
+                            nonsensical += e - ec; // coverage.rs:163-176: one per position > L
+                            if (s <= ec) {
+                                const uint64_t i0 = s - win_base, i1 = ec + 1 - win_base;
+                                if (rf == win_ref && s >= win_base && i1 < FT_WINDOW) {
+                                    atomicAdd(&win[i0], 1u);
+                                    atomicAdd(&win[i1], 0xFFFFFFFFu);
+                                    my_max = max(my_max, (uint32_t)i1);
+                                } else {
+                                    atomicAdd(&st.depth[off + s], 1u);
+                                    atomicAdd(&st.depth[off + ec + 1], 0xFFFFFFFFu);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        if (a.do_cov) {
+            // ---- one barrier per tile: publish the window, then flush its touched part with
+            // coalesced global atomics while the next tile fills the other buffer
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_down(my_max, o, 64));
+            if (lane == 0 && my_max) atomicMax(&s_max[it & 1u], my_max);
+            __syncthreads();
+            const uint32_t top = s_max[it & 1u];
+            if (win_ref >= 0 && top) {
+                uint32_t *dst = st.depth + win_off + win_base;
+                for (uint32_t i = tid; i <= top; i += FT_THREADS) {
+                    const uint32_t v = win[i];
+                    if (v) {
+                        atomicAdd(&dst[i], v);
+                        win[i] = 0;
+                    }
+                }
+            }
+            // s_max[it&1] is next written two tiles from now, after the next barrier
+            if (tid == 0) s_max[(it + 1) & 1u] = 0;
+        }
+        it += 1;
+    };
+
+    const uint64_t n_full = b.n / FT_TILE; // tiles with all 1024 records
+    uint64_t tile = blockIdx.x;
+    if (tile < n_full) {
+        FtRaw cur = load_tile(tile);
+        while (tile < n_full) {
+            const uint64_t nt = tile + gridDim.x;
+            // branch-free prefetch of this block's next full tile (past the end: re-read this one)
+            const FtRaw nxt = load_tile(nt < n_full ? nt : tile);
+            process(cur, tile, FT_PER_THREAD);
+            cur = nxt;
+            tile = nt;
+        }
+    }
+    if (tile == n_full && n_full < n_tiles) { // the partial tile belongs to exactly one block
+        uint32_t nrec = 0;
+        const FtRaw tail = load_tail(tile, nrec);
+        process(tail, tile, nrec);
+    }
+
+    // ---- block epilogue
+    { // `seen`: one atomic per wave when the wave saw a single sequence
+        const u64 act = __ballot(seen_cnt != 0);
+        if (act) {
+            const int leader = __ffsll((long long)act) - 1;
+            const int32_t rr = __shfl(seen_ref, leader, 64);
+            const bool same = seen_cnt != 0 && seen_ref == rr;
+            const uint32_t sum = ft_wave_sum(same ? seen_cnt : 0u);
+            if (lane == 0) atomicAdd(&st.counters[st.off_seen + rr], (u64)sum);
+            if (seen_cnt != 0 && !same) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+        }
+    }
+    {
+        u64 ns = nonsensical;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ns += __shfl_down(ns, o, 64);
+        if (lane == 0 && ns) atomicAdd(&st.counters[C_COV_NONSENSICAL], ns);
+    }
+    // wave-uniform tallies: lane 0 of each wave holds the wave's total already
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 19; k++)
+            if (g[k]) atomicAdd(&s_acc[k], (u64)g[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const uint32_t r1 = ft_wave_sum(one[k]), r2 = ft_wave_sum(two[k]);
+        if (lane == 0 && r1) atomicAdd(&s_acc[19 + k], (u64)r1);
+        if (lane == 0 && r2) atomicAdd(&s_acc[28 + k], (u64)r2);
+    }
+    {
+        const uint32_t r = ft_wave_sum(bad_op);
+        if (lane == 0 && r) atomicAdd(&s_acc[37], (u64)r);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i <= st.tlen_cap; i += FT_THREADS) {
+        const uint32_t v = s_tlen[i];
+        if (v) atomicAdd(&st.counters[st.off_tlen + i], (u64)v);
+    }
+    if (tid < FT_NSLOT) {
+        const u64 r = s_acc[tid];
+        if (r) atomicAdd(&st.counters[slot_counter(tid)], r);
+    }
+}
+
+hipError_t launch_fields(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint32_t rec_facets,
+                         bool coverage, hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    FieldsArgs a;
+    a.do_general = (rec_facets & NGSQ_FACET_GENERAL) ? 1 : 0;
+    a.do_tlen = (rec_facets & NGSQ_FACET_TEMPLATE_LENGTH) ? 1 : 0;
+    a.do_cov = coverage ? 1 : 0;
+    const size_t lds = (((size_t)st.tlen_cap + 1 + 3) & ~(size_t)3) * 4 + (coverage ? 2 * FT_WINDOW * 4 : 0);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fields),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    uint64_t g = (b.n + FT_TILE - 1) / FT_TILE;
+    const uint64_t cap = (uint64_t)li.n_cu * 4;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(k_fields, dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
+    return hipGetLastError();
+}
+
+} // namespace ngsq

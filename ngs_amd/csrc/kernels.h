@@ -97,12 +97,10 @@ struct LaunchInfo {
     int n_cu; // compute units of the device
 };
 
-// General flag tallies + Template Length (general.rs:31-100, template_length.rs:79-87)
-hipError_t launch_flags_tlen(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
-                             uint32_t facets, hipStream_t s);
-// General CIGAR-op tallies (general.rs:103-121) + Coverage range-add (coverage.rs:148-180)
-hipError_t launch_cigar_cov(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
-                            uint32_t facets, hipStream_t s);
+// General flag + CIGAR-op tallies (general.rs:31-121), Template Length
+// (template_length.rs:79-87) and Coverage range-add (coverage.rs:148-180): fields_kernel.hip
+hipError_t launch_fields(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                         uint32_t rec_facets, bool coverage, hipStream_t s);
 // GC Content (gc_content.rs:38-100)
 hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                      uint64_t seq_bytes, hipStream_t s);

@@ -55,191 +55,6 @@ __device__ __forceinline__ void block_slice(uint64_t n, uint64_t &lo, uint64_t &
 }
 
 // ---------------------------------------------------------------------------
-// General flag tallies + Template Length
-// reference: general.rs:31-100, template_length.rs:79-87
-// reads 15 B/record: flag 2, mapq 1, ref_id 4, mate_ref_id 4, tlen 4
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flags_tlen(DeviceState st, DeviceBatch b, uint32_t facets) {
-    extern __shared__ uint32_t s_tlen[]; // tlen_cap + 1 bins
-    __shared__ u64 s_acc[19];
-    const uint32_t nb = st.tlen_cap + 1;
-    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_tlen[i] = 0;
-    if (threadIdx.x < 19) s_acc[threadIdx.x] = 0;
-    __syncthreads();
-
-    const bool do_general = facets & NGSQ_FACET_GENERAL;
-    const bool do_tlen = facets & NGSQ_FACET_TEMPLATE_LENGTH;
-    uint32_t c[19];
-#pragma unroll
-    for (int k = 0; k < 19; k++) c[k] = 0;
-
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
-        if (do_general) {
-            const uint32_t f = b.flag[i];
-            const uint32_t unmapped = (f >> 2) & 1u, dup = (f >> 10) & 1u;
-            c[0] += 1;       // total            general.rs:33
-            c[1] += unmapped; // :37-39
-            c[2] += dup;      // :41-43
-            if (f & 0x100u) { // :45-46
-                c[4] += 1;
-            } else if (f & 0x800u) { // :47-48
-                c[5] += 1;
-            } else {
-                c[3] += 1;             // primary :50
-                c[6] += unmapped ^ 1u; // primary_mapped :52-54
-                c[7] += dup;           // primary_duplicate :56-58
-                if (f & 0x1u) {        // :60
-                    c[8] += 1;
-                    c[9] += (f >> 6) & 1u;  // read_1 :63-65
-                    c[10] += (f >> 7) & 1u; // read_2 :67-69
-                    if (!unmapped) {        // :71
-                        c[11] += (f >> 1) & 1u; // proper_pair :72-74
-                        if (f & 0x8u) {
-                            c[12] += 1; // singleton :76-77
-                        } else {
-                            c[13] += 1; // mate_mapped :79
-                            const int32_t r = b.ref_id[i], m = b.mate_ref_id[i];
-                            if (r < 0 || m < 0) {
-                                c[16] += 1; // :81-83 unwrap() on None
-                            } else if (r != m) {
-                                c[14] += 1; // :85-86
-                                if (b.mapq[i] >= 5) c[15] += 1; // :88-95 (255 = missing counts)
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (do_tlen) {
-            // template_length.rs:80  `as usize`: negatives wrap above any capacity
-            const int32_t t = b.tlen[i];
-            if (t >= 0 && (uint32_t)t <= st.tlen_cap) {
-                atomicAdd(&s_tlen[t], 1u);
-                c[17] += 1; // processed
-            } else {
-                c[18] += 1; // ignored
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
-        uint32_t v = s_tlen[i];
-        if (v) atomicAdd(&st.counters[st.off_tlen + i], (u64)v);
-    }
-    const uint32_t idx[19] = {C_GENERAL + 0,  C_GENERAL + 1,  C_GENERAL + 2,  C_GENERAL + 3,
-                              C_GENERAL + 4,  C_GENERAL + 5,  C_GENERAL + 6,  C_GENERAL + 7,
-                              C_GENERAL + 8,  C_GENERAL + 9,  C_GENERAL + 10, C_GENERAL + 11,
-                              C_GENERAL + 12, C_GENERAL + 13, C_GENERAL + 14, C_GENERAL + 15,
-                              C_ERR + E_MISSING_REF, C_TLEN_PROCESSED, C_TLEN_IGNORED};
-    block_flush<19>(c, s_acc, st.counters, idx);
-}
-
-// ---------------------------------------------------------------------------
-// CIGAR walk: General op tallies + Coverage range-add
-// reference: general.rs:103-121, coverage.rs:148-180, noodles query()
-// reads per record: flag 2, n_cigar 2, ref_id 4, pos 4, cigar 4*ops
-//
-// Coverage is accumulated as a DIFFERENCE array: +1 at alignment_start, -1 at
-// alignment_end+1 (uint32 wrap-around arithmetic), prefix-summed at teardown.
-// Two atomics per record replace `span` bounds-checked increments.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cigar_cov(DeviceState st, DeviceBatch b, uint32_t facets) {
-    __shared__ u64 s_acc[20];
-    if (threadIdx.x < 20) s_acc[threadIdx.x] = 0;
-    __syncthreads();
-    const bool do_general = facets & NGSQ_FACET_GENERAL;
-    const bool do_cov = facets & NGSQ_FACET_COVERAGE;
-
-    uint32_t one[9], two[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) one[k] = two[k] = 0;
-    uint32_t bad_op = 0;
-    u64 nonsensical = 0;
-    int32_t seen_ref = -1; // run-length tally of `seen` per sequence
-    uint32_t seen_cnt = 0;
-
-    uint64_t lo, hi;
-    block_slice(b.n, lo, hi);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t n_ops = b.n_cigar[i];
-        const uint64_t base = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
-        const uint32_t r1 = do_general ? (((uint32_t)b.flag[i] >> 6) & 1u) : 0u; // 0x40
-        uint64_t span = 0;
-        for (uint32_t k = 0; k < n_ops; k++) {
-            const uint32_t cg = b.cigar[base + k];
-            const uint32_t op = cg & 0xFu, len = cg >> 4;
-            if (op > 8u) {
-                bad_op += 1;
-                continue;
-            }
-            // utils/cigar.rs:6-11  M D N = X consume the reference
-            if ((0x18Du >> op) & 1u) span += len;
-            if (do_general) {
-#pragma unroll
-                for (int q = 0; q < 9; q++) {
-                    const uint32_t hit = (op == (uint32_t)q);
-                    one[q] += hit & r1;
-                    two[q] += hit & (r1 ^ 1u);
-                }
-            }
-        }
-        if (do_cov) {
-            const int32_t ref = b.ref_id[i];
-            const int32_t pos = b.pos[i];
-            if (ref >= 0 && (uint32_t)ref < st.n_refs && pos >= 0) {
-                const uint64_t off = st.ref_depth_off[ref];
-                const uint64_t L = st.ref_len[ref];
-                const uint64_t s = (uint64_t)pos + 1, e = s + span - 1;
-                // noodles query(): end must be Some (>= 1) and [s,e] must meet [1,L]
-                if (off != NO_DEPTH && e != 0 && s <= L) {
-                    if (ref != seen_ref) {
-                        if (seen_cnt) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
-                        seen_ref = ref;
-                        seen_cnt = 0;
-                    }
-                    seen_cnt += 1;
-                    const uint64_t ec = e < L ? e : L;
-                    nonsensical += e - ec; // coverage.rs:163-176, one per position > L
-                    if (s <= ec) {
-                        atomicAdd(&st.depth[off + s], 1u);
-                        atomicAdd(&st.depth[off + ec + 1], 0xFFFFFFFFu);
-                    }
-                }
-            }
-        }
-    }
-    // flush the per-thread run: one atomic per wave when the wave saw one sequence
-    {
-        const int lane = threadIdx.x & 63;
-        const unsigned long long active = __ballot(seen_cnt != 0);
-        if (active) {
-            const int leader = __ffsll((long long)active) - 1;
-            const int32_t r0 = __shfl(seen_ref, leader, 64);
-            const bool same = seen_cnt != 0 && seen_ref == r0;
-            const uint32_t s = wave_sum(same ? seen_cnt : 0u);
-            if (lane == 0) atomicAdd(&st.counters[st.off_seen + r0], (u64)s);
-            if (seen_cnt != 0 && !same) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
-        }
-    }
-    u64 ns = wave_sum64(nonsensical);
-    if ((threadIdx.x & 63) == 0 && ns) atomicAdd(&st.counters[C_COV_NONSENSICAL], ns);
-
-    uint32_t v[19];
-    uint32_t idx[19];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        v[k] = one[k];
-        idx[k] = C_CIGAR1 + k;
-        v[9 + k] = two[k];
-        idx[9 + k] = C_CIGAR2 + k;
-    }
-    v[18] = bad_op;
-    idx[18] = C_ERR + E_BAD_CIGAR;
-    block_flush<19>(v, s_acc, st.counters, idx);
-}
-
-// ---------------------------------------------------------------------------
 // GC Content: one thread per record, gathering only the 100-base window.
 // reference: gc_content.rs:38-100
 //
@@ -675,23 +490,6 @@ static inline uint32_t grid_for(uint64_t n, uint32_t per_block, uint32_t max_blo
     if (g < 1) g = 1;
     if (g > max_blocks) g = max_blocks;
     return (uint32_t)g;
-}
-
-hipError_t launch_flags_tlen(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
-                             uint32_t facets, hipStream_t s) {
-    if (!b.n) return hipSuccess;
-    const uint32_t grid = grid_for(b.n, 256 * 4, li.n_cu * 8);
-    const size_t lds = (size_t)(st.tlen_cap + 1) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_flags_tlen, dim3(grid), dim3(256), lds, s, st, b, facets);
-    return hipGetLastError();
-}
-
-hipError_t launch_cigar_cov(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
-                            uint32_t facets, hipStream_t s) {
-    if (!b.n) return hipSuccess;
-    const uint32_t grid = grid_for(b.n, 256 * 4, li.n_cu * 8);
-    hipLaunchKernelGGL(k_cigar_cov, dim3(grid), dim3(256), 0, s, st, b, facets);
-    return hipGetLastError();
 }
 
 hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint64_t seq_bytes,
