@@ -154,15 +154,17 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
 
     // ---- per-sequence tables
     std::vector<uint64_t> depth_off(nr, NO_DEPTH), edits_off(nr, NO_DEPTH), bases_off(nr, NO_DEPTH);
+    std::vector<uint32_t> first_chunk(nr + 1, 0);
     uint64_t nd = 0, ne = 0, nbases = 0;
     c->bin_off.assign(nr + 1, 0);
     uint64_t max_len = 0;
     for (uint32_t r = 0; r < nr; r++) {
         const uint64_t L = c->ref_len[r];
         if (L > max_len) max_len = L;
+        first_chunk[r] = (uint32_t)(nd / COV_CHUNK);
         if ((c->cfg.facets & NGSQ_FACET_COVERAGE) && c->primary[r]) {
             depth_off[r] = nd;
-            nd += round_up(L + 2, 4);
+            nd += round_up(L + 2, COV_CHUNK); // chunks never straddle sequences
         }
         const uint64_t nb = 1 + L / c->cfg.bin_size + (L % c->cfg.bin_size != 0);
         c->bin_off[r + 1] = c->bin_off[r] + ((c->cfg.facets & NGSQ_FACET_COVERAGE) && c->primary[r] ? nb : 0);
@@ -173,8 +175,14 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
             nbases += round_up(L, 16);
         }
     }
+    first_chunk[nr] = (uint32_t)(nd / COV_CHUNK);
     c->depth_off = depth_off;
     c->edits_off = edits_off;
+    // depth block = difference arrays | one sum per chunk | one sum per COV_SUPER chunks
+    c->n_diff = nd;
+    c->n_chunks = nd / COV_CHUNK;
+    const uint64_t n_chunk_pad = round_up(c->n_chunks, 4), n_super_pad = round_up((c->n_chunks + COV_SUPER - 1) / COV_SUPER, 4);
+    if (nd) nd += n_chunk_pad + n_super_pad;
     c->n_depth = nd;
     c->n_edits = ne;
     if (nr) {
@@ -186,6 +194,10 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         CTX_TRY(hipMemcpy(c->d_edits_off, edits_off.data(), nr * 8, hipMemcpyHostToDevice));
         CTX_TRY(hipMalloc((void **)&c->d_bases_off, nr * 8));
         CTX_TRY(hipMemcpy(c->d_bases_off, bases_off.data(), nr * 8, hipMemcpyHostToDevice));
+        CTX_TRY(hipMalloc((void **)&c->d_first_chunk, (nr + 1) * 4));
+        CTX_TRY(hipMemcpy(c->d_first_chunk, first_chunk.data(), (nr + 1) * 4, hipMemcpyHostToDevice));
+        CTX_TRY(hipMalloc((void **)&c->d_bin_off, (nr + 1) * 8));
+        CTX_TRY(hipMemcpy(c->d_bin_off, c->bin_off.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
     }
     st.ref_len = c->d_ref_len;
     st.ref_depth_off = c->d_depth_off;
@@ -194,8 +206,9 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     if (nd) {
         CTX_TRY(hipMalloc((void **)&st.depth, nd * 4));
         CTX_TRY(hipMemsetAsync(st.depth, 0, nd * 4, c->stream));
-        const uint64_t chunks = (max_len + 2 + cov_scan_chunk_elems() - 1) / cov_scan_chunk_elems();
-        CTX_TRY(hipMalloc((void **)&c->d_chunk_sums, (chunks + 1) * 4));
+        st.chunk_sums = st.depth + c->n_diff;
+        st.super_sums = st.chunk_sums + n_chunk_pad;
+        (void)max_len;
         c->n_cov_hist = (uint64_t)nr * (c->cfg.cov_cap + 2);
         CTX_TRY(hipMalloc((void **)&c->d_cov_hist, c->n_cov_hist * 8));
         CTX_TRY(hipMemsetAsync(c->d_cov_hist, 0, c->n_cov_hist * 8, c->stream));
@@ -249,7 +262,8 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_depth_off);
     (void)hipFree(c->d_edits_off);
     (void)hipFree(c->d_bases_off);
-    (void)hipFree(c->d_chunk_sums);
+    (void)hipFree(c->d_first_chunk);
+    (void)hipFree(c->d_bin_off);
     (void)hipFree(c->d_cov_hist);
     (void)hipFree(c->d_bin_totals);
     (void)hipFree(c->d_vaf);
@@ -501,24 +515,25 @@ int ngsq_finalize(ngsq_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t facets = c->cfg.facets;
     const uint32_t nr = c->st.n_refs;
-    // which sequences have a coverage entry (coverage.rs:187-193)?
-    std::vector<unsigned long long> seen(nr ? nr : 1, 0);
-    if ((facets & NGSQ_FACET_COVERAGE) && nr) {
-        HIP_TRY(c, hipMemcpyAsync(seen.data(), c->st.counters + c->st.off_seen, nr * 8, hipMemcpyDeviceToHost,
-                                  c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (uint32_t r = 0; r < nr; r++) {
-            if (!seen[r] || c->depth_off[r] == NO_DEPTH) continue;
-            CovScanArgs a{};
-            a.diff = c->st.depth + c->depth_off[r];
-            a.ref_len = c->ref_len[r];
-            a.bin_size = c->cfg.bin_size;
-            a.cov_cap = c->cfg.cov_cap;
-            a.hist = c->d_cov_hist + (uint64_t)r * (c->cfg.cov_cap + 2);
-            a.bin_totals = c->d_bin_totals + c->bin_off[r];
-            a.chunk_sums = c->d_chunk_sums;
-            a.reset = 1;
-            Bracket br(c, K_COV_SCAN, ((uint64_t)a.ref_len + 2) * 8);
+    if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) {
+        // one launch tears down every sequence that has an entry (coverage.rs:187-193 skips the rest)
+        CovScanArgs a{};
+        a.depth = c->st.depth;
+        a.n_chunks = c->n_chunks;
+        a.chunk_sums = c->st.chunk_sums;
+        a.super_sums = c->st.super_sums;
+        a.ref_first_chunk = c->d_first_chunk;
+        a.ref_len = c->d_ref_len;
+        a.seen = c->st.counters + c->st.off_seen;
+        a.hist = c->d_cov_hist;
+        a.bin_totals = c->d_bin_totals;
+        a.bin_off = c->d_bin_off;
+        a.n_refs = nr;
+        a.bin_size = c->cfg.bin_size;
+        a.cov_cap = c->cfg.cov_cap;
+        a.reset = 1;
+        {
+            Bracket br(c, K_COV_SCAN, 0);
             HIP_TRY(c, launch_cov_scan(c->li, a, c->stream));
         }
         HIP_TRY(c, hipMemcpyAsync(c->h_cov_hist.data(), c->d_cov_hist, c->n_cov_hist * 8, hipMemcpyDeviceToHost,
@@ -541,6 +556,10 @@ int ngsq_finalize(ngsq_ctx *c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     resolve_timing(c);
     c->finalized = true;
+    if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) // algorithmic bytes of the scan: 8 B per torn-down position
+        for (uint32_t r = 0; r < nr; r++)
+            if (c->depth_off[r] != NO_DEPTH && c->h_counters[c->st.off_seen + r])
+                c->timing[K_COV_SCAN].algo_bytes += ((uint64_t)c->ref_len[r] + 2) * 8;
     const unsigned long long *err = c->h_counters.data() + C_ERR;
     for (int k = 0; k < 8; k++)
         if (err[k])
@@ -557,8 +576,12 @@ int ngsq_reset(ngsq_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->st.counters, 0, c->n_counters * 8, c->stream));
     if (c->n_depth) {
-        // a finalized context has already zeroed the difference arrays behind the scan
-        if (!c->finalized) HIP_TRY(c, hipMemsetAsync(c->st.depth, 0, c->n_depth * 4, c->stream));
+        // a finalized context has already zeroed the difference arrays behind the scan:
+        // only the chunk / super-chunk sums are left
+        if (!c->finalized)
+            HIP_TRY(c, hipMemsetAsync(c->st.depth, 0, c->n_depth * 4, c->stream));
+        else
+            HIP_TRY(c, hipMemsetAsync(c->st.chunk_sums, 0, (c->n_depth - c->n_diff) * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_cov_hist, 0, c->n_cov_hist * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_bin_totals, 0, (c->bin_off[c->st.n_refs] + 1) * 8, c->stream));
     }

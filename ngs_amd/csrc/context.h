@@ -41,7 +41,9 @@ struct ngsq_ctx {
     uint32_t *d_ref_len = nullptr;
     uint64_t *d_depth_off = nullptr, *d_edits_off = nullptr, *d_bases_off = nullptr;
     uint8_t *d_ref_bases = nullptr;
-    uint32_t *d_chunk_sums = nullptr;
+    uint32_t *d_first_chunk = nullptr;
+    uint64_t *d_bin_off = nullptr;
+    uint64_t n_diff = 0, n_chunks = 0; // difference-array entries / scan chunks of the depth block
     unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
     std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;
     bool finalized = false;

@@ -267,9 +267,12 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                                     atomicAdd(&win[i0], 1u);
                                     atomicAdd(&win[i1], 0xFFFFFFFFu);
                                     my_max = max(my_max, (uint32_t)i1);
-                                } else {
-                                    atomicAdd(&st.depth[off + s], 1u);
-                                    atomicAdd(&st.depth[off + ec + 1], 0xFFFFFFFFu);
+                                } else { // outside the window: straight to the arrays and their sums
+                                    const uint64_t g0 = off + s, g1 = off + ec + 1;
+                                    atomicAdd(&st.depth[g0], 1u);
+                                    atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
+                                    atomicAdd(&st.chunk_sums[g0 / COV_CHUNK], 1u);
+                                    atomicAdd(&st.chunk_sums[g1 / COV_CHUNK], 0xFFFFFFFFu);
                                 }
                             }
                         }
@@ -287,13 +290,25 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             __syncthreads();
             const uint32_t top = s_max[it & 1u];
             if (win_ref >= 0 && top) {
-                uint32_t *dst = st.depth + win_off + win_base;
+                const uint64_t goff = win_off + win_base; // element index of window entry 0
+                uint32_t *dst = st.depth + goff;
+                // running sum per scan chunk (cov_scan.hip): the window spans at most two chunks
+                const uint32_t c0 = (uint32_t)(goff / COV_CHUNK);
+                const uint32_t split = (uint32_t)((uint64_t)(c0 + 1) * COV_CHUNK - goff); // first entry of chunk c0+1
+                uint32_t sa = 0, sb = 0;
                 for (uint32_t i = tid; i <= top; i += FT_THREADS) {
                     const uint32_t v = win[i];
                     if (v) {
                         atomicAdd(&dst[i], v);
                         win[i] = 0;
+                        if (i < split) sa += v; else sb += v;
                     }
+                }
+                sa = ft_wave_sum(sa);
+                sb = ft_wave_sum(sb);
+                if (lane == 0) {
+                    if (sa) atomicAdd(&st.chunk_sums[c0], sa);
+                    if (sb) atomicAdd(&st.chunk_sums[c0 + 1], sb);
                 }
             }
             // s_max[it&1] is next written two tiles from now, after the next barrier

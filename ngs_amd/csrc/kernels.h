@@ -63,6 +63,8 @@ struct DeviceState {
     uint32_t off_tlen, off_qual, off_edits1, off_edits2, off_seen;
     uint32_t tlen_cap, max_read_len, n_refs, cov_cap;
     uint32_t *depth;               // coverage difference arrays, all primary sequences
+    uint32_t *chunk_sums;          // per COV_CHUNK positions: sum of the difference entries
+    uint32_t *super_sums;          // per COV_SUPER chunks
     const uint64_t *ref_depth_off; // [n_refs] element offset into depth, NO_DEPTH if not primary
     const uint32_t *ref_len;       // [n_refs]
     uint32_t *edits;               // refs/alts per position, all sequences with bases
@@ -115,20 +117,28 @@ hipError_t launch_qual_window(const LaunchInfo &li, const DeviceState &st, const
 hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                         hipStream_t s);
 
-// Coverage teardown for one sequence (coverage.rs:182-246): prefix-sum the
-// difference array, histogram the depths, integer bin totals; zeroes the
-// difference array behind itself when `reset` is set.
+// Coverage teardown for every sequence in ONE launch (coverage.rs:182-246): prefix-sum the
+// difference arrays, histogram the depths, integer bin totals; zeroes the arrays behind
+// itself when `reset` is set.  cov_scan.hip
+//
+// Layout of the uint32 "depth" block: per covered sequence a difference array of
+// ref_len+2 entries padded to a multiple of COV_CHUNK, then one sum per chunk
+// (maintained by the range-add kernel), then one sum per COV_SUPER chunks (scratch of the scan).
+constexpr uint32_t COV_CHUNK = 4096; // positions per scan chunk
+constexpr uint32_t COV_SUPER = 256;  // chunks per super-chunk
 struct CovScanArgs {
-    uint32_t *diff;      // L+2 entries (positions 0..L, sentinel L+1)
-    uint32_t ref_len;    // L
-    uint32_t bin_size;
-    uint32_t cov_cap;
-    unsigned long long *hist;       // [cov_cap+2]; last entry = positions with depth > cov_cap
-    unsigned long long *bin_totals; // [1 + L/bin + (L%bin!=0)]
-    uint32_t *chunk_sums;           // scratch [n_chunks]
+    uint32_t *depth;                 // whole block
+    uint64_t n_chunks;               // chunks of all sequences
+    uint32_t *chunk_sums, *super_sums;
+    const uint32_t *ref_first_chunk; // [n_refs + 1]
+    const uint32_t *ref_len;         // [n_refs]
+    const unsigned long long *seen;  // [n_refs] records Coverage processed
+    unsigned long long *hist;        // [n_refs][cov_cap + 2]; last entry = positions with depth > cov_cap
+    unsigned long long *bin_totals;  // concatenated per sequence
+    const uint64_t *bin_off;         // [n_refs + 1] offsets into bin_totals
+    uint32_t n_refs, bin_size, cov_cap;
     int reset;
 };
-uint32_t cov_scan_chunk_elems();
 hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream_t s);
 
 // Edits teardown for one sequence (edits.rs:320-341): VAF histogram from refs/alts

@@ -310,153 +310,6 @@ __global__ __launch_bounds__(256) void k_edits(DeviceState st, DeviceBatch b) {
 }
 
 // ---------------------------------------------------------------------------
-// Coverage teardown (coverage.rs:182-246) as a three-phase scan of the
-// difference array of one sequence:
-//   A  per-chunk sums of diff              (read  4 B/position)
-//   B  exclusive scan of the chunk sums    (tiny)
-//   C  per-chunk prefix sums -> depth; depth histogram in LDS; integer bin
-//      totals; optional zeroing of the array (read 4 B + write 4 B/position)
-// ---------------------------------------------------------------------------
-constexpr uint32_t SCAN_THREADS = 256;
-constexpr uint32_t SCAN_PER_THREAD = 16;
-constexpr uint32_t SCAN_CHUNK = SCAN_THREADS * SCAN_PER_THREAD; // 4096 positions
-
-uint32_t cov_scan_chunk_elems() { return SCAN_CHUNK; }
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_cov_chunk_sums(const uint32_t *diff, uint64_t n,
-                                                                uint32_t *chunk_sums) {
-    __shared__ uint32_t s_w[SCAN_THREADS / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * 4;
-    uint32_t sum = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < SCAN_PER_THREAD / 4; r++) {
-        const uint64_t j = base + (uint64_t)r * (SCAN_THREADS * 4);
-        if (j + 3 < n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(diff + j);
-            sum += v.x + v.y + v.z + v.w;
-        } else {
-            for (uint64_t t = j; t < n && t < j + 4; t++) sum += diff[t];
-        }
-    }
-    sum = wave_sum(sum);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (uint32_t w = 0; w < SCAN_THREADS / 64; w++) t += s_w[w];
-        chunk_sums[blockIdx.x] = t;
-    }
-}
-
-// single block: exclusive scan of chunk sums in place
-__global__ __launch_bounds__(1024) void k_cov_scan_chunks(uint32_t *chunk_sums, uint32_t n_chunks) {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < n_chunks; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n_chunks ? chunk_sums[i] : 0;
-        uint32_t inc = v; // inclusive scan within the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t t = __shfl_up(inc, o, 64);
-            if ((int)lane >= o) inc += t;
-        }
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (uint32_t w = 0; w < wave; w++) wave_off += s_w[w];
-        const uint32_t carry = s_carry;
-        if (i < n_chunks) chunk_sums[i] = carry + wave_off + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_off + inc;
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_cov_depth_hist(CovScanArgs a) {
-    extern __shared__ uint32_t s_hist[]; // cov_cap + 2
-    __shared__ uint32_t s_w[SCAN_THREADS / 64];
-    const uint32_t nb = a.cov_cap + 2;
-    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_hist[i] = 0;
-    __syncthreads();
-
-    const uint64_t n = (uint64_t)a.ref_len + 2; // entries of diff
-    const uint64_t L = a.ref_len;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // each thread owns 16 CONSECUTIVE positions so that its prefix is local
-    const uint64_t j0 = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
-    uint32_t d[SCAN_PER_THREAD];
-#pragma unroll
-    for (uint32_t r = 0; r < SCAN_PER_THREAD / 4; r++) {
-        const uint64_t j = j0 + r * 4;
-        if (j + 3 < n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.diff + j);
-            d[r * 4 + 0] = v.x;
-            d[r * 4 + 1] = v.y;
-            d[r * 4 + 2] = v.z;
-            d[r * 4 + 3] = v.w;
-            if (a.reset) *reinterpret_cast<uint4 *>(a.diff + j) = make_uint4(0, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (uint32_t t = 0; t < 4; t++) {
-                d[r * 4 + t] = (j + t < n) ? a.diff[j + t] : 0u;
-                if (a.reset && j + t < n) a.diff[j + t] = 0u;
-            }
-        }
-    }
-    uint32_t tsum = 0;
-#pragma unroll
-    for (uint32_t t = 0; t < SCAN_PER_THREAD; t++) tsum += d[t];
-    uint32_t inc = tsum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(inc, o, 64);
-        if ((int)lane >= o) inc += t;
-    }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    uint32_t run = a.chunk_sums[blockIdx.x] + inc - tsum;
-    for (uint32_t w = 0; w < wave; w++) run += s_w[w];
-
-    // depth of each position -> histogram + bin totals
-    // bin of position i: 0 for i == 0, else 1 + (i-1)/bin_size  (coverage.rs:206-230)
-    u64 bin_sum = 0;
-    uint64_t cur_bin = ~0ull;
-#pragma unroll
-    for (uint32_t t = 0; t < SCAN_PER_THREAD; t++) {
-        run += d[t];
-        const uint64_t i = j0 + t;
-        if (i <= L) {
-            const uint32_t depth = run;
-            atomicAdd(&s_hist[depth <= a.cov_cap ? depth : a.cov_cap + 1], 1u);
-            const uint64_t bin = i == 0 ? 0 : 1 + (i - 1) / a.bin_size;
-            if (bin != cur_bin) {
-                if (bin_sum) atomicAdd(&a.bin_totals[cur_bin], bin_sum);
-                cur_bin = bin;
-                bin_sum = 0;
-            }
-            bin_sum += depth;
-        }
-    }
-    // wave-aggregate the common case: the whole wave lies in one bin
-    const uint64_t b0 = __shfl(cur_bin, 0, 64);
-    if (__all(cur_bin == b0)) {
-        u64 s = wave_sum64(bin_sum);
-        if (lane == 0 && s && b0 != ~0ull) atomicAdd(&a.bin_totals[b0], s);
-    } else if (bin_sum) {
-        atomicAdd(&a.bin_totals[cur_bin], bin_sum);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
-        uint32_t v = s_hist[i];
-        if (v) atomicAdd(&a.hist[i], (u64)v);
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Edits teardown (edits.rs:320-341): one VAF histogram increment per covered position.
 // f32 arithmetic exactly as the reference: alts as f32 / total as f32, * 100.0, truncate.
 // ---------------------------------------------------------------------------
@@ -534,17 +387,6 @@ hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const Devic
     if (!b.n) return hipSuccess;
     const uint32_t grid = grid_for(b.n, 256, li.n_cu * 8);
     hipLaunchKernelGGL(k_edits, dim3(grid), dim3(256), 0, s, st, b);
-    return hipGetLastError();
-}
-
-hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream_t s) {
-    (void)li;
-    const uint64_t n = (uint64_t)a.ref_len + 2;
-    const uint32_t n_chunks = (uint32_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    hipLaunchKernelGGL(k_cov_chunk_sums, dim3(n_chunks), dim3(SCAN_THREADS), 0, s, a.diff, n, a.chunk_sums);
-    hipLaunchKernelGGL(k_cov_scan_chunks, dim3(1), dim3(1024), 0, s, a.chunk_sums, n_chunks);
-    const size_t lds = (size_t)(a.cov_cap + 2) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_cov_depth_hist, dim3(n_chunks), dim3(SCAN_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
