@@ -166,6 +166,8 @@ def main() -> int:
         kernels = {k: {"avg_ms": round(v["total_ms"] / v["launches"], 4),
                        "GBps": round(v["algo_bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)}
                    for k, v in timing.items() if v["launches"] and v["total_ms"] > 0}
+        if roofline is not None:
+            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(n, args)
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline(lib, host, ffi, scfg, min(args.cpu_sample, n), max_len)
@@ -195,6 +197,27 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def pmc_traffic(n: int, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/*_traffic.json, made by tools/collect_traffic.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same command).  Only valid for the workload it was collected on."""
+    import glob
+    if n != 100_000_000 or args.read_len != 150 or args.workload != "fixed":
+        return None, "no PMC summary for this workload"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, "profiles/*_traffic.json absent"
+    try:
+        with open(files[-1]) as f:
+            doc = json.load(f)
+        for name, v in doc["kernels"].items():
+            if "k_qual_win" in name:
+                return v["hbm_bytes_corrected"], os.path.relpath(files[-1], ROOT)
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable: {e}"
+    return None, "kernel not in summary"
 
 
 def cpu_baseline(lib, host, ffi, scfg, sample: int, max_len: int):

@@ -48,6 +48,7 @@ struct FtRaw {
     uint32_t mapq;
     int4 ref, mate, tlen, pos;
     uint4 cig;
+    int32_t a_ref, a_pos; // ref_id / pos of the tile's FIRST record: anchor of the coverage window
 };
 
 // number of lanes of the wave for which `c` holds: a wave-uniform value (SALU)
@@ -111,7 +112,15 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             r.mate = *reinterpret_cast<const int4 *>(b.mate_ref_id + r0);
         }
         if (a.do_tlen) r.tlen = *reinterpret_cast<const int4 *>(b.tlen + r0);
-        if (a.do_cov) r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
+        r.a_ref = -1;
+        r.a_pos = -1;
+        if (a.do_cov) {
+            r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
+            // fetched with the tile (same address in every lane) so that the hot loop issues no
+            // load of its own: one more in-order VMEM wait there would drain the whole prefetch
+            r.a_ref = b.ref_id[tile * FT_TILE];
+            r.a_pos = b.pos[tile * FT_TILE];
+        }
         return r;
     };
     auto load_tail = [&](uint64_t tile, uint32_t &nrec) -> FtRaw {
@@ -145,10 +154,15 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         r.tlen = make_int4(tlen[0], tlen[1], tlen[2], tlen[3]);
         r.pos = make_int4(pos[0], pos[1], pos[2], pos[3]);
         r.cig = make_uint4(cig[0], cig[1], cig[2], cig[3]);
+        r.a_ref = a.do_cov ? b.ref_id[tile * FT_TILE] : -1;
+        r.a_pos = a.do_cov ? b.pos[tile * FT_TILE] : -1;
         return r;
     };
 
     uint32_t it = 0; // tile counter of this block: selects the window buffer
+    // facts of the sequence the window was last anchored on (reloaded only when it changes)
+    int32_t meta_ref = -1;
+    uint64_t meta_off = NO_DEPTH, meta_L = 0;
     auto process = [&](const FtRaw &raw, uint64_t tile, uint32_t nrec) {
         const uint64_t t0 = tile * FT_TILE;
         const uint64_t r0 = t0 + (uint64_t)tid * FT_PER_THREAD;
@@ -167,10 +181,15 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         uint32_t win_base = 0;
         uint64_t win_off = NO_DEPTH, win_L = 0;
         if (a.do_cov) {
-            const int32_t fr = b.ref_id[t0], fp = b.pos[t0];
+            const int32_t fr = raw.a_ref, fp = raw.a_pos;
             if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
-                win_off = st.ref_depth_off[fr];
-                win_L = st.ref_len[fr];
+                if (fr != meta_ref) {
+                    meta_ref = fr;
+                    meta_off = st.ref_depth_off[fr];
+                    meta_L = st.ref_len[fr];
+                }
+                win_off = meta_off;
+                win_L = meta_L;
                 if (win_off != NO_DEPTH) {
                     win_ref = fr;
                     win_base = (uint32_t)fp & ~3u; // <= alignment_start of that record
