@@ -38,13 +38,6 @@ def algorithmic_bytes_per_record(read_len: int, n_ops: float) -> float:
     return 25.0 + 4.0 * n_ops + (read_len + 1) // 2 + read_len
 
 
-class _DevArray:
-    """Zero-copy view of a library-owned device block for torch (RCCL collectives)."""
-
-    def __init__(self, ptr: int, n: int, typestr: str):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
-
-
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +49,8 @@ def main() -> int:
     ap.add_argument("--cpu-sample", type=int, default=2_000_000,
                     help="records of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP event brackets")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the torch.distributed/RCCL path even with one rank (plumbing check)")
     ap.add_argument("--facets", type=lambda x: int(x, 0), default=0x1F,
                     help="facet mask (default 0x1F = all default facets; 0x0E = BASELINE configs[1])")
     args = ap.parse_args()
@@ -76,11 +71,14 @@ def main() -> int:
     lib = None
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist.barrier()
     lib = ffi.load_library()
     if lib.ngsq_device_count() < 1:
@@ -92,6 +90,7 @@ def main() -> int:
     max_len = 300 if mixed else args.read_len
     # the whole synthetic file has world * n records; this rank owns the contiguous
     # record range [rank*n, (rank+1)*n) = a contiguous BGZF block range of a sorted BAM
+    # (weak scaling: ngs_amd.shard.shard_range(n * world, rank, world) == (rank * n, n))
     scfg = host.synth_config(n * world, mode=ffi.SYNTH_MIXED if mixed else ffi.SYNTH_FIXED,
                              read_len=args.read_len, ref_len=CHR1, n_refs=2)
     ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=local_rank,
@@ -100,16 +99,14 @@ def main() -> int:
     db = ctx.synth_device_batch(scfg, rank * n, n)
     t_gen = time.perf_counter() - t_gen
 
-    counters_t = depth_t = None
-    if world > 1:
-        p, cnt, _ = ctx.state_block(0)
-        counters_t = torch.as_tensor(_DevArray(p, cnt, "<i8"), device=f"cuda:{local_rank}")
-        p, cnt, _ = ctx.state_block(1)
-        depth_t = torch.as_tensor(_DevArray(p, cnt, "<i4"), device=f"cuda:{local_rank}")
+    views = None
+    if use_dist:
+        from ngs_amd import shard
+        views = shard.device_views(ctx, torch, local_rank)
 
     def sync():
         ctx.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -117,13 +114,10 @@ def main() -> int:
     def step():
         ctx.reset()
         ctx.process_batch(db)
-        if world > 1:
+        if use_dist:
             # every facet state is an integer sum over records -> one RCCL
             # sum of the packed counter block and of the coverage difference arrays
-            ctx.synchronize()
-            dist.all_reduce(counters_t)
-            dist.all_reduce(depth_t)
-            torch.cuda.synchronize()
+            shard.allreduce_state(ctx, dist, torch, views)
         ctx.finalize()
 
     for _ in range(args.warmup):
@@ -135,7 +129,7 @@ def main() -> int:
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -193,7 +187,7 @@ def main() -> int:
         print(json.dumps(out), flush=True)
     ctx.free_batch(db)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0 if ok else 1

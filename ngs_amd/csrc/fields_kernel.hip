@@ -12,12 +12,13 @@
 // Coverage is accumulated as a DIFFERENCE array (+1 at alignment_start, -1 at
 // alignment_end+1, uint32 wrap-around; prefix-summed at teardown).  In a
 // coordinate-sorted file the 1024 records of a tile start inside a few thousand
-// positions, so the block keeps an LDS WINDOW of the reference axis anchored at
-// the tile's first record: both updates of a record are LDS atomics, and the
-// touched part of the window is then flushed with coalesced global atomics
-// (one wave instruction = 256 contiguous bytes).  Records that do not fit the
-// window (unsorted input, other sequence, long skips) fall back to direct
-// global atomics -- always correct, just slower.
+// positions, so every WAVE keeps its own LDS window of the reference axis anchored
+// at the first of its 256 records: both updates of a record are LDS atomics, and
+// the touched part of the window is then flushed by the same wave with coalesced
+// global atomics (one wave instruction = 256 contiguous bytes).  Wave-private
+// windows need no block barrier: the tile loop has none.  Records that do not fit
+// the window (unsorted input, other sequence, long skips, very sparse files) fall
+// back to direct global atomics -- always correct, just slower.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -29,13 +30,26 @@ typedef unsigned long long u64;
 constexpr uint32_t FT_THREADS = 256;
 constexpr uint32_t FT_PER_THREAD = 4;
 constexpr uint32_t FT_TILE = FT_THREADS * FT_PER_THREAD; // records per tile
-constexpr uint32_t FT_WINDOW = 4096;                     // positions in one LDS window (two are kept)
+constexpr uint32_t FT_WINDOW = 2048;                     // positions in one wave's LDS window
 constexpr uint32_t FT_NSLOT = 16 + 3 + 18 + 1;           // block tallies: see slot_counter()
 
 __device__ __forceinline__ uint32_t ft_wave_sum(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
+}
+
+// One chunk-sum update per wave for the lanes that share the leader's chunk (the common
+// case in a sorted file); the others add on their own.  `active` may be false in any lane.
+__device__ __forceinline__ void ft_chunk_add(uint32_t *chunk_sums, bool active, uint32_t chunk, uint32_t val) {
+    const unsigned long long m = __ballot(active);
+    if (!m) return;
+    const int leader = __ffsll((long long)m) - 1;
+    const uint32_t c0 = __shfl(chunk, leader, 64);
+    const bool same = active && chunk == c0;
+    const uint32_t s = ft_wave_sum(same ? val : 0u);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&chunk_sums[c0], s);
+    if (active && !same) atomicAdd(&chunk_sums[chunk], val);
 }
 
 struct FieldsArgs {
@@ -48,7 +62,6 @@ struct FtRaw {
     uint32_t mapq;
     int4 ref, mate, tlen, pos;
     uint4 cig;
-    int32_t a_ref, a_pos; // ref_id / pos of the tile's FIRST record: anchor of the coverage window
 };
 
 // number of lanes of the wave for which `c` holds: a wave-uniform value (SALU)
@@ -67,15 +80,13 @@ __device__ __forceinline__ uint32_t slot_counter(uint32_t slot) {
 __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, DeviceBatch b, FieldsArgs a) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *const s_tlen = s_dyn;                                 // tlen_cap + 1
-    uint32_t *const s_win = s_dyn + ((st.tlen_cap + 1 + 3) & ~3u);  // 2 x FT_WINDOW
+    uint32_t *const s_win = s_dyn + ((st.tlen_cap + 1 + 3) & ~3u);  // one FT_WINDOW per wave
     __shared__ u64 s_acc[FT_NSLOT];
-    __shared__ uint32_t s_max[2]; // highest window index touched, per window buffer
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     for (uint32_t i = tid; i <= st.tlen_cap; i += FT_THREADS) s_tlen[i] = 0;
     if (a.do_cov)
-        for (uint32_t i = tid; i < 2 * FT_WINDOW; i += FT_THREADS) s_win[i] = 0;
+        for (uint32_t i = tid; i < (FT_THREADS / 64) * FT_WINDOW; i += FT_THREADS) s_win[i] = 0;
     if (tid < FT_NSLOT) s_acc[tid] = 0;
-    if (tid < 2) s_max[tid] = 0;
     __syncthreads();
 
     // wave-uniform tallies (ballot + popcount): 16 RecordMetrics, missing ref, tlen processed/ignored
@@ -112,15 +123,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             r.mate = *reinterpret_cast<const int4 *>(b.mate_ref_id + r0);
         }
         if (a.do_tlen) r.tlen = *reinterpret_cast<const int4 *>(b.tlen + r0);
-        r.a_ref = -1;
-        r.a_pos = -1;
-        if (a.do_cov) {
-            r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
-            // fetched with the tile (same address in every lane) so that the hot loop issues no
-            // load of its own: one more in-order VMEM wait there would drain the whole prefetch
-            r.a_ref = b.ref_id[tile * FT_TILE];
-            r.a_pos = b.pos[tile * FT_TILE];
-        }
+        if (a.do_cov) r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
         return r;
     };
     auto load_tail = [&](uint64_t tile, uint32_t &nrec) -> FtRaw {
@@ -154,18 +157,14 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         r.tlen = make_int4(tlen[0], tlen[1], tlen[2], tlen[3]);
         r.pos = make_int4(pos[0], pos[1], pos[2], pos[3]);
         r.cig = make_uint4(cig[0], cig[1], cig[2], cig[3]);
-        r.a_ref = a.do_cov ? b.ref_id[tile * FT_TILE] : -1;
-        r.a_pos = a.do_cov ? b.pos[tile * FT_TILE] : -1;
         return r;
     };
 
-    uint32_t it = 0; // tile counter of this block: selects the window buffer
     // facts of the sequence the window was last anchored on (reloaded only when it changes)
     int32_t meta_ref = -1;
     uint64_t meta_off = NO_DEPTH, meta_L = 0;
     auto process = [&](const FtRaw &raw, uint64_t tile, uint32_t nrec) {
-        const uint64_t t0 = tile * FT_TILE;
-        const uint64_t r0 = t0 + (uint64_t)tid * FT_PER_THREAD;
+        const uint64_t r0 = tile * FT_TILE + (uint64_t)tid * FT_PER_THREAD;
         const uint32_t flag[4] = {raw.flag.x & 0xFFFFu, raw.flag.x >> 16, raw.flag.y & 0xFFFFu, raw.flag.y >> 16};
         const uint32_t ncig[4] = {raw.ncig.x & 0xFFFFu, raw.ncig.x >> 16, raw.ncig.y & 0xFFFFu, raw.ncig.y >> 16};
         const int32_t ref[4] = {raw.ref.x, raw.ref.y, raw.ref.z, raw.ref.w};
@@ -174,14 +173,14 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         const int32_t pos[4] = {raw.pos.x, raw.pos.y, raw.pos.z, raw.pos.w};
         const uint32_t cig1[4] = {raw.cig.x, raw.cig.y, raw.cig.z, raw.cig.w};
 
-        // ---- coverage window of this tile: anchored at the tile's first record (block-uniform
-        // loads; no LDS round trip).  Not placed / not covered => no window for this tile.
-        uint32_t *const win = s_win + (it & 1u) * FT_WINDOW;
+        // ---- coverage window of this wave: anchored at the wave's first record (lane 0 holds it).
+        // Not placed / not a covered sequence => no window for this round.
+        uint32_t *const win = s_win + (tid >> 6) * FT_WINDOW;
         int32_t win_ref = -1;
         uint32_t win_base = 0;
         uint64_t win_off = NO_DEPTH, win_L = 0;
         if (a.do_cov) {
-            const int32_t fr = raw.a_ref, fp = raw.a_pos;
+            const int32_t fr = __shfl(ref[0], 0, 64), fp = __shfl(pos[0], 0, 64);
             if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
                 if (fr != meta_ref) {
                     meta_ref = fr;
@@ -201,6 +200,8 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
 #pragma unroll
         for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
             const bool live = j < nrec;
+            bool fb = false;          // this record went straight to the arrays (outside the window)
+            uint32_t fb_c0 = 0, fb_c1 = 0;
             const uint32_t f = flag[j];
             if (a.do_general) {
                 // general.rs:31-100 as mask tests; every tally is a ballot popcount (SALU)
@@ -286,28 +287,33 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                                     atomicAdd(&win[i0], 1u);
                                     atomicAdd(&win[i1], 0xFFFFFFFFu);
                                     my_max = max(my_max, (uint32_t)i1);
-                                } else { // outside the window: straight to the arrays and their sums
+                                } else { // outside the window: straight to the arrays
                                     const uint64_t g0 = off + s, g1 = off + ec + 1;
                                     atomicAdd(&st.depth[g0], 1u);
                                     atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
-                                    atomicAdd(&st.chunk_sums[g0 / COV_CHUNK], 1u);
-                                    atomicAdd(&st.chunk_sums[g1 / COV_CHUNK], 0xFFFFFFFFu);
+                                    fb = true;
+                                    fb_c0 = (uint32_t)(g0 / COV_CHUNK);
+                                    fb_c1 = (uint32_t)(g1 / COV_CHUNK);
                                 }
                             }
                         }
                     }
                 }
             }
+            if (a.do_cov) { // chunk sums of the records that bypassed the window (wave-aggregated)
+                ft_chunk_add(st.chunk_sums, fb, fb_c0, 1u);
+                ft_chunk_add(st.chunk_sums, fb, fb_c1, 0xFFFFFFFFu);
+            }
         }
 
         if (a.do_cov) {
-            // ---- one barrier per tile: publish the window, then flush its touched part with
-            // coalesced global atomics while the next tile fills the other buffer
+            // ---- the wave flushes the touched part of its own window with coalesced global
+            // atomics and leaves it zeroed.  No barrier: LDS operations of one wave execute in order.
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_down(my_max, o, 64));
-            if (lane == 0 && my_max) atomicMax(&s_max[it & 1u], my_max);
-            __syncthreads();
-            const uint32_t top = s_max[it & 1u];
+            for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor(my_max, o, 64));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t top = my_max;
             if (win_ref >= 0 && top) {
                 const uint64_t goff = win_off + win_base; // element index of window entry 0
                 uint32_t *dst = st.depth + goff;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 const uint32_t c0 = (uint32_t)(goff / COV_CHUNK);
                 const uint32_t split = (uint32_t)((uint64_t)(c0 + 1) * COV_CHUNK - goff); // first entry of chunk c0+1
                 uint32_t sa = 0, sb = 0;
-                for (uint32_t i = tid; i <= top; i += FT_THREADS) {
+                for (uint32_t i = lane; i <= top; i += 64) {
                     const uint32_t v = win[i];
                     if (v) {
                         atomicAdd(&dst[i], v);
@@ -329,11 +335,10 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                     if (sa) atomicAdd(&st.chunk_sums[c0], sa);
                     if (sb) atomicAdd(&st.chunk_sums[c0 + 1], sb);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            // s_max[it&1] is next written two tiles from now, after the next barrier
-            if (tid == 0) s_max[(it + 1) & 1u] = 0;
         }
-        it += 1;
     };
 
     const uint64_t n_full = b.n / FT_TILE; // tiles with all 1024 records
@@ -407,7 +412,7 @@ hipError_t launch_fields(const LaunchInfo &li, const DeviceState &st, const Devi
     a.do_general = (rec_facets & NGSQ_FACET_GENERAL) ? 1 : 0;
     a.do_tlen = (rec_facets & NGSQ_FACET_TEMPLATE_LENGTH) ? 1 : 0;
     a.do_cov = coverage ? 1 : 0;
-    const size_t lds = (((size_t)st.tlen_cap + 1 + 3) & ~(size_t)3) * 4 + (coverage ? 2 * FT_WINDOW * 4 : 0);
+    const size_t lds = (((size_t)st.tlen_cap + 1 + 3) & ~(size_t)3) * 4 + (coverage ? (FT_THREADS / 64) * FT_WINDOW * 4 : 0);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fields),
