@@ -117,7 +117,8 @@ def main() -> int:
         if use_dist:
             # every facet state is an integer sum over records -> one RCCL
             # sum of the packed counter block and of the coverage difference arrays
-            shard.allreduce_state(ctx, dist, torch, views)
+            # (ngs_amd/shard.py: counters all-reduced; coverage by owner-computes halo exchange)
+            shard.owner_teardown(ctx, dist, torch, views)
         ctx.finalize()
 
     for _ in range(args.warmup):
@@ -177,7 +178,8 @@ def main() -> int:
                        "records_per_gpu": n, "read_len": max_len if mixed else args.read_len,
                        "facets": ",".join(n for b_, n in ((1, "General"), (2, "Template Length"), (4, "GC Content"),
                                                            (8, "Quality Score"), (16, "Coverage")) if args.facets & b_),
-                       "sharding": "contiguous record (BGZF block) ranges, RCCL sum of states" if world > 1 else "single GPU",
+                       "sharding": ("contiguous record (BGZF block) ranges; RCCL all-reduce of counters, owner-computes "
+                                    "coverage teardown with halo exchange") if world > 1 else "single GPU",
                        "algorithmic_bytes_per_record": round(algo_rec, 2),
                        "hbm_frac_whole_pass": round(value / world * algo_rec / (HBM_PEAK_GBS * 1e9), 4)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,

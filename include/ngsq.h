@@ -290,8 +290,26 @@ int ngsq_kernel_timing_reset(ngsq_ctx *ctx);
 int ngsq_state_counters(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u64);
 int ngsq_state_depth(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u32);
 int ngsq_state_edits(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u32);
+
+/* Owner-computes teardown for sharded scans: instead of summing
+ * whole depth blocks, shards exchange only the entries that fall into another
+ * shard's part of the reference axis, each shard tears down a disjoint range of
+ * 4096-entry chunks, and the (small) teardown results are summed.
+ *   ngsq_depth_layout    entries of the difference arrays, number of chunks (the
+ *                        per-chunk sums start at entry n_diff of the depth block),
+ *                        and the [lo, hi) entry range this context has written
+ *   ngsq_set_scan_range  chunks [lo, hi) to tear down and the sum of every entry in front
+ *   ngsq_teardown        sequence-facet teardown on the device only (ngsq_finalize calls it
+ *                        when it has not run yet)
+ *   ngsq_state_teardown  device pointer of the teardown results: uint64 partial sums
+ *                        (depth histograms, bin totals, VAF histogram) */
+int ngsq_depth_layout(ngsq_ctx *ctx, uint64_t *n_diff, uint64_t *n_chunks, uint64_t *touched_lo,
+                      uint64_t *touched_hi);
+int ngsq_set_scan_range(ngsq_ctx *ctx, uint64_t chunk_lo, uint64_t chunk_hi, uint32_t carry_in);
+int ngsq_teardown(ngsq_ctx *ctx);
+int ngsq_state_teardown(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u64);
 /* host-visible copies for CPU-side reductions and tests */
-int ngsq_state_download(ngsq_ctx *ctx, int which /*0 counters,1 depth,2 edits*/, void *dst,
+int ngsq_state_download(ngsq_ctx *ctx, int which /*0 counters,1 depth,2 edits,3 teardown*/, void *dst,
                         uint64_t n_bytes);
 int ngsq_state_upload(ngsq_ctx *ctx, int which, const void *src, uint64_t n_bytes);
 

@@ -210,12 +210,21 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         st.super_sums = st.chunk_sums + n_chunk_pad;
         (void)max_len;
         c->n_cov_hist = (uint64_t)nr * (c->cfg.cov_cap + 2);
-        CTX_TRY(hipMalloc((void **)&c->d_cov_hist, c->n_cov_hist * 8));
-        CTX_TRY(hipMemsetAsync(c->d_cov_hist, 0, c->n_cov_hist * 8, c->stream));
-        CTX_TRY(hipMalloc((void **)&c->d_bin_totals, (c->bin_off[nr] + 1) * 8));
-        CTX_TRY(hipMemsetAsync(c->d_bin_totals, 0, (c->bin_off[nr] + 1) * 8, c->stream));
         c->h_cov_hist.assign(c->n_cov_hist, 0);
         c->h_bin_totals.assign(c->bin_off[nr] + 1, 0);
+        c->scan_hi = c->n_chunks;
+    }
+    {   // teardown block: [depth histograms | bin totals | VAF histogram]
+        const uint64_t n_bins = nd ? c->bin_off[nr] + 1 : 0;
+        c->n_td = round_up(c->n_cov_hist + n_bins + NGSQ_VAF_BINS, 8);
+        CTX_TRY(hipMalloc((void **)&c->d_td, c->n_td * 8));
+        CTX_TRY(hipMemsetAsync(c->d_td, 0, c->n_td * 8, c->stream));
+        c->d_cov_hist = c->d_td;
+        c->d_bin_totals = c->d_td + c->n_cov_hist;
+        c->d_vaf = c->d_td + c->n_cov_hist + n_bins;
+        CTX_TRY(hipMalloc((void **)&c->d_touched, 16));
+        CTX_TRY(hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
+        st.touched = c->d_touched;
     }
     if (ne) {
         CTX_TRY(hipMalloc((void **)&st.edits, ne * 4));
@@ -227,10 +236,6 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         for (uint32_t r = 0; r < nr; r++)
             if (bases_off[r] != NO_DEPTH)
                 CTX_TRY(hipMemcpy(bases + bases_off[r], cfg->ref_bases[r], c->ref_len[r], hipMemcpyHostToDevice));
-    }
-    if (c->cfg.facets & NGSQ_FACET_EDITS) {
-        CTX_TRY(hipMalloc((void **)&c->d_vaf, NGSQ_VAF_BINS * 8));
-        CTX_TRY(hipMemsetAsync(c->d_vaf, 0, NGSQ_VAF_BINS * 8, c->stream));
     }
     c->h_vaf.assign(NGSQ_VAF_BINS, 0);
     for (int k = 0; k < K_COUNT; k++) c->timing[k] = {KERNEL_NAMES[k], 0, 0.0, 0};
@@ -264,9 +269,8 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_bases_off);
     (void)hipFree(c->d_first_chunk);
     (void)hipFree(c->d_bin_off);
-    (void)hipFree(c->d_cov_hist);
-    (void)hipFree(c->d_bin_totals);
-    (void)hipFree(c->d_vaf);
+    (void)hipFree(c->d_td);
+    (void)hipFree(c->d_touched);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -509,9 +513,9 @@ int ngsq_synchronize(ngsq_ctx *c) {
 
 void *ngsq_stream(ngsq_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-int ngsq_finalize(ngsq_ctx *c) {
+int ngsq_teardown(ngsq_ctx *c) {
     if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
-    if (c->finalized) return fail(c, NGSQ_ERR_STATE, "already finalized");
+    if (c->finalized || c->torn_down) return fail(c, NGSQ_ERR_STATE, "already torn down");
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t facets = c->cfg.facets;
     const uint32_t nr = c->st.n_refs;
@@ -520,6 +524,9 @@ int ngsq_finalize(ngsq_ctx *c) {
         CovScanArgs a{};
         a.depth = c->st.depth;
         a.n_chunks = c->n_chunks;
+        a.c_begin = c->scan_lo;
+        a.c_end = c->scan_hi;
+        a.carry_in = c->scan_carry;
         a.chunk_sums = c->st.chunk_sums;
         a.super_sums = c->st.super_sums;
         a.ref_first_chunk = c->d_first_chunk;
@@ -532,14 +539,8 @@ int ngsq_finalize(ngsq_ctx *c) {
         a.bin_size = c->cfg.bin_size;
         a.cov_cap = c->cfg.cov_cap;
         a.reset = 1;
-        {
-            Bracket br(c, K_COV_SCAN, 0);
-            HIP_TRY(c, launch_cov_scan(c->li, a, c->stream));
-        }
-        HIP_TRY(c, hipMemcpyAsync(c->h_cov_hist.data(), c->d_cov_hist, c->n_cov_hist * 8, hipMemcpyDeviceToHost,
-                                  c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_bin_totals.data(), c->d_bin_totals, c->bin_off[nr] * 8 + 8,
-                                  hipMemcpyDeviceToHost, c->stream));
+        Bracket br(c, K_COV_SCAN, 0);
+        HIP_TRY(c, launch_cov_scan(c->li, a, c->stream));
     }
     if (facets & NGSQ_FACET_EDITS) {
         for (uint32_t r = 0; r < nr; r++) {
@@ -549,17 +550,44 @@ int ngsq_finalize(ngsq_ctx *c) {
             HIP_TRY(c, launch_edits_vaf(c->li, refs, refs + (uint64_t)c->ref_len[r] + 1, c->ref_len[r], c->d_vaf,
                                         c->stream));
         }
-        HIP_TRY(c, hipMemcpyAsync(c->h_vaf.data(), c->d_vaf, NGSQ_VAF_BINS * 8, hipMemcpyDeviceToHost, c->stream));
     }
+    c->torn_down = true;
+    return NGSQ_OK;
+}
+
+int ngsq_finalize(ngsq_ctx *c) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    if (c->finalized) return fail(c, NGSQ_ERR_STATE, "already finalized");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t facets = c->cfg.facets;
+    const uint32_t nr = c->st.n_refs;
+    if (!c->torn_down) {
+        int rc = ngsq_teardown(c);
+        if (rc != NGSQ_OK) return rc;
+    }
+    if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_cov_hist.data(), c->d_cov_hist, c->n_cov_hist * 8, hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_bin_totals.data(), c->d_bin_totals, c->bin_off[nr] * 8 + 8,
+                                  hipMemcpyDeviceToHost, c->stream));
+    }
+    if (facets & NGSQ_FACET_EDITS)
+        HIP_TRY(c, hipMemcpyAsync(c->h_vaf.data(), c->d_vaf, NGSQ_VAF_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_touched, c->d_touched, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_counters.data(), c->st.counters, c->n_counters * 8, hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     resolve_timing(c);
     c->finalized = true;
-    if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) // algorithmic bytes of the scan: 8 B per torn-down position
-        for (uint32_t r = 0; r < nr; r++)
-            if (c->depth_off[r] != NO_DEPTH && c->h_counters[c->st.off_seen + r])
-                c->timing[K_COV_SCAN].algo_bytes += ((uint64_t)c->ref_len[r] + 2) * 8;
+    if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) { // algorithmic bytes of the scan: 8 B per torn-down position
+        if (c->scan_partial) {
+            c->timing[K_COV_SCAN].algo_bytes += (c->scan_hi - c->scan_lo) * (uint64_t)COV_CHUNK * 8;
+        } else {
+            for (uint32_t r = 0; r < nr; r++)
+                if (c->depth_off[r] != NO_DEPTH && c->h_counters[c->st.off_seen + r])
+                    c->timing[K_COV_SCAN].algo_bytes += ((uint64_t)c->ref_len[r] + 2) * 8;
+        }
+    }
     const unsigned long long *err = c->h_counters.data() + C_ERR;
     for (int k = 0; k < 8; k++)
         if (err[k])
@@ -571,23 +599,68 @@ int ngsq_finalize(ngsq_ctx *c) {
     return NGSQ_OK;
 }
 
+int ngsq_depth_layout(ngsq_ctx *c, uint64_t *n_diff, uint64_t *n_chunks, uint64_t *touched_lo, uint64_t *touched_hi) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long t[2];
+    HIP_TRY(c, hipMemcpyAsync(t, c->d_touched, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_diff) *n_diff = c->n_diff;
+    if (n_chunks) *n_chunks = c->n_chunks;
+    if (touched_lo) *touched_lo = t[0] == ~0ull ? 0 : t[0];
+    if (touched_hi) *touched_hi = t[0] == ~0ull ? 0 : t[1];
+    return NGSQ_OK;
+}
+
+int ngsq_set_scan_range(ngsq_ctx *c, uint64_t chunk_lo, uint64_t chunk_hi, uint32_t carry_in) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    if (c->torn_down || c->finalized) return fail(c, NGSQ_ERR_STATE, "set the scan range before teardown");
+    if (chunk_lo > chunk_hi || chunk_hi > c->n_chunks)
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "scan range [%llu,%llu) outside [0,%llu)", (unsigned long long)chunk_lo,
+                    (unsigned long long)chunk_hi, (unsigned long long)c->n_chunks);
+    c->scan_lo = chunk_lo;
+    c->scan_hi = chunk_hi;
+    c->scan_carry = carry_in;
+    c->scan_partial = !(chunk_lo == 0 && chunk_hi == c->n_chunks && carry_in == 0);
+    return NGSQ_OK;
+}
+
+int ngsq_state_teardown(ngsq_ctx *c, void **p, uint64_t *n) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    *p = c->d_td;
+    *n = c->n_td;
+    return NGSQ_OK;
+}
+
 int ngsq_reset(ngsq_ctx *c) {
     if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->st.counters, 0, c->n_counters * 8, c->stream));
     if (c->n_depth) {
-        // a finalized context has already zeroed the difference arrays behind the scan:
-        // only the chunk / super-chunk sums are left
-        if (!c->finalized)
+        if (!c->finalized) {
             HIP_TRY(c, hipMemsetAsync(c->st.depth, 0, c->n_depth * 4, c->stream));
-        else
+        } else {
+            // the scan zeroed the difference arrays behind itself; what is left are the chunk /
+            // super-chunk sums and, after a partial teardown, this shard's own entries outside
+            // the chunk range it tore down (h_touched was read back by ngsq_finalize)
             HIP_TRY(c, hipMemsetAsync(c->st.chunk_sums, 0, (c->n_depth - c->n_diff) * 4, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_cov_hist, 0, c->n_cov_hist * 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_bin_totals, 0, (c->bin_off[c->st.n_refs] + 1) * 8, c->stream));
+            if (c->scan_partial && c->h_touched[0] != ~0ull && c->h_touched[1] > c->h_touched[0]) {
+                const uint64_t lo = c->h_touched[0], hi = c->h_touched[1] < c->n_diff ? c->h_touched[1] : c->n_diff;
+                if (hi > lo) HIP_TRY(c, hipMemsetAsync(c->st.depth + lo, 0, (hi - lo) * 4, c->stream));
+            }
+        }
     }
+    HIP_TRY(c, hipMemsetAsync(c->d_td, 0, c->n_td * 8, c->stream));
     if (c->n_edits) HIP_TRY(c, hipMemsetAsync(c->st.edits, 0, c->n_edits * 4, c->stream));
-    if (c->d_vaf) HIP_TRY(c, hipMemsetAsync(c->d_vaf, 0, NGSQ_VAF_BINS * 8, c->stream));
+    c->h_touched[0] = ~0ull;
+    c->h_touched[1] = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
     c->finalized = false;
+    c->torn_down = false;
+    c->scan_lo = 0;
+    c->scan_hi = c->n_chunks;
+    c->scan_carry = 0;
+    c->scan_partial = false;
     return NGSQ_OK;
 }
 
@@ -729,6 +802,7 @@ static int state_block(ngsq_ctx *c, int which, void **p, uint64_t *bytes) {
     case 0: *p = c->st.counters; *bytes = c->n_counters * 8; return NGSQ_OK;
     case 1: *p = c->st.depth; *bytes = c->n_depth * 4; return NGSQ_OK;
     case 2: *p = c->st.edits; *bytes = c->n_edits * 4; return NGSQ_OK;
+    case 3: *p = c->d_td; *bytes = c->n_td * 8; return NGSQ_OK;
     default: return NGSQ_ERR_INVALID_ARGUMENT;
     }
 }
@@ -755,6 +829,11 @@ int ngsq_state_upload(ngsq_ctx *c, int which, const void *src, uint64_t n_bytes)
     if (n_bytes != bytes) return fail(c, NGSQ_ERR_BUFFER_TOO_SMALL, "state block is %llu bytes", (unsigned long long)bytes);
     HIP_TRY(c, hipSetDevice(c->device));
     if (bytes) HIP_TRY(c, hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (which == 1 && c->n_diff) { // uploaded differences may sit anywhere
+        c->h_touched[0] = 0;
+        c->h_touched[1] = c->n_diff;
+        HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return NGSQ_OK;
 }

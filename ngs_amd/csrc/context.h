@@ -44,6 +44,15 @@ struct ngsq_ctx {
     uint32_t *d_first_chunk = nullptr;
     uint64_t *d_bin_off = nullptr;
     uint64_t n_diff = 0, n_chunks = 0; // difference-array entries / scan chunks of the depth block
+    // teardown results (per-sequence depth histograms | bin totals | VAF histogram): ONE block of
+    // partial sums, so that shards which tear down disjoint chunk ranges can add them up
+    unsigned long long *d_td = nullptr;
+    uint64_t n_td = 0;
+    unsigned long long *d_touched = nullptr; // [2] min / max+1 element of the depth block written
+    unsigned long long h_touched[2] = {~0ull, 0};
+    uint64_t scan_lo = 0, scan_hi = 0; // chunk range this context tears down (default: all)
+    uint32_t scan_carry = 0;
+    bool scan_partial = false, torn_down = false;
     unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
     std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;
     bool finalized = false;

@@ -62,21 +62,28 @@ __global__ __launch_bounds__(CS_THREADS) void k_cov_scan(CovScanArgs a) {
 
     const uint64_t n_units = (uint64_t)gridDim.x * (CS_THREADS / 64);
     const uint64_t unit = (uint64_t)blockIdx.x * (CS_THREADS / 64) + wave;
-    const uint64_t per = (a.n_chunks + n_units - 1) / n_units;
-    const uint64_t c_lo = per * unit < a.n_chunks ? per * unit : a.n_chunks;
-    const uint64_t c_hi = c_lo + per < a.n_chunks ? c_lo + per : a.n_chunks;
+    const uint64_t n_range = a.c_end - a.c_begin;
+    const uint64_t per = (n_range + n_units - 1) / n_units;
+    const uint64_t c_lo = a.c_begin + (per * unit < n_range ? per * unit : n_range);
+    const uint64_t c_hi = c_lo + per < a.c_end ? c_lo + per : a.c_end;
     if (c_lo >= c_hi) return;
 
-    // ---- carry in front of the wave: super sums, then the chunk sums of the partial super-chunk
+    // ---- carry in front of the wave: carry_in (everything before c_begin) + the sums of
+    // [c_begin, c_lo): whole super-chunks through super_sums, the ragged ends chunk by chunk
     uint32_t carry = 0;
     {
         uint32_t part = 0;
-        const uint64_t n_super = c_lo / COV_SUPER;
-        for (uint64_t i = lane; i < n_super; i += 64) part += a.super_sums[i];
-        for (uint64_t i = n_super * COV_SUPER + lane; i < c_lo; i += 64) part += a.chunk_sums[i];
+        const uint64_t s0 = (a.c_begin + COV_SUPER - 1) / COV_SUPER, s1 = c_lo / COV_SUPER; // whole supers [s0, s1)
+        if (s0 < s1) {
+            for (uint64_t i = a.c_begin + lane; i < s0 * COV_SUPER; i += 64) part += a.chunk_sums[i];
+            for (uint64_t i = s0 + lane; i < s1; i += 64) part += a.super_sums[i];
+            for (uint64_t i = s1 * COV_SUPER + lane; i < c_lo; i += 64) part += a.chunk_sums[i];
+        } else {
+            for (uint64_t i = a.c_begin + lane; i < c_lo; i += 64) part += a.chunk_sums[i];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        carry = part;
+        carry = a.carry_in + part;
     }
 
     // ---- sequence of the first chunk (wave-uniform binary search)
@@ -237,7 +244,8 @@ hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream
     }
     const uint32_t n_super = (uint32_t)((a.n_chunks + COV_SUPER - 1) / COV_SUPER);
     hipLaunchKernelGGL(k_cov_super_sums, dim3(n_super), dim3(COV_SUPER), 0, s, a.chunk_sums, a.n_chunks, a.super_sums);
-    uint64_t g = (a.n_chunks + CS_THREADS / 64 - 1) / (CS_THREADS / 64); // one chunk per wave at least
+    if (a.c_end <= a.c_begin) return hipSuccess;
+    uint64_t g = (a.c_end - a.c_begin + CS_THREADS / 64 - 1) / (CS_THREADS / 64); // one chunk per wave at least
     const uint64_t cap = (uint64_t)li.n_cu * 4;
     if (g > cap) g = cap;
     if (a.reset)

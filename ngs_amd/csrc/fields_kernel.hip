@@ -100,6 +100,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
     u64 nonsensical = 0;
     int32_t seen_ref = -1; // run-length tally of records Coverage processed, per sequence
     uint32_t seen_cnt = 0;
+    u64 t_lo = ~0ull, t_hi = 0; // entries of the depth block this thread has written: [t_lo, t_hi)
 
     const uint64_t n_tiles = (b.n + FT_TILE - 1) / FT_TILE;
     const bool cigar_vec = b.cigar_off == nullptr && b.cigar_stride == 1;
@@ -292,6 +293,8 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                                     atomicAdd(&st.depth[g0], 1u);
                                     atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
                                     fb = true;
+                                    t_lo = g0 < t_lo ? g0 : t_lo;
+                                    t_hi = g1 + 1 > t_hi ? g1 + 1 : t_hi;
                                     fb_c0 = (uint32_t)(g0 / COV_CHUNK);
                                     fb_c1 = (uint32_t)(g1 / COV_CHUNK);
                                 }
@@ -317,6 +320,8 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             if (win_ref >= 0 && top) {
                 const uint64_t goff = win_off + win_base; // element index of window entry 0
                 uint32_t *dst = st.depth + goff;
+                t_lo = goff < t_lo ? goff : t_lo;
+                t_hi = goff + top + 1 > t_hi ? goff + top + 1 : t_hi;
                 // running sum per scan chunk (cov_scan.hip): the window spans at most two chunks
                 const uint32_t c0 = (uint32_t)(goff / COV_CHUNK);
                 const uint32_t split = (uint32_t)((uint64_t)(c0 + 1) * COV_CHUNK - goff); // first entry of chunk c0+1
@@ -370,6 +375,18 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             const uint32_t sum = ft_wave_sum(same ? seen_cnt : 0u);
             if (lane == 0) atomicAdd(&st.counters[st.off_seen + rr], (u64)sum);
             if (seen_cnt != 0 && !same) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+        }
+    }
+    if (a.do_cov) { // written range of the depth block (min / max over the wave, then one atomic each)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 l2 = __shfl_xor(t_lo, o, 64), h2 = __shfl_xor(t_hi, o, 64);
+            t_lo = l2 < t_lo ? l2 : t_lo;
+            t_hi = h2 > t_hi ? h2 : t_hi;
+        }
+        if (lane == 0 && t_hi > 0) {
+            atomicMin(&st.touched[0], t_lo);
+            atomicMax(&st.touched[1], t_hi);
         }
     }
     {

@@ -65,6 +65,7 @@ struct DeviceState {
     uint32_t *depth;               // coverage difference arrays, all primary sequences
     uint32_t *chunk_sums;          // per COV_CHUNK positions: sum of the difference entries
     uint32_t *super_sums;          // per COV_SUPER chunks
+    unsigned long long *touched;   // [2] min / max+1 element of `depth` written (shard exchange)
     const uint64_t *ref_depth_off; // [n_refs] element offset into depth, NO_DEPTH if not primary
     const uint32_t *ref_len;       // [n_refs]
     uint32_t *edits;               // refs/alts per position, all sequences with bases
@@ -129,6 +130,8 @@ constexpr uint32_t COV_SUPER = 256;  // chunks per super-chunk
 struct CovScanArgs {
     uint32_t *depth;                 // whole block
     uint64_t n_chunks;               // chunks of all sequences
+    uint64_t c_begin, c_end;         // chunk range to tear down (shards own disjoint ranges)
+    uint32_t carry_in;               // sum of every difference entry in front of c_begin
     uint32_t *chunk_sums, *super_sums;
     const uint32_t *ref_first_chunk; // [n_refs + 1]
     const uint32_t *ref_len;         // [n_refs]

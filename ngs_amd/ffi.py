@@ -201,6 +201,10 @@ PROTOTYPES = {
     "ngsq_state_counters": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
     "ngsq_state_depth": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
     "ngsq_state_edits": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
+    "ngsq_depth_layout": (C.c_int, [ctx_p, u64p, u64p, u64p, u64p]),
+    "ngsq_set_scan_range": (C.c_int, [ctx_p, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "ngsq_teardown": (C.c_int, [ctx_p]),
+    "ngsq_state_teardown": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
     "ngsq_state_download": (C.c_int, [ctx_p, C.c_int, C.c_void_p, C.c_uint64]),
     "ngsq_state_upload": (C.c_int, [ctx_p, C.c_int, C.c_void_p, C.c_uint64]),
     "ngsq_device_malloc": (C.c_int, [ctx_p, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -311,3 +311,77 @@ def test_full_size_properties(gpu_lib):
         gpu.process_batch(db)
         gpu.finalize()
         json_equal(gpu.results(["chr1", "chr2"]), first)  # deterministic
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 with REAL contexts: three processes share the one GPU of the box, collectives over gloo
+# (small tensors staged through the host), owner-computes coverage teardown (ngs_amd/shard.py)
+# ---------------------------------------------------------------------------------------------
+def _rank_worker(rank, world, port, q, mode):
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch
+        import torch.distributed as dist
+        from ngs_amd import ffi as F, host as H, shard
+        from oracle import oracle_py
+        from tests.util import json_equal as jeq
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        lib = F.load_library()
+        n, L = 90_000, 700_000
+        ref_len = [L, 50_000]
+        scfg = H.synth_config(n, mode=F.SYNTH_MIXED if mode == "mixed" else F.SYNTH_FIXED, ref_len=L, n_refs=2)
+        whole = H.synth_host_batch(scfg, 0, n, lib)
+        first, cnt = shard.shard_range(n, rank, world)
+        kw = dict(facets=F.FACETS_DEFAULT, bin_size=50_000, max_read_len=300, gc_seed=5)
+        ctx = H.QcContext(ref_len, device=0, lib=lib, **kw)
+        views = shard.device_views(ctx, torch, 0)
+        names = ["chr1", "chr2"]
+        want = None
+        if rank == 0:
+            orc = oracle_py.Oracle(ref_len, **kw)
+            orc.process_batch(whole)
+            orc.finalize()
+            want = orc.results(names)
+        for step in range(2):  # the second pass checks reset after a partial teardown
+            ctx.process_batch(whole.slice(first, first + cnt))
+            rep = shard.owner_teardown(ctx, dist, torch, views, coll_device="cpu")
+            assert rep["mode"] == "owner", rep
+            ctx.finalize()
+            got = ctx.results(names)
+            if rank == 0:
+                jeq(got, want)
+            blob = [got if rank == 0 else None]
+            dist.broadcast_object_list(blob, src=0)
+            jeq(got, blob[0])  # every rank holds the whole-file result
+            ctx.reset()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("mode", ["fixed", "mixed"])
+def test_three_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode):
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_worker, args=(r, 3, port, q, mode)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"

@@ -121,3 +121,105 @@ def test_world_size_2_gloo():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+# ---------------------------------------------------------------------------------------------
+# owner-computes coverage teardown (ngs_amd/shard.py owner_teardown) with a numpy context
+# ---------------------------------------------------------------------------------------------
+def test_plan_owners_is_a_disjoint_cover():
+    from ngs_amd.shard import plan_owners
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        world, n_chunks = int(rng.integers(1, 9)), int(rng.integers(1, 500))
+        ranges = []
+        for r in range(world):
+            if rng.random() < 0.2:
+                ranges.append((5, 5))
+            else:
+                a = int(rng.integers(0, n_chunks))
+                ranges.append((a, int(rng.integers(a + 1, n_chunks + 1))))
+        own, owners, xfer = plan_owners(ranges, n_chunks)
+        covered = np.zeros(n_chunks, dtype=int)
+        for r in owners:
+            covered[own[r][0]:own[r][1]] += 1
+        if owners:
+            assert (covered == 1).all()
+        # every written chunk of every rank reaches exactly one owner (itself or via a transfer)
+        for s, (lo, hi) in enumerate(ranges):
+            reach = np.zeros(n_chunks, dtype=int)
+            if hi > lo:
+                reach[max(lo, own[s][0]):min(hi, own[s][1])] += 1
+            for (a, d), (c0, c1) in xfer.items():
+                if a == s:
+                    assert own[d][0] <= c0 and c1 <= own[d][1]
+                    reach[c0:c1] += 1
+            assert (reach[lo:hi] == 1).all() and reach.sum() == max(0, hi - lo)
+
+
+def _owner_worker(rank, world, port, q, layout):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        from ngs_amd import shard
+        from tests.fake_ctx import FakeCtx
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ref_len = [30_000, 9_000, 12_345]
+        rng = np.random.default_rng(5)
+        n = 4000
+        refs = np.sort(rng.integers(0, 3, n)) if layout != "unsorted" else rng.integers(0, 3, n)
+        starts = np.array([rng.integers(1, ref_len[r] - 400) for r in refs])
+        if layout != "unsorted":
+            order = np.lexsort((starts, refs))
+            refs, starts = refs[order], starts[order]
+        ends = starts + rng.integers(0, 300, n)
+        ends[::97] += 5000  # a few long skips crossing shard boundaries
+        ends = np.minimum(ends, np.array([ref_len[r] for r in refs]))
+
+        def fill(ctx, lo, hi):
+            for r in range(3):
+                m = refs[lo:hi] == r
+                ctx.add_reads(r, starts[lo:hi][m], ends[lo:hi][m])
+
+        whole = FakeCtx(ref_len)
+        fill(whole, 0, n)
+        whole.teardown()
+        if layout == "empty_rank" and rank == 1:
+            first, cnt = 0, 0
+        elif layout == "empty_rank":
+            first, cnt = shard.shard_range(n, 0 if rank == 0 else rank - 1, world - 1)
+        else:
+            first, cnt = shard.shard_range(n, rank, world)
+        mine = FakeCtx(ref_len)
+        fill(mine, first, first + cnt)
+        if layout == "unsorted":
+            shard.HALO_LIMIT_BYTES = 1 << 10  # force the all-reduce fallback
+        rep = shard.owner_teardown(mine, dist, torch, mine.views())
+        assert rep["mode"] == ("allreduce" if layout == "unsorted" else "owner"), rep
+        assert (mine.td == whole.td).all(), "teardown results differ from the single-context scan"
+        assert (mine.counters == whole.counters).all()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,layout", [(2, "sorted"), (3, "sorted"), (3, "empty_rank"), (2, "unsorted")])
+def test_owner_teardown_gloo(world, layout):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, q, layout)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
