@@ -1,0 +1,54 @@
+/*
+ * ngsq_bam.h -- host ingest for the `ngs qc` hot path: BGZF inflate + BAM record
+ * parse -> structure-of-arrays batches (ngsq_batch, NGSQ_MEM_HOST) ready for
+ * ngsq_process_batch.  SURVEY.md 8(f) rank 1 "the step before the path".
+ *
+ * Reference interfaces replaced (all in the un-vendored noodles crates the
+ * reference calls; restated from the SAM/BAM specification, sections 4.1-4.2):
+ *   - utils/formats/bam.rs:77-123  open_and_parse: open, require + parse <bam>.bai
+ *                                  (IndexCheck::Full), read header + reference sequences
+ *   - qc/command.rs:305            reader.records(&header): BGZF inflate + record decode
+ * No GPU is needed by anything in this header.
+ */
+#ifndef NGSQ_BAM_H
+#define NGSQ_BAM_H
+
+#include "ngsq.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ngsq_bam ngsq_bam;
+
+/* message of the last failing ngsq_bam_* call of this thread */
+const char *ngsq_bam_last_error(void);
+
+/* Open a BAM file and read its header and reference sequences.
+ * n_threads: BGZF inflate workers (0 = hardware concurrency). */
+int ngsq_bam_open(const char *path, int n_threads, ngsq_bam **out);
+void ngsq_bam_close(ngsq_bam *bam);
+
+/* utils/formats/bam.rs:86-96: "<path>.bai" must exist and parse as a BAI index
+ * (magic, per-reference bins/chunks and linear index, optional n_no_coor). */
+int ngsq_bam_check_index(const char *bam_path);
+
+uint32_t ngsq_bam_n_refs(const ngsq_bam *bam);
+const char *ngsq_bam_ref_name(const ngsq_bam *bam, uint32_t i);
+uint32_t ngsq_bam_ref_len(const ngsq_bam *bam, uint32_t i);
+const char *ngsq_bam_header_text(const ngsq_bam *bam, uint64_t *len);
+
+/* Decode up to max_records further records into `out` (host SoA columns owned
+ * by the reader, valid until the next call / close).  out->n_records == 0 at end
+ * of file.  out->first_record_index = index of the first record in the file.
+ * Layout: fixed-pitch rows (pitch = longest read of the batch) when that wastes
+ * little, else offsets arrays; cigar pitch 1 when every record has <= 1 op. */
+int ngsq_bam_next_batch(ngsq_bam *bam, uint64_t max_records, ngsq_batch *out);
+
+/* records decoded so far */
+uint64_t ngsq_bam_records_read(const ngsq_bam *bam);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

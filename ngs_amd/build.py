@@ -12,9 +12,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
-SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "context.cpp", "results.cpp"]
+SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "context.cpp", "results.cpp", "bam_reader.cpp"]
 HEADERS = ["kernels.h", "context.h", "../../include/ngsq.h", "../../include/ngsq_shared.h",
-           "../../include/ngsq_synth.h"]
+           "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
          "-fno-gpu-rdc"]
 
@@ -34,14 +34,34 @@ def up_to_date() -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+CLI_SRC = os.path.join(CSRC, "cli", "ngs_main.cpp")
+CLI_OUT = os.path.join(HERE, "ngs")
+
+
+def build_cli(force: bool = False, verbose: bool = True) -> str:
+    """The `ngs qc` command line (host C++ only), linked against libngsq.so next to it."""
+    deps = [CLI_SRC, OUT, os.path.join(HERE, "..", "include", "ngsq.h"), os.path.join(HERE, "..", "include", "ngsq_bam.h")]
+    if not force and os.path.exists(CLI_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(CLI_OUT) for d in deps):
+        return CLI_OUT
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", CLI_SRC, "-L" + HERE, "-lngsq", "-Wl,-rpath,$ORIGIN",
+           "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", CLI_OUT + ".tmp"]
+    if verbose:
+        print("[ngs_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(CLI_OUT + ".tmp", CLI_OUT)
+    return CLI_OUT
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and up_to_date():
+        build_cli(False, verbose)
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-lpthread", "-o", OUT + ".tmp"]
     if verbose:
         print("[ngs_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(OUT + ".tmp", OUT)
+    build_cli(True, verbose)
     return OUT
 
 

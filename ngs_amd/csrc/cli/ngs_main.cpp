@@ -1,0 +1,503 @@
+// ngs_main.cpp -- the `ngs qc` command line over the MI355X hot path.
+//
+// Mirrors the reference's CLI surface for this subcommand (flag names, defaults, error texts,
+// output file): src/main.rs:19-105 (global -q/-v, dispatch), src/qc/command.rs:36-102 (QcArgs),
+// :109-218 (qc), :226-421 (app: open_and_parse, sequence concordance check, facet selection,
+// pass 1 / pass 2 with the two `-n` rules, aggregate, write <prefix>.results.json).
+// The per-record facet loops are replaced by SoA batches through the C ABI (include/ngsq.h);
+// ingest is include/ngsq_bam.h.  Additive flags: --device, --batch-records, --threads, --gc-seed.
+// Not built (out of scope this round): the other subcommands, the Genomic
+// Features facet (-f) and --vaf-file.
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../../include/ngsq.h"
+#include "../../../include/ngsq_bam.h"
+
+namespace {
+
+int g_level = 2; // 0 off (-q), 2 info (default), 3 debug (-v)   src/main.rs:71-83
+
+void logf(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void logf(int level, const char *fmt, ...) {
+    if (level > g_level) return;
+    char ts[64];
+    const auto now = std::chrono::system_clock::now();
+    const std::time_t t = std::chrono::system_clock::to_time_t(now);
+    std::tm tm{};
+    gmtime_r(&t, &tm);
+    const long us = (long)(std::chrono::duration_cast<std::chrono::microseconds>(now.time_since_epoch()).count() % 1000000);
+    strftime(ts, sizeof ts, "%Y-%m-%dT%H:%M:%S", &tm);
+    fprintf(stderr, "%s.%06ldZ %5s ngs::qc::command: ", ts, us, level <= 1 ? "ERROR" : level == 2 ? "INFO" : "DEBUG");
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+
+[[noreturn]] void bail(const std::string &msg) { // anyhow::bail! -> "Error: ..." and exit code 1
+    fprintf(stderr, "Error: %s\n", msg.c_str());
+    exit(1);
+}
+
+std::string with_commas(unsigned long long v) { // num_format Locale::en
+    std::string s = std::to_string(v), out;
+    for (size_t i = 0; i < s.size(); i++) {
+        out += s[i];
+        const size_t left = s.size() - 1 - i;
+        if (left && left % 3 == 0) out += ',';
+    }
+    return out;
+}
+
+bool ieq(const std::string &a, const std::string &b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); i++)
+        if (tolower((unsigned char)a[i]) != tolower((unsigned char)b[i])) return false;
+    return true;
+}
+
+std::string exe_dir() {
+    char buf[4096];
+    const ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1);
+    if (n <= 0) return ".";
+    buf[n] = 0;
+    std::string p(buf);
+    const size_t k = p.rfind('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+}
+
+// ---- reference genome tables (src/utils/genome.rs:29-126): name -> sequences by group
+struct Genome {
+    std::string name;
+    std::set<std::string> all, primary;
+};
+
+bool load_genome(const std::string &want, Genome *g, std::string *supported) {
+    std::vector<std::string> dirs;
+    if (const char *e = getenv("NGSQ_DATA_DIR")) dirs.push_back(e);
+    dirs.push_back(exe_dir() + "/data");
+    // the default feature set of the reference ships one genome (Cargo.toml:48-50)
+    static const char *const known[] = {"GRCh38_no_alt_AnalysisSet"};
+    for (const char *k : known) {
+        if (!supported->empty()) *supported += ", ";
+        *supported += k;
+        if (!ieq(want, k)) continue;
+        for (const auto &d : dirs) {
+            std::ifstream f(d + "/" + k + ".tsv");
+            if (!f) continue;
+            g->name = k;
+            std::string line;
+            while (std::getline(f, line)) {
+                if (line.empty() || line[0] == '#') continue;
+                const size_t tab = line.find('\t');
+                if (tab == std::string::npos) continue;
+                const std::string nm = line.substr(0, tab), grp = line.substr(tab + 1);
+                g->all.insert(nm);
+                // get_primary_assembly, genome.rs:59-83: autosomes + sex + alt + unlocalized + unplaced
+                if (grp == "autosome" || grp == "sex" || grp == "alt" || grp == "unlocalized" || grp == "unplaced")
+                    g->primary.insert(nm);
+            }
+            return true;
+        }
+        bail(std::string("genome table ") + k + ".tsv not found (set NGSQ_DATA_DIR)");
+    }
+    return false;
+}
+
+// ---- FASTA (Edits facet, edits.rs:185-205): name -> 4-bit BAM base codes, one per byte
+int base_code(char c) {
+    static const char tab[] = "=ACMGRSVTWYHKDBN";
+    const char *p = (const char *)memchr(tab, c, 16); // upper case only, as noodles' Base::try_from(char)
+    return p ? (int)(p - tab) : -1;
+}
+
+std::map<std::string, std::vector<uint8_t>> read_fasta(const std::string &path) {
+    std::ifstream f(path);
+    if (!f) bail("opening reference FASTA file: " + path);
+    std::map<std::string, std::vector<uint8_t>> out;
+    std::string line, name;
+    std::vector<uint8_t> *cur = nullptr;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            const size_t sp = line.find_first_of(" \t");
+            name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+            cur = &out[name];
+            continue;
+        }
+        if (!cur) bail("invalid FASTA: sequence data before the first definition line");
+        for (char c : line) {
+            const int code = base_code(c);
+            if (code < 0) bail(std::string("invalid base in reference FASTA sequence ") + name + ": '" + c + "'");
+            cur->push_back((uint8_t)code);
+        }
+    }
+    return out;
+}
+
+// ---- record subsets for the `-n` rules -----------------------------------------------------
+struct Compact { // offsets-layout batch assembled from picked records
+    std::vector<uint16_t> flag, n_cigar;
+    std::vector<uint8_t> mapq, seq, qual;
+    std::vector<int32_t> ref_id, pos, mate_ref_id, tlen;
+    std::vector<uint32_t> l_seq, cigar;
+    std::vector<uint64_t> seq_off{0}, qual_off{0}, cigar_off{0};
+    void push(const ngsq_batch &b, uint64_t i) {
+        flag.push_back(b.flag[i]);
+        mapq.push_back(b.mapq[i]);
+        ref_id.push_back(b.ref_id[i]);
+        pos.push_back(b.pos[i]);
+        mate_ref_id.push_back(b.mate_ref_id[i]);
+        tlen.push_back(b.tlen[i]);
+        l_seq.push_back(b.l_seq[i]);
+        n_cigar.push_back(b.n_cigar[i]);
+        const uint32_t l = b.l_seq[i];
+        const uint8_t *s = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
+        seq.insert(seq.end(), s, s + (l + 1) / 2);
+        seq_off.push_back(seq.size());
+        if (b.qual_off) {
+            qual.insert(qual.end(), b.qual + b.qual_off[i], b.qual + b.qual_off[i + 1]);
+        } else {
+            const uint8_t *q = b.qual + i * (uint64_t)b.qual_stride;
+            bool missing = l > 0;
+            for (uint32_t k = 0; k < l && missing; k++) missing = q[k] == 0xFF;
+            if (!missing) qual.insert(qual.end(), q, q + l);
+        }
+        qual_off.push_back(qual.size());
+        const uint32_t *c = b.cigar + (b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride);
+        cigar.insert(cigar.end(), c, c + b.n_cigar[i]);
+        cigar_off.push_back(cigar.size());
+    }
+    ngsq_batch batch() {
+        ngsq_batch o;
+        memset(&o, 0, sizeof o);
+        o.struct_size = sizeof o;
+        o.location = NGSQ_MEM_HOST;
+        o.n_records = flag.size();
+        seq.resize(seq.size() + 64); // slack for the device's vector loads
+        qual.resize(qual.size() + 64);
+        cigar.resize(cigar.size() + 16);
+        mapq.resize(mapq.size() + 16);
+        o.flag = flag.data(); o.mapq = mapq.data(); o.ref_id = ref_id.data(); o.pos = pos.data();
+        o.mate_ref_id = mate_ref_id.data(); o.tlen = tlen.data(); o.l_seq = l_seq.data(); o.n_cigar = n_cigar.data();
+        o.seq = seq.data(); o.seq_off = seq_off.data(); o.qual = qual.data(); o.qual_off = qual_off.data();
+        o.cigar = cigar.data(); o.cigar_off = cigar_off.data();
+        o.seq_bytes = seq_off.back(); o.qual_bytes = qual_off.back(); o.cigar_ops = cigar_off.back();
+        return o;
+    }
+};
+
+// noodles bam::Reader::query over Region(name, 1..=L) (command.rs:369-373), as in the kernels
+bool query_yields(const ngsq_batch &b, uint64_t i, const std::vector<uint32_t> &ref_len) {
+    const int32_t r = b.ref_id[i], p = b.pos[i];
+    if (r < 0 || (size_t)r >= ref_len.size() || p < 0) return false;
+    uint64_t span = 0;
+    const uint32_t *c = b.cigar + (b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride);
+    for (uint32_t k = 0; k < b.n_cigar[i]; k++) {
+        const uint32_t op = c[k] & 0xF;
+        if (op <= 8 && ((0x18Du >> op) & 1u)) span += c[k] >> 4;
+    }
+    const uint64_t s = (uint64_t)p + 1, e = s + span - 1;
+    return e != 0 && s <= ref_len[r];
+}
+
+struct Args {
+    std::string src, genome, gff, fasta, out_dir, prefix, only, vaf;
+    bool has_n = false, has_out_dir = false, has_prefix = false, has_only = false;
+    unsigned long long n = 0;
+    int device = 0, threads = 0;
+    unsigned long long batch_records = 1ull << 21, gc_seed = 0x4E4753;
+};
+
+void usage() {
+    fprintf(stderr,
+            "Usage: ngs [-q|-v] qc [OPTIONS] <BAM> <REFERENCE_GENOME>\n\n"
+            "Options:\n"
+            "  -f, --features-gff <PATH>       Features GFF file (not supported by this build)\n"
+            "  -n, --num-records <USIZE>       Number of records to process in the first pass; also caps the\n"
+            "                                  records per sequence in the second pass\n"
+            "  -o, --output-directory <PATH>   Directory to output files to [default: current directory]\n"
+            "  -p, --output-prefix <STRING>    Output prefix [default: name of the BAM file]\n"
+            "  -r, --reference-fasta <PATH>    Reference FASTA file (enables the Edits facet)\n"
+            "      --only <FACET>              Only process one QC facet\n"
+            "      --vaf-file <PATH>           (not supported by this build)\n"
+            "      --five-prime-utr-feature-name, --three-prime-utr-feature-name, --coding-sequence-feature-name,\n"
+            "      --exon-feature-name, --gene-feature-name <STRING>   accepted for compatibility\n"
+            "      --device <N> --batch-records <N> --threads <N> --gc-seed <N>   (additive, this build)\n");
+}
+
+#define CHECK(ctx, expr)                                                                                   \
+    do {                                                                                                   \
+        const int rc_ = (expr);                                                                            \
+        if (rc_ != NGSQ_OK) bail(std::string(ngsq_last_error(ctx) && *ngsq_last_error(ctx) ? ngsq_last_error(ctx) : ngsq_last_global_error())); \
+    } while (0)
+
+} // namespace
+
+int main(int argc, char **argv) {
+    Args a;
+    std::vector<std::string> pos;
+    bool saw_qc = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string s = argv[i];
+        auto val = [&](const char *name) -> std::string {
+            if (i + 1 >= argc) bail(std::string("a value is required for '") + name + "' but none was supplied");
+            return argv[++i];
+        };
+        if (s == "-q" || s == "--quiet") g_level = 0;
+        else if (s == "-v" || s == "--verbose") g_level = 3;
+        else if (s == "-h" || s == "--help") { usage(); return 0; }
+        else if (!saw_qc && s == "qc") saw_qc = true;
+        else if (s == "-f" || s == "--features-gff") a.gff = val("--features-gff");
+        else if (s == "-n" || s == "--num-records") { a.n = strtoull(val("--num-records").c_str(), nullptr, 10); a.has_n = true; }
+        else if (s == "-o" || s == "--output-directory") { a.out_dir = val("--output-directory"); a.has_out_dir = true; }
+        else if (s == "-p" || s == "--output-prefix") { a.prefix = val("--output-prefix"); a.has_prefix = true; }
+        else if (s == "-r" || s == "--reference-fasta") a.fasta = val("--reference-fasta");
+        else if (s == "--only") { a.only = val("--only"); a.has_only = true; }
+        else if (s == "--vaf-file") a.vaf = val("--vaf-file");
+        else if (s == "--five-prime-utr-feature-name" || s == "--three-prime-utr-feature-name" ||
+                 s == "--coding-sequence-feature-name" || s == "--exon-feature-name" || s == "--gene-feature-name")
+            (void)val(s.c_str());
+        else if (s == "--device") a.device = atoi(val("--device").c_str());
+        else if (s == "--threads") a.threads = atoi(val("--threads").c_str());
+        else if (s == "--batch-records") a.batch_records = strtoull(val("--batch-records").c_str(), nullptr, 10);
+        else if (s == "--gc-seed") a.gc_seed = strtoull(val("--gc-seed").c_str(), nullptr, 0);
+        else if (!s.empty() && s[0] == '-') bail("unexpected argument '" + s + "' found");
+        else pos.push_back(s);
+    }
+    if (!saw_qc) {
+        usage();
+        bail("this build provides the `qc` subcommand only");
+    }
+    if (pos.size() != 2) {
+        usage();
+        bail("the following required arguments were not provided: <BAM> <REFERENCE_GENOME>");
+    }
+    a.src = pos[0];
+    a.genome = pos[1];
+
+    // ---- qc(): command.rs:109-218
+    logf(2, "Starting qc command...");
+    logf(3, "  [*] Source: %s", a.src.c_str());
+    Genome genome;
+    std::string supported;
+    if (!load_genome(a.genome, &genome, &supported))
+        bail("reference genome is not supported: " + a.genome +
+             ". Did you set the correct reference genome?. Use the `list genomes` subcommand to see supported reference genomes.");
+    logf(3, "  [*] Reference genome: %s", a.genome.c_str());
+    if (!a.has_prefix) { // default: the file name of the BAM (command.rs:156-162)
+        const size_t k = a.src.rfind('/');
+        a.prefix = k == std::string::npos ? a.src : a.src.substr(k + 1);
+    }
+    if (!a.has_out_dir) {
+        char cwd[4096];
+        a.out_dir = getcwd(cwd, sizeof cwd) ? cwd : ".";
+    }
+    if (!a.gff.empty()) bail("the Genomic Features facet (-f/--features-gff) is not supported by this build");
+    if (!a.vaf.empty()) bail("--vaf-file is not supported by this build");
+
+    // ---- app(): command.rs:226-421
+    // open_and_parse(IndexCheck::Full): extension sniff, <bam>.bai must parse, header + references
+    {
+        const size_t dot = a.src.rfind('.');
+        const std::string ext = dot == std::string::npos ? "" : a.src.substr(dot + 1);
+        if (!ieq(ext, "bam")) bail("Not able to determine filetype for extension: " + ext);
+    }
+    ngsq_bam *bam = nullptr;
+    if (ngsq_bam_open(a.src.c_str(), a.threads, &bam) != NGSQ_OK) bail(ngsq_bam_last_error());
+    if (ngsq_bam_check_index(a.src.c_str()) != NGSQ_OK) bail(ngsq_bam_last_error());
+    {
+        struct stat st;
+        if (stat(a.out_dir.c_str(), &st) != 0) {
+            std::string cmd = "mkdir -p '" + a.out_dir + "'";
+            if (system(cmd.c_str()) != 0) bail("Could not create output directory.");
+        }
+    }
+    const uint32_t n_refs = ngsq_bam_n_refs(bam);
+    std::vector<std::string> names(n_refs);
+    std::vector<uint32_t> ref_len(n_refs);
+    std::vector<uint8_t> primary(n_refs);
+    for (uint32_t r = 0; r < n_refs; r++) {
+        names[r] = ngsq_bam_ref_name(bam, r);
+        ref_len[r] = ngsq_bam_ref_len(bam, r);
+        if (!genome.all.count(names[r])) // command.rs:258-272
+            bail("Sequence \"" + names[r] + "\" not found in specified reference genome. Did you set the correct reference genome?");
+        primary[r] = genome.primary.count(names[r]) ? 1 : 0; // coverage.rs:133-138
+    }
+
+    // facets: qc.rs:44-126
+    uint32_t facets = NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH | NGSQ_FACET_GC_CONTENT | NGSQ_FACET_QUALITY_SCORE |
+                      NGSQ_FACET_COVERAGE;
+    if (!a.fasta.empty()) facets |= NGSQ_FACET_EDITS;
+    if (a.has_only) {
+        uint32_t sel = 0;
+        int matched = 0;
+        for (uint32_t bit = 1; bit <= NGSQ_FACET_EDITS; bit <<= 1)
+            if ((facets & bit) && ieq(a.only, ngsq_facet_name(bit))) {
+                sel |= bit;
+                matched++;
+            }
+        if (matched == 0) bail("No facets matched the specified `--only` flag: " + a.only);
+        facets = sel;
+    }
+    std::map<std::string, std::vector<uint8_t>> fasta;
+    std::vector<const uint8_t *> bases(n_refs, nullptr);
+    if (facets & NGSQ_FACET_EDITS) {
+        fasta = read_fasta(a.fasta);
+        for (uint32_t r = 0; r < n_refs; r++) { // EditsFacet::setup runs for every sequence (edits.rs:173-209)
+            auto it = fasta.find(names[r]);
+            if (it == fasta.end()) bail("sequence " + names[r] + " not found in reference FASTA.");
+            if (it->second.size() != ref_len[r])
+                bail("sequence " + names[r] + " has a different length in the reference FASTA");
+            bases[r] = it->second.data();
+        }
+    }
+
+    ngsq_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
+    cfg.facets = facets;
+    cfg.device = a.device;
+    cfg.n_refs = n_refs;
+    cfg.ref_len = ref_len.data();
+    cfg.ref_is_primary = primary.data();
+    cfg.bin_size = 50000;  // qc.rs:87
+    cfg.tlen_cap = 1024;   // qc.rs:62
+    cfg.cov_cap = 2048;    // coverage.rs:76
+    cfg.max_read_len = NGSQ_MAX_READ_LEN_LIMIT;
+    cfg.gc_seed = a.gc_seed;
+    cfg.ref_bases = (facets & NGSQ_FACET_EDITS) ? bases.data() : nullptr;
+    ngsq_ctx *ctx = nullptr;
+    if (ngsq_create(&cfg, &ctx) != NGSQ_OK) bail(ngsq_last_global_error());
+
+    const bool rec_facets = (facets & NGSQ_FACETS_RECORD_BASED) != 0, seq_facets = (facets & NGSQ_FACETS_SEQUENCE_BASED) != 0;
+    if (rec_facets) {
+        logf(2, "First pass with the following facets enabled:");
+        static const char *load[] = {"Light", "Light", "Light", "Moderate"};
+        for (int k = 0; k < 4; k++)
+            if (facets & (1u << k)) logf(2, "  [*] %s, %s", ngsq_facet_name(1u << k), load[k]);
+        logf(2, "Starting first pass for QC stats.");
+    } else {
+        logf(2, "No facets specified that require first pass. Skipping...");
+    }
+
+    unsigned long long n_pass1 = 0;
+    if (!a.has_n) {
+        // no truncation: both passes see every record -> one scan
+        for (;;) {
+            ngsq_batch b;
+            if (ngsq_bam_next_batch(bam, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
+            if (!b.n_records) break;
+            CHECK(ctx, ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH));
+            const unsigned long long before = n_pass1;
+            n_pass1 += b.n_records;
+            for (unsigned long long m = before / 1000000 + 1; m * 1000000 <= n_pass1; m++)
+                logf(2, "  [*] Processed %s records.", with_commas(m * 1000000).c_str()); // display.rs:43-52
+        }
+    } else {
+        // pass 1: stop after exactly n records (display.rs:58-63, `>=` after the increment)
+        // pass 2: one counter over all sequences (command.rs:354,384-388): a sequence stops once the
+        //         counter has reached n, so every later sequence still processes ONE record.
+        std::vector<std::vector<unsigned long long>> yielded(n_refs); // file indices, first max(n,1) per sequence
+        const unsigned long long keep = std::max<unsigned long long>(a.n, 1);
+        for (;;) {
+            ngsq_batch b;
+            if (ngsq_bam_next_batch(bam, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
+            if (!b.n_records) break;
+            if (rec_facets && (n_pass1 < keep)) {
+                const unsigned long long take = std::min<unsigned long long>(b.n_records, keep - n_pass1);
+                Compact c;
+                for (unsigned long long i = 0; i < take; i++) c.push(b, i);
+                ngsq_batch cb = c.batch();
+                cb.first_record_index = b.first_record_index;
+                CHECK(ctx, ngsq_process_batch(ctx, &cb, NGSQ_PASS_RECORD));
+                n_pass1 += take;
+            }
+            if (seq_facets)
+                for (unsigned long long i = 0; i < b.n_records; i++)
+                    if (query_yields(b, i, ref_len)) {
+                        auto &v = yielded[b.ref_id[i]];
+                        if (v.size() < keep) v.push_back(b.first_record_index + i);
+                    }
+            if (!seq_facets && n_pass1 >= keep) break;
+        }
+        if (seq_facets) {
+            std::set<unsigned long long> picks;
+            unsigned long long counter = 0;
+            for (uint32_t r = 0; r < n_refs; r++)
+                for (unsigned long long idx : yielded[r]) {
+                    picks.insert(idx);
+                    counter += 1;
+                    if (counter >= a.n) break;
+                }
+            ngsq_bam_close(bam);
+            if (ngsq_bam_open(a.src.c_str(), a.threads, &bam) != NGSQ_OK) bail(ngsq_bam_last_error());
+            Compact c;
+            unsigned long long first_idx = 0;
+            bool have_first = false;
+            for (;;) {
+                ngsq_batch b;
+                if (ngsq_bam_next_batch(bam, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
+                if (!b.n_records) break;
+                auto lo = picks.lower_bound(b.first_record_index);
+                for (; lo != picks.end() && *lo < b.first_record_index + b.n_records; ++lo) {
+                    if (!have_first) {
+                        first_idx = *lo;
+                        have_first = true;
+                    }
+                    c.push(b, *lo - b.first_record_index);
+                }
+            }
+            if (!c.flag.empty()) {
+                ngsq_batch cb = c.batch();
+                cb.first_record_index = first_idx; // sequence facets do not use the record index
+                CHECK(ctx, ngsq_process_batch(ctx, &cb, NGSQ_PASS_SEQUENCE));
+            }
+        }
+    }
+    if (rec_facets) {
+        logf(2, "Processed %s records in the first pass.", with_commas(n_pass1).c_str());
+        logf(2, "Summarizing quality control facets for the first pass.");
+    }
+    if (seq_facets) {
+        logf(2, "Second pass with the following facets enabled:");
+        if (facets & NGSQ_FACET_COVERAGE) logf(2, "  [*] Coverage, Moderate");
+        if (facets & NGSQ_FACET_EDITS) logf(2, "  [*] Edits, Heavy");
+        logf(2, "Starting second pass for QC stats.");
+    } else {
+        logf(2, "No facets specified that require second pass. Skipping...");
+    }
+    CHECK(ctx, ngsq_finalize(ctx));
+
+    logf(2, "Aggregating results.");
+    std::vector<const char *> name_ptrs(n_refs ? n_refs : 1, "");
+    for (uint32_t r = 0; r < n_refs; r++) name_ptrs[r] = names[r].c_str();
+    const int64_t need = ngsq_results_json(ctx, name_ptrs.data(), nullptr, 0);
+    if (need < 0) bail("could not serialize results");
+    std::vector<char> buf((size_t)need + 1);
+    ngsq_results_json(ctx, name_ptrs.data(), buf.data(), buf.size());
+    logf(2, "Writing output.");
+    const std::string out_path = a.out_dir + "/" + a.prefix + ".results.json"; // results.rs:50-60
+    FILE *of = fopen(out_path.c_str(), "wb");
+    if (!of || fwrite(buf.data(), 1, (size_t)need, of) != (size_t)need) bail("could not write " + out_path);
+    fclose(of);
+    ngsq_destroy(ctx);
+    ngsq_bam_close(bam);
+    return 0;
+}

@@ -216,6 +216,16 @@ PROTOTYPES = {
     "ngsq_gc_offset": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32]),
     "ngsq_synth_sizes": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, u64p, u64p, u64p]),
     "ngsq_synth_fill_host": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
+    "ngsq_bam_last_error": (C.c_char_p, []),
+    "ngsq_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "ngsq_bam_close": (None, [C.c_void_p]),
+    "ngsq_bam_check_index": (C.c_int, [C.c_char_p]),
+    "ngsq_bam_n_refs": (C.c_uint32, [C.c_void_p]),
+    "ngsq_bam_ref_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "ngsq_bam_ref_len": (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    "ngsq_bam_header_text": (C.c_char_p, [C.c_void_p, u64p]),
+    "ngsq_bam_next_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(Batch)]),
+    "ngsq_bam_records_read": (C.c_uint64, [C.c_void_p]),
     "ngsq_synth_fill_device": (
         C.c_int, [ctx_p, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
 }

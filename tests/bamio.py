@@ -1,0 +1,86 @@
+"""Test-side BAM / BAI writer (pure Python + zlib): turns a HostBatch into a real BGZF-compressed
+BAM file and a minimal, well-formed BAI, so that the C++ ingest (include/ngsq_bam.h) and the
+`ngs qc` command line can be exercised end to end.  SAM/BAM specification 4.1, 4.2, 5.2."""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import List, Sequence
+
+import numpy as np
+
+EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def bgzf_block(data: bytes, level: int = 1) -> bytes:
+    assert len(data) <= 65280
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def reg2bin(beg: int, end: int) -> int:
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def record_bytes(hb, i: int, name: bytes = b"r") -> bytes:
+    c = hb.cols
+    l = int(c["l_seq"][i])
+    if c["seq_off"] is not None:
+        seq = c["seq"][int(c["seq_off"][i]):int(c["seq_off"][i + 1])].tobytes()
+        q = c["qual"][int(c["qual_off"][i]):int(c["qual_off"][i + 1])].tobytes()
+    else:
+        seq = c["seq"][i * hb.seq_stride:i * hb.seq_stride + (l + 1) // 2].tobytes()
+        q = c["qual"][i * hb.qual_stride:i * hb.qual_stride + l].tobytes()
+    if len(q) != l:
+        q = b"\xff" * l  # absent qualities
+    if c["cigar_off"] is not None:
+        cig = c["cigar"][int(c["cigar_off"][i]):int(c["cigar_off"][i + 1])]
+    else:
+        cig = c["cigar"][i * hb.cigar_stride:i * hb.cigar_stride + int(c["n_cigar"][i])]
+    nm = name + b"%d" % i + b"\0"
+    pos = int(c["pos"][i])
+    span = sum(int(x) >> 4 for x in cig if (int(x) & 15) in (0, 2, 3, 7, 8))
+    bin_ = reg2bin(max(pos, 0), max(pos, 0) + max(span, 1))
+    body = struct.pack("<iiBBHHHIiii", int(c["ref_id"][i]), pos, len(nm), int(c["mapq"][i]), bin_, len(cig),
+                       int(c["flag"][i]), l, int(c["mate_ref_id"][i]), -1, int(c["tlen"][i]))
+    body += nm + np.asarray(cig, dtype="<u4").tobytes() + seq + q
+    return struct.pack("<I", len(body)) + body
+
+
+def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], block_payload: int = 60000,
+              with_index: bool = True, sort_order: str = "coordinate") -> None:
+    text = f"@HD\tVN:1.6\tSO:{sort_order}\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(ref_names, ref_len))
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(ref_names))
+    for n, l in zip(ref_names, ref_len):
+        head += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    out: List[bytes] = []
+    cur = bytearray(head)
+    for i in range(hb.n):
+        rec = record_bytes(hb, i)
+        while len(cur) + len(rec) > block_payload:  # records may straddle blocks
+            take = block_payload - len(cur)
+            cur += rec[:take]
+            rec = rec[take:]
+            out.append(bgzf_block(bytes(cur)))
+            cur = bytearray()
+        cur += rec
+    if cur:
+        out.append(bgzf_block(bytes(cur)))
+    out.append(EOF_BLOCK)
+    with open(path, "wb") as f:
+        f.write(b"".join(out))
+    if with_index:
+        # a structurally valid BAI without bins (the hot path scans the file once; the index is
+        # only required to exist and parse: utils/formats/bam.rs:86-96)
+        with open(path + ".bai", "wb") as f:
+            f.write(b"BAI\1" + struct.pack("<i", len(ref_names)))
+            for _ in ref_names:
+                f.write(struct.pack("<ii", 0, 0))
+            f.write(struct.pack("<Q", 0))

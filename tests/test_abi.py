@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("ngsq.h", "ngsq_synth.h"):
+    for h in ("ngsq.h", "ngsq_synth.h", "ngsq_bam.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(ngsq_[a-z0-9_]+)\s*\(", text))

@@ -1,0 +1,122 @@
+"""Host ingest (include/ngsq_bam.h, no GPU needed): BGZF inflate + BAM parse -> SoA batches.
+The staged batches must hold exactly the records that were written, in both layouts."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ngs_amd import ffi, host
+from tests import bamio
+from tests.util import random_batch, to_fixed_stride
+
+
+def read_all(lib, path, max_records, threads=3):
+    h = C.c_void_p()
+    rc = lib.ngsq_bam_open(path.encode(), threads, C.byref(h))
+    assert rc == 0, lib.ngsq_bam_last_error()
+    refs = [(lib.ngsq_bam_ref_name(h, i).decode(), lib.ngsq_bam_ref_len(h, i)) for i in range(lib.ngsq_bam_n_refs(h))]
+    batches = []
+    while True:
+        b = ffi.Batch()
+        rc = lib.ngsq_bam_next_batch(h, max_records, C.byref(b))
+        assert rc == 0, lib.ngsq_bam_last_error()
+        if b.n_records == 0:
+            break
+        batches.append(copy_batch(b))
+    n = lib.ngsq_bam_records_read(h)
+    lib.ngsq_bam_close(h)
+    return refs, batches, n
+
+
+def copy_batch(b: ffi.Batch) -> host.HostBatch:
+    n = int(b.n_records)
+
+    def arr(ptr, count, dt):
+        if not ptr or count == 0:
+            return np.zeros(0, dtype=dt) if ptr else None
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(count,)).copy()
+
+    cols = {k: arr(getattr(b, k), n, host.COLUMN_DTYPES[k]) for k in host.FIXED_COLUMNS}
+    for data, off, stride, tot in (("seq", "seq_off", b.seq_stride, b.seq_bytes), ("qual", "qual_off", b.qual_stride, b.qual_bytes),
+                                   ("cigar", "cigar_off", b.cigar_stride, b.cigar_ops)):
+        cols[off] = arr(getattr(b, off), n + 1, np.uint64) if getattr(b, off) else None
+        cols[data] = arr(getattr(b, data), int(tot), host.COLUMN_DTYPES[data])
+    return host.HostBatch(n, cols, b.seq_stride, b.qual_stride, b.cigar_stride, int(b.first_record_index))
+
+
+def records_of(hb):
+    """Layout-independent view: list of (fixed fields, seq bytes, qual bytes, cigar ops)."""
+    out = []
+    c = hb.cols
+    for i in range(hb.n):
+        l = int(c["l_seq"][i])
+        if c["seq_off"] is not None:
+            s = c["seq"][int(c["seq_off"][i]):int(c["seq_off"][i + 1])].tobytes()
+            q = c["qual"][int(c["qual_off"][i]):int(c["qual_off"][i + 1])].tobytes()
+        else:
+            s = c["seq"][i * hb.seq_stride:i * hb.seq_stride + (l + 1) // 2].tobytes()
+            q = c["qual"][i * hb.qual_stride:i * hb.qual_stride + l].tobytes()
+            if q == b"\xff" * l:
+                q = b""
+        nc = int(c["n_cigar"][i])
+        if c["cigar_off"] is not None:
+            g = tuple(int(x) for x in c["cigar"][int(c["cigar_off"][i]):int(c["cigar_off"][i + 1])])
+        else:
+            g = tuple(int(x) for x in c["cigar"][i * hb.cigar_stride:i * hb.cigar_stride + nc])
+        out.append((tuple(int(c[k][i]) for k in host.FIXED_COLUMNS), s, q, g))
+    return out
+
+
+@pytest.mark.parametrize("case", ["ragged", "uniform150", "long"])
+def test_round_trip(lib, tmp_path, case):
+    rng = np.random.default_rng(9)
+    ref_len = [50_000, 7_000]
+    if case == "ragged":
+        hb = random_batch(rng, 3000, ref_len, max_len=300, weird=True)
+    elif case == "uniform150":
+        hb = random_batch(rng, 3000, ref_len, max_len=150, min_len=150, weird=False)
+    else:
+        hb = random_batch(rng, 400, ref_len, max_len=900, min_len=321, weird=False)
+    # qualities == 0xFF for a whole read mean "absent" in BAM: keep real scores <= 93 (random_batch does)
+    path = str(tmp_path / "t.bam")
+    bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000)
+    assert lib.ngsq_bam_check_index(path.encode()) == 0
+    want = records_of(hb)
+    for max_records in (1 << 20, 257):
+        refs, batches, n = read_all(lib, path, max_records)
+        assert refs == [("chr1", 50_000), ("chr2", 7_000)] and n == hb.n
+        got = [r for b in batches for r in records_of(b)]
+        assert got == want
+        assert [b.first_record_index for b in batches] == list(np.cumsum([0] + [b.n for b in batches[:-1]]))
+    if case == "uniform150":
+        assert batches[0].seq_stride == 75 and batches[0].qual_stride == 150
+    if case == "long":
+        assert batches[0].qual_stride == 0 and batches[0].cols["qual_off"] is not None
+
+
+def test_errors(lib, tmp_path):
+    p = str(tmp_path / "x.bam")
+    h = C.c_void_p()
+    assert lib.ngsq_bam_open(p.encode(), 1, C.byref(h)) != 0 and b"opening BAM file" in lib.ngsq_bam_last_error()
+    open(p, "wb").write(b"not a bam at all, definitely not....")
+    assert lib.ngsq_bam_open(p.encode(), 1, C.byref(h)) != 0
+    assert lib.ngsq_bam_check_index(p.encode()) != 0 and b"reading BAM index" in lib.ngsq_bam_last_error()
+    rng = np.random.default_rng(1)
+    hb = random_batch(rng, 200, [9000], max_len=80)
+    bamio.write_bam(p, hb, ["chr1"], [9000])
+    data = open(p, "rb").read()
+    open(p, "wb").write(data[:len(data) // 2])  # truncated file
+    rc = lib.ngsq_bam_open(p.encode(), 2, C.byref(h))
+    if rc == 0:
+        b = ffi.Batch()
+        rc = lib.ngsq_bam_next_batch(h, 1 << 20, C.byref(b))
+        lib.ngsq_bam_close(h)
+    assert rc != 0
+
+
+def test_empty_bam(lib, tmp_path):
+    p = str(tmp_path / "e.bam")
+    bamio.write_bam(p, random_batch(np.random.default_rng(0), 0, [100]), ["chr1"], [100])
+    refs, batches, n = read_all(lib, p, 100)
+    assert refs == [("chr1", 100)] and batches == [] and n == 0

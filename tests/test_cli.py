@@ -1,0 +1,171 @@
+"""The `ngs qc` command line (ngs_amd/csrc/cli/ngs_main.cpp) against the reference's CLI contract
+(src/qc/command.rs:36-218, :226-421): flags, error texts, output file, and -- on a GPU -- the
+whole path BAM file -> ingest -> kernels -> <prefix>.results.json compared with the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ngs_amd import build, ffi, host
+from tests import bamio
+from tests.util import json_equal, random_batch
+
+GENOME = "GRCh38_no_alt_AnalysisSet"
+NAMES = ["chr1", "chr2", "chrM", "chrUn_KI270302v1"]      # chrM is not in the primary assembly
+LENS = [60_000, 20_000, 16_569, 2_274]
+PRIMARY = [1, 1, 0, 1]
+
+
+@pytest.fixture(scope="module")
+def ngs(lib):
+    return build.build_cli(verbose=False)
+
+
+def run(ngs, *args, cwd=None):
+    return subprocess.run([ngs, *args], capture_output=True, text=True, cwd=cwd)
+
+
+def sorted_batch(seed, n, max_len=150, min_len=150):
+    rng = np.random.default_rng(seed)
+    hb = random_batch(rng, n, LENS, max_len=max_len, min_len=min_len, weird=False)
+    # placed, coordinate-sorted, well-formed (no records the reference would abort on)
+    c = hb.cols
+    c["flag"] &= np.uint16(0xFFFF ^ 0x1)          # unpaired: no mate reference needed
+    order = np.lexsort((c["pos"], c["ref_id"]))
+    recs = [hb.slice(int(i), int(i) + 1) for i in order]
+    cols = {}
+    for k in host.FIXED_COLUMNS:
+        cols[k] = np.concatenate([r.cols[k] for r in recs])
+    for data, off in (("seq", "seq_off"), ("qual", "qual_off"), ("cigar", "cigar_off")):
+        cols[data] = np.concatenate([r.cols[data] for r in recs])
+        lens = [len(r.cols[data]) for r in recs]
+        cols[off] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    return host.HostBatch(hb.n, cols, 0, 0, 0, 0)
+
+
+def test_error_texts(ngs, tmp_path):
+    hb = sorted_batch(1, 50)
+    bam = str(tmp_path / "a.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS, with_index=False)
+    r = run(ngs, "qc", bam, "hg19")
+    assert r.returncode == 1 and "reference genome is not supported: hg19." in r.stderr
+    r = run(ngs, "qc", bam, GENOME)
+    assert r.returncode == 1 and "reading BAM index" in r.stderr           # <bam>.bai is required
+    bamio.write_bam(bam, hb, NAMES, LENS)
+    r = run(ngs, "qc", bam, GENOME.lower(), "--only", "Nope")                # genome names match case-insensitively
+    assert r.returncode == 1 and "No facets matched the specified `--only` flag: Nope" in r.stderr
+    bad = str(tmp_path / "b.bam")
+    bamio.write_bam(bad, hb, ["chr1", "chr2", "chrM", "contig_7"], LENS)
+    r = run(ngs, "qc", bad, GENOME)
+    assert r.returncode == 1 and 'Sequence "contig_7" not found in specified reference genome.' in r.stderr
+    r = run(ngs, "qc", str(tmp_path / "a.sam"), GENOME)
+    assert r.returncode == 1
+    r = run(ngs, "qc", bam)
+    assert r.returncode == 1 and "required arguments" in r.stderr
+    r = run(ngs, "view", bam)
+    assert r.returncode == 1
+
+
+def oracle_json(oracle_mod, hb, facets=ffi.FACETS_DEFAULT, ref_bases=None, pass1=None, pass2=None):
+    o = oracle_mod.Oracle(LENS, PRIMARY, facets=facets, max_read_len=1024, gc_seed=0x4E4753, ref_bases=ref_bases)
+    if pass1 is None:
+        o.process_batch(hb)
+    else:
+        o.process_batch(pass1, ffi.PASS_RECORD)
+        for b in pass2:
+            o.process_batch(b, ffi.PASS_SEQUENCE)
+    o.finalize()
+    return o.results(NAMES)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["uniform150", "ragged"])
+def test_end_to_end(ngs, gpu_lib, oracle_mod, tmp_path, shape):
+    hb = sorted_batch(3, 6000) if shape == "uniform150" else sorted_batch(4, 6000, max_len=260, min_len=30)
+    bam = str(tmp_path / "sample.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=20_000)
+    out = tmp_path / "out"
+    r = run(ngs, "-v", "qc", bam, GENOME, "-o", str(out), "--batch-records", "1700")
+    assert r.returncode == 0, r.stderr
+    assert "Processed 6,000 records in the first pass." in r.stderr
+    got = json.load(open(out / "sample.bam.results.json"))     # default prefix = BAM file name
+    json_equal(got, oracle_json(oracle_mod, hb))
+    assert "chrM" not in got["coverage"]["mean_coverage"]      # not part of the primary assembly
+    # --only + -p, written to the current directory
+    r = run(ngs, "-q", "qc", bam, GENOME, "--only", "gc content", "-p", "x", cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stderr == ""
+    g2 = json.load(open(tmp_path / "x.results.json"))
+    assert g2["gc_content"] == got["gc_content"] and all(g2[k] is None for k in g2 if k != "gc_content")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 7, 300, 100_000])
+def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n):
+    """-n: pass 1 stops after n records; pass 2 shares ONE counter over all sequences, so every
+    sequence after the n-th record still processes one record (command.rs:354,384-388)."""
+    hb = sorted_batch(5, 2500)
+    bam = str(tmp_path / "s.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS)
+    r = run(ngs, "-q", "qc", bam, GENOME, "-n", str(n), "-o", str(tmp_path), "--batch-records", "999")
+    assert r.returncode == 0, r.stderr
+    got = json.load(open(tmp_path / "s.bam.results.json"))
+    # emulate the reference driver on the record list
+    c = hb.cols
+    keep1 = min(max(n, 1), hb.n)
+    picks, counter = [], 0
+    for ref in range(len(NAMES)):
+        for i in range(hb.n):
+            if c["ref_id"][i] != ref or c["pos"][i] < 0:
+                continue
+            ops = c["cigar"][int(c["cigar_off"][i]):int(c["cigar_off"][i + 1])]
+            span = sum(int(x) >> 4 for x in ops if (int(x) & 15) in (0, 2, 3, 7, 8))
+            s = int(c["pos"][i]) + 1
+            if s + span - 1 == 0 or s > LENS[ref]:
+                continue                      # not yielded by query()
+            picks.append(i)
+            counter += 1
+            if counter >= n:
+                break
+    want = oracle_json(oracle_mod, hb, pass1=hb.slice(0, keep1), pass2=[hb.slice(i, i + 1) for i in picks])
+    json_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_edits_with_reference_fasta(ngs, gpu_lib, oracle_mod, tmp_path):
+    from tests.util import batch_from_records
+    rng = np.random.default_rng(6)
+    letters = "=ACMGRSVTWYHKDBN"
+    bases = [rng.choice(np.array([1, 2, 4, 8, 15], dtype=np.uint8), L, p=[.25, .25, .25, .24, .01]) for L in LENS]
+    recs = []
+    for _ in range(3000):
+        ref = int(rng.integers(0, len(LENS)))
+        pos = int(rng.integers(0, LENS[ref] - 120))
+        codes = bases[ref][pos:pos + 100].copy()
+        codes[rng.integers(0, 100, 2)] = 1   # up to two edits (some coincide with an A already there)
+        recs.append(dict(flag=int(rng.choice([0, 0x40, 0x80, 0x400, 0x4])), mapq=30, ref_id=ref, pos=pos,
+                         mate_ref_id=-1, tlen=0, cigar=str(rng.choice(["100M", "40M5D60M", "30M10S60M", "10S90M", "50M3I47M"])),
+                         seq="".join(letters[x] for x in codes), qual=[int(x) for x in rng.integers(0, 60, 100)]))
+    recs.sort(key=lambda r: (r["ref_id"], r["pos"]))
+    hb = batch_from_records(recs)
+    bam = str(tmp_path / "e.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS)
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as f:
+        for name, b in zip(NAMES, bases):
+            f.write(f">{name} test\n")
+            s_ = "".join(letters[x] for x in b)
+            for k in range(0, len(s_), 60):
+                f.write(s_[k:k + 60] + "\n")
+    r = run(ngs, "-q", "qc", bam, GENOME, "-r", str(fa), "-o", str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    got = json.load(open(tmp_path / "e.bam.results.json"))
+    want = oracle_json(oracle_mod, hb, facets=ffi.FACETS_DEFAULT | ffi.FACET_EDITS, ref_bases=bases)
+    json_equal(got, want)
+    assert sum(got["edits"]["read_one_edits"]["values"][1:]) > 0 and sum(got["edits"]["vaf_histogram"]["values"]) > 0
+    # a sequence missing from the FASTA aborts like EditsFacet::setup (edits.rs:207-209)
+    with open(fa, "w") as f:
+        f.write(">chr1\nACGT\n")
+    r = run(ngs, "-q", "qc", bam, GENOME, "-r", str(fa), "-o", str(tmp_path))
+    assert r.returncode == 1 and "not found in reference FASTA." in r.stderr
