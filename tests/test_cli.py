@@ -166,6 +166,6 @@ def test_edits_with_reference_fasta(ngs, gpu_lib, oracle_mod, tmp_path):
     assert sum(got["edits"]["read_one_edits"]["values"][1:]) > 0 and sum(got["edits"]["vaf_histogram"]["values"]) > 0
     # a sequence missing from the FASTA aborts like EditsFacet::setup (edits.rs:207-209)
     with open(fa, "w") as f:
-        f.write(">chr1\nACGT\n")
+        f.write(">chr1\n" + "".join(letters[x] for x in bases[0]) + "\n")
     r = run(ngs, "-q", "qc", bam, GENOME, "-r", str(fa), "-o", str(tmp_path))
-    assert r.returncode == 1 and "not found in reference FASTA." in r.stderr
+    assert r.returncode == 1 and "sequence chr2 not found in reference FASTA." in r.stderr
