@@ -30,6 +30,11 @@ int ngsq_synth_fill_host(const ngsq_synth_config *cfg, uint64_t first, uint64_t 
 int ngsq_synth_fill_device(ngsq_ctx *ctx, const ngsq_synth_config *cfg, uint64_t first, uint64_t n,
                            const ngsq_batch *batch);
 
+/* Write records [0, n_records) as a BGZF BAM (@SQ chr1 [, chr2]) plus a minimal BAI
+ * ("<path>.bai"), rendered and deflated by n_threads workers (0 = all cores). */
+int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *path, uint64_t n_records, int level,
+                         int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

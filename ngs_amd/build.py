@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
-SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "context.cpp", "results.cpp", "bam_reader.cpp"]
+SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "context.cpp", "results.cpp", "bam_reader.cpp", "synth_bam.cpp"]
 HEADERS = ["kernels.h", "context.h", "../../include/ngsq.h", "../../include/ngsq_shared.h",
            "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",

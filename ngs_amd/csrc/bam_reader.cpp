@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -35,6 +36,36 @@ int bfail(int code, const char *fmt, ...) {
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
+// uninitialised growable byte buffer (std::vector would zero gigabytes on one core)
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    uint8_t *reserve(size_t n) {
+        if (n > cap) {
+            free(p);
+            cap = n + n / 8 + 4096;
+            p = (uint8_t *)malloc(cap);
+        }
+        return p;
+    }
+    ~RawBuf() { free(p); }
+};
+
+template <typename F> void parallel_for(int n_threads, uint64_t n, F fn) {
+    const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_threads, n / 4096 + 1));
+    if (nt == 1) {
+        fn((uint64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const uint64_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) {
+        const uint64_t lo = std::min(n, per * t), hi = std::min(n, lo + per);
+        if (lo < hi) pool.emplace_back([=]() { fn(lo, hi); });
+    }
+    for (auto &th : pool) th.join();
+}
+
 struct Block {
     size_t in_off, in_len; // deflate payload inside the compressed buffer
     size_t out_off;
@@ -57,7 +88,8 @@ struct ngsq_bam {
     uint64_t n_read = 0;
     // batch columns
     std::vector<uint16_t> flag, n_cigar;
-    std::vector<uint8_t> mapq, seq, qual;
+    std::vector<uint8_t> mapq, missing;
+    RawBuf seq, qual; // large: grown without initialisation, padded by the fill threads
     std::vector<int32_t> ref_id, pos, mate_ref_id, tlen;
     std::vector<uint32_t> l_seq, cigar;
     std::vector<uint64_t> seq_off, qual_off, cigar_off;
@@ -162,7 +194,7 @@ int ensure(ngsq_bam *b, size_t need) {
         if (b->eof && b->comp.empty()) break;
         const size_t a0 = b->data.size() - b->data_pos, c0 = b->comp.size();
         const bool e0 = b->eof;
-        const int rc = inflate_more(b, e0 ? 0 : (size_t)8 << 20);
+        const int rc = inflate_more(b, e0 ? 0 : (size_t)64 << 20);
         if (rc) return rc;
         if (e0 && b->data.size() - b->data_pos == a0 && b->comp.size() == c0)
             return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated BGZF block at end of file", b->path.c_str());
@@ -258,7 +290,7 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     std::vector<size_t> recs; // offsets (relative to data_pos) of block_size fields
     size_t cursor = 0;
     uint32_t max_l = 0, max_ops = 0;
-    uint64_t sum_seq = 0, sum_qual = 0, sum_ops = 0;
+    uint64_t sum_qual = 0;
     while (recs.size() < max_records) {
         int rc = ensure(b, cursor + 4);
         if (rc) return rc;
@@ -282,9 +314,9 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
         recs.push_back(cursor);
         max_l = std::max(max_l, l);
         max_ops = std::max(max_ops, n_ops);
-        sum_seq += (l + 1) / 2;
+
         sum_qual += l;
-        sum_ops += n_ops;
+
         cursor += 4 + (size_t)block_size;
     }
     const uint64_t n = recs.size();
@@ -295,60 +327,82 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     const bool cig1 = max_ops <= 1;
     b->flag.resize(n); b->n_cigar.resize(n); b->mapq.resize(n + 16);
     b->ref_id.resize(n); b->pos.resize(n); b->mate_ref_id.resize(n); b->tlen.resize(n); b->l_seq.resize(n);
-    if (fixed) {
-        b->seq.assign((size_t)pitch_s * n + 64, 0);
-        b->qual.assign((size_t)pitch_q * n + 64, 0xFF);
-    } else {
-        b->seq.resize(sum_seq + 64);
-        b->qual.resize(sum_qual + 64);
-        b->seq_off.resize(n + 1);
-        b->qual_off.resize(n + 1);
-    }
-    if (cig1) {
-        b->cigar.assign(n + 16, 0);
-    } else {
-        b->cigar.resize(sum_ops + 16);
-        b->cigar_off.resize(n + 1);
-    }
+    const uint8_t *const D = b->data.data() + b->data_pos;
     uint64_t so = 0, qo = 0, co = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        const uint8_t *r = b->data.data() + b->data_pos + recs[i] + 4;
-        const uint32_t l_read_name = r[8], n_ops = rd16(r + 12), l = rd32(r + 16);
-        b->ref_id[i] = (int32_t)rd32(r);
-        b->pos[i] = (int32_t)rd32(r + 4);
-        b->mapq[i] = r[9];
-        b->n_cigar[i] = (uint16_t)n_ops;
-        b->flag[i] = rd16(r + 14);
-        b->l_seq[i] = l;
-        b->mate_ref_id[i] = (int32_t)rd32(r + 20);
-        b->tlen[i] = (int32_t)rd32(r + 28);
-        const uint8_t *cg = r + 32 + l_read_name;
-        const uint8_t *sq = cg + 4ull * n_ops;
-        const uint8_t *ql = sq + (l + 1) / 2;
-        if (cig1) {
-            if (n_ops) b->cigar[i] = rd32(cg);
-        } else {
-            b->cigar_off[i] = co;
-            for (uint32_t k = 0; k < n_ops; k++) b->cigar[co + k] = rd32(cg + 4 * k);
-            co += n_ops;
+    if (!fixed || !cig1) {
+        // offsets layout: absent qualities (l_seq bytes of 0xFF, spec 4.2.3; noodles yields no scores)
+        // take no bytes, so the offsets need the `missing` flags first (parallel), then one prefix pass
+        b->missing.resize(n);
+        if (!fixed) {
+            parallel_for(b->n_threads, n, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; i++) {
+                    const uint8_t *r = D + recs[i] + 4;
+                    const uint32_t l = rd32(r + 16);
+                    const uint8_t *ql = r + 32 + r[8] + 4ull * rd16(r + 12) + (l + 1) / 2;
+                    bool miss = l > 0;
+                    for (uint32_t k = 0; k < l && miss; k++) miss = ql[k] == 0xFF;
+                    b->missing[i] = miss;
+                }
+            });
+            b->seq_off.resize(n + 1);
+            b->qual_off.resize(n + 1);
         }
-        // BAM: absent qualities are l_seq bytes of 0xFF (spec 4.2.3); noodles yields no scores
-        bool missing = l > 0;
-        for (uint32_t k = 0; k < l && missing; k++) missing = ql[k] == 0xFF;
-        if (fixed) {
-            memcpy(b->seq.data() + (size_t)pitch_s * i, sq, (l + 1) / 2);
-            if (!missing) memcpy(b->qual.data() + (size_t)pitch_q * i, ql, l);
-        } else {
-            b->seq_off[i] = so;
-            memcpy(b->seq.data() + so, sq, (l + 1) / 2);
-            so += (l + 1) / 2;
-            b->qual_off[i] = qo;
-            if (!missing) {
-                memcpy(b->qual.data() + qo, ql, l);
-                qo += l;
+        if (!cig1) b->cigar_off.resize(n + 1);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint8_t *r = D + recs[i] + 4;
+            const uint32_t n_ops = rd16(r + 12), l = rd32(r + 16);
+            if (!fixed) {
+                b->seq_off[i] = so;
+                b->qual_off[i] = qo;
+                so += (l + 1) / 2;
+                if (!b->missing[i]) qo += l;
+            }
+            if (!cig1) {
+                b->cigar_off[i] = co;
+                co += n_ops;
             }
         }
     }
+    uint8_t *const SEQ = b->seq.reserve(fixed ? (size_t)pitch_s * n + 64 : (size_t)so + 64);
+    uint8_t *const QUAL = b->qual.reserve(fixed ? (size_t)pitch_q * n + 64 : (size_t)qo + 64);
+    b->cigar.resize((cig1 ? n : co) + 16);
+    parallel_for(b->n_threads, n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint8_t *r = D + recs[i] + 4;
+            const uint32_t l_read_name = r[8], n_ops = rd16(r + 12), l = rd32(r + 16);
+            b->ref_id[i] = (int32_t)rd32(r);
+            b->pos[i] = (int32_t)rd32(r + 4);
+            b->mapq[i] = r[9];
+            b->n_cigar[i] = (uint16_t)n_ops;
+            b->flag[i] = rd16(r + 14);
+            b->l_seq[i] = l;
+            b->mate_ref_id[i] = (int32_t)rd32(r + 20);
+            b->tlen[i] = (int32_t)rd32(r + 28);
+            const uint8_t *cg = r + 32 + l_read_name;
+            const uint8_t *sq = cg + 4ull * n_ops;
+            const uint8_t *ql = sq + (l + 1) / 2;
+            if (cig1) {
+                b->cigar[i] = n_ops ? rd32(cg) : 0u;
+            } else {
+                const uint64_t c0 = b->cigar_off[i];
+                for (uint32_t k = 0; k < n_ops; k++) b->cigar[c0 + k] = rd32(cg + 4 * k);
+            }
+            if (fixed) {
+                // rows padded here: zero nibbles for SEQ, 0xFF ("no score") for QUAL; an absent-quality
+                // record is already a row of 0xFF in the file
+                uint8_t *srow = SEQ + (size_t)pitch_s * i, *qrow = QUAL + (size_t)pitch_q * i;
+                memcpy(srow, sq, (l + 1) / 2);
+                memset(srow + (l + 1) / 2, 0, pitch_s - (l + 1) / 2);
+                memcpy(qrow, ql, l);
+                memset(qrow + l, 0xFF, pitch_q - l);
+            } else {
+                memcpy(SEQ + b->seq_off[i], sq, (l + 1) / 2);
+                if (!b->missing[i]) memcpy(QUAL + b->qual_off[i], ql, l);
+            }
+        }
+    });
+    memset(SEQ + (fixed ? (size_t)pitch_s * n : (size_t)so), 0, 64);     // slack read by the device's vector loads
+    memset(QUAL + (fixed ? (size_t)pitch_q * n : (size_t)qo), 0xFF, 64);
     b->data_pos += cursor;
     b->n_read += n;
     out->n_records = n;
@@ -360,8 +414,8 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     out->tlen = b->tlen.data();
     out->l_seq = b->l_seq.data();
     out->n_cigar = b->n_cigar.data();
-    out->seq = b->seq.data();
-    out->qual = b->qual.data();
+    out->seq = b->seq.p;
+    out->qual = b->qual.p;
     out->cigar = b->cigar.data();
     if (fixed) {
         out->seq_stride = pitch_s;

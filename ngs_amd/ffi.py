@@ -216,6 +216,7 @@ PROTOTYPES = {
     "ngsq_gc_offset": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32]),
     "ngsq_synth_sizes": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, u64p, u64p, u64p]),
     "ngsq_synth_fill_host": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
+    "ngsq_synth_write_bam": (C.c_int, [C.POINTER(SynthConfig), C.c_char_p, C.c_uint64, C.c_int, C.c_int]),
     "ngsq_bam_last_error": (C.c_char_p, []),
     "ngsq_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ngsq_bam_close": (None, [C.c_void_p]),

@@ -120,3 +120,18 @@ def test_empty_bam(lib, tmp_path):
     bamio.write_bam(p, random_batch(np.random.default_rng(0), 0, [100]), ["chr1"], [100])
     refs, batches, n = read_all(lib, p, 100)
     assert refs == [("chr1", 100)] and batches == [] and n == 0
+
+
+def test_synthetic_bam_writer_round_trip(lib, tmp_path):
+    """ngsq_synth_write_bam -> ngsq_bam_next_batch gives back exactly the generator's records."""
+    for mode in (ffi.SYNTH_FIXED, ffi.SYNTH_MIXED):
+        cfg = host.synth_config(20_000, mode=mode, ref_len=3_000_000)
+        p = str(tmp_path / f"s{mode}.bam")
+        assert lib.ngsq_synth_write_bam(C.byref(cfg), p.encode(), 20_000, 1, 4) == 0
+        assert lib.ngsq_bam_check_index(p.encode()) == 0
+        refs, batches, n = read_all(lib, p, 7000)
+        assert n == 20_000 and refs[0] == ("chr1", 3_000_000)
+        got = [r for b in batches for r in records_of(b)]
+        assert got == records_of(host.synth_host_batch(cfg, 0, 20_000, lib))
+        if mode == ffi.SYNTH_FIXED:
+            assert batches[0].qual_stride == 150 and batches[0].cigar_stride == 1
