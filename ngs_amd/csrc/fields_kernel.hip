@@ -77,6 +77,9 @@ __device__ __forceinline__ uint32_t slot_counter(uint32_t slot) {
                         : C_ERR + E_BAD_CIGAR;
 }
 
+// CIG_OFF: CIGARs addressed through cigar_off (a compile-time choice: a conditional load in the
+// tile loop would make hipcc drain the in-order vmcnt queue, i.e. the prefetch, on every tile)
+template <bool CIG_OFF>
 __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, DeviceBatch b, FieldsArgs a) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *const s_tlen = s_dyn;                                 // tlen_cap + 1
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
     u64 t_lo = ~0ull, t_hi = 0; // entries of the depth block this thread has written: [t_lo, t_hi)
 
     const uint64_t n_tiles = (b.n + FT_TILE - 1) / FT_TILE;
-    const bool cigar_vec = b.cigar_off == nullptr && b.cigar_stride == 1;
+    const bool cigar_vec = !CIG_OFF && b.cigar_stride == 1;
 
     auto load_tile = [&](uint64_t tile) -> FtRaw {
         // full tiles only: every column with one aligned vector load per thread
@@ -181,12 +184,16 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         uint32_t win_base = 0;
         uint64_t win_off = NO_DEPTH, win_L = 0;
         if (a.do_cov) {
-            const int32_t fr = __shfl(ref[0], 0, 64), fp = __shfl(pos[0], 0, 64);
+            const int32_t fr = __builtin_amdgcn_readfirstlane(ref[0]), fp = __builtin_amdgcn_readfirstlane(pos[0]);
             if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
-                if (fr != meta_ref) {
+                if (fr != meta_ref) { // wave-uniform branch; the loaded facts leave it in scalar registers,
+                                      // so the join needs no vmcnt wait (which would drain the prefetch)
+                    const uint64_t o = st.ref_depth_off[fr];
+                    const uint32_t l = st.ref_len[fr];
                     meta_ref = fr;
-                    meta_off = st.ref_depth_off[fr];
-                    meta_L = st.ref_len[fr];
+                    meta_off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o);
+                    meta_L = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
                 }
                 win_off = meta_off;
                 win_L = meta_L;
@@ -244,7 +251,8 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 const uint32_t n_ops = ncig[j];
                 const uint32_t r1 = (f >> 6) & 1u; // first segment -> "read one"
                 uint64_t span = 0;
-                const uint64_t cbase = b.cigar_off ? b.cigar_off[r0 + j] : (r0 + j) * (uint64_t)b.cigar_stride;
+                uint64_t cbase = (r0 + j) * (uint64_t)b.cigar_stride;
+                if (CIG_OFF) cbase = b.cigar_off[r0 + j];
                 for (uint32_t k = 0; k < n_ops; k++) {
                     const uint32_t cg = (cigar_vec && k == 0) ? cig1[j] : b.cigar[cbase + k];
                     const uint32_t op = cg & 0xFu, len = cg >> 4;
@@ -265,40 +273,41 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 if (a.do_cov) {
                     const int32_t rf = ref[j];
                     const int32_t ps = pos[j];
-                    if (rf >= 0 && (uint32_t)rf < st.n_refs && ps >= 0) {
-                        uint64_t off = win_off, L = win_L;
-                        if (rf != win_ref) {
-                            off = st.ref_depth_off[rf];
-                            L = st.ref_len[rf];
-                        }
+                    // one record's range-add; `in_seq` = it lies on the window's sequence
+                    auto cover = [&](uint64_t off, uint64_t L, bool in_seq) {
                         const uint64_t s = (uint64_t)ps + 1, e = s + span - 1;
                         // noodles query(): alignment_end must be Some (>= 1) and [s,e] must meet [1,L]
-                        if (off != NO_DEPTH && e != 0 && s <= L) {
-                            if (rf != seen_ref) {
-                                if (seen_cnt) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
-                                seen_ref = rf;
-                                seen_cnt = 0;
-                            }
-                            seen_cnt += 1;
-                            const uint64_t ec = e < L ? e : L;
-                            nonsensical += e - ec; // coverage.rs:163-176: one per position > L
-                            if (s <= ec) {
-                                const uint64_t i0 = s - win_base, i1 = ec + 1 - win_base;
-                                if (rf == win_ref && s >= win_base && i1 < FT_WINDOW) {
-                                    atomicAdd(&win[i0], 1u);
-                                    atomicAdd(&win[i1], 0xFFFFFFFFu);
-                                    my_max = max(my_max, (uint32_t)i1);
-                                } else { // outside the window: straight to the arrays
-                                    const uint64_t g0 = off + s, g1 = off + ec + 1;
-                                    atomicAdd(&st.depth[g0], 1u);
-                                    atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
-                                    fb = true;
-                                    t_lo = g0 < t_lo ? g0 : t_lo;
-                                    t_hi = g1 + 1 > t_hi ? g1 + 1 : t_hi;
-                                    fb_c0 = (uint32_t)(g0 / COV_CHUNK);
-                                    fb_c1 = (uint32_t)(g1 / COV_CHUNK);
-                                }
-                            }
+                        if (off == NO_DEPTH || e == 0 || s > L) return;
+                        if (rf != seen_ref) {
+                            if (seen_cnt) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+                            seen_ref = rf;
+                            seen_cnt = 0;
+                        }
+                        seen_cnt += 1;
+                        const uint64_t ec = e < L ? e : L;
+                        nonsensical += e - ec; // coverage.rs:163-176: one per position > L
+                        if (s > ec) return;
+                        const uint64_t i0 = s - win_base, i1 = ec + 1 - win_base;
+                        if (in_seq && s >= win_base && i1 < FT_WINDOW) {
+                            atomicAdd(&win[i0], 1u);
+                            atomicAdd(&win[i1], 0xFFFFFFFFu);
+                            my_max = max(my_max, (uint32_t)i1);
+                        } else { // outside the window: straight to the arrays
+                            const uint64_t g0 = off + s, g1 = off + ec + 1;
+                            atomicAdd(&st.depth[g0], 1u);
+                            atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
+                            fb = true;
+                            t_lo = g0 < t_lo ? g0 : t_lo;
+                            t_hi = g1 + 1 > t_hi ? g1 + 1 : t_hi;
+                            fb_c0 = (uint32_t)(g0 / COV_CHUNK);
+                            fb_c1 = (uint32_t)(g1 / COV_CHUNK);
+                        }
+                    };
+                    if (rf >= 0 && (uint32_t)rf < st.n_refs && ps >= 0) {
+                        if (rf == win_ref) {
+                            cover(win_off, win_L, true);
+                        } else { // another sequence: its facts are loaded and consumed inside this branch
+                            cover(st.ref_depth_off[rf], st.ref_len[rf], false);
                         }
                     }
                 }
@@ -326,12 +335,22 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 const uint32_t c0 = (uint32_t)(goff / COV_CHUNK);
                 const uint32_t split = (uint32_t)((uint64_t)(c0 + 1) * COV_CHUNK - goff); // first entry of chunk c0+1
                 uint32_t sa = 0, sb = 0;
-                for (uint32_t i = lane; i <= top; i += 64) {
-                    const uint32_t v = win[i];
-                    if (v) {
-                        atomicAdd(&dst[i], v);
-                        win[i] = 0;
-                        if (i < split) sa += v; else sb += v;
+                // four independent LDS reads in flight per pass (entries past `top` are zero)
+                for (uint32_t ib = 0; ib <= top; ib += 256) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t i = ib + 64 * k + lane;
+                        v[k] = i < FT_WINDOW ? win[i] : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t i = ib + 64 * k + lane;
+                        if (v[k]) {
+                            atomicAdd(&dst[i], v[k]);
+                            win[i] = 0;
+                            if (i < split) sa += v[k]; else sb += v[k];
+                        }
                     }
                 }
                 sa = ft_wave_sum(sa);
@@ -432,15 +451,21 @@ hipError_t launch_fields(const LaunchInfo &li, const DeviceState &st, const Devi
     const size_t lds = (((size_t)st.tlen_cap + 1 + 3) & ~(size_t)3) * 4 + (coverage ? (FT_THREADS / 64) * FT_WINDOW * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fields),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fields<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fields<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
     uint64_t g = (b.n + FT_TILE - 1) / FT_TILE;
     const uint64_t cap = (uint64_t)li.n_cu * 4;
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(k_fields, dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
+    if (b.cigar_off)
+        hipLaunchKernelGGL(k_fields<true>, dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
+    else
+        hipLaunchKernelGGL(k_fields<false>, dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
     return hipGetLastError();
 }
 

@@ -48,12 +48,11 @@ template <uint32_t R, uint32_t NROT>
 __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t *__restrict__ qual, uint64_t n_rec,
                                                    uint32_t pitch) {
     constexpr uint32_t RP = qw_rp(R), CP = qw_cp(R), CP4 = CP * 4, RP4 = RP * 4;
+    constexpr uint32_t S4 = 4u * RP4; // table bytes between the first entries of two consecutive dwords of a window
     constexpr uint32_t magicR = R == 1 ? 0u : (uint32_t)(((1ull << 32) + R - 1) / R);
-    extern __shared__ uint32_t s_q[]; // QUAL_BINS x CP words
-    __shared__ u64 s_acc[1];
+    extern __shared__ uint32_t s_q[]; // QUAL_BINS x CP words; the ONLY LDS object, so table offsets are LDS addresses
     constexpr uint32_t nb = QUAL_BINS * CP;
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_q[i] = 0;
-    if (threadIdx.x == 0) s_acc[0] = 0;
     __syncthreads();
 
     const uint32_t rem = pitch - 16u * (R - 1); // bytes of the last window that belong to the row
@@ -61,22 +60,18 @@ __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t
     const uint64_t per = (n_win + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = min(per * blockIdx.x, n_win), hi = min(lo + per, n_win);
     const uint64_t rec_lo = lo / R;
-    // block-local (record, window) of this thread's first window; advanced incrementally
+    // block-local (record, window) of this thread's first window
     const uint32_t tl0 = (uint32_t)(lo - rec_lo * R) + threadIdx.x; // < R + 1024: magic division exact
-    uint32_t rl = R == 1 ? tl0 : __umulhi(tl0, magicR);
-    uint32_t w = tl0 - rl * R;
+    const uint32_t rl0 = R == 1 ? tl0 : __umulhi(tl0, magicR);
+    uint32_t w = tl0 - rl0 * R;
+    uint32_t rot = rl0 & 3u; // dword order of this record (advanced with the record index)
     constexpr uint32_t STEP_R = 1024 / R, STEP_W = 1024 % R; // blockDim.x == 1024
-    uint32_t bad[1] = {0};
+    // the thread's window address advances by a fixed number of bytes per pass (+ one row tail on a wrap)
+    const uint32_t d0 = STEP_R * pitch + 16u * STEP_W, d1 = d0 + pitch - 16u * R;
+    const uint8_t *p = qual + (rec_lo + rl0) * (uint64_t)pitch + 16u * w;
+    uint32_t bad = 0;
     char *const tab = reinterpret_cast<char *>(s_q);
 
-    // The hot loop never touches the last window of the whole buffer (its 16-byte load
-    // would run past the allocation); that single window is tallied exactly below.
-    const uint64_t hi_fast = min(hi, n_win - 1);
-    auto load = [&](uint32_t rl_, uint32_t w_) -> uint4 {
-        uint4 v;
-        __builtin_memcpy(&v, qual + (rec_lo + rl_) * (uint64_t)pitch + 16u * w_, 16); // one unaligned dwordx4
-        return v;
-    };
     auto exact = [&](const uint32_t (&x)[4], uint32_t w_) {
         // 0xFF = no score at this cycle (ngsq.h), 94..254 = decode error
         const uint32_t nvalid = (w_ == R - 1) ? rem : 16u;
@@ -85,64 +80,41 @@ __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t
             if (q <= NGSQ_MAX_SCORE)
                 atomicAdd(reinterpret_cast<uint32_t *>(tab + q * CP4 + 4u * w_ + j * RP4), 1u);
             else if (q != 0xFFu)
-                bad[0] += 1;
+                bad += 1;
         }
     };
-
-    uint64_t t = lo + threadIdx.x;
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    if (t < hi_fast) cur = load(rl, w);
-    while (t < hi_fast) {
-        // ---- prefetch the next window of this thread
-        uint32_t rl_n = rl + STEP_R, w_n = w + STEP_W;
-        if (w_n >= R) {
-            w_n -= R;
-            rl_n += 1;
-        }
-        const uint64_t t_n = t + 1024;
-        // unconditional (branch-free) prefetch: past the end re-read the current window
-        const bool more = t_n < hi_fast;
-        const uint4 nxt = load(more ? rl_n : rl, more ? w_n : w);
-
+    // one 16-byte window: 2 VALU operations + one ds_add per byte on the fast path
+    auto tally = [&](const uint4 &cur, uint32_t w_, uint32_t rot_) {
         const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
-        const uint32_t wbase = 4u * w;
         // any byte >= 64 (bit 6 or 7)?  Then it may be 0xFF / invalid: exact path.
         const uint32_t any = (ww[0] | ww[1] | ww[2] | ww[3]) & 0xC0C0C0C0u;
         if (__builtin_expect(any == 0u, 1)) {
-            // every byte is a score < 64.  Bytes of the last window that lie beyond the row
-            // are the next row's leading scores: they fall into cells of cycles >= pitch,
-            // which exist in the table but are never read back.
+            // every byte is a score < 64.  Bytes of the last window that lie beyond the row are the
+            // next row's leading scores: they fall into cells of cycles >= pitch, which exist in the
+            // table but are never read back.
+            const uint32_t wbase = 4u * w_;
             uint32_t x[4], bd[4];
             if (NROT == 1) {
 #pragma unroll
                 for (uint32_t d = 0; d < 4; d++) {
                     x[d] = ww[d];
-                    bd[d] = wbase + d * (4u * RP4);
+                    bd[d] = wbase + d * S4;
                 }
-            } else if (NROT == 2) {
-                const bool sw = rl & 1u;
-                x[0] = sw ? ww[2] : ww[0];
-                x[1] = sw ? ww[3] : ww[1];
-                x[2] = sw ? ww[0] : ww[2];
-                x[3] = sw ? ww[1] : ww[3];
-                const uint32_t b0 = wbase + (sw ? 8u * RP4 : 0u), b2 = wbase + (sw ? 0u : 8u * RP4);
-                bd[0] = b0;
-                bd[1] = b0 + 4u * RP4;
-                bd[2] = b2;
-                bd[3] = b2 + 4u * RP4;
             } else {
-                // step d takes dword (d + rot) & 3 of the window: two-level barrel rotate
-                const uint32_t rot = rl & 3u;
-                const bool by2 = rot & 2u, by1 = rot & 1u;
-                const uint32_t y0 = by2 ? ww[2] : ww[0], y1 = by2 ? ww[3] : ww[1], y2 = by2 ? ww[0] : ww[2],
-                               y3 = by2 ? ww[1] : ww[3];
-                x[0] = by1 ? y1 : y0;
-                x[1] = by1 ? y2 : y1;
-                x[2] = by1 ? y3 : y2;
-                x[3] = by1 ? y0 : y3;
-                const uint32_t b_rot = __umul24(rot, 4u * RP4) + wbase, b_wrap = b_rot - 16u * RP4;
-#pragma unroll
-                for (uint32_t d = 0; d < 4; d++) bd[d] = (rot + d >= 4u ? b_wrap : b_rot) + d * (4u * RP4);
+                // step d takes dword d ^ rot of the window (a bijection in d and in rot): lanes of the
+                // up to four records of a 32-lane group never update the same table word in one instruction
+                const bool r1 = rot_ & 1u, r2 = (NROT == 4) && (rot_ & 2u);
+                const uint32_t y0 = r2 ? ww[2] : ww[0], y1 = r2 ? ww[3] : ww[1], y2 = r2 ? ww[0] : ww[2],
+                               y3 = r2 ? ww[1] : ww[3];
+                x[0] = r1 ? y1 : y0;
+                x[1] = r1 ? y0 : y1;
+                x[2] = r1 ? y3 : y2;
+                x[3] = r1 ? y2 : y3;
+                const uint32_t h = r2 ? 2u * S4 : 0u, l = r1 ? S4 : 0u;
+                bd[0] = wbase + h + l;
+                bd[1] = wbase + h + (S4 - l);
+                bd[2] = wbase + (2u * S4 - h) + l;
+                bd[3] = wbase + (2u * S4 - h) + (S4 - l);
             }
 #pragma unroll
             for (uint32_t d = 0; d < 4; d++) {
@@ -153,15 +125,39 @@ __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t
                 }
             }
         } else {
-            exact(ww, w);
+            exact(ww, w_);
         }
-        cur = nxt;
-        rl = rl_n;
-        w = w_n;
-        t = t_n;
+    };
+    auto load = [&](const uint8_t *q) -> uint4 {
+        uint4 v;
+        __builtin_memcpy(&v, q, 16); // one unaligned global_load_dwordx4
+        return v;
+    };
+
+    // The hot loop never touches the last window of the whole buffer (its 16-byte load would run
+    // past the allocation); that single window is tallied exactly below.
+    const uint64_t hi_fast = min(hi, n_win - 1);
+    uint64_t t = lo + threadIdx.x;
+    if (t < hi_fast) {
+        uint4 cur = load(p);
+        // main loop: the next window of this thread exists, so the prefetch needs no guard
+        while (t + 1024 < hi_fast) {
+            uint32_t w_n = w + STEP_W;
+            const bool wrap = w_n >= R;
+            w_n = wrap ? w_n - R : w_n;
+            p += wrap ? d1 : d0;
+            const uint4 nxt = load(p);
+            tally(cur, w, rot);
+            cur = nxt;
+            w = w_n;
+            rot = (rot + STEP_R + (wrap ? 1u : 0u)) & 3u;
+            t += 1024;
+        }
+        tally(cur, w, rot);
+        t += 1024;
     }
     // the last window of the buffer, byte by byte, by the thread that owns it
-    if (hi == n_win && n_win > 0 && t == n_win - 1) {
+    if (hi == n_win && n_win > 0 && (n_win - 1 - lo) % 1024 == threadIdx.x && n_win - 1 >= lo) {
         uint32_t x[4] = {0, 0, 0, 0};
         const uint64_t off = (n_rec - 1) * (uint64_t)pitch + 16u * (R - 1);
         for (uint32_t k = 0; k < rem; k++) x[k >> 2] |= (uint32_t)qual[off + k] << (8 * (k & 3));
@@ -175,13 +171,166 @@ __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t
         const uint32_t v = s_q[q * CP + (c & 15u) * RP + (c >> 4)];
         if (v) atomicAdd(&st.counters[st.off_qual + i], (u64)v);
     }
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t r = bad[0];
+    uint32_t r = bad;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o, 64);
-    if (lane == 0 && r) atomicAdd(&s_acc[0], (u64)r);
+    if ((threadIdx.x & 63) == 0 && r) atomicAdd(&st.counters[C_ERR + E_BAD_QUAL], (u64)r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_qual_perm: rows of up to 256 bytes (R <= 16 windows).  One VALU operation per byte.
+//
+// LDS table of 64 scores x 4 dword planes x 64 words (64 KiB, two blocks per CU):
+//     byte address(q, cycle c = 16 w + 4 d + k) = d * 16384 + q * 256 + w * 16 + k * 4
+// so the address of byte k of dword d is  { byte1 = the score, byte0 = w*16 + k*4 }  + immediate
+// d*16384: ONE v_perm_b32 assembles it from the data dword and a per-lane register holding the
+// four byte-0 values.  The bank, (w*4 + k) mod 32, never depends on the score.  Scores 64..93 (never
+// seen on this path's short-read rows in practice) and 0xFF cells take the exact path: LDS for
+// q < 64, a global atomic otherwise.
+// Lanes that hold the same window w in one wave are R lanes apart; each takes the four bytes of a
+// dword in an order rotated by (lane / R) & 3, a per-lane constant folded into the v_perm selectors,
+// so they never update the same table word in one instruction.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t QP_MAX_R = 16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+constexpr uint32_t QP_LDS_BYTES = 64 * 1024;
+
+template <uint32_t R>
+__global__ __launch_bounds__(1024) void k_qual_perm(DeviceState st, const uint8_t *__restrict__ qual, uint64_t n_rec,
+                                                    uint32_t pitch) {
+    static_assert(R >= 1 && R <= QP_MAX_R, "window index must fit the low byte of a table address");
+    constexpr uint32_t magicR = R == 1 ? 0u : (uint32_t)(((1ull << 32) + R - 1) / R);
+    extern __shared__ uint32_t s_q[]; // the ONLY LDS object: table offsets are LDS addresses
+    if (reinterpret_cast<uintptr_t>((lds_u32 *)s_q) != 0) __builtin_trap();
+    for (uint32_t i = threadIdx.x; i < QP_LDS_BYTES / 4; i += blockDim.x) s_q[i] = 0;
     __syncthreads();
-    if (threadIdx.x == 0 && s_acc[0]) atomicAdd(&st.counters[C_ERR + E_BAD_QUAL], s_acc[0]);
+
+    const uint32_t rem = pitch - 16u * (R - 1); // bytes of the last window that belong to the row
+    const uint64_t n_win = n_rec * R;
+    const uint64_t per = (n_win + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = min(per * blockIdx.x, n_win), hi = min(lo + per, n_win);
+    const uint64_t rec_lo = lo / R;
+    const uint32_t tl0 = (uint32_t)(lo - rec_lo * R) + threadIdx.x; // < R + 1024: magic division exact
+    const uint32_t rl0 = R == 1 ? tl0 : __umulhi(tl0, magicR);
+    uint32_t w = tl0 - rl0 * R;
+    constexpr uint32_t STEP_R = 1024 / R, STEP_W = 1024 % R; // blockDim.x == 1024
+    // the thread's window address advances by a fixed number of bytes per pass (+ one row tail on a wrap)
+    const uint32_t d0 = STEP_R * pitch + 16u * STEP_W, d1 = d0 + pitch - 16u * R;
+    const uint8_t *p = qual + (rec_lo + rl0) * (uint64_t)pitch + 16u * w;
+    uint32_t bad = 0;
+    char *const tab = reinterpret_cast<char *>(s_q);
+
+    // byte order of this lane and the four selectors { 0, 0, data byte kk, cvec byte kk }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rb = (R == 1 ? lane : __umulhi(lane, magicR)) & 3u;
+    uint32_t sel[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t kk = (k + rb) & 3u;
+        sel[k] = 0x0C0C0000u | ((4u + kk) << 8) | kk;
+    }
+    // byte j = low address byte of byte j of a dword of window w
+    uint32_t cvec = w * 0x10101010u + 0x0C080400u;
+
+    auto exact = [&](const uint32_t (&x)[4], uint32_t w_) {
+        // 0xFF = no score at this cycle (ngsq.h), 94..254 = decode error
+        const uint32_t nvalid = (w_ == R - 1) ? rem : 16u;
+        for (uint32_t j = 0; j < nvalid; j++) {
+            const uint32_t q = (x[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            if (q < 64u)
+                atomicAdd(reinterpret_cast<uint32_t *>(tab + (j >> 2) * 16384u + q * 256u + w_ * 16u + (j & 3u) * 4u),
+                          1u);
+            else if (q <= NGSQ_MAX_SCORE)
+                atomicAdd(&st.counters[st.off_qual + (uint64_t)(16u * w_ + j) * QUAL_BINS + q], (u64)1);
+            else if (q != 0xFFu)
+                bad += 1;
+        }
+    };
+    auto tally = [&](const uint4 &cur, uint32_t w_, uint32_t cvec_) {
+        const uint32_t x[4] = {cur.x, cur.y, cur.z, cur.w};
+        // any byte >= 64 (bit 6 or 7)?  Then it may be 0xFF / a high or invalid score: exact path.
+        const uint32_t any = (x[0] | x[1] | x[2] | x[3]) & 0xC0C0C0C0u;
+        if (__builtin_expect(any == 0u, 1)) {
+            // Bytes of the last window that lie beyond the row are the next row's leading scores:
+            // they fall into cells of cycles >= pitch, which exist in the table but are never read back.
+#pragma unroll
+            for (uint32_t d = 0; d < 4; d++) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    // LDS address straight from the integer (the table starts at LDS offset 0)
+                    const uint32_t a = __builtin_amdgcn_perm(x[d], cvec_, sel[k]);
+                    lds_u32 *cell = reinterpret_cast<lds_u32 *>(a) + d * 4096u;
+                    __hip_atomic_fetch_add(cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        } else {
+            exact(x, w_);
+        }
+    };
+    auto load = [&](const uint8_t *q) -> uint4 {
+        uint4 v;
+        __builtin_memcpy(&v, q, 16); // one unaligned global_load_dwordx4
+        return v;
+    };
+
+    // The hot loop never touches the last window of the whole buffer (its 16-byte load would run
+    // past the allocation); that single window is tallied exactly below.
+    const uint64_t hi_fast = min(hi, n_win - 1);
+    uint64_t t = lo + threadIdx.x;
+    if (t < hi_fast) {
+        uint4 cur = load(p);
+        // main loop: the next window of this thread exists, so the prefetch needs no guard
+        while (t + 1024 < hi_fast) {
+            uint32_t w_n = w + STEP_W;
+            const bool wrap = w_n >= R;
+            w_n = wrap ? w_n - R : w_n;
+            p += wrap ? d1 : d0;
+            const uint4 nxt = load(p);
+            tally(cur, w, cvec);
+            cur = nxt;
+            cvec += wrap ? (STEP_W - R) * 0x10101010u : STEP_W * 0x10101010u;
+            w = w_n;
+            t += 1024;
+        }
+        tally(cur, w, cvec);
+    }
+    // the last window of the buffer, byte by byte, by the thread that owns it
+    if (hi == n_win && n_win > 0 && n_win - 1 >= lo && (n_win - 1 - lo) % 1024 == threadIdx.x) {
+        uint32_t x[4] = {0, 0, 0, 0};
+        const uint64_t off = (n_rec - 1) * (uint64_t)pitch + 16u * (R - 1);
+        for (uint32_t k = 0; k < rem; k++) x[k >> 2] |= (uint32_t)qual[off + k] << (8 * (k & 3));
+        exact(x, R - 1);
+    }
+    __syncthreads();
+    // flush in table order (conflict-free reads): word i = d*4096 + q*64 + w*4 + k
+    for (uint32_t i = threadIdx.x; i < QP_LDS_BYTES / 4; i += blockDim.x) {
+        const uint32_t v = s_q[i];
+        if (v) {
+            const uint32_t d = i >> 12, q = (i >> 6) & 63u, c = ((i >> 2) & 15u) * 16u + d * 4u + (i & 3u);
+            if (c < pitch) atomicAdd(&st.counters[st.off_qual + (uint64_t)c * QUAL_BINS + q], (u64)v);
+        }
+    }
+    uint32_t r = bad;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o, 64);
+    if ((threadIdx.x & 63) == 0 && r) atomicAdd(&st.counters[C_ERR + E_BAD_QUAL], (u64)r);
+}
+
+template <uint32_t R>
+static hipError_t launch_perm(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_perm<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)QP_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    uint64_t g = (b.n * R + 1023) / 1024;
+    if (g > (uint64_t)li.n_cu * 2) g = (uint64_t)li.n_cu * 2;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((k_qual_perm<R>), dim3((uint32_t)g), dim3(1024), QP_LDS_BYTES, s, st, b.qual, b.n,
+                       b.qual_stride);
+    return hipGetLastError();
 }
 
 template <uint32_t R, uint32_t NROT>
@@ -222,6 +371,14 @@ bool qual_window_supported(const DeviceState &st, const DeviceBatch &b) {
 hipError_t launch_qual_window(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint32_t nrot,
                               hipStream_t s) {
     const uint32_t R = (b.qual_stride + 15) / 16;
+    switch (R) {
+#define CASE(r) \
+    case r: return launch_perm<r>(li, st, b, s);
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+        CASE(14) CASE(15) CASE(16)
+#undef CASE
+    default: break;
+    }
     switch (nrot) {
     case 1: return dispatch<1>(R, li, st, b, s);
     case 2: return dispatch<2>(R, li, st, b, s);
