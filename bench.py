@@ -154,7 +154,7 @@ def main() -> int:
         if q["launches"] and q["total_ms"] > 0:
             avg_ms = q["total_ms"] / q["launches"]
             achieved = (q["algo_bytes"] / q["launches"]) / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_qual", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            roofline = {"bound": "hbm", "kernel": "k_qual_perm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_ms": round(avg_ms, 4),
                         "algo_bytes_per_launch": q["algo_bytes"] // q["launches"]}
@@ -209,7 +209,7 @@ def pmc_traffic(n: int, args):
         with open(files[-1]) as f:
             doc = json.load(f)
         for name, v in doc["kernels"].items():
-            if "k_qual_win" in name:
+            if "k_qual_perm" in name or "k_qual_win" in name:
                 return v["hbm_bytes_corrected"], os.path.relpath(files[-1], ROOT)
     except Exception as e:  # noqa: BLE001
         return None, f"unreadable: {e}"

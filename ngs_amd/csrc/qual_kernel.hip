@@ -3,24 +3,30 @@
 //     for (i, val) in record.quality_scores() { scores[i + 1][val] += 1 }
 //
 // This is the dominant kernel of the `ngs qc` scan: 150 of the 254 algorithmic
-// bytes per 150 bp record.  Design (measurements: tools/micro_qual.hip):
+// bytes per 150 bp record.  Two kernels (measurements: DESIGN.md section 4):
 //
-//  * thread = one 16-byte WINDOW of one row: (record, w), cycles 16w .. 16w+15.
-//    Consecutive lanes hold consecutive windows, so a wave's global_load_dwordx4
+//  k_qual_perm  rows of up to 256 bytes.  thread = one 16-byte WINDOW (record, w) of
+//               a row, w fixed per thread; ONE v_perm_b32 per byte builds the LDS
+//               address of its (cycle, score) cell; see the comment above the kernel.
+//  k_qual_win   rows of 257..320 bytes (and the measurement knob NGSQ_QUAL_NROT):
+//               the same window-per-thread shape with a [q][kb * RP + w] table
+//               and two VALU operations per byte.
+//
+// Shared design points:
+//  * Consecutive lanes hold consecutive windows, so a wave's global_load_dwordx4
 //    covers 1 KiB of contiguous bytes (rows are dense: the load is unaligned by
 //    design, gfx950 serves it as one request per lane).
-//  * per-block LDS table [q][kb * RP + w] (q score, kb byte inside the window,
-//    w window; row pitch CP = multiple of 32 words).  The bank of an update
-//    depends only on (kb, w) -- never on the score -- so skewed real-world score
-//    distributions cannot serialise the LDS atomics.  Address = q*CP4 + lane
-//    base + immediate: two VALU operations per byte.
-//  * lanes of different records in one wave hold the same window w; taking the
-//    four dwords in an order rotated by the record index (NROT positions) keeps
-//    them off the same table word in the same instruction.
-//  * one OR-filter per 16 bytes finds windows that may hold 0xFF (absent score)
+//  * The LDS bank of an update depends only on the cycle -- never on the score --
+//    so skewed real-world score distributions cannot serialise the LDS atomics.
+//  * Lanes of different records in one wave hold the same window w; taking the
+//    bytes in an order rotated by the record keeps them off the same table word
+//    in the same instruction.
+//  * One OR-filter per 16 bytes finds windows that may hold 0xFF (absent score)
 //    or an invalid score and sends only those lanes down the exact path.
-//  * next window prefetched while the current one is tallied.
+//  * Next window(s) prefetched while the current one is tallied.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -192,122 +198,134 @@ __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t
 // so they never update the same table word in one instruction.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t QP_MAX_R = 16;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
 constexpr uint32_t QP_LDS_BYTES = 64 * 1024;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-template <uint32_t R>
+// threads per block: the largest multiple of R up to 1024, so a thread keeps its window index w
+__host__ __device__ constexpr uint32_t qp_threads(uint32_t R) { return R * (1024u / R); }
+
+// exact tally of one window (rare: a 0xFF cell, a score >= 64 or an invalid byte in it)
+static __device__ __noinline__ uint32_t qp_exact(u64 *__restrict__ qual_counters, uint32_t x0, uint32_t x1, uint32_t x2,
+                                                 uint32_t x3, uint32_t w, uint32_t nvalid) {
+    const uint32_t x[4] = {x0, x1, x2, x3};
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < nvalid; j++) {
+        const uint32_t q = (x[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (q < 64u) {
+            lds_u32 *cell = reinterpret_cast<lds_u32 *>((j >> 2) * 16384u + q * 256u + w * 16u + (j & 3u) * 4u);
+            __hip_atomic_fetch_add(cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (q <= NGSQ_MAX_SCORE) {
+            atomicAdd(&qual_counters[(uint64_t)(16u * w + j) * QUAL_BINS + q], (u64)1);
+        } else if (q != 0xFFu) { // 0xFF = no score at this cycle (ngsq.h), 94..254 = decode error
+            bad += 1;
+        }
+    }
+    return bad;
+}
+
+template <uint32_t R, uint32_t D>
 __global__ __launch_bounds__(1024) void k_qual_perm(DeviceState st, const uint8_t *__restrict__ qual, uint64_t n_rec,
                                                     uint32_t pitch) {
     static_assert(R >= 1 && R <= QP_MAX_R, "window index must fit the low byte of a table address");
+    constexpr uint32_t T = qp_threads(R), RPB = T / R; // records per pass of the block
     constexpr uint32_t magicR = R == 1 ? 0u : (uint32_t)(((1ull << 32) + R - 1) / R);
     extern __shared__ uint32_t s_q[]; // the ONLY LDS object: table offsets are LDS addresses
     if (reinterpret_cast<uintptr_t>((lds_u32 *)s_q) != 0) __builtin_trap();
-    for (uint32_t i = threadIdx.x; i < QP_LDS_BYTES / 4; i += blockDim.x) s_q[i] = 0;
+    for (uint32_t i = threadIdx.x; i < QP_LDS_BYTES / 4; i += T) s_q[i] = 0;
     __syncthreads();
 
     const uint32_t rem = pitch - 16u * (R - 1); // bytes of the last window that belong to the row
-    const uint64_t n_win = n_rec * R;
-    const uint64_t per = (n_win + gridDim.x - 1) / gridDim.x;
-    const uint64_t lo = min(per * blockIdx.x, n_win), hi = min(lo + per, n_win);
-    const uint64_t rec_lo = lo / R;
-    const uint32_t tl0 = (uint32_t)(lo - rec_lo * R) + threadIdx.x; // < R + 1024: magic division exact
-    const uint32_t rl0 = R == 1 ? tl0 : __umulhi(tl0, magicR);
-    uint32_t w = tl0 - rl0 * R;
-    constexpr uint32_t STEP_R = 1024 / R, STEP_W = 1024 % R; // blockDim.x == 1024
-    // the thread's window address advances by a fixed number of bytes per pass (+ one row tail on a wrap)
-    const uint32_t d0 = STEP_R * pitch + 16u * STEP_W, d1 = d0 + pitch - 16u * R;
-    const uint8_t *p = qual + (rec_lo + rl0) * (uint64_t)pitch + 16u * w;
-    uint32_t bad = 0;
-    char *const tab = reinterpret_cast<char *>(s_q);
+    const uint32_t r0 = R == 1 ? threadIdx.x : __umulhi(threadIdx.x, magicR); // < RPB
+    const uint32_t w = threadIdx.x - r0 * R;
+    // each block streams one contiguous run of rows, RPB rows per pass
+    const uint64_t per = (n_rec + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = min(per * blockIdx.x, n_rec), hi = min(lo + per, n_rec);
+    const uint64_t step = (uint64_t)RPB * pitch;
+    const uint8_t *pf = qual + (lo + r0) * (uint64_t)pitch + 16u * w;
+    u64 *const qc = st.counters + st.off_qual;
 
-    // byte order of this lane and the four selectors { 0, 0, data byte kk, cvec byte kk }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rb = (R == 1 ? lane : __umulhi(lane, magicR)) & 3u;
+    // Lanes with the same w in a wave belong to consecutive records: rotate the byte order by the
+    // record.  Selector k = { 0, 0, data byte kk, cvec byte kk }.
     uint32_t sel[4];
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t kk = (k + rb) & 3u;
+        const uint32_t kk = (k + r0) & 3u;
         sel[k] = 0x0C0C0000u | ((4u + kk) << 8) | kk;
     }
     // byte j = low address byte of byte j of a dword of window w
-    uint32_t cvec = w * 0x10101010u + 0x0C080400u;
+    const uint32_t cvec = w * 0x10101010u + 0x0C080400u;
 
-    auto exact = [&](const uint32_t (&x)[4], uint32_t w_) {
-        // 0xFF = no score at this cycle (ngsq.h), 94..254 = decode error
-        const uint32_t nvalid = (w_ == R - 1) ? rem : 16u;
-        for (uint32_t j = 0; j < nvalid; j++) {
-            const uint32_t q = (x[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            if (q < 64u)
-                atomicAdd(reinterpret_cast<uint32_t *>(tab + (j >> 2) * 16384u + q * 256u + w_ * 16u + (j & 3u) * 4u),
-                          1u);
-            else if (q <= NGSQ_MAX_SCORE)
-                atomicAdd(&st.counters[st.off_qual + (uint64_t)(16u * w_ + j) * QUAL_BINS + q], (u64)1);
-            else if (q != 0xFFu)
-                bad += 1;
-        }
-    };
-    auto tally = [&](const uint4 &cur, uint32_t w_, uint32_t cvec_) {
-        const uint32_t x[4] = {cur.x, cur.y, cur.z, cur.w};
+    // passes of this thread; the very last window of the buffer is never loaded as 16 bytes (the
+    // load would run past the allocation): its owner stops one pass early and tallies it by bytes
+    uint32_t n_it = lo + r0 < hi ? (uint32_t)((hi - lo - r0 + RPB - 1) / RPB) : 0u;
+    const bool owns_last = n_it > 0 && w == R - 1 && lo + r0 + (uint64_t)(n_it - 1) * RPB == n_rec - 1;
+    if (owns_last) n_it -= 1;
+
+    uint32_t bad = 0;
+    auto tally = [&](const uint4 &v) {
         // any byte >= 64 (bit 6 or 7)?  Then it may be 0xFF / a high or invalid score: exact path.
-        const uint32_t any = (x[0] | x[1] | x[2] | x[3]) & 0xC0C0C0C0u;
+        const uint32_t any = (v.x | v.y | v.z | v.w) & 0xC0C0C0C0u;
         if (__builtin_expect(any == 0u, 1)) {
             // Bytes of the last window that lie beyond the row are the next row's leading scores:
             // they fall into cells of cycles >= pitch, which exist in the table but are never read back.
+            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t d = 0; d < 4; d++) {
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     // LDS address straight from the integer (the table starts at LDS offset 0)
-                    const uint32_t a = __builtin_amdgcn_perm(x[d], cvec_, sel[k]);
+                    const uint32_t a = __builtin_amdgcn_perm(x[d], cvec, sel[k]);
                     lds_u32 *cell = reinterpret_cast<lds_u32 *>(a) + d * 4096u;
                     __hip_atomic_fetch_add(cell, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         } else {
-            exact(x, w_);
+            bad += qp_exact(qc, v.x, v.y, v.z, v.w, w, w == R - 1 ? rem : 16u);
         }
     };
-    auto load = [&](const uint8_t *q) -> uint4 {
+    auto load = [&]() -> uint4 {
         uint4 v;
-        __builtin_memcpy(&v, q, 16); // one unaligned global_load_dwordx4
+        __builtin_memcpy(&v, pf, 16); // one unaligned global_load_dwordx4
+        pf += step;
         return v;
     };
 
-    // The hot loop never touches the last window of the whole buffer (its 16-byte load would run
-    // past the allocation); that single window is tallied exactly below.
-    const uint64_t hi_fast = min(hi, n_win - 1);
-    uint64_t t = lo + threadIdx.x;
-    if (t < hi_fast) {
-        uint4 cur = load(p);
-        // main loop: the next window of this thread exists, so the prefetch needs no guard
-        while (t + 1024 < hi_fast) {
-            uint32_t w_n = w + STEP_W;
-            const bool wrap = w_n >= R;
-            w_n = wrap ? w_n - R : w_n;
-            p += wrap ? d1 : d0;
-            const uint4 nxt = load(p);
-            tally(cur, w, cvec);
-            cur = nxt;
-            cvec += wrap ? (STEP_W - R) * 0x10101010u : STEP_W * 0x10101010u;
-            w = w_n;
-            t += 1024;
+    // D windows in flight per thread.  Pass i lives in register slot i % (D+1): a load never targets
+    // the slot being tallied, so the compiler needs no copies (and no vmcnt(0)) to rotate them.
+    constexpr uint32_t NB = D + 1;
+    uint4 buf[NB];
+#pragma unroll
+    for (uint32_t j = 0; j < D; j++)
+        if (j < n_it) buf[j] = load();
+    uint32_t done = 0;
+    for (; done + NB + D <= n_it; done += NB) {
+#pragma unroll
+        for (uint32_t j = 0; j < NB; j++) {
+            buf[(j + D) % NB] = load(); // pass done + j + D exists: no guard, nothing drains the queue
+            tally(buf[j]);
         }
-        tally(cur, w, cvec);
     }
-    // the last window of the buffer, byte by byte, by the thread that owns it
-    if (hi == n_win && n_win > 0 && n_win - 1 >= lo && (n_win - 1 - lo) % 1024 == threadIdx.x) {
+#pragma unroll
+    for (uint32_t j = 0; j < NB + D; j++) {
+        if (done + j < n_it) {
+            if (done + j + D < n_it) buf[(j + D) % NB] = load();
+            tally(buf[j % NB]);
+        }
+    }
+
+    if (owns_last) {
         uint32_t x[4] = {0, 0, 0, 0};
         const uint64_t off = (n_rec - 1) * (uint64_t)pitch + 16u * (R - 1);
         for (uint32_t k = 0; k < rem; k++) x[k >> 2] |= (uint32_t)qual[off + k] << (8 * (k & 3));
-        exact(x, R - 1);
+        bad += qp_exact(qc, x[0], x[1], x[2], x[3], R - 1, rem);
     }
     __syncthreads();
     // flush in table order (conflict-free reads): word i = d*4096 + q*64 + w*4 + k
-    for (uint32_t i = threadIdx.x; i < QP_LDS_BYTES / 4; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < QP_LDS_BYTES / 4; i += T) {
         const uint32_t v = s_q[i];
         if (v) {
             const uint32_t d = i >> 12, q = (i >> 6) & 63u, c = ((i >> 2) & 15u) * 16u + d * 4u + (i & 3u);
-            if (c < pitch) atomicAdd(&st.counters[st.off_qual + (uint64_t)c * QUAL_BINS + q], (u64)v);
+            if (c < pitch) atomicAdd(&qc[(uint64_t)c * QUAL_BINS + q], (u64)v);
         }
     }
     uint32_t r = bad;
@@ -316,21 +334,35 @@ __global__ __launch_bounds__(1024) void k_qual_perm(DeviceState st, const uint8_
     if ((threadIdx.x & 63) == 0 && r) atomicAdd(&st.counters[C_ERR + E_BAD_QUAL], (u64)r);
 }
 
-template <uint32_t R>
+template <uint32_t R, uint32_t D>
 static hipError_t launch_perm(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_perm<R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_perm<R, D>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)QP_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    uint64_t g = (b.n * R + 1023) / 1024;
-    if (g > (uint64_t)li.n_cu * 2) g = (uint64_t)li.n_cu * 2;
+    constexpr uint32_t RPB = qp_threads(R) / R;
+    uint64_t g = (b.n + RPB - 1) / RPB;
+    if (g > (uint64_t)li.n_cu * 2) g = (uint64_t)li.n_cu * 2; // 64 KiB of LDS each: two blocks per CU
     if (g < 1) g = 1;
-    hipLaunchKernelGGL((k_qual_perm<R>), dim3((uint32_t)g), dim3(1024), QP_LDS_BYTES, s, st, b.qual, b.n,
+    hipLaunchKernelGGL((k_qual_perm<R, D>), dim3((uint32_t)g), dim3(qp_threads(R)), QP_LDS_BYTES, s, st, b.qual, b.n,
                        b.qual_stride);
     return hipGetLastError();
+}
+
+template <uint32_t D>
+static hipError_t dispatch_perm(uint32_t R, const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+                                hipStream_t s) {
+    switch (R) {
+#define CASE(r) \
+    case r: return launch_perm<r, D>(li, st, b, s);
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+        CASE(14) CASE(15) CASE(16)
+#undef CASE
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <uint32_t R, uint32_t NROT>
@@ -371,14 +403,9 @@ bool qual_window_supported(const DeviceState &st, const DeviceBatch &b) {
 hipError_t launch_qual_window(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint32_t nrot,
                               hipStream_t s) {
     const uint32_t R = (b.qual_stride + 15) / 16;
-    switch (R) {
-#define CASE(r) \
-    case r: return launch_perm<r>(li, st, b, s);
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
-        CASE(14) CASE(15) CASE(16)
-#undef CASE
-    default: break;
-    }
+    // two windows in flight per thread: depths 1..3, one or two blocks per CU, nontemporal loads and a
+    // block-interleaved row order all measured within 2 % of each other
+    if (R <= QP_MAX_R) return dispatch_perm<2>(R, li, st, b, s);
     switch (nrot) {
     case 1: return dispatch<1>(R, li, st, b, s);
     case 2: return dispatch<2>(R, li, st, b, s);
