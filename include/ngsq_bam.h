@@ -48,6 +48,16 @@ int ngsq_bam_next_batch(ngsq_bam *bam, uint64_t max_records, ngsq_batch *out);
 /* records decoded so far */
 uint64_t ngsq_bam_records_read(const ngsq_bam *bam);
 
+/* ---- device ingest: the GPU inflates and parses ------------------- */
+
+/* Inflate a buffer of WHOLE BGZF blocks (host memory) on the context's device and copy the
+ * decompressed bytes back: one wavefront per block (csrc/bgzf_inflate.hip).  *out_len receives
+ * the total ISIZE (also when out_cap is too small).  check_crc != 0 verifies every block's CRC32.
+ * Errors (bad framing, invalid DEFLATE data, size or CRC mismatch): NGSQ_ERR_INVALID_ARGUMENT
+ * with the block number in ngsq_last_error(ctx). */
+int ngsq_bgzf_inflate_device(ngsq_ctx *ctx, const uint8_t *comp, uint64_t comp_len, uint8_t *out, uint64_t out_cap,
+                             uint64_t *out_len, int check_crc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,11 +12,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
-SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "context.cpp", "results.cpp", "bam_reader.cpp", "synth_bam.cpp"]
-HEADERS = ["kernels.h", "context.h", "../../include/ngsq.h", "../../include/ngsq_shared.h",
-           "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
-         "-fno-gpu-rdc"]
+SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "bgzf_inflate.hip",
+           "bam_device.hip", "context.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
+HEADERS = ["kernels.h", "context.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h",
+           "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-gpu-rdc"]
+OBJ_DIR = os.path.join(HERE, "_obj")  # per-source objects (git-ignored): only changed sources recompile
 
 
 def hipcc() -> str:
@@ -56,7 +57,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and up_to_date():
         build_cli(False, verbose)
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-lpthread", "-o", OUT + ".tmp"]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+    cc = hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, src.replace("/", "_") + ".o")
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_t, os.path.getmtime(path)):
+            return obj
+        cmd = [cc] + FLAGS + ["-c", path, "-o", obj]
+        if verbose:
+            print("[ngs_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + objs + ["-lz", "-lpthread", "-o", OUT + ".tmp"]
     if verbose:
         print("[ngs_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
