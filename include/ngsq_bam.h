@@ -50,6 +50,15 @@ uint64_t ngsq_bam_records_read(const ngsq_bam *bam);
 
 /* ---- device ingest: the GPU inflates and parses ------------------- */
 
+/* Device ingest of an opened BAM: like ngsq_bam_next_batch, but the compressed BGZF blocks are
+ * copied to the context's device, inflated there (csrc/bgzf_inflate.hip) and parsed into
+ * NGSQ_MEM_DEVICE columns (csrc/bam_device.hip) owned by the reader and valid until the next
+ * call / close; work is enqueued on the context's stream.  Same records, same layout rules and
+ * the same errors as the host reader; a call may return fewer than max_records before the end of
+ * the file (out->n_records == 0 only at the end).  One handle serves either the host or the device
+ * calls, not both (NGSQ_ERR_STATE).  Needs a GPU. */
+int ngsq_bam_next_batch_device(ngsq_bam *bam, ngsq_ctx *ctx, uint64_t max_records, ngsq_batch *out);
+
 /* Inflate a buffer of WHOLE BGZF blocks (host memory) on the context's device and copy the
  * decompressed bytes back: one wavefront per block (csrc/bgzf_inflate.hip).  *out_len receives
  * the total ISIZE (also when out_cap is too small).  check_crc != 0 verifies every block's CRC32.

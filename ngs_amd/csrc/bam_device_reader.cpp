@@ -4,11 +4,14 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "../../include/ngsq_bam.h"
+#include "bam_reader.h"
 #include "bgzf.h"
 #include "context.h"
 #include "ingest_kernels.h"
@@ -48,10 +51,353 @@ const char *inflate_status_text(uint32_t s) {
     }
 }
 
+
+// growable device buffer
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+    hipError_t reserve(size_t n, bool keep = false) {
+        if (n <= cap) return hipSuccess;
+        const size_t want = n + n / 8 + 64;
+        T *q = nullptr;
+        hipError_t e = hipMalloc((void **)&q, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) (void)hipMemcpy(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
+        (void)hipFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
+    ~DevBuf() { (void)hipFree(p); }
+};
+
+size_t env_mb(const char *name, size_t dflt_mb) {
+    const char *e = getenv(name);
+    const long v = e ? atol(e) : 0;
+    return (size_t)(v > 0 ? v : (long)dflt_mb) << 20;
+}
+
+} // namespace
+
+namespace ngsq {
+
+// State of the device ingest of one BAM file: compressed chunk -> inflate -> record index -> batches.
+struct DeviceIngest {
+    FILE *f = nullptr;
+    ngsq_ctx *ctx = nullptr;
+    size_t raw_cap = 0, comp_chunk = 0;
+    uint8_t *h_comp = nullptr; // pinned, 2 x comp_chunk
+    size_t comp_fill = 0;
+    bool file_eof = false;
+    uint64_t first = 0; // offset in d_raw of the first record of the next chunk
+    bool first_chunk = true;
+    // device
+    DevBuf<uint8_t> d_comp, d_raw, d_seq, d_qual, d_scan_tmp;
+    DevBuf<BgzfBlock> d_blocks;
+    DevBuf<uint32_t> d_status, d_l_seq, d_cigar;
+    DevBuf<RecCandidate> d_cand;
+    DevBuf<uint64_t> d_seg, d_rec_off, d_len; // d_seg: entry | base; d_len: seq | qual | cigar lengths -> offsets
+    DevBuf<unsigned long long> d_small;       // [0] bad record, [1..3] stats, [4..] walk_one result
+    DevBuf<uint16_t> d_flag, d_n_cigar;
+    DevBuf<uint8_t> d_mapq;
+    DevBuf<int32_t> d_ref_id, d_pos, d_mate, d_tlen;
+    uint64_t raw_len = 0, tail_off = 0;
+    uint64_t n_rec = 0, cursor = 0; // records indexed in the current chunk / handed out
+    uint64_t blocks_done = 0;
+    std::vector<BgzfBlock> blocks;
+    std::vector<uint32_t> status;
+    std::vector<RecCandidate> cand;
+    std::vector<uint64_t> seg;
+    ~DeviceIngest() {
+        if (f) fclose(f);
+        if (h_comp) (void)hipHostFree(h_comp);
+    }
+};
+
+} // namespace ngsq
+
+namespace {
+
+void free_ingest(DeviceIngest *d) { delete d; }
+
+#define BHIP(expr)                                                                                          \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return ngsq_bam_fail(NGSQ_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// Inflate the next run of BGZF blocks behind the unparsed tail of d_raw and index its records.
+int load_chunk(ngsq_bam *b, DeviceIngest *d) {
+    hipStream_t st = d->ctx->stream;
+    // ---- 1. keep the cut record at the end of the previous chunk
+    const uint64_t carry = d->raw_len - d->tail_off;
+    if (carry && d->tail_off) {
+        if (carry <= d->tail_off) {
+            BHIP(hipMemcpyAsync(d->d_raw.p, d->d_raw.p + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
+        } else { // overlapping ranges: through the (idle) compressed buffer
+            BHIP(d->d_comp.reserve(carry));
+            BHIP(hipMemcpyAsync(d->d_comp.p, d->d_raw.p + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
+            BHIP(hipMemcpyAsync(d->d_raw.p, d->d_comp.p, carry, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    if (carry + REC_SEGMENT > d->raw_cap)
+        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest buffer (%zu MiB)",
+                             b->path.c_str(), d->raw_cap >> 20);
+    // ---- 2. compressed bytes: top up the pinned buffer, take the complete blocks that fit
+    if (!d->file_eof && d->comp_fill < d->comp_chunk) {
+        const size_t want = 2 * d->comp_chunk - d->comp_fill;
+        const size_t got = fread(d->h_comp + d->comp_fill, 1, want, d->f);
+        if (got < want) {
+            if (ferror(d->f)) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "read error on %s", b->path.c_str());
+            d->file_eof = true;
+        }
+        d->comp_fill += got;
+    }
+    d->blocks.clear();
+    size_t consumed = 0;
+    uint64_t total = 0;
+    std::string err;
+    if (!bgzf_split(d->h_comp, d->comp_fill, &d->blocks, &consumed, &total, &err, d->raw_cap - carry))
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: %s", b->path.c_str(), err.c_str());
+    const size_t n_blk = d->blocks.size();
+    if (!n_blk) {
+        if (d->comp_fill && d->file_eof)
+            return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated BGZF block at end of file", b->path.c_str());
+        if (d->comp_fill >= 2 * d->comp_chunk)
+            return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: BGZF block does not fit the ingest buffer", b->path.c_str());
+    }
+    // ---- 3. inflate
+    for (auto &bl : d->blocks) bl.out_off += carry;
+    if (n_blk) {
+        BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
+        BHIP(d->d_blocks.reserve(n_blk));
+        BHIP(d->d_status.reserve(n_blk));
+        BHIP(hipMemcpyAsync(d->d_comp.p, d->h_comp, consumed, hipMemcpyHostToDevice, st));
+        BHIP(hipMemsetAsync(d->d_comp.p + consumed, 0, INFLATE_IN_SLACK, st));
+        BHIP(hipMemcpyAsync(d->d_blocks.p, d->blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
+        BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, true, st));
+        d->status.resize(n_blk);
+        BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        BHIP(hipStreamSynchronize(st)); // also: h_comp may be rewritten now
+        for (size_t k = 0; k < n_blk; k++)
+            if (d->status[k] != INF_OK)
+                return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: BGZF block %llu: %s", b->path.c_str(),
+                                     (unsigned long long)(d->blocks_done + k), inflate_status_text(d->status[k]));
+        d->blocks_done += n_blk;
+        memmove(d->h_comp, d->h_comp + consumed, d->comp_fill - consumed);
+        d->comp_fill -= consumed;
+    }
+    d->raw_len = carry + total;
+    d->n_rec = d->cursor = 0;
+    d->tail_off = 0;
+    const uint64_t first = d->first_chunk ? b->header_bytes : 0;
+    d->first_chunk = d->first_chunk && d->raw_len < first; // the header may span the first chunk(s)
+    if (d->raw_len < first) {
+        // nothing but header bytes so far: drop them and carry on
+        d->first = 0;
+        b->header_bytes -= d->raw_len;
+        d->tail_off = d->raw_len;
+        return NGSQ_OK;
+    }
+    // ---- 4. record index
+    const uint32_t n_seg = (uint32_t)((d->raw_len + REC_SEGMENT - 1) / REC_SEGMENT);
+    if (!n_seg) return NGSQ_OK;
+    BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
+    BHIP(d->d_seg.reserve((size_t)n_seg * 2));
+    BHIP(d->d_small.reserve(16));
+    BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+    d->cand.resize((size_t)n_seg * REC_CANDIDATES);
+    BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
+    BHIP(hipStreamSynchronize(st));
+    d->seg.resize((size_t)n_seg * 2);
+    uint64_t cur = first, total_rec = 0;
+    for (uint32_t s = 0; s < n_seg; s++) {
+        const uint64_t s1 = std::min<uint64_t>(((uint64_t)s + 1) * REC_SEGMENT, d->raw_len);
+        d->seg[s] = cur;
+        d->seg[n_seg + s] = total_rec;
+        if (cur >= s1) continue;
+        const RecCandidate *c = nullptr;
+        for (uint32_t k = 0; k < REC_CANDIDATES; k++) {
+            const RecCandidate &x = d->cand[(size_t)s * REC_CANDIDATES + k];
+            if (x.valid && x.start == cur) c = &x;
+        }
+        RecCandidate one{};
+        if (!c) {
+            RecCandidate *d_one = reinterpret_cast<RecCandidate *>(d->d_small.p + 4);
+            BHIP(launch_walk_one(d->d_raw.p, d->raw_len, cur, s1, d_one, st));
+            BHIP(hipMemcpyAsync(&one, d_one, sizeof one, hipMemcpyDeviceToHost, st));
+            BHIP(hipStreamSynchronize(st));
+            c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
+        }
+        total_rec += c->count;
+        if (!c->valid) {
+            cur = d->raw_len;
+            break;
+        }
+        cur = c->landing;
+    }
+    d->tail_off = std::min(cur, d->raw_len);
+    BHIP(d->d_rec_off.reserve(total_rec + 1));
+    BHIP(hipMemcpyAsync(d->d_seg.p, d->seg.data(), d->seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    BHIP(hipMemsetAsync(d->d_small.p, 0xFF, sizeof(unsigned long long), st));
+    BHIP(launch_rec_offsets(d->d_raw.p, d->raw_len, n_seg, d->d_seg.p, d->d_seg.p + n_seg, d->d_rec_off.p, d->d_small.p, st));
+    unsigned long long bad = 0;
+    BHIP(hipMemcpyAsync(&bad, d->d_small.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    BHIP(hipStreamSynchronize(st));
+    if (bad != ~0ull)
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
+                             (unsigned long long)(b->n_read + bad));
+    d->n_rec = total_rec;
+    d->first = 0;
+    return NGSQ_OK;
+}
+
 } // namespace
 
 extern "C" {
 
+int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, ngsq_batch *out) {
+    if (!b || !c || !out) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (b->host_mode) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: this reader is in host ingest mode", b->path.c_str());
+    memset(out, 0, sizeof *out);
+    out->struct_size = sizeof *out;
+    out->location = NGSQ_MEM_DEVICE;
+    out->first_record_index = b->n_read;
+    BHIP(hipSetDevice(c->device));
+    DeviceIngest *d = b->dev;
+    if (!d) {
+        d = new DeviceIngest();
+        d->ctx = c;
+        d->f = fopen(b->path.c_str(), "rb");
+        if (!d->f) {
+            delete d;
+            return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "opening BAM file: %s", b->path.c_str());
+        }
+        d->raw_cap = env_mb("NGSQ_INGEST_RAW_MB", 1024);
+        d->comp_chunk = std::max<size_t>(d->raw_cap / 4, (size_t)1 << 17);
+        b->dev = d;
+        b->dev_free = free_ingest;
+        BHIP(hipHostMalloc((void **)&d->h_comp, 2 * d->comp_chunk, hipHostMallocDefault));
+        BHIP(d->d_raw.reserve(d->raw_cap + 64));
+        // the host side of this handle is done: release its buffers
+        std::vector<uint8_t>().swap(b->comp);
+        std::vector<uint8_t>().swap(b->data);
+    }
+    if (d->ctx != c) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: device ingest is bound to another context", b->path.c_str());
+    if (max_records == 0) return NGSQ_OK;
+    hipStream_t st = c->stream;
+    while (d->cursor == d->n_rec) {
+        if (d->file_eof && d->comp_fill == 0 && !d->first_chunk) {
+            if (d->tail_off != d->raw_len)
+                return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated record", b->path.c_str());
+            return NGSQ_OK; // clean end of file
+        }
+        const uint64_t before = d->blocks_done;
+        const bool was_eof = d->file_eof;
+        const int rc = load_chunk(b, d);
+        if (rc) return rc;
+        if (d->n_rec == 0 && was_eof && d->blocks_done == before && d->comp_fill == 0) {
+            if (d->tail_off != d->raw_len)
+                return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated record", b->path.c_str());
+            return NGSQ_OK;
+        }
+    }
+    const uint64_t n = std::min<uint64_t>(max_records, d->n_rec - d->cursor);
+    const uint64_t *rec = d->d_rec_off.p + d->cursor;
+    // ---- fixed-width columns and the layout decision (the rule of bam_reader.cpp)
+    BHIP(d->d_flag.reserve(n + 64));
+    BHIP(d->d_n_cigar.reserve(n + 64));
+    BHIP(d->d_mapq.reserve(n + 64));
+    BHIP(d->d_ref_id.reserve(n + 64));
+    BHIP(d->d_pos.reserve(n + 64));
+    BHIP(d->d_mate.reserve(n + 64));
+    BHIP(d->d_tlen.reserve(n + 64));
+    BHIP(d->d_l_seq.reserve(n + 64));
+    RecColumns col{};
+    col.flag = d->d_flag.p;
+    col.n_cigar = d->d_n_cigar.p;
+    col.mapq = d->d_mapq.p;
+    col.ref_id = d->d_ref_id.p;
+    col.pos = d->d_pos.p;
+    col.mate_ref_id = d->d_mate.p;
+    col.tlen = d->d_tlen.p;
+    col.l_seq = d->d_l_seq.p;
+    BHIP(hipMemsetAsync(d->d_small.p + 1, 0, 3 * sizeof(unsigned long long), st));
+    BHIP(launch_rec_fixed(d->d_raw.p, rec, n, col, d->d_small.p + 1, st));
+    unsigned long long stats[3] = {0, 0, 0};
+    BHIP(hipMemcpyAsync(stats, d->d_small.p + 1, sizeof stats, hipMemcpyDeviceToHost, st));
+    BHIP(hipStreamSynchronize(st));
+    const uint32_t max_l = (uint32_t)stats[0], max_ops = (uint32_t)stats[1];
+    const uint64_t sum_qual = stats[2];
+    const uint32_t pitch_q = max_l, pitch_s = (max_l + 1) / 2;
+    const bool fixed = max_l >= 1 && max_l <= 320 && (uint64_t)pitch_q * n <= sum_qual + sum_qual / 2 + 4096;
+    const bool cig1 = max_ops <= 1;
+    uint64_t so = (uint64_t)pitch_s * n, qo = (uint64_t)pitch_q * n, co = n;
+    if (!fixed || !cig1) {
+        BHIP(d->d_len.reserve(3 * (n + 1)));
+        uint64_t *sl = d->d_len.p, *ql = sl + (n + 1), *cl = ql + (n + 1);
+        BHIP(hipMemsetAsync(d->d_len.p, 0, 3 * (n + 1) * sizeof(uint64_t), st));
+        BHIP(launch_rec_lengths(d->d_raw.p, rec, n, sl, ql, cl, st));
+        size_t tmp_bytes = 0;
+        BHIP(launch_exclusive_scan_u64(sl, n + 1, nullptr, &tmp_bytes, st));
+        BHIP(d->d_scan_tmp.reserve(tmp_bytes + 256));
+        uint64_t totals[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) {
+            if (k < 2 ? fixed : cig1) continue;
+            uint64_t *arr = d->d_len.p + (size_t)k * (n + 1);
+            size_t tb = d->d_scan_tmp.cap;
+            BHIP(launch_exclusive_scan_u64(arr, n + 1, d->d_scan_tmp.p, &tb, st));
+            BHIP(hipMemcpyAsync(&totals[k], arr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        }
+        BHIP(hipStreamSynchronize(st));
+        if (!fixed) {
+            so = totals[0];
+            qo = totals[1];
+            col.seq_off = sl;
+            col.qual_off = ql;
+        }
+        if (!cig1) {
+            co = totals[2];
+            col.cigar_off = cl;
+        }
+    }
+    BHIP(d->d_seq.reserve(so + 64));
+    BHIP(d->d_qual.reserve(qo + 64));
+    BHIP(d->d_cigar.reserve(co + 16));
+    col.seq = d->d_seq.p;
+    col.qual = d->d_qual.p;
+    col.cigar = d->d_cigar.p;
+    col.seq_pitch = pitch_s;
+    col.qual_pitch = pitch_q;
+    BHIP(launch_rec_var(d->d_raw.p, rec, n, col, so, qo, st));
+    d->cursor += n;
+    b->n_read += n;
+    out->n_records = n;
+    out->flag = col.flag;
+    out->mapq = col.mapq;
+    out->ref_id = col.ref_id;
+    out->pos = col.pos;
+    out->mate_ref_id = col.mate_ref_id;
+    out->tlen = col.tlen;
+    out->l_seq = col.l_seq;
+    out->n_cigar = col.n_cigar;
+    out->seq = col.seq;
+    out->qual = col.qual;
+    out->cigar = col.cigar;
+    out->seq_bytes = so;
+    out->qual_bytes = qo;
+    out->cigar_ops = co;
+    if (fixed) {
+        out->seq_stride = pitch_s;
+        out->qual_stride = pitch_q;
+    } else {
+        out->seq_off = col.seq_off;
+        out->qual_off = col.qual_off;
+    }
+    if (cig1) out->cigar_stride = 1;
+    else out->cigar_off = col.cigar_off;
+    return NGSQ_OK;
+}
 int ngsq_bgzf_inflate_device(ngsq_ctx *c, const uint8_t *comp, uint64_t comp_len, uint8_t *out, uint64_t out_cap,
                              uint64_t *out_len, int check_crc) {
     if (!c || !comp || !out_len) return dfail(c, NGSQ_ERR_INVALID_ARGUMENT, "null argument");

@@ -18,12 +18,11 @@
 #include <vector>
 
 #include "../../include/ngsq_bam.h"
+#include "bam_reader.h"
 
-namespace {
+static thread_local std::string g_bam_err;
 
-thread_local std::string g_bam_err;
-
-int bfail(int code, const char *fmt, ...) {
+int ngsq_bam_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -32,24 +31,14 @@ int bfail(int code, const char *fmt, ...) {
     g_bam_err = buf;
     return code;
 }
+#define bfail ngsq_bam_fail
+
+using ngsq::RawBuf;
+
+namespace {
 
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
-
-// uninitialised growable byte buffer (std::vector would zero gigabytes on one core)
-struct RawBuf {
-    uint8_t *p = nullptr;
-    size_t cap = 0;
-    uint8_t *reserve(size_t n) {
-        if (n > cap) {
-            free(p);
-            cap = n + n / 8 + 4096;
-            p = (uint8_t *)malloc(cap);
-        }
-        return p;
-    }
-    ~RawBuf() { free(p); }
-};
 
 template <typename F> void parallel_for(int n_threads, uint64_t n, F fn) {
     const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_threads, n / 4096 + 1));
@@ -73,27 +62,6 @@ struct Block {
 };
 
 } // namespace
-
-struct ngsq_bam {
-    FILE *f = nullptr;
-    std::string path;
-    int n_threads = 1;
-    bool eof = false;
-    std::vector<uint8_t> comp;   // compressed bytes not yet consumed
-    std::vector<uint8_t> data;   // decompressed bytes not yet parsed (starts at a record boundary after the header)
-    size_t data_pos = 0;
-    std::string header_text;
-    std::vector<std::string> ref_names;
-    std::vector<uint32_t> ref_lens;
-    uint64_t n_read = 0;
-    // batch columns
-    std::vector<uint16_t> flag, n_cigar;
-    std::vector<uint8_t> mapq, missing;
-    RawBuf seq, qual; // large: grown without initialisation, padded by the fill threads
-    std::vector<int32_t> ref_id, pos, mate_ref_id, tlen;
-    std::vector<uint32_t> l_seq, cigar;
-    std::vector<uint64_t> seq_off, qual_off, cigar_off;
-};
 
 namespace {
 
@@ -147,6 +115,7 @@ int inflate_more(ngsq_bam *b, size_t want_compressed) {
     // ---- compact the unparsed tail of `data`, then inflate the blocks in parallel behind it
     if (b->data_pos) {
         b->data.erase(b->data.begin(), b->data.begin() + (ptrdiff_t)b->data_pos);
+        b->data_base += b->data_pos;
         b->data_pos = 0;
     }
     const size_t base = b->data.size();
@@ -194,7 +163,7 @@ int ensure(ngsq_bam *b, size_t need) {
         if (b->eof && b->comp.empty()) break;
         const size_t a0 = b->data.size() - b->data_pos, c0 = b->comp.size();
         const bool e0 = b->eof;
-        const int rc = inflate_more(b, e0 ? 0 : (size_t)64 << 20);
+        const int rc = inflate_more(b, e0 ? 0 : b->read_chunk);
         if (rc) return rc;
         if (e0 && b->data.size() - b->data_pos == a0 && b->comp.size() == c0)
             return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated BGZF block at end of file", b->path.c_str());
@@ -217,6 +186,7 @@ int ngsq_bam_open(const char *path, int n_threads, ngsq_bam **out) {
     b->f = f;
     b->path = path;
     b->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    b->read_chunk = (size_t)1 << 20; // the header needs little; the device ingest re-reads the file itself
 #define OPEN_TRY(expr)            \
     do {                          \
         int rc_ = (expr);         \
@@ -259,12 +229,15 @@ int ngsq_bam_open(const char *path, int n_threads, ngsq_bam **out) {
         b->data_pos += 8 + l_name;
     }
 #undef OPEN_TRY
+    b->header_bytes = b->data_base + b->data_pos;
+    b->read_chunk = (size_t)64 << 20;
     *out = b;
     return NGSQ_OK;
 }
 
 void ngsq_bam_close(ngsq_bam *b) {
     if (!b) return;
+    if (b->dev && b->dev_free) b->dev_free(b->dev);
     if (b->f) fclose(b->f);
     delete b;
 }
@@ -281,6 +254,8 @@ uint64_t ngsq_bam_records_read(const ngsq_bam *b) { return b ? b->n_read : 0; }
 
 int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     if (!b || !out) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (b->dev) return bfail(NGSQ_ERR_STATE, "%s: this reader is in device ingest mode", b->path.c_str());
+    b->host_mode = true;
     memset(out, 0, sizeof *out);
     out->struct_size = sizeof *out;
     out->location = NGSQ_MEM_HOST;

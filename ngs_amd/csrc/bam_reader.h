@@ -1,0 +1,66 @@
+// bam_reader.h -- private definition of ngsq_bam (shared by the host reader, bam_reader.cpp, and
+// the device ingest, bam_device_reader.cpp)
+#pragma once
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ngsq_bam.h"
+
+namespace ngsq {
+
+// uninitialised growable byte buffer (std::vector would zero gigabytes on one core)
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    uint8_t *reserve(size_t n) {
+        if (n > cap) {
+            free(p);
+            cap = n + n / 8 + 4096;
+            p = (uint8_t *)malloc(cap);
+        }
+        return p;
+    }
+    ~RawBuf() { free(p); }
+};
+
+struct DeviceIngest; // bam_device_reader.cpp
+
+} // namespace ngsq
+
+struct ngsq_bam {
+    FILE *f = nullptr;
+    std::string path;
+    int n_threads = 1;
+    bool eof = false;
+    std::vector<uint8_t> comp;   // compressed bytes not yet consumed
+    std::vector<uint8_t> data;   // decompressed bytes not yet parsed (starts at a record boundary after the header)
+    size_t data_pos = 0;
+    std::string header_text;
+    std::vector<std::string> ref_names;
+    std::vector<uint32_t> ref_lens;
+    uint64_t n_read = 0;
+    // batch columns
+    std::vector<uint16_t> flag, n_cigar;
+    std::vector<uint8_t> mapq, missing;
+    ngsq::RawBuf seq, qual; // large: grown without initialisation, padded by the fill threads
+    std::vector<int32_t> ref_id, pos, mate_ref_id, tlen;
+    std::vector<uint32_t> l_seq, cigar;
+    std::vector<uint64_t> seq_off, qual_off, cigar_off;
+    // bookkeeping shared with the device ingest
+    size_t read_chunk = (size_t)64 << 20; // compressed bytes per read
+    uint64_t data_base = 0;               // offset in the decompressed stream of data[0]
+    uint64_t header_bytes = 0;            // decompressed bytes before the first record
+    bool host_mode = false;               // ngsq_bam_next_batch has been called
+    ngsq::DeviceIngest *dev = nullptr;    // set by ngsq_bam_next_batch_device
+    void (*dev_free)(ngsq::DeviceIngest *) = nullptr;
+};
+
+// message of this thread's last failing ngsq_bam_* call (bam_reader.cpp)
+int ngsq_bam_fail(int code, const char *fmt, ...);
+
+

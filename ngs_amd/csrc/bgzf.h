@@ -19,9 +19,10 @@ inline uint32_t bgzf_rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t
 
 // Append every COMPLETE block of c[0..n) to `blocks` (in_off relative to c, out_off running from
 // *out_total) and set *consumed to the bytes they span.  Returns false (with *err) for bytes that
-// are not BGZF.  A trailing incomplete block is left unconsumed.
+// are not BGZF.  A trailing incomplete block is left unconsumed, and so is everything from the first
+// block that would take the decompressed total past out_limit.
 inline bool bgzf_split(const uint8_t *c, size_t n, std::vector<BgzfBlock> *blocks, size_t *consumed,
-                       uint64_t *out_total, std::string *err) {
+                       uint64_t *out_total, std::string *err, uint64_t out_limit = ~0ull) {
     size_t p = 0;
     while (n - p >= 18) {
         if (c[p] != 31 || c[p + 1] != 139 || c[p + 2] != 8 || !(c[p + 3] & 4)) {
@@ -59,6 +60,7 @@ inline bool bgzf_split(const uint8_t *c, size_t n, std::vector<BgzfBlock> *block
             *err = "BGZF ISIZE > 64 KiB";
             return false;
         }
+        if (*out_total + bl.isize > out_limit) break;
         *out_total += bl.isize;
         blocks->push_back(bl);
         p += bsize;

@@ -38,4 +38,42 @@ constexpr uint32_t INFLATE_IN_SLACK = 1024;
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
                                uint32_t *status, bool check_crc, hipStream_t s);
 
+// ---- BAM record parse (csrc/bam_device.hip) -------------------------------------------------------
+constexpr uint64_t REC_SEGMENT = 65536;  // bytes of the inflated stream walked by one lane / wave
+constexpr uint32_t REC_CANDIDATES = 4;   // chain starts kept per segment
+
+struct RecCandidate {
+    uint64_t start;   // offset of a plausible record start inside the segment
+    uint64_t landing; // where its chain leaves the segment (offset of a record start, or of the cut tail)
+    uint32_t count;   // records on the chain inside the segment
+    uint32_t valid;
+};
+
+// device columns of one batch (include/ngsq.h layout rules)
+struct RecColumns {
+    uint16_t *flag, *n_cigar;
+    uint8_t *mapq;
+    int32_t *ref_id, *pos, *mate_ref_id, *tlen;
+    uint32_t *l_seq;
+    uint8_t *seq, *qual;
+    uint32_t *cigar;
+    const uint64_t *seq_off, *qual_off, *cigar_off; // null: fixed pitch (cigar: one op per record)
+    uint32_t seq_pitch, qual_pitch;
+};
+
+hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
+                                 RecCandidate *cand, hipStream_t s);
+hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t end, RecCandidate *out,
+                           hipStream_t s);
+hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_seg, const uint64_t *seg_entry,
+                              const uint64_t *seg_base, uint64_t *rec_off, unsigned long long *bad, hipStream_t s);
+hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c,
+                            unsigned long long *stats, hipStream_t s);
+hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,
+                              uint64_t *qual_len, uint64_t *cig_len, hipStream_t s);
+// exclusive prefix sums of n+1 entries in place (entry n = total); tmp: scratch of *tmp_bytes
+hipError_t launch_exclusive_scan_u64(uint64_t *data, uint64_t n_plus_1, void *tmp, size_t *tmp_bytes, hipStream_t s);
+hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t seq_bytes,
+                          uint64_t qual_bytes, hipStream_t s);
+
 } // namespace ngsq

@@ -227,6 +227,7 @@ PROTOTYPES = {
     "ngsq_bam_header_text": (C.c_char_p, [C.c_void_p, u64p]),
     "ngsq_bam_next_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(Batch)]),
     "ngsq_bam_records_read": (C.c_uint64, [C.c_void_p]),
+    "ngsq_bam_next_batch_device": (C.c_int, [C.c_void_p, ctx_p, C.c_uint64, C.POINTER(Batch)]),
     "ngsq_bgzf_inflate_device": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_int]),
     "ngsq_synth_fill_device": (
         C.c_int, [ctx_p, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),

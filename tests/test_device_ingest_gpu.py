@@ -124,3 +124,143 @@ def test_inflate_errors(gpu_lib, ctx):
         device_inflate(gpu_lib, ctx, b"\x00" * 64)
     with pytest.raises(RuntimeError, match="truncated"):
         device_inflate(gpu_lib, ctx, good[:-5])
+
+
+# ---- BAM record parse on the device ------------------------------------------------------------
+from tests import bamio  # noqa: E402
+from tests.test_bam_ingest import read_all, records_of  # noqa: E402
+from tests.util import random_batch  # noqa: E402
+
+
+def download_batch(lib, ctx, b: ffi.Batch) -> host.HostBatch:
+    n = int(b.n_records)
+
+    def arr(ptr, count, dt):
+        if not ptr:
+            return None
+        a = np.empty(count, dtype=dt)
+        if count:
+            assert lib.ngsq_memcpy_d2h(ctx._ctx, a.ctypes.data, ptr, a.nbytes) == 0
+        return a
+
+    assert b.location == ffi.MEM_DEVICE
+    cols = {k: arr(getattr(b, k), n, host.COLUMN_DTYPES[k]) for k in host.FIXED_COLUMNS}
+    for data, off, tot in (("seq", "seq_off", b.seq_bytes), ("qual", "qual_off", b.qual_bytes), ("cigar", "cigar_off", b.cigar_ops)):
+        cols[off] = arr(getattr(b, off), n + 1, np.uint64) if getattr(b, off) else None
+        cols[data] = arr(getattr(b, data), int(tot), host.COLUMN_DTYPES[data])
+    return host.HostBatch(n, cols, b.seq_stride, b.qual_stride, b.cigar_stride, int(b.first_record_index))
+
+
+def read_all_device(lib, ctx, path, max_records):
+    h = C.c_void_p()
+    assert lib.ngsq_bam_open(path.encode(), 2, C.byref(h)) == 0, lib.ngsq_bam_last_error()
+    batches = []
+    try:
+        while True:
+            b = ffi.Batch()
+            rc = lib.ngsq_bam_next_batch_device(h, ctx._ctx, max_records, C.byref(b))
+            if rc != 0:
+                raise RuntimeError(lib.ngsq_bam_last_error().decode())
+            if b.n_records == 0:
+                break
+            batches.append(download_batch(lib, ctx, b))
+        n = lib.ngsq_bam_records_read(h)
+    finally:
+        lib.ngsq_bam_close(h)
+    return batches, n
+
+
+def same_batches(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert (x.n, x.seq_stride, x.qual_stride, x.cigar_stride, x.first_record_index) == \
+               (y.n, y.seq_stride, y.qual_stride, y.cigar_stride, y.first_record_index)
+        for k in x.cols:
+            if x.cols[k] is None or y.cols[k] is None:
+                assert x.cols[k] is None and y.cols[k] is None, k
+            else:
+                assert np.array_equal(x.cols[k], y.cols[k]), k
+
+
+@pytest.mark.parametrize("case", ["ragged", "uniform150", "long", "multiop150"])
+def test_device_reader_matches_host_reader(gpu_lib, ctx, tmp_path, monkeypatch, case):
+    rng = np.random.default_rng(19)
+    ref_len = [50_000, 7_000]
+    if case == "ragged":
+        hb = random_batch(rng, 6000, ref_len, max_len=300, weird=True)
+    elif case == "uniform150":
+        hb = random_batch(rng, 6000, ref_len, max_len=150, min_len=150, weird=False)
+    elif case == "multiop150":
+        hb = random_batch(rng, 6000, ref_len, max_len=150, min_len=140, weird=True)
+    else:
+        hb = random_batch(rng, 700, ref_len, max_len=900, min_len=321, weird=False)
+    path = str(tmp_path / "t.bam")
+    bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000)
+    for max_records in (1 << 20, 257):
+        _, hbatches, n = read_all(gpu_lib, path, max_records)
+        dbatches, dn = read_all_device(gpu_lib, ctx, path, max_records)
+        assert dn == n == hb.n
+        same_batches(dbatches, hbatches)
+    # many small chunks: the cut record at a chunk's end is carried into the next one
+    monkeypatch.setenv("NGSQ_INGEST_RAW_MB", "1")
+    dbatches, dn = read_all_device(gpu_lib, ctx, path, 1 << 20)
+    assert dn == hb.n
+    assert [r for b in dbatches for r in records_of(b)] == records_of(hb)
+
+
+def test_device_reader_synthetic_bam_and_results(gpu_lib, ctx, tmp_path):
+    """file -> device ingest -> facet kernels gives the JSON of file -> host ingest -> facet kernels."""
+    cfg = host.synth_config(60_000, mode=ffi.SYNTH_MIXED, ref_len=3_000_000)
+    p = str(tmp_path / "s.bam")
+    assert gpu_lib.ngsq_synth_write_bam(C.byref(cfg), p.encode(), 60_000, 6, 4) == 0
+    _, hbatches, n = read_all(gpu_lib, p, 25_000)
+    dbatches, dn = read_all_device(gpu_lib, ctx, p, 25_000)
+    assert dn == n == 60_000
+    same_batches(dbatches, hbatches)
+
+    def run(device: bool):
+        q = host.QcContext([3_000_000, 3_000_000], [1, 1], lib=gpu_lib)
+        h = C.c_void_p()
+        assert gpu_lib.ngsq_bam_open(p.encode(), 2, C.byref(h)) == 0
+        while True:
+            b = ffi.Batch()
+            rc = (gpu_lib.ngsq_bam_next_batch_device(h, q._ctx, 25_000, C.byref(b)) if device
+                  else gpu_lib.ngsq_bam_next_batch(h, 25_000, C.byref(b)))
+            assert rc == 0
+            if b.n_records == 0:
+                break
+            assert gpu_lib.ngsq_process_batch(q._ctx, C.byref(b), ffi.PASS_BOTH) == 0, gpu_lib.ngsq_last_error(q._ctx)
+        gpu_lib.ngsq_bam_close(h)
+        q.finalize()
+        r = q.results(["chr1", "chr2"])
+        q.close()
+        return r
+
+    assert run(True) == run(False)
+
+
+def test_device_reader_errors(gpu_lib, ctx, tmp_path):
+    rng = np.random.default_rng(1)
+    hb = random_batch(rng, 2000, [9000], max_len=80)
+    p = str(tmp_path / "x.bam")
+    bamio.write_bam(p, hb, ["chr1"], [9000], block_payload=3000)
+    data = open(p, "rb").read()
+    # a file cut inside a BGZF block
+    open(p, "wb").write(data[:len(data) // 2])
+    with pytest.raises(RuntimeError, match="truncated"):
+        read_all_device(gpu_lib, ctx, p, 1 << 20)
+    # host and device calls do not mix on one handle
+    open(p, "wb").write(data)
+    h = C.c_void_p()
+    assert gpu_lib.ngsq_bam_open(p.encode(), 1, C.byref(h)) == 0
+    b = ffi.Batch()
+    assert gpu_lib.ngsq_bam_next_batch(h, 10, C.byref(b)) == 0
+    assert gpu_lib.ngsq_bam_next_batch_device(h, ctx._ctx, 10, C.byref(b)) == ffi.ERR_STATE
+    gpu_lib.ngsq_bam_close(h)
+
+
+def test_device_reader_empty_bam(gpu_lib, ctx, tmp_path):
+    p = str(tmp_path / "e.bam")
+    bamio.write_bam(p, random_batch(np.random.default_rng(0), 0, [100]), ["chr1"], [100])
+    batches, n = read_all_device(gpu_lib, ctx, p, 100)
+    assert batches == [] and n == 0
