@@ -89,8 +89,10 @@ __global__ __launch_bounds__(64) void k_rec_candidates(const uint8_t *__restrict
         bool ok = false;
         if (o < s1 && o + 4 <= n_bytes) {
             const uint32_t bs = ld32(raw + o);
-            // cheap screen before the walk: the record itself must be plausible (or be the cut tail)
-            if (o + 4 + (uint64_t)bs <= n_bytes ? record_plausible(raw + o, bs, n_ref) : bs >= 32)
+            // cheap screen before the walk: a complete, plausible record.  (Bytes inside a record read as a
+            // huge block_size look like "the record cut by the end of the buffer": never a candidate.  The
+            // one true cut record of a chunk is then found by k_walk_one.)
+            if (o + 4 + (uint64_t)bs <= n_bytes && record_plausible(raw + o, bs, n_ref))
                 ok = walk(raw, n_bytes, o, s1, n_ref, true, &landing, &count);
         }
         uint64_t m = __ballot(ok);

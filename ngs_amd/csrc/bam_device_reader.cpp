@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -71,6 +72,15 @@ template <typename T> struct DevBuf {
     ~DevBuf() { (void)hipFree(p); }
 };
 
+// NGSQ_INGEST_TRACE=1: wall-clock of the ingest stages on stderr (measurement aid)
+bool trace_on() {
+    static const bool on = getenv("NGSQ_INGEST_TRACE") && atoi(getenv("NGSQ_INGEST_TRACE"));
+    return on;
+}
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 size_t env_mb(const char *name, size_t dflt_mb) {
     const char *e = getenv(name);
     const long v = e ? atol(e) : 0;
@@ -129,6 +139,7 @@ void free_ingest(DeviceIngest *d) { delete d; }
 // Inflate the next run of BGZF blocks behind the unparsed tail of d_raw and index its records.
 int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     hipStream_t st = d->ctx->stream;
+    const double t0 = now_ms();
     // ---- 1. keep the cut record at the end of the previous chunk
     const uint64_t carry = d->raw_len - d->tail_off;
     if (carry && d->tail_off) {
@@ -153,6 +164,7 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         }
         d->comp_fill += got;
     }
+    const double t1 = now_ms();
     d->blocks.clear();
     size_t consumed = 0;
     uint64_t total = 0;
@@ -167,6 +179,7 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
             return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: BGZF block does not fit the ingest buffer", b->path.c_str());
     }
     // ---- 3. inflate
+    const double t2 = now_ms();
     for (auto &bl : d->blocks) bl.out_off += carry;
     if (n_blk) {
         BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
@@ -187,6 +200,7 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         memmove(d->h_comp, d->h_comp + consumed, d->comp_fill - consumed);
         d->comp_fill -= consumed;
     }
+    const double t3 = now_ms();
     d->raw_len = carry + total;
     d->n_rec = d->cursor = 0;
     d->tail_off = 0;
@@ -249,6 +263,10 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
                              (unsigned long long)(b->n_read + bad));
     d->n_rec = total_rec;
     d->first = 0;
+    if (trace_on())
+        fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | read %.1f ms, split %.1f ms, "
+                        "h2d+inflate %.1f ms, index %.1f ms\n",
+                n_blk, consumed / 1e6, total / 1e6, (unsigned long long)total_rec, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
     return NGSQ_OK;
 }
 

@@ -8,14 +8,18 @@
 //  * the bit stream is decoded by the whole wave in lock step -- every lane holds the same
 //    decoder state, forced into SGPRs with readfirstlane/readlane, so the serial part runs
 //    on the scalar unit and the vector unit is used where DEFLATE is parallel:
-//      - the compressed bytes are fetched 256 B at a time, one dword per lane (coalesced,
-//        one buffer ahead), and handed to the bit reader with v_readlane;
+//      - (the compressed bytes themselves are read with scalar loads, one dword ahead);
 //      - Huffman tables are built by the 64 lanes (ballot-ranked canonical sort, parallel fill);
 //      - LZ77 matches are copied by the lanes, 64 bytes per step;
 //      - the finished block leaves LDS as coalesced dword stores.
-//  * the whole output of the block (<= 64 KiB) lives in LDS, so a match never reads HBM.
-//  * CRC32 of the block (gzip trailer) is verified on request: 64 slices in parallel, then
-//    combined with GF(2) polynomial multiplication.
+//  * the last 32 KiB of output (DEFLATE's window) live in an LDS ring, so a match never reads
+//    HBM; finished 16 KiB pieces leave the ring as coalesced dword stores.  39 KiB of LDS per
+//    wave: four waves per CU, one per SIMD -- the decoder is bound by instruction issue (one
+//    instruction per wave every four cycles), not by memory.
+//  * literals are collected in a register, one byte per lane (v_writelane), and reach the ring
+//    64 at a time; table entries carry two literals when both codes fit the lookup index.
+//  * CRC32 of the block (gzip trailer) is verified on request: 64 slices per piece in
+//    parallel, combined with GF(2) polynomial multiplication.
 #include <hip/hip_runtime.h>
 
 #include "ingest_kernels.h"
@@ -25,10 +29,12 @@ namespace ngsq {
 namespace {
 
 constexpr uint32_t LB = 10, DB = 8; // bits of the primary lookup tables
-constexpr uint32_t OUT_CAP = 65536;
+constexpr uint32_t RING = 32768, RMASK = RING - 1; // the DEFLATE window
+constexpr uint32_t PIECE = 16384;                  // bytes that leave the ring together
 
 // table entry: value << 16 | extra_bits << 8 | kind << 5 | code_bits
-constexpr uint32_t K_LIT = 0, K_EOB = 1, K_BASE = 2, K_ESC = 3, K_INVALID = 7;
+// K_LIT2: two literals (bits 16..23, then 24..31), code_bits = both codes.  Literal <=> (kind & 3) == 0.
+constexpr uint32_t K_LIT = 0, K_EOB = 1, K_BASE = 2, K_ESC = 3, K_LIT2 = 4, K_INVALID = 7;
 __device__ __forceinline__ constexpr uint32_t mk_entry(uint32_t value, uint32_t extra, uint32_t kind, uint32_t bits) {
     return value << 16 | extra << 8 | kind << 5 | bits;
 }
@@ -44,7 +50,7 @@ __constant__ uint8_t c_dist_extra[32] = {0, 0, 0, 0, 1, 1, 2, 2,  3,  3,  4,  4,
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct Lds {
-    uint8_t out[OUT_CAP];
+    uint8_t ring[RING];
     uint32_t lit_tab[1u << LB];
     uint32_t dist_tab[1u << DB]; // also the code-length-code table while a dynamic header is read
     uint32_t crc_tab[256];
@@ -56,26 +62,35 @@ struct Lds {
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// v[lane] = value (both uniform): one v_writelane_b32, no EXEC change, no memory
+__device__ __forceinline__ void write_lane(uint32_t &v, uint32_t value, uint32_t lane) {
+    // two SGPR sources would break the constant-bus rule: the lane select goes through M0
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane) : "m0"); // NOLINT
+}
 
-// ---- bit reader: uniform state, input staged one dword per lane ------------------------------
+// ---- bit reader: every field is uniform (SGPRs) ----------------------------------------------
+// The compressed bytes are read with SCALAR loads, one dword ahead of the bit buffer: the load for
+// the next refill is issued by this one and waited for together with the next table lookup.
+// constant address space: the compressed buffer is never written while the kernel runs, and this
+// is what lets the compiler use s_load_dword for it
+typedef const __attribute__((address_space(4))) uint32_t const_u32;
+
 struct BitReader {
-    const uint32_t *src; // dword-aligned start
-    uint32_t cur, nxt;   // per lane: dword (base + lane), dword (base + 64 + lane)
-    uint32_t base;       // dword index of lane 0 of cur
-    uint32_t idx;        // next dword to hand to the bit buffer
+    const_u32 *src; // dword-aligned origin (read-only, uniform address: s_load_dword)
+    uint32_t idx;        // dword that `ahead` holds
+    uint32_t ahead;      // src[idx], already loaded
     uint64_t buf;
     uint32_t cnt;
 
     __device__ void init(const uint8_t *p) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-        src = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-        seek((uint32_t)(a & 3));
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+        src = (const_u32 *)(reinterpret_cast<uintptr_t>(p - mis));
+        seek(mis);
     }
     // continue at byte `b` (counted from the dword-aligned origin `src`)
     __device__ void seek(uint32_t b) {
-        base = idx = b >> 2;
-        cur = src[base + (threadIdx.x & 63)];
-        nxt = src[base + 64 + (threadIdx.x & 63)];
+        idx = b >> 2;
+        ahead = src[idx];
         buf = 0;
         cnt = 0;
         refill();
@@ -85,15 +100,10 @@ struct BitReader {
     // make at least 33 bits available
     __device__ __forceinline__ void refill() {
         if (cnt <= 32) {
-            if (idx - base >= 64) {
-                base += 64;
-                cur = nxt;
-                nxt = src[base + 64 + (threadIdx.x & 63)];
-            }
-            const uint32_t w = __builtin_amdgcn_readlane(cur, idx - base);
-            buf |= (uint64_t)w << cnt;
+            buf |= (uint64_t)ahead << cnt;
             cnt += 32;
             idx += 1;
+            ahead = src[idx];
         }
     }
     __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
@@ -106,7 +116,7 @@ struct BitReader {
         drop(n);
         return v;
     }
-    // bits consumed since init, counted from the dword-aligned start
+    // bits consumed, counted from the dword-aligned origin (`ahead` is not in the buffer yet)
     __device__ uint64_t consumed_bits() const { return (uint64_t)idx * 32 - cnt; }
 };
 
@@ -239,6 +249,29 @@ __device__ uint32_t crc_xpow8(uint32_t n_bytes) { // x^(8 n) mod P
 
 } // namespace
 
+// After build_table(lit): pair up literals.  Index i starts with a literal of L1 bits; if the code
+// that follows is decided by the remaining LB - L1 bits and is a literal too, the entry takes both.
+__device__ void pair_literals(Lds &L, uint32_t lane) {
+    uint32_t ne[(1u << LB) / 64];
+#pragma unroll
+    for (uint32_t k = 0; k < (1u << LB) / 64; k++) {
+        const uint32_t i = k * 64 + lane;
+        uint32_t e = L.lit_tab[i];
+        const uint32_t l1 = e & 31u;
+        if (((e >> 5) & 7u) == K_LIT && l1 < LB) {
+            const uint32_t e2 = L.lit_tab[i >> l1];
+            const uint32_t l2 = e2 & 31u;
+            if (((e2 >> 5) & 7u) == K_LIT && l1 + l2 <= LB)
+                e = ((e2 >> 16) & 0xFFu) << 24 | ((e >> 16) & 0xFFu) << 16 | K_LIT2 << 5 | (l1 + l2);
+        }
+        ne[k] = e;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < (1u << LB) / 64; k++) L.lit_tab[k * 64 + lane] = ne[k];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
                                                      const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
@@ -254,6 +287,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         if (lane == 0) status[bi] = INF_OK;
         return;
     }
+    uint32_t xs_full = 0; // x^(8 * slice) for full pieces
+    constexpr uint32_t SLICE = 260; // PIECE / 64 rounded up to 4 * odd: the lanes' slices start in distinct banks
     if (check_crc) {
         // byte-wise CRC table
         for (uint32_t i = lane; i < 256; i += 64) {
@@ -262,17 +297,62 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
             L.crc_tab[i] = c;
         }
+        xs_full = crc_xpow8(SLICE);
     }
     BitReader br;
     br.init(comp + blk.in_off);
     const uint64_t bit_limit = (uint64_t)((reinterpret_cast<uintptr_t>(comp + blk.in_off) & 3u) + in_len) * 8u;
+    uint8_t *const gdst = out + blk.out_off;
 
-    uint32_t pos = 0, err = INF_OK;
+    // output state: bytes [0, spos) are in the ring, [spos, pos) are staged in `lit` (lane = position & 63),
+    // [0, flushed) have left for HBM
+    uint32_t pos = 0, spos = 0, flushed = 0, err = INF_OK, crc = 0;
+    uint32_t lit = 0;
+
+    auto flush_stage = [&]() {
+        const uint32_t p = (spos & ~63u) + lane;
+        if (p >= spos && p < pos) L.ring[p & RMASK] = (uint8_t)lit;
+        spos = pos;
+    };
+    // ring bytes [flushed, flushed + n) -> HBM (and into the running CRC)
+    auto flush_piece = [&](uint32_t n) {
+        if (check_crc) {
+            const uint32_t lo = min(lane * SLICE, n), hi = min(lo + SLICE, n);
+            uint32_t c = 0xFFFFFFFFu;
+            for (uint32_t i = lo; i < hi; i++) c = L.crc_tab[(c ^ L.ring[(flushed + i) & RMASK]) & 0xFFu] ^ (c >> 8);
+            c = ~c; // CRC of the slice (of the empty string: 0)
+            for (uint32_t k = 0; k < 64; k++) {
+                const uint32_t lk = min(k * SLICE, n), hk = min(lk + SLICE, n);
+                if (hk == lk) break;
+                // crc(A || B) = crc(A) * x^(8 |B|) + crc(B)
+                crc = crc_mul(hk - lk == SLICE ? xs_full : crc_xpow8(hk - lk), crc) ^ __builtin_amdgcn_readlane(c, k);
+            }
+        }
+        uint8_t *dst = gdst + flushed;
+        const uint32_t head = min((uint32_t)((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u), n);
+        if (lane < head) dst[lane] = L.ring[(flushed + lane) & RMASK];
+        const uint32_t body = (n - head) / 4;
+        uint32_t *dw = reinterpret_cast<uint32_t *>(dst + head);
+        const uint32_t *lw = reinterpret_cast<const uint32_t *>(L.ring);
+        for (uint32_t j = lane; j < body; j += 64) {
+            const uint32_t k = flushed + head + 4 * j; // stream offset of this dword
+            const uint32_t w0 = lw[(k & RMASK) >> 2], w1 = lw[((k + 4) & RMASK) >> 2];
+            dw[j] = __builtin_amdgcn_alignbyte(w1, w0, k & 3u);
+        }
+        const uint32_t tail0 = head + 4 * body;
+        if (tail0 + lane < n) dst[tail0 + lane] = L.ring[(flushed + tail0 + lane) & RMASK];
+        flushed += n;
+    };
+
     bool last = false;
     while (!last && err == INF_OK) {
         br.refill();
         last = br.take(1);
         const uint32_t type = br.take(2);
+        if (br.consumed_bits() > bit_limit) {
+            err = INF_INPUT_OVERRUN;
+            break;
+        }
         if (type == 0) {
             // stored: skip to the byte boundary, LEN, NLEN, then LEN raw bytes
             br.drop(br.cnt & 7u);
@@ -288,11 +368,18 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 err = INF_OUTPUT_OVERRUN;
                 break;
             }
+            flush_stage();
             // the bit buffer holds whole bytes now: copy the source bytes directly, then restart behind them
             const uint32_t byte0 = (uint32_t)(br.consumed_bits() >> 3);
-            const uint8_t *sp = reinterpret_cast<const uint8_t *>(br.src) + byte0;
-            for (uint32_t i = lane; i < len; i += 64) L.out[pos + i] = sp[i];
-            pos += len;
+            const uint8_t *sp = comp + blk.in_off - (reinterpret_cast<uintptr_t>(comp + blk.in_off) & 3u) + byte0;
+            for (uint32_t done = 0; done < len;) {
+                const uint32_t n = min(len - done, PIECE - (pos - flushed));
+                for (uint32_t i = lane; i < n; i += 64) L.ring[(pos + i) & RMASK] = sp[done + i];
+                pos += n;
+                done += n;
+                if (pos - flushed >= PIECE) flush_piece(PIECE);
+            }
+            spos = pos;
             br.seek(byte0 + len);
             continue;
         }
@@ -386,21 +473,32 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             err = INF_BAD_CODE_LENGTHS;
             break;
         }
+        pair_literals(L, lane);
         // ---- the symbol loop
         for (;;) {
             br.refill();
             const uint32_t e = next_entry(L, L.lit_tab, LB, 0, 0, br);
-            const uint32_t kind = (e >> 5) & 7u;
             br.drop(e & 31u);
-            if (kind == K_LIT) {
-                if (pos >= isize) {
-                    err = INF_OUTPUT_OVERRUN;
-                    break;
-                }
-                if (lane == 0) L.out[pos] = (uint8_t)(e >> 16);
+            if ((e & (3u << 5)) == 0) {
+                // one or two literals: into the staging register, lane = output position & 63
+                write_lane(lit, (e >> 16) & 0xFFu, pos & 63u);
                 pos += 1;
+                if (e & (4u << 5)) {
+                    if ((pos & 63u) == 0) flush_stage();
+                    write_lane(lit, e >> 24, pos & 63u);
+                    pos += 1;
+                }
+                if ((pos & 63u) == 0) {
+                    flush_stage();
+                    if (pos > isize) { // also bounds the work on a corrupt stream
+                        err = INF_OUTPUT_OVERRUN;
+                        break;
+                    }
+                    if (pos - flushed >= PIECE) flush_piece(PIECE);
+                }
                 continue;
             }
+            const uint32_t kind = (e >> 5) & 7u;
             if (kind == K_EOB) break;
             if (kind != K_BASE) {
                 err = INF_BAD_SYMBOL;
@@ -423,55 +521,28 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 err = INF_OUTPUT_OVERRUN;
                 break;
             }
+            flush_stage();
             // the source run [pos - dist, pos) is final: byte i of the match is its byte i mod dist
             const uint32_t from = pos - dist;
             if (dist >= len) {
-                for (uint32_t i = lane; i < len; i += 64) L.out[pos + i] = L.out[from + i];
+                for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
             } else {
-                for (uint32_t i = lane; i < len; i += 64) L.out[pos + i] = L.out[from + i % dist];
+                for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dist) & RMASK];
             }
             pos += len;
+            spos = pos;
+            if (pos - flushed >= PIECE) flush_piece(PIECE);
         }
     }
-    if (err == INF_OK && pos != isize) err = INF_SIZE_MISMATCH;
+    flush_stage();
+    if (err == INF_OK && pos != isize) err = pos > isize ? INF_OUTPUT_OVERRUN : INF_SIZE_MISMATCH;
     if (err == INF_OK && br.consumed_bits() > bit_limit) err = INF_INPUT_OVERRUN;
     __syncthreads();
-
-    if (err == INF_OK && check_crc) {
-        // 64 slices of S bytes (S/4 odd: the lanes read distinct LDS banks), then combine
-        const uint32_t S = (((isize + 63) / 64 + 3) / 4 | 1u) * 4;
-        const uint32_t lo = min(lane * S, isize), hi = min(lo + S, isize);
-        uint32_t c = 0xFFFFFFFFu;
-        for (uint32_t i = lo; i < hi; i++) c = L.crc_tab[(c ^ L.out[i]) & 0xFFu] ^ (c >> 8);
-        c = ~c; // CRC of the slice (of the empty string: 0)
-        const uint32_t xs = crc_xpow8(S);
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < 64; k++) {
-            const uint32_t ck = __builtin_amdgcn_readlane(c, k);
-            const uint32_t lk = min(k * S, isize), hk = min(lk + S, isize);
-            if (hk == lk) break;
-            // crc(A || B) = crc(A) * x^(8 |B|) + crc(B)
-            acc = crc_mul(hk - lk == S ? xs : crc_xpow8(hk - lk), acc) ^ ck;
-        }
-        if (acc != uni(blk.crc)) err = INF_CRC_MISMATCH;
+    if (err == INF_OK) {
+        while (flushed < pos) flush_piece(min(pos - flushed, PIECE));
+        if (check_crc && crc != uni(blk.crc)) err = INF_CRC_MISMATCH;
     }
     if (lane == 0) status[bi] = err;
-    if (err != INF_OK) return;
-
-    // ---- LDS -> HBM, aligned dword stores
-    uint8_t *dst = out + blk.out_off;
-    const uint32_t head = min((uint32_t)((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u), isize);
-    if (lane < head) dst[lane] = L.out[lane];
-    const uint32_t body = (isize - head) / 4;
-    uint32_t *dw = reinterpret_cast<uint32_t *>(dst + head);
-    const uint32_t *lw = reinterpret_cast<const uint32_t *>(L.out);
-    for (uint32_t j = lane; j < body; j += 64) {
-        const uint32_t k = head + 4 * j; // LDS byte offset of this dword
-        const uint32_t w0 = lw[k >> 2], w1 = lw[(k >> 2) + 1 < OUT_CAP / 4 ? (k >> 2) + 1 : k >> 2];
-        dw[j] = __builtin_amdgcn_alignbyte(w1, w0, k & 3u);
-    }
-    const uint32_t tail0 = head + 4 * body;
-    if (tail0 + lane < isize) dst[tail0 + lane] = L.out[tail0 + lane];
 }
 
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,

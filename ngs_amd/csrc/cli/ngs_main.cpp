@@ -5,7 +5,8 @@
 // :109-218 (qc), :226-421 (app: open_and_parse, sequence concordance check, facet selection,
 // pass 1 / pass 2 with the two `-n` rules, aggregate, write <prefix>.results.json).
 // The per-record facet loops are replaced by SoA batches through the C ABI (include/ngsq.h);
-// ingest is include/ngsq_bam.h.  Additive flags: --device, --batch-records, --threads, --gc-seed.
+// ingest is include/ngsq_bam.h.  Additive flags: --device, --batch-records, --threads, --gc-seed,
+// --ingest host|device (device: the GPU inflates and parses the BAM; without -n only).
 // Not built (out of scope this round): the other subcommands, the Genomic
 // Features facet (-f) and --vaf-file.
 #include <sys/stat.h>
@@ -222,6 +223,7 @@ struct Args {
     bool has_n = false, has_out_dir = false, has_prefix = false, has_only = false;
     unsigned long long n = 0;
     int device = 0, threads = 0;
+    bool ingest_device = false; // --ingest device: BGZF inflate + BAM parse on the GPU (ngsq_bam_next_batch_device)
     unsigned long long batch_records = 1ull << 21, gc_seed = 0x4E4753;
 };
 
@@ -239,7 +241,7 @@ void usage() {
             "      --vaf-file <PATH>           (not supported by this build)\n"
             "      --five-prime-utr-feature-name, --three-prime-utr-feature-name, --coding-sequence-feature-name,\n"
             "      --exon-feature-name, --gene-feature-name <STRING>   accepted for compatibility\n"
-            "      --device <N> --batch-records <N> --threads <N> --gc-seed <N>   (additive, this build)\n");
+            "      --device <N> --batch-records <N> --threads <N> --gc-seed <N> --ingest host|device   (additive, this build)\n");
 }
 
 #define CHECK(ctx, expr)                                                                                   \
@@ -276,6 +278,14 @@ int main(int argc, char **argv) {
             (void)val(s.c_str());
         else if (s == "--device") a.device = atoi(val("--device").c_str());
         else if (s == "--threads") a.threads = atoi(val("--threads").c_str());
+        else if (s == "--ingest") {
+            const std::string v = val("--ingest");
+            if (v != "host" && v != "device") {
+                fprintf(stderr, "error: --ingest takes 'host' or 'device'\n");
+                return 2;
+            }
+            a.ingest_device = v == "device";
+        }
         else if (s == "--batch-records") a.batch_records = strtoull(val("--batch-records").c_str(), nullptr, 10);
         else if (s == "--gc-seed") a.gc_seed = strtoull(val("--gc-seed").c_str(), nullptr, 0);
         else if (!s.empty() && s[0] == '-') bail("unexpected argument '" + s + "' found");
@@ -402,7 +412,9 @@ int main(int argc, char **argv) {
         // no truncation: both passes see every record -> one scan
         for (;;) {
             ngsq_batch b;
-            if (ngsq_bam_next_batch(bam, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
+            if ((a.ingest_device ? ngsq_bam_next_batch_device(bam, ctx, a.batch_records, &b)
+                                 : ngsq_bam_next_batch(bam, a.batch_records, &b)) != NGSQ_OK)
+                bail(ngsq_bam_last_error());
             if (!b.n_records) break;
             CHECK(ctx, ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH));
             const unsigned long long before = n_pass1;

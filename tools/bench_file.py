@@ -43,29 +43,31 @@ def main():
     ap.add_argument("--records", type=int, default=20_000_000)
     ap.add_argument("--batch", type=int, default=4_000_000)
     ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--skip-pcie", action="store_true")
     args = ap.parse_args()
     build.build(verbose=False)
     lib = ffi.load_library()
     out = {}
     # ---- (a) PCIe-inclusive
-    scfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2)
-    hb = host.synth_host_batch(scfg, 0, args.batch, lib)
-    pb, keep = pinned_copy(lib, hb)
-    ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=150, gc_seed=0x4E4753, lib=lib)
-    for variant, b in (("pinned", pb), ("pageable", hb)):
-        ctx.reset()
-        ctx.process_batch(b)
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        reps = 6
-        for _ in range(reps):
+    if not args.skip_pcie:
+        scfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2)
+        hb = host.synth_host_batch(scfg, 0, args.batch, lib)
+        pb, keep = pinned_copy(lib, hb)
+        ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=150, gc_seed=0x4E4753, lib=lib)
+        for variant, b in (("pinned", pb), ("pageable", hb)):
+            ctx.reset()
             ctx.process_batch(b)
-        ctx.synchronize()
-        dt = time.perf_counter() - t0
-        out[f"h2d_inclusive_{variant}"] = {"records_per_s": round(reps * b.n / dt), "GB_per_s": round(reps * b.n * 254 / dt / 1e9, 1),
-                                            "batch_records": b.n}
-    ctx.finalize()
-    ctx.close()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            reps = 6
+            for _ in range(reps):
+                ctx.process_batch(b)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            out[f"h2d_inclusive_{variant}"] = {"records_per_s": round(reps * b.n / dt), "GB_per_s": round(reps * b.n * 254 / dt / 1e9, 1),
+                                                "batch_records": b.n}
+        ctx.finalize()
+        ctx.close()
     # ---- (b) file end to end
     tmp = tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
     bam = os.path.join(tmp, "synth.bam")
@@ -75,13 +77,19 @@ def main():
     out["bam_write_s"] = round(time.perf_counter() - t0, 2)
     out["bam_bytes"] = os.path.getsize(bam)
     ngs = build.build_cli(verbose=False)
-    for run_i in range(2):
-        t0 = time.perf_counter()
-        r = subprocess.run([ngs, "-q", "qc", bam, "GRCh38_no_alt_AnalysisSet", "-o", tmp], capture_output=True, text=True)
-        dt = time.perf_counter() - t0
-        assert r.returncode == 0, r.stderr
-        out[f"file_end_to_end_run{run_i}"] = {"seconds": round(dt, 2), "records_per_s": round(args.records / dt),
-                                             "compressed_MB_per_s": round(out["bam_bytes"] / dt / 1e6)}
+    results = {}
+    for ingest in ("host", "device"):
+        for run_i in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([ngs, "-q", "qc", bam, "GRCh38_no_alt_AnalysisSet", "-o", tmp, "--ingest", ingest],
+                               capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            assert r.returncode == 0, r.stderr
+            out[f"file_end_to_end_{ingest}_run{run_i}"] = {
+                "seconds": round(dt, 2), "records_per_s": round(args.records / dt),
+                "compressed_MB_per_s": round(out["bam_bytes"] / dt / 1e6)}
+        results[ingest] = json.load(open(os.path.join(tmp, "synth.bam.results.json")))
+    out["device_ingest_json_equals_host_ingest_json"] = results["host"] == results["device"]
     res = json.load(open(os.path.join(tmp, "synth.bam.results.json")))
     out["check_total"] = res["general"]["records"]["total"]
     out["host_cores"] = os.cpu_count()
