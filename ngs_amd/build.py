@@ -17,6 +17,7 @@ SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip"
 HEADERS = ["kernels.h", "context.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h",
            "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-gpu-rdc"]
+FLAGS += os.environ.get("NGSQ_EXTRA_FLAGS", "").split()  # measurement builds, e.g. -DNGSQ_INFLATE_PROFILE (use --force)
 OBJ_DIR = os.path.join(HERE, "_obj")  # per-source objects (git-ignored): only changed sources recompile
 
 

@@ -4,27 +4,56 @@
 // (flate2 1.0.24 / miniz_oxide 0.5.4) under `reader.records(&header)`, src/qc/command.rs:305 and
 // src/utils/formats/bam.rs:32-56.  Written from RFC 1951 and the SAM/BAM specification 4.1.
 //
-// One WAVEFRONT per BGZF block (blocks are independent gzip members of <= 64 KiB):
-//  * the bit stream is decoded by the whole wave in lock step -- every lane holds the same
-//    decoder state, forced into SGPRs with readfirstlane/readlane, so the serial part runs
-//    on the scalar unit and the vector unit is used where DEFLATE is parallel:
-//      - (the compressed bytes themselves are read with scalar loads, one dword ahead);
-//      - Huffman tables are built by the 64 lanes (ballot-ranked canonical sort, parallel fill);
-//      - LZ77 matches are copied by the lanes, 64 bytes per step;
-//      - the finished block leaves LDS as coalesced dword stores.
-//  * the last 32 KiB of output (DEFLATE's window) live in an LDS ring, so a match never reads
-//    HBM; finished 16 KiB pieces leave the ring as coalesced dword stores.  39 KiB of LDS per
-//    wave: four waves per CU, one per SIMD -- the decoder is bound by instruction issue (one
-//    instruction per wave every four cycles), not by memory.
-//  * literals are collected in a register, one byte per lane (v_writelane), and reach the ring
-//    64 at a time; table entries carry two literals when both codes fit the lookup index.
+// One WAVEFRONT per BGZF block (blocks are independent gzip members of <= 64 KiB).  A wave running
+// alone on its SIMD issues one instruction every ~5 cycles, so the design minimises instructions
+// per symbol and puts all 64 lanes to work on the one bit stream:
+//  * SYMBOL WINDOW.  Lane j looks up the Huffman code that WOULD start at bit j of the next 64
+//    bits (two LDS gathers: literal/length and distance table, every lane at once).  The real
+//    symbol boundaries are then a chain 0 -> L[0] -> L[0]+L[L[0]] ... followed with one
+//    v_readlane + add per symbol on the scalar unit; the lanes on the chain write their literals
+//    to the output ring in one store.  A length code ends the chain: its extra bits, the distance
+//    code and its extra bits are already sitting in the lanes at those bit offsets.
+//  * the bit stream lives in SGPRs (four window dwords + four prefetched by scalar loads).
+//  * Huffman tables are built by the 64 lanes (ballot-ranked canonical sort, parallel fill).
+//  * LZ77 matches are copied by the lanes, 64 bytes per step, inside a 32 KiB LDS ring (DEFLATE's
+//    window), so a match never reads HBM; finished 16 KiB pieces leave the ring as coalesced
+//    dword stores.  39 KiB of LDS per wave: four waves per CU, one per SIMD.
 //  * CRC32 of the block (gzip trailer) is verified on request: 64 slices per piece in
 //    parallel, combined with GF(2) polynomial multiplication.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "ingest_kernels.h"
 
 namespace ngsq {
+
+// Build with -DNGSQ_INFLATE_PROFILE to accumulate s_memtime deltas per decoder phase (measurement aid
+// for DESIGN.md; the counters are read back by launch_bgzf_inflate and printed to stderr).
+#ifdef NGSQ_INFLATE_PROFILE
+__device__ unsigned long long g_inflate_prof[16];
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(k)                                                     \
+    do {                                                            \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof_acc[k] += now_ - prof_t;                               \
+        prof_t = now_;                                              \
+    } while (0)
+#define PROF_COUNT(k, n) prof_cnt[k] += (n)
+#define PROF_FLUSH                                                                             \
+    do {                                                                                       \
+        if (lane == 0)                                                                         \
+            for (int k_ = 0; k_ < 8; k_++) {                                                   \
+                atomicAdd(&g_inflate_prof[k_], prof_acc[k_]);                                  \
+                atomicAdd(&g_inflate_prof[8 + k_], prof_cnt[k_]);                              \
+            }                                                                                  \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_COUNT(k, n)
+#define PROF_FLUSH
+#endif
 
 namespace {
 
@@ -33,8 +62,7 @@ constexpr uint32_t RING = 32768, RMASK = RING - 1; // the DEFLATE window
 constexpr uint32_t PIECE = 16384;                  // bytes that leave the ring together
 
 // table entry: value << 16 | extra_bits << 8 | kind << 5 | code_bits
-// K_LIT2: two literals (bits 16..23, then 24..31), code_bits = both codes.  Literal <=> (kind & 3) == 0.
-constexpr uint32_t K_LIT = 0, K_EOB = 1, K_BASE = 2, K_ESC = 3, K_LIT2 = 4, K_INVALID = 7;
+constexpr uint32_t K_LIT = 0, K_EOB = 1, K_BASE = 2, K_ESC = 3, K_INVALID = 7;
 __device__ __forceinline__ constexpr uint32_t mk_entry(uint32_t value, uint32_t extra, uint32_t kind, uint32_t bits) {
     return value << 16 | extra << 8 | kind << 5 | bits;
 }
@@ -62,62 +90,85 @@ struct Lds {
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-// v[lane] = value (both uniform): one v_writelane_b32, no EXEC change, no memory
-__device__ __forceinline__ void write_lane(uint32_t &v, uint32_t value, uint32_t lane) {
-    // two SGPR sources would break the constant-bus rule: the lane select goes through M0
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane) : "m0"); // NOLINT
+// The serial core of the decoder, seven scalar instructions per symbol: starting at bit s, mark the
+// symbol start in `lits` and step to the next one (step[s] bits further) until a lane says stop
+// (bit 7 of its step) or the window ends (s >= 64).  Hand-scheduled: the compiler's structurised
+// control flow needs about twice as many instructions for this loop.
+__device__ __forceinline__ void chain_literals(uint32_t step, uint32_t &s, uint64_t &lits) {
+    uint32_t st;
+    asm volatile("1:\n\t"
+                 "v_readlane_b32 %[st], %[step], %[s]\n\t"
+                 "s_bitcmp1_b32 %[st], 7\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_bitset1_b64 %[lits], %[s]\n\t"
+                 "s_add_u32 %[s], %[s], %[st]\n\t"
+                 "s_cmp_lt_u32 %[s], 64\n\t"
+                 "s_cbranch_scc1 1b\n"
+                 "2:"
+                 : [s] "+s"(s), [lits] "+s"(lits), [st] "=&s"(st)
+                 : [step] "v"(step)
+                 : "scc");
 }
-
-// ---- bit reader: every field is uniform (SGPRs) ----------------------------------------------
-// The compressed bytes are read with SCALAR loads, one dword ahead of the bit buffer: the load for
-// the next refill is issued by this one and waited for together with the next table lookup.
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v);
+}
+// ---- bit stream: every field is uniform (SGPRs) -------------------------------------------------
 // constant address space: the compressed buffer is never written while the kernel runs, and this
 // is what lets the compiler use s_load_dword for it
 typedef const __attribute__((address_space(4))) uint32_t const_u32;
 
-struct BitReader {
-    const_u32 *src; // dword-aligned origin (read-only, uniform address: s_load_dword)
-    uint32_t idx;        // dword that `ahead` holds
-    uint32_t ahead;      // src[idx], already loaded
-    uint64_t buf;
-    uint32_t cnt;
+struct BitWindow {
+    const_u32 *src;          // dword-aligned origin
+    uint32_t w0, w1, w2, w3; // the next 128 - off bits of the stream start at bit `off` of w0
+    uint32_t n0, n1, n2, n3; // src[idx .. idx+3], loaded ahead
+    uint32_t idx;            // dword index of n0
+    uint32_t off;            // 0..31
 
-    __device__ void init(const uint8_t *p) {
+    __device__ __forceinline__ void init(const uint8_t *p) {
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
         src = (const_u32 *)(reinterpret_cast<uintptr_t>(p - mis));
         seek(mis);
     }
-    // continue at byte `b` (counted from the dword-aligned origin `src`)
-    __device__ void seek(uint32_t b) {
+    // continue at byte `b` (counted from the dword-aligned origin)
+    __device__ __forceinline__ void seek(uint32_t b) {
         idx = b >> 2;
-        ahead = src[idx];
-        buf = 0;
-        cnt = 0;
-        refill();
-        drop((b & 3) * 8);
-        refill();
+        w0 = src[idx], w1 = src[idx + 1], w2 = src[idx + 2], w3 = src[idx + 3];
+        idx += 4;
+        n0 = src[idx], n1 = src[idx + 1], n2 = src[idx + 2], n3 = src[idx + 3];
+        off = (b & 3u) * 8u;
     }
-    // make at least 33 bits available
-    __device__ __forceinline__ void refill() {
-        if (cnt <= 32) {
-            buf |= (uint64_t)ahead << cnt;
-            cnt += 32;
-            idx += 1;
-            ahead = src[idx];
+    // drop n bits (n <= 128 - 32)
+    __device__ __forceinline__ void consume(uint32_t n) {
+        off += n;
+        const uint32_t k = off >> 5;
+        off &= 31u;
+        if (k) {
+            if (k == 1) w0 = w1, w1 = w2, w2 = w3, w3 = n0;
+            else if (k == 2) w0 = w2, w1 = w3, w2 = n0, w3 = n1;
+            else if (k == 3) w0 = w3, w1 = n0, w2 = n1, w3 = n2;
+            else w0 = n0, w1 = n1, w2 = n2, w3 = n3;
+            idx += k;
+            n0 = src[idx], n1 = src[idx + 1], n2 = src[idx + 2], n3 = src[idx + 3];
         }
     }
-    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
-    __device__ __forceinline__ void drop(uint32_t n) {
-        buf >>= n;
-        cnt -= n;
-    }
-    __device__ __forceinline__ uint32_t take(uint32_t n) {
-        const uint32_t v = peek(n);
-        drop(n);
+    // the next 32 bits (uniform)
+    __device__ __forceinline__ uint32_t bits32() const { return (uint32_t)((((uint64_t)w1 << 32) | w0) >> off); }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { // n <= 25
+        const uint32_t v = bits32() & ((1u << n) - 1u);
+        consume(n);
         return v;
     }
-    // bits consumed, counted from the dword-aligned origin (`ahead` is not in the buffer yet)
-    __device__ uint64_t consumed_bits() const { return (uint64_t)idx * 32 - cnt; }
+    // 32 bits starting `lane` bits further on (per lane, lane < 64)
+    __device__ __forceinline__ uint32_t lane_bits32(uint32_t lane) const {
+        // three funnel shifts, then a choice between VALUES (a choice between the members themselves
+        // would be turned into an indexed load from the struct, which then has to live in memory)
+        const uint32_t t = off + lane, sh = t & 31u;
+        const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh),
+                       a2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+        return t < 32 ? a0 : t < 64 ? a1 : a2;
+    }
+    // bits consumed, counted from the dword-aligned origin
+    __device__ __forceinline__ uint64_t consumed_bits() const { return (uint64_t)(idx - 4) * 32 + off; }
 };
 
 // ---- canonical Huffman tables ----------------------------------------------------------------
@@ -188,44 +239,35 @@ __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t wh
     return true;
 }
 
-// decode one symbol whose code is longer than the primary table (bit-serial canonical decode);
-// returns the symbol or 0xFFFF, and the code length in *bits
-__device__ uint32_t slow_symbol(const Lds &L, uint32_t which, uint64_t buf, uint32_t *bits) {
-    uint32_t code = 0, first = 0, index = 0;
-    for (uint32_t l = 1; l < 16; l++) {
-        code |= (uint32_t)(buf >> (l - 1)) & 1u;
-        const uint32_t c = uni(L.cnt[which][l]);
-        if (code - first < c) {
+// Decode one symbol whose code is longer than TB bits.  x = the stream bits at the symbol.  For each
+// length l the first l bits, read as a number MSB first, are a code of that length iff they fall into
+// [fcode[l], fcode[l] + cnt[l]) (canonical Huffman codes).  Returns the symbol or 0xFFFF; *bits = l.
+__device__ uint32_t slow_symbol(const Lds &L, uint32_t which, uint32_t TB, uint32_t x, uint32_t *bits) {
+    const uint32_t rev = __brev(x);
+    for (uint32_t l = TB + 1; l < 16; l++) {
+        const uint32_t code = rev >> (32 - l);
+        const uint32_t f = uni(L.fcode[which][l]), c = uni(L.cnt[which][l]);
+        if (code - f < c) {
             *bits = l;
-            return uni(L.syms[which][index + (code - first)]);
+            return uni(L.syms[which][uni(L.start[which][l]) + (code - f)]);
         }
-        index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
     }
     *bits = 15;
     return 0xFFFFu;
 }
 
-// entry of the next symbol of table `tab`; resolves long codes to a full entry
-__device__ __forceinline__ uint32_t next_entry(const Lds &L, const uint32_t *tab, uint32_t TB, uint32_t which,
-                                               uint32_t alphabet, const BitReader &br) {
-    uint32_t e = uni(tab[br.peek(TB)]);
-    if (__builtin_expect(((e >> 5) & 7u) == K_ESC, 0)) {
-        uint32_t bits;
-        const uint32_t s = slow_symbol(L, which, br.buf, &bits);
-        if (s == 0xFFFFu) return mk_entry(0, 0, K_INVALID, 15);
-        if (alphabet == 0) {
-            if (s < 256) e = mk_entry(s, 0, K_LIT, bits);
-            else if (s == 256) e = mk_entry(0, 0, K_EOB, bits);
-            else if (s < 286) e = mk_entry(c_len_base[s - 257], c_len_extra[s - 257], K_BASE, bits);
-            else e = mk_entry(0, 0, K_INVALID, bits);
-        } else {
-            e = s < 30 ? mk_entry(c_dist_base[s], c_dist_extra[s], K_BASE, bits) : mk_entry(0, 0, K_INVALID, bits);
-        }
+// full entry of a symbol whose primary entry says "long code"
+__device__ uint32_t resolve_long(const Lds &L, uint32_t alphabet, uint32_t x) {
+    uint32_t bits;
+    const uint32_t s = slow_symbol(L, alphabet, alphabet == 0 ? LB : DB, x, &bits);
+    if (s == 0xFFFFu) return mk_entry(0, 0, K_INVALID, 15);
+    if (alphabet == 0) {
+        if (s < 256) return mk_entry(s, 0, K_LIT, bits);
+        if (s == 256) return mk_entry(0, 0, K_EOB, bits);
+        if (s < 286) return mk_entry(c_len_base[s - 257], c_len_extra[s - 257], K_BASE, bits);
+        return mk_entry(0, 0, K_INVALID, bits);
     }
-    return e;
+    return s < 30 ? mk_entry(c_dist_base[s], c_dist_extra[s], K_BASE, bits) : mk_entry(0, 0, K_INVALID, bits);
 }
 
 // ---- CRC32 (gzip): GF(2) helpers in the reflected representation -----------------------------
@@ -249,29 +291,6 @@ __device__ uint32_t crc_xpow8(uint32_t n_bytes) { // x^(8 n) mod P
 
 } // namespace
 
-// After build_table(lit): pair up literals.  Index i starts with a literal of L1 bits; if the code
-// that follows is decided by the remaining LB - L1 bits and is a literal too, the entry takes both.
-__device__ void pair_literals(Lds &L, uint32_t lane) {
-    uint32_t ne[(1u << LB) / 64];
-#pragma unroll
-    for (uint32_t k = 0; k < (1u << LB) / 64; k++) {
-        const uint32_t i = k * 64 + lane;
-        uint32_t e = L.lit_tab[i];
-        const uint32_t l1 = e & 31u;
-        if (((e >> 5) & 7u) == K_LIT && l1 < LB) {
-            const uint32_t e2 = L.lit_tab[i >> l1];
-            const uint32_t l2 = e2 & 31u;
-            if (((e2 >> 5) & 7u) == K_LIT && l1 + l2 <= LB)
-                e = ((e2 >> 16) & 0xFFu) << 24 | ((e >> 16) & 0xFFu) << 16 | K_LIT2 << 5 | (l1 + l2);
-        }
-        ne[k] = e;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < (1u << LB) / 64; k++) L.lit_tab[k * 64 + lane] = ne[k];
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
                                                      const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
@@ -281,7 +300,11 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     const uint32_t lane = threadIdx.x;
     const uint32_t bi = blockIdx.x;
     if (bi >= n_blocks) return;
-    const BgzfBlock blk = blocks[bi];
+    // the descriptor, forced uniform: everything derived from it (the whole bit stream state) stays in SGPRs
+    BgzfBlock blk = blocks[bi];
+    blk.in_off = uni64(blk.in_off);
+    blk.out_off = uni64(blk.out_off);
+    blk.crc = uni(blk.crc);
     const uint32_t isize = uni(blk.isize), in_len = uni(blk.in_len);
     if (isize == 0 && in_len == 0) {
         if (lane == 0) status[bi] = INF_OK;
@@ -299,21 +322,15 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         }
         xs_full = crc_xpow8(SLICE);
     }
-    BitReader br;
+    BitWindow br;
     br.init(comp + blk.in_off);
-    const uint64_t bit_limit = (uint64_t)((reinterpret_cast<uintptr_t>(comp + blk.in_off) & 3u) + in_len) * 8u;
+    const uint32_t in_mis = (uint32_t)(reinterpret_cast<uintptr_t>(comp + blk.in_off) & 3u);
+    const uint64_t bit_limit = (uint64_t)(in_mis + in_len) * 8u;
     uint8_t *const gdst = out + blk.out_off;
 
-    // output state: bytes [0, spos) are in the ring, [spos, pos) are staged in `lit` (lane = position & 63),
-    // [0, flushed) have left for HBM
-    uint32_t pos = 0, spos = 0, flushed = 0, err = INF_OK, crc = 0;
-    uint32_t lit = 0;
+    // output state: bytes [0, pos) are in the ring (the last 32 KiB of them), [0, flushed) have left for HBM
+    uint32_t pos = 0, flushed = 0, err = INF_OK, crc = 0;
 
-    auto flush_stage = [&]() {
-        const uint32_t p = (spos & ~63u) + lane;
-        if (p >= spos && p < pos) L.ring[p & RMASK] = (uint8_t)lit;
-        spos = pos;
-    };
     // ring bytes [flushed, flushed + n) -> HBM (and into the running CRC)
     auto flush_piece = [&](uint32_t n) {
         if (check_crc) {
@@ -344,9 +361,10 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         flushed += n;
     };
 
+    PROF_DECL;
     bool last = false;
     while (!last && err == INF_OK) {
-        br.refill();
+        PROF(0); // other
         last = br.take(1);
         const uint32_t type = br.take(2);
         if (br.consumed_bits() > bit_limit) {
@@ -355,10 +373,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         }
         if (type == 0) {
             // stored: skip to the byte boundary, LEN, NLEN, then LEN raw bytes
-            br.drop(br.cnt & 7u);
-            br.refill();
+            br.consume((8u - (br.off & 7u)) & 7u);
             const uint32_t len = br.take(16);
-            br.refill();
             const uint32_t nlen = br.take(16);
             if ((len ^ nlen) != 0xFFFFu) {
                 err = INF_BAD_STORED_LEN;
@@ -368,10 +384,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 err = INF_OUTPUT_OVERRUN;
                 break;
             }
-            flush_stage();
-            // the bit buffer holds whole bytes now: copy the source bytes directly, then restart behind them
+            // the stream is at a byte boundary now: copy the source bytes directly, then restart behind them
             const uint32_t byte0 = (uint32_t)(br.consumed_bits() >> 3);
-            const uint8_t *sp = comp + blk.in_off - (reinterpret_cast<uintptr_t>(comp + blk.in_off) & 3u) + byte0;
+            const uint8_t *sp = comp + blk.in_off - in_mis + byte0;
             for (uint32_t done = 0; done < len;) {
                 const uint32_t n = min(len - done, PIECE - (pos - flushed));
                 for (uint32_t i = lane; i < n; i += 64) L.ring[(pos + i) & RMASK] = sp[done + i];
@@ -379,7 +394,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 done += n;
                 if (pos - flushed >= PIECE) flush_piece(PIECE);
             }
-            spos = pos;
             br.seek(byte0 + len);
             continue;
         }
@@ -396,7 +410,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             hdist = 32;
             __syncthreads();
         } else {
-            br.refill();
             hlit = br.take(5) + 257;
             hdist = br.take(5) + 1;
             const uint32_t hclen = br.take(4) + 4;
@@ -407,7 +420,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             if (lane < 19) L.lens[lane] = 0;
             __syncthreads();
             for (uint32_t i = 0; i < hclen; i++) {
-                br.refill();
                 const uint32_t v = br.take(3);
                 if (lane == 0) L.lens[c_cl_order[i]] = (uint8_t)v;
             }
@@ -422,16 +434,15 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             const uint32_t total = hlit + hdist;
             uint32_t i = 0, prev = 0;
             while (i < total) {
-                br.refill();
-                uint32_t e = uni(L.dist_tab[br.peek(7)]);
-                const uint32_t kind = (e >> 5) & 7u;
-                if (kind != K_LIT) { // the code-length code has at most 7 bits: no long codes
+                const uint32_t x = br.bits32();
+                const uint32_t e = uni(L.dist_tab[x & 127u]);
+                if (((e >> 5) & 7u) != K_LIT) { // the code-length code has at most 7 bits: no long codes
                     err = INF_BAD_CODE_LENGTHS;
                     break;
                 }
-                br.drop(e & 31u);
-                const uint32_t s = e >> 16;
+                const uint32_t nb = e & 31u, s = e >> 16;
                 if (s < 16) {
+                    br.consume(nb);
                     if (lane == 0) cl[i] = (uint8_t)s;
                     prev = s;
                     i += 1;
@@ -443,14 +454,17 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                         err = INF_BAD_CODE_LENGTHS;
                         break;
                     }
-                    rep = 3 + br.take(2);
+                    rep = 3 + ((x >> nb) & 3u);
+                    br.consume(nb + 2);
                     val = prev;
                 } else if (s == 17) {
-                    rep = 3 + br.take(3);
+                    rep = 3 + ((x >> nb) & 7u);
+                    br.consume(nb + 3);
                     val = 0;
                     prev = 0;
                 } else {
-                    rep = 11 + br.take(7);
+                    rep = 11 + ((x >> nb) & 127u);
+                    br.consume(nb + 7);
                     val = 0;
                     prev = 0;
                 }
@@ -473,68 +487,118 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             err = INF_BAD_CODE_LENGTHS;
             break;
         }
-        pair_literals(L, lane);
-        // ---- the symbol loop
-        for (;;) {
-            br.refill();
-            const uint32_t e = next_entry(L, L.lit_tab, LB, 0, 0, br);
-            br.drop(e & 31u);
-            if ((e & (3u << 5)) == 0) {
-                // one or two literals: into the staging register, lane = output position & 63
-                write_lane(lit, (e >> 16) & 0xFFu, pos & 63u);
-                pos += 1;
-                if (e & (4u << 5)) {
-                    if ((pos & 63u) == 0) flush_stage();
-                    write_lane(lit, e >> 24, pos & 63u);
-                    pos += 1;
-                }
-                if ((pos & 63u) == 0) {
-                    flush_stage();
-                    if (pos > isize) { // also bounds the work on a corrupt stream
-                        err = INF_OUTPUT_OVERRUN;
-                        break;
+        PROF(1); // block header + tables
+        // ---- the symbol windows
+        bool end_of_block = false;
+        while (!end_of_block && err == INF_OK) {
+            PROF(6); // tail of the previous window (piece flush, loop)
+            // lane j: the code that would start j bits from here, in both alphabets
+            const uint32_t x = br.lane_bits32(lane);
+            uint32_t E = L.lit_tab[x & ((1u << LB) - 1u)];
+            const uint32_t D = L.dist_tab[x & ((1u << DB) - 1u)];
+            // per lane: bits to the next symbol if this one is a literal, else a stop mark
+            uint32_t step = (E & (7u << 5)) == (K_LIT << 5) ? (E & 31u) : 0x80u;
+            uint32_t s = 0; // bits of the window used so far
+            PROF(2);        // window bits + gathers
+            PROF_COUNT(0, 1);
+            // One window serves several runs of literals and the matches between them: everything a
+            // match needs is in the lanes at its bit offsets.
+            for (;;) {
+                // follow the chain of real symbol starts while they are literals: readlane + add per symbol
+                uint64_t lits = 0;
+                uint32_t e = 0;
+                for (;;) {
+                    chain_literals(step, s, lits);
+                    if (s >= 64) break;
+                    // not a short literal.  A literal with a long code is patched into its lane and the
+                    // chain goes on; anything else ends it.
+                    e = __builtin_amdgcn_readlane(E, s);
+                    if (((e >> 5) & 7u) != K_ESC) break;
+                    e = resolve_long(L, 0, __builtin_amdgcn_readlane(x, s));
+                    PROF_COUNT(5, 1);
+                    if (((e >> 5) & 7u) != K_LIT) break;
+                    if (lane == s) {
+                        E = e;
+                        step = e & 31u;
                     }
-                    if (pos - flushed >= PIECE) flush_piece(PIECE);
                 }
-                continue;
+                PROF(3); // chain
+                // the literals on the chain, in stream order
+                if ((lits >> lane) & 1ull) {
+                    const uint32_t k =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u));
+                    L.ring[(pos + k) & RMASK] = (uint8_t)(E >> 16);
+                }
+                pos += __popcll(lits);
+                PROF_COUNT(1, __popcll(lits));
+                if (pos > isize) { // also bounds the work on a corrupt stream
+                    err = INF_OUTPUT_OVERRUN;
+                    break;
+                }
+                PROF(4); // literal store
+                if (s >= 64) break;
+                // the symbol at bit s (entry e, long codes resolved) is an end-of-block, a length or invalid
+                const uint32_t kind = (e >> 5) & 7u, nb = e & 31u;
+                if (kind == K_EOB) {
+                    s += nb;
+                    end_of_block = true;
+                    break;
+                }
+                if (kind != K_BASE) {
+                    err = INF_BAD_SYMBOL;
+                    break;
+                }
+                const uint32_t xs = __builtin_amdgcn_readlane(x, s);
+                const uint32_t lex = (e >> 8) & 15u;
+                const uint32_t len = (e >> 16) + ((xs >> nb) & ((1u << lex) - 1u));
+                uint32_t s2 = s + nb + lex; // where the distance code starts
+                uint32_t d, xd;
+                const bool in_window = s2 < 64;
+                if (in_window) {
+                    d = __builtin_amdgcn_readlane(D, s2);
+                    xd = __builtin_amdgcn_readlane(x, s2);
+                } else {
+                    br.consume(s2);
+                    s2 = 0;
+                    xd = br.bits32();
+                    d = uni(L.dist_tab[xd & ((1u << DB) - 1u)]);
+                }
+                if (((d >> 5) & 7u) == K_ESC) d = resolve_long(L, 1, xd);
+                if (((d >> 5) & 7u) != K_BASE) {
+                    err = INF_BAD_SYMBOL;
+                    break;
+                }
+                const uint32_t db = d & 31u, dex = (d >> 8) & 15u;
+                const uint32_t dist = (d >> 16) + ((xd >> db) & ((1u << dex) - 1u));
+                s = s2 + db + dex;
+                if (dist > pos) {
+                    err = INF_BAD_DISTANCE;
+                    break;
+                }
+                if (pos + len > isize) {
+                    err = INF_OUTPUT_OVERRUN;
+                    break;
+                }
+                // the source run [pos - dist, pos) is final: byte i of the match is its byte i mod dist
+                const uint32_t from = pos - dist;
+                if (dist >= len) {
+                    for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
+                } else {
+                    for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dist) & RMASK];
+                }
+                pos += len;
+                PROF_COUNT(2, 1);
+                PROF_COUNT(3, len);
+                PROF_COUNT(4, dist < len ? 1 : 0);
+                PROF(5); // match
+                if (pos - flushed >= PIECE) flush_piece(PIECE);
+                if (!in_window || s >= 64) break; // the lanes' view of the stream is used up
             }
-            const uint32_t kind = (e >> 5) & 7u;
-            if (kind == K_EOB) break;
-            if (kind != K_BASE) {
-                err = INF_BAD_SYMBOL;
-                break;
-            }
-            const uint32_t len = (e >> 16) + br.take((e >> 8) & 15u);
-            br.refill();
-            const uint32_t d = next_entry(L, L.dist_tab, DB, 1, 1, br);
-            if (((d >> 5) & 7u) != K_BASE) {
-                err = INF_BAD_SYMBOL;
-                break;
-            }
-            br.drop(d & 31u);
-            const uint32_t dist = (d >> 16) + br.take((d >> 8) & 15u);
-            if (dist > pos) {
-                err = INF_BAD_DISTANCE;
-                break;
-            }
-            if (pos + len > isize) {
-                err = INF_OUTPUT_OVERRUN;
-                break;
-            }
-            flush_stage();
-            // the source run [pos - dist, pos) is final: byte i of the match is its byte i mod dist
-            const uint32_t from = pos - dist;
-            if (dist >= len) {
-                for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
-            } else {
-                for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dist) & RMASK];
-            }
-            pos += len;
-            spos = pos;
+            if (err == INF_OK) br.consume(s);
             if (pos - flushed >= PIECE) flush_piece(PIECE);
         }
     }
-    flush_stage();
+    PROF(0);
     if (err == INF_OK && pos != isize) err = pos > isize ? INF_OUTPUT_OVERRUN : INF_SIZE_MISMATCH;
     if (err == INF_OK && br.consumed_bits() > bit_limit) err = INF_INPUT_OVERRUN;
     __syncthreads();
@@ -542,6 +606,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         while (flushed < pos) flush_piece(min(pos - flushed, PIECE));
         if (check_crc && crc != uni(blk.crc)) err = INF_CRC_MISMATCH;
     }
+    PROF(7); // final flush + CRC
+    PROF_FLUSH;
     if (lane == 0) status[bi] = err;
 }
 
@@ -557,6 +623,23 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
     }
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks), dim3(64), sizeof(Lds), s, comp, blocks, n_blocks, out, status,
                        check_crc ? 1u : 0u);
+#ifdef NGSQ_INFLATE_PROFILE
+    {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_inflate_prof), sizeof h);
+        static const char *names[8] = {"other", "header+tables", "window+gathers", "chain", "literals+consume", "match",
+                                       "window tail/piece flush", "final flush+crc"};
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) tot += h[k];
+        for (int k = 0; k < 8; k++)
+            fprintf(stderr, "[inflate-prof] %-24s %6.2f %%\n", names[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
+        fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, matches %llu (bytes %llu, overlapping %llu), long codes %llu\n",
+                h[8], h[9], h[10], h[11], h[12], h[13]);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_prof), z, sizeof z);
+    }
+#endif
     return hipGetLastError();
 }
 
