@@ -81,7 +81,7 @@ struct Lds {
     uint8_t ring[RING];
     uint32_t lit_tab[1u << LB];
     uint32_t dist_tab[1u << DB]; // also the code-length-code table while a dynamic header is read
-    uint32_t crc_tab[256];
+    uint32_t in_ring[128]; // two 256-byte chunks of the compressed stream (chunk c in slot c & 1)
     uint32_t cnt[2][16];   // codes per length: [0] literal/length, [1] distance (or code-length code)
     uint32_t start[2][16]; // first index in syms of each length
     uint32_t fcode[2][16]; // first canonical code of each length
@@ -112,63 +112,80 @@ __device__ __forceinline__ void chain_literals(uint32_t step, uint32_t &s, uint6
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
     return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v);
 }
-// ---- bit stream: every field is uniform (SGPRs) -------------------------------------------------
-// constant address space: the compressed buffer is never written while the kernel runs, and this
-// is what lets the compiler use s_load_dword for it
-typedef const __attribute__((address_space(4))) uint32_t const_u32;
+// ---- the compressed stream ---------------------------------------------------------------------
+// Two 256-byte chunks of it sit in LDS, a third is in flight in a register (one dword per lane);
+// the only decoder state is the bit position.  Lane j reads the 32 bits that start j bits further on
+// with one ds_read2_b32 (all lanes hit the same two or three words: broadcast reads).
+struct InStream {
+    const uint32_t *src; // dword-aligned origin
+    uint32_t *ring;      // Lds::in_ring
+    uint32_t bitpos;     // uniform: bits consumed, counted from the origin
+    uint32_t chunk;      // uniform: chunks `chunk` and `chunk + 1` are in the ring
+    uint32_t pre;        // per lane: dword 64 * (chunk + 2) + lane
 
-struct BitWindow {
-    const_u32 *src;          // dword-aligned origin
-    uint32_t w0, w1, w2, w3; // the next 128 - off bits of the stream start at bit `off` of w0
-    uint32_t n0, n1, n2, n3; // src[idx .. idx+3], loaded ahead
-    uint32_t idx;            // dword index of n0
-    uint32_t off;            // 0..31
-
-    __device__ __forceinline__ void init(const uint8_t *p) {
+    __device__ __forceinline__ void init(const uint8_t *p, uint32_t *lds_ring) {
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
-        src = (const_u32 *)(reinterpret_cast<uintptr_t>(p - mis));
+        src = reinterpret_cast<const uint32_t *>(p - mis);
+        ring = lds_ring;
         seek(mis);
     }
-    // continue at byte `b` (counted from the dword-aligned origin)
+    // continue at byte `b` (counted from the origin)
     __device__ __forceinline__ void seek(uint32_t b) {
-        idx = b >> 2;
-        w0 = src[idx], w1 = src[idx + 1], w2 = src[idx + 2], w3 = src[idx + 3];
-        idx += 4;
-        n0 = src[idx], n1 = src[idx + 1], n2 = src[idx + 2], n3 = src[idx + 3];
-        off = (b & 3u) * 8u;
+        const uint32_t lane = threadIdx.x & 63u;
+        bitpos = b * 8u;
+        chunk = b >> 8;
+        ring[(chunk & 1u) * 64u + lane] = src[chunk * 64u + lane];
+        ring[((chunk + 1u) & 1u) * 64u + lane] = src[(chunk + 1u) * 64u + lane];
+        pre = src[(chunk + 2u) * 64u + lane];
     }
-    // drop n bits (n <= 128 - 32)
-    __device__ __forceinline__ void consume(uint32_t n) {
-        off += n;
-        const uint32_t k = off >> 5;
-        off &= 31u;
-        if (k) {
-            if (k == 1) w0 = w1, w1 = w2, w2 = w3, w3 = n0;
-            else if (k == 2) w0 = w2, w1 = w3, w2 = n0, w3 = n1;
-            else if (k == 3) w0 = w3, w1 = n0, w2 = n1, w3 = n2;
-            else w0 = n0, w1 = n1, w2 = n2, w3 = n3;
-            idx += k;
-            n0 = src[idx], n1 = src[idx + 1], n2 = src[idx + 2], n3 = src[idx + 3];
+    // bring the ring up to the bit position (call before reading; at most one chunk per call in the
+    // symbol loops, which consume less than 256 bytes between calls)
+    __device__ __forceinline__ void sync() {
+        while ((bitpos >> 11) != chunk) {
+            chunk += 1;
+            ring[((chunk + 1u) & 1u) * 64u + (threadIdx.x & 63u)] = pre;
+            pre = src[(chunk + 2u) * 64u + (threadIdx.x & 63u)];
         }
     }
-    // the next 32 bits (uniform)
-    __device__ __forceinline__ uint32_t bits32() const { return (uint32_t)((((uint64_t)w1 << 32) | w0) >> off); }
-    __device__ __forceinline__ uint32_t take(uint32_t n) { // n <= 25
-        const uint32_t v = bits32() & ((1u << n) - 1u);
-        consume(n);
+    // 32 bits starting `lane` bits ahead of the bit position (lane < 64), per lane
+    __device__ __forceinline__ uint32_t lane_bits32(uint32_t lane) const {
+        const uint32_t t = bitpos + lane, dw = t >> 5;
+        return __builtin_amdgcn_alignbit(ring[(dw + 1u) & 127u], ring[dw & 127u], t & 31u);
+    }
+    // the next 32 bits, uniform (one LDS round trip: the serial header code uses HeadBits instead)
+    __device__ __forceinline__ uint32_t bits32() const { return uni(lane_bits32(0)); }
+    __device__ __forceinline__ void consume(uint32_t n) { bitpos += n; }
+    __device__ __forceinline__ uint64_t consumed_bits() const { return bitpos; }
+};
+
+// uniform bit buffer over an InStream for the serial parts (block headers, code lengths): one LDS
+// round trip per ~33 bits instead of one per field
+struct HeadBits {
+    InStream &in;
+    uint64_t buf = 0;
+    uint32_t cnt = 0;
+    __device__ __forceinline__ explicit HeadBits(InStream &i) : in(i) {}
+    __device__ __forceinline__ void fill() {
+        in.sync();
+        const uint32_t dw = in.bitpos >> 5;
+        const uint32_t lo = uni(in.ring[dw & 127u]), hi = uni(in.ring[(dw + 1u) & 127u]);
+        buf = (((uint64_t)hi << 32) | lo) >> (in.bitpos & 31u);
+        cnt = 64u - (in.bitpos & 31u);
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) { // n <= 32
+        if (cnt < n) fill();
+        return (uint32_t)buf & (uint32_t)((1ull << n) - 1ull);
+    }
+    __device__ __forceinline__ void drop(uint32_t n) {
+        buf >>= n;
+        cnt -= n;
+        in.bitpos += n;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {
+        const uint32_t v = peek(n);
+        drop(n);
         return v;
     }
-    // 32 bits starting `lane` bits further on (per lane, lane < 64)
-    __device__ __forceinline__ uint32_t lane_bits32(uint32_t lane) const {
-        // three funnel shifts, then a choice between VALUES (a choice between the members themselves
-        // would be turned into an indexed load from the struct, which then has to live in memory)
-        const uint32_t t = off + lane, sh = t & 31u;
-        const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh),
-                       a2 = __builtin_amdgcn_alignbit(w3, w2, sh);
-        return t < 32 ? a0 : t < 64 ? a1 : a2;
-    }
-    // bits consumed, counted from the dword-aligned origin
-    __device__ __forceinline__ uint64_t consumed_bits() const { return (uint64_t)(idx - 4) * 32 + off; }
 };
 
 // ---- canonical Huffman tables ----------------------------------------------------------------
@@ -257,7 +274,8 @@ __device__ uint32_t slow_symbol(const Lds &L, uint32_t which, uint32_t TB, uint3
 }
 
 // full entry of a symbol whose primary entry says "long code"
-__device__ uint32_t resolve_long(const Lds &L, uint32_t alphabet, uint32_t x) {
+// (out of line: rare, and bulky enough to slow the window loop down when inlined into it)
+__device__ __noinline__ uint32_t resolve_long(const Lds &L, uint32_t alphabet, uint32_t x) {
     uint32_t bits;
     const uint32_t s = slow_symbol(L, alphabet, alphabet == 0 ? LB : DB, x, &bits);
     if (s == 0xFFFFu) return mk_entry(0, 0, K_INVALID, 15);
@@ -272,6 +290,18 @@ __device__ uint32_t resolve_long(const Lds &L, uint32_t alphabet, uint32_t x) {
 
 // ---- CRC32 (gzip): GF(2) helpers in the reflected representation -----------------------------
 constexpr uint32_t CRC_POLY = 0xEDB88320u;
+struct CrcTable {
+    uint32_t t[256];
+    constexpr CrcTable() : t() {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+            t[i] = c;
+        }
+    }
+};
+// byte-wise table, read through the vector cache (LDS is full: ring + tables of four waves per CU)
+__constant__ CrcTable c_crc;
 __device__ uint32_t crc_mul(uint32_t a, uint32_t b) { // a * b mod P
     uint32_t p = 0;
     for (uint32_t m = 1u << 31; m; m >>= 1) {
@@ -312,18 +342,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     }
     uint32_t xs_full = 0; // x^(8 * slice) for full pieces
     constexpr uint32_t SLICE = 260; // PIECE / 64 rounded up to 4 * odd: the lanes' slices start in distinct banks
-    if (check_crc) {
-        // byte-wise CRC table
-        for (uint32_t i = lane; i < 256; i += 64) {
-            uint32_t c = i;
-#pragma unroll
-            for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
-            L.crc_tab[i] = c;
-        }
-        xs_full = crc_xpow8(SLICE);
-    }
-    BitWindow br;
-    br.init(comp + blk.in_off);
+    if (check_crc) xs_full = crc_xpow8(SLICE);
+    InStream br;
+    br.init(comp + blk.in_off, L.in_ring);
     const uint32_t in_mis = (uint32_t)(reinterpret_cast<uintptr_t>(comp + blk.in_off) & 3u);
     const uint64_t bit_limit = (uint64_t)(in_mis + in_len) * 8u;
     uint8_t *const gdst = out + blk.out_off;
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         if (check_crc) {
             const uint32_t lo = min(lane * SLICE, n), hi = min(lo + SLICE, n);
             uint32_t c = 0xFFFFFFFFu;
-            for (uint32_t i = lo; i < hi; i++) c = L.crc_tab[(c ^ L.ring[(flushed + i) & RMASK]) & 0xFFu] ^ (c >> 8);
+            for (uint32_t i = lo; i < hi; i++) c = c_crc.t[(c ^ L.ring[(flushed + i) & RMASK]) & 0xFFu] ^ (c >> 8);
             c = ~c; // CRC of the slice (of the empty string: 0)
             for (uint32_t k = 0; k < 64; k++) {
                 const uint32_t lk = min(k * SLICE, n), hk = min(lk + SLICE, n);
@@ -365,17 +386,18 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     bool last = false;
     while (!last && err == INF_OK) {
         PROF(0); // other
-        last = br.take(1);
-        const uint32_t type = br.take(2);
+        HeadBits hb(br);
+        last = hb.take(1);
+        const uint32_t type = hb.take(2);
         if (br.consumed_bits() > bit_limit) {
             err = INF_INPUT_OVERRUN;
             break;
         }
         if (type == 0) {
             // stored: skip to the byte boundary, LEN, NLEN, then LEN raw bytes
-            br.consume((8u - (br.off & 7u)) & 7u);
-            const uint32_t len = br.take(16);
-            const uint32_t nlen = br.take(16);
+            hb.take((8u - (br.bitpos & 7u)) & 7u);
+            const uint32_t len = hb.take(16);
+            const uint32_t nlen = hb.take(16);
             if ((len ^ nlen) != 0xFFFFu) {
                 err = INF_BAD_STORED_LEN;
                 break;
@@ -410,9 +432,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             hdist = 32;
             __syncthreads();
         } else {
-            hlit = br.take(5) + 257;
-            hdist = br.take(5) + 1;
-            const uint32_t hclen = br.take(4) + 4;
+            hlit = hb.take(5) + 257;
+            hdist = hb.take(5) + 1;
+            const uint32_t hclen = hb.take(4) + 4;
             if (hlit > 286 || hdist > 30) {
                 err = INF_BAD_CODE_LENGTHS;
                 break;
@@ -420,7 +442,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             if (lane < 19) L.lens[lane] = 0;
             __syncthreads();
             for (uint32_t i = 0; i < hclen; i++) {
-                const uint32_t v = br.take(3);
+                const uint32_t v = hb.take(3);
                 if (lane == 0) L.lens[c_cl_order[i]] = (uint8_t)v;
             }
             __syncthreads();
@@ -434,7 +456,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             const uint32_t total = hlit + hdist;
             uint32_t i = 0, prev = 0;
             while (i < total) {
-                const uint32_t x = br.bits32();
+                const uint32_t x = hb.peek(14); // a code (<= 7 bits) and its repeat count (<= 7 bits)
                 const uint32_t e = uni(L.dist_tab[x & 127u]);
                 if (((e >> 5) & 7u) != K_LIT) { // the code-length code has at most 7 bits: no long codes
                     err = INF_BAD_CODE_LENGTHS;
@@ -442,7 +464,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 }
                 const uint32_t nb = e & 31u, s = e >> 16;
                 if (s < 16) {
-                    br.consume(nb);
+                    hb.drop(nb);
                     if (lane == 0) cl[i] = (uint8_t)s;
                     prev = s;
                     i += 1;
@@ -455,16 +477,16 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                         break;
                     }
                     rep = 3 + ((x >> nb) & 3u);
-                    br.consume(nb + 2);
+                    hb.drop(nb + 2);
                     val = prev;
                 } else if (s == 17) {
                     rep = 3 + ((x >> nb) & 7u);
-                    br.consume(nb + 3);
+                    hb.drop(nb + 3);
                     val = 0;
                     prev = 0;
                 } else {
                     rep = 11 + ((x >> nb) & 127u);
-                    br.consume(nb + 7);
+                    hb.drop(nb + 7);
                     val = 0;
                     prev = 0;
                 }
@@ -493,6 +515,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         while (!end_of_block && err == INF_OK) {
             PROF(6); // tail of the previous window (piece flush, loop)
             // lane j: the code that would start j bits from here, in both alphabets
+            br.sync();
             const uint32_t x = br.lane_bits32(lane);
             uint32_t E = L.lit_tab[x & ((1u << LB) - 1u)];
             const uint32_t D = L.dist_tab[x & ((1u << DB) - 1u)];
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                     // chain goes on; anything else ends it.
                     e = __builtin_amdgcn_readlane(E, s);
                     if (((e >> 5) & 7u) != K_ESC) break;
-                    e = resolve_long(L, 0, __builtin_amdgcn_readlane(x, s));
+                    e = uni(resolve_long(L, 0, __builtin_amdgcn_readlane(x, s)));
                     PROF_COUNT(5, 1);
                     if (((e >> 5) & 7u) != K_LIT) break;
                     if (lane == s) {
@@ -539,52 +562,37 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 if (s >= 64) break;
                 // the symbol at bit s (entry e, long codes resolved) is an end-of-block, a length or invalid
                 const uint32_t kind = (e >> 5) & 7u, nb = e & 31u;
-                if (kind == K_EOB) {
-                    s += nb;
-                    end_of_block = true;
-                    break;
-                }
                 if (kind != K_BASE) {
-                    err = INF_BAD_SYMBOL;
+                    if (kind == K_EOB) {
+                        s += nb;
+                        end_of_block = true;
+                    } else {
+                        err = INF_BAD_SYMBOL;
+                    }
                     break;
                 }
-                const uint32_t xs = __builtin_amdgcn_readlane(x, s);
                 const uint32_t lex = (e >> 8) & 15u;
+                const uint32_t s2 = s + nb + lex; // where the distance code starts
+                if (s2 >= 64) break;              // beyond the lanes' view: the next window starts at this length code
+                const uint32_t xs = __builtin_amdgcn_readlane(x, s);
                 const uint32_t len = (e >> 16) + ((xs >> nb) & ((1u << lex) - 1u));
-                uint32_t s2 = s + nb + lex; // where the distance code starts
-                uint32_t d, xd;
-                const bool in_window = s2 < 64;
-                if (in_window) {
-                    d = __builtin_amdgcn_readlane(D, s2);
-                    xd = __builtin_amdgcn_readlane(x, s2);
-                } else {
-                    br.consume(s2);
-                    s2 = 0;
-                    xd = br.bits32();
-                    d = uni(L.dist_tab[xd & ((1u << DB) - 1u)]);
-                }
-                if (((d >> 5) & 7u) == K_ESC) d = resolve_long(L, 1, xd);
-                if (((d >> 5) & 7u) != K_BASE) {
-                    err = INF_BAD_SYMBOL;
-                    break;
-                }
+                uint32_t d = __builtin_amdgcn_readlane(D, s2);
+                const uint32_t xd = __builtin_amdgcn_readlane(x, s2);
+                if (__builtin_expect(((d >> 5) & 7u) == K_ESC, 0)) d = uni(resolve_long(L, 1, xd));
                 const uint32_t db = d & 31u, dex = (d >> 8) & 15u;
                 const uint32_t dist = (d >> 16) + ((xd >> db) & ((1u << dex) - 1u));
                 s = s2 + db + dex;
-                if (dist > pos) {
-                    err = INF_BAD_DISTANCE;
-                    break;
-                }
-                if (pos + len > isize) {
-                    err = INF_OUTPUT_OVERRUN;
-                    break;
-                }
+                // errors are sticky and checked once per window: every access below is masked into the ring
+                if (((d >> 5) & 7u) != K_BASE) err = INF_BAD_SYMBOL;
+                else if (dist > pos) err = INF_BAD_DISTANCE;
+                else if (pos + len > isize) err = INF_OUTPUT_OVERRUN;
                 // the source run [pos - dist, pos) is final: byte i of the match is its byte i mod dist
                 const uint32_t from = pos - dist;
-                if (dist >= len) {
+                if (__builtin_expect(dist >= len, 1)) {
                     for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
                 } else {
-                    for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dist) & RMASK];
+                    const uint32_t dd = max(dist, 1u);
+                    for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dd) & RMASK];
                 }
                 pos += len;
                 PROF_COUNT(2, 1);
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 PROF_COUNT(4, dist < len ? 1 : 0);
                 PROF(5); // match
                 if (pos - flushed >= PIECE) flush_piece(PIECE);
-                if (!in_window || s >= 64) break; // the lanes' view of the stream is used up
+                if (s >= 64) break; // the lanes' view of the stream is used up
             }
             if (err == INF_OK) br.consume(s);
             if (pos - flushed >= PIECE) flush_piece(PIECE);
