@@ -8,7 +8,10 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ngsq_bam.h"
@@ -96,9 +99,22 @@ struct DeviceIngest {
     FILE *f = nullptr;
     ngsq_ctx *ctx = nullptr;
     size_t raw_cap = 0, comp_chunk = 0;
-    uint8_t *h_comp = nullptr; // pinned, 2 x comp_chunk
-    size_t comp_fill = 0;
-    bool file_eof = false;
+    // Compressed chunks come from a reader thread: while the GPU inflates and parses chunk k the
+    // thread reads and frames chunk k+1 into the other pinned buffer.
+    struct HostChunk {
+        uint8_t *h = nullptr; // pinned, 2 x comp_chunk
+        size_t fill = 0, consumed = 0;
+        uint64_t total = 0; // decompressed bytes of `blocks`
+        std::vector<BgzfBlock> blocks;
+        bool ready = false, last = false; // last: the file ends with this chunk
+        std::string err;
+    } hc[2];
+    int cur = 0; // chunk the consumer takes next
+    std::thread reader;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false;
+    bool file_done = false; // the consumer has taken the last chunk
     uint64_t first = 0; // offset in d_raw of the first record of the next chunk
     bool first_chunk = true;
     // device
@@ -114,15 +130,24 @@ struct DeviceIngest {
     uint64_t raw_len = 0, tail_off = 0;
     uint64_t n_rec = 0, cursor = 0; // records indexed in the current chunk / handed out
     uint64_t blocks_done = 0;
-    std::vector<BgzfBlock> blocks;
     std::vector<uint32_t> status;
     std::vector<RecCandidate> cand;
     std::vector<uint64_t> seg;
     ~DeviceIngest() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        if (reader.joinable()) reader.join();
         if (f) fclose(f);
-        if (h_comp) (void)hipHostFree(h_comp);
+        for (auto &c : hc)
+            if (c.h) (void)hipHostFree(c.h);
     }
 };
+
+// a record cut by a chunk boundary is carried into the next chunk: room kept for it in the ingest buffer
+constexpr uint64_t CARRY_MAX = (uint64_t)1 << 24;
 
 } // namespace ngsq
 
@@ -136,12 +161,63 @@ void free_ingest(DeviceIngest *d) { delete d; }
         if (e_ != hipSuccess) return ngsq_bam_fail(NGSQ_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Reader thread: fill the pinned buffers alternately with whole BGZF blocks (the bytes of a block
+// cut by the end of a buffer start the next one).
+void reader_main(DeviceIngest *d, std::string path) {
+    std::vector<uint8_t> leftover;
+    bool eof = false;
+    const size_t cap = 2 * d->comp_chunk;
+    const uint64_t out_limit = d->raw_cap > 2 * CARRY_MAX ? d->raw_cap - CARRY_MAX : d->raw_cap / 2;
+    for (int k = 0;; k ^= 1) {
+        DeviceIngest::HostChunk &c = d->hc[k];
+        {
+            std::unique_lock<std::mutex> g(d->mu);
+            d->cv.wait(g, [&] { return d->stop || !c.ready; });
+            if (d->stop) return;
+        }
+        memcpy(c.h, leftover.data(), leftover.size());
+        c.fill = leftover.size();
+        c.err.clear();
+        if (!eof && c.fill < cap) {
+            const size_t want = cap - c.fill;
+            const size_t got = fread(c.h + c.fill, 1, want, d->f);
+            if (got < want) {
+                if (ferror(d->f)) c.err = "read error on " + path;
+                eof = true;
+            }
+            c.fill += got;
+        }
+        c.blocks.clear();
+        c.consumed = 0;
+        c.total = 0;
+        std::string err;
+        if (c.err.empty() && !bgzf_split(c.h, c.fill, &c.blocks, &c.consumed, &c.total, &err, out_limit))
+            c.err = path + ": " + err;
+        leftover.assign(c.h + c.consumed, c.h + c.fill);
+        if (c.err.empty() && c.blocks.empty()) {
+            if (eof && !leftover.empty()) c.err = path + ": truncated BGZF block at end of file";
+            else if (!eof) c.err = path + ": BGZF block does not fit the ingest buffer";
+        }
+        c.last = !c.err.empty() || (eof && leftover.empty());
+        const bool last = c.last;
+        {
+            std::lock_guard<std::mutex> g(d->mu);
+            c.ready = true;
+        }
+        d->cv.notify_all();
+        if (last) return;
+    }
+}
+
 // Inflate the next run of BGZF blocks behind the unparsed tail of d_raw and index its records.
 int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     hipStream_t st = d->ctx->stream;
     const double t0 = now_ms();
     // ---- 1. keep the cut record at the end of the previous chunk
     const uint64_t carry = d->raw_len - d->tail_off;
+    if (carry > CARRY_MAX || carry + REC_SEGMENT > d->raw_cap)
+        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest carry space (%llu MiB)",
+                             b->path.c_str(), (unsigned long long)(std::min<uint64_t>(CARRY_MAX, d->raw_cap) >> 20));
     if (carry && d->tail_off) {
         if (carry <= d->tail_off) {
             BHIP(hipMemcpyAsync(d->d_raw.p, d->d_raw.p + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
@@ -151,55 +227,44 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
             BHIP(hipMemcpyAsync(d->d_raw.p, d->d_comp.p, carry, hipMemcpyDeviceToDevice, st));
         }
     }
-    if (carry + REC_SEGMENT > d->raw_cap)
-        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest buffer (%zu MiB)",
-                             b->path.c_str(), d->raw_cap >> 20);
-    // ---- 2. compressed bytes: top up the pinned buffer, take the complete blocks that fit
-    if (!d->file_eof && d->comp_fill < d->comp_chunk) {
-        const size_t want = 2 * d->comp_chunk - d->comp_fill;
-        const size_t got = fread(d->h_comp + d->comp_fill, 1, want, d->f);
-        if (got < want) {
-            if (ferror(d->f)) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "read error on %s", b->path.c_str());
-            d->file_eof = true;
-        }
-        d->comp_fill += got;
+    // ---- 2. the next framed chunk from the reader thread
+    DeviceIngest::HostChunk &c = d->hc[d->cur];
+    {
+        std::unique_lock<std::mutex> g(d->mu);
+        d->cv.wait(g, [&] { return c.ready; });
     }
     const double t1 = now_ms();
-    d->blocks.clear();
-    size_t consumed = 0;
-    uint64_t total = 0;
-    std::string err;
-    if (!bgzf_split(d->h_comp, d->comp_fill, &d->blocks, &consumed, &total, &err, d->raw_cap - carry))
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: %s", b->path.c_str(), err.c_str());
-    const size_t n_blk = d->blocks.size();
-    if (!n_blk) {
-        if (d->comp_fill && d->file_eof)
-            return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated BGZF block at end of file", b->path.c_str());
-        if (d->comp_fill >= 2 * d->comp_chunk)
-            return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: BGZF block does not fit the ingest buffer", b->path.c_str());
-    }
-    // ---- 3. inflate
+    if (!c.err.empty()) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s", c.err.c_str());
+    const size_t n_blk = c.blocks.size(), consumed = c.consumed;
+    const uint64_t total = c.total;
     const double t2 = now_ms();
-    for (auto &bl : d->blocks) bl.out_off += carry;
+    // ---- 3. inflate
+    for (auto &bl : c.blocks) bl.out_off += carry;
     if (n_blk) {
         BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
         BHIP(d->d_blocks.reserve(n_blk));
         BHIP(d->d_status.reserve(n_blk));
-        BHIP(hipMemcpyAsync(d->d_comp.p, d->h_comp, consumed, hipMemcpyHostToDevice, st));
+        BHIP(hipMemcpyAsync(d->d_comp.p, c.h, consumed, hipMemcpyHostToDevice, st));
         BHIP(hipMemsetAsync(d->d_comp.p + consumed, 0, INFLATE_IN_SLACK, st));
-        BHIP(hipMemcpyAsync(d->d_blocks.p, d->blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
+        BHIP(hipMemcpyAsync(d->d_blocks.p, c.blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
         BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, true, st));
         d->status.resize(n_blk);
         BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        BHIP(hipStreamSynchronize(st)); // also: h_comp may be rewritten now
+        BHIP(hipStreamSynchronize(st));
         for (size_t k = 0; k < n_blk; k++)
             if (d->status[k] != INF_OK)
                 return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: BGZF block %llu: %s", b->path.c_str(),
                                      (unsigned long long)(d->blocks_done + k), inflate_status_text(d->status[k]));
         d->blocks_done += n_blk;
-        memmove(d->h_comp, d->h_comp + consumed, d->comp_fill - consumed);
-        d->comp_fill -= consumed;
     }
+    // the pinned buffer goes back to the reader thread
+    d->file_done = c.last;
+    {
+        std::lock_guard<std::mutex> g(d->mu);
+        c.ready = false;
+    }
+    d->cv.notify_all();
+    d->cur ^= 1;
     const double t3 = now_ms();
     d->raw_len = carry + total;
     d->n_rec = d->cursor = 0;
@@ -264,7 +329,7 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     d->n_rec = total_rec;
     d->first = 0;
     if (trace_on())
-        fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | read %.1f ms, split %.1f ms, "
+        fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | wait for reader %.1f ms, - %.1f ms, "
                         "h2d+inflate %.1f ms, index %.1f ms\n",
                 n_blk, consumed / 1e6, total / 1e6, (unsigned long long)total_rec, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
     return NGSQ_OK;
@@ -295,8 +360,9 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         d->comp_chunk = std::max<size_t>(d->raw_cap / 4, (size_t)1 << 17);
         b->dev = d;
         b->dev_free = free_ingest;
-        BHIP(hipHostMalloc((void **)&d->h_comp, 2 * d->comp_chunk, hipHostMallocDefault));
+        for (auto &c : d->hc) BHIP(hipHostMalloc((void **)&c.h, 2 * d->comp_chunk, hipHostMallocDefault));
         BHIP(d->d_raw.reserve(d->raw_cap + 64));
+        d->reader = std::thread(reader_main, d, b->path);
         // the host side of this handle is done: release its buffers
         std::vector<uint8_t>().swap(b->comp);
         std::vector<uint8_t>().swap(b->data);
@@ -305,20 +371,13 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     if (max_records == 0) return NGSQ_OK;
     hipStream_t st = c->stream;
     while (d->cursor == d->n_rec) {
-        if (d->file_eof && d->comp_fill == 0 && !d->first_chunk) {
+        if (d->file_done) {
             if (d->tail_off != d->raw_len)
                 return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated record", b->path.c_str());
             return NGSQ_OK; // clean end of file
         }
-        const uint64_t before = d->blocks_done;
-        const bool was_eof = d->file_eof;
         const int rc = load_chunk(b, d);
         if (rc) return rc;
-        if (d->n_rec == 0 && was_eof && d->blocks_done == before && d->comp_fill == 0) {
-            if (d->tail_off != d->raw_len)
-                return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated record", b->path.c_str());
-            return NGSQ_OK;
-        }
     }
     const uint64_t n = std::min<uint64_t>(max_records, d->n_rec - d->cursor);
     const uint64_t *rec = d->d_rec_off.p + d->cursor;

@@ -6,7 +6,8 @@
 // pass 1 / pass 2 with the two `-n` rules, aggregate, write <prefix>.results.json).
 // The per-record facet loops are replaced by SoA batches through the C ABI (include/ngsq.h);
 // ingest is include/ngsq_bam.h.  Additive flags: --device, --batch-records, --threads, --gc-seed,
-// --ingest host|device (device: the GPU inflates and parses the BAM; without -n only).
+// --ingest host|device (default device: the GPU inflates and parses the BAM; runs with -n
+// always ingest on the host).
 // Not built (out of scope this round): the other subcommands, the Genomic
 // Features facet (-f) and --vaf-file.
 #include <sys/stat.h>
@@ -223,7 +224,7 @@ struct Args {
     bool has_n = false, has_out_dir = false, has_prefix = false, has_only = false;
     unsigned long long n = 0;
     int device = 0, threads = 0;
-    bool ingest_device = false; // --ingest device: BGZF inflate + BAM parse on the GPU (ngsq_bam_next_batch_device)
+    bool ingest_device = true; // --ingest host|device: where BGZF inflate + BAM parse run (ngsq_bam_next_batch[_device])
     unsigned long long batch_records = 1ull << 21, gc_seed = 0x4E4753;
 };
 
