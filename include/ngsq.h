@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGSQ_ABI_VERSION 1u
+#define NGSQ_ABI_VERSION 2u
 
 /* ---- status codes (reference: anyhow::Result<()> / panic) ---- */
 #define NGSQ_OK 0
@@ -51,7 +51,8 @@ extern "C" {
 #define NGSQ_FACET_QUALITY_SCORE 0x08u   /* "Quality Score"    quality_scores.rs:29 */
 #define NGSQ_FACET_COVERAGE 0x10u        /* "Coverage"         coverage.rs:125      */
 #define NGSQ_FACET_EDITS 0x20u           /* "Edits"            edits.rs:165         */
-#define NGSQ_FACETS_RECORD_BASED 0x0Fu   /* pass 1, command.rs:288-333 */
+#define NGSQ_FACET_FEATURES 0x40u        /* "Genomic Features" features.rs:107 (needs ngsq_set_features) */
+#define NGSQ_FACETS_RECORD_BASED 0x4Fu   /* pass 1, command.rs:288-333 */
 #define NGSQ_FACETS_SEQUENCE_BASED 0x30u /* pass 2, command.rs:335-400 */
 #define NGSQ_FACETS_DEFAULT 0x1Fu        /* qc.rs:60-65,85-89 (Edits only with -r) */
 
@@ -201,7 +202,45 @@ typedef struct ngsq_error_counts {
     uint64_t edits_not_consumed;    /* alignment.rs:100-104 not fully consumed               */
     uint64_t edits_too_many;        /* edits.rs:297-299 edits > 512 -> unwrap panic          */
     uint64_t bad_cigar_op;          /* op code > 8                                           */
+    uint64_t features_missing_reference_id; /* features.rs:132-140 bail!: mapped record, no reference id */
+    uint64_t features_missing_position;     /* features.rs:171-174 bail!: no alignment start           */
 } ngsq_error_counts;
+
+/* features/metrics.rs:10-80, in declaration order */
+typedef struct ngsq_features_metrics {
+    uint64_t utr_five_prime_count;
+    uint64_t utr_three_prime_count;
+    uint64_t coding_sequence_count;
+    uint64_t intergenic_count;
+    uint64_t exonic_count;
+    uint64_t intronic_count;
+    uint64_t processed;
+    uint64_t ignored_flags;
+    uint64_t ignored_nonprimary_chromosome;
+} ngsq_features_metrics;
+
+/*
+ * The gene model of the Genomic Features facet: what GenomicFeaturesFacet::try_from
+ * (features.rs:270-355) keeps of the GFF.  Every GFF record whose sequence is a primary one and whose
+ * type is one of the five configured feature names becomes rust_lapper::Interval { start: GFF start,
+ * stop: GFF end } (half-open in the lookup, features.rs:314-318 -- a quirk that is reproduced).
+ * Names are compared as strings by the reference, so two roles configured with the same name act as
+ * one name: role_name[] carries that (distinct names get distinct ids < 5).
+ */
+#define NGSQ_ROLE_FIVE_PRIME_UTR 0
+#define NGSQ_ROLE_THREE_PRIME_UTR 1
+#define NGSQ_ROLE_CODING_SEQUENCE 2
+#define NGSQ_ROLE_EXON 3
+#define NGSQ_ROLE_GENE 4
+typedef struct ngsq_features {
+    uint32_t struct_size;
+    uint32_t role_name[5]; /* name id of each NGSQ_ROLE_*                         */
+    uint64_t n;            /* intervals                                             */
+    const uint32_t *ref_id; /* [n] index of the interval's sequence in the header   */
+    const uint32_t *name;   /* [n] name id (one of role_name[])                     */
+    const uint32_t *start;  /* [n] GFF start (1-based)                              */
+    const uint32_t *stop;   /* [n] GFF end                                          */
+} ngsq_features;
 
 /* one row of ngsq_kernel_timing */
 typedef struct ngsq_kernel_time {
@@ -225,6 +264,11 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out);
 void ngsq_destroy(ngsq_ctx *ctx);
 const char *ngsq_last_error(const ngsq_ctx *ctx);
 
+/* Install the gene model of the Genomic Features facet (required before the first batch when
+ * NGSQ_FACET_FEATURES is enabled; the arrays are copied).  Replaces GenomicFeaturesFacet::try_from's
+ * interval stores (features.rs:300-343). */
+int ngsq_set_features(ngsq_ctx *ctx, const ngsq_features *features);
+
 /* facet.process for every record of the batch (asynchronous on the context's
  * stream for device batches; host batches are copied to the device first and
  * the host buffers may be reused when the call returns). */
@@ -243,6 +287,7 @@ void *ngsq_stream(ngsq_ctx *ctx); /* the hipStream_t kernels are launched on */
 /* ---- results (valid after ngsq_finalize) ---- */
 
 int ngsq_get_error_counts(const ngsq_ctx *ctx, ngsq_error_counts *out);
+int ngsq_get_features(const ngsq_ctx *ctx, ngsq_features_metrics *out);
 int ngsq_get_general(const ngsq_ctx *ctx, ngsq_general_metrics *out);
 /* histogram: tlen_cap+1 bins (template_length.rs:44-53) */
 int ngsq_get_template_length(const ngsq_ctx *ctx, uint64_t *histogram, size_t n_bins,

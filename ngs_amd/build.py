@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
 SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "bgzf_inflate.hip",
-           "bam_device.hip", "context.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
+           "bam_device.hip", "features_kernel.hip", "context.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
 HEADERS = ["kernels.h", "context.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h",
            "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-gpu-rdc"]
@@ -46,7 +46,7 @@ def build_cli(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(CLI_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(CLI_OUT) for d in deps):
         return CLI_OUT
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", CLI_SRC, "-L" + HERE, "-lngsq", "-Wl,-rpath,$ORIGIN",
-           "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", CLI_OUT + ".tmp"]
+           "-Wl,-rpath-link," + "/opt/rocm/lib", "-lz", "-o", CLI_OUT + ".tmp"]
     if verbose:
         print("[ngs_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

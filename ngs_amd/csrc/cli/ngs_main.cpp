@@ -12,6 +12,7 @@
 // Features facet (-f) and --vaf-file.
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <chrono>
@@ -219,8 +220,101 @@ bool query_yields(const ngsq_batch &b, uint64_t i, const std::vector<uint32_t> &
     return e != 0 && s <= ref_len[r];
 }
 
+// ---- Genomic Features gene model: GenomicFeaturesFacet::try_from (features.rs:270-355) ----------
+struct GeneModel {
+    std::vector<uint32_t> ref, name, start, stop;
+    uint32_t role_name[5] = {0, 1, 2, 3, 4};
+};
+
+// formats/gff.rs:19-47 (open by extension) + noodles-gff records(): nine tab-separated columns,
+// '#' lines are comments/directives, "##FASTA" ends the records.
+GeneModel load_gff(const std::string &path, const std::string (&feature_name)[5], const std::set<std::string> &primary,
+                   const std::map<std::string, uint32_t> &ref_index) {
+    auto ends_with = [&](const char *suf) {
+        const size_t n = strlen(suf);
+        return path.size() >= n && path.compare(path.size() - n, n, suf) == 0;
+    };
+    const size_t dot = path.rfind('.');
+    const std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
+    const bool gz = ends_with("gff.gz") || ends_with("gff3.gz");
+    if (!gz && !ieq(ext, "gff") && !ieq(ext, "gff3"))
+        bail("opening GFF file: " + path + ": Not able to determine filetype for extension: " + ext);
+    gzFile f = gzopen(path.c_str(), "rb"); // reads plain text as well
+    if (!f) bail("opening GFF file: " + path + ": No such file or directory (os error 2)");
+    GeneModel m;
+    // roles that are configured with the same name are one name (the reference compares strings)
+    for (int k = 0; k < 5; k++)
+        for (int q = 0; q <= k; q++)
+            if (feature_name[q] == feature_name[k]) {
+                m.role_name[k] = (uint32_t)q;
+                break;
+            }
+    logf(3, "Reading all records in GFF.");
+    std::string line;
+    char buf[1 << 16];
+    unsigned long long line_no = 0;
+    bool more = true;
+    while (more) {
+        line.clear();
+        for (;;) { // one line of any length
+            if (!gzgets(f, buf, sizeof buf)) {
+                more = false;
+                break;
+            }
+            line += buf;
+            if (!line.empty() && line.back() == '\n') break;
+        }
+        if (line.empty()) break;
+        line_no++;
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '#') {
+            if (line.compare(0, 7, "##FASTA") == 0) break;
+            continue;
+        }
+        std::vector<std::string> col;
+        size_t p = 0;
+        for (;;) {
+            const size_t t = line.find('\t', p);
+            col.push_back(line.substr(p, t == std::string::npos ? std::string::npos : t - p));
+            if (t == std::string::npos) break;
+            p = t + 1;
+        }
+        char *e1 = nullptr, *e2 = nullptr;
+        const unsigned long long start = col.size() >= 5 ? strtoull(col[3].c_str(), &e1, 10) : 0;
+        const unsigned long long stop = col.size() >= 5 ? strtoull(col[4].c_str(), &e2, 10) : 0;
+        if (col.size() != 9 || col[3].empty() || col[4].empty() || *e1 || *e2 || start == 0 || stop < start ||
+            stop > 0xFFFFFFFFull) {
+            gzclose(f);
+            bail("invalid GFF record on line " + std::to_string(line_no) + " of " + path); // result.unwrap(): features.rs:291
+        }
+        if (!primary.count(col[0])) continue; // :300-304 only primary-assembly sequences get interval stores
+        // :310-312: the strand of EVERY record on a primary sequence is parsed, '+' or '-' only
+        if (col[6] != "+" && col[6] != "-") {
+            gzclose(f);
+            bail("attempted to parse strand from value: " + col[6]);
+        }
+        int name = -1;
+        for (int k = 0; k < 5 && name < 0; k++)
+            if (col[2] == feature_name[k]) name = (int)m.role_name[k];
+        if (name < 0) continue;
+        const auto it = ref_index.find(col[0]);
+        if (it == ref_index.end()) continue; // a primary sequence this BAM does not have: never looked up
+        m.ref.push_back(it->second);
+        m.name.push_back((uint32_t)name);
+        m.start.push_back((uint32_t)start);
+        m.stop.push_back((uint32_t)stop);
+    }
+    gzclose(f);
+    logf(3, "Tabulating GFF features.");
+    logf(3, "Finalizing GFF features lookup.");
+    return m;
+}
+
 struct Args {
     std::string src, genome, gff, fasta, out_dir, prefix, only, vaf;
+    // command.rs:77-101: GENCODE feature names by default; order = NGSQ_ROLE_*
+    std::string feature_name[5] = {"five_prime_UTR", "three_prime_UTR", "CDS", "exon", "gene"};
     bool has_n = false, has_out_dir = false, has_prefix = false, has_only = false;
     unsigned long long n = 0;
     int device = 0, threads = 0;
@@ -232,7 +326,7 @@ void usage() {
     fprintf(stderr,
             "Usage: ngs [-q|-v] qc [OPTIONS] <BAM> <REFERENCE_GENOME>\n\n"
             "Options:\n"
-            "  -f, --features-gff <PATH>       Features GFF file (not supported by this build)\n"
+            "  -f, --features-gff <PATH>       Features GFF file (enables the Genomic Features facet)\n"
             "  -n, --num-records <USIZE>       Number of records to process in the first pass; also caps the\n"
             "                                  records per sequence in the second pass\n"
             "  -o, --output-directory <PATH>   Directory to output files to [default: current directory]\n"
@@ -274,9 +368,11 @@ int main(int argc, char **argv) {
         else if (s == "-r" || s == "--reference-fasta") a.fasta = val("--reference-fasta");
         else if (s == "--only") { a.only = val("--only"); a.has_only = true; }
         else if (s == "--vaf-file") a.vaf = val("--vaf-file");
-        else if (s == "--five-prime-utr-feature-name" || s == "--three-prime-utr-feature-name" ||
-                 s == "--coding-sequence-feature-name" || s == "--exon-feature-name" || s == "--gene-feature-name")
-            (void)val(s.c_str());
+        else if (s == "--five-prime-utr-feature-name") a.feature_name[NGSQ_ROLE_FIVE_PRIME_UTR] = val(s.c_str());
+        else if (s == "--three-prime-utr-feature-name") a.feature_name[NGSQ_ROLE_THREE_PRIME_UTR] = val(s.c_str());
+        else if (s == "--coding-sequence-feature-name") a.feature_name[NGSQ_ROLE_CODING_SEQUENCE] = val(s.c_str());
+        else if (s == "--exon-feature-name") a.feature_name[NGSQ_ROLE_EXON] = val(s.c_str());
+        else if (s == "--gene-feature-name") a.feature_name[NGSQ_ROLE_GENE] = val(s.c_str());
         else if (s == "--device") a.device = atoi(val("--device").c_str());
         else if (s == "--threads") a.threads = atoi(val("--threads").c_str());
         else if (s == "--ingest") {
@@ -320,7 +416,6 @@ int main(int argc, char **argv) {
         char cwd[4096];
         a.out_dir = getcwd(cwd, sizeof cwd) ? cwd : ".";
     }
-    if (!a.gff.empty()) bail("the Genomic Features facet (-f/--features-gff) is not supported by this build");
     if (!a.vaf.empty()) bail("--vaf-file is not supported by this build");
 
     // ---- app(): command.rs:226-421
@@ -356,10 +451,18 @@ int main(int argc, char **argv) {
     uint32_t facets = NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH | NGSQ_FACET_GC_CONTENT | NGSQ_FACET_QUALITY_SCORE |
                       NGSQ_FACET_COVERAGE;
     if (!a.fasta.empty()) facets |= NGSQ_FACET_EDITS;
+    // Genomic Features: the gene model is read while the facets are built (qc.rs:68-79), before --only
+    GeneModel model;
+    if (!a.gff.empty()) {
+        std::map<std::string, uint32_t> ref_index;
+        for (uint32_t r = 0; r < n_refs; r++) ref_index[names[r]] = r;
+        model = load_gff(a.gff, a.feature_name, genome.primary, ref_index);
+        facets |= NGSQ_FACET_FEATURES;
+    }
     if (a.has_only) {
         uint32_t sel = 0;
         int matched = 0;
-        for (uint32_t bit = 1; bit <= NGSQ_FACET_EDITS; bit <<= 1)
+        for (uint32_t bit = 1; bit <= NGSQ_FACET_FEATURES; bit <<= 1)
             if ((facets & bit) && ieq(a.only, ngsq_facet_name(bit))) {
                 sel |= bit;
                 matched++;
@@ -396,6 +499,18 @@ int main(int argc, char **argv) {
     cfg.ref_bases = (facets & NGSQ_FACET_EDITS) ? bases.data() : nullptr;
     ngsq_ctx *ctx = nullptr;
     if (ngsq_create(&cfg, &ctx) != NGSQ_OK) bail(ngsq_last_global_error());
+    if (facets & NGSQ_FACET_FEATURES) {
+        ngsq_features f;
+        memset(&f, 0, sizeof f);
+        f.struct_size = sizeof f;
+        for (int k = 0; k < 5; k++) f.role_name[k] = model.role_name[k];
+        f.n = model.ref.size();
+        f.ref_id = model.ref.data();
+        f.name = model.name.data();
+        f.start = model.start.data();
+        f.stop = model.stop.data();
+        CHECK(ctx, ngsq_set_features(ctx, &f));
+    }
 
     const bool rec_facets = (facets & NGSQ_FACETS_RECORD_BASED) != 0, seq_facets = (facets & NGSQ_FACETS_SEQUENCE_BASED) != 0;
     if (rec_facets) {
@@ -403,6 +518,7 @@ int main(int argc, char **argv) {
         static const char *load[] = {"Light", "Light", "Light", "Moderate"};
         for (int k = 0; k < 4; k++)
             if (facets & (1u << k)) logf(2, "  [*] %s, %s", ngsq_facet_name(1u << k), load[k]);
+        if (facets & NGSQ_FACET_FEATURES) logf(2, "  [*] Genomic Features, Moderate"); // features.rs:107-113
         logf(2, "Starting first pass for QC stats.");
     } else {
         logf(2, "No facets specified that require first pass. Skipping...");

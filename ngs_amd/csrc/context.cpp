@@ -7,6 +7,7 @@
 // with NGSQ_ERR_NO_DEVICE.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -42,7 +43,7 @@ static int fail(ngsq_ctx *c, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits", "cov_scan", "edits_vaf", "h2d"};
+static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits", "cov_scan", "edits_vaf", "h2d", "features"};
 
 extern "C" {
 
@@ -62,6 +63,7 @@ const char *ngsq_facet_name(uint32_t bit) {
     case NGSQ_FACET_QUALITY_SCORE: return "Quality Score";
     case NGSQ_FACET_COVERAGE: return "Coverage";
     case NGSQ_FACET_EDITS: return "Edits";
+    case NGSQ_FACET_FEATURES: return "Genomic Features";
     default: return nullptr;
     }
 }
@@ -249,6 +251,10 @@ void ngsq_destroy(ngsq_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_ft_idx);
+    (void)hipFree(c->d_ft_starts);
+    (void)hipFree(c->d_ft_stops);
+    (void)hipFree(c->d_ft_primary);
     for (auto &p : c->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -337,6 +343,8 @@ static int check_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t facets) {
     }
     if ((facets & NGSQ_FACET_GENERAL) && (!b->mapq || !b->ref_id || !b->mate_ref_id || !b->n_cigar))
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "General needs mapq, ref_id, mate_ref_id, n_cigar");
+    if ((facets & NGSQ_FACET_FEATURES) && (!b->ref_id || !b->pos || !b->n_cigar))
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Genomic Features needs flag, ref_id, pos, n_cigar (+ cigar)");
     if ((facets & NGSQ_FACET_TEMPLATE_LENGTH) && !b->tlen)
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Template Length needs tlen");
     if ((facets & (NGSQ_FACET_GC_CONTENT | NGSQ_FACET_EDITS)) && (!b->l_seq || !b->seq))
@@ -403,10 +411,72 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
         Bracket br(c, K_QUAL, cs.qual_bytes);
         HIP_TRY(c, launch_qual(c->li, c->st, db, c->stream));
     }
+    if (rec_f & NGSQ_FACET_FEATURES) {
+        if (!c->have_features)
+            return fail(c, NGSQ_ERR_STATE, "NGSQ_FACET_FEATURES is enabled but ngsq_set_features was not called");
+        Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4);
+        HIP_TRY(c, launch_features(c->li, c->st, db, c->ft, c->stream));
+    }
     if (seq_f & NGSQ_FACET_EDITS) {
         Bracket br(c, K_EDITS, n * 16 + cs.cigar_ops * 4 + cs.seq_bytes);
         HIP_TRY(c, launch_edits(c->li, c->st, db, c->stream));
     }
+    return NGSQ_OK;
+}
+
+int ngsq_set_features(ngsq_ctx *c, const ngsq_features *f) {
+    if (!c || !f) return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (f->struct_size != sizeof(ngsq_features))
+        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "ngsq_features.struct_size %u != %zu", f->struct_size, sizeof(ngsq_features));
+    if (f->n && (!f->ref_id || !f->name || !f->start || !f->stop)) return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "null interval column");
+    if (f->n > 0xFFFFFFF0ull) return fail(c, NGSQ_ERR_UNSUPPORTED, "too many feature intervals");
+    for (int r = 0; r < 5; r++)
+        if (f->role_name[r] >= 5) return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "role_name[%d] = %u: name ids are < 5", r, f->role_name[r]);
+    const uint32_t n_refs = c->cfg.n_refs;
+    // bucket by (name id, sequence), then sort starts and stops of each bucket independently
+    std::vector<uint32_t> idx((size_t)5 * n_refs + 1, 0);
+    for (uint64_t i = 0; i < f->n; i++) {
+        if (f->ref_id[i] >= n_refs || f->name[i] >= 5)
+            return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "feature interval %llu: sequence %u / name id %u out of range",
+                        (unsigned long long)i, f->ref_id[i], f->name[i]);
+        if (f->start[i] > f->stop[i])
+            return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "feature interval %llu: start %u > end %u", (unsigned long long)i,
+                        f->start[i], f->stop[i]);
+        idx[(size_t)f->name[i] * n_refs + f->ref_id[i] + 1] += 1;
+    }
+    for (size_t k = 1; k < idx.size(); k++) idx[k] += idx[k - 1];
+    std::vector<uint32_t> starts(f->n + 1), stops(f->n + 1), fill(idx.begin(), idx.end() - 1);
+    for (uint64_t i = 0; i < f->n; i++) {
+        const uint32_t slot = fill[(size_t)f->name[i] * n_refs + f->ref_id[i]]++;
+        starts[slot] = f->start[i];
+        stops[slot] = f->stop[i];
+    }
+    for (size_t k = 0; k + 1 < idx.size(); k++) {
+        std::sort(starts.begin() + idx[k], starts.begin() + idx[k + 1]);
+        std::sort(stops.begin() + idx[k], stops.begin() + idx[k + 1]);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    (void)hipFree(c->d_ft_idx);
+    (void)hipFree(c->d_ft_starts);
+    (void)hipFree(c->d_ft_stops);
+    (void)hipFree(c->d_ft_primary);
+    c->d_ft_idx = c->d_ft_starts = c->d_ft_stops = nullptr;
+    c->d_ft_primary = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->d_ft_idx, idx.size() * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ft_starts, starts.size() * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ft_stops, stops.size() * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ft_primary, n_refs + 1));
+    HIP_TRY(c, hipMemcpy(c->d_ft_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_ft_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_ft_stops, stops.data(), stops.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_ft_primary, c->primary.data(), n_refs, hipMemcpyHostToDevice));
+    c->ft.idx = c->d_ft_idx;
+    c->ft.starts = c->d_ft_starts;
+    c->ft.stops = c->d_ft_stops;
+    c->ft.primary = c->d_ft_primary;
+    c->ft.n_refs = n_refs;
+    for (int r = 0; r < 5; r++) c->ft.role_name[r] = f->role_name[r];
+    c->have_features = true;
     return NGSQ_OK;
 }
 
@@ -596,6 +666,11 @@ int ngsq_finalize(ngsq_ctx *c) {
                         "(missing_ref_id=%llu bad_quality=%llu read_too_long=%llu edits_bad_ref=%llu "
                         "edits_record_short=%llu edits_not_consumed=%llu edits_too_many=%llu bad_cigar_op=%llu)",
                         err[0], err[1], err[2], err[3], err[4], err[5], err[6], err[7]);
+    if (c->h_counters[C_FEAT_ERR_REF] || c->h_counters[C_FEAT_ERR_POS])
+        return fail(c, NGSQ_ERR_MALFORMED_RECORD,
+                    "malformed record(s): the reference would abort this run (Genomic Features: mapped records "
+                    "without a reference sequence id=%llu, without an alignment start=%llu)",
+                    c->h_counters[C_FEAT_ERR_REF], c->h_counters[C_FEAT_ERR_POS]);
     return NGSQ_OK;
 }
 
@@ -674,7 +749,17 @@ int ngsq_reset(ngsq_ctx *c) {
 
 int ngsq_get_error_counts(const ngsq_ctx *c, ngsq_error_counts *out) {
     NEED_FINAL(c);
-    memcpy(out, c->h_counters.data() + C_ERR, sizeof *out);
+    static_assert(sizeof(ngsq_error_counts) == 10 * 8, "layout");
+    memcpy(out, c->h_counters.data() + C_ERR, 8 * 8);
+    out->features_missing_reference_id = c->h_counters[C_FEAT_ERR_REF];
+    out->features_missing_position = c->h_counters[C_FEAT_ERR_POS];
+    return NGSQ_OK;
+}
+
+int ngsq_get_features(const ngsq_ctx *c, ngsq_features_metrics *out) {
+    NEED_FINAL(c);
+    static_assert(sizeof(ngsq_features_metrics) == 9 * 8, "layout");
+    memcpy(out, c->h_counters.data() + C_FEAT, sizeof *out);
     return NGSQ_OK;
 }
 

@@ -11,7 +11,7 @@
 
 namespace ngsq {
 
-enum KernelId { K_FIELDS = 0, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_COUNT };
+enum KernelId { K_FIELDS = 0, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_FEATURES, K_COUNT };
 
 struct PendingTime {
     int id;
@@ -56,6 +56,11 @@ struct ngsq_ctx {
     unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
     std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;
     bool finalized = false;
+    // Genomic Features gene model (ngsq_set_features)
+    ngsq::FeatureTables ft{};
+    uint32_t *d_ft_idx = nullptr, *d_ft_starts = nullptr, *d_ft_stops = nullptr;
+    uint8_t *d_ft_primary = nullptr;
+    bool have_features = false;
     ngsq::Staging stage[2];
     int stage_next = 0;
     ngsq_kernel_time timing[ngsq::K_COUNT]{};

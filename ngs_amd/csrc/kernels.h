@@ -11,7 +11,8 @@
 //   C_TLEN_PROCESSED, C_TLEN_IGNORED
 //   C_GC_GC, C_GC_AT, C_GC_OTHER, C_GC_PROCESSED, C_GC_IGN_FLAGS, C_GC_IGN_SHORT
 //   C_COV_NONSENSICAL
-//   [C_ERR .. +8)           ngsq_error_counts
+//   [C_ERR .. +8)           ngsq_error_counts (first eight)
+//   [C_FEAT .. +9)          ngsq_features_metrics; C_FEAT_ERR_REF, C_FEAT_ERR_POS (the last two error counts)
 //   [OFF_GC_HIST .. +101)   GC histogram
 //   [off_tlen .. +tlen_cap+1)
 //   [off_qual .. +max_read_len*94)   per-cycle quality table, row = 0-based cycle
@@ -48,6 +49,18 @@ enum : uint32_t {
     E_EDITS_NOT_CONSUMED = 5,
     E_EDITS_TOO_MANY = 6,
     E_BAD_CIGAR = 7,
+    C_FEAT = 51,
+    F_UTR5 = 0,
+    F_UTR3 = 1,
+    F_CDS = 2,
+    F_INTERGENIC = 3,
+    F_EXONIC = 4,
+    F_INTRONIC = 5,
+    F_PROCESSED = 6,
+    F_IGN_FLAGS = 7,
+    F_IGN_NONPRIMARY = 8,
+    C_FEAT_ERR_REF = 60,
+    C_FEAT_ERR_POS = 61,
     OFF_GC_HIST = 64,
     OFF_TLEN_HIST = 168,
 };
@@ -114,6 +127,19 @@ hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const Device
 bool qual_window_supported(const DeviceState &st, const DeviceBatch &b);
 hipError_t launch_qual_window(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint32_t nrot,
                               hipStream_t s);
+// Genomic Features (features.rs:115-242): gene model as sorted coordinate lists, features_kernel.hip
+struct FeatureTables {
+    // intervals of name id k on sequence r: entries [idx[k * n_refs + r], idx[k * n_refs + r + 1]) of
+    // `starts` (sorted) and, independently sorted, `stops`
+    const uint32_t *idx;    // [5 * n_refs + 1]
+    const uint32_t *starts; // [n]
+    const uint32_t *stops;  // [n]
+    const uint8_t *primary; // [n_refs]
+    uint32_t n_refs;
+    uint32_t role_name[5]; // name id of NGSQ_ROLE_*
+};
+hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const FeatureTables &ft,
+                           hipStream_t s);
 // Edits process (edits.rs:217-303)
 hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                         hipStream_t s);

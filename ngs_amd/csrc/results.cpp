@@ -220,7 +220,38 @@ extern "C" int64_t ngsq_results_json(const ngsq_ctx *c, const char *const *ref_n
     }
 
     j.key(1, "features");
-    j.s += "null,\n";
+    if (facets & NGSQ_FACET_FEATURES) {
+        // features/metrics.rs:10-80 (declaration order); summary: features.rs:244-262
+        const u64 *f = cnt + C_FEAT;
+        j.s += "{\n";
+        j.key(2, "exonic_translation_regions");
+        j.s += "{\n";
+        j.u_field(3, "utr_five_prime_count", f[F_UTR5], false);
+        j.u_field(3, "utr_three_prime_count", f[F_UTR3], false);
+        j.u_field(3, "coding_sequence_count", f[F_CDS], true);
+        j.close(2, false);
+        j.key(2, "gene_regions");
+        j.s += "{\n";
+        j.u_field(3, "intergenic_count", f[F_INTERGENIC], false);
+        j.u_field(3, "exonic_count", f[F_EXONIC], false);
+        j.u_field(3, "intronic_count", f[F_INTRONIC], true);
+        j.close(2, false);
+        j.key(2, "records");
+        j.s += "{\n";
+        j.u_field(3, "processed", f[F_PROCESSED], false);
+        j.u_field(3, "ignored_flags", f[F_IGN_FLAGS], false);
+        j.u_field(3, "ignored_nonprimary_chromosome", f[F_IGN_NONPRIMARY], true);
+        j.close(2, false);
+        const double denom = (double)(f[F_IGN_FLAGS] + f[F_IGN_NONPRIMARY] + f[F_PROCESSED]);
+        j.key(2, "summary");
+        j.s += "{\n";
+        j.f_field(3, "ignored_flags_pct", ((double)f[F_IGN_FLAGS] / denom) * 100.0, false);
+        j.f_field(3, "ignored_nonprimary_chromosome_pct", ((double)f[F_IGN_NONPRIMARY] / denom) * 100.0, true);
+        j.close(2, true);
+        j.close(1, false);
+    } else {
+        j.s += "null,\n";
+    }
 
     j.key(1, "gc_content");
     if (facets & NGSQ_FACET_GC_CONTENT) {

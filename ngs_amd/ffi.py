@@ -13,7 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libngsq.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -30,7 +30,8 @@ FACET_GC_CONTENT = 0x04
 FACET_QUALITY_SCORE = 0x08
 FACET_COVERAGE = 0x10
 FACET_EDITS = 0x20
-FACETS_RECORD_BASED = 0x0F
+FACET_FEATURES = 0x40
+FACETS_RECORD_BASED = 0x4F
 FACETS_SEQUENCE_BASED = 0x30
 FACETS_DEFAULT = 0x1F
 
@@ -135,7 +136,30 @@ class GcMetrics(C.Structure):
 ERROR_FIELDS = [
     "missing_reference_id", "bad_quality_score", "read_too_long", "edits_bad_reference",
     "edits_record_short", "edits_not_consumed", "edits_too_many", "bad_cigar_op",
+    "features_missing_reference_id", "features_missing_position",
 ]
+
+FEATURES_FIELDS = [
+    "utr_five_prime_count", "utr_three_prime_count", "coding_sequence_count", "intergenic_count", "exonic_count",
+    "intronic_count", "processed", "ignored_flags", "ignored_nonprimary_chromosome",
+]
+ROLE_FIVE_PRIME_UTR, ROLE_THREE_PRIME_UTR, ROLE_CODING_SEQUENCE, ROLE_EXON, ROLE_GENE = range(5)
+
+
+class FeaturesMetrics(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in FEATURES_FIELDS]
+
+
+class Features(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("role_name", C.c_uint32 * 5),
+        ("n", C.c_uint64),
+        ("ref_id", C.c_void_p),
+        ("name", C.c_void_p),
+        ("start", C.c_void_p),
+        ("stop", C.c_void_p),
+    ]
 
 
 class ErrorCounts(C.Structure):
@@ -181,6 +205,8 @@ PROTOTYPES = {
     "ngsq_synchronize": (C.c_int, [ctx_p]),
     "ngsq_stream": (C.c_void_p, [ctx_p]),
     "ngsq_get_error_counts": (C.c_int, [ctx_p, C.POINTER(ErrorCounts)]),
+    "ngsq_get_features": (C.c_int, [ctx_p, C.POINTER(FeaturesMetrics)]),
+    "ngsq_set_features": (C.c_int, [ctx_p, C.POINTER(Features)]),
     "ngsq_get_general": (C.c_int, [ctx_p, C.POINTER(GeneralMetrics)]),
     "ngsq_get_template_length": (C.c_int, [ctx_p, u64p, C.c_size_t, u64p, u64p]),
     "ngsq_get_gc_content": (C.c_int, [ctx_p, C.POINTER(GcMetrics)]),

@@ -44,6 +44,13 @@ typedef struct {
     orc_histogram *refs_per_position, *alts_per_position; /* [n_refs], lazily allocated */
 } orc_edits;
 
+/* rust_lapper::Interval<usize, FeatureNameStrand> as features.rs:314-318 builds it (the strand is
+   never read back) */
+struct orc_interval {
+    uint32_t ref_id, name;
+    uint64_t start, stop;
+};
+
 struct orc_ctx {
     ngsq_config cfg;
     uint32_t *ref_len;
@@ -65,6 +72,14 @@ struct orc_ctx {
     orc_histogram *scores;
     orc_coverage cov;
     orc_edits edits;
+    /* features.rs:83-106: the two interval stores (per sequence lookups are a filter on ref here)
+       and the feature names, kept as the name ids of ngsq_features */
+    struct orc_interval *utr_store, *gene_store;
+    uint64_t n_utr, n_gene;
+    uint32_t role_name[5];
+    int have_features;
+    ngsq_features_metrics features;
+    double feat_ignored_flags_pct, feat_ignored_nonprimary_pct;
     ngsq_error_counts errors;
     int finalized;
     double cpu_seconds;
@@ -127,6 +142,40 @@ orc_ctx *orc_create(const ngsq_config *cfg) {
     return c;
 }
 
+/* features.rs:300-343: every GFF record on a primary sequence whose type is a UTR/CDS name goes to the
+   exonic-translation store, else one whose type is the exon or gene name to the gene-region store.
+   Lapper::new sorts by start (rust-lapper 1.1.0 sorts the intervals): a stable sort by (start, stop). */
+static int interval_cmp(const void *a, const void *b) {
+    const struct orc_interval *x = (const struct orc_interval *)a, *y = (const struct orc_interval *)b;
+    if (x->start != y->start) return x->start < y->start ? -1 : 1;
+    if (x->stop != y->stop) return x->stop < y->stop ? -1 : 1;
+    return 0;
+}
+
+int orc_set_features(orc_ctx *c, const ngsq_features *f) {
+    if (!c || !f || f->struct_size != sizeof(ngsq_features)) return NGSQ_ERR_INVALID_ARGUMENT;
+    free(c->utr_store);
+    free(c->gene_store);
+    c->utr_store = (struct orc_interval *)calloc(f->n ? f->n : 1, sizeof(struct orc_interval));
+    c->gene_store = (struct orc_interval *)calloc(f->n ? f->n : 1, sizeof(struct orc_interval));
+    c->n_utr = c->n_gene = 0;
+    for (int r = 0; r < 5; r++) c->role_name[r] = f->role_name[r];
+    for (uint64_t i = 0; i < f->n; i++) {
+        if (f->ref_id[i] >= c->cfg.n_refs) return NGSQ_ERR_INVALID_ARGUMENT;
+        if (!c->ref_is_primary[f->ref_id[i]]) continue; /* :300: only primary-assembly sequences get a store */
+        struct orc_interval iv = {f->ref_id[i], f->name[i], f->start[i], f->stop[i]};
+        if (iv.name == f->role_name[NGSQ_ROLE_FIVE_PRIME_UTR] || iv.name == f->role_name[NGSQ_ROLE_THREE_PRIME_UTR] ||
+            iv.name == f->role_name[NGSQ_ROLE_CODING_SEQUENCE]) /* :322-326 */
+            c->utr_store[c->n_utr++] = iv;
+        else if (iv.name == f->role_name[NGSQ_ROLE_EXON] || iv.name == f->role_name[NGSQ_ROLE_GENE]) /* :327-331 */
+            c->gene_store[c->n_gene++] = iv;
+    }
+    qsort(c->utr_store, c->n_utr, sizeof(struct orc_interval), interval_cmp);
+    qsort(c->gene_store, c->n_gene, sizeof(struct orc_interval), interval_cmp);
+    c->have_features = 1;
+    return NGSQ_OK;
+}
+
 void orc_destroy(orc_ctx *c) {
     if (!c) return;
     uint32_t n = c->cfg.n_refs;
@@ -156,6 +205,8 @@ void orc_destroy(orc_ctx *c) {
     orc_hist_free(&c->edits.vaf_histogram);
     free(c->edits.refs_per_position);
     free(c->edits.alts_per_position);
+    free(c->utr_store);
+    free(c->gene_store);
     free(c->ref_len);
     free(c->ref_is_primary);
     free(c->ref_bases);
@@ -589,6 +640,76 @@ static void edits_teardown(orc_ctx *c, uint32_t ref) {
 
 /* ------------------------------------------------------------ batch driver */
 
+/* ------------------------------------------------------------ Genomic Features */
+
+/* rust_lapper Interval::overlap (lib.rs, 1.1.0): self.start < stop && self.stop > start */
+static int lapper_overlap(const struct orc_interval *iv, uint64_t start, uint64_t stop) {
+    return iv->start < stop && iv->stop > start;
+}
+
+/* features.rs:115-242 */
+static void features_process(orc_ctx *c, const orc_record *r) {
+    ngsq_features_metrics *m = &c->features;
+    if (flag_unmapped(r->flag)) { /* :127-130 */
+        m->ignored_flags += 1;
+        return;
+    }
+    if (r->ref_id < 0 || (uint32_t)r->ref_id >= c->cfg.n_refs) { /* :132-155 bail! */
+        c->errors.features_missing_reference_id += 1;
+        return;
+    }
+    if (!c->ref_is_primary[r->ref_id]) { /* :157-165 */
+        m->ignored_nonprimary_chromosome += 1;
+        return;
+    }
+    if (r->pos < 0) { /* :171-174 bail! */
+        c->errors.features_missing_position += 1;
+        return;
+    }
+    const uint64_t start = (uint64_t)r->pos + 1; /* 1-based alignment_start */
+    const uint64_t end = start + alignment_span(r); /* :178 */
+    /* :186-214: walk find(start, end + 1) of the exonic-translation store in store order */
+    int counted5 = 0, counted3 = 0, counted_cds = 0;
+    for (uint64_t k = 0; k < c->n_utr; k++) {
+        const struct orc_interval *iv = &c->utr_store[k];
+        if (iv->ref_id != (uint32_t)r->ref_id || !lapper_overlap(iv, start, end + 1)) continue;
+        if (!counted5 && iv->name == c->role_name[NGSQ_ROLE_FIVE_PRIME_UTR]) {
+            counted5 = 1;
+            m->utr_five_prime_count += 1;
+        } else if (!counted3 && iv->name == c->role_name[NGSQ_ROLE_THREE_PRIME_UTR]) {
+            counted3 = 1;
+            m->utr_three_prime_count += 1;
+        } else if (!counted_cds && iv->name == c->role_name[NGSQ_ROLE_CODING_SEQUENCE]) {
+            counted_cds = 1;
+            m->coding_sequence_count += 1;
+        }
+    }
+    /* :216-238 */
+    int has_gene = 0, has_exon = 0;
+    for (uint64_t k = 0; k < c->n_gene; k++) {
+        const struct orc_interval *iv = &c->gene_store[k];
+        if (iv->ref_id != (uint32_t)r->ref_id || !lapper_overlap(iv, start, end + 1)) continue;
+        if (iv->name == c->role_name[NGSQ_ROLE_GENE]) has_gene = 1;
+        else if (iv->name == c->role_name[NGSQ_ROLE_EXON]) has_exon = 1;
+        if (has_gene && has_exon) break;
+    }
+    if (has_gene) {
+        if (has_exon) m->exonic_count += 1;
+        else m->intronic_count += 1;
+    } else {
+        m->intergenic_count += 1;
+    }
+    m->processed += 1; /* :240 */
+}
+
+/* features.rs:244-262 */
+static void features_summarize(orc_ctx *c) {
+    const ngsq_features_metrics *m = &c->features;
+    const double denom = (double)(m->ignored_flags + m->ignored_nonprimary_chromosome + m->processed);
+    c->feat_ignored_flags_pct = ((double)m->ignored_flags / denom) * 100.0;
+    c->feat_ignored_nonprimary_pct = ((double)m->ignored_nonprimary_chromosome / denom) * 100.0;
+}
+
 static int fetch_record(const ngsq_batch *b, uint64_t i, orc_record *r) {
     r->flag = b->flag[i];
     r->mapq = b->mapq ? b->mapq[i] : 255;
@@ -627,6 +748,7 @@ int orc_process_batch(orc_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
     uint32_t facets = c->cfg.facets;
     orc_record r;
     /* pass 1: command.rs:305-316 */
+    if ((pass_mask & NGSQ_PASS_RECORD) && (facets & NGSQ_FACET_FEATURES) && !c->have_features) return NGSQ_ERR_STATE;
     if ((pass_mask & NGSQ_PASS_RECORD) && (facets & NGSQ_FACETS_RECORD_BASED)) {
         for (uint64_t i = 0; i < b->n_records; i++) {
             fetch_record(b, i, &r);
@@ -635,6 +757,7 @@ int orc_process_batch(orc_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
             if (facets & NGSQ_FACET_TEMPLATE_LENGTH) tlen_process(c, &r);
             if (facets & NGSQ_FACET_GC_CONTENT) gc_process(c, &r);
             if (facets & NGSQ_FACET_QUALITY_SCORE) quality_process(c, &r);
+            if (facets & NGSQ_FACET_FEATURES) features_process(c, &r); /* pushed last: qc.rs:68-79 */
         }
     }
     /* pass 2: command.rs:356-397.  The reference visits sequences one at a
@@ -670,6 +793,7 @@ int orc_finalize(orc_ctx *c) {
     if (facets & NGSQ_FACET_GENERAL) general_summarize(c);
     if (facets & NGSQ_FACET_TEMPLATE_LENGTH) tlen_summarize(c);
     if (facets & NGSQ_FACET_GC_CONTENT) gc_summarize(c);
+    if (facets & NGSQ_FACET_FEATURES) features_summarize(c);
     /* command.rs:392-396, per sequence in header order */
     int rc = NGSQ_OK;
     for (uint32_t r = 0; r < c->cfg.n_refs; r++) {
@@ -696,6 +820,11 @@ int orc_finalize(orc_ctx *c) {
 
 int orc_get_error_counts(const orc_ctx *c, ngsq_error_counts *out) {
     *out = c->errors;
+    return NGSQ_OK;
+}
+
+int orc_get_features(const orc_ctx *c, ngsq_features_metrics *out) {
+    *out = c->features;
     return NGSQ_OK;
 }
 
@@ -983,7 +1112,41 @@ int64_t orc_results_json(const orc_ctx *c, const char *const *ref_names, char *b
         sb_puts(s, "null,\n");
     }
     js_key(s, 1, "features");
-    sb_puts(s, "null,\n");
+    if (facets & NGSQ_FACET_FEATURES) { /* features/metrics.rs:66-80 */
+        const ngsq_features_metrics *m = &c->features;
+        sb_puts(s, "{\n");
+        js_key(s, 2, "exonic_translation_regions");
+        sb_puts(s, "{\n");
+        js_u64_field(s, 3, "utr_five_prime_count", m->utr_five_prime_count, 0);
+        js_u64_field(s, 3, "utr_three_prime_count", m->utr_three_prime_count, 0);
+        js_u64_field(s, 3, "coding_sequence_count", m->coding_sequence_count, 1);
+        sb_indent(s, 2);
+        sb_puts(s, "},\n");
+        js_key(s, 2, "gene_regions");
+        sb_puts(s, "{\n");
+        js_u64_field(s, 3, "intergenic_count", m->intergenic_count, 0);
+        js_u64_field(s, 3, "exonic_count", m->exonic_count, 0);
+        js_u64_field(s, 3, "intronic_count", m->intronic_count, 1);
+        sb_indent(s, 2);
+        sb_puts(s, "},\n");
+        js_key(s, 2, "records");
+        sb_puts(s, "{\n");
+        js_u64_field(s, 3, "processed", m->processed, 0);
+        js_u64_field(s, 3, "ignored_flags", m->ignored_flags, 0);
+        js_u64_field(s, 3, "ignored_nonprimary_chromosome", m->ignored_nonprimary_chromosome, 1);
+        sb_indent(s, 2);
+        sb_puts(s, "},\n");
+        js_key(s, 2, "summary");
+        sb_puts(s, "{\n");
+        js_f64_field(s, 3, "ignored_flags_pct", c->feat_ignored_flags_pct, 0);
+        js_f64_field(s, 3, "ignored_nonprimary_chromosome_pct", c->feat_ignored_nonprimary_pct, 1);
+        sb_indent(s, 2);
+        sb_puts(s, "}\n");
+        sb_indent(s, 1);
+        sb_puts(s, "},\n");
+    } else {
+        sb_puts(s, "null,\n");
+    }
     js_key(s, 1, "gc_content");
     if (facets & NGSQ_FACET_GC_CONTENT) {
         sb_puts(s, "{\n");

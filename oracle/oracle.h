@@ -62,6 +62,9 @@ int orc_process_batch(orc_ctx *ctx, const ngsq_batch *batch, uint32_t pass_mask)
 /* summarize (command.rs:328-330), teardown per sequence (:392-396), aggregate (:406-414) */
 int orc_finalize(orc_ctx *ctx);
 
+/* GenomicFeaturesFacet::try_from's interval stores (features.rs:300-343) */
+int orc_set_features(orc_ctx *ctx, const ngsq_features *features);
+int orc_get_features(const orc_ctx *ctx, ngsq_features_metrics *out);
 int orc_get_error_counts(const orc_ctx *ctx, ngsq_error_counts *out);
 int orc_get_general(const orc_ctx *ctx, ngsq_general_metrics *out);
 int orc_get_template_length(const orc_ctx *ctx, uint64_t *histogram, size_t n_bins,

@@ -52,6 +52,8 @@ def load() -> C.CDLL:
     lib.orc_process_batch.argtypes = [P, C.POINTER(ffi.Batch), C.c_uint32]
     lib.orc_finalize.argtypes = [P]
     lib.orc_get_error_counts.argtypes = [P, C.POINTER(ffi.ErrorCounts)]
+    lib.orc_set_features.argtypes = [P, C.POINTER(ffi.Features)]
+    lib.orc_get_features.argtypes = [P, C.POINTER(ffi.FeaturesMetrics)]
     lib.orc_get_general.argtypes = [P, C.POINTER(ffi.GeneralMetrics)]
     lib.orc_get_template_length.argtypes = [P, ffi.u64p, C.c_size_t, ffi.u64p, ffi.u64p]
     lib.orc_get_gc_content.argtypes = [P, C.POINTER(ffi.GcMetrics)]
@@ -173,6 +175,18 @@ class Oracle:
 
     def elapsed_seconds(self) -> float:
         return float(self.lib.orc_elapsed_seconds(self._ctx))
+
+    def set_features(self, ref_id, name, start, stop, role_name=(0, 1, 2, 3, 4)):
+        from ngs_amd import host
+        f, keep = host.features_struct(ref_id, name, start, stop, role_name)
+        rc = self.lib.orc_set_features(self._ctx, C.byref(f))
+        if rc != 0:
+            raise RuntimeError(f"orc_set_features: {rc}")
+
+    def features(self) -> Dict[str, int]:
+        m = ffi.FeaturesMetrics()
+        self.lib.orc_get_features(self._ctx, C.byref(m))
+        return {k: int(getattr(m, k)) for k in ffi.FEATURES_FIELDS}
 
     def error_counts(self) -> Dict[str, int]:
         e = ffi.ErrorCounts()

@@ -169,3 +169,61 @@ def test_edits_with_reference_fasta(ngs, gpu_lib, oracle_mod, tmp_path):
         f.write(">chr1\n" + "".join(letters[x] for x in bases[0]) + "\n")
     r = run(ngs, "-q", "qc", bam, GENOME, "-r", str(fa), "-o", str(tmp_path))
     assert r.returncode == 1 and "sequence chr2 not found in reference FASTA." in r.stderr
+
+
+@pytest.mark.gpu
+def test_genomic_features_with_gff(ngs, gpu_lib, oracle_mod, tmp_path):
+    """-f GFF: file -> gene model -> Genomic Features facet, against the oracle fed the same intervals;
+    plus the facet's own error paths (formats/gff.rs:19-47, features.rs:291,310-312)."""
+    import gzip
+    hb = sorted_batch(5, 3000)
+    c = hb.cols   # a mapped record needs a sequence and a position here (features.rs:132-140,171-174 bail otherwise)
+    c["flag"][(c["pos"] < 0) | (c["ref_id"] < 0)] |= np.uint16(0x4)
+    bam = str(tmp_path / "g.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS)
+    rng = np.random.default_rng(8)
+    types = ["five_prime_UTR", "three_prime_UTR", "CDS", "exon", "gene", "transcript", "start_codon"]
+    rows, model = ["##gff-version 3", "#comment"], []
+    for _ in range(400):
+        seq = int(rng.integers(0, 4))
+        s = int(rng.integers(1, LENS[seq]))
+        e = min(LENS[seq], s + int(rng.integers(0, 3000)))
+        t = types[int(rng.integers(0, len(types)))]
+        rows.append(f"{NAMES[seq]}\tHAVANA\t{t}\t{s}\t{e}\t.\t{'+-'[int(rng.integers(0, 2))]}\t.\tID=x")
+        if t in types[:5] and PRIMARY[seq]:
+            model.append((seq, types.index(t), s, e))
+    rows += ["chr9\tHAVANA\tgene\t5\t900\t.\t+\t.\tID=primary_but_not_in_this_bam", "##FASTA", ">junk", "ACGT"]
+    gff = str(tmp_path / "m.gff3.gz")
+    with gzip.open(gff, "wt") as f:
+        f.write("\n".join(rows) + "\n")
+    r = run(ngs, "-q", "qc", bam, GENOME, "-f", gff, "-o", str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    got = json.load(open(str(tmp_path / "g.bam.results.json")))
+    o = oracle_mod.Oracle(LENS, PRIMARY, facets=ffi.FACETS_DEFAULT | ffi.FACET_FEATURES, max_read_len=1024, gc_seed=0x4E4753)
+    o.set_features(*[np.array(c) for c in zip(*model)])
+    o.process_batch(hb)
+    o.finalize()
+    json_equal(got, o.results(NAMES))
+    assert got["features"]["records"]["processed"] > 1000 and got["features"]["gene_regions"]["exonic_count"] > 0
+    # --only selects it by its display name, case-insensitively (qc.rs:101-123)
+    r = run(ngs, "-q", "qc", bam, GENOME, "-f", gff, "-o", str(tmp_path), "--only", "genomic features")
+    assert r.returncode == 0, r.stderr
+    only = json.load(open(str(tmp_path / "g.bam.results.json")))
+    assert only["features"] == got["features"] and only["general"] is None and only["coverage"] is None
+    # custom feature names: exons called "gene" make every genic read ... still genic, never exonic
+    r = run(ngs, "-q", "qc", bam, GENOME, "-f", gff, "-o", str(tmp_path), "--only", "Genomic Features",
+            "--exon-feature-name", "gene")
+    assert r.returncode == 0, r.stderr
+    same = json.load(open(str(tmp_path / "g.bam.results.json")))["features"]["gene_regions"]
+    assert same["exonic_count"] == 0 and same["intronic_count"] == got["features"]["gene_regions"]["exonic_count"] + \
+        got["features"]["gene_regions"]["intronic_count"]
+    # error paths
+    plain = str(tmp_path / "bad.gff")
+    open(plain, "w").write("chr1\tx\tgene\t10\t20\t.\t.\t.\tID=1\n")
+    r = run(ngs, "-q", "qc", bam, GENOME, "-f", plain, "-o", str(tmp_path))
+    assert r.returncode == 1 and "attempted to parse strand from value: ." in r.stderr
+    open(plain, "w").write("chr1\tx\tgene\t10\n")
+    r = run(ngs, "-q", "qc", bam, GENOME, "-f", plain, "-o", str(tmp_path))
+    assert r.returncode == 1 and "invalid GFF record on line 1" in r.stderr
+    r = run(ngs, "-q", "qc", bam, GENOME, "-f", str(tmp_path / "m.bed"), "-o", str(tmp_path))
+    assert r.returncode == 1 and "opening GFF file" in r.stderr

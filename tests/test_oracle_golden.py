@@ -109,3 +109,37 @@ def test_vaf_f32_truncation(oracle_mod):
         o.finalize()
         vaf = o.edits()[2]
         assert vaf[want] == 1 and vaf.sum() == 1, (alts, np.nonzero(vaf))
+
+
+def test_genomic_features_hand_golden(oracle_mod):
+    """Hand-derived from features.rs:115-262 (incl. its two boundary quirks: a feature's last base is
+    outside its rust_lapper interval, and the lookup reaches one base past the read's end)."""
+    NAMES = dict(five_prime_UTR=0, three_prime_UTR=1, CDS=2, exon=3, gene=4)
+    model = [("gene", 1000, 5000), ("exon", 1000, 1200), ("exon", 3000, 3300), ("five_prime_UTR", 1000, 1050),
+             ("CDS", 1051, 1200), ("CDS", 3000, 3200), ("three_prime_UTR", 3201, 3300),
+             ("gene", 10, 500)]  # the last one sits on the non-primary sequence below
+    ref = [0] * 7 + [1]
+    rec = lambda **kw: dict(dict(flag=0, mapq=60, ref_id=0, cigar="50M", seq="A" * 50, qual=[30] * 50), **kw)  # noqa: E731
+    records = [
+        rec(pos=999),                                       # A [1000,1051): gene+exon, 5'UTR (CDS starts at 1051: no)
+        rec(pos=1999, cigar="100M", seq="A" * 100, qual=[30] * 100),   # B intronic
+        rec(pos=5999, cigar="100M", seq="A" * 100, qual=[30] * 100),   # C intergenic
+        rec(pos=0, flag=4),                                 # D unmapped
+        rec(pos=99, ref_id=1),                              # E non-primary sequence
+        rec(pos=3149, cigar="100M", seq="A" * 100, qual=[30] * 100),   # F CDS + 3'UTR, exonic
+        rec(pos=1199, cigar="1M", seq="A", qual=[30]),      # G exon/CDS end at 1200 = exclusive: intronic
+        rec(pos=949),                                       # H [950,1001) touches base 1000: gene, exon, 5'UTR
+    ]
+    from tests.util import batch_from_records
+    orc = oracle_mod.Oracle([10_000, 1_000], [1, 0], facets=ffi.FACET_FEATURES)
+    orc.set_features(ref, [NAMES[n] for n, _, _ in model], [s for _, s, _ in model], [e for _, _, e in model])
+    orc.process_batch(batch_from_records(records))
+    orc.finalize()
+    got = orc.results(["chr1", "chrUn"])["features"]
+    assert got == {
+        "exonic_translation_regions": {"utr_five_prime_count": 2, "utr_three_prime_count": 1, "coding_sequence_count": 1},
+        "gene_regions": {"intergenic_count": 1, "exonic_count": 3, "intronic_count": 2},
+        "records": {"processed": 6, "ignored_flags": 1, "ignored_nonprimary_chromosome": 1},
+        "summary": {"ignored_flags_pct": 12.5, "ignored_nonprimary_chromosome_pct": 12.5},
+    }
+    assert orc.results(["chr1", "chrUn"])["general"] is None

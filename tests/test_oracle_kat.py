@@ -184,7 +184,7 @@ def test_facet_names_and_default_set():  # qc.rs:238-271 + each facet's name()
 
 
 def test_facet_names_from_library(lib):
-    names = {b: lib.ngsq_facet_name(b).decode() for b in (1, 2, 4, 8, 16, 32)}
+    names = {b: lib.ngsq_facet_name(b).decode() for b in (1, 2, 4, 8, 16, 32, 64)}
     assert names == {1: "General", 2: "Template Length", 4: "GC Content", 8: "Quality Score",
-                     16: "Coverage", 32: "Edits"}
-    assert lib.ngsq_facet_name(64) is None
+                     16: "Coverage", 32: "Edits", 64: "Genomic Features"}   # qc.rs:138-139 names, features.rs:107
+    assert lib.ngsq_facet_name(128) is None

@@ -19,10 +19,14 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hand_
 
 
 def run_both(oracle_mod, lib, batches, ref_len, primary=None, facets=ffi.FACETS_DEFAULT, bin_size=1000,
-             max_read_len=320, gc_seed=7, ref_bases=None, on_device=False, allow_malformed=True, names=None):
+             max_read_len=320, gc_seed=7, ref_bases=None, on_device=False, allow_malformed=True, names=None,
+             features=None):
     kw = dict(facets=facets, bin_size=bin_size, max_read_len=max_read_len, gc_seed=gc_seed, ref_bases=ref_bases)
     orc = oracle_mod.Oracle(ref_len, primary, **kw)
     gpu = host.QcContext(ref_len, primary, lib=lib, **kw)
+    if features is not None:
+        orc.set_features(*features)
+        gpu.set_features(*features)
     for hb in batches:
         orc.process_batch(hb)
         if on_device:
@@ -385,3 +389,59 @@ def test_three_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode):
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+# ---- Genomic Features facet (features.rs) ------------------------------------------------------
+def random_gene_model(rng, ref_len, n, max_span=4000):
+    """(ref_id, name id, start, end) of n random GFF features incl. 1-bp ones (start == end)."""
+    ref = rng.integers(0, len(ref_len), n).astype(np.uint32)
+    start = np.array([rng.integers(1, ref_len[r] + 1) for r in ref], dtype=np.uint32)
+    span = np.where(rng.random(n) < 0.1, 0, rng.integers(0, max_span, n)).astype(np.uint32)
+    name = rng.choice(5, n, p=[.1, .1, .25, .4, .15]).astype(np.uint32)
+    return ref, name, start, start + span
+
+
+@pytest.mark.parametrize("roles", [(0, 1, 2, 3, 4), (0, 0, 2, 3, 4), (0, 0, 0, 3, 4), (0, 1, 2, 3, 3), (0, 1, 2, 2, 4),
+                                   (0, 1, 2, 3, 0)])
+def test_genomic_features_matches_oracle(gpu_lib, oracle_mod, roles):
+    """Random gene models and records; feature roles that share a name (the reference compares name
+    strings) exercise the order-dependent if/else-if chains of features.rs:186-238."""
+    rng = np.random.default_rng(sum(roles) + 31)
+    ref_len = [60_000, 9_000, 25_000]
+    primary = [1, 0, 1]
+    ref, name, start, stop = random_gene_model(rng, ref_len, 600)
+    name = np.array([roles[k] for k in name], dtype=np.uint32)  # intervals carry name ids that are in use
+    hb = random_batch(rng, 30_000, ref_len, weird=True)
+    hb.cols["ref_id"][hb.cols["ref_id"] < 0] = 0  # no mapped record without a sequence here (tested below)
+    hb.cols["pos"][hb.cols["pos"] < 0] = 5
+    facets = ffi.FACET_FEATURES | ffi.FACET_GENERAL
+    gpu, orc = run_both(oracle_mod, gpu_lib, [hb.slice(0, 11_111), hb.slice(11_111, hb.n)], ref_len, primary,
+                        facets=facets, features=(ref, name, start, stop, roles))
+    f = gpu.features()
+    assert f["processed"] + f["ignored_flags"] + f["ignored_nonprimary_chromosome"] == hb.n
+    assert f["intergenic_count"] + f["exonic_count"] + f["intronic_count"] == f["processed"]
+    assert f["processed"] > 10_000 and f["utr_five_prime_count"] > 0
+    # a gene / exon name equal to a UTR/CDS name lands in the other store, and an exon name equal to the gene
+    # name never reaches the `has_exon` branch
+    gene_ok = roles[4] not in roles[:3]
+    assert (f["exonic_count"] > 0) == (gene_ok and roles[3] not in (roles[0], roles[1], roles[2], roles[4]))
+    assert (f["intergenic_count"] == f["processed"]) == (not gene_ok)
+    assert gpu.results(["a", "b", "c"])["features"]["records"]["processed"] == f["processed"]
+
+
+def test_genomic_features_errors_and_state(gpu_lib, oracle_mod):
+    ref_len = [5000]
+    feats = (np.array([0]), np.array([4]), np.array([100]), np.array([900]), (0, 1, 2, 3, 4))
+    recs = [dict(flag=0, mapq=9, ref_id=0, pos=150, cigar="50M", seq="A" * 50, qual=[30] * 50),
+            dict(flag=0, mapq=9, ref_id=-1, pos=150, cigar="50M", seq="A" * 50, qual=[30] * 50),   # features.rs:132-140
+            dict(flag=0, mapq=9, ref_id=0, pos=-1, cigar="50M", seq="A" * 50, qual=[30] * 50)]     # features.rs:171-174
+    gpu, orc = run_both(oracle_mod, gpu_lib, [batch_from_records(recs)], ref_len, facets=ffi.FACET_FEATURES,
+                        features=feats)
+    e = gpu.error_counts()
+    assert e["features_missing_reference_id"] == 1 and e["features_missing_position"] == 1
+    assert gpu.features()["intronic_count"] == 1
+    # the facet cannot run without a gene model
+    q = host.QcContext(ref_len, facets=ffi.FACET_FEATURES, lib=gpu_lib)
+    with pytest.raises(Exception, match="ngsq_set_features"):
+        q.process_batch(batch_from_records(recs[:1]))
+    q.close()

@@ -69,7 +69,7 @@ def _worker(rank, world, port, q):
         first, cnt = shard.shard_range(whole.n, rank, world)
         mine = whole.slice(first, first + cnt)
         assert mine.first_record_index == first
-        kw = dict(facets=ffi.FACETS_RECORD_BASED, max_read_len=320, gc_seed=11)
+        kw = dict(facets=ffi.FACETS_DEFAULT & ffi.FACETS_RECORD_BASED, max_read_len=320, gc_seed=11)
         o = oracle_py.Oracle(ref_len, **kw)
         o.process_batch(mine)
         o.finalize(allow_malformed=True)

@@ -231,6 +231,8 @@ def compare_contexts(gpu, orc, n_refs: int, facets: int, bin_size: int, ref_len:
             if L % bin_size:
                 div[-1] = float(L % bin_size)
             np.testing.assert_array_equal(tg.astype(np.float64) / div, mo)
+    if facets & ffi.FACET_FEATURES:
+        assert gpu.features() == orc.features()
     if facets & ffi.FACET_EDITS:
         for a, b in zip(gpu.edits(), orc.edits()):
             np.testing.assert_array_equal(a, b)
