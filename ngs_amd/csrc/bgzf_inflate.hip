@@ -91,7 +91,7 @@ struct Lds {
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // The serial core of the decoder, seven scalar instructions per symbol: starting at bit s, mark the
-// symbol start in `lits` and step to the next one (step[s] bits further) until a lane says stop
+// symbol start in `lits` (literals and whole matches alike) and step to the next one (step[s] bits further) until a lane says stop
 // (bit 7 of its step) or the window ends (s >= 64).  Hand-scheduled: the compiler's structurised
 // control flow needs about twice as many instructions for this loop.
 __device__ __forceinline__ void chain_literals(uint32_t step, uint32_t &s, uint64_t &lits) {
@@ -108,6 +108,17 @@ __device__ __forceinline__ void chain_literals(uint32_t step, uint32_t &s, uint6
                  : [s] "+s"(s), [lits] "+s"(lits), [st] "=&s"(st)
                  : [step] "v"(step)
                  : "scc");
+}
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside the rows of 16, then the two
+// row broadcasts (DPP, no LDS)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
 }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
     return (uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v);
@@ -514,96 +525,128 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         bool end_of_block = false;
         while (!end_of_block && err == INF_OK) {
             PROF(6); // tail of the previous window (piece flush, loop)
-            // lane j: the code that would start j bits from here, in both alphabets
+            // Lane j decodes what would start j bits from here: a literal, or a whole match -- length code,
+            // its extra bits, and (from the lane at that bit offset) the distance code and its extra bits.
             br.sync();
             const uint32_t x = br.lane_bits32(lane);
             uint32_t E = L.lit_tab[x & ((1u << LB) - 1u)];
-            const uint32_t D = L.dist_tab[x & ((1u << DB) - 1u)];
-            // per lane: bits to the next symbol if this one is a literal, else a stop mark
-            uint32_t step = (E & (7u << 5)) == (K_LIT << 5) ? (E & 31u) : 0x80u;
-            uint32_t s = 0; // bits of the window used so far
-            PROF(2);        // window bits + gathers
+            const uint32_t nb = E & 31u, lex = (E >> 8) & 15u;
+            const uint32_t len = (E >> 16) + ((x >> nb) & ((1u << lex) - 1u));
+            const uint32_t s2 = lane + nb + lex; // bit offset of the distance code
+            const uint32_t xd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s2 << 2), (int)x);
+            const uint32_t D = L.dist_tab[xd & ((1u << DB) - 1u)];
+            const uint32_t db = D & 31u, dex = (D >> 8) & 15u;
+            const uint32_t dist = (D >> 16) + ((xd >> db) & ((1u << dex) - 1u));
+            bool is_lit = (E & (7u << 5)) == (K_LIT << 5);
+            const bool is_match = (E & (7u << 5)) == (K_BASE << 5) && s2 < 64 && (D & (7u << 5)) == (K_BASE << 5);
+            // bits to the next symbol, or a stop mark: end of block, long codes, a distance code beyond lane 63
+            uint32_t step = is_lit ? nb : is_match ? nb + lex + db + dex : 0x80u;
+            PROF(2); // window bits + gathers
             PROF_COUNT(0, 1);
-            // One window serves several runs of literals and the matches between them: everything a
-            // match needs is in the lanes at its bit offsets.
+            // the chain of real symbol starts: readlane + add per symbol
+            uint64_t syms = 0;
+            uint32_t s = 0;
             for (;;) {
-                // follow the chain of real symbol starts while they are literals: readlane + add per symbol
-                uint64_t lits = 0;
-                uint32_t e = 0;
-                for (;;) {
-                    chain_literals(step, s, lits);
-                    if (s >= 64) break;
-                    // not a short literal.  A literal with a long code is patched into its lane and the
-                    // chain goes on; anything else ends it.
-                    e = __builtin_amdgcn_readlane(E, s);
-                    if (((e >> 5) & 7u) != K_ESC) break;
-                    e = uni(resolve_long(L, 0, __builtin_amdgcn_readlane(x, s)));
-                    PROF_COUNT(5, 1);
-                    if (((e >> 5) & 7u) != K_LIT) break;
-                    if (lane == s) {
-                        E = e;
-                        step = e & 31u;
-                    }
-                }
-                PROF(3); // chain
-                // the literals on the chain, in stream order
-                if ((lits >> lane) & 1ull) {
-                    const uint32_t k =
-                        __builtin_amdgcn_mbcnt_hi((uint32_t)(lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lits, 0u));
-                    L.ring[(pos + k) & RMASK] = (uint8_t)(E >> 16);
-                }
-                pos += __popcll(lits);
-                PROF_COUNT(1, __popcll(lits));
-                if (pos > isize) { // also bounds the work on a corrupt stream
-                    err = INF_OUTPUT_OVERRUN;
-                    break;
-                }
-                PROF(4); // literal store
+                chain_literals(step, s, syms);
                 if (s >= 64) break;
-                // the symbol at bit s (entry e, long codes resolved) is an end-of-block, a length or invalid
-                const uint32_t kind = (e >> 5) & 7u, nb = e & 31u;
-                if (kind != K_BASE) {
-                    if (kind == K_EOB) {
-                        s += nb;
-                        end_of_block = true;
-                    } else {
-                        err = INF_BAD_SYMBOL;
-                    }
-                    break;
+                // a literal with a long code is patched into its lane and the chain goes on
+                uint32_t e = __builtin_amdgcn_readlane(E, s);
+                if (((e >> 5) & 7u) != K_ESC) break;
+                e = uni(resolve_long(L, 0, __builtin_amdgcn_readlane(x, s)));
+                PROF_COUNT(5, 1);
+                if (((e >> 5) & 7u) != K_LIT) break;
+                if (lane == s) {
+                    E = e;
+                    step = e & 31u;
+                    is_lit = true;
                 }
-                const uint32_t lex = (e >> 8) & 15u;
-                const uint32_t s2 = s + nb + lex; // where the distance code starts
-                if (s2 >= 64) break;              // beyond the lanes' view: the next window starts at this length code
-                const uint32_t xs = __builtin_amdgcn_readlane(x, s);
-                const uint32_t len = (e >> 16) + ((xs >> nb) & ((1u << lex) - 1u));
-                uint32_t d = __builtin_amdgcn_readlane(D, s2);
-                const uint32_t xd = __builtin_amdgcn_readlane(x, s2);
-                if (__builtin_expect(((d >> 5) & 7u) == K_ESC, 0)) d = uni(resolve_long(L, 1, xd));
-                const uint32_t db = d & 31u, dex = (d >> 8) & 15u;
-                const uint32_t dist = (d >> 16) + ((xd >> db) & ((1u << dex) - 1u));
-                s = s2 + db + dex;
-                // errors are sticky and checked once per window: every access below is masked into the ring
-                if (((d >> 5) & 7u) != K_BASE) err = INF_BAD_SYMBOL;
-                else if (dist > pos) err = INF_BAD_DISTANCE;
-                else if (pos + len > isize) err = INF_OUTPUT_OVERRUN;
-                // the source run [pos - dist, pos) is final: byte i of the match is its byte i mod dist
-                const uint32_t from = pos - dist;
-                if (__builtin_expect(dist >= len, 1)) {
-                    for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
-                } else {
-                    const uint32_t dd = max(dist, 1u);
-                    for (uint32_t i = lane; i < len; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dd) & RMASK];
-                }
-                pos += len;
-                PROF_COUNT(2, 1);
-                PROF_COUNT(3, len);
-                PROF_COUNT(4, dist < len ? 1 : 0);
-                PROF(5); // match
-                if (pos - flushed >= PIECE) flush_piece(PIECE);
-                if (s >= 64) break; // the lanes' view of the stream is used up
             }
-            if (err == INF_OK) br.consume(s);
-            if (pos - flushed >= PIECE) flush_piece(PIECE);
+            PROF(3); // chain
+            // where each symbol on the chain writes: prefix sum of the output lengths
+            const bool on_chain = (syms >> lane) & 1ull;
+            const uint32_t olen = !on_chain ? 0u : is_lit ? 1u : len;
+            const uint32_t incl = wave_inclusive_sum(olen);
+            const uint32_t at = pos + incl - olen;
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            PROF_COUNT(1, __popcll(__ballot(on_chain && is_lit)));
+            uint64_t mm = __ballot(on_chain && !is_lit);
+            if (__ballot(on_chain && !is_lit && dist > at)) err = INF_BAD_DISTANCE; // sticky; accesses stay in the ring
+            // All literals of the window go out in one store BEFORE the matches are copied in stream order (a
+            // match may read what an earlier symbol of this window wrote).  That is safe unless a match reaches
+            // so far back that a later literal of this window lands on its source in the 32 KiB ring.
+            const bool far = __ballot(on_chain && !is_lit && dist + total > RING) != 0;
+            if (__builtin_expect(far, 0)) mm = syms; // strict stream order, literals included
+            else if (on_chain && is_lit) L.ring[at & RMASK] = (uint8_t)(E >> 16);
+            PROF(4); // literal store
+            while (mm) {
+                const uint32_t m = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                const uint32_t l = __builtin_amdgcn_readlane(olen, m), d = __builtin_amdgcn_readlane(dist, m);
+                const uint32_t o = __builtin_amdgcn_readlane(at, m), from = o - d;
+                if (far && ((__ballot(is_lit) >> m) & 1ull)) { // only on the strict path
+                    if (lane == m) L.ring[o & RMASK] = (uint8_t)(E >> 16);
+                    continue;
+                }
+                // the source run [o - d, o) is final: byte i of the match is its byte i mod d
+                if (__builtin_expect(d >= l, 1)) {
+                    for (uint32_t i = lane; i < l; i += 64) L.ring[(o + i) & RMASK] = L.ring[(from + i) & RMASK];
+                } else {
+                    const uint32_t dd = max(d, 1u);
+                    for (uint32_t i = lane; i < l; i += 64) L.ring[(o + i) & RMASK] = L.ring[(from + i % dd) & RMASK];
+                }
+                PROF_COUNT(2, 1);
+                PROF_COUNT(3, l);
+            }
+            pos += total;
+            br.consume(s);
+            if (pos > isize) { // also bounds the work on a corrupt stream
+                err = INF_OUTPUT_OVERRUN;
+                break;
+            }
+            PROF(5); // matches
+            if (s < 64 && err == INF_OK) {
+                // The chain stopped at a symbol the lanes could not finish: end of block, a long code, a
+                // distance code beyond lane 63, or an invalid code.  One symbol the plain way.
+                br.sync();
+                const uint32_t x0 = br.bits32();
+                uint32_t e = uni(L.lit_tab[x0 & ((1u << LB) - 1u)]);
+                if (((e >> 5) & 7u) == K_ESC) e = uni(resolve_long(L, 0, x0));
+                const uint32_t kind = (e >> 5) & 7u, eb = e & 31u;
+                if (kind == K_LIT) {
+                    if (lane == 0) L.ring[pos & RMASK] = (uint8_t)(e >> 16);
+                    pos += 1;
+                    br.consume(eb);
+                } else if (kind == K_EOB) {
+                    br.consume(eb);
+                    end_of_block = true;
+                } else if (kind == K_BASE) {
+                    const uint32_t ex = (e >> 8) & 15u;
+                    const uint32_t l = (e >> 16) + ((x0 >> eb) & ((1u << ex) - 1u));
+                    br.consume(eb + ex);
+                    br.sync();
+                    const uint32_t x1 = br.bits32();
+                    uint32_t d = uni(L.dist_tab[x1 & ((1u << DB) - 1u)]);
+                    if (((d >> 5) & 7u) == K_ESC) d = uni(resolve_long(L, 1, x1));
+                    const uint32_t b2 = d & 31u, ex2 = (d >> 8) & 15u;
+                    const uint32_t dd0 = (d >> 16) + ((x1 >> b2) & ((1u << ex2) - 1u));
+                    br.consume(b2 + ex2);
+                    if (((d >> 5) & 7u) != K_BASE) err = INF_BAD_SYMBOL;
+                    else if (dd0 > pos) err = INF_BAD_DISTANCE;
+                    else if (pos + l > isize) err = INF_OUTPUT_OVERRUN;
+                    else {
+                        const uint32_t from = pos - dd0;
+                        if (dd0 >= l) {
+                            for (uint32_t i = lane; i < l; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
+                        } else {
+                            for (uint32_t i = lane; i < l; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dd0) & RMASK];
+                        }
+                        pos += l;
+                    }
+                } else {
+                    err = INF_BAD_SYMBOL;
+                }
+            }
+            while (pos - flushed >= PIECE) flush_piece(PIECE);
         }
     }
     PROF(0);
