@@ -115,7 +115,6 @@ struct DeviceIngest {
     std::condition_variable cv;
     bool stop = false;
     bool file_done = false; // the consumer has taken the last chunk
-    uint64_t first = 0; // offset in d_raw of the first record of the next chunk
     bool first_chunk = true;
     // device
     DevBuf<uint8_t> d_comp, d_raw, d_seq, d_qual, d_scan_tmp;
@@ -237,7 +236,6 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     if (!c.err.empty()) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s", c.err.c_str());
     const size_t n_blk = c.blocks.size(), consumed = c.consumed;
     const uint64_t total = c.total;
-    const double t2 = now_ms();
     // ---- 3. inflate
     for (auto &bl : c.blocks) bl.out_off += carry;
     if (n_blk) {
@@ -273,7 +271,6 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     d->first_chunk = d->first_chunk && d->raw_len < first; // the header may span the first chunk(s)
     if (d->raw_len < first) {
         // nothing but header bytes so far: drop them and carry on
-        d->first = 0;
         b->header_bytes -= d->raw_len;
         d->tail_off = d->raw_len;
         return NGSQ_OK;
@@ -327,11 +324,10 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
                              (unsigned long long)(b->n_read + bad));
     d->n_rec = total_rec;
-    d->first = 0;
     if (trace_on())
-        fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | wait for reader %.1f ms, - %.1f ms, "
+        fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | wait for reader %.1f ms, "
                         "h2d+inflate %.1f ms, index %.1f ms\n",
-                n_blk, consumed / 1e6, total / 1e6, (unsigned long long)total_rec, t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
+                n_blk, consumed / 1e6, total / 1e6, (unsigned long long)total_rec, t1 - t0, t3 - t1, now_ms() - t3);
     return NGSQ_OK;
 }
 

@@ -18,8 +18,8 @@
 //  * LZ77 matches are copied by the lanes, 64 bytes per step, inside a 32 KiB LDS ring (DEFLATE's
 //    window), so a match never reads HBM; finished 16 KiB pieces leave the ring as coalesced
 //    dword stores.  39 KiB of LDS per wave: four waves per CU, one per SIMD.
-//  * CRC32 of the block (gzip trailer) is verified on request: 64 slices per piece in
-//    parallel, combined with GF(2) polynomial multiplication.
+//  * CRC32 of the block (gzip trailer) is verified on request by a second, wide kernel
+//    (k_bgzf_crc: 64 slices per block, combined with GF(2) polynomial multiplication).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -334,8 +334,7 @@ __device__ uint32_t crc_xpow8(uint32_t n_bytes) { // x^(8 n) mod P
 
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
                                                      const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status,
-                                                     uint32_t check_crc) {
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
     extern __shared__ __align__(16) uint8_t s_raw[];
     Lds &L = *reinterpret_cast<Lds *>(s_raw);
     const uint32_t lane = threadIdx.x;
@@ -345,15 +344,11 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     BgzfBlock blk = blocks[bi];
     blk.in_off = uni64(blk.in_off);
     blk.out_off = uni64(blk.out_off);
-    blk.crc = uni(blk.crc);
     const uint32_t isize = uni(blk.isize), in_len = uni(blk.in_len);
     if (isize == 0 && in_len == 0) {
         if (lane == 0) status[bi] = INF_OK;
         return;
     }
-    uint32_t xs_full = 0; // x^(8 * slice) for full pieces
-    constexpr uint32_t SLICE = 260; // PIECE / 64 rounded up to 4 * odd: the lanes' slices start in distinct banks
-    if (check_crc) xs_full = crc_xpow8(SLICE);
     InStream br;
     br.init(comp + blk.in_off, L.in_ring);
     const uint32_t in_mis = (uint32_t)(reinterpret_cast<uintptr_t>(comp + blk.in_off) & 3u);
@@ -361,22 +356,10 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     uint8_t *const gdst = out + blk.out_off;
 
     // output state: bytes [0, pos) are in the ring (the last 32 KiB of them), [0, flushed) have left for HBM
-    uint32_t pos = 0, flushed = 0, err = INF_OK, crc = 0;
+    uint32_t pos = 0, flushed = 0, err = INF_OK;
 
-    // ring bytes [flushed, flushed + n) -> HBM (and into the running CRC)
+    // ring bytes [flushed, flushed + n) -> HBM
     auto flush_piece = [&](uint32_t n) {
-        if (check_crc) {
-            const uint32_t lo = min(lane * SLICE, n), hi = min(lo + SLICE, n);
-            uint32_t c = 0xFFFFFFFFu;
-            for (uint32_t i = lo; i < hi; i++) c = c_crc.t[(c ^ L.ring[(flushed + i) & RMASK]) & 0xFFu] ^ (c >> 8);
-            c = ~c; // CRC of the slice (of the empty string: 0)
-            for (uint32_t k = 0; k < 64; k++) {
-                const uint32_t lk = min(k * SLICE, n), hk = min(lk + SLICE, n);
-                if (hk == lk) break;
-                // crc(A || B) = crc(A) * x^(8 |B|) + crc(B)
-                crc = crc_mul(hk - lk == SLICE ? xs_full : crc_xpow8(hk - lk), crc) ^ __builtin_amdgcn_readlane(c, k);
-            }
-        }
         uint8_t *dst = gdst + flushed;
         const uint32_t head = min((uint32_t)((4u - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u), n);
         if (lane < head) dst[lane] = L.ring[(flushed + lane) & RMASK];
@@ -596,6 +579,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 }
                 PROF_COUNT(2, 1);
                 PROF_COUNT(3, l);
+                PROF_COUNT(4, d > 4096 ? 1 : 0);
+                PROF_COUNT(6, d > 8192 ? 1 : 0);
+                PROF_COUNT(7, d > 16384 ? 1 : 0);
             }
             pos += total;
             br.consume(s);
@@ -655,11 +641,52 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     __syncthreads();
     if (err == INF_OK) {
         while (flushed < pos) flush_piece(min(pos - flushed, PIECE));
-        if (check_crc && crc != uni(blk.crc)) err = INF_CRC_MISMATCH;
     }
     PROF(7); // final flush + CRC
     PROF_FLUSH;
     if (lane == 0) status[bi] = err;
+}
+
+// CRC32 of every inflated block against its gzip trailer: its own kernel (one wave per block, no LDS
+// ring, so many waves per CU) instead of a tax on the four decoders of a CU.  The block is cut into 64
+// equal slices, right-aligned (the CRC register is linear in the message once the initial value is
+// accounted for, and leading zero bytes leave a zero register at zero): the lane that holds byte 0
+// starts from 0xFFFFFFFF, the others from 0, and the slices are combined pairwise in six steps,
+// register(A || B) = register(A) * x^(8 |B|) + register(B), with |B| the same for every pair of a step.
+__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ out, const BgzfBlock *__restrict__ blocks,
+                                                  uint32_t n_blocks, uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_tab[256];
+    s_tab[threadIdx.x] = c_crc.t[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t bi = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (bi >= n_blocks) return;
+    const uint32_t isize = uni(blocks[bi].isize);
+    if (uni(status[bi]) != INF_OK) return;
+    const uint8_t *p = out + uni64(blocks[bi].out_off);
+    const uint32_t S = (isize + 63u) / 64u, pad = 64u * S - isize;
+    // real bytes of this lane's slice
+    const uint32_t v0 = lane * S, v1 = v0 + S;
+    const uint32_t a = v0 > pad ? v0 - pad : 0u, b = v1 > pad ? v1 - pad : 0u;
+    uint32_t c = (a == 0 && b > 0) ? 0xFFFFFFFFu : 0u;
+    uint32_t i = a;
+    for (; i < b && ((reinterpret_cast<uintptr_t>(p + i)) & 3u); i++) c = s_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    for (; i + 4 <= b; i += 4) {
+        c ^= *reinterpret_cast<const uint32_t *>(p + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) c = s_tab[c & 0xFFu] ^ (c >> 8);
+    }
+    for (; i < b; i++) c = s_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    // pairwise combination: after step j the lanes whose low j+1 bits are ones hold 2^(j+1) slices
+    uint32_t mult = crc_xpow8(S); // x^(8 |B|) of this step (uniform)
+    for (uint32_t j = 0; j < 6; j++) {
+        const uint32_t left = (uint32_t)__shfl_up((int)c, 1u << j, 64);
+        if ((lane & ((2u << j) - 1u)) == (2u << j) - 1u) c = crc_mul(left, mult) ^ c;
+        mult = crc_mul(mult, mult);
+    }
+    const uint32_t crc = ~__builtin_amdgcn_readlane(c, 63);
+    if (isize && lane == 0 && crc != blocks[bi].crc) status[bi] = INF_CRC_MISMATCH;
+    if (!isize && lane == 0 && blocks[bi].crc != 0) status[bi] = INF_CRC_MISMATCH;
 }
 
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
@@ -672,8 +699,8 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks), dim3(64), sizeof(Lds), s, comp, blocks, n_blocks, out, status,
-                       check_crc ? 1u : 0u);
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks), dim3(64), sizeof(Lds), s, comp, blocks, n_blocks, out, status);
+    if (check_crc) hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, s, out, blocks, n_blocks, status);
 #ifdef NGSQ_INFLATE_PROFILE
     {
         unsigned long long h[16];
@@ -685,8 +712,9 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         for (int k = 0; k < 8; k++) tot += h[k];
         for (int k = 0; k < 8; k++)
             fprintf(stderr, "[inflate-prof] %-24s %6.2f %%\n", names[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
-        fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, matches %llu (bytes %llu, overlapping %llu), long codes %llu\n",
-                h[8], h[9], h[10], h[11], h[12], h[13]);
+        fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, matches %llu (bytes %llu; distance > 4 KiB %llu, > 8 KiB %llu, "
+                        "> 16 KiB %llu), long codes %llu\n",
+                h[8], h[9], h[10], h[11], h[12], h[14], h[15], h[13]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_prof), z, sizeof z);
     }
