@@ -313,6 +313,9 @@ int ngsq_get_coverage_nonsensical(const ngsq_ctx *ctx, uint64_t *nonsensical_rec
 /* edits.rs:32-57 */
 int ngsq_get_edits(const ngsq_ctx *ctx, uint64_t *read_one_edits, uint64_t *read_two_edits,
                    size_t n_edit_bins, uint64_t *vaf_histogram, size_t n_vaf_bins);
+/* refs_per_position / alts_per_position of one sequence (edits.rs:322-324), ref_len+1 entries each:
+ * what the reference's --vaf-file lines are computed from (edits.rs:331-340) */
+int ngsq_get_edits_positions(ngsq_ctx *ctx, uint32_t ref, uint32_t *refs, uint32_t *alts, size_t n);
 
 /* Full `Results` JSON (results.rs:23-60, serde_json pretty layout, maps in
  * sorted / header order).  `ref_names` = @SQ names in header order.  Returns

@@ -8,13 +8,13 @@
 // ingest is include/ngsq_bam.h.  Additive flags: --device, --batch-records, --threads, --gc-seed,
 // --ingest host|device (default device: the GPU inflates and parses the BAM; runs with -n
 // always ingest on the host).
-// Not built (out of scope this round): the other subcommands, the Genomic
-// Features facet (-f) and --vaf-file.
+// Not built (out of scope this round): the other subcommands.
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <charconv>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -333,7 +333,7 @@ void usage() {
             "  -p, --output-prefix <STRING>    Output prefix [default: name of the BAM file]\n"
             "  -r, --reference-fasta <PATH>    Reference FASTA file (enables the Edits facet)\n"
             "      --only <FACET>              Only process one QC facet\n"
-            "      --vaf-file <PATH>           (not supported by this build)\n"
+            "      --vaf-file <PATH>           Write the VAF of every covered position (Edits facet, needs -r)\n"
             "      --five-prime-utr-feature-name, --three-prime-utr-feature-name, --coding-sequence-feature-name,\n"
             "      --exon-feature-name, --gene-feature-name <STRING>   accepted for compatibility\n"
             "      --device <N> --batch-records <N> --threads <N> --gc-seed <N> --ingest host|device   (additive, this build)\n");
@@ -416,7 +416,6 @@ int main(int argc, char **argv) {
         char cwd[4096];
         a.out_dir = getcwd(cwd, sizeof cwd) ? cwd : ".";
     }
-    if (!a.vaf.empty()) bail("--vaf-file is not supported by this build");
 
     // ---- app(): command.rs:226-421
     // open_and_parse(IndexCheck::Full): extension sniff, <bam>.bai must parse, header + references
@@ -481,6 +480,17 @@ int main(int argc, char **argv) {
                 bail("sequence " + names[r] + " has a different length in the reference FASTA");
             bases[r] = it->second.data();
         }
+    }
+    // EditsFacet::try_from (edits.rs:134-151) creates the VAF file while the facets are built -- before
+    // --only filters them -- and refuses to overwrite one
+    FILE *vaf_file = nullptr;
+    if (!a.fasta.empty() && !a.vaf.empty()) {
+        struct stat st;
+        if (stat(a.vaf.c_str(), &st) == 0)
+            bail("refusing to overwrite existing VAF file: " + a.vaf + ". Please delete and rerun if you'd like to replace it.");
+        vaf_file = fopen(a.vaf.c_str(), "wb");
+        if (!vaf_file) bail("creating VAF file");
+        fputs("Sequence\tPosition\tVAF\n", vaf_file);
     }
 
     ngsq_config cfg;
@@ -613,6 +623,27 @@ int main(int argc, char **argv) {
         logf(2, "No facets specified that require second pass. Skipping...");
     }
     CHECK(ctx, ngsq_finalize(ctx));
+    if (vaf_file && (facets & NGSQ_FACET_EDITS)) {
+        // edits.rs:320-341, per sequence in header order: one line per position any record covered; the
+        // value is the f32 the histogram bin was taken from, printed as Rust prints it (shortest digits
+        // that round-trip, never an exponent)
+        std::vector<uint32_t> refs, alts;
+        for (uint32_t r = 0; r < n_refs; r++) {
+            const size_t L1 = (size_t)ref_len[r] + 1;
+            refs.resize(L1);
+            alts.resize(L1);
+            CHECK(ctx, ngsq_get_edits_positions(ctx, r, refs.data(), alts.data(), L1));
+            for (size_t i = 0; i < L1; i++) {
+                const uint64_t total = (uint64_t)refs[i] + alts[i];
+                if (!total) continue;
+                const float vaf = (float)alts[i] / (float)total;
+                char num[64];
+                const auto res = std::to_chars(num, num + sizeof num, vaf, std::chars_format::fixed);
+                fprintf(vaf_file, "%s\t%zu\t%.*s\n", names[r].c_str(), i, (int)(res.ptr - num), num);
+            }
+        }
+    }
+    if (vaf_file) fclose(vaf_file);
 
     logf(2, "Aggregating results.");
     std::vector<const char *> name_ptrs(n_refs ? n_refs : 1, "");

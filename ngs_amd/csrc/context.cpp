@@ -844,6 +844,20 @@ int ngsq_get_edits(const ngsq_ctx *c, uint64_t *r1, uint64_t *r2, size_t n_edit_
     return NGSQ_OK;
 }
 
+int ngsq_get_edits_positions(ngsq_ctx *c, uint32_t ref, uint32_t *refs, uint32_t *alts, size_t n) {
+    NEED_FINAL(c);
+    if (ref >= c->cfg.n_refs || !refs || !alts) return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!(c->cfg.facets & NGSQ_FACET_EDITS) || c->edits_off[ref] == NO_DEPTH)
+        return fail(c, NGSQ_ERR_STATE, "sequence %u has no Edits state", ref);
+    const size_t L1 = (size_t)c->ref_len[ref] + 1;
+    if (n < L1) return NGSQ_ERR_BUFFER_TOO_SMALL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t *base = c->st.edits + c->edits_off[ref];
+    HIP_TRY(c, hipMemcpy(refs, base, L1 * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(alts, base + L1, L1 * 4, hipMemcpyDeviceToHost));
+    return NGSQ_OK;
+}
+
 // ---- measurement -----------------------------------------------------------------
 
 int ngsq_kernel_timing_count(const ngsq_ctx *c) { return c ? K_COUNT : 0; }

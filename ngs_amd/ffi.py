@@ -206,6 +206,7 @@ PROTOTYPES = {
     "ngsq_stream": (C.c_void_p, [ctx_p]),
     "ngsq_get_error_counts": (C.c_int, [ctx_p, C.POINTER(ErrorCounts)]),
     "ngsq_get_features": (C.c_int, [ctx_p, C.POINTER(FeaturesMetrics)]),
+    "ngsq_get_edits_positions": (C.c_int, [ctx_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ngsq_set_features": (C.c_int, [ctx_p, C.POINTER(Features)]),
     "ngsq_get_general": (C.c_int, [ctx_p, C.POINTER(GeneralMetrics)]),
     "ngsq_get_template_length": (C.c_int, [ctx_p, u64p, C.c_size_t, u64p, u64p]),

@@ -164,6 +164,26 @@ def test_edits_with_reference_fasta(ngs, gpu_lib, oracle_mod, tmp_path):
     want = oracle_json(oracle_mod, hb, facets=ffi.FACETS_DEFAULT | ffi.FACET_EDITS, ref_bases=bases)
     json_equal(got, want)
     assert sum(got["edits"]["read_one_edits"]["values"][1:]) > 0 and sum(got["edits"]["vaf_histogram"]["values"]) > 0
+    # --vaf-file (edits.rs:134-151, :320-341): one line per covered position, in header order; binning the
+    # written f32 values the way the facet does reproduces the VAF histogram; Rust's f32 Display
+    vaf = tmp_path / "vafs.tsv"
+    r = run(ngs, "-q", "qc", bam, GENOME, "-r", str(fa), "-o", str(tmp_path), "--vaf-file", str(vaf))
+    assert r.returncode == 0, r.stderr
+    lines = open(vaf).read().splitlines()
+    assert lines[0] == "Sequence\tPosition\tVAF"
+    hist = [0] * 101
+    last = (-1, -1)
+    for ln in lines[1:]:
+        name, pos, val = ln.split("\t")
+        key = (NAMES.index(name), int(pos))
+        assert key > last
+        last = key
+        v = np.float32(val)
+        assert val == np.format_float_positional(v, unique=True, trim="-") and "e" not in val
+        hist[int(v * np.float32(100.0))] += 1
+    assert hist == got["edits"]["vaf_histogram"]["values"]
+    r = run(ngs, "-q", "qc", bam, GENOME, "-r", str(fa), "-o", str(tmp_path), "--vaf-file", str(vaf))
+    assert r.returncode == 1 and "refusing to overwrite existing VAF file" in r.stderr
     # a sequence missing from the FASTA aborts like EditsFacet::setup (edits.rs:207-209)
     with open(fa, "w") as f:
         f.write(">chr1\n" + "".join(letters[x] for x in bases[0]) + "\n")
