@@ -59,6 +59,28 @@ uint64_t ngsq_bam_records_read(const ngsq_bam *bam);
  * calls, not both (NGSQ_ERR_STATE).  Needs a GPU. */
 int ngsq_bam_next_batch_device(ngsq_bam *bam, ngsq_ctx *ctx, uint64_t max_records, ngsq_batch *out);
 
+/* ---- sharded device ingest: one BAM file, several GPUs -----------------
+ * Shard s of n reads the BGZF blocks that start in [split(s), split(s+1)), split(k) = the first
+ * block start at or after k * file_size / n (found the same way by every shard), inflates and
+ * indexes them at once -- the shard stays resident in device memory -- and then hands out batches
+ * with ngsq_bam_next_batch_device.  A record belongs to the shard its first byte lies in; the blocks
+ * that complete a shard's last record are read too.
+ *
+ * Shards other than 0 do not know where their first record starts: prepare() assumes the first
+ * plausible record chain, and reports what it assumed (begin_voffset) and where its own chain enters
+ * the next shard (end_voffset).  The caller compares neighbours (shard s+1's begin must equal shard
+ * s's end; ngs_amd/shard.py does it with one all-gather) and calls commit() with the confirmed begin
+ * (re-indexing if it differs) and with the number of records in front of the shard, which
+ * first_record_index needs.  Virtual offsets are the BAM index's: block file offset << 16 | offset in
+ * the block's data; end_voffset is 0 at the end of the file. */
+typedef struct ngsq_bam_shard_info {
+    uint64_t n_records;     /* records starting in this shard */
+    uint64_t begin_voffset; /* first record of this shard */
+    uint64_t end_voffset;   /* first record after this shard */
+} ngsq_bam_shard_info;
+int ngsq_bam_shard_prepare(ngsq_bam *bam, ngsq_ctx *ctx, uint32_t shard, uint32_t n_shards, ngsq_bam_shard_info *out);
+int ngsq_bam_shard_commit(ngsq_bam *bam, uint64_t begin_voffset, uint64_t first_record_index, ngsq_bam_shard_info *out);
+
 /* Inflate a buffer of WHOLE BGZF blocks (host memory) on the context's device and copy the
  * decompressed bytes back: one wavefront per block (csrc/bgzf_inflate.hip).  *out_len receives
  * the total ISIZE (also when out_cap is too small).  check_crc != 0 verifies every block's CRC32.

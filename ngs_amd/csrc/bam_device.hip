@@ -239,6 +239,17 @@ __global__ void k_fill_slack(uint8_t *seq_end, uint8_t *qual_end) {
     }
 }
 
+__global__ void k_count_below_u64(const uint64_t *__restrict__ a, uint64_t n, uint64_t value, unsigned long long *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < value) lo = mid + 1;
+        else hi = mid;
+    }
+    *out = lo;
+}
+
 // ---- launchers ----------------------------------------------------------------------------------
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
                                  RecCandidate *cand, hipStream_t s) {
@@ -256,6 +267,10 @@ hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_s
     if (!n_seg) return hipSuccess;
     hipLaunchKernelGGL(k_rec_offsets, dim3((n_seg + 255) / 256), dim3(256), 0, s, raw, n_bytes, n_seg, seg_entry, seg_base,
                        rec_off, bad);
+    return hipGetLastError();
+}
+hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value, unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_below_u64, dim3(1), dim3(64), 0, s, a, n, value, out);
     return hipGetLastError();
 }
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c,

@@ -129,6 +129,14 @@ struct DeviceIngest {
     uint64_t raw_len = 0, tail_off = 0;
     uint64_t n_rec = 0, cursor = 0; // records indexed in the current chunk / handed out
     uint64_t blocks_done = 0;
+    // sharded mode (ngsq_bam_shard_prepare): the shard's blocks are inflated at once and stay resident
+    bool sharded = false, committed = false;
+    uint64_t c_lo = 0;                   // file offset of the shard's first block
+    uint64_t u_hi = 0;                   // raw offset where the next shard's first block starts
+    bool last_shard = false;
+    std::vector<BgzfBlock> shard_blocks; // out_off / isize of every inflated block
+    std::vector<uint64_t> blk_start;     // file offset of every block
+    uint64_t entry = 0, n_all = 0, own = 0, base_index = 0;
     std::vector<uint32_t> status;
     std::vector<RecCandidate> cand;
     std::vector<uint64_t> seg;
@@ -208,6 +216,62 @@ void reader_main(DeviceIngest *d, std::string path) {
     }
 }
 
+// Offsets of every complete record of d_raw[0, raw_len) whose chain starts at `first` -> d_rec_off; sets
+// d->tail_off to the offset of the cut record (or raw_len).  DESIGN.md section 9 "Record boundaries".
+int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_total) {
+    hipStream_t st = d->ctx->stream;
+    const uint32_t n_seg = (uint32_t)((d->raw_len + REC_SEGMENT - 1) / REC_SEGMENT);
+    *out_total = 0;
+    if (!n_seg) return NGSQ_OK;
+    BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
+    BHIP(d->d_seg.reserve((size_t)n_seg * 2));
+    BHIP(d->d_small.reserve(16));
+    BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+    d->cand.resize((size_t)n_seg * REC_CANDIDATES);
+    BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
+    BHIP(hipStreamSynchronize(st));
+    d->seg.resize((size_t)n_seg * 2);
+    uint64_t cur = first, total_rec = 0;
+    for (uint32_t s = 0; s < n_seg; s++) {
+        const uint64_t s1 = std::min<uint64_t>(((uint64_t)s + 1) * REC_SEGMENT, d->raw_len);
+        d->seg[s] = cur;
+        d->seg[n_seg + s] = total_rec;
+        if (cur >= s1) continue;
+        const RecCandidate *c = nullptr;
+        for (uint32_t k = 0; k < REC_CANDIDATES; k++) {
+            const RecCandidate &x = d->cand[(size_t)s * REC_CANDIDATES + k];
+            if (x.valid && x.start == cur) c = &x;
+        }
+        RecCandidate one{};
+        if (!c) {
+            RecCandidate *d_one = reinterpret_cast<RecCandidate *>(d->d_small.p + 4);
+            BHIP(launch_walk_one(d->d_raw.p, d->raw_len, cur, s1, d_one, st));
+            BHIP(hipMemcpyAsync(&one, d_one, sizeof one, hipMemcpyDeviceToHost, st));
+            BHIP(hipStreamSynchronize(st));
+            c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
+        }
+        total_rec += c->count;
+        if (!c->valid) {
+            cur = d->raw_len;
+            break;
+        }
+        cur = c->landing;
+    }
+    d->tail_off = std::min(cur, d->raw_len);
+    BHIP(d->d_rec_off.reserve(total_rec + 1));
+    BHIP(hipMemcpyAsync(d->d_seg.p, d->seg.data(), d->seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    BHIP(hipMemsetAsync(d->d_small.p, 0xFF, sizeof(unsigned long long), st));
+    BHIP(launch_rec_offsets(d->d_raw.p, d->raw_len, n_seg, d->d_seg.p, d->d_seg.p + n_seg, d->d_rec_off.p, d->d_small.p, st));
+    unsigned long long bad = 0;
+    BHIP(hipMemcpyAsync(&bad, d->d_small.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    BHIP(hipStreamSynchronize(st));
+    if (bad != ~0ull)
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
+                             (unsigned long long)(b->n_read + bad));
+    *out_total = total_rec;
+    return NGSQ_OK;
+}
+
 // Inflate the next run of BGZF blocks behind the unparsed tail of d_raw and index its records.
 int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     hipStream_t st = d->ctx->stream;
@@ -276,53 +340,11 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         return NGSQ_OK;
     }
     // ---- 4. record index
-    const uint32_t n_seg = (uint32_t)((d->raw_len + REC_SEGMENT - 1) / REC_SEGMENT);
-    if (!n_seg) return NGSQ_OK;
-    BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
-    BHIP(d->d_seg.reserve((size_t)n_seg * 2));
-    BHIP(d->d_small.reserve(16));
-    BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
-    d->cand.resize((size_t)n_seg * REC_CANDIDATES);
-    BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
-    BHIP(hipStreamSynchronize(st));
-    d->seg.resize((size_t)n_seg * 2);
-    uint64_t cur = first, total_rec = 0;
-    for (uint32_t s = 0; s < n_seg; s++) {
-        const uint64_t s1 = std::min<uint64_t>(((uint64_t)s + 1) * REC_SEGMENT, d->raw_len);
-        d->seg[s] = cur;
-        d->seg[n_seg + s] = total_rec;
-        if (cur >= s1) continue;
-        const RecCandidate *c = nullptr;
-        for (uint32_t k = 0; k < REC_CANDIDATES; k++) {
-            const RecCandidate &x = d->cand[(size_t)s * REC_CANDIDATES + k];
-            if (x.valid && x.start == cur) c = &x;
-        }
-        RecCandidate one{};
-        if (!c) {
-            RecCandidate *d_one = reinterpret_cast<RecCandidate *>(d->d_small.p + 4);
-            BHIP(launch_walk_one(d->d_raw.p, d->raw_len, cur, s1, d_one, st));
-            BHIP(hipMemcpyAsync(&one, d_one, sizeof one, hipMemcpyDeviceToHost, st));
-            BHIP(hipStreamSynchronize(st));
-            c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
-        }
-        total_rec += c->count;
-        if (!c->valid) {
-            cur = d->raw_len;
-            break;
-        }
-        cur = c->landing;
+    uint64_t total_rec = 0;
+    {
+        const int rc = index_records(b, d, first, &total_rec);
+        if (rc) return rc;
     }
-    d->tail_off = std::min(cur, d->raw_len);
-    BHIP(d->d_rec_off.reserve(total_rec + 1));
-    BHIP(hipMemcpyAsync(d->d_seg.p, d->seg.data(), d->seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    BHIP(hipMemsetAsync(d->d_small.p, 0xFF, sizeof(unsigned long long), st));
-    BHIP(launch_rec_offsets(d->d_raw.p, d->raw_len, n_seg, d->d_seg.p, d->d_seg.p + n_seg, d->d_rec_off.p, d->d_small.p, st));
-    unsigned long long bad = 0;
-    BHIP(hipMemcpyAsync(&bad, d->d_small.p, sizeof bad, hipMemcpyDeviceToHost, st));
-    BHIP(hipStreamSynchronize(st));
-    if (bad != ~0ull)
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
-                             (unsigned long long)(b->n_read + bad));
     d->n_rec = total_rec;
     if (trace_on())
         fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | wait for reader %.1f ms, "
@@ -335,6 +357,246 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
 
 extern "C" {
 
+} // extern "C" (reopened below)
+
+// ---- sharded mode --------------------------------------------------------------------------------
+
+namespace {
+
+// first BGZF block start at or after `from`: the gzip/BGZF header bytes, confirmed by following BSIZE
+// through the next blocks (compressed data can contain the magic by chance)
+int find_block_start(FILE *f, uint64_t from, uint64_t file_size, uint64_t *out, std::string *err) {
+    if (from == 0 || from >= file_size) {
+        *out = std::min(from, file_size);
+        return 0;
+    }
+    std::vector<uint8_t> buf((size_t)std::min<uint64_t>(file_size - from, (uint64_t)5 << 16));
+    if (fseeko(f, (off_t)from, SEEK_SET) != 0 || fread(buf.data(), 1, buf.size(), f) != buf.size()) {
+        *err = "read error while looking for a BGZF block boundary";
+        return -1;
+    }
+    auto header_at = [&](size_t p, uint32_t *bsize) {
+        if (p + 18 > buf.size()) return false;
+        const uint8_t *c = buf.data() + p;
+        if (c[0] != 31 || c[1] != 139 || c[2] != 8 || !(c[3] & 4)) return false;
+        const uint32_t xlen = bgzf_rd16(c + 10);
+        if (p + 12 + xlen > buf.size()) return false;
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const uint32_t slen = bgzf_rd16(buf.data() + q + 2);
+            if (buf[q] == 'B' && buf[q + 1] == 'C' && slen == 2) {
+                *bsize = bgzf_rd16(buf.data() + q + 4) + 1;
+                return *bsize >= 12 + xlen + 8;
+            }
+            q += 4 + slen;
+        }
+        return false;
+    };
+    for (size_t p = 0; p + 18 <= buf.size() && p < ((size_t)1 << 16) + 18; p++) {
+        uint32_t bs = 0;
+        if (!header_at(p, &bs)) continue;
+        // follow the chain for up to three more blocks (or to the end of the file)
+        size_t q = p + bs;
+        int ok = 1;
+        for (int k = 0; k < 3 && ok; k++) {
+            if (from + q == file_size) break;
+            uint32_t b2 = 0;
+            if (q + 18 > buf.size()) break; // ran out of look-ahead: accept
+            if (!header_at(q, &b2)) ok = 0;
+            q += b2;
+        }
+        if (ok) {
+            *out = from + p;
+            return 0;
+        }
+    }
+    *err = "no BGZF block boundary found";
+    return -1;
+}
+
+uint64_t raw_to_voffset(const DeviceIngest *d, uint64_t o) {
+    // the block whose data holds raw offset o (blocks without data are skipped)
+    size_t lo = 0, hi = d->shard_blocks.size();
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (d->shard_blocks[mid].out_off + d->shard_blocks[mid].isize <= o) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo == d->shard_blocks.size()) return 0; // behind the last byte: end of file
+    return d->blk_start[lo] << 16 | (o - d->shard_blocks[lo].out_off);
+}
+
+bool voffset_to_raw(const DeviceIngest *d, uint64_t v, uint64_t *o) {
+    const uint64_t coff = v >> 16, uoff = v & 0xFFFF;
+    const auto it = std::lower_bound(d->blk_start.begin(), d->blk_start.end(), coff);
+    if (it == d->blk_start.end() || *it != coff) return false;
+    const BgzfBlock &bl = d->shard_blocks[(size_t)(it - d->blk_start.begin())];
+    if (uoff > bl.isize) return false;
+    *o = bl.out_off + uoff;
+    return true;
+}
+
+// index from d->entry, count the shard's own records, fill `out`
+int shard_index(ngsq_bam *b, DeviceIngest *d, ngsq_bam_shard_info *out) {
+    hipStream_t st = d->ctx->stream;
+    uint64_t total = 0;
+    const int rc = index_records(b, d, d->entry, &total);
+    if (rc) return rc;
+    d->n_all = total;
+    unsigned long long own = 0;
+    if (total) {
+        BHIP(launch_count_below_u64(d->d_rec_off.p, total, d->u_hi, d->d_small.p + 8, st));
+        BHIP(hipMemcpyAsync(&own, d->d_small.p + 8, sizeof own, hipMemcpyDeviceToHost, st));
+        BHIP(hipStreamSynchronize(st));
+    }
+    d->own = own;
+    // where the chain enters the next shard: the record after the last own one, or the cut tail
+    uint64_t next = d->tail_off;
+    if (own < total) {
+        BHIP(hipMemcpyAsync(&next, d->d_rec_off.p + own, sizeof next, hipMemcpyDeviceToHost, st));
+        BHIP(hipStreamSynchronize(st));
+    } else if (d->tail_off < d->u_hi) {
+        // the cut record itself starts inside the shard: its end lies beyond the blocks that were read
+        return ngsq_bam_fail(d->last_shard ? NGSQ_ERR_INVALID_ARGUMENT : NGSQ_ERR_UNSUPPORTED,
+                             d->last_shard ? "%s: truncated record" : "%s: a record reaches more than four BGZF blocks past its shard",
+                             b->path.c_str());
+    }
+    if (d->entry >= d->u_hi) next = d->entry; // no record starts here: the chain only passes through
+    out->n_records = own;
+    out->begin_voffset = raw_to_voffset(d, d->entry);
+    out->end_voffset = d->last_shard ? 0 : raw_to_voffset(d, next);
+    d->n_rec = own;
+    d->cursor = 0;
+    return NGSQ_OK;
+}
+
+} // namespace
+
+extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, uint32_t n_shards, ngsq_bam_shard_info *out) {
+    if (!b || !c || !out || !n_shards || shard >= n_shards) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "bad argument");
+    if (b->host_mode || b->dev) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: the reader is already in use", b->path.c_str());
+    BHIP(hipSetDevice(c->device));
+    DeviceIngest *d = new DeviceIngest();
+    d->ctx = c;
+    d->sharded = true;
+    b->dev = d;
+    b->dev_free = free_ingest;
+    d->f = fopen(b->path.c_str(), "rb");
+    if (!d->f) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "opening BAM file: %s", b->path.c_str());
+    if (fseeko(d->f, 0, SEEK_END) != 0) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "cannot seek in %s", b->path.c_str());
+    const uint64_t file_size = (uint64_t)ftello(d->f);
+    std::string err;
+    uint64_t lo = 0, hi = file_size;
+    if (find_block_start(d->f, file_size / n_shards * shard, file_size, &lo, &err) ||
+        find_block_start(d->f, shard + 1 == n_shards ? file_size : file_size / n_shards * (shard + 1), file_size, &hi, &err))
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: %s", b->path.c_str(), err.c_str());
+    d->c_lo = lo;
+    d->last_shard = hi >= file_size;
+    // the shard's blocks + up to four more, which hold the end of its last record
+    const uint64_t want = std::min<uint64_t>(file_size, hi + ((uint64_t)4 << 16)) - lo;
+    uint8_t *h = nullptr;
+    BHIP(hipHostMalloc((void **)&h, want + 64, hipHostMallocDefault));
+    d->hc[0].h = h; // freed with the ingest state
+    if (fseeko(d->f, (off_t)lo, SEEK_SET) != 0 || fread(h, 1, want, d->f) != want)
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "read error on %s", b->path.c_str());
+    size_t consumed = 0;
+    uint64_t total = 0;
+    if (!bgzf_split(h, want, &d->shard_blocks, &consumed, &total, &err))
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: %s", b->path.c_str(), err.c_str());
+    if (d->last_shard && consumed != want)
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated BGZF block at end of file", b->path.c_str());
+    const size_t n_blk = d->shard_blocks.size();
+    d->blk_start.resize(n_blk);
+    d->u_hi = total;
+    bool hit = d->last_shard;
+    for (size_t k = 0; k < n_blk; k++) {
+        const uint64_t start = lo + (k ? d->shard_blocks[k - 1].in_off + d->shard_blocks[k - 1].in_len + 8 : 0);
+        d->blk_start[k] = start;
+        if (start == hi) {
+            d->u_hi = d->shard_blocks[k].out_off;
+            hit = true;
+        }
+    }
+    if (!hit && !(n_blk && lo + consumed == hi))
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: the BGZF block chain from offset %llu does not reach the shard boundary at %llu",
+                             b->path.c_str(), (unsigned long long)lo, (unsigned long long)hi);
+    hipStream_t st = c->stream;
+    d->raw_cap = total + 64;
+    d->raw_len = total;
+    BHIP(d->d_raw.reserve(d->raw_cap));
+    if (n_blk) {
+        BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
+        BHIP(d->d_blocks.reserve(n_blk));
+        BHIP(d->d_status.reserve(n_blk));
+        BHIP(hipMemcpyAsync(d->d_comp.p, h, consumed, hipMemcpyHostToDevice, st));
+        BHIP(hipMemsetAsync(d->d_comp.p + consumed, 0, INFLATE_IN_SLACK, st));
+        BHIP(hipMemcpyAsync(d->d_blocks.p, d->shard_blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
+        BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, true, st));
+        d->status.resize(n_blk);
+        BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        BHIP(hipStreamSynchronize(st));
+        for (size_t k = 0; k < n_blk; k++)
+            if (d->status[k] != INF_OK)
+                return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: BGZF block at offset %llu: %s", b->path.c_str(),
+                                     (unsigned long long)d->blk_start[k], inflate_status_text(d->status[k]));
+    }
+    BHIP(d->d_small.reserve(16));
+    // the first record: known for shard 0 (behind the header), assumed elsewhere -- the first candidate chain
+    if (shard == 0) {
+        if (b->header_bytes > total) return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: the BAM header is larger than the first shard", b->path.c_str());
+        d->entry = b->header_bytes;
+    } else {
+        const uint32_t n_seg = (uint32_t)((d->raw_len + REC_SEGMENT - 1) / REC_SEGMENT);
+        d->entry = d->raw_len;
+        if (n_seg) {
+            BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
+            BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, 0, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+            d->cand.resize((size_t)n_seg * REC_CANDIDATES);
+            BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
+            BHIP(hipStreamSynchronize(st));
+            for (const RecCandidate &x : d->cand)
+                if (x.valid) {
+                    d->entry = x.start;
+                    break;
+                }
+        }
+    }
+    // the host side of this handle is done: release its buffers
+    std::vector<uint8_t>().swap(b->comp);
+    std::vector<uint8_t>().swap(b->data);
+    return shard_index(b, d, out);
+}
+
+extern "C" int ngsq_bam_shard_commit(ngsq_bam *b, uint64_t begin_voffset, uint64_t first_record_index, ngsq_bam_shard_info *out) {
+    if (!b || !b->dev || !b->dev->sharded || !out) return ngsq_bam_fail(NGSQ_ERR_STATE, "ngsq_bam_shard_prepare first");
+    DeviceIngest *d = b->dev;
+    BHIP(hipSetDevice(d->ctx->device));
+    uint64_t entry = d->entry;
+    if (begin_voffset && !voffset_to_raw(d, begin_voffset, &entry))
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: virtual offset %llu is not inside this shard", b->path.c_str(),
+                             (unsigned long long)begin_voffset);
+    if (entry != d->entry) { // the assumed first record was not the real one: index again from the confirmed start
+        d->entry = entry;
+        const int rc = shard_index(b, d, out);
+        if (rc) return rc;
+    } else {
+        out->n_records = d->own;
+        out->begin_voffset = raw_to_voffset(d, d->entry);
+        uint64_t next = d->tail_off;
+        if (d->own < d->n_all) {
+            BHIP(hipMemcpy(&next, d->d_rec_off.p + d->own, sizeof next, hipMemcpyDeviceToHost));
+        }
+        if (d->entry >= d->u_hi) next = d->entry;
+        out->end_voffset = d->last_shard ? 0 : raw_to_voffset(d, next);
+    }
+    d->base_index = first_record_index;
+    b->n_read = first_record_index;
+    d->committed = true;
+    d->file_done = true; // nothing more to load: the batches come from the resident shard
+    return NGSQ_OK;
+}
+
+extern "C" {
+
 int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, ngsq_batch *out) {
     if (!b || !c || !out) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
     if (b->host_mode) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: this reader is in host ingest mode", b->path.c_str());
@@ -344,6 +606,8 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     out->first_record_index = b->n_read;
     BHIP(hipSetDevice(c->device));
     DeviceIngest *d = b->dev;
+    if (d && d->sharded && !d->committed)
+        return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: ngsq_bam_shard_commit before the first batch", b->path.c_str());
     if (!d) {
         d = new DeviceIngest();
         d->ctx = c;
@@ -368,9 +632,9 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     hipStream_t st = c->stream;
     while (d->cursor == d->n_rec) {
         if (d->file_done) {
-            if (d->tail_off != d->raw_len)
+            if (!d->sharded && d->tail_off != d->raw_len)
                 return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated record", b->path.c_str());
-            return NGSQ_OK; // clean end of file
+            return NGSQ_OK; // clean end of file (of the shard)
         }
         const int rc = load_chunk(b, d);
         if (rc) return rc;

@@ -67,6 +67,8 @@ hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start,
                            hipStream_t s);
 hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_seg, const uint64_t *seg_entry,
                               const uint64_t *seg_base, uint64_t *rec_off, unsigned long long *bad, hipStream_t s);
+// out[0] = number of entries of the ascending array a[0, n) that are < value (one thread)
+hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value, unsigned long long *out, hipStream_t s);
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c,
                             unsigned long long *stats, hipStream_t s);
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,

@@ -146,6 +146,10 @@ FEATURES_FIELDS = [
 ROLE_FIVE_PRIME_UTR, ROLE_THREE_PRIME_UTR, ROLE_CODING_SEQUENCE, ROLE_EXON, ROLE_GENE = range(5)
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("begin_voffset", C.c_uint64), ("end_voffset", C.c_uint64)]
+
+
 class FeaturesMetrics(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in FEATURES_FIELDS]
 
@@ -255,6 +259,8 @@ PROTOTYPES = {
     "ngsq_bam_next_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(Batch)]),
     "ngsq_bam_records_read": (C.c_uint64, [C.c_void_p]),
     "ngsq_bam_next_batch_device": (C.c_int, [C.c_void_p, ctx_p, C.c_uint64, C.POINTER(Batch)]),
+    "ngsq_bam_shard_prepare": (C.c_int, [C.c_void_p, ctx_p, C.c_uint32, C.c_uint32, C.POINTER(ShardInfo)]),
+    "ngsq_bam_shard_commit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(ShardInfo)]),
     "ngsq_bgzf_inflate_device": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_int]),
     "ngsq_synth_fill_device": (
         C.c_int, [ctx_p, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),

@@ -214,3 +214,40 @@ def allreduce_blocks_cpu(blocks: Sequence[np.ndarray], dist, torch) -> List[np.n
         dist.all_reduce(t)
         out.append(t.numpy().view(b.dtype))
     return out
+
+
+# ---- one BAM file, several GPUs (include/ngsq_bam.h "sharded device ingest") ---------------------
+def open_file_shard(lib, ctx, path: str, rank: int, world: int, dist, torch, coll_device="cpu", threads: int = 2):
+    """Open shard `rank` of `world` of a BAM file on the context's GPU and agree with the other ranks on
+    the record boundaries: every rank inflates + indexes its BGZF block range (the shard stays resident
+    in HBM), assuming the first plausible record chain; the ranks all-gather (records, assumed begin,
+    found end) and a rank whose assumed begin differs from its predecessor's end re-indexes from there
+    (repeated until stable: a corrected rank reports a new end).  Returns (bam handle, ffi.ShardInfo);
+    batches then come from lib.ngsq_bam_next_batch_device(handle, ctx, ...), numbered from the records
+    of the shards in front (first_record_index is shard-invariant).  Close with ngsq_bam_close."""
+    import ctypes as C
+
+    from . import ffi
+
+    h = C.c_void_p()
+    if lib.ngsq_bam_open(path.encode(), threads, C.byref(h)) != 0:
+        raise RuntimeError(lib.ngsq_bam_last_error().decode())
+    info = ffi.ShardInfo()
+    if lib.ngsq_bam_shard_prepare(h, ctx, rank, world, C.byref(info)) != 0:
+        raise RuntimeError(lib.ngsq_bam_last_error().decode())
+    begin = 0  # keep the assumption
+    for _ in range(world + 1):
+        rows = _all_gather_ints([int(info.n_records), int(info.begin_voffset), int(info.end_voffset)], dist, torch,
+                                coll_device)
+        # shard k+1 must begin where shard k's record chain ends; shards without a record start pass it on
+        want = [rows[0][1]]
+        for k in range(1, world):
+            want.append(rows[k - 1][2] if rows[k - 1][2] else rows[k][1])
+        stable = all(want[k] == rows[k][1] for k in range(world))
+        first = sum(rows[k][0] for k in range(rank))
+        begin = want[rank] if want[rank] != rows[rank][1] else 0
+        if lib.ngsq_bam_shard_commit(h, begin, first, C.byref(info)) != 0:
+            raise RuntimeError(lib.ngsq_bam_last_error().decode())
+        if stable:
+            return h, info
+    raise RuntimeError("shard boundaries did not settle")

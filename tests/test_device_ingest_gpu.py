@@ -264,3 +264,155 @@ def test_device_reader_empty_bam(gpu_lib, ctx, tmp_path):
     bamio.write_bam(p, random_batch(np.random.default_rng(0), 0, [100]), ["chr1"], [100])
     batches, n = read_all_device(gpu_lib, ctx, p, 100)
     assert batches == [] and n == 0
+
+
+# ---- one BAM file, three ranks (sharded device ingest + owner-computes teardown) -----------------
+def _file_shard_worker(rank, world, port, q, bam, writer):
+    try:
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch
+        import torch.distributed as dist
+        from ngs_amd import ffi as F, host as H, shard
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        lib = F.load_library()
+        ref_len = [3_000_000, 3_000_000] if writer == "synth" else [50_000, 7_000]
+        names = ["chr1", "chr2"]
+        kw = dict(facets=F.FACETS_DEFAULT, bin_size=50_000, max_read_len=1024, gc_seed=5)
+
+        def whole_file():
+            c = H.QcContext(ref_len, device=0, lib=lib, **kw)
+            h = C.c_void_p()
+            assert lib.ngsq_bam_open(bam.encode(), 2, C.byref(h)) == 0
+            n = 0
+            while True:
+                b = F.Batch()
+                assert lib.ngsq_bam_next_batch_device(h, c._ctx, 20_000, C.byref(b)) == 0, lib.ngsq_bam_last_error()
+                if b.n_records == 0:
+                    break
+                n += b.n_records
+                assert lib.ngsq_process_batch(c._ctx, C.byref(b), F.PASS_BOTH) == 0
+            lib.ngsq_bam_close(h)
+            c.finalize()
+            r = c.results(names)
+            c.close()
+            return r, n
+
+        want, n_total = whole_file() if rank == 0 else (None, None)
+        ctx = H.QcContext(ref_len, device=0, lib=lib, **kw)
+        views = shard.device_views(ctx, torch, 0)
+        h, info = shard.open_file_shard(lib, ctx._ctx, bam, rank, world, dist, torch, coll_device="cpu")
+        mine = 0
+        first_seen = None
+        while True:
+            b = F.Batch()
+            assert lib.ngsq_bam_next_batch_device(h, ctx._ctx, 7_000, C.byref(b)) == 0, lib.ngsq_bam_last_error()
+            if b.n_records == 0:
+                break
+            if first_seen is None:
+                first_seen = int(b.first_record_index)
+            mine += int(b.n_records)
+            assert lib.ngsq_process_batch(ctx._ctx, C.byref(b), F.PASS_BOTH) == 0, lib.ngsq_last_error(ctx._ctx)
+        assert mine == info.n_records
+        lib.ngsq_bam_close(h)
+        counts = [None] * world
+        dist.all_gather_object(counts, (mine, first_seen))
+        if rank == 0:
+            assert sum(c for c, _ in counts) == n_total, (counts, n_total)
+            run = 0
+            for c, f in counts:   # first_record_index continues across the shards
+                assert f is None or f == run
+                run += c
+        shard.owner_teardown(ctx, dist, torch, views, coll_device="cpu")
+        ctx.finalize()
+        got = ctx.results(names)
+        if rank == 0:
+            from tests.util import json_equal as jeq
+            jeq(got, want)
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("writer", ["synth", "straddling"])
+def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer):
+    """Each rank ingests its BGZF block range of the same file; record boundaries at the shard edges are
+    agreed by exchange; results equal the single-reader run.  "straddling": a file whose records cross
+    every block boundary, so no shard starts at a record start."""
+    import multiprocessing as mp
+    import socket
+    bam = str(tmp_path / "f.bam")
+    if writer == "synth":
+        cfg = host.synth_config(120_000, mode=ffi.SYNTH_MIXED, ref_len=3_000_000)
+        assert gpu_lib.ngsq_synth_write_bam(C.byref(cfg), bam.encode(), 120_000, 6, 4) == 0
+    else:
+        rng = np.random.default_rng(23)
+        hb = random_batch(rng, 9000, [50_000, 7_000], max_len=200, weird=False)
+        c = hb.cols
+        c["flag"] &= np.uint16(0xFFFF ^ 0x1)
+        bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=3000)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_file_shard_worker, args=(r, 3, port, q, bam, writer)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_shard_prepare_commit_api(gpu_lib, ctx, tmp_path):
+    """Neighbouring shards agree on the record at their boundary; a confirmed begin that differs from
+    the assumed one re-indexes the shard (here: pushed to the next shard's first record, so the shard
+    keeps no record and only passes the chain through)."""
+    rng = np.random.default_rng(29)
+    hb = random_batch(rng, 8000, [50_000, 7_000], max_len=180, weird=False)
+    bam = str(tmp_path / "p.bam")
+    bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=2500)
+
+    def prepare(shard, n):
+        h = C.c_void_p()
+        assert gpu_lib.ngsq_bam_open(bam.encode(), 1, C.byref(h)) == 0
+        info = ffi.ShardInfo()
+        assert gpu_lib.ngsq_bam_shard_prepare(h, ctx._ctx, shard, n, C.byref(info)) == 0, gpu_lib.ngsq_bam_last_error()
+        return h, info
+
+    for n in (2, 5):
+        parts = [prepare(k, n) for k in range(n)]
+        assert sum(i.n_records for _, i in parts) == hb.n
+        for k in range(n - 1):
+            assert parts[k][1].end_voffset == parts[k + 1][1].begin_voffset != 0
+        assert parts[-1][1].end_voffset == 0
+        # batches before commit are refused
+        b = ffi.Batch()
+        assert gpu_lib.ngsq_bam_next_batch_device(parts[1][0], ctx._ctx, 10, C.byref(b)) == ffi.ERR_STATE
+        # move shard 1's begin to the first record of shard 2 (n = 5): nothing left in shard 1
+        if n == 5:
+            h1, i1 = parts[1]
+            moved = ffi.ShardInfo()
+            assert gpu_lib.ngsq_bam_shard_commit(h1, i1.end_voffset, 123, C.byref(moved)) == 0, gpu_lib.ngsq_bam_last_error()
+            assert moved.n_records == 0 and moved.begin_voffset == i1.end_voffset == moved.end_voffset
+            assert gpu_lib.ngsq_bam_next_batch_device(h1, ctx._ctx, 10, C.byref(b)) == 0 and b.n_records == 0
+            # and back: the original begin gives the original shard, numbered from the given index
+            assert gpu_lib.ngsq_bam_shard_commit(h1, i1.begin_voffset, 1000, C.byref(moved)) == 0
+            assert moved.n_records == i1.n_records and moved.end_voffset == i1.end_voffset
+            assert gpu_lib.ngsq_bam_next_batch_device(h1, ctx._ctx, 10, C.byref(b)) == 0
+            assert b.n_records == 10 and b.first_record_index == 1000
+            bad = ffi.ShardInfo()
+            assert gpu_lib.ngsq_bam_shard_commit(h1, (1 << 40) | 5, 0, C.byref(bad)) != 0   # not a block of this shard
+        for h, _ in parts:
+            gpu_lib.ngsq_bam_close(h)
