@@ -669,12 +669,18 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ ou
     const uint32_t v0 = lane * S, v1 = v0 + S;
     const uint32_t a = v0 > pad ? v0 - pad : 0u, b = v1 > pad ? v1 - pad : 0u;
     uint32_t c = (a == 0 && b > 0) ? 0xFFFFFFFFu : 0u;
+    // 64 bytes per step into registers: every lane walks its own slice, so with narrower loads a cache line
+    // would be fetched again for each of them (the 64 lanes' lines of a step do not fit the vector cache)
     uint32_t i = a;
-    for (; i < b && ((reinterpret_cast<uintptr_t>(p + i)) & 3u); i++) c = s_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
-    for (; i + 4 <= b; i += 4) {
-        c ^= *reinterpret_cast<const uint32_t *>(p + i);
+    for (; i + 64 <= b; i += 64) {
+        uint32_t w[16];
+        __builtin_memcpy(w, p + i, 64);
 #pragma unroll
-        for (int k = 0; k < 4; k++) c = s_tab[c & 0xFFu] ^ (c >> 8);
+        for (int k = 0; k < 16; k++) {
+            c ^= w[k];
+#pragma unroll
+            for (int q = 0; q < 4; q++) c = s_tab[c & 0xFFu] ^ (c >> 8);
+        }
     }
     for (; i < b; i++) c = s_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
     // pairwise combination: after step j the lanes whose low j+1 bits are ones hold 2^(j+1) slices
