@@ -15,9 +15,10 @@
 //    code and its extra bits are already sitting in the lanes at those bit offsets.
 //  * the bit stream lives in SGPRs (four window dwords + four prefetched by scalar loads).
 //  * Huffman tables are built by the 64 lanes (ballot-ranked canonical sort, parallel fill).
-//  * LZ77 matches are copied by the lanes, 64 bytes per step, inside a 32 KiB LDS ring (DEFLATE's
-//    window), so a match never reads HBM; finished 16 KiB pieces leave the ring as coalesced
-//    dword stores.  39 KiB of LDS per wave: four waves per CU, one per SIMD.
+//  * LZ77 matches are copied by the lanes, 64 bytes per step.  The last 8 KiB of output live in an
+//    LDS ring; finished 2 KiB pieces leave it as coalesced dword stores, and a match that reaches
+//    further back than the ring reads its source from HBM (the bytes this wave wrote earlier).
+//    16 KiB of LDS per wave: ten decoders per CU.
 //  * CRC32 of the block (gzip trailer) is verified on request by a second, wide kernel
 //    (k_bgzf_crc: 64 slices per block, combined with GF(2) polynomial multiplication).
 #include <hip/hip_runtime.h>
@@ -58,8 +59,19 @@ __device__ unsigned long long g_inflate_prof[16];
 namespace {
 
 constexpr uint32_t LB = 10, DB = 8; // bits of the primary lookup tables
-constexpr uint32_t RING = 32768, RMASK = RING - 1; // the DEFLATE window
-constexpr uint32_t PIECE = 16384;                  // bytes that leave the ring together
+// The most recent RING bytes of output live in LDS; older ones (already written to HBM) are read back
+// from there when a match reaches that far.  A decoder alone on its SIMD is bound by instruction
+// latency, so decoders per CU matter more than the 1-2 us a far match costs: measured on the synthetic
+// BAM (19 % of the matches reach beyond 4 KiB, 10 % beyond 8 KiB, 2.6 % beyond 16 KiB), kernel time for
+// 1.09 GB: ring 32768 (4 decoders per CU) 67 ms, 16384 (6) 46 ms, 8192 (10) 33 ms, 4096 (13) 29 ms,
+// 2048 (15) 41 ms.  8192 is the default: within 15 % of the best here and less exposed to files whose
+// matches reach further.  (-DNGSQ_INFLATE_RING=... to rebuild with another size, tools/ring_sweep.sh)
+#ifndef NGSQ_INFLATE_RING
+#define NGSQ_INFLATE_RING 8192
+#endif
+constexpr uint32_t RING = NGSQ_INFLATE_RING, RMASK = RING - 1;
+constexpr uint32_t PIECE = RING / 4;  // bytes that leave the ring together
+constexpr uint32_t MAXWIN = RING / 4; // most output one window may produce on the fast path
 
 // table entry: value << 16 | extra_bits << 8 | kind << 5 | code_bits
 constexpr uint32_t K_LIT = 0, K_EOB = 1, K_BASE = 2, K_ESC = 3, K_INVALID = 7;
@@ -311,7 +323,7 @@ struct CrcTable {
         }
     }
 };
-// byte-wise table, read through the vector cache (LDS is full: ring + tables of four waves per CU)
+// byte-wise table (copied to LDS by k_bgzf_crc)
 __constant__ CrcTable c_crc;
 __device__ uint32_t crc_mul(uint32_t a, uint32_t b) { // a * b mod P
     uint32_t p = 0;
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     const uint64_t bit_limit = (uint64_t)(in_mis + in_len) * 8u;
     uint8_t *const gdst = out + blk.out_off;
 
-    // output state: bytes [0, pos) are in the ring (the last 32 KiB of them), [0, flushed) have left for HBM
+    // output state: the last RING bytes of [0, pos) are in the ring, [0, flushed) have left for HBM
     uint32_t pos = 0, flushed = 0, err = INF_OK;
 
     // ring bytes [flushed, flushed + n) -> HBM
@@ -374,6 +386,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         const uint32_t tail0 = head + 4 * body;
         if (tail0 + lane < n) dst[tail0 + lane] = L.ring[(flushed + tail0 + lane) & RMASK];
         flushed += n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // far matches read these bytes back
     };
 
     PROF_DECL;
@@ -555,10 +568,12 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             uint64_t mm = __ballot(on_chain && !is_lit);
             if (__ballot(on_chain && !is_lit && dist > at)) err = INF_BAD_DISTANCE; // sticky; accesses stay in the ring
             // All literals of the window go out in one store BEFORE the matches are copied in stream order (a
-            // match may read what an earlier symbol of this window wrote).  That is safe unless a match reaches
-            // so far back that a later literal of this window lands on its source in the 32 KiB ring.
-            const bool far = __ballot(on_chain && !is_lit && dist + total > RING) != 0;
-            if (__builtin_expect(far, 0)) mm = syms; // strict stream order, literals included
+            // match may read what an earlier symbol of this window wrote).  A source byte is still in the ring,
+            // and untouched by this window's stores, iff its position is >= pos + total - RING; older bytes
+            // have left for HBM (pos - flushed < PIECE at every window start) and are read back from there.
+            const bool strict = total > MAXWIN; // very long output of one window: one symbol at a time
+            const uint32_t bound = pos + total - RING; // (wraps below RING bytes of output: then everything is in the ring)
+            if (__builtin_expect(strict, 0)) mm = syms;
             else if (on_chain && is_lit) L.ring[at & RMASK] = (uint8_t)(E >> 16);
             PROF(4); // literal store
             while (mm) {
@@ -566,12 +581,22 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 mm &= mm - 1;
                 const uint32_t l = __builtin_amdgcn_readlane(olen, m), d = __builtin_amdgcn_readlane(dist, m);
                 const uint32_t o = __builtin_amdgcn_readlane(at, m), from = o - d;
-                if (far && ((__ballot(is_lit) >> m) & 1ull)) { // only on the strict path
-                    if (lane == m) L.ring[o & RMASK] = (uint8_t)(E >> 16);
-                    continue;
+                if (strict) {
+                    while (o - flushed >= PIECE) flush_piece(PIECE);
+                    if ((__ballot(is_lit) >> m) & 1ull) {
+                        if (lane == m) L.ring[o & RMASK] = (uint8_t)(E >> 16);
+                        continue;
+                    }
                 }
-                // the source run [o - d, o) is final: byte i of the match is its byte i mod d
-                if (__builtin_expect(d >= l, 1)) {
+                const bool in_ring = strict ? d <= RING - 512 && (int32_t)(from - (o - (RING - 512))) >= 0
+                                            : pos + total < RING || (int32_t)(from - bound) >= 0;
+                if (__builtin_expect(!in_ring, 0)) {
+                    // far match: the source left the ring (d > l here, no overlap)
+                    const uint8_t *g = gdst + from;
+                    for (uint32_t i = lane; i < l; i += 64)
+                        L.ring[(o + i) & RMASK] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (__builtin_expect(d >= l, 1)) {
+                    // the source run [o - d, o) is final: byte i of the match is its byte i mod d
                     for (uint32_t i = lane; i < l; i += 64) L.ring[(o + i) & RMASK] = L.ring[(from + i) & RMASK];
                 } else {
                     const uint32_t dd = max(d, 1u);
@@ -621,7 +646,11 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                     else if (pos + l > isize) err = INF_OUTPUT_OVERRUN;
                     else {
                         const uint32_t from = pos - dd0;
-                        if (dd0 >= l) {
+                        if (dd0 > RING - 512) { // the source left the ring
+                            const uint8_t *g = gdst + from;
+                            for (uint32_t i = lane; i < l; i += 64)
+                                L.ring[(pos + i) & RMASK] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else if (dd0 >= l) {
                             for (uint32_t i = lane; i < l; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
                         } else {
                             for (uint32_t i = lane; i < l; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dd0) & RMASK];
