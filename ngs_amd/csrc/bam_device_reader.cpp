@@ -112,6 +112,12 @@ struct DeviceIngest {
         std::string err;
     } hc[2];
     int cur = 0; // chunk the consumer takes next
+    // the compressed bytes of a chunk cross PCIe on their own stream as soon as the reader thread has
+    // framed them, i.e. while the GPU works on the previous chunk
+    DevBuf<uint8_t> d_comp_slot[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t h2d_done[2] = {nullptr, nullptr};
+    bool h2d_issued[2] = {false, false};
     std::thread reader;
     std::mutex mu;
     std::condition_variable cv;
@@ -150,6 +156,12 @@ struct DeviceIngest {
         cv.notify_all();
         if (reader.joinable()) reader.join();
         if (f) fclose(f);
+        if (copy_stream) {
+            (void)hipStreamSynchronize(copy_stream);
+            (void)hipStreamDestroy(copy_stream);
+        }
+        for (auto &e : h2d_done)
+            if (e) (void)hipEventDestroy(e);
         for (auto &c : hc)
             if (c.h) (void)hipHostFree(c.h);
     }
@@ -193,7 +205,7 @@ void reader_main(DeviceIngest *d, std::string path) {
             // (~7 GB/s) would be slower than the GPU inflates
             const size_t want = cap - c.fill;
             const int fd = fileno(d->f);
-            constexpr int NT = 8;
+            constexpr int NT = 16;
             size_t got_part[NT] = {};
             bool bad_part[NT] = {};
             const size_t per = (want + NT - 1) / NT;
@@ -240,6 +252,18 @@ void reader_main(DeviceIngest *d, std::string path) {
         }
         c.last = !c.err.empty() || (eof && leftover.empty());
         const bool last = c.last;
+        // start the host-to-device copy right away, on the copy stream: it overlaps whatever the GPU is
+        // doing for the previous chunk (its device buffer is free: the consumer released this slot only
+        // after the kernels that read it had finished)
+        d->h2d_issued[k] = false;
+        if (c.err.empty() && !c.blocks.empty() && d->copy_stream) {
+            bool ok = hipSetDevice(d->ctx->device) == hipSuccess &&
+                      d->d_comp_slot[k].reserve(c.consumed + INFLATE_IN_SLACK) == hipSuccess &&
+                      hipMemcpyAsync(d->d_comp_slot[k].p, c.h, c.consumed, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess &&
+                      hipMemsetAsync(d->d_comp_slot[k].p + c.consumed, 0, INFLATE_IN_SLACK, d->copy_stream) == hipSuccess &&
+                      hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
+            d->h2d_issued[k] = ok; // on failure the consumer copies on its own stream (and reports errors)
+        }
         {
             std::lock_guard<std::mutex> g(d->mu);
             c.ready = true;
@@ -309,6 +333,8 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
 int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     hipStream_t st = d->ctx->stream;
     const double t0 = now_ms();
+    static thread_local double last_end = 0;
+    const double batches_ms = last_end ? t0 - last_end : 0.0; // time the caller spent on the previous chunk's batches
     // ---- 1. keep the cut record at the end of the previous chunk
     const uint64_t carry = d->raw_len - d->tail_off;
     if (carry > CARRY_MAX || carry + REC_SEGMENT > d->raw_cap)
@@ -324,7 +350,8 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         }
     }
     // ---- 2. the next framed chunk from the reader thread
-    DeviceIngest::HostChunk &c = d->hc[d->cur];
+    const int slot = d->cur;
+    DeviceIngest::HostChunk &c = d->hc[slot];
     {
         std::unique_lock<std::mutex> g(d->mu);
         d->cv.wait(g, [&] { return c.ready; });
@@ -336,13 +363,17 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     // ---- 3. inflate
     for (auto &bl : c.blocks) bl.out_off += carry;
     if (n_blk) {
-        BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
         BHIP(d->d_blocks.reserve(n_blk));
         BHIP(d->d_status.reserve(n_blk));
-        BHIP(hipMemcpyAsync(d->d_comp.p, c.h, consumed, hipMemcpyHostToDevice, st));
-        BHIP(hipMemsetAsync(d->d_comp.p + consumed, 0, INFLATE_IN_SLACK, st));
+        if (d->h2d_issued[slot]) { // already on its way (prefetch_h2d)
+            BHIP(hipStreamWaitEvent(st, d->h2d_done[slot], 0));
+        } else {
+            BHIP(d->d_comp_slot[slot].reserve(consumed + INFLATE_IN_SLACK));
+            BHIP(hipMemcpyAsync(d->d_comp_slot[slot].p, c.h, consumed, hipMemcpyHostToDevice, st));
+            BHIP(hipMemsetAsync(d->d_comp_slot[slot].p + consumed, 0, INFLATE_IN_SLACK, st));
+        }
         BHIP(hipMemcpyAsync(d->d_blocks.p, c.blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
-        BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, true, st));
+        BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, true, st));
         d->status.resize(n_blk);
         BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         BHIP(hipStreamSynchronize(st));
@@ -354,6 +385,7 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     }
     // the pinned buffer goes back to the reader thread
     d->file_done = c.last;
+    d->h2d_issued[slot] = false;
     {
         std::lock_guard<std::mutex> g(d->mu);
         c.ready = false;
@@ -380,9 +412,10 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     }
     d->n_rec = total_rec;
     if (trace_on())
-        fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | wait for reader %.1f ms, "
-                        "h2d+inflate %.1f ms, index %.1f ms\n",
-                n_blk, consumed / 1e6, total / 1e6, (unsigned long long)total_rec, t1 - t0, t3 - t1, now_ms() - t3);
+        fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | batches of the previous chunk %.1f ms, "
+                        "wait for reader %.1f ms, inflate %.1f ms, index %.1f ms\n",
+                n_blk, consumed / 1e6, total / 1e6, (unsigned long long)total_rec, batches_ms, t1 - t0, t3 - t1, now_ms() - t3);
+    last_end = now_ms();
     return NGSQ_OK;
 }
 
@@ -655,6 +688,8 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         b->dev_free = free_ingest;
         for (auto &c : d->hc) BHIP(hipHostMalloc((void **)&c.h, 2 * d->comp_chunk, hipHostMallocDefault));
         BHIP(d->d_raw.reserve(d->raw_cap + 64));
+        BHIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+        for (auto &e : d->h2d_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         d->reader = std::thread(reader_main, d, b->path);
         // the host side of this handle is done: release its buffers
         std::vector<uint8_t>().swap(b->comp);
