@@ -59,6 +59,12 @@ def payloads():
     yield "runs", b"".join(bytes([i & 255]) * (1 + (i * 7) % 300) for i in range(2000))
     yield "one", b"x"
     yield "empty", b""
+    # far matches: repeats 20 KiB and 31 KiB back (sources that have left the decoder's LDS ring)
+    blk = rng.integers(0, 256, 20_000, dtype=np.uint8).tobytes()
+    yield "far20k", blk + blk + blk[:15_000]
+    blk = rng.integers(0, 256, 31_000, dtype=np.uint8).tobytes()
+    yield "far31k", blk + blk + b"tail" * 100
+    yield "far_mixed", b"".join(blk[i:i + 700] + bytes(rng.integers(0, 4, 300, dtype=np.uint8)) for i in range(0, 30_000, 700)) * 2
     # long codes: a very skewed alphabet forces 15-bit Huffman codes
     w = np.array([2.0 ** -(i // 8) for i in range(256)])
     yield "longcodes", rng.choice(np.arange(256, dtype=np.uint8), 400_000, p=w / w.sum()).tobytes()
