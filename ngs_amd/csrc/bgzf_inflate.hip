@@ -605,7 +605,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 PROF_COUNT(2, 1);
                 PROF_COUNT(3, l);
                 PROF_COUNT(4, d > 4096 ? 1 : 0);
-                PROF_COUNT(6, d > 8192 ? 1 : 0);
                 PROF_COUNT(7, d > 16384 ? 1 : 0);
             }
             pos += total;
@@ -615,9 +614,13 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 break;
             }
             PROF(5); // matches
-            if (s < 64 && err == INF_OK) {
-                // The chain stopped at a symbol the lanes could not finish: end of block, a long code, a
-                // distance code beyond lane 63, or an invalid code.  One symbol the plain way.
+            // A chain that stopped at a length code whose distance code lies beyond lane 63 just ends the
+            // window there: the next window starts at that length code and sees all of the match.
+            const bool resume = s > 0 && s < 64 && ((__builtin_amdgcn_readlane(E, s & 63u) >> 5) & 7u) == K_BASE;
+            if (s < 64 && !resume && err == INF_OK) {
+                // The chain stopped at a symbol the lanes could not finish: end of block, a long code (or a
+                // distance code with one), or an invalid code.  One symbol the plain way.
+                PROF_COUNT(6, 1);
                 br.sync();
                 const uint32_t x0 = br.bits32();
                 uint32_t e = uni(L.lit_tab[x0 & ((1u << LB) - 1u)]);
@@ -747,9 +750,9 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         for (int k = 0; k < 8; k++) tot += h[k];
         for (int k = 0; k < 8; k++)
             fprintf(stderr, "[inflate-prof] %-24s %6.2f %%\n", names[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
-        fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, matches %llu (bytes %llu; distance > 4 KiB %llu, > 8 KiB %llu, "
-                        "> 16 KiB %llu), long codes %llu\n",
-                h[8], h[9], h[10], h[11], h[12], h[14], h[15], h[13]);
+        fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, matches %llu (bytes %llu; distance > 4 KiB %llu, > 16 KiB %llu), "
+                        "long codes %llu, symbols taken the plain way %llu\n",
+                h[8], h[9], h[10], h[11], h[12], h[15], h[13], h[14]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_prof), z, sizeof z);
     }
