@@ -40,7 +40,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
 
 // ---- BAM record parse (csrc/bam_device.hip) -------------------------------------------------------
 constexpr uint64_t REC_SEGMENT = 65536;  // bytes of the inflated stream walked by one lane / wave
-constexpr uint32_t REC_CANDIDATES = 4;   // chain starts kept per segment
+constexpr uint32_t REC_CANDIDATES = 2;   // chain starts kept per segment (the walks are serial: each one costs)
 
 struct RecCandidate {
     uint64_t start;   // offset of a plausible record start inside the segment
