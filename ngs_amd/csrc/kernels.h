@@ -140,6 +140,9 @@ struct FeatureTables {
 };
 hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const FeatureTables &ft,
                            hipStream_t s);
+// Quality Score for the offsets layout with max_read_len <= 320 (qual_kernel.hip)
+bool qual_ragged_supported(const DeviceState &st, const DeviceBatch &b);
+hipError_t launch_qual_ragged(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s);
 // Edits process (edits.rs:217-303)
 hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                         hipStream_t s);

@@ -364,6 +364,7 @@ hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const Device
         }
         return launch_qual_window(li, st, b, (uint32_t)nrot, s);
     }
+    if (qual_ragged_supported(st, b)) return launch_qual_ragged(li, st, b, s);
     uint32_t rows = b.qual_off ? st.max_read_len : b.qual_stride;
     if (rows > st.max_read_len) rows = st.max_read_len;
     if (rows > QUAL_LDS_MAX_ROWS) rows = QUAL_LDS_MAX_ROWS;

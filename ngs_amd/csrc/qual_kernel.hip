@@ -184,6 +184,200 @@ __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_qual_ragged: the offsets layout (reads of different lengths packed back to back).
+// Same window-per-lane tally as k_qual_win, but the (record, window) of a lane comes from a
+// per-wave schedule: a wave takes 64 records, prefix-sums their window counts (DPP), and for every
+// batch of 64 consecutive windows each lane finds its record by a six-step binary search over the
+// prefix held across the lanes (ds_bpermute, no LDS memory).  Consecutive lanes therefore still read
+// consecutive 16-byte pieces of the byte stream.  The last window of a record (fewer than 16 bytes)
+// and windows with a score >= 64 take the exact path.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t qr_wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31
+    return v;
+}
+__device__ __forceinline__ uint32_t qr_from_lane(uint32_t v, uint32_t src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+
+template <uint32_t R, uint32_t NROT>
+__global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint8_t *__restrict__ qual,
+                                                      const uint64_t *__restrict__ qual_off, uint64_t n_rec) {
+    constexpr uint32_t RP = qw_rp(R), CP = qw_cp(R), CP4 = CP * 4, RP4 = RP * 4;
+    constexpr uint32_t S4 = 4u * RP4;
+    extern __shared__ uint32_t s_q[]; // QUAL_BINS x CP words: the only LDS object
+    constexpr uint32_t nb = QUAL_BINS * CP;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_q[i] = 0;
+    __syncthreads();
+    char *const tab = reinterpret_cast<char *>(s_q);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t per = (n_rec + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = min(per * blockIdx.x, n_rec), hi = min(lo + per, n_rec);
+    const uint64_t end_bytes = n_rec ? qual_off[n_rec] : 0; // a 16-byte load must not run past this
+    uint32_t bad = 0, too_long = 0;
+
+    for (uint64_t i0 = lo + 64ull * wave; i0 < hi; i0 += 64ull * 16) {
+        // this wave's 64 records: offset, length (clamped to the table), windows
+        const uint64_t rec = i0 + lane;
+        uint64_t off = 0;
+        uint32_t len = 0;
+        if (rec < hi) {
+            off = qual_off[rec];
+            const uint64_t l64 = qual_off[rec + 1] - off;
+            len = (uint32_t)min(l64, (uint64_t)st.max_read_len);
+            too_long += l64 > st.max_read_len; // quality_scores.rs: the table is sized for max_read_len
+        }
+        // pass A: the whole 16-byte windows of the 64 records, 64 consecutive windows per step
+        const uint32_t nwin = len >> 4;
+        const uint32_t P = qr_wave_inclusive_sum(nwin); // whole windows of records 0..lane
+        const uint32_t T = __builtin_amdgcn_readlane(P, 63);
+        const uint32_t off_lo = (uint32_t)off, off_hi = (uint32_t)(off >> 32);
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const bool active = t < T;
+            // record of window t: the first lane whose inclusive prefix exceeds t
+            uint32_t a = 0, b = 63;
+#pragma unroll
+            for (int step = 0; step < 6; step++) {
+                const uint32_t mid = (a + b) >> 1;
+                const bool right = qr_from_lane(P, mid) <= t;
+                a = right ? mid + 1 : a;
+                b = right ? b : mid;
+            }
+            const uint32_t r = min(a, 63u);
+            const uint32_t before = qr_from_lane(P, r) - qr_from_lane(nwin, r);
+            const uint32_t w = t - before;
+            const uint32_t rl = qr_from_lane(len, r);
+            const uint64_t ro = ((uint64_t)qr_from_lane(off_hi, r) << 32) | qr_from_lane(off_lo, r);
+            if (!active) continue;
+            (void)rl;
+            const uint64_t at = ro + 16ull * w;
+            constexpr uint32_t nvalid = 16u;
+            uint32_t ww[4];
+            {
+                uint4 v;
+                __builtin_memcpy(&v, qual + at, 16); // a whole window of the record: inside the buffer
+                ww[0] = v.x, ww[1] = v.y, ww[2] = v.z, ww[3] = v.w;
+            }
+            const uint32_t any = (ww[0] | ww[1] | ww[2] | ww[3]) & 0xC0C0C0C0u;
+            if (__builtin_expect(any == 0u, 1)) {
+                const uint32_t wbase = 4u * w, rot = r & 3u;
+                uint32_t x[4], bd[4];
+                if (NROT == 1) {
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++) {
+                        x[d] = ww[d];
+                        bd[d] = wbase + d * S4;
+                    }
+                } else {
+                    const bool r1 = rot & 1u, r2 = (NROT == 4) && (rot & 2u);
+                    const uint32_t y0 = r2 ? ww[2] : ww[0], y1 = r2 ? ww[3] : ww[1], y2 = r2 ? ww[0] : ww[2],
+                                   y3 = r2 ? ww[1] : ww[3];
+                    x[0] = r1 ? y1 : y0;
+                    x[1] = r1 ? y0 : y1;
+                    x[2] = r1 ? y3 : y2;
+                    x[3] = r1 ? y2 : y3;
+                    const uint32_t h = r2 ? 2u * S4 : 0u, l = r1 ? S4 : 0u;
+                    bd[0] = wbase + h + l;
+                    bd[1] = wbase + h + (S4 - l);
+                    bd[2] = wbase + (2u * S4 - h) + l;
+                    bd[3] = wbase + (2u * S4 - h) + (S4 - l);
+                }
+#pragma unroll
+                for (uint32_t d = 0; d < 4; d++) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t q = (x[d] >> (8 * k)) & 0xFFu;
+                        atomicAdd(reinterpret_cast<uint32_t *>(tab + (__umul24(q, CP4) + bd[d]) + k * RP4), 1u);
+                    }
+                }
+            } else {
+                // every byte is a score in this layout: 94..255 are decode errors
+                for (uint32_t j = 0; j < nvalid; j++) {
+                    const uint32_t q = (ww[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                    if (q <= NGSQ_MAX_SCORE)
+                        atomicAdd(reinterpret_cast<uint32_t *>(tab + q * CP4 + 4u * w + j * RP4), 1u);
+                    else
+                        bad += 1;
+                }
+            }
+        }
+        // pass B: the last, partial window of every record (lane = record): all lanes walk their bytes
+        // together instead of a few lanes of every step above
+        const uint32_t tail = len & 15u, wl = len >> 4;
+        if (tail) {
+            const uint64_t at = off + 16ull * wl;
+            uint32_t ww[4] = {0, 0, 0, 0};
+            if (at + 16 <= end_bytes) {
+                uint4 v;
+                __builtin_memcpy(&v, qual + at, 16); // the bytes behind the record are the next record's: ignored
+                ww[0] = v.x, ww[1] = v.y, ww[2] = v.z, ww[3] = v.w;
+            } else {
+                for (uint32_t k = 0; k < tail; k++) ww[k >> 2] |= (uint32_t)qual[at + k] << (8 * (k & 3));
+            }
+            for (uint32_t j = 0; j < tail; j++) {
+                const uint32_t q = (ww[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                if (q <= NGSQ_MAX_SCORE)
+                    atomicAdd(reinterpret_cast<uint32_t *>(tab + q * CP4 + 4u * wl + j * RP4), 1u);
+                else
+                    bad += 1;
+            }
+        }
+    }
+    __syncthreads();
+    // flush the cells of real cycles: cycle c = 16 w + kb < max_read_len
+    const uint32_t n_out = min(st.max_read_len, 16u * R) * QUAL_BINS;
+    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) {
+        const uint32_t c = i / QUAL_BINS, q = i - c * QUAL_BINS;
+        const uint32_t v = s_q[q * CP + (c & 15u) * RP + (c >> 4)];
+        if (v) atomicAdd(&st.counters[st.off_qual + i], (u64)v);
+    }
+    uint32_t r0 = bad, r1 = too_long;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        r0 += __shfl_down(r0, o, 64);
+        r1 += __shfl_down(r1, o, 64);
+    }
+    if (lane == 0 && r0) atomicAdd(&st.counters[C_ERR + E_BAD_QUAL], (u64)r0);
+    if (lane == 0 && r1) atomicAdd(&st.counters[C_ERR + E_READ_TOO_LONG], (u64)r1);
+}
+
+template <uint32_t R>
+static hipError_t launch_ragged_r(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+    const uint32_t lds = qual_window_lds_bytes(R);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_ragged<R, 4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const uint32_t per_cu = lds <= 78 * 1024 ? 2 : 1;
+    uint64_t g = (b.n + 1023) / 1024;
+    if (g > (uint64_t)li.n_cu * per_cu) g = (uint64_t)li.n_cu * per_cu;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((k_qual_ragged<R, 4>), dim3((uint32_t)g), dim3(1024), lds, s, st, b.qual, b.qual_off, b.n);
+    return hipGetLastError();
+}
+
+bool qual_ragged_supported(const DeviceState &st, const DeviceBatch &b) {
+    return b.qual_off != nullptr && st.max_read_len <= 16 * QUAL_WIN_MAX_R;
+}
+
+hipError_t launch_qual_ragged(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+    const uint32_t R = (st.max_read_len + 15) / 16;
+    if (R <= 5) return launch_ragged_r<5>(li, st, b, s);
+    if (R <= 10) return launch_ragged_r<10>(li, st, b, s);
+    if (R <= 16) return launch_ragged_r<16>(li, st, b, s);
+    return launch_ragged_r<20>(li, st, b, s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_qual_perm: rows of up to 256 bytes (R <= 16 windows).  One VALU operation per byte.
 //
 // LDS table of 64 scores x 4 dword planes x 64 words (64 KiB, two blocks per CU):
