@@ -475,6 +475,10 @@ int find_block_start(FILE *f, uint64_t from, uint64_t file_size, uint64_t *out, 
             return 0;
         }
     }
+    if (from + buf.size() >= file_size) { // `from` lies inside the last block: the next boundary is the end of the file
+        *out = file_size;
+        return 0;
+    }
     *err = "no BGZF block boundary found";
     return -1;
 }
