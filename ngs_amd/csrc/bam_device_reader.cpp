@@ -308,11 +308,9 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
             c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
         }
         total_rec += c->count;
-        if (!c->valid) {
-            cur = d->raw_len;
-            break;
-        }
-        cur = c->landing;
+        // an invalid record ends the chain: the later segments get no entry (k_rec_offsets then reports
+        // the record's index from this segment)
+        cur = c->valid ? c->landing : d->raw_len;
     }
     d->tail_off = std::min(cur, d->raw_len);
     BHIP(d->d_rec_off.reserve(total_rec + 1));
@@ -365,7 +363,7 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     if (n_blk) {
         BHIP(d->d_blocks.reserve(n_blk));
         BHIP(d->d_status.reserve(n_blk));
-        if (d->h2d_issued[slot]) { // already on its way (prefetch_h2d)
+        if (d->h2d_issued[slot]) { // already on its way: the reader thread issued the copy
             BHIP(hipStreamWaitEvent(st, d->h2d_done[slot], 0));
         } else {
             BHIP(d->d_comp_slot[slot].reserve(consumed + INFLATE_IN_SLACK));

@@ -265,6 +265,37 @@ def test_device_reader_errors(gpu_lib, ctx, tmp_path):
     gpu_lib.ngsq_bam_close(h)
 
 
+def test_device_reader_malformed_record(gpu_lib, ctx, tmp_path):
+    """A record whose fields do not fit its block_size is refused by both readers, wherever it sits."""
+    import struct
+    rng = np.random.default_rng(2)
+    hb = random_batch(rng, 1500, [9000], max_len=120, weird=False)
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:9000\n"
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1)
+    head += struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 9000)
+    recs = [bamio.record_bytes(hb, i) for i in range(hb.n)]
+    for victim in (0, 700, 1499):
+        bad = list(recs)
+        r = bytearray(bad[victim])
+        r[4 + 8] = 0                      # l_read_name = 0 (noodles: the read name is never empty)
+        bad[victim] = bytes(r)
+        stream = head + b"".join(bad)
+        p = str(tmp_path / f"bad{victim}.bam")
+        with open(p, "wb") as f:
+            for k in range(0, len(stream), 4000):
+                f.write(bamio.bgzf_block(stream[k:k + 4000]))
+            f.write(bamio.EOF_BLOCK)
+        open(p + ".bai", "wb").write(b"BAI\1" + struct.pack("<i", 1) + struct.pack("<ii", 0, 0))
+        with pytest.raises(RuntimeError, match=f"malformed record {victim}"):
+            read_all_device(gpu_lib, ctx, p, 1 << 20)
+        h = C.c_void_p()
+        assert gpu_lib.ngsq_bam_open(p.encode(), 1, C.byref(h)) == 0
+        b = ffi.Batch()
+        assert gpu_lib.ngsq_bam_next_batch(h, 1 << 20, C.byref(b)) != 0
+        assert f"malformed record {victim}".encode() in gpu_lib.ngsq_bam_last_error()
+        gpu_lib.ngsq_bam_close(h)
+
+
 def test_device_reader_empty_bam(gpu_lib, ctx, tmp_path):
     p = str(tmp_path / "e.bam")
     bamio.write_bam(p, random_batch(np.random.default_rng(0), 0, [100]), ["chr1"], [100])
