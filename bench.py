@@ -51,6 +51,9 @@ def main() -> int:
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP event brackets")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed/RCCL path even with one rank (plumbing check)")
+    ap.add_argument("--coverage", choices=["stream", "array"], default="stream",
+                    help="stream: sorted_input context, Coverage finishes positions while the sorted records stream by; "
+                         "array: difference arrays + teardown scan (any record order)")
     ap.add_argument("--facets", type=lambda x: int(x, 0), default=0x1F,
                     help="facet mask (default 0x1F = all default facets; 0x0E = BASELINE configs[1])")
     args = ap.parse_args()
@@ -94,7 +97,10 @@ def main() -> int:
     scfg = host.synth_config(n * world, mode=ffi.SYNTH_MIXED if mixed else ffi.SYNTH_FIXED,
                              read_len=args.read_len, ref_len=CHR1, n_refs=2)
     ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=local_rank,
-                         max_read_len=max_len, gc_seed=0x4E4753, timing=not args.no_timing, lib=lib)
+                         max_read_len=max_len, gc_seed=0x4E4753, timing=not args.no_timing,
+                         sorted_input=args.coverage == "stream",
+                         # shards behind the first: positions a read of the shard in front may still cover
+                         cov_head_guard=(1 << 20) if rank > 0 else 0, lib=lib)
     t_gen = time.perf_counter()
     db = ctx.synth_device_batch(scfg, rank * n, n)
     t_gen = time.perf_counter() - t_gen
@@ -180,6 +186,8 @@ def main() -> int:
                                                            (8, "Quality Score"), (16, "Coverage")) if args.facets & b_),
                        "sharding": ("contiguous record (BGZF block) ranges; RCCL all-reduce of counters, owner-computes "
                                     "coverage teardown with halo exchange") if world > 1 else "single GPU",
+                       "coverage": ("streamed from the coordinate-sorted records (sorted_input)" if args.coverage == "stream"
+                                    else "difference arrays + teardown scan"),
                        "algorithmic_bytes_per_record": round(algo_rec, 2),
                        "hbm_frac_whole_pass": round(value / world * algo_rec / (HBM_PEAK_GBS * 1e9), 4)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGSQ_ABI_VERSION 2u
+#define NGSQ_ABI_VERSION 3u
 
 /* ---- status codes (reference: anyhow::Result<()> / panic) ---- */
 #define NGSQ_OK 0
@@ -43,6 +43,7 @@ extern "C" {
 #define NGSQ_ERR_STATE (-5)            /* call out of lifecycle order            */
 #define NGSQ_ERR_BUFFER_TOO_SMALL (-6)
 #define NGSQ_ERR_UNSUPPORTED (-7)
+#define NGSQ_ERR_UNSORTED (-8)         /* sorted_input was promised and a record broke the order */
 
 /* ---- facets (names: `name()` of each facet under src/qc/record_based, sequence_based) ---- */
 #define NGSQ_FACET_GENERAL 0x01u         /* "General"          general.rs:23        */
@@ -95,6 +96,14 @@ typedef struct ngsq_config {
                                         NULL entries => sequence not in FASTA               */
     void *stream;           /* optional hipStream_t to launch on; NULL -> library creates one */
     uint32_t timing;        /* 1 -> bracket every kernel with HIP events (ngsq_kernel_timing) */
+    uint32_t sorted_input;  /* 1 -> the caller promises coordinate-sorted records over all batches of this
+                               context (what `ngs qc` requires: a BAI exists only for sorted files,
+                               formats/bam.rs:86-96).  Coverage then finishes positions while it streams
+                               the records instead of keeping a depth array for the teardown; a record that
+                               breaks the promise makes ngsq_finalize fail with NGSQ_ERR_UNSORTED           */
+    uint32_t cov_head_guard; /* sorted_input shards other than the first of a file: number of positions
+                               after this context's first record on a sequence that records of the shard
+                               in front may still cover (kept on the exchanged depth array); 0 = none      */
     uint32_t reserved;
 } ngsq_config;
 
@@ -356,8 +365,11 @@ int ngsq_depth_layout(ngsq_ctx *ctx, uint64_t *n_diff, uint64_t *n_chunks, uint6
 int ngsq_set_scan_range(ngsq_ctx *ctx, uint64_t chunk_lo, uint64_t chunk_hi, uint32_t carry_in);
 int ngsq_teardown(ngsq_ctx *ctx);
 int ngsq_state_teardown(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u64);
+/* sorted_input contexts: one byte per chunk, 1 = Coverage already finished the chunk while streaming
+ * (the teardown skips it; a shard must not receive exchanged entries for such a chunk).  n = 0 otherwise. */
+int ngsq_state_chunk_flags(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u8);
 /* host-visible copies for CPU-side reductions and tests */
-int ngsq_state_download(ngsq_ctx *ctx, int which /*0 counters,1 depth,2 edits,3 teardown*/, void *dst,
+int ngsq_state_download(ngsq_ctx *ctx, int which /*0 counters,1 depth,2 edits,3 teardown,4 chunk flags*/, void *dst,
                         uint64_t n_bytes);
 int ngsq_state_upload(ngsq_ctx *ctx, int which, const void *src, uint64_t n_bytes);
 

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
-SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "synth.hip", "bgzf_inflate.hip",
+SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "cov_stream.hip", "synth.hip", "bgzf_inflate.hip",
            "bam_device.hip", "features_kernel.hip", "context.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
 HEADERS = ["kernels.h", "context.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h",
            "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]

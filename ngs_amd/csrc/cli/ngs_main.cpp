@@ -9,7 +9,9 @@
 // --ingest host|device (default device: the GPU inflates and parses the BAM; runs with -n
 // always ingest on the host).
 // Not built (out of scope this round): the other subcommands.
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -318,6 +320,7 @@ struct Args {
     bool has_n = false, has_out_dir = false, has_prefix = false, has_only = false;
     unsigned long long n = 0;
     int device = 0, threads = 0;
+    int coverage = 0; // --coverage auto|stream|array: 0 auto (stream when @HD says SO:coordinate), 1 stream, 2 array
     bool ingest_device = true; // --ingest host|device: where BGZF inflate + BAM parse run (ngsq_bam_next_batch[_device])
     unsigned long long batch_records = 1ull << 21, gc_seed = 0x4E4753;
 };
@@ -336,7 +339,8 @@ void usage() {
             "      --vaf-file <PATH>           Write the VAF of every covered position (Edits facet, needs -r)\n"
             "      --five-prime-utr-feature-name, --three-prime-utr-feature-name, --coding-sequence-feature-name,\n"
             "      --exon-feature-name, --gene-feature-name <STRING>   accepted for compatibility\n"
-            "      --device <N> --batch-records <N> --threads <N> --gc-seed <N> --ingest host|device   (additive, this build)\n");
+            "      --device <N> --batch-records <N> --threads <N> --gc-seed <N> --ingest host|device   (additive, this build)\n"
+            "      --coverage auto|stream|array   Coverage finished while sorted records stream by / on depth arrays (additive)\n");
 }
 
 #define CHECK(ctx, expr)                                                                                   \
@@ -382,6 +386,14 @@ int main(int argc, char **argv) {
                 return 2;
             }
             a.ingest_device = v == "device";
+        }
+        else if (s == "--coverage") {
+            const std::string v = val("--coverage");
+            if (v != "auto" && v != "stream" && v != "array") {
+                fprintf(stderr, "error: --coverage takes 'auto', 'stream' or 'array'\n");
+                return 2;
+            }
+            a.coverage = v == "auto" ? 0 : v == "stream" ? 1 : 2;
         }
         else if (s == "--batch-records") a.batch_records = strtoull(val("--batch-records").c_str(), nullptr, 10);
         else if (s == "--gc-seed") a.gc_seed = strtoull(val("--gc-seed").c_str(), nullptr, 0);
@@ -507,6 +519,21 @@ int main(int argc, char **argv) {
     cfg.max_read_len = NGSQ_MAX_READ_LEN_LIMIT;
     cfg.gc_seed = a.gc_seed;
     cfg.ref_bases = (facets & NGSQ_FACET_EDITS) ? bases.data() : nullptr;
+    // Coverage while the records stream by (ngsq_config.sorted_input) needs coordinate order.  `ngs qc` only
+    // accepts indexed, i.e. sorted, files (formats/bam.rs:86-96); "auto" takes the header's word for it and
+    // falls back to the depth arrays when a record turns out to break the order.
+    bool header_sorted = false;
+    {
+        uint64_t hl = 0;
+        const char *ht = ngsq_bam_header_text(bam, &hl);
+        const std::string text(ht ? ht : "", ht ? hl : 0);
+        const size_t hd = text.rfind("@HD", 0) == 0 ? 0 : text.find("\n@HD");
+        if (hd != std::string::npos) {
+            const size_t eol = text.find('\n', hd + 1);
+            header_sorted = text.substr(hd, eol == std::string::npos ? std::string::npos : eol - hd).find("SO:coordinate") != std::string::npos;
+        }
+    }
+    cfg.sorted_input = (!a.has_n && (facets & NGSQ_FACET_COVERAGE) && (a.coverage == 1 || (a.coverage == 0 && header_sorted))) ? 1 : 0;
     ngsq_ctx *ctx = nullptr;
     if (ngsq_create(&cfg, &ctx) != NGSQ_OK) bail(ngsq_last_global_error());
     if (facets & NGSQ_FACET_FEATURES) {
@@ -622,7 +649,30 @@ int main(int argc, char **argv) {
     } else {
         logf(2, "No facets specified that require second pass. Skipping...");
     }
-    CHECK(ctx, ngsq_finalize(ctx));
+    {
+        const int rc = ngsq_finalize(ctx);
+        if (rc == NGSQ_ERR_UNSORTED && a.coverage == 0) {
+            // the header promised coordinate order and the records broke it: run again on the depth arrays
+            logf(1, "records are not in coordinate order although the header says so: re-running with --coverage array");
+            ngsq_destroy(ctx);
+            ngsq_bam_close(bam);
+            if (vaf_file) {
+                fclose(vaf_file);
+                unlink(a.vaf.c_str());
+            }
+            std::vector<char *> av(argv, argv + argc);
+            char opt[] = "--coverage", valv[] = "array";
+            av.push_back(opt);
+            av.push_back(valv);
+            av.push_back(nullptr);
+            pid_t pid;
+            if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, av.data(), environ) != 0) bail("could not re-run");
+            int status = 0;
+            waitpid(pid, &status, 0);
+            return WIFEXITED(status) ? WEXITSTATUS(status) : 1;
+        }
+        if (rc != NGSQ_OK) bail(ngsq_last_error(ctx));
+    }
     if (vaf_file && (facets & NGSQ_FACET_EDITS)) {
         // edits.rs:320-341, per sequence in header order: one line per position any record covered; the
         // value is the f32 the histogram bin was taken from, printed as Rust prints it (shortest digits

@@ -43,7 +43,7 @@ static int fail(ngsq_ctx *c, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits", "cov_scan", "edits_vaf", "h2d", "features"};
+static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits", "cov_scan", "edits_vaf", "h2d", "features", "cov_stream"};
 
 extern "C" {
 
@@ -228,6 +228,33 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         CTX_TRY(hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
         st.touched = c->d_touched;
     }
+    c->stream_cov = c->cfg.sorted_input && nd;
+    if (c->stream_cov) {
+        const uint64_t nr4 = round_up(nr ? nr : 1, 4);
+        CTX_TRY(hipMalloc((void **)&c->d_stream_u32, (6 * nr4 + 4) * 4));
+        CTX_TRY(hipMalloc((void **)&c->d_last_key, 8));
+        CTX_TRY(hipMalloc((void **)&c->d_chunk_flags, c->n_chunks ? c->n_chunks : 1));
+        st.end_acc = c->d_stream_u32;
+        st.batch_span = c->d_stream_u32 + 6 * nr4;
+        CovStreamArgs &sa = c->csa;
+        sa.prev_end = c->d_stream_u32 + nr4;
+        sa.plan_a = c->d_stream_u32 + 2 * nr4;
+        sa.plan_z = c->d_stream_u32 + 3 * nr4;
+        sa.plan_h = c->d_stream_u32 + 4 * nr4;
+        sa.plan_t = c->d_stream_u32 + 5 * nr4;
+        sa.last_key = c->d_last_key;
+        sa.chunk_flags = c->d_chunk_flags;
+        sa.hist = c->d_cov_hist;
+        sa.bin_totals = c->d_bin_totals;
+        sa.bin_off = c->d_bin_off;
+        sa.bin_size = c->cfg.bin_size;
+        sa.cov_cap = c->cfg.cov_cap;
+        sa.head_guard = c->cfg.cov_head_guard;
+        CTX_TRY(hipMemsetAsync(c->d_stream_u32, 0, (6 * nr4 + 4) * 4, c->stream));
+        CTX_TRY(hipMemsetAsync(sa.plan_a, 0xFF, nr4 * 4, c->stream));
+        CTX_TRY(hipMemsetAsync(c->d_last_key, 0, 8, c->stream));
+        CTX_TRY(hipMemsetAsync(c->d_chunk_flags, 0, c->n_chunks ? c->n_chunks : 1, c->stream));
+    }
     if (ne) {
         CTX_TRY(hipMalloc((void **)&st.edits, ne * 4));
         CTX_TRY(hipMemsetAsync(st.edits, 0, ne * 4, c->stream));
@@ -277,6 +304,10 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_bin_off);
     (void)hipFree(c->d_td);
     (void)hipFree(c->d_touched);
+    (void)hipFree(c->d_cov_end);
+    (void)hipFree(c->d_stream_u32);
+    (void)hipFree(c->d_last_key);
+    (void)hipFree(c->d_chunk_flags);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -400,8 +431,28 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
     const uint32_t seq_f = (pass_mask & NGSQ_PASS_SEQUENCE) ? (facets & NGSQ_FACETS_SEQUENCE_BASED) : 0;
     if ((rec_f & (NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH)) || (seq_f & NGSQ_FACET_COVERAGE)) {
         const bool walk = (rec_f & NGSQ_FACET_GENERAL) || (seq_f & NGSQ_FACET_COVERAGE);
-        Bracket br(c, K_FIELDS, n * 25 + (walk ? cs.cigar_ops * 4 : 0));
-        HIP_TRY(c, launch_fields(c->li, c->st, db, rec_f, (seq_f & NGSQ_FACET_COVERAGE) != 0, c->stream));
+        const bool cov = (seq_f & NGSQ_FACET_COVERAGE) != 0;
+        if (cov && c->stream_cov) { // scratch column of the streaming pass
+            const uint64_t need = round_up(n, 1024) + 1024;
+            if (c->cov_end_cap < need) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                (void)hipFree(c->d_cov_end);
+                c->d_cov_end = nullptr;
+                c->cov_end_cap = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->d_cov_end, need * 4));
+                c->cov_end_cap = need;
+                c->st.cov_end = c->d_cov_end;
+            }
+            HIP_TRY(c, hipMemsetAsync(c->st.batch_span, 0, 4, c->stream));
+        }
+        {
+            Bracket br(c, K_FIELDS, n * 25 + (walk ? cs.cigar_ops * 4 : 0));
+            HIP_TRY(c, launch_fields(c->li, c->st, db, rec_f, cov ? (c->stream_cov ? 2 : 1) : 0, c->stream));
+        }
+        if (cov && c->stream_cov) {
+            Bracket br(c, K_COV_STREAM, n * 8); // pos + cov_end of every record
+            HIP_TRY(c, launch_cov_stream(c->li, c->st, db, c->csa, c->stream));
+        }
     }
     if (rec_f & NGSQ_FACET_GC_CONTENT) {
         Bracket br(c, K_GC, n * 6 + cs.seq_bytes);
@@ -609,6 +660,7 @@ int ngsq_teardown(ngsq_ctx *c) {
         a.bin_size = c->cfg.bin_size;
         a.cov_cap = c->cfg.cov_cap;
         a.reset = 1;
+        a.chunk_flags = c->stream_cov ? c->d_chunk_flags : nullptr;
         Bracket br(c, K_COV_SCAN, 0);
         HIP_TRY(c, launch_cov_scan(c->li, a, c->stream));
     }
@@ -658,6 +710,11 @@ int ngsq_finalize(ngsq_ctx *c) {
                     c->timing[K_COV_SCAN].algo_bytes += ((uint64_t)c->ref_len[r] + 2) * 8;
         }
     }
+    if (c->stream_cov && c->h_counters[C_COV_UNSORTED])
+        return fail(c, NGSQ_ERR_UNSORTED,
+                    "sorted_input was set but %llu adjacent record pair(s) are out of coordinate order; "
+                    "create the context without sorted_input for such input",
+                    c->h_counters[C_COV_UNSORTED]);
     const unsigned long long *err = c->h_counters.data() + C_ERR;
     for (int k = 0; k < 8; k++)
         if (err[k])
@@ -707,6 +764,13 @@ int ngsq_state_teardown(ngsq_ctx *c, void **p, uint64_t *n) {
     return NGSQ_OK;
 }
 
+int ngsq_state_chunk_flags(ngsq_ctx *c, void **p, uint64_t *n) {
+    if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
+    *p = c->d_chunk_flags;
+    *n = c->stream_cov ? c->n_chunks : 0;
+    return NGSQ_OK;
+}
+
 int ngsq_reset(ngsq_ctx *c) {
     if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -726,6 +790,13 @@ int ngsq_reset(ngsq_ctx *c) {
         }
     }
     HIP_TRY(c, hipMemsetAsync(c->d_td, 0, c->n_td * 8, c->stream));
+    if (c->stream_cov) {
+        const uint64_t nr4 = round_up(c->st.n_refs ? c->st.n_refs : 1, 4);
+        HIP_TRY(c, hipMemsetAsync(c->d_stream_u32, 0, (6 * nr4 + 4) * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->csa.plan_a, 0xFF, nr4 * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_last_key, 0, 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_chunk_flags, 0, c->n_chunks ? c->n_chunks : 1, c->stream));
+    }
     if (c->n_edits) HIP_TRY(c, hipMemsetAsync(c->st.edits, 0, c->n_edits * 4, c->stream));
     c->h_touched[0] = ~0ull;
     c->h_touched[1] = 0;
@@ -902,6 +973,7 @@ static int state_block(ngsq_ctx *c, int which, void **p, uint64_t *bytes) {
     case 1: *p = c->st.depth; *bytes = c->n_depth * 4; return NGSQ_OK;
     case 2: *p = c->st.edits; *bytes = c->n_edits * 4; return NGSQ_OK;
     case 3: *p = c->d_td; *bytes = c->n_td * 8; return NGSQ_OK;
+    case 4: *p = c->d_chunk_flags; *bytes = c->stream_cov ? c->n_chunks : 0; return NGSQ_OK;
     default: return NGSQ_ERR_INVALID_ARGUMENT;
     }
 }

@@ -11,7 +11,7 @@
 
 namespace ngsq {
 
-enum KernelId { K_FIELDS = 0, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_FEATURES, K_COUNT };
+enum KernelId { K_FIELDS = 0, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_FEATURES, K_COV_STREAM, K_COUNT };
 
 struct PendingTime {
     int id;
@@ -56,6 +56,14 @@ struct ngsq_ctx {
     unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
     std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;
     bool finalized = false;
+    // streaming Coverage (cfg.sorted_input): per-batch scratch column, per-sequence plan, chunk flags
+    bool stream_cov = false;
+    uint32_t *d_cov_end = nullptr;
+    uint64_t cov_end_cap = 0;
+    uint32_t *d_stream_u32 = nullptr; // end_acc | prev_end | plan_a | plan_z | plan_h | plan_t (n_refs each) | batch_span
+    unsigned long long *d_last_key = nullptr;
+    uint8_t *d_chunk_flags = nullptr;
+    ngsq::CovStreamArgs csa{};
     // Genomic Features gene model (ngsq_set_features)
     ngsq::FeatureTables ft{};
     uint32_t *d_ft_idx = nullptr, *d_ft_starts = nullptr, *d_ft_stops = nullptr;

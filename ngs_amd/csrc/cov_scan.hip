@@ -51,7 +51,9 @@ __global__ __launch_bounds__(COV_SUPER) void k_cov_super_sums(const uint32_t *ch
 // has no block barrier.  One step = 1024 positions (16 consecutive positions per lane).
 constexpr uint32_t CS_STEP = 64 * CS_PER_THREAD; // positions per wave step
 
-template <bool RESET>
+// SKIP: chunks flagged in a.chunk_flags were finished by the streaming pass (cov_stream.hip): they are
+// not positions of this scan, hold no entries, and only their chunk sum joins the running carry.
+template <bool RESET, bool SKIP>
 __global__ __launch_bounds__(CS_THREADS) void k_cov_scan(CovScanArgs a) {
     extern __shared__ uint32_t s_hist[]; // one histogram of cov_cap + 2 bins per wave
     const uint32_t nb = a.cov_cap + 2;
@@ -132,6 +134,11 @@ __global__ __launch_bounds__(CS_THREADS) void k_cov_scan(CovScanArgs a) {
                 ref += 1;
             }
             if (a.seen[ref] != 0) { // coverage.rs:187-193: only sequences with an entry
+                if (SKIP && a.chunk_flags[c]) {
+                    carry += a.chunk_sums[c];
+                    c += 1;
+                    continue;
+                }
                 load_ref(ref);
                 return c;
             }
@@ -155,7 +162,8 @@ __global__ __launch_bounds__(CS_THREADS) void k_cov_scan(CovScanArgs a) {
         // ---- prefetch the next step while this one is tallied (same sequence only: a sequence
         // change flushes the histogram first)
         const uint64_t en = e + CS_STEP;
-        const bool same_ref = en < c_hi * (uint64_t)COV_CHUNK && en < ref_e1;
+        bool same_ref = en < c_hi * (uint64_t)COV_CHUNK && en < ref_e1;
+        if (SKIP && same_ref && en % COV_CHUNK == 0 && a.chunk_flags[en / COV_CHUNK]) same_ref = false;
         uint4 nxt[CS_PER_THREAD / 4];
         load_step(same_ref ? en : e, nxt); // branch-free: past the end re-read this step (zeros by now)
 
@@ -234,12 +242,12 @@ hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream
     const size_t lds = (size_t)(CS_THREADS / 64) * (a.cov_cap + 2) * sizeof(uint32_t);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cov_scan<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cov_scan<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        if (e != hipSuccess) return e;
+        const void *fns[4] = {reinterpret_cast<const void *>(k_cov_scan<true, false>), reinterpret_cast<const void *>(k_cov_scan<false, false>),
+                              reinterpret_cast<const void *>(k_cov_scan<true, true>), reinterpret_cast<const void *>(k_cov_scan<false, true>)};
+        for (const void *f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            if (e != hipSuccess) return e;
+        }
         attr = true;
     }
     const uint32_t n_super = (uint32_t)((a.n_chunks + COV_SUPER - 1) / COV_SUPER);
@@ -248,10 +256,14 @@ hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream
     uint64_t g = (a.c_end - a.c_begin + CS_THREADS / 64 - 1) / (CS_THREADS / 64); // one chunk per wave at least
     const uint64_t cap = (uint64_t)li.n_cu * 4;
     if (g > cap) g = cap;
-    if (a.reset)
-        hipLaunchKernelGGL(k_cov_scan<true>, dim3((uint32_t)g), dim3(CS_THREADS), lds, s, a);
+    if (a.reset && a.chunk_flags)
+        hipLaunchKernelGGL((k_cov_scan<true, true>), dim3((uint32_t)g), dim3(CS_THREADS), lds, s, a);
+    else if (a.reset)
+        hipLaunchKernelGGL((k_cov_scan<true, false>), dim3((uint32_t)g), dim3(CS_THREADS), lds, s, a);
+    else if (a.chunk_flags)
+        hipLaunchKernelGGL((k_cov_scan<false, true>), dim3((uint32_t)g), dim3(CS_THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL(k_cov_scan<false>, dim3((uint32_t)g), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((k_cov_scan<false, false>), dim3((uint32_t)g), dim3(CS_THREADS), lds, s, a);
     return hipGetLastError();
 }
 

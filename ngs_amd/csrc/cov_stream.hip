@@ -1,0 +1,482 @@
+// cov_stream.hip -- Coverage (coverage.rs:148-246) for coordinate-sorted batches without the
+// difference array: the depth of a position is final as soon as every record that can cover it has
+// been seen, so a tile of consecutive records finishes the positions between its first start and
+// the next tile's first start in LDS (range-add -> prefix sum -> depth histogram + bin totals).
+//
+// Contract (ngsq_config.sorted_input): the records of a context arrive in coordinate order, as in the
+// BAM files `ngs qc` accepts (it requires a BAI, formats/bam.rs:86-96).  k_fields<STREAM> counts every
+// adjacent pair that breaks the order and ngsq_finalize then fails with NGSQ_ERR_UNSORTED; the kernels
+// here stay memory-safe on such input but their results are discarded.
+//
+// Per batch and sequence r the tiles (CS_TILE = 256 consecutive records, one wave each) whose first
+// record and whose successor's first record lie on r are STREAMABLE; tile t owns the positions
+// [start(first record of t), start(first record of t+1)).  The union over the run of streamable
+// tiles is [a_r, z_r); of that, whole scan chunks [H_r, T_r) are streamed:
+//   H_r = chunk_ceil(max(a_r, 1 + largest end of any earlier batch, a_r + head_guard on first touch))
+//   T_r = chunk_floor(min(z_r, L_r + 1))
+// Positions outside [H_r, T_r) -- the seams between batches, shards and sequences -- keep the classic
+// path: every record adds the parts of its range outside [H_r, T_r) to the difference array (global
+// atomics + chunk sums), and the teardown scan (cov_scan.hip) skips the chunks flagged here.  A -1
+// that would land exactly on H_r is recorded in the chunk sum only, so no entry is ever written into
+// a streamed chunk and the scan's running sum stays exact across the skipped chunks.
+//
+// A tile sees the records of EARLIER tiles that reach into its positions by walking back through the
+// (pos, cov_end) columns, 64 records at a time, until a group's first record cannot reach any more
+// (start + largest span of the batch <= first owned position) or lies on another sequence.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace ngsq {
+
+typedef unsigned long long u64;
+
+constexpr uint32_t ST_THREADS = 256;
+constexpr uint32_t ST_WAVES = ST_THREADS / 64;
+constexpr uint32_t ST_W = 1024; // positions of one wave's LDS window
+#ifndef ST_EXP
+#define ST_EXP 0 // measurement builds only (tools/exp_stream.sh): 1 no look-back, 2 no prefix passes, 3 no histogram atomics, 4 neither
+#endif
+
+__device__ __forceinline__ u64 st_key(int32_t rf, int32_t ps) { // as in k_fields<STREAM>
+    return rf < 0 ? 0xFFFFFFFF00000000ull : ((u64)(uint32_t)rf << 32) | (uint32_t)(ps + 1);
+}
+__device__ __forceinline__ bool st_valid(const DeviceState &st, int32_t rf, int32_t ps) {
+    return rf >= 0 && (uint32_t)rf < st.n_refs && ps >= 0 && st.ref_depth_off[rf] != NO_DEPTH;
+}
+
+// one thread per tile: first start of each run of streamable tiles (plan_a) and the start that ends it (plan_z)
+__global__ __launch_bounds__(256) void k_cov_plan_tiles(DeviceState st, DeviceBatch b, CovStreamArgs a) {
+    const uint64_t n_wt = (b.n + CS_TILE - 1) / CS_TILE;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { // coordinate order across the batch boundary
+        const u64 k0 = st_key(b.ref_id[0], b.pos[0]);
+        if (k0 < *a.last_key) atomicAdd(&st.counters[C_COV_UNSORTED], 1ull);
+        *a.last_key = st_key(b.ref_id[b.n - 1], b.pos[b.n - 1]);
+    }
+    if (t >= n_wt) return;
+    int32_t rf[4], ps[4]; // first records of tiles t-1 .. t+2 (absent: -1)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t u = (int64_t)t - 1 + k;
+        const bool ok = u >= 0 && (uint64_t)u < n_wt;
+        rf[k] = ok ? b.ref_id[(uint64_t)u * CS_TILE] : -1;
+        ps[k] = ok ? b.pos[(uint64_t)u * CS_TILE] : -1;
+    }
+    auto streamable = [&](int k) { // tile t-1+k and its successor start on the same covered sequence
+        return st_valid(st, rf[k], ps[k]) && rf[k + 1] == rf[k] && ps[k + 1] >= 0;
+    };
+    if (!streamable(1)) return;
+    const bool prev_same = streamable(0) && rf[0] == rf[1];
+    const bool next_same = streamable(2) && rf[2] == rf[1];
+    if (!prev_same) atomicMin(&a.plan_a[rf[1]], (uint32_t)ps[1] + 1);
+    if (!next_same) atomicMax(&a.plan_z[rf[1]], (uint32_t)ps[2] + 1);
+}
+
+// one thread per sequence: the streamed chunk range of this batch; rolls the per-sequence end forward
+__global__ __launch_bounds__(256) void k_cov_plan_refs(DeviceState st, CovStreamArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= st.n_refs) return;
+    const uint32_t pa = a.plan_a[r], pz = a.plan_z[r], prev = a.prev_end[r];
+    uint32_t H = CS_NONE, T = CS_NONE;
+    if (pa != CS_NONE && pz > pa) {
+        uint64_t base = pa > prev + 1 ? pa : (uint64_t)prev + 1; // entry `prev` may hold an earlier batch's -1
+        if (prev == 0 && a.head_guard) base = (uint64_t)pa + a.head_guard > base ? (uint64_t)pa + a.head_guard : base;
+        const uint64_t h = (base + COV_CHUNK - 1) / COV_CHUNK * COV_CHUNK;
+        const uint64_t lim = pz < (uint64_t)st.ref_len[r] + 1 ? pz : (uint64_t)st.ref_len[r] + 1;
+        const uint64_t tt = lim / COV_CHUNK * COV_CHUNK;
+        if (h < tt) {
+            H = (uint32_t)h;
+            T = (uint32_t)tt;
+        }
+    }
+    a.plan_h[r] = H;
+    a.plan_t[r] = T;
+    const uint32_t acc = st.end_acc[r];
+    a.prev_end[r] = acc > prev ? acc : prev;
+    a.plan_a[r] = CS_NONE; // ready for the next batch
+    a.plan_z[r] = 0;
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: four row_shr steps inside the rows of 16, two row broadcasts)
+__device__ __forceinline__ uint32_t st_wave_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t st_wave_max(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o, 64));
+    return v;
+}
+
+// 16-bit histogram counters, two per word: bin i < hw is the low half of word i, bin i >= hw the high half of
+// word i - hw (neighbouring depths, which are hot together, never share a word)
+__host__ __device__ inline uint32_t st_hist_words(uint32_t cov_cap) { return ((cov_cap + 2 + 1) / 2 + 3) & ~3u; }
+
+constexpr uint32_t ST_PER_LANE = 8;              // consecutive positions per lane in one prefix pass
+constexpr uint32_t ST_PASS = 64 * ST_PER_LANE;   // positions per pass
+static_assert(ST_W % ST_PASS == 0, "whole passes");
+
+// everything a full tile reads, loaded one tile ahead (the addresses depend on the tile number only)
+struct StTileIn {
+    int4 p;                          // pos of this lane's four records
+    uint4 c;                         // their cov_end
+    int32_t rf_t, ps_t, rf_n, ps_n;  // first record of the tile and of its successor
+    int32_t l_rf0[2];                // look-back groups 1 and 2 (the 64 / 128 records in front): sequence of the
+    int32_t l_ps[2];                 // group's first record; pos and cov_end of this lane's record
+    uint32_t l_ee[2];
+};
+
+__global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, DeviceBatch b, CovStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const uint32_t nb = a.cov_cap + 2;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    // wave-private window + depth histogram: no block barrier anywhere.  The histogram holds 16-bit
+    // counters, two per word (st_hist_words); it is flushed before any counter can reach 2^16 (`since_flush`).
+    const uint32_t hw = st_hist_words(a.cov_cap);
+    uint32_t *const win = s_dyn + wave * (ST_W + hw);
+    uint32_t *const hist = win + ST_W;
+    for (uint32_t i = lane; i < ST_W + hw; i += 64) win[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const uint64_t n_wt = (b.n + CS_TILE - 1) / CS_TILE;
+    const uint64_t n_full = b.n / CS_TILE; // tiles with all 256 records
+    const uint64_t n_units = (uint64_t)gridDim.x * ST_WAVES, unit = (uint64_t)blockIdx.x * ST_WAVES + wave;
+    const uint64_t per = (n_wt + n_units - 1) / n_units;
+    const uint64_t t_begin = per * unit < n_wt ? per * unit : n_wt;
+    const uint64_t t_end = t_begin + per < n_wt ? t_begin + per : n_wt;
+    const uint32_t maxspan = *st.batch_span;
+
+    int32_t hist_ref = -1;  // sequence the wave's histogram and bin accumulator belong to
+    uint32_t since_flush = 0; // positions tallied since the histogram was last flushed (< 2^16 - ST_PASS)
+    u64 zero_run = 0;         // positions of depth 0 skipped in closed form (wave-uniform)
+    u64 *bins = a.bin_totals;
+    u64 lane_bin = 0;                           // this lane's share of the depth sum of bin `bin_q`
+    uint32_t bin_q = 0, bin_p0 = 1, bin_p1 = 0; // bin_q holds the positions [bin_p0, bin_p1)
+    u64 t_lo = ~0ull, t_hi = 0;                 // entries of the depth block this wave accounts for
+    int32_t plan_ref = -1;                      // sequence whose facts are cached in scalar registers
+    uint32_t pH = CS_NONE, pT = CS_NONE, pL = 0;
+    uint64_t pOff = 0;
+
+    auto flush_bin = [&]() {
+        u64 v = lane_bin;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && v) atomicAdd(&bins[bin_q], v);
+        lane_bin = 0;
+    };
+    auto flush_hist = [&]() {
+        if (hist_ref < 0) return;
+        u64 *dst = a.hist + (u64)hist_ref * nb;
+        for (uint32_t i = lane; i < hw; i += 64) {
+            const uint32_t v = hist[i];
+            if (v) {
+                if ((v & 0xFFFFu) && i < nb) atomicAdd(&dst[i], (u64)(v & 0xFFFFu));
+                if ((v >> 16) && i + hw < nb) atomicAdd(&dst[i + hw], (u64)(v >> 16));
+                hist[i] = 0;
+            }
+        }
+        if (lane == 0 && zero_run) atomicAdd(&dst[0], zero_run);
+        zero_run = 0;
+        since_flush = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // +1 at q0, -1 at q1 of the difference array starting at `off` (the classic path, cov_scan.hip)
+    auto classic = [&](uint64_t off, uint32_t q0, uint32_t q1, bool minus_in_sum_only) {
+        const uint64_t g0 = off + q0, g1 = off + q1;
+        atomicAdd(&st.depth[g0], 1u);
+        atomicAdd(&st.chunk_sums[g0 / COV_CHUNK], 1u);
+        if (!minus_in_sum_only) atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
+        atomicAdd(&st.chunk_sums[g1 / COV_CHUNK], 0xFFFFFFFFu);
+        t_lo = g0 < t_lo ? g0 : t_lo;
+        t_hi = g1 + 1 > t_hi ? g1 + 1 : t_hi;
+    };
+    // the parts of [sj, ej) outside the streamed range [H, T) of its sequence
+    auto outside = [&](uint64_t off, uint32_t sj, uint32_t ej, uint32_t H, uint32_t T) {
+        if (sj < H) {
+            const uint32_t m = ej < H ? ej : H;
+            classic(off, sj, m, m == H);
+        }
+        if (T != CS_NONE && ej > T) classic(off, sj > T ? sj : T, ej, false);
+    };
+
+    auto load_full = [&](uint64_t t) -> StTileIn { // t < n_full; branch-free
+        const uint64_t base = t * CS_TILE, r0 = base + (uint64_t)lane * 4;
+        StTileIn in;
+        in.p = *reinterpret_cast<const int4 *>(b.pos + r0);
+        in.c = *reinterpret_cast<const uint4 *>(st.cov_end + r0);
+        const uint64_t nx = base + CS_TILE < b.n ? base + CS_TILE : base;
+        in.rf_t = b.ref_id[base];
+        in.ps_t = b.pos[base];
+        in.rf_n = b.ref_id[nx];
+        in.ps_n = b.pos[nx];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const uint64_t back = 64 * (g + 1);
+            const uint64_t li = base + lane >= back ? base + lane - back : 0;
+            in.l_rf0[g] = b.ref_id[base >= back ? base - back : 0];
+            in.l_ps[g] = b.pos[li];
+            in.l_ee[g] = st.cov_end[li];
+        }
+        return in;
+    };
+
+    auto process = [&](const StTileIn &in, uint64_t t) {
+        const uint64_t base = t * CS_TILE;
+        const uint64_t r0 = base + (uint64_t)lane * 4;
+        const uint32_t s[4] = {(uint32_t)in.p.x + 1, (uint32_t)in.p.y + 1, (uint32_t)in.p.z + 1, (uint32_t)in.p.w + 1};
+        const uint32_t e[4] = {in.c.x, in.c.y, in.c.z, in.c.w};
+        const int32_t rf_t = __builtin_amdgcn_readfirstlane(in.rf_t), ps_t = __builtin_amdgcn_readfirstlane(in.ps_t);
+        const int32_t rf_n = __builtin_amdgcn_readfirstlane(in.rf_n), ps_n = __builtin_amdgcn_readfirstlane(in.ps_n);
+        // st_valid() without its load: the sequence's facts are cached, and a load per tile would make the
+        // compiler wait for everything in flight, i.e. for the prefetch of the next tile
+        const bool cand = base + CS_TILE < b.n && rf_t >= 0 && (uint32_t)rf_t < st.n_refs && ps_t >= 0 && rf_n == rf_t && ps_n >= 0;
+        if (cand && rf_t != plan_ref) { // the facts leave this branch in scalar registers: no wait at the join
+            plan_ref = rf_t;
+            pH = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.plan_h[rf_t]);
+            pT = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.plan_t[rf_t]);
+            pL = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.ref_len[rf_t]);
+            const uint64_t o = st.ref_depth_off[rf_t];
+            pOff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o);
+        }
+        const bool streamable = cand && pOff != NO_DEPTH; // cand => the cache holds rf_t
+        const uint32_t H = streamable ? pH : CS_NONE, T = streamable ? pT : CS_NONE, Lr = pL;
+        const uint64_t off = pOff;
+
+        // ---- classic parts of this tile's own records
+        if (streamable) { // a sorted tile lies on one sequence; clamping keeps unsorted input inside the array
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t ej = e[j] < Lr + 1 ? e[j] : Lr + 1;
+                if (e[j] != 0 && s[j] < ej && (s[j] < H || ej > T)) outside(off, s[j], ej, H, T);
+            }
+        } else {
+            for (uint32_t j = 0; j < 4; j++) {
+                if (e[j] == 0) continue;
+                const int32_t rj = b.ref_id[r0 + j];
+                if (rj < 0 || (uint32_t)rj >= st.n_refs) continue;
+                const uint64_t oj = st.ref_depth_off[rj];
+                const uint32_t Lj = st.ref_len[rj];
+                const uint32_t ej = e[j] < Lj + 1 ? e[j] : Lj + 1;
+                if (oj != NO_DEPTH && s[j] < ej) outside(oj, s[j], ej, a.plan_h[rj], a.plan_t[rj]);
+            }
+            return;
+        }
+        if (H == CS_NONE) return;
+        const uint32_t lo = (uint32_t)ps_t + 1 > H ? (uint32_t)ps_t + 1 : H;
+        const uint32_t hi = (uint32_t)ps_n + 1 < T ? (uint32_t)ps_n + 1 : T;
+        if (lo >= hi) return;
+
+        // ---- the positions [lo, hi) are finished here
+        if (hist_ref != rf_t) {
+            flush_hist();
+            flush_bin();
+            hist_ref = rf_t;
+            bins = a.bin_totals + a.bin_off[rf_t];
+            bin_p0 = 1;
+            bin_p1 = 0;
+        }
+        for (uint64_t p = ((uint64_t)lo + COV_CHUNK - 1) / COV_CHUNK * COV_CHUNK + (uint64_t)lane * COV_CHUNK; p < hi;
+             p += 64ull * COV_CHUNK)
+            a.chunk_flags[(off + p) / COV_CHUNK] = 1;
+        t_lo = off + lo < t_lo ? off + lo : t_lo;
+        t_hi = off + hi > t_hi ? off + hi : t_hi;
+
+        bool rec[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) rec[j] = e[j] > lo && s[j] < hi;
+        uint32_t w = lo, carry = 0;
+        uint32_t lb_reach = CS_NONE; // wave-uniform: largest end among the earlier tiles' records (CS_NONE: not walked yet)
+        uint32_t lb_lane = 0;        // per lane, reduced only if the owned range needs another window
+        bool first = true;
+        while (w < hi) {
+            const uint32_t wend = hi - w > ST_W ? w + ST_W : hi;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t sp = s[j] > lo ? s[j] : lo;
+                if (rec[j] && sp >= w && sp < wend) atomicAdd(&win[sp - w], 1u);
+                if (rec[j] && e[j] >= w && e[j] < wend) atomicAdd(&win[e[j] - w], 0xFFFFFFFFu);
+            }
+            if (lb_reach > w && ST_EXP != 1 && ST_EXP != 4) { // records of earlier tiles that reach into [lo, hi)
+                uint32_t cnt0 = 0, reach = 0;
+                bool more = true; // wave-uniform
+                // one group of 64 records in front of the tile; returns whether anything further in front can reach
+                // (rf0: sequence of the group's first record; in a sorted batch everything between it and the tile
+                // lies on the same one, so the per-record column is read only across a sequence boundary)
+                auto group = [&](uint64_t back, int32_t rf0, uint32_t ss, uint32_t ee) -> bool {
+                    bool same = base + lane >= back;
+                    if (base < back || rf0 != rf_t) same = same && b.ref_id[same ? base + lane - back : 0] == rf_t;
+                    const bool hit = same && ee > lo;
+                    if (first) cnt0 += (uint32_t)__popcll(__ballot(hit));
+                    if (hit && ee >= w && ee < wend) atomicAdd(&win[ee - w], 0xFFFFFFFFu);
+                    reach = hit && ee > reach ? ee : reach;
+                    if (base <= back) return false; // the group reached the start of the batch
+                    const uint32_t ss0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ss);
+                    return rf0 == rf_t && (uint64_t)ss0 + maxspan > lo; // lane 0 holds the group's first record
+                };
+                more = group(64, __builtin_amdgcn_readfirstlane(in.l_rf0[0]), (uint32_t)in.l_ps[0] + 1, in.l_ee[0]); // prefetched
+                if (more) more = group(128, __builtin_amdgcn_readfirstlane(in.l_rf0[1]), (uint32_t)in.l_ps[1] + 1, in.l_ee[1]);
+                for (uint64_t back = 192; more; back += 64) {                             // rare: loaded on demand
+                    const uint64_t idx = base + lane >= back ? base + lane - back : 0;
+                    more = group(back, b.ref_id[base >= back ? base - back : 0], (uint32_t)b.pos[idx] + 1, st.cov_end[idx]);
+                }
+                lb_lane = reach;
+                if (first && lane == 0 && cnt0) atomicAdd(&win[0], cnt0); // they all start before lo
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- prefix sum of the window, ST_PASS positions per pass (8 consecutive per lane)
+            const uint32_t len = wend - w;
+            for (uint32_t pb = 0; pb < len && ST_EXP != 2 && ST_EXP != 4; pb += ST_PASS) {
+                uint4 *cell = reinterpret_cast<uint4 *>(win + pb + lane * ST_PER_LANE);
+                const uint4 d0 = cell[0], d1 = cell[1];
+                cell[0] = make_uint4(0, 0, 0, 0);
+                cell[1] = make_uint4(0, 0, 0, 0);
+                uint32_t x[ST_PER_LANE] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                for (uint32_t k = 1; k < ST_PER_LANE; k++) x[k] += x[k - 1];
+                const uint32_t inc = st_wave_scan(x[ST_PER_LANE - 1]);
+                const uint32_t before = carry + inc - x[ST_PER_LANE - 1];
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                const uint32_t p_first = w + pb, p_last = (len - pb > ST_PASS ? p_first + ST_PASS - 1 : wend - 1);
+                const bool one_bin = p_first >= bin_p0 && p_last < bin_p1; // wave-uniform
+                if (!one_bin) { // coverage.rs:206-230: position i >= 1 is in bin 1 + (i-1)/bin_size
+                    const uint32_t q0 = (p_first - 1) / a.bin_size, q1 = (p_last - 1) / a.bin_size;
+                    if (q0 == q1) {
+                        flush_bin();
+                        bin_q = q0 + 1;
+                        bin_p0 = q0 * a.bin_size + 1;
+                        const uint64_t top = (uint64_t)(q0 + 1) * a.bin_size + 1;
+                        bin_p1 = top > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)top;
+                    }
+                }
+                const bool in_acc = p_first >= bin_p0 && p_last < bin_p1;
+                uint32_t lsum = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < ST_PER_LANE; k++) { // branch-free: positions past the end add 0
+                    const uint32_t i = pb + lane * ST_PER_LANE + k;
+                    const uint32_t depth = before + x[k];
+                    const uint32_t bin = depth <= a.cov_cap ? depth : a.cov_cap + 1;
+                    const uint32_t one = i < len ? 1u : 0u;
+                    // (a dead lane adds 0 to a word of its own: the same word for all of them would serialise)
+                    const uint32_t word = one ? (bin < hw ? bin : bin - hw) : lane;
+                    if (ST_EXP != 3) atomicAdd(&hist[word], bin < hw ? one : one << 16);
+                    lsum += i < len ? depth : 0u;
+                }
+                if (in_acc) {
+                    lane_bin += lsum;
+                } else { // the pass straddles a bin boundary (once per bin_size positions): position by position
+                    for (uint32_t k = 0; k < ST_PER_LANE; k++) {
+                        const uint32_t i = pb + lane * ST_PER_LANE + k;
+                        const uint32_t depth = before + x[k];
+                        if (i < len && depth) atomicAdd(&bins[(u64)(w + i - 1) / a.bin_size + 1], (u64)depth);
+                    }
+                }
+                since_flush += ST_PASS;
+            }
+            if (since_flush > 0xFFFFu - 2 * ST_PASS) flush_hist(); // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            first = false;
+            w = wend;
+            if (w < hi) { // jump over positions nothing covers
+                lb_reach = st_wave_max(lb_lane);
+                uint32_t reach = lb_reach, nxt = 0xFFFFFFFFu - hi;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    if (rec[j] && s[j] < w) reach = max(reach, e[j]);
+                    if (rec[j] && s[j] >= w) nxt = max(nxt, 0xFFFFFFFFu - s[j]);
+                }
+                reach = st_wave_max(reach);
+                nxt = 0xFFFFFFFFu - st_wave_max(nxt); // the smallest start >= w (hi if none)
+                if (reach <= w && nxt > w) {
+                    zero_run += nxt - w;
+                    carry = 0;
+                    w = nxt;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    };
+
+    // ---- full tiles: the next tile's inputs are in flight while this one is processed
+    uint64_t t = t_begin;
+    const uint64_t t_full_end = t_end < n_full ? t_end : n_full;
+    if (t < t_full_end) {
+        StTileIn cur = load_full(t);
+        while (t < t_full_end) {
+            const uint64_t tn = t + 1;
+            const StTileIn nxt = load_full(tn < n_full ? tn : t); // past the end: a re-read
+            process(cur, t);
+            cur = nxt;
+            t = tn;
+        }
+    }
+    if (n_full < n_wt && t_begin <= n_full && n_full < t_end) { // the partial last tile: element by element, never streamable
+        const uint64_t base = n_full * CS_TILE, r0 = base + (uint64_t)lane * 4;
+        int32_t p[4];
+        uint32_t c[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const bool ok = r0 + j < b.n;
+            p[j] = ok ? b.pos[r0 + j] : -1;
+            c[j] = ok ? st.cov_end[r0 + j] : 0u;
+        }
+        StTileIn in;
+        in.p = make_int4(p[0], p[1], p[2], p[3]);
+        in.c = make_uint4(c[0], c[1], c[2], c[3]);
+        in.rf_t = in.rf_n = b.ref_id[base];
+        in.ps_t = in.ps_n = b.pos[base];
+        in.l_rf0[0] = in.l_rf0[1] = -1;
+        in.l_ps[0] = in.l_ps[1] = -1;
+        in.l_ee[0] = in.l_ee[1] = 0;
+        process(in, n_full);
+    }
+    flush_hist();
+    flush_bin();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 l2 = __shfl_xor(t_lo, o, 64), h2 = __shfl_xor(t_hi, o, 64);
+        t_lo = l2 < t_lo ? l2 : t_lo;
+        t_hi = h2 > t_hi ? h2 : t_hi;
+    }
+    if (lane == 0 && t_hi > 0) {
+        atomicMin(&st.touched[0], t_lo);
+        atomicMax(&st.touched[1], t_hi);
+    }
+}
+
+hipError_t launch_cov_stream(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const CovStreamArgs &a,
+                             hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    const uint64_t n_wt = (b.n + CS_TILE - 1) / CS_TILE;
+    hipLaunchKernelGGL(k_cov_plan_tiles, dim3((uint32_t)((n_wt + 255) / 256)), dim3(256), 0, s, st, b, a);
+    hipLaunchKernelGGL(k_cov_plan_refs, dim3((st.n_refs + 255) / 256), dim3(256), 0, s, st, a);
+    const size_t lds = (size_t)ST_WAVES * (ST_W + st_hist_words(a.cov_cap)) * sizeof(uint32_t);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cov_stream),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    uint64_t g = (n_wt + ST_WAVES - 1) / ST_WAVES;
+    const uint64_t per_cu = (160 * 1024 - 1024) / lds; // blocks that fit the 160 KB of LDS of one CU
+    const uint64_t cap = (uint64_t)li.n_cu * (per_cu < 1 ? 1 : per_cu > 6 ? 6 : per_cu);
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(k_cov_stream, dim3((uint32_t)g), dim3(ST_THREADS), lds, s, st, b, a);
+    return hipGetLastError();
+}
+
+} // namespace ngsq

@@ -19,6 +19,11 @@
 // windows need no block barrier: the tile loop has none.  Records that do not fit
 // the window (unsorted input, other sequence, long skips, very sparse files) fall
 // back to direct global atomics -- always correct, just slower.
+//
+// STREAM (contexts created with sorted_input): Coverage is finished by cov_stream.hip from the
+// (pos, cov_end) columns instead; this kernel then only applies noodles' query() filter, writes
+// every record's exclusive alignment end into the scratch column st.cov_end, counts adjacent
+// records that are out of coordinate order, and tracks the largest end per sequence / span per batch.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -31,7 +36,7 @@ constexpr uint32_t FT_THREADS = 256;
 constexpr uint32_t FT_PER_THREAD = 4;
 constexpr uint32_t FT_TILE = FT_THREADS * FT_PER_THREAD; // records per tile
 constexpr uint32_t FT_WINDOW = 2048;                     // positions in one wave's LDS window
-constexpr uint32_t FT_NSLOT = 16 + 3 + 18 + 1;           // block tallies: see slot_counter()
+constexpr uint32_t FT_NSLOT = 16 + 3 + 18 + 1 + 1;       // block tallies: see slot_counter()
 
 __device__ __forceinline__ uint32_t ft_wave_sum(uint32_t v) {
 #pragma unroll
@@ -62,6 +67,7 @@ struct FtRaw {
     uint32_t mapq;
     int4 ref, mate, tlen, pos;
     uint4 cig;
+    int32_t prev_ref, prev_pos; // STREAM: the record in front of this thread's first one
 };
 
 // number of lanes of the wave for which `c` holds: a wave-uniform value (SALU)
@@ -74,12 +80,13 @@ __device__ __forceinline__ uint32_t slot_counter(uint32_t slot) {
            : slot == 18 ? C_TLEN_IGNORED
            : slot < 28  ? C_CIGAR1 + (slot - 19)
            : slot < 37  ? C_CIGAR2 + (slot - 28)
-                        : C_ERR + E_BAD_CIGAR;
+           : slot == 37 ? C_ERR + E_BAD_CIGAR
+                        : C_COV_UNSORTED;
 }
 
 // CIG_OFF: CIGARs addressed through cigar_off (a compile-time choice: a conditional load in the
 // tile loop would make hipcc drain the in-order vmcnt queue, i.e. the prefetch, on every tile)
-template <bool CIG_OFF>
+template <bool CIG_OFF, bool STREAM>
 __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, DeviceBatch b, FieldsArgs a) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *const s_tlen = s_dyn;                                 // tlen_cap + 1
@@ -87,15 +94,17 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
     __shared__ u64 s_acc[FT_NSLOT];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     for (uint32_t i = tid; i <= st.tlen_cap; i += FT_THREADS) s_tlen[i] = 0;
-    if (a.do_cov)
+    if (a.do_cov && !STREAM)
         for (uint32_t i = tid; i < (FT_THREADS / 64) * FT_WINDOW; i += FT_THREADS) s_win[i] = 0;
     if (tid < FT_NSLOT) s_acc[tid] = 0;
     __syncthreads();
 
     // wave-uniform tallies (ballot + popcount): 16 RecordMetrics, missing ref, tlen processed/ignored
-    uint32_t g[19];
+    uint32_t g[20]; // [19]: STREAM, records out of coordinate order
 #pragma unroll
-    for (int k = 0; k < 19; k++) g[k] = 0;
+    for (int k = 0; k < 20; k++) g[k] = 0;
+    int32_t run_ref = -1; // STREAM: largest end on the sequence this thread is currently in
+    uint32_t run_end = 0, max_span = 0;
     uint32_t one[9], two[9]; // per-lane CIGAR-op tallies
 #pragma unroll
     for (int k = 0; k < 9; k++) one[k] = two[k] = 0;
@@ -128,6 +137,12 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         }
         if (a.do_tlen) r.tlen = *reinterpret_cast<const int4 *>(b.tlen + r0);
         if (a.do_cov) r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
+        r.prev_ref = r.prev_pos = 0;
+        if (STREAM) { // unconditional (same cache lines as the vector loads of the neighbouring lane)
+            const uint64_t pi = r0 ? r0 - 1 : 0;
+            r.prev_ref = b.ref_id[pi];
+            r.prev_pos = b.pos[pi];
+        }
         return r;
     };
     auto load_tail = [&](uint64_t tile, uint32_t &nrec) -> FtRaw {
@@ -161,6 +176,12 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         r.tlen = make_int4(tlen[0], tlen[1], tlen[2], tlen[3]);
         r.pos = make_int4(pos[0], pos[1], pos[2], pos[3]);
         r.cig = make_uint4(cig[0], cig[1], cig[2], cig[3]);
+        r.prev_ref = r.prev_pos = 0;
+        if (STREAM && nrec) {
+            const uint64_t pi = r0 ? r0 - 1 : 0;
+            r.prev_ref = b.ref_id[pi];
+            r.prev_pos = b.pos[pi];
+        }
         return r;
     };
 
@@ -197,13 +218,26 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 }
                 win_off = meta_off;
                 win_L = meta_L;
-                if (win_off != NO_DEPTH) {
+                if (win_off != NO_DEPTH || STREAM) {
                     win_ref = fr;
                     win_base = (uint32_t)fp & ~3u; // <= alignment_start of that record
                 }
             }
         }
         uint32_t my_max = 0;
+        uint32_t cend[4] = {0, 0, 0, 0}; // STREAM: exclusive alignment end of each record (0: covers nothing)
+        if (STREAM) { // coordinate order of adjacent records; unplaced (-1) sorts last, as in a sorted BAM
+            auto key = [](int32_t rf, int32_t ps) -> u64 { // st_key() of cov_stream.hip
+                return rf < 0 ? 0xFFFFFFFF00000000ull : ((u64)(uint32_t)rf << 32) | (uint32_t)(ps + 1);
+            };
+            u64 kp = key(raw.prev_ref, raw.prev_pos);
+#pragma unroll
+            for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
+                const u64 kj = key(ref[j], pos[j]);
+                g[19] += ft_count(j < nrec && kj < kp);
+                kp = kj;
+            }
+        }
 
 #pragma unroll
         for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
@@ -287,6 +321,17 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                         const uint64_t ec = e < L ? e : L;
                         nonsensical += e - ec; // coverage.rs:163-176: one per position > L
                         if (s > ec) return;
+                        if (STREAM) {
+                            cend[j] = (uint32_t)ec + 1;
+                            if (rf != run_ref) {
+                                if (run_end) atomicMax(&st.end_acc[run_ref], run_end);
+                                run_ref = rf;
+                                run_end = 0;
+                            }
+                            run_end = max(run_end, (uint32_t)ec + 1);
+                            max_span = max(max_span, (uint32_t)(ec + 1 - s));
+                            return;
+                        }
                         const uint64_t i0 = s - win_base, i1 = ec + 1 - win_base;
                         if (in_seq && s >= win_base && i1 < FT_WINDOW) {
                             atomicAdd(&win[i0], 1u);
@@ -312,13 +357,20 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                     }
                 }
             }
-            if (a.do_cov) { // chunk sums of the records that bypassed the window (wave-aggregated)
+            if (a.do_cov && !STREAM) { // chunk sums of the records that bypassed the window (wave-aggregated)
                 ft_chunk_add(st.chunk_sums, fb, fb_c0, 1u);
                 ft_chunk_add(st.chunk_sums, fb, fb_c1, 0xFFFFFFFFu);
             }
         }
 
-        if (a.do_cov) {
+        if (STREAM) {
+            if (nrec == FT_PER_THREAD) {
+                *reinterpret_cast<uint4 *>(st.cov_end + r0) = make_uint4(cend[0], cend[1], cend[2], cend[3]);
+            } else {
+                for (uint32_t j = 0; j < nrec; j++) st.cov_end[r0 + j] = cend[j];
+            }
+        }
+        if (a.do_cov && !STREAM) {
             // ---- the wave flushes the touched part of its own window with coalesced global
             // atomics and leaves it zeroed.  No barrier: LDS operations of one wave execute in order.
 #pragma unroll
@@ -396,7 +448,39 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             if (seen_cnt != 0 && !same) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
         }
     }
-    if (a.do_cov) { // written range of the depth block (min / max over the wave, then one atomic each)
+    if (STREAM) { // one atomic per block: a quarter of a million same-address atomics would take milliseconds
+        __shared__ int32_t s_end_ref;
+        __shared__ uint32_t s_end_max, s_span_max;
+        if (tid == 0) {
+            s_end_ref = -1;
+            s_end_max = 0;
+            s_span_max = 0;
+        }
+        __syncthreads();
+        { // the block's sequence: that of the first thread (of any wave) that covered something
+            const u64 act = __ballot(run_end != 0);
+            const int32_t wr = __shfl(run_ref, act ? __ffsll((long long)act) - 1 : 0, 64);
+            if (act && lane == 0) atomicCAS(&s_end_ref, -1, wr);
+        }
+        __syncthreads();
+        const int32_t lead = s_end_ref;
+        const bool same = run_end != 0 && run_ref == lead;
+        uint32_t m = same ? run_end : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m = max(m, (uint32_t)__shfl_xor(m, o, 64));
+            max_span = max(max_span, (uint32_t)__shfl_xor(max_span, o, 64));
+        }
+        if (lane == 0 && m) atomicMax(&s_end_max, m);
+        if (lane == 0 && max_span) atomicMax(&s_span_max, max_span);
+        if (run_end != 0 && !same) atomicMax(&st.end_acc[run_ref], run_end); // the block crossed a sequence boundary
+        __syncthreads();
+        if (tid == 0) {
+            if (s_end_max) atomicMax(&st.end_acc[lead], s_end_max);
+            if (s_span_max) atomicMax(st.batch_span, s_span_max);
+        }
+    }
+    if (a.do_cov && !STREAM) { // written range of the depth block (min / max over the wave, then one atomic each)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const u64 l2 = __shfl_xor(t_lo, o, 64), h2 = __shfl_xor(t_hi, o, 64);
@@ -419,6 +503,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
 #pragma unroll
         for (int k = 0; k < 19; k++)
             if (g[k]) atomicAdd(&s_acc[k], (u64)g[k]);
+        if (g[19]) atomicAdd(&s_acc[38], (u64)g[19]);
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -442,30 +527,35 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
 }
 
 hipError_t launch_fields(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, uint32_t rec_facets,
-                         bool coverage, hipStream_t s) {
+                         int coverage, hipStream_t s) {
     if (!b.n) return hipSuccess;
     FieldsArgs a;
     a.do_general = (rec_facets & NGSQ_FACET_GENERAL) ? 1 : 0;
     a.do_tlen = (rec_facets & NGSQ_FACET_TEMPLATE_LENGTH) ? 1 : 0;
     a.do_cov = coverage ? 1 : 0;
-    const size_t lds = (((size_t)st.tlen_cap + 1 + 3) & ~(size_t)3) * 4 + (coverage ? (FT_THREADS / 64) * FT_WINDOW * 4 : 0);
+    const bool stream = coverage == 2;
+    const size_t lds = (((size_t)st.tlen_cap + 1 + 3) & ~(size_t)3) * 4 + (coverage == 1 ? (FT_THREADS / 64) * FT_WINDOW * 4 : 0);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fields<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fields<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        if (e != hipSuccess) return e;
+        const void *fns[4] = {reinterpret_cast<const void *>(k_fields<false, false>), reinterpret_cast<const void *>(k_fields<true, false>),
+                              reinterpret_cast<const void *>(k_fields<false, true>), reinterpret_cast<const void *>(k_fields<true, true>)};
+        for (const void *f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            if (e != hipSuccess) return e;
+        }
         attr = true;
     }
     uint64_t g = (b.n + FT_TILE - 1) / FT_TILE;
     const uint64_t cap = (uint64_t)li.n_cu * 4;
     if (g > cap) g = cap;
-    if (b.cigar_off)
-        hipLaunchKernelGGL(k_fields<true>, dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
+    if (b.cigar_off && stream)
+        hipLaunchKernelGGL((k_fields<true, true>), dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
+    else if (b.cigar_off)
+        hipLaunchKernelGGL((k_fields<true, false>), dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
+    else if (stream)
+        hipLaunchKernelGGL((k_fields<false, true>), dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
     else
-        hipLaunchKernelGGL(k_fields<false>, dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
+        hipLaunchKernelGGL((k_fields<false, false>), dim3((uint32_t)g), dim3(FT_THREADS), lds, s, st, b, a);
     return hipGetLastError();
 }
 

@@ -61,6 +61,7 @@ enum : uint32_t {
     F_IGN_NONPRIMARY = 8,
     C_FEAT_ERR_REF = 60,
     C_FEAT_ERR_POS = 61,
+    C_COV_UNSORTED = 62, // sorted_input contexts: adjacent record pairs out of coordinate order
     OFF_GC_HIST = 64,
     OFF_TLEN_HIST = 168,
 };
@@ -86,6 +87,10 @@ struct DeviceState {
     const uint8_t *ref_bases;      // concatenated 4-bit codes, one per byte
     const uint64_t *ref_bases_off; // [n_refs] byte offset, NO_DEPTH if absent
     uint64_t gc_seed;
+    // ---- streaming Coverage (sorted_input contexts, cov_stream.hip); all null otherwise
+    uint32_t *cov_end;     // [batch records] scratch column: exclusive alignment end clipped to L+1, 0 = covers nothing
+    uint32_t *end_acc;     // [n_refs] largest cov_end of any record so far
+    uint32_t *batch_span;  // [1] largest (cov_end - alignment_start) of the current batch
 };
 
 // device view of one batch (all pointers device memory)
@@ -115,8 +120,26 @@ struct LaunchInfo {
 
 // General flag + CIGAR-op tallies (general.rs:31-121), Template Length
 // (template_length.rs:79-87) and Coverage range-add (coverage.rs:148-180): fields_kernel.hip
+// coverage: 0 = off, 1 = range-add into the difference arrays, 2 = streaming pass 1 (writes st.cov_end)
 hipError_t launch_fields(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
-                         uint32_t rec_facets, bool coverage, hipStream_t s);
+                         uint32_t rec_facets, int coverage, hipStream_t s);
+
+// Streaming Coverage for coordinate-sorted batches (cov_stream.hip): pass 2 over (pos, cov_end).
+constexpr uint32_t CS_TILE = 256;          // records per wave tile
+constexpr uint32_t CS_NONE = 0xFFFFFFFFu;  // "no streamed range on this sequence in this batch"
+struct CovStreamArgs {
+    uint32_t *plan_a, *plan_z;       // [n_refs] first start of the first / next start after the last streamable tile
+    uint32_t *plan_h, *plan_t;       // [n_refs] streamed position range [H, T), chunk-aligned; CS_NONE = none
+    uint32_t *prev_end;              // [n_refs] largest exclusive end of the batches before this one
+    unsigned long long *last_key;    // [1] sort key of the last record of the previous batch
+    uint8_t *chunk_flags;            // [n_chunks] 1 = finished by the streaming pass: the teardown scan skips it
+    unsigned long long *hist;        // as CovScanArgs
+    unsigned long long *bin_totals;
+    const uint64_t *bin_off;
+    uint32_t bin_size, cov_cap, head_guard;
+};
+hipError_t launch_cov_stream(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const CovStreamArgs &a,
+                             hipStream_t s);
 // GC Content (gc_content.rs:38-100)
 hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
                      uint64_t seq_bytes, hipStream_t s);
@@ -170,6 +193,7 @@ struct CovScanArgs {
     const uint64_t *bin_off;         // [n_refs + 1] offsets into bin_totals
     uint32_t n_refs, bin_size, cov_cap;
     int reset;
+    const uint8_t *chunk_flags;      // null, or per chunk 1 = already finished by the streaming pass (skipped)
 };
 hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream_t s);
 

@@ -13,7 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libngsq.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -23,6 +23,7 @@ ERR_MALFORMED_RECORD = -4
 ERR_STATE = -5
 ERR_BUFFER_TOO_SMALL = -6
 ERR_UNSUPPORTED = -7
+ERR_UNSORTED = -8
 
 FACET_GENERAL = 0x01
 FACET_TEMPLATE_LENGTH = 0x02
@@ -73,6 +74,8 @@ class Config(C.Structure):
         ("ref_bases", C.POINTER(u8p)),
         ("stream", C.c_void_p),
         ("timing", C.c_uint32),
+        ("sorted_input", C.c_uint32),
+        ("cov_head_guard", C.c_uint32),
         ("reserved", C.c_uint32),
     ]
 
@@ -236,6 +239,7 @@ PROTOTYPES = {
     "ngsq_set_scan_range": (C.c_int, [ctx_p, C.c_uint64, C.c_uint64, C.c_uint32]),
     "ngsq_teardown": (C.c_int, [ctx_p]),
     "ngsq_state_teardown": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
+    "ngsq_state_chunk_flags": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), u64p]),
     "ngsq_state_download": (C.c_int, [ctx_p, C.c_int, C.c_void_p, C.c_uint64]),
     "ngsq_state_upload": (C.c_int, [ctx_p, C.c_int, C.c_void_p, C.c_uint64]),
     "ngsq_device_malloc": (C.c_int, [ctx_p, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -20,6 +20,14 @@ coordinate-sorted file a shard writes only its own stretch of the reference axis
 If the shards are not sorted (written ranges overlap so much that step 3 would move more than
 `HALO_LIMIT_BYTES`), the protocol falls back to all-reducing the whole depth block.
 
+Contexts created with `sorted_input` (streaming Coverage, csrc/cov_stream.hip) have already finished
+most chunks of their stretch while scanning: those chunks are flagged, hold no entries and are skipped
+by the teardown; only the seams (the first `cov_head_guard` positions of a shard, its last few reads,
+sequence boundaries) are on the depth array and take part in steps 1-5 unchanged.  What must not
+happen is another shard's entry landing in a flagged chunk -- a read of the shard in front reaching
+beyond the guard, or shards that are not in coordinate order: that is detected here (every rank
+raises) instead of giving a wrong depth.
+
 torch.distributed ("nccl" = RCCL over xGMI; "gloo" for CPU tests) has no unsigned reductions:
 blocks are viewed as int64 / int32, two's-complement addition is the same bit pattern.
 PyTorch is plumbing for the collectives only; nothing here computes facet results.
@@ -53,7 +61,7 @@ def device_views(ctx, torch, device_index: int) -> Dict[str, object]:
     teardown (int64)."""
     dev = torch.device("cuda", device_index)
     out = {}
-    for name, which, ts in (("counters", 0, "<i8"), ("depth", 1, "<i4"), ("teardown", 3, "<i8")):
+    for name, which, ts in (("counters", 0, "<i8"), ("depth", 1, "<i4"), ("teardown", 3, "<i8"), ("flags", 4, "|u1")):
         p, n, _ = ctx.state_block(which)
         out[name] = torch.as_tensor(_DevArray(p, n, ts), device=dev) if n else None
     return out
@@ -144,6 +152,20 @@ def owner_teardown(ctx, dist, torch, views, coll_device=None) -> dict:
         out_bytes[s] += (c1 - c0) * (COV_CHUNK + 1) * 4
     diff = depth[:n_diff]
     sums = depth[n_diff:n_diff + n_chunks]
+
+    # streaming contexts: no exchanged entry may fall into a chunk this rank has already finished
+    flags = views.get("flags")
+    if flags is not None and flags.numel():
+        bad = 0
+        for (s, d), (c0, c1) in xfer.items():
+            if d == rank and bool(flags[c0:c1].any().item()):
+                bad = 1
+        if max(out_bytes) > HALO_LIMIT_BYTES and bool(flags.any().item()):
+            bad = 1
+        if max(b for row in _all_gather_ints([bad], dist, torch, cdev) for b in row):
+            raise RuntimeError("sorted_input shards overlap: records of another shard reach into positions this shard "
+                               "already finished (cov_head_guard too small, or the shards are not in coordinate "
+                               "order); re-run without sorted_input")
 
     if max(out_bytes) > HALO_LIMIT_BYTES:
         # unsorted shards: the written ranges overlap -- sum the whole block, every rank scans all

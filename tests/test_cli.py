@@ -247,3 +247,35 @@ def test_genomic_features_with_gff(ngs, gpu_lib, oracle_mod, tmp_path):
     assert r.returncode == 1 and "invalid GFF record on line 1" in r.stderr
     r = run(ngs, "-q", "qc", bam, GENOME, "-f", str(tmp_path / "m.bed"), "-o", str(tmp_path))
     assert r.returncode == 1 and "opening GFF file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_coverage_modes_and_unsorted_fallback(ngs, gpu_lib, oracle_mod, tmp_path):
+    """--coverage stream / array / auto give the same document on a sorted file; a file whose header claims
+    SO:coordinate but whose records are not in order is re-run on the depth arrays (auto) or refused (stream)."""
+    hb = sorted_batch(9, 20_000)
+    bam = str(tmp_path / "s.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=30_000)
+    docs = {}
+    for mode in ("auto", "stream", "array"):
+        out = tmp_path / mode
+        r = run(ngs, "-q", "qc", bam, GENOME, "-o", str(out), "--coverage", mode, "--batch-records", "7001")
+        assert r.returncode == 0, r.stderr
+        docs[mode] = json.load(open(out / "s.bam.results.json"))
+    json_equal(docs["stream"], oracle_json(oracle_mod, hb))
+    json_equal(docs["array"], docs["stream"])
+    json_equal(docs["auto"], docs["stream"])
+    # same records, two of them swapped: not sorted any more
+    from tests.util import take_records
+    order = np.arange(hb.n)
+    order[[5000, 15000]] = [15000, 5000]
+    bad = take_records(hb, order)
+    ubam = str(tmp_path / "u.bam")
+    bamio.write_bam(ubam, bad, NAMES, LENS)
+    r = run(ngs, "qc", ubam, GENOME, "-o", str(tmp_path / "u1"), "--coverage", "stream")
+    assert r.returncode == 1 and "coordinate order" in r.stderr
+    r = run(ngs, "qc", ubam, GENOME, "-o", str(tmp_path / "u2"))
+    assert r.returncode == 0 and "re-running with --coverage array" in r.stderr, r.stderr
+    got = json.load(open(tmp_path / "u2" / "u.bam.results.json"))
+    json_equal(got["coverage"], docs["array"]["coverage"])          # coverage does not depend on the record order
+    json_equal(got["general"], docs["array"]["general"])

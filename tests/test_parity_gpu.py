@@ -337,13 +337,26 @@ def _rank_worker(rank, world, port, q, mode):
         lib = F.load_library()
         n, L = 90_000, 700_000
         ref_len = [L, 50_000]
-        scfg = H.synth_config(n, mode=F.SYNTH_MIXED if mode == "mixed" else F.SYNTH_FIXED, ref_len=L, n_refs=2)
+        stream = "stream" in mode   # sorted_input contexts: Coverage streamed, only the seams are exchanged
+        scfg = H.synth_config(n, mode=F.SYNTH_MIXED if "mixed" in mode else F.SYNTH_FIXED, ref_len=L, n_refs=2)
         whole = H.synth_host_batch(scfg, 0, n, lib)
         first, cnt = shard.shard_range(n, rank, world)
         kw = dict(facets=F.FACETS_DEFAULT, bin_size=50_000, max_read_len=300, gc_seed=5)
-        ctx = H.QcContext(ref_len, device=0, lib=lib, **kw)
+        ctx = H.QcContext(ref_len, device=0, lib=lib, sorted_input=stream,
+                          cov_head_guard=8192 if stream and rank else 0, **kw)
         views = shard.device_views(ctx, torch, 0)
         names = ["chr1", "chr2"]
+        if mode == "stream-overlap":  # every rank scans the same records: the exchange must refuse, on every rank
+            ctx.process_batch(whole.slice(0, cnt))
+            try:
+                shard.owner_teardown(ctx, dist, torch, views, coll_device="cpu")
+                q.put((rank, "FAIL overlapping sorted_input shards were accepted"))
+            except RuntimeError as e:
+                q.put((rank, "ok" if "overlap" in str(e) else "FAIL " + str(e)))
+            ctx.close()
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         want = None
         if rank == 0:
             orc = oracle_py.Oracle(ref_len, **kw)
@@ -354,6 +367,8 @@ def _rank_worker(rank, world, port, q, mode):
             ctx.process_batch(whole.slice(first, first + cnt))
             rep = shard.owner_teardown(ctx, dist, torch, views, coll_device="cpu")
             assert rep["mode"] == "owner", rep
+            if stream:
+                assert int(views["flags"].sum().item()) > 30   # most of this shard's chunks never touched the array
             ctx.finalize()
             got = ctx.results(names)
             if rank == 0:
@@ -371,7 +386,7 @@ def _rank_worker(rank, world, port, q, mode):
         q.put((rank, "FAIL " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("mode", ["fixed", "mixed"])
+@pytest.mark.parametrize("mode", ["fixed", "mixed", "fixed-stream", "mixed-stream", "stream-overlap"])
 def test_three_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode):
     import multiprocessing as mp
     import socket

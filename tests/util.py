@@ -279,3 +279,30 @@ def to_fixed_stride(hb: HostBatch, min_len: int = 0) -> HostBatch:
 
 
 FIXED_COLS = ["flag", "mapq", "ref_id", "pos", "mate_ref_id", "tlen", "l_seq", "n_cigar"]
+
+
+def take_records(hb: HostBatch, order: np.ndarray) -> HostBatch:
+    """The records of an offsets-layout batch in another order (or a subset)."""
+    order = np.asarray(order, dtype=np.int64)
+    cols: Dict[str, Optional[np.ndarray]] = {}
+    for name in ("flag", "mapq", "ref_id", "pos", "mate_ref_id", "tlen", "l_seq", "n_cigar"):
+        a = hb.cols.get(name)
+        cols[name] = None if a is None else np.ascontiguousarray(a[order])
+    for data, off in (("seq", "seq_off"), ("qual", "qual_off"), ("cigar", "cigar_off")):
+        a, o = hb.cols[data], hb.cols[off]
+        assert o is not None, "take_records needs the offsets layout"
+        lens = (o[1:] - o[:-1])[order].astype(np.int64)
+        new_off = np.zeros(order.size + 1, dtype=np.uint64)
+        new_off[1:] = np.cumsum(lens)
+        starts = o[:-1][order].astype(np.int64)
+        idx = np.repeat(starts - new_off[:-1].astype(np.int64), lens) + np.arange(int(new_off[-1]), dtype=np.int64)
+        cols[data] = np.ascontiguousarray(a[idx]) if idx.size else np.zeros(0, a.dtype)
+        cols[off] = new_off
+    return HostBatch(order.size, cols, 0, 0, 0, hb.first_record_index)
+
+
+def coordinate_sorted(hb: HostBatch) -> HostBatch:
+    """Records in BAM coordinate order: by (ref_id, pos), unplaced (ref_id -1) last; stable."""
+    ref = hb.cols["ref_id"].astype(np.int64)
+    key = np.where(ref < 0, np.int64(1) << 40, ref << 32 | (hb.cols["pos"].astype(np.int64) + 1))
+    return take_records(hb, np.argsort(key, kind="stable"))
