@@ -20,9 +20,13 @@
 // that would land exactly on H_r is recorded in the chunk sum only, so no entry is ever written into
 // a streamed chunk and the scan's running sum stays exact across the skipped chunks.
 //
-// A tile sees the records of EARLIER tiles that reach into its positions by walking back through the
-// (pos, cov_end) columns, 64 records at a time, until a group's first record cannot reach any more
-// (start + largest span of the batch <= first owned position) or lies on another sequence.
+// A tile must also see the records of EARLIER tiles that reach into its positions.  A wave works through
+// consecutive tiles and carries their ends forward in an LDS list (everything in front with end > first
+// owned position: about one entry per unit of depth); the list is filtered and extended with the tile's own
+// records after each tile.  Without a valid list -- the first tile of a wave, after a sequence boundary, an
+// empty tile or a pile deeper than the list -- the tile walks back through the (pos, cov_end) columns, 64
+// records at a time, until a group's first record cannot reach any more (start + largest span of the batch
+// <= first owned position) or lies on another sequence, and rebuilds the list from what it found.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -34,6 +38,7 @@ typedef unsigned long long u64;
 constexpr uint32_t ST_THREADS = 256;
 constexpr uint32_t ST_WAVES = ST_THREADS / 64;
 constexpr uint32_t ST_W = 1024; // positions of one wave's LDS window
+constexpr uint32_t ST_LIST = 256; // entries of a wave's list of open ends (a deeper pile walks back instead)
 #ifndef ST_EXP
 #define ST_EXP 0 // measurement builds only (tools/exp_stream.sh): 1 no look-back, 2 no prefix passes, 3 no histogram atomics, 4 neither
 #endif
@@ -127,9 +132,6 @@ struct StTileIn {
     int4 p;                          // pos of this lane's four records
     uint4 c;                         // their cov_end
     int32_t rf_t, ps_t, rf_n, ps_n;  // first record of the tile and of its successor
-    int32_t l_rf0[2];                // look-back groups 1 and 2 (the 64 / 128 records in front): sequence of the
-    int32_t l_ps[2];                 // group's first record; pos and cov_end of this lane's record
-    uint32_t l_ee[2];
 };
 
 __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, DeviceBatch b, CovStreamArgs a) {
@@ -140,9 +142,10 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
     // wave-private window + depth histogram: no block barrier anywhere.  The histogram holds 16-bit
     // counters, two per word (st_hist_words); it is flushed before any counter can reach 2^16 (`since_flush`).
     const uint32_t hw = st_hist_words(a.cov_cap);
-    uint32_t *const win = s_dyn + wave * (ST_W + hw);
+    uint32_t *const win = s_dyn + wave * (ST_W + hw + ST_LIST);
     uint32_t *const hist = win + ST_W;
-    for (uint32_t i = lane; i < ST_W + hw; i += 64) win[i] = 0;
+    uint32_t *const lst = hist + hw;
+    for (uint32_t i = lane; i < ST_W + hw + ST_LIST; i += 64) win[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -161,6 +164,11 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
     u64 lane_bin = 0;                           // this lane's share of the depth sum of bin `bin_q`
     uint32_t bin_q = 0, bin_p0 = 1, bin_p1 = 0; // bin_q holds the positions [bin_p0, bin_p1)
     u64 t_lo = ~0ull, t_hi = 0;                 // entries of the depth block this wave accounts for
+    // the list: cov_end of every record in front of tile `lst_tile` on `lst_ref` with cov_end > lst_lo
+    bool lst_valid = false;
+    uint64_t lst_tile = 0;
+    int32_t lst_ref = -1;
+    uint32_t lst_lo = 0, lst_n = 0;
     int32_t plan_ref = -1;                      // sequence whose facts are cached in scalar registers
     uint32_t pH = CS_NONE, pT = CS_NONE, pL = 0;
     uint64_t pOff = 0;
@@ -218,14 +226,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
         in.ps_t = b.pos[base];
         in.rf_n = b.ref_id[nx];
         in.ps_n = b.pos[nx];
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-            const uint64_t back = 64 * (g + 1);
-            const uint64_t li = base + lane >= back ? base + lane - back : 0;
-            in.l_rf0[g] = b.ref_id[base >= back ? base - back : 0];
-            in.l_ps[g] = b.pos[li];
-            in.l_ee[g] = st.cov_end[li];
-        }
         return in;
     };
 
@@ -294,6 +294,9 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
         bool rec[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) rec[j] = e[j] > lo && s[j] < hi;
+        const bool from_list = lst_valid && lst_tile == t && lst_ref == rf_t && lst_lo == lo; // wave-uniform
+        uint32_t new_n = 0; // the list for tile t + 1 (built in place: it never outruns the read position)
+        bool new_ok = true;
         uint32_t w = lo, carry = 0;
         uint32_t lb_reach = CS_NONE; // wave-uniform: largest end among the earlier tiles' records (CS_NONE: not walked yet)
         uint32_t lb_lane = 0;        // per lane, reduced only if the owned range needs another window
@@ -307,30 +310,47 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                 if (rec[j] && e[j] >= w && e[j] < wend) atomicAdd(&win[e[j] - w], 0xFFFFFFFFu);
             }
             if (lb_reach > w && ST_EXP != 1 && ST_EXP != 4) { // records of earlier tiles that reach into [lo, hi)
-                uint32_t cnt0 = 0, reach = 0;
-                bool more = true; // wave-uniform
-                // one group of 64 records in front of the tile; returns whether anything further in front can reach
-                // (rf0: sequence of the group's first record; in a sorted batch everything between it and the tile
-                // lies on the same one, so the per-record column is read only across a sequence boundary)
-                auto group = [&](uint64_t back, int32_t rf0, uint32_t ss, uint32_t ee) -> bool {
-                    bool same = base + lane >= back;
-                    if (base < back || rf0 != rf_t) same = same && b.ref_id[same ? base + lane - back : 0] == rf_t;
-                    const bool hit = same && ee > lo;
-                    if (first) cnt0 += (uint32_t)__popcll(__ballot(hit));
-                    if (hit && ee >= w && ee < wend) atomicAdd(&win[ee - w], 0xFFFFFFFFu);
-                    reach = hit && ee > reach ? ee : reach;
-                    if (base <= back) return false; // the group reached the start of the batch
-                    const uint32_t ss0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ss);
-                    return rf0 == rf_t && (uint64_t)ss0 + maxspan > lo; // lane 0 holds the group's first record
-                };
-                more = group(64, __builtin_amdgcn_readfirstlane(in.l_rf0[0]), (uint32_t)in.l_ps[0] + 1, in.l_ee[0]); // prefetched
-                if (more) more = group(128, __builtin_amdgcn_readfirstlane(in.l_rf0[1]), (uint32_t)in.l_ps[1] + 1, in.l_ee[1]);
-                for (uint64_t back = 192; more; back += 64) {                             // rare: loaded on demand
-                    const uint64_t idx = base + lane >= back ? base + lane - back : 0;
-                    more = group(back, b.ref_id[base >= back ? base - back : 0], (uint32_t)b.pos[idx] + 1, st.cov_end[idx]);
+                uint32_t reach = 0;
+                if (from_list) {
+                    if (first && lane == 0 && lst_n) atomicAdd(&win[0], lst_n); // they all start before lo
+                    for (uint32_t c = 0; c < lst_n; c += 64) {
+                        const uint32_t ee = c + lane < lst_n ? lst[c + lane] : 0u;
+                        if (ee >= w && ee < wend && ee > lo) atomicAdd(&win[ee - w], 0xFFFFFFFFu);
+                        reach = ee > reach ? ee : reach;
+                    }
+                } else {
+                    uint32_t cnt0 = 0;
+                    bool more = true; // wave-uniform
+                    // one group of 64 records in front of the tile; in a sorted batch everything between the group's
+                    // first record and the tile lies on one sequence, so the per-record column is read only across a
+                    // sequence boundary.  The first walk also collects the ends beyond hi: the next tile's list.
+                    for (uint64_t back = 64; more; back += 64) {
+                        const bool okl = base + lane >= back;
+                        const uint64_t idx = okl ? base + lane - back : 0;
+                        const int32_t rf0 = b.ref_id[base >= back ? base - back : 0];
+                        const uint32_t ss = (uint32_t)b.pos[idx] + 1, ee = st.cov_end[idx];
+                        bool same = okl;
+                        if (base < back || rf0 != rf_t) same = same && b.ref_id[idx] == rf_t;
+                        const bool hit = same && ee > lo;
+                        if (first) {
+                            cnt0 += (uint32_t)__popcll(__ballot(hit));
+                            const u64 km = __ballot(hit && ee > hi);
+                            const uint32_t kn = (uint32_t)__popcll(km);
+                            if (new_n + kn <= ST_LIST) {
+                                if (hit && ee > hi) lst[new_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0))] = ee;
+                                new_n += kn;
+                            } else {
+                                new_ok = false;
+                            }
+                        }
+                        if (hit && ee >= w && ee < wend) atomicAdd(&win[ee - w], 0xFFFFFFFFu);
+                        reach = hit && ee > reach ? ee : reach;
+                        const uint32_t ss0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ss); // the group's first record
+                        more = base > back && rf0 == rf_t && (uint64_t)ss0 + maxspan > lo;      // can anything in front reach?
+                    }
+                    if (first && lane == 0 && cnt0) atomicAdd(&win[0], cnt0); // they all start before lo
                 }
                 lb_lane = reach;
-                if (first && lane == 0 && cnt0) atomicAdd(&win[0], cnt0); // they all start before lo
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -408,6 +428,35 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                 }
             }
         }
+
+        // ---- the list for the next tile: what was open in front and still is beyond hi, plus this tile's records
+        if (ST_EXP == 1 || ST_EXP == 4) return;
+        if (from_list) {
+            for (uint32_t c = 0; c < lst_n; c += 64) {
+                const uint32_t ee = c + lane < lst_n ? lst[c + lane] : 0u;
+                const u64 km = __ballot(ee > hi);
+                if (ee > hi) lst[new_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0))] = ee;
+                new_n += (uint32_t)__popcll(km);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const u64 km = __ballot(e[j] > hi);
+            const uint32_t kn = (uint32_t)__popcll(km);
+            if (new_ok && new_n + kn <= ST_LIST) {
+                if (e[j] > hi) lst[new_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0))] = e[j];
+                new_n += kn;
+            } else {
+                new_ok = false;
+            }
+        }
+        lst_valid = new_ok;
+        lst_n = new_n;
+        lst_tile = t + 1;
+        lst_ref = rf_t;
+        lst_lo = hi;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
 
     // ---- full tiles: the next tile's inputs are in flight while this one is processed
@@ -438,9 +487,6 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
         in.c = make_uint4(c[0], c[1], c[2], c[3]);
         in.rf_t = in.rf_n = b.ref_id[base];
         in.ps_t = in.ps_n = b.pos[base];
-        in.l_rf0[0] = in.l_rf0[1] = -1;
-        in.l_ps[0] = in.l_ps[1] = -1;
-        in.l_ee[0] = in.l_ee[1] = 0;
         process(in, n_full);
     }
     flush_hist();
@@ -463,7 +509,7 @@ hipError_t launch_cov_stream(const LaunchInfo &li, const DeviceState &st, const 
     const uint64_t n_wt = (b.n + CS_TILE - 1) / CS_TILE;
     hipLaunchKernelGGL(k_cov_plan_tiles, dim3((uint32_t)((n_wt + 255) / 256)), dim3(256), 0, s, st, b, a);
     hipLaunchKernelGGL(k_cov_plan_refs, dim3((st.n_refs + 255) / 256), dim3(256), 0, s, st, a);
-    const size_t lds = (size_t)ST_WAVES * (ST_W + st_hist_words(a.cov_cap)) * sizeof(uint32_t);
+    const size_t lds = (size_t)ST_WAVES * (ST_W + st_hist_words(a.cov_cap) + ST_LIST) * sizeof(uint32_t);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cov_stream),

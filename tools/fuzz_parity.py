@@ -16,14 +16,69 @@ import numpy as np  # noqa: E402
 from ngs_amd import ffi, host  # noqa: E402
 from oracle import oracle_py  # noqa: E402
 from tests import bamio  # noqa: E402
-from tests.util import compare_contexts, json_equal, random_batch, to_fixed_stride  # noqa: E402
+from tests.util import (batch_from_records, compare_contexts, coordinate_sorted, json_equal, random_batch,  # noqa: E402
+                        take_records, to_fixed_stride)
+
+
+def sorted_sweep(lib, seeds):
+    """Streaming Coverage (sorted_input) against the oracle: random densities (sparse to piles deeper than the
+    open-ends list and than cov_cap), span mixes with long skips, several sequences, batches cut anywhere."""
+    for seed in range(seeds):
+        rng = np.random.default_rng(5000 + seed)
+        n_refs = int(rng.integers(1, 4))
+        ref_len = [int(rng.integers(5_000, 600_000)) for _ in range(n_refs)]
+        primary = [int(rng.random() < 0.85) for _ in range(n_refs)]
+        n = int(rng.integers(300, 60_000))
+        recs = []
+        long_p = float(rng.choice([0.0, 0.02, 0.3]))
+        for _ in range(n):
+            r = int(rng.integers(0, n_refs))
+            L = ref_len[r]
+            if rng.random() < 0.3:   # clusters: piles of a few hundred reads on a few hundred positions
+                c = int(rng.integers(0, 8)) * (L // 8)
+                pos = c + int(rng.integers(0, 300))
+            else:
+                pos = int(rng.integers(0, L + 20))
+            k = rng.random()
+            if k < long_p:
+                cig = f"{int(rng.integers(1, 60))}M{int(rng.integers(100, 40_000))}N{int(rng.integers(1, 60))}M"
+            elif k < 0.9:
+                cig = f"{int(rng.integers(1, 300))}M"
+            elif k < 0.95:
+                cig = f"{int(rng.integers(1, 30))}S{int(rng.integers(1, 100))}M{int(rng.integers(1, 9))}D{int(rng.integers(1, 50))}M"
+            else:
+                cig = "*"
+            recs.append(dict(flag=int(rng.integers(0, 4096)), ref_id=r if rng.random() > 0.01 else -1, pos=pos,
+                             mate_ref_id=r, cigar=cig, seq="ACGT", qual=[20] * 4))
+        hb = coordinate_sorted(batch_from_records(recs))
+        kw = dict(facets=ffi.FACET_COVERAGE | ffi.FACET_GENERAL, bin_size=int(rng.choice([7, 1000, 50_000])),
+                  max_read_len=320, gc_seed=seed, cov_cap=int(rng.choice([0, 64])))
+        orc = oracle_py.Oracle(ref_len, primary, **kw)
+        gpu = host.QcContext(ref_len, primary, lib=lib, sorted_input=True,
+                             cov_head_guard=int(rng.choice([0, 0, 5000])), **kw)
+        cuts = sorted(set([0, hb.n] + [int(x) for x in rng.integers(0, hb.n + 1, int(rng.integers(0, 4)))]))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = take_records(hb, np.arange(lo, hi))
+            orc.process_batch(part)
+            gpu.process_batch(gpu.upload(part) if rng.random() < 0.5 else part)
+        assert orc.finalize(allow_malformed=True) == gpu.finalize(allow_malformed=True)
+        compare_contexts(gpu, orc, n_refs, kw["facets"], kw["bin_size"], ref_len)
+        names = [f"s{i}" for i in range(n_refs)]
+        json_equal(gpu.results(names), orc.results(names))
+        flagged = int(gpu.state_download(4).sum())
+        gpu.close()
+        print(f"sorted seed {seed}: n={hb.n} refs={ref_len} long={long_p} batches={len(cuts) - 1} streamed_chunks={flagged} ok", flush=True)
+    print("sorted sweep ok")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=40)
+    ap.add_argument("--sorted", type=int, default=0, help="seeds of the sorted_input (streaming Coverage) sweep")
     a = ap.parse_args()
     lib = ffi.load_library()
+    if a.sorted:
+        sorted_sweep(lib, a.sorted)
     td = tempfile.mkdtemp(prefix="ngsq_fuzz_")
     for seed in range(a.seeds):
         rng = np.random.default_rng(1000 + seed)
