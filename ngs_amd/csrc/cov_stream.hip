@@ -29,6 +29,8 @@
 // <= first owned position) or lies on another sequence, and rebuilds the list from what it found.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace ngsq {
@@ -355,20 +357,36 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
-            // ---- prefix sum of the window, ST_PASS positions per pass (8 consecutive per lane)
+            // ---- prefix sum of the window: passes of 8, 4 or 2 consecutive positions per lane -- the widest that
+            // the rest of the window fills to more than half, so that few lanes of the last pass are dead (a tile
+            // of 256 reads owns ~640 positions at 60x: one pass of 512 and one of 128 instead of two of 512)
             const uint32_t len = wend - w;
-            for (uint32_t pb = 0; pb < len && ST_EXP != 2 && ST_EXP != 4; pb += ST_PASS) {
-                uint4 *cell = reinterpret_cast<uint4 *>(win + pb + lane * ST_PER_LANE);
-                const uint4 d0 = cell[0], d1 = cell[1];
-                cell[0] = make_uint4(0, 0, 0, 0);
-                cell[1] = make_uint4(0, 0, 0, 0);
-                uint32_t x[ST_PER_LANE] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            auto pass = [&](auto pl_tag, uint32_t pb) {
+                constexpr uint32_t PL = decltype(pl_tag)::value;
+                uint32_t x[PL];
+                if constexpr (PL == 8) {
+                    uint4 *cell = reinterpret_cast<uint4 *>(win + pb + lane * PL);
+                    const uint4 d0 = cell[0], d1 = cell[1];
+                    cell[0] = make_uint4(0, 0, 0, 0);
+                    cell[1] = make_uint4(0, 0, 0, 0);
+                    x[0] = d0.x, x[1] = d0.y, x[2] = d0.z, x[3] = d0.w, x[4] = d1.x, x[5] = d1.y, x[6] = d1.z, x[7] = d1.w;
+                } else if constexpr (PL == 4) {
+                    uint4 *cell = reinterpret_cast<uint4 *>(win + pb + lane * PL);
+                    const uint4 d0 = cell[0];
+                    cell[0] = make_uint4(0, 0, 0, 0);
+                    x[0] = d0.x, x[1] = d0.y, x[2] = d0.z, x[3] = d0.w;
+                } else {
+                    uint2 *cell = reinterpret_cast<uint2 *>(win + pb + lane * PL);
+                    const uint2 d0 = cell[0];
+                    cell[0] = make_uint2(0, 0);
+                    x[0] = d0.x, x[1] = d0.y;
+                }
 #pragma unroll
-                for (uint32_t k = 1; k < ST_PER_LANE; k++) x[k] += x[k - 1];
-                const uint32_t inc = st_wave_scan(x[ST_PER_LANE - 1]);
-                const uint32_t before = carry + inc - x[ST_PER_LANE - 1];
+                for (uint32_t k = 1; k < PL; k++) x[k] += x[k - 1];
+                const uint32_t inc = st_wave_scan(x[PL - 1]);
+                const uint32_t before = carry + inc - x[PL - 1];
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                const uint32_t p_first = w + pb, p_last = (len - pb > ST_PASS ? p_first + ST_PASS - 1 : wend - 1);
+                const uint32_t p_first = w + pb, p_last = (len - pb > 64 * PL ? p_first + 64 * PL - 1 : wend - 1);
                 const bool one_bin = p_first >= bin_p0 && p_last < bin_p1; // wave-uniform
                 if (!one_bin) { // coverage.rs:206-230: position i >= 1 is in bin 1 + (i-1)/bin_size
                     const uint32_t q0 = (p_first - 1) / a.bin_size, q1 = (p_last - 1) / a.bin_size;
@@ -383,8 +401,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                 const bool in_acc = p_first >= bin_p0 && p_last < bin_p1;
                 uint32_t lsum = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < ST_PER_LANE; k++) { // branch-free: positions past the end add 0
-                    const uint32_t i = pb + lane * ST_PER_LANE + k;
+                for (uint32_t k = 0; k < PL; k++) { // branch-free: positions past the end add 0
+                    const uint32_t i = pb + lane * PL + k;
                     const uint32_t depth = before + x[k];
                     const uint32_t bin = depth <= a.cov_cap ? depth : a.cov_cap + 1;
                     const uint32_t one = i < len ? 1u : 0u;
@@ -396,13 +414,26 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                 if (in_acc) {
                     lane_bin += lsum;
                 } else { // the pass straddles a bin boundary (once per bin_size positions): position by position
-                    for (uint32_t k = 0; k < ST_PER_LANE; k++) {
-                        const uint32_t i = pb + lane * ST_PER_LANE + k;
+                    for (uint32_t k = 0; k < PL; k++) {
+                        const uint32_t i = pb + lane * PL + k;
                         const uint32_t depth = before + x[k];
                         if (i < len && depth) atomicAdd(&bins[(u64)(w + i - 1) / a.bin_size + 1], (u64)depth);
                     }
                 }
-                since_flush += ST_PASS;
+                since_flush += 64 * PL;
+            };
+            for (uint32_t pb = 0; pb < len && ST_EXP != 2 && ST_EXP != 4;) {
+                const uint32_t rem = len - pb;
+                if (rem > 256) {
+                    pass(std::integral_constant<uint32_t, 8>{}, pb);
+                    pb += 512;
+                } else if (rem > 128) {
+                    pass(std::integral_constant<uint32_t, 4>{}, pb);
+                    pb += 256;
+                } else {
+                    pass(std::integral_constant<uint32_t, 2>{}, pb);
+                    pb += 128;
+                }
             }
             if (since_flush > 0xFFFFu - 2 * ST_PASS) flush_hist(); // wave-uniform
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -459,7 +490,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
         __builtin_amdgcn_wave_barrier();
     };
 
-    // ---- full tiles: the next tile's inputs are in flight while this one is processed
+    // ---- full tiles: the next tile's inputs are in flight while this one is processed (two tiles ahead was
+    // measured: no faster, and the extra registers spill)
     uint64_t t = t_begin;
     const uint64_t t_full_end = t_end < n_full ? t_end : n_full;
     if (t < t_full_end) {
