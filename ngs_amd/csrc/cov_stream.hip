@@ -311,7 +311,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                 if (rec[j] && sp >= w && sp < wend) atomicAdd(&win[sp - w], 1u);
                 if (rec[j] && e[j] >= w && e[j] < wend) atomicAdd(&win[e[j] - w], 0xFFFFFFFFu);
             }
-            if (lb_reach > w && ST_EXP != 1 && ST_EXP != 4) { // records of earlier tiles that reach into [lo, hi)
+            if (lb_reach >= w && ST_EXP != 1 && ST_EXP != 4) { // earlier tiles' records that reach into [lo, hi); >=: an end exactly on w still owes its -1
                 uint32_t reach = 0;
                 if (from_list) {
                     if (first && lane == 0 && lst_n) atomicAdd(&win[0], lst_n); // they all start before lo

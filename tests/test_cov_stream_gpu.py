@@ -141,3 +141,48 @@ def test_full_size_stream_equals_classic(gpu_lib):
             res.append(gpu.results(["chr1", "chr2"]))
             gpu.free_batch(db)
     json_equal(res[0], res[1])
+
+
+def test_end_of_an_earlier_record_exactly_on_a_window_boundary(gpu_lib, oracle_mod):
+    """A record of tile 0 ends exactly 2048 positions (two LDS windows) into the range tile 1 owns, while a long
+    record of tile 1 keeps the windows from being skipped: its -1 is the first entry of the third window."""
+    recs = []
+    def add(pos, cigar):
+        recs.append(dict(flag=0, ref_id=0, pos=pos, cigar=cigar, seq="ACGT", qual=[30] * 4))
+    S = 20_001                                   # 1-based start of tile 1's first record
+    for i in range(256):
+        pos0 = 8192 + i * 10
+        add(pos0, f"10M{S + 2048 - (pos0 + 1) - 20}N10M" if i == 100 else "50M")
+    add(S - 1, "10M5000N10M")
+    for i in range(255):
+        add(30_000 + i * 40, "50M")
+    for i in range(300):
+        add(60_000 + i * 30, "75M")
+    hb = batch_from_records(recs)
+    for k in (0, 1, 1023, 1024, 1025):           # and the same with the end moved around the boundary
+        r2 = list(recs)
+        pos0 = 8192 + 100 * 10
+        r2[100] = dict(recs[100], cigar=f"10M{S + 2048 + k - 1024 - (pos0 + 1) - 20}N10M")
+        run_sorted(oracle_mod, gpu_lib, [batch_from_records(r2)], [2_000_000], facets=ffi.FACET_COVERAGE, bin_size=64)
+    flags = run_sorted(oracle_mod, gpu_lib, [hb], [2_000_000], facets=ffi.FACET_COVERAGE, bin_size=64)
+    assert flags.sum() >= 10
+
+
+@pytest.mark.parametrize("n,batch", [(1_000_000, None), (3_000_000, 1 << 20)])
+def test_sparse_spliced_chr1_stream_equals_array(gpu_lib, n, batch):
+    """1-4x coverage of a chr1-sized axis with skips up to 5 kb: a tile of 256 reads owns ~60 LDS windows, ends of
+    earlier tiles land anywhere in them (this shape caught a lost -1 on a window boundary).  No oracle at this
+    size: the two Coverage paths must agree."""
+    L = 248_956_422
+    cfg = host.synth_config(n, mode=ffi.SYNTH_MIXED, ref_len=L, n_refs=2)
+    res = []
+    for sorted_input in (False, True):
+        with host.QcContext([L, 1000], lib=gpu_lib, max_read_len=300, gc_seed=3, sorted_input=sorted_input,
+                            facets=ffi.FACET_COVERAGE | ffi.FACET_GENERAL) as gpu:
+            step = batch or n
+            for lo in range(0, n, step):
+                db = gpu.synth_device_batch(cfg, lo, min(step, n - lo))
+                gpu.process_batch(db)
+            gpu.finalize()
+            res.append(gpu.results(["chr1", "chr2"]))
+    json_equal(res[0], res[1])

@@ -26,7 +26,8 @@ def sorted_sweep(lib, seeds):
     for seed in range(seeds):
         rng = np.random.default_rng(5000 + seed)
         n_refs = int(rng.integers(1, 4))
-        ref_len = [int(rng.integers(5_000, 600_000)) for _ in range(n_refs)]
+        # one seed in three on long sequences: sparse reads, a tile of 256 then owns dozens of LDS windows
+        ref_len = [int(rng.integers(5_000, 600_000 if seed % 3 else 30_000_000)) for _ in range(n_refs)]
         primary = [int(rng.random() < 0.85) for _ in range(n_refs)]
         n = int(rng.integers(300, 60_000))
         recs = []

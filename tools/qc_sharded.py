@@ -41,6 +41,7 @@ def main():
     ap.add_argument("-o", "--output-directory", default=".")
     ap.add_argument("--batch-records", type=int, default=1 << 21)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--coverage", choices=["stream", "array"], default="stream")
     ap.add_argument("--same-gpu", action="store_true", help="all ranks on GPU 0 (test boxes with one GPU)")
     a = ap.parse_args()
     import torch
@@ -78,7 +79,10 @@ def main():
         if n not in genome:
             raise SystemExit(f'Sequence "{n}" not found in specified reference genome. Did you set the correct reference genome?')
     ctx = host.QcContext(lens, [int(genome[n]) for n in names], facets=ffi.FACETS_DEFAULT, device=gpu,
-                         max_read_len=1024, gc_seed=0x4E4753, lib=lib)
+                         max_read_len=1024, gc_seed=0x4E4753,
+                         # the file is indexed, i.e. coordinate-sorted: Coverage streams; behind the first shard the
+                         # first Mi positions per sequence stay on the exchanged array (reads of the shard in front)
+                         sorted_input=a.coverage == "stream", cov_head_guard=(1 << 20) if rank else 0, lib=lib)
     views = shard.device_views(ctx, torch, gpu)
     h, info = shard.open_file_shard(lib, ctx._ctx, a.bam, rank, world, dist, torch, coll_device=coll or f"cuda:{gpu}")
     n = 0
