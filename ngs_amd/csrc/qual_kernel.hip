@@ -186,10 +186,13 @@ __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t
 // ---------------------------------------------------------------------------------------------
 // k_qual_ragged: the offsets layout (reads of different lengths packed back to back).
 // Same window-per-lane tally as k_qual_win, but the (record, window) of a lane comes from a
-// per-wave schedule: a wave takes 64 records, prefix-sums their window counts (DPP), and for every
-// batch of 64 consecutive windows each lane finds its record by a six-step binary search over the
-// prefix held across the lanes (ds_bpermute, no LDS memory).  Consecutive lanes therefore still read
-// consecutive 16-byte pieces of the byte stream.  The last window of a record (fewer than 16 bytes)
+// per-wave schedule: a wave takes 64 records, prefix-sums their window counts (DPP), and writes the
+// record (lane) of every window into a byte map in LDS (each record lane fills its own run: at most R
+// byte stores for the 64 records); for every batch of 64 consecutive windows a lane then reads its
+// record from the map and fetches that record's first window and byte offset from the record's lane
+// (two ds_bpermute).  Consecutive lanes therefore still read consecutive 16-byte pieces of the byte
+// stream.  (The first version searched the prefix with six dependent ds_bpermute steps per window and
+// gathered five values: eleven LDS-pipe operations beside the sixteen atomics of a window.)  The last window of a record (fewer than 16 bytes)
 // and windows with a score >= 64 take the exact path.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t qr_wave_inclusive_sum(uint32_t v) {
@@ -216,19 +219,30 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
     __syncthreads();
     char *const tab = reinterpret_cast<char *>(s_q);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint8_t *const map = reinterpret_cast<uint8_t *>(s_q + nb) + wave * (64u * R); // window -> record lane, this wave's
     const uint64_t per = (n_rec + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = min(per * blockIdx.x, n_rec), hi = min(lo + per, n_rec);
     const uint64_t end_bytes = n_rec ? qual_off[n_rec] : 0; // a 16-byte load must not run past this
     uint32_t bad = 0, too_long = 0;
 
+    // offsets of a wave's 64 records, loaded one group ahead (branch-free: past the end the last entry twice)
+    auto load_offs = [&](uint64_t i0, uint64_t &o0, uint64_t &o1) {
+        const uint64_t rec = i0 + lane;
+        o0 = qual_off[rec < n_rec ? rec : n_rec];
+        o1 = qual_off[rec + 1 < n_rec ? rec + 1 : n_rec];
+    };
+    uint64_t nx_o0 = 0, nx_o1 = 0;
+    if (lo + 64ull * wave < hi) load_offs(lo + 64ull * wave, nx_o0, nx_o1);
     for (uint64_t i0 = lo + 64ull * wave; i0 < hi; i0 += 64ull * 16) {
         // this wave's 64 records: offset, length (clamped to the table), windows
         const uint64_t rec = i0 + lane;
+        const uint64_t cur_o0 = nx_o0, cur_o1 = nx_o1;
+        load_offs(i0 + 64ull * 16, nx_o0, nx_o1);
         uint64_t off = 0;
         uint32_t len = 0;
         if (rec < hi) {
-            off = qual_off[rec];
-            const uint64_t l64 = qual_off[rec + 1] - off;
+            off = cur_o0;
+            const uint64_t l64 = cur_o1 - off;
             len = (uint32_t)min(l64, (uint64_t)st.max_read_len);
             too_long += l64 > st.max_read_len; // quality_scores.rs: the table is sized for max_read_len
         }
@@ -236,34 +250,42 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
         const uint32_t nwin = len >> 4;
         const uint32_t P = qr_wave_inclusive_sum(nwin); // whole windows of records 0..lane
         const uint32_t T = __builtin_amdgcn_readlane(P, 63);
-        const uint32_t off_lo = (uint32_t)off, off_hi = (uint32_t)(off >> 32);
-        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+        // byte offsets relative to the wave's first record (64 records of at most 16 R bytes: 32 bits)
+        const uint64_t off0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+        const uint32_t rel = rec < hi ? (uint32_t)(off - off0) : 0u;
+        const uint32_t first_win = P - nwin;
+        for (uint32_t j = 0; __ballot(j < nwin); j++) // nwin <= R
+            if (j < nwin) map[first_win + j] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the window of the NEXT step is in flight while this one is tallied (every lane loads: an idle lane
+        // re-reads the first window of the step, which is inside the buffer)
+        struct Sched {
+            uint32_t r, w;
+            bool active;
+            uint4 v;
+        };
+        auto fetch = [&](uint32_t t0) -> Sched {
+            Sched sc;
             const uint32_t t = t0 + lane;
-            const bool active = t < T;
-            // record of window t: the first lane whose inclusive prefix exceeds t
-            uint32_t a = 0, b = 63;
-#pragma unroll
-            for (int step = 0; step < 6; step++) {
-                const uint32_t mid = (a + b) >> 1;
-                const bool right = qr_from_lane(P, mid) <= t;
-                a = right ? mid + 1 : a;
-                b = right ? b : mid;
-            }
-            const uint32_t r = min(a, 63u);
-            const uint32_t before = qr_from_lane(P, r) - qr_from_lane(nwin, r);
-            const uint32_t w = t - before;
-            const uint32_t rl = qr_from_lane(len, r);
-            const uint64_t ro = ((uint64_t)qr_from_lane(off_hi, r) << 32) | qr_from_lane(off_lo, r);
+            sc.active = t < T;
+            sc.r = sc.active ? map[t] : map[t0 < T ? t0 : 0u]; // record of window t
+            sc.w = (sc.active ? t : (t0 < T ? t0 : 0u)) - qr_from_lane(first_win, sc.r);
+            const uint64_t at = off0 + qr_from_lane(rel, sc.r) + 16ull * sc.w;
+            __builtin_memcpy(&sc.v, qual + at, 16); // a whole window of a record: inside the buffer
+            return sc;
+        };
+        Sched nx{};
+        if (T) nx = fetch(0);
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const Sched cu = nx;
+            nx = fetch(t0 + 64 < T ? t0 + 64 : t0); // past the end: a re-read
+            const bool active = cu.active;
+            const uint32_t r = cu.r, w = cu.w;
             if (!active) continue;
-            (void)rl;
-            const uint64_t at = ro + 16ull * w;
             constexpr uint32_t nvalid = 16u;
-            uint32_t ww[4];
-            {
-                uint4 v;
-                __builtin_memcpy(&v, qual + at, 16); // a whole window of the record: inside the buffer
-                ww[0] = v.x, ww[1] = v.y, ww[2] = v.z, ww[3] = v.w;
-            }
+            const uint32_t ww[4] = {cu.v.x, cu.v.y, cu.v.z, cu.v.w};
             const uint32_t any = (ww[0] | ww[1] | ww[2] | ww[3]) & 0xC0C0C0C0u;
             if (__builtin_expect(any == 0u, 1)) {
                 const uint32_t wbase = 4u * w, rot = r & 3u;
@@ -307,6 +329,8 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the map is rewritten for the next 64 records
+        __builtin_amdgcn_wave_barrier();
         // pass B: the last, partial window of every record (lane = record): all lanes walk their bytes
         // together instead of a few lanes of every step above
         const uint32_t tail = len & 15u, wl = len >> 4;
@@ -349,7 +373,7 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
 
 template <uint32_t R>
 static hipError_t launch_ragged_r(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
-    const uint32_t lds = qual_window_lds_bytes(R);
+    const uint32_t lds = qual_window_lds_bytes(R) + 16u * 64u * R; // table + one window->record byte map per wave
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_ragged<R, 4>),
