@@ -51,9 +51,14 @@ def main() -> int:
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP event brackets")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed/RCCL path even with one rank (plumbing check)")
-    ap.add_argument("--coverage", choices=["stream", "array"], default="stream",
+    ap.add_argument("--coverage", choices=["auto", "stream", "array"], default="auto",
                     help="stream: sorted_input context, Coverage finishes positions while the sorted records stream by; "
-                         "array: difference arrays + teardown scan (any record order)")
+                         "array: difference arrays + teardown scan (any record order); auto: stream up to 0.5 records per "
+                         "reference position in the whole file (whole-genome depths: measured faster there), array above "
+                         "(the weak-scaling runs pile N x 100 M reads on chr1: DESIGN.md section 5.4)")
+    ap.add_argument("--emulate-shard", default="",
+                    help="R/W: on ONE GPU, scan the records shard R of a W-GPU run would scan (the W x --records file's "
+                         "slice, W times the depth, head guard as for rank R) -- kernel cost of a shard without the exchange")
     ap.add_argument("--facets", type=lambda x: int(x, 0), default=0x1F,
                     help="facet mask (default 0x1F = all default facets; 0x0E = BASELINE configs[1])")
     args = ap.parse_args()
@@ -94,15 +99,19 @@ def main() -> int:
     # the whole synthetic file has world * n records; this rank owns the contiguous
     # record range [rank*n, (rank+1)*n) = a contiguous BGZF block range of a sorted BAM
     # (weak scaling: ngs_amd.shard.shard_range(n * world, rank, world) == (rank * n, n))
-    scfg = host.synth_config(n * world, mode=ffi.SYNTH_MIXED if mixed else ffi.SYNTH_FIXED,
+    emu_rank, emu_world = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
+    scfg = host.synth_config(n * emu_world, mode=ffi.SYNTH_MIXED if mixed else ffi.SYNTH_FIXED,
                              read_len=args.read_len, ref_len=CHR1, n_refs=2)
+    if args.coverage == "auto":
+        args.coverage = "stream" if emu_world * n / CHR1 <= 0.5 else "array"
     ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=local_rank,
                          max_read_len=max_len, gc_seed=0x4E4753, timing=not args.no_timing,
                          sorted_input=args.coverage == "stream",
                          # shards behind the first: positions a read of the shard in front may still cover
-                         cov_head_guard=(1 << 20) if rank > 0 else 0, lib=lib)
+                         # (the synthetic reads span at most 5.3 kb; real files: tools/qc_sharded.py keeps 1 Mi)
+                         cov_head_guard=(1 << 16) if emu_rank > 0 else 0, lib=lib)
     t_gen = time.perf_counter()
-    db = ctx.synth_device_batch(scfg, rank * n, n)
+    db = ctx.synth_device_batch(scfg, emu_rank * n, n)
     t_gen = time.perf_counter() - t_gen
 
     views = None

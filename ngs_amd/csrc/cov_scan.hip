@@ -110,8 +110,16 @@ __global__ __launch_bounds__(CS_THREADS) void k_cov_scan(CovScanArgs a) {
         bins = a.bin_totals + a.bin_off[r];
     };
 
+    uint32_t zeros = 0; // positions of depth 0 this lane met on the current sequence
     auto flush_hist = [&](uint32_t r) { // wave-private: no barrier needed
         u64 *dst = a.hist + (u64)r * nb;
+        {
+            u64 z = zeros;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+            if (lane == 0 && z) atomicAdd(&dst[0], z);
+            zeros = 0;
+        }
         for (uint32_t i = lane; i < nb; i += 64) {
             const uint32_t v = my_hist[i];
             if (v) {
@@ -200,7 +208,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cov_scan(CovScanArgs a) {
             run += d[t];
             if (t < nvalid) {
                 const uint32_t depth = run;
-                atomicAdd(&my_hist[depth <= a.cov_cap ? depth : a.cov_cap + 1], 1u);
+                // depth 0 is counted in a register: in targeted data and on the untouched stretches of a shard
+                // every lane would queue on bin 0 (measured: the scan of a mostly empty axis took 1.8x as long)
+                zeros += depth == 0;
+                if (depth) atomicAdd(&my_hist[depth <= a.cov_cap ? depth : a.cov_cap + 1], 1u);
                 if (i0 + t != 0) {
                     bin_sum += depth;
                     rem += 1;

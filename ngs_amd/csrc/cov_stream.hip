@@ -40,7 +40,7 @@ typedef unsigned long long u64;
 constexpr uint32_t ST_THREADS = 256;
 constexpr uint32_t ST_WAVES = ST_THREADS / 64;
 constexpr uint32_t ST_W = 1024; // positions of one wave's LDS window
-constexpr uint32_t ST_LIST = 256; // entries of a wave's list of open ends (a deeper pile walks back instead)
+constexpr uint32_t ST_LIST = 448;  // entries of a wave's list of open ends (a deeper pile walks back instead)
 #ifndef ST_EXP
 #define ST_EXP 0 // measurement builds only (tools/exp_stream.sh): 1 no look-back, 2 no prefix passes, 3 no histogram atomics, 4 neither
 #endif
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
     int32_t hist_ref = -1;  // sequence the wave's histogram and bin accumulator belong to
     uint32_t since_flush = 0; // positions tallied since the histogram was last flushed (< 2^16 - ST_PASS)
     u64 zero_run = 0;         // positions of depth 0 skipped in closed form (wave-uniform)
+    uint32_t lane_zero = 0;   // positions of depth 0 this lane met inside the windows
     u64 *bins = a.bin_totals;
     u64 lane_bin = 0;                           // this lane's share of the depth sum of bin `bin_q`
     uint32_t bin_q = 0, bin_p0 = 1, bin_p1 = 0; // bin_q holds the positions [bin_p0, bin_p1)
@@ -201,29 +202,51 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                 hist[i] = 0;
             }
         }
-        if (lane == 0 && zero_run) atomicAdd(&dst[0], zero_run);
+        {
+            u64 z = lane_zero;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+            if (lane == 0 && zero_run + z) atomicAdd(&dst[0], zero_run + z);
+        }
         zero_run = 0;
+        lane_zero = 0;
         since_flush = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    // +1 at q0, -1 at q1 of the difference array starting at `off` (the classic path, cov_scan.hip)
-    auto classic = [&](uint64_t off, uint32_t q0, uint32_t q1, bool minus_in_sum_only) {
-        const uint64_t g0 = off + q0, g1 = off + q1;
-        atomicAdd(&st.depth[g0], 1u);
-        atomicAdd(&st.chunk_sums[g0 / COV_CHUNK], 1u);
-        if (!minus_in_sum_only) atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
-        atomicAdd(&st.chunk_sums[g1 / COV_CHUNK], 0xFFFFFFFFu);
-        t_lo = g0 < t_lo ? g0 : t_lo;
-        t_hi = g1 + 1 > t_hi ? g1 + 1 : t_hi;
+    // One chunk-sum update per wave for the lanes that share the leader's chunk (the rule in a sorted file: at
+    // 3 reads per position ten thousand records would otherwise queue on the same word); the others add on
+    // their own.  Convergent: every lane calls, `active` says whether it takes part.
+    auto chunk_add = [&](bool active, uint64_t chunk, uint32_t val) {
+        const u64 m = __ballot(active);
+        if (!m) return;
+        const uint32_t c0 = __shfl((uint32_t)chunk, __ffsll((long long)m) - 1, 64);
+        const bool same = active && (uint32_t)chunk == c0;
+        uint32_t sum = same ? val : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0 && sum) atomicAdd(&st.chunk_sums[c0], sum);
+        if (active && !same) atomicAdd(&st.chunk_sums[chunk], val);
     };
-    // the parts of [sj, ej) outside the streamed range [H, T) of its sequence
-    auto outside = [&](uint64_t off, uint32_t sj, uint32_t ej, uint32_t H, uint32_t T) {
-        if (sj < H) {
-            const uint32_t m = ej < H ? ej : H;
-            classic(off, sj, m, m == H);
+    // +1 at q0, -1 at q1 of the difference array starting at `off` (the classic path, cov_scan.hip); convergent
+    auto classic = [&](bool on, uint64_t off, uint32_t q0, uint32_t q1, bool minus_in_sum_only) {
+        const uint64_t g0 = off + q0, g1 = off + q1;
+        if (on) {
+            atomicAdd(&st.depth[g0], 1u);
+            if (!minus_in_sum_only) atomicAdd(&st.depth[g1], 0xFFFFFFFFu);
+            t_lo = g0 < t_lo ? g0 : t_lo;
+            t_hi = g1 + 1 > t_hi ? g1 + 1 : t_hi;
         }
-        if (T != CS_NONE && ej > T) classic(off, sj > T ? sj : T, ej, false);
+        chunk_add(on, g0 / COV_CHUNK, 1u);
+        chunk_add(on, g1 / COV_CHUNK, 0xFFFFFFFFu);
+    };
+    // the parts of [sj, ej) outside the streamed range [H, T) of its sequence; convergent
+    auto outside = [&](bool on, uint64_t off, uint32_t sj, uint32_t ej, uint32_t H, uint32_t T) {
+        const bool head = on && sj < H;
+        const uint32_t m = ej < H ? ej : H;
+        if (__ballot(head)) classic(head, off, sj, m, m == H);
+        const bool tl = on && T != CS_NONE && ej > T;
+        if (__ballot(tl)) classic(tl, off, sj > T ? sj : T, ej, false);
     };
 
     auto load_full = [&](uint64_t t) -> StTileIn { // t < n_full; branch-free
@@ -267,17 +290,19 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
                 const uint32_t ej = e[j] < Lr + 1 ? e[j] : Lr + 1;
-                if (e[j] != 0 && s[j] < ej && (s[j] < H || ej > T)) outside(off, s[j], ej, H, T);
+                const bool on = e[j] != 0 && s[j] < ej && (s[j] < H || ej > T);
+                if (__ballot(on)) outside(on, off, s[j], ej, H, T); // only tiles at a seam get here
             }
         } else {
             for (uint32_t j = 0; j < 4; j++) {
-                if (e[j] == 0) continue;
-                const int32_t rj = b.ref_id[r0 + j];
-                if (rj < 0 || (uint32_t)rj >= st.n_refs) continue;
-                const uint64_t oj = st.ref_depth_off[rj];
-                const uint32_t Lj = st.ref_len[rj];
+                const int32_t rj = e[j] != 0 ? b.ref_id[r0 + j] : -1;
+                const bool okr = rj >= 0 && (uint32_t)rj < st.n_refs;
+                const uint64_t oj = okr ? st.ref_depth_off[rj] : NO_DEPTH;
+                const uint32_t Lj = okr ? st.ref_len[rj] : 0u;
                 const uint32_t ej = e[j] < Lj + 1 ? e[j] : Lj + 1;
-                if (oj != NO_DEPTH && s[j] < ej) outside(oj, s[j], ej, a.plan_h[rj], a.plan_t[rj]);
+                const uint32_t hj = okr ? a.plan_h[rj] : CS_NONE, tj = okr ? a.plan_t[rj] : CS_NONE;
+                const bool on = oj != NO_DEPTH && s[j] < ej;
+                if (__ballot(on)) outside(on, oj == NO_DEPTH ? 0 : oj, s[j], ej, hj, tj);
             }
             return;
         }
@@ -413,8 +438,11 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                     const uint32_t i = pb + lane * PL + k;
                     const uint32_t depth = before + x[k];
                     const uint32_t bin = depth <= a.cov_cap ? depth : a.cov_cap + 1;
-                    const uint32_t one = i < len ? 1u : 0u;
-                    // (a dead lane adds 0 to a word of its own: the same word for all of them would serialise)
+                    // Depth 0 is counted in a register (targeted sequencing leaves most positions uncovered: every
+                    // lane would queue on bin 0).  A dead or zero lane adds 0 to a word of its own: the same word
+                    // for all of them would serialise just the same.
+                    lane_zero += i < len && depth == 0;
+                    const uint32_t one = i < len && depth != 0 ? 1u : 0u;
                     const uint32_t word = one ? (bin < hw ? bin : bin - hw) : lane;
                     if (ST_EXP != 3) atomicAdd(&hist[word], bin < hw ? one : one << 16);
                     lsum += i < len ? depth : 0u;
