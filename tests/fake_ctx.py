@@ -29,6 +29,7 @@ class FakeCtx:
         self.counters = np.zeros(8 + len(ref_len), dtype=np.uint64)  # [.. , seen per sequence]
         self.t_lo, self.t_hi = None, None
         self.scan = (0, self.n_chunks, 0)
+        self.flags = None  # sorted_input contexts: one byte per chunk, 1 = finished while streaming (state block 4)
 
     def add_reads(self, ref, starts, ends):
         """+1 at start, -1 at end+1 (1-based positions) for reads on sequence `ref`."""
@@ -42,9 +43,12 @@ class FakeCtx:
             self.counters[8 + ref] += 1
 
     def views(self):
-        return {"counters": torch.from_numpy(self.counters.view(np.int64)),
-                "depth": torch.from_numpy(self.depth.view(np.int32)),
-                "teardown": torch.from_numpy(self.td.view(np.int64))}
+        v = {"counters": torch.from_numpy(self.counters.view(np.int64)),
+             "depth": torch.from_numpy(self.depth.view(np.int32)),
+             "teardown": torch.from_numpy(self.td.view(np.int64))}
+        if self.flags is not None:
+            v["flags"] = torch.from_numpy(self.flags)
+        return v
 
     def synchronize(self):
         pass

@@ -197,7 +197,26 @@ def _owner_worker(rank, world, port, q, layout):
         fill(mine, first, first + cnt)
         if layout == "unsorted":
             shard.HALO_LIMIT_BYTES = 1 << 10  # force the all-reduce fallback
-        rep = shard.owner_teardown(mine, dist, torch, mine.views())
+        if layout.startswith("flags"):
+            # streaming contexts flag the chunks they finished on their own.  "flags_ok": a chunk no other rank
+            # wrote to; "flags_overlap": the first chunk this rank wrote -- the halo of the rank in front lands there
+            mine.flags = np.zeros(mine.n_chunks, dtype=np.uint8)
+            _, _, t_lo, t_hi = mine.depth_layout()
+            if layout == "flags_ok":
+                mid = (t_lo + t_hi) // 2 // 4096
+                mine.flags[mid] = 1 if not mine.depth[mid * 4096:(mid + 1) * 4096].any() else 0
+            elif rank > 0:
+                mine.flags[t_lo // 4096] = 1
+            try:
+                rep = shard.owner_teardown(mine, dist, torch, mine.views())
+                assert layout == "flags_ok", "an exchanged entry in a finished chunk was accepted"
+            except RuntimeError as e:
+                assert layout == "flags_overlap" and "overlap" in str(e), e
+                dist.barrier()
+                dist.destroy_process_group()
+                q.put((rank, "ok"))
+                return
+        rep = shard.owner_teardown(mine, dist, torch, mine.views()) if not layout.startswith("flags") else rep
         assert rep["mode"] == ("allreduce" if layout == "unsorted" else "owner"), rep
         assert (mine.td == whole.td).all(), "teardown results differ from the single-context scan"
         assert (mine.counters == whole.counters).all()
@@ -209,7 +228,8 @@ def _owner_worker(rank, world, port, q, layout):
         q.put((rank, "FAIL " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,layout", [(2, "sorted"), (3, "sorted"), (3, "empty_rank"), (2, "unsorted")])
+@pytest.mark.parametrize("world,layout", [(2, "sorted"), (3, "sorted"), (3, "empty_rank"), (2, "unsorted"),
+                                          (3, "flags_ok"), (3, "flags_overlap")])
 def test_owner_teardown_gloo(world, layout):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
