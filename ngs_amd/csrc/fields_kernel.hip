@@ -138,8 +138,10 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         if (a.do_tlen) r.tlen = *reinterpret_cast<const int4 *>(b.tlen + r0);
         if (a.do_cov) r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
         r.prev_ref = r.prev_pos = 0;
-        if (STREAM) { // unconditional (same cache lines as the vector loads of the neighbouring lane)
-            const uint64_t pi = r0 ? r0 - 1 : 0;
+        if (STREAM) { // the record in front of the WAVE's first one: a wave-uniform address, i.e. a scalar load;
+                      // the other lanes take their predecessor from the neighbouring lane (process())
+            const uint64_t w0 = tile * FT_TILE + (uint64_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * 256;
+            const uint64_t pi = w0 ? w0 - 1 : 0;
             r.prev_ref = b.ref_id[pi];
             r.prev_pos = b.pos[pi];
         }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
     // facts of the sequence the window was last anchored on (reloaded only when it changes)
     int32_t meta_ref = -1;
     uint64_t meta_off = NO_DEPTH, meta_L = 0;
-    auto process = [&](const FtRaw &raw, uint64_t tile, uint32_t nrec) {
+    auto process = [&](const FtRaw &raw, uint64_t tile, uint32_t nrec, bool full_tile) {
         const uint64_t r0 = tile * FT_TILE + (uint64_t)tid * FT_PER_THREAD;
         const uint32_t flag[4] = {raw.flag.x & 0xFFFFu, raw.flag.x >> 16, raw.flag.y & 0xFFFFu, raw.flag.y >> 16};
         const uint32_t ncig[4] = {raw.ncig.x & 0xFFFFu, raw.ncig.x >> 16, raw.ncig.y & 0xFFFFu, raw.ncig.y >> 16};
@@ -231,6 +233,10 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 return rf < 0 ? 0xFFFFFFFF00000000ull : ((u64)(uint32_t)rf << 32) | (uint32_t)(ps + 1);
             };
             u64 kp = key(raw.prev_ref, raw.prev_pos);
+            if (full_tile) { // raw.prev_* is the wave's predecessor: lanes 1.. look at the lane in front
+                const int32_t nr = __shfl_up(ref[3], 1, 64), np_ = __shfl_up(pos[3], 1, 64);
+                if (lane) kp = key(nr, np_);
+            }
 #pragma unroll
             for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
                 const u64 kj = key(ref[j], pos[j]);
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             const uint64_t nt = tile + gridDim.x;
             // branch-free prefetch of this block's next full tile (past the end: re-read this one)
             const FtRaw nxt = load_tile(nt < n_full ? nt : tile);
-            process(cur, tile, FT_PER_THREAD);
+            process(cur, tile, FT_PER_THREAD, true);
             cur = nxt;
             tile = nt;
         }
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
     if (tile == n_full && n_full < n_tiles) { // the partial tile belongs to exactly one block
         uint32_t nrec = 0;
         const FtRaw tail = load_tail(tile, nrec);
-        process(tail, tile, nrec);
+        process(tail, tile, nrec, false);
     }
 
     // ---- block epilogue
