@@ -46,6 +46,7 @@ def main() -> int:
     ap.add_argument("--records", type=int, default=100_000_000, help="records per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--workload", choices=["fixed", "mixed"], default="fixed")
+    ap.add_argument("--mixed-max-len", type=int, default=300, help="longest read of --workload mixed (50..N bp)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000,
                     help="records of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP event brackets")
@@ -95,13 +96,13 @@ def main() -> int:
 
     n = args.records
     mixed = args.workload == "mixed"
-    max_len = 300 if mixed else args.read_len
+    max_len = args.mixed_max_len if mixed else args.read_len
     # the whole synthetic file has world * n records; this rank owns the contiguous
     # record range [rank*n, (rank+1)*n) = a contiguous BGZF block range of a sorted BAM
     # (weak scaling: ngs_amd.shard.shard_range(n * world, rank, world) == (rank * n, n))
     emu_rank, emu_world = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
     scfg = host.synth_config(n * emu_world, mode=ffi.SYNTH_MIXED if mixed else ffi.SYNTH_FIXED,
-                             read_len=args.read_len, ref_len=CHR1, n_refs=2)
+                             read_len=args.read_len, max_len=args.mixed_max_len, ref_len=CHR1, n_refs=2)
     if args.coverage == "auto":
         args.coverage = "stream" if emu_world * n / CHR1 <= 0.5 else "array"
     ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=local_rank,
