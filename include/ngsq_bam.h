@@ -33,6 +33,19 @@ void ngsq_bam_close(ngsq_bam *bam);
  * (magic, per-reference bins/chunks and linear index, optional n_no_coor). */
 int ngsq_bam_check_index(const char *bam_path);
 
+/* Region queries of the sequence-based pass (qc/command.rs:356-397: `reader.query(&header, &index, &region)` with
+ * the region = one whole reference sequence).  In a coordinate-sorted file the records of a sequence are contiguous,
+ * so the query is: the smallest chunk begin the index holds for the sequence, a seek, and sequential reads until the
+ * sequence changes.
+ *   ngsq_bam_index_ref_starts  start_voffset[r] = smallest virtual offset (block file offset << 16 | offset in the
+ *                              block's data) of any chunk of reference r, 0 when the index holds none;
+ *                              *n_bins = bins with records over all references (0: an index without bins, as some
+ *                              writers produce for empty files -- scan the file instead)
+ *   ngsq_bam_seek              continue ngsq_bam_next_batch (host reader) at a record boundary given as a virtual
+ *                              offset; first_record_index of later batches then counts from that point only */
+int ngsq_bam_index_ref_starts(const char *bam_path, uint32_t n_refs, uint64_t *start_voffset, uint64_t *n_bins);
+int ngsq_bam_seek(ngsq_bam *bam, uint64_t voffset);
+
 uint32_t ngsq_bam_n_refs(const ngsq_bam *bam);
 const char *ngsq_bam_ref_name(const ngsq_bam *bam, uint32_t i);
 uint32_t ngsq_bam_ref_len(const ngsq_bam *bam, uint32_t i);

@@ -416,7 +416,10 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     return NGSQ_OK;
 }
 
-int ngsq_bam_check_index(const char *bam_path) {
+// spec 5.2: magic "BAI\1", n_ref, per ref: n_bin {bin u32, n_chunk i32, chunks 16 B each}, n_intv, ioffsets.
+// starts (optional, [n_starts]): smallest chunk begin of each reference (0: nothing indexed); bins (optional): number
+// of bins that hold records, the metadata pseudo-bin 37450 not counted.
+static int parse_bai(const char *bam_path, uint32_t n_starts, uint64_t *starts, uint64_t *bins) {
     if (!bam_path) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
     const std::string p = std::string(bam_path) + ".bai";
     FILE *f = fopen(p.c_str(), "rb");
@@ -426,22 +429,31 @@ int ngsq_bam_check_index(const char *bam_path) {
     size_t g;
     while ((g = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + g);
     fclose(f);
-    // spec 5.2: magic "BAI\1", n_ref, per ref: n_bin {bin u32, n_chunk i32, chunks 16 B each}, n_intv, ioffsets
     size_t q = 0;
     auto need = [&](size_t k) { return q + k <= d.size(); };
+    auto rd64 = [&](size_t at) { return (uint64_t)rd32(d.data() + at) | ((uint64_t)rd32(d.data() + at + 4) << 32); };
     if (!need(8) || memcmp(d.data(), "BAI\1", 4) != 0)
         return bfail(NGSQ_ERR_INVALID_ARGUMENT, "reading BAM index: invalid BAI magic in %s", p.c_str());
     const uint32_t n_ref = rd32(d.data() + 4);
     q = 8;
+    if (bins) *bins = 0;
+    for (uint32_t r = 0; r < n_starts; r++) starts[r] = 0;
     for (uint32_t r = 0; r < n_ref; r++) {
         if (!need(4)) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "reading BAM index: truncated (bins of reference %u)", r);
         const uint32_t n_bin = rd32(d.data() + q);
         q += 4;
         for (uint32_t k = 0; k < n_bin; k++) {
             if (!need(8)) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "reading BAM index: truncated bin");
-            const uint32_t n_chunk = rd32(d.data() + q + 4);
+            const uint32_t bin = rd32(d.data() + q), n_chunk = rd32(d.data() + q + 4);
             q += 8;
             if (!need((size_t)n_chunk * 16)) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "reading BAM index: truncated chunks");
+            if (bin != 37450u) { // 37450: samtools' metadata pseudo-bin
+                if (bins) *bins += 1;
+                for (uint32_t c = 0; c < n_chunk; c++) {
+                    const uint64_t beg = rd64(q + (size_t)c * 16);
+                    if (r < n_starts && (starts[r] == 0 || beg < starts[r])) starts[r] = beg;
+                }
+            }
             q += (size_t)n_chunk * 16;
         }
         if (!need(4)) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "reading BAM index: truncated (intervals)");
@@ -452,6 +464,34 @@ int ngsq_bam_check_index(const char *bam_path) {
     }
     if (q != d.size() && q + 8 != d.size())
         return bfail(NGSQ_ERR_INVALID_ARGUMENT, "reading BAM index: trailing bytes in %s", p.c_str());
+    return NGSQ_OK;
+}
+
+int ngsq_bam_check_index(const char *bam_path) { return parse_bai(bam_path, 0, nullptr, nullptr); }
+
+int ngsq_bam_index_ref_starts(const char *bam_path, uint32_t n_refs, uint64_t *start_voffset, uint64_t *n_bins) {
+    if (n_refs && !start_voffset) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    return parse_bai(bam_path, n_refs, start_voffset, n_bins);
+}
+
+int ngsq_bam_seek(ngsq_bam *b, uint64_t voffset) {
+    if (!b) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (b->dev) return bfail(NGSQ_ERR_STATE, "%s: this reader is in device ingest mode", b->path.c_str());
+    if (fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET) != 0)
+        return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: cannot seek to block %llu", b->path.c_str(), (unsigned long long)(voffset >> 16));
+    b->comp.clear();
+    b->data.clear();
+    b->data_pos = 0;
+    b->data_base = 0;
+    b->eof = false;
+    b->read_chunk = (size_t)4 << 20; // a query usually wants a few records: read little at a time
+    const size_t in_block = (size_t)(voffset & 0xFFFFu);
+    const int rc = ensure(b, in_block + 1);
+    if (rc) return rc;
+    if (b->data.size() < in_block) // == : the offset points at the end of the data (no record follows)
+        return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: virtual offset %llu lies outside its block", b->path.c_str(),
+                     (unsigned long long)voffset);
+    b->data_pos = in_block;
     return NGSQ_OK;
 }
 

@@ -582,9 +582,21 @@ int main(int argc, char **argv) {
         //         counter has reached n, so every later sequence still processes ONE record.
         std::vector<std::vector<unsigned long long>> yielded(n_refs); // file indices, first max(n,1) per sequence
         const unsigned long long keep = std::max<unsigned long long>(a.n, 1);
+        // With a real index the sequence pass does what the reference does (command.rs:356-397): one region query
+        // per sequence -- the index gives the first record of the sequence, the reader seeks there and stops at
+        // the counter or at the next sequence -- and nothing else of the file is read.  An index without bins
+        // (nothing to look up) falls back to one scan of the file.
+        std::vector<uint64_t> ref_start(n_refs, 0);
+        uint64_t index_bins = 0;
+        if (seq_facets && ngsq_bam_index_ref_starts(a.src.c_str(), n_refs, ref_start.data(), &index_bins) != NGSQ_OK)
+            bail(ngsq_bam_last_error());
+        const bool by_index = seq_facets && index_bins > 0;
         for (;;) {
             ngsq_batch b;
-            if (ngsq_bam_next_batch(bam, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
+            // (when only the first `keep` records are wanted from this loop, do not decode a whole batch)
+            const unsigned long long want = (!seq_facets || by_index) ? std::min<unsigned long long>(a.batch_records, keep - std::min(keep, n_pass1) + 1)
+                                                                      : a.batch_records;
+            if (ngsq_bam_next_batch(bam, want, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
             if (!b.n_records) break;
             if (rec_facets && (n_pass1 < keep)) {
                 const unsigned long long take = std::min<unsigned long long>(b.n_records, keep - n_pass1);
@@ -595,15 +607,47 @@ int main(int argc, char **argv) {
                 CHECK(ctx, ngsq_process_batch(ctx, &cb, NGSQ_PASS_RECORD));
                 n_pass1 += take;
             }
-            if (seq_facets)
+            if (seq_facets && !by_index)
                 for (unsigned long long i = 0; i < b.n_records; i++)
                     if (query_yields(b, i, ref_len)) {
                         auto &v = yielded[b.ref_id[i]];
                         if (v.size() < keep) v.push_back(b.first_record_index + i);
                     }
-            if (!seq_facets && n_pass1 >= keep) break;
+            if ((!seq_facets || by_index) && n_pass1 >= keep) break;
+            if (!rec_facets && by_index) break;
         }
-        if (seq_facets) {
+        if (by_index) {
+            Compact c;
+            unsigned long long counter = 0, queries = 0;
+            for (uint32_t r = 0; r < n_refs; r++) {
+                if (!ref_start[r]) continue; // the index holds nothing for this sequence
+                if (ngsq_bam_seek(bam, ref_start[r]) != NGSQ_OK) bail(ngsq_bam_last_error());
+                queries += 1;
+                bool done = false;
+                while (!done) {
+                    ngsq_batch b;
+                    if (ngsq_bam_next_batch(bam, std::min<unsigned long long>(a.batch_records, 4096), &b) != NGSQ_OK)
+                        bail(ngsq_bam_last_error());
+                    if (!b.n_records) break;
+                    for (unsigned long long i = 0; i < b.n_records && !done; i++) {
+                        if (b.ref_id[i] != (int32_t)r) { // the sorted file has moved on (the chunk may begin a little early)
+                            done = b.ref_id[i] > (int32_t)r || b.ref_id[i] < 0;
+                            continue;
+                        }
+                        if (!query_yields(b, i, ref_len)) continue;
+                        c.push(b, i);
+                        counter += 1;
+                        if (counter >= a.n) done = true; // one counter over all sequences: command.rs:354,384-388
+                    }
+                }
+            }
+            logf(3, "  [*] %llu region queries through the index.", queries);
+            if (!c.flag.empty()) {
+                ngsq_batch cb = c.batch();
+                cb.first_record_index = 0; // sequence facets do not use the record index
+                CHECK(ctx, ngsq_process_batch(ctx, &cb, NGSQ_PASS_SEQUENCE));
+            }
+        } else if (seq_facets) {
             std::set<unsigned long long> picks;
             unsigned long long counter = 0;
             for (uint32_t r = 0; r < n_refs; r++)

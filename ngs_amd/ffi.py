@@ -256,6 +256,8 @@ PROTOTYPES = {
     "ngsq_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ngsq_bam_close": (None, [C.c_void_p]),
     "ngsq_bam_check_index": (C.c_int, [C.c_char_p]),
+    "ngsq_bam_index_ref_starts": (C.c_int, [C.c_char_p, C.c_uint32, u64p, u64p]),
+    "ngsq_bam_seek": (C.c_int, [C.c_void_p, C.c_uint64]),
     "ngsq_bam_n_refs": (C.c_uint32, [C.c_void_p]),
     "ngsq_bam_ref_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "ngsq_bam_ref_len": (C.c_uint32, [C.c_void_p, C.c_uint32]),

@@ -54,16 +54,63 @@ def record_bytes(hb, i: int, name: bytes = b"r") -> bytes:
     return struct.pack("<I", len(body)) + body
 
 
+def _ref_span(hb, i: int) -> int:
+    o0, o1 = int(hb.cols["cigar_off"][i]), int(hb.cols["cigar_off"][i + 1])
+    return sum(int(c) >> 4 for c in hb.cols["cigar"][o0:o1] if (int(c) & 15) in (0, 2, 3, 7, 8))
+
+
+def write_bai(path: str, hb, n_refs: int, rec_voff: Sequence[int], end_voff: int) -> None:
+    """A real BAI (SAM spec 5.2) for the records of `hb` written at the virtual offsets `rec_voff`: binning index
+    (adjacent records of a bin merged into one chunk) and 16 kb linear index, as samtools index writes them."""
+    bins = [dict() for _ in range(n_refs)]
+    lin = [dict() for _ in range(n_refs)]
+    n_no_coor = 0
+    for i in range(hb.n):
+        r, pos = int(hb.cols["ref_id"][i]), int(hb.cols["pos"][i])
+        if r < 0 or pos < 0:
+            n_no_coor += 1
+            continue
+        end = pos + max(_ref_span(hb, i), 1)
+        v0, v1 = rec_voff[i], rec_voff[i + 1] if i + 1 < hb.n else end_voff
+        chunks = bins[r].setdefault(reg2bin(pos, end), [])
+        if chunks and chunks[-1][1] == v0:
+            chunks[-1][1] = v1
+        else:
+            chunks.append([v0, v1])
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            lin[r][w] = min(lin[r].get(w, v0), v0)
+    with open(path, "wb") as f:
+        f.write(b"BAI\1" + struct.pack("<i", n_refs))
+        for r in range(n_refs):
+            f.write(struct.pack("<i", len(bins[r])))
+            for b in sorted(bins[r]):
+                f.write(struct.pack("<Ii", b, len(bins[r][b])))
+                for c0, c1 in bins[r][b]:
+                    f.write(struct.pack("<QQ", c0, c1))
+            n_intv = max(lin[r]) + 1 if lin[r] else 0
+            f.write(struct.pack("<i", n_intv))
+            last = 0
+            for w in range(n_intv):
+                last = lin[r].get(w, last)
+                f.write(struct.pack("<Q", last))
+        f.write(struct.pack("<Q", n_no_coor))
+
+
 def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], block_payload: int = 60000,
-              with_index: bool = True, sort_order: str = "coordinate") -> None:
+              with_index: bool = True, sort_order: str = "coordinate", real_index: bool = False) -> None:
     text = f"@HD\tVN:1.6\tSO:{sort_order}\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(ref_names, ref_len))
     head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(ref_names))
     for n, l in zip(ref_names, ref_len):
         head += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
     out: List[bytes] = []
     cur = bytearray(head)
+    rec_at = []  # (block number, offset in the block's data) of every record
     for i in range(hb.n):
         rec = record_bytes(hb, i)
+        if len(cur) >= block_payload:  # a record starts in the block that holds its first byte
+            out.append(bgzf_block(bytes(cur)))
+            cur = bytearray()
+        rec_at.append((len(out), len(cur)))
         while len(cur) + len(rec) > block_payload:  # records may straddle blocks
             take = block_payload - len(cur)
             cur += rec[:take]
@@ -76,7 +123,12 @@ def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], b
     out.append(EOF_BLOCK)
     with open(path, "wb") as f:
         f.write(b"".join(out))
-    if with_index:
+    if with_index and real_index:
+        starts = [0]
+        for blk in out:
+            starts.append(starts[-1] + len(blk))
+        write_bai(path + ".bai", hb, len(ref_names), [(starts[k] << 16) | u for k, u in rec_at], starts[len(out) - 1] << 16)
+    elif with_index:
         # a structurally valid BAI without bins (the hot path scans the file once; the index is
         # only required to exist and parse: utils/formats/bam.rs:86-96)
         with open(path + ".bai", "wb") as f:

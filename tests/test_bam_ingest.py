@@ -135,3 +135,41 @@ def test_synthetic_bam_writer_round_trip(lib, tmp_path):
         assert got == records_of(host.synth_host_batch(cfg, 0, 20_000, lib))
         if mode == ffi.SYNTH_FIXED:
             assert batches[0].qual_stride == 150 and batches[0].cigar_stride == 1
+
+
+def test_index_region_query_by_seek(lib, tmp_path):
+    """The whole-sequence region query of the sequence pass (command.rs:369-373): the BAI gives the first chunk of a
+    sequence, ngsq_bam_seek continues the reader there, and the records that follow are the sequence's, in file order."""
+    from tests.util import coordinate_sorted
+    rng = np.random.default_rng(12)
+    ref_len = [40_000, 500, 25_000, 9_000]              # nothing will map to sequence 1
+    hb = random_batch(rng, 6000, ref_len, max_len=120, weird=False)
+    hb.cols["ref_id"][hb.cols["ref_id"] == 1] = 2
+    hb = coordinate_sorted(hb)
+    names = [f"s{i}" for i in range(4)]
+    p = str(tmp_path / "q.bam")
+    bamio.write_bam(p, hb, names, ref_len, block_payload=2500, real_index=True)   # records straddle many small blocks
+    assert lib.ngsq_bam_check_index(p.encode()) == 0
+    starts = (C.c_uint64 * 4)()
+    bins = C.c_uint64()
+    assert lib.ngsq_bam_index_ref_starts(p.encode(), 4, starts, C.byref(bins)) == 0
+    assert bins.value > 4 and starts[1] == 0 and all(starts[r] for r in (0, 2, 3))
+    ref = hb.cols["ref_id"]
+    h = C.c_void_p()
+    assert lib.ngsq_bam_open(p.encode(), 2, C.byref(h)) == 0
+    for r in (3, 0, 2):                                  # any order: every query is a seek
+        assert lib.ngsq_bam_seek(h, starts[r]) == 0, lib.ngsq_bam_last_error()
+        first = int(np.argmax((ref == r) & (hb.cols["pos"] >= 0)))
+        b = ffi.Batch()
+        assert lib.ngsq_bam_next_batch(h, 50, C.byref(b)) == 0
+        got = copy_batch(b)
+        n_same = min(50, int((ref[first:first + 50] == r).sum()))
+        for col in ("ref_id", "pos", "flag", "tlen"):
+            np.testing.assert_array_equal(got.cols[col][:n_same], hb.cols[col][first:first + n_same], err_msg=f"{col} of sequence {r}")
+    assert lib.ngsq_bam_seek(h, (10 ** 9) << 16) == 0     # beyond the end of the file: nothing follows
+    b = ffi.Batch()
+    assert lib.ngsq_bam_next_batch(h, 50, C.byref(b)) == 0 and b.n_records == 0
+    lib.ngsq_bam_close(h)
+    # an index without bins: nothing to look up
+    bamio.write_bam(p, hb, names, ref_len)
+    assert lib.ngsq_bam_index_ref_starts(p.encode(), 4, starts, C.byref(bins)) == 0 and bins.value == 0

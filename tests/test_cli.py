@@ -101,15 +101,19 @@ def test_end_to_end(ngs, gpu_lib, oracle_mod, tmp_path, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("index", ["bare", "real"])
 @pytest.mark.parametrize("n", [0, 1, 7, 300, 100_000])
-def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n):
+def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n, index):
     """-n: pass 1 stops after n records; pass 2 shares ONE counter over all sequences, so every
-    sequence after the n-th record still processes one record (command.rs:354,384-388)."""
+    sequence after the n-th record still processes one record (command.rs:354,384-388).  With a real BAI the
+    sequence pass runs as region queries through the index (seek to the sequence's first chunk); with an index
+    that holds no bins it scans the file: same document."""
     hb = sorted_batch(5, 2500)
     bam = str(tmp_path / "s.bam")
-    bamio.write_bam(bam, hb, NAMES, LENS)
-    r = run(ngs, "-q", "qc", bam, GENOME, "-n", str(n), "-o", str(tmp_path), "--batch-records", "999")
+    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=3000 if index == "real" else 60000, real_index=index == "real")
+    r = run(ngs, "-v", "qc", bam, GENOME, "-n", str(n), "-o", str(tmp_path), "--batch-records", "999")
     assert r.returncode == 0, r.stderr
+    assert ("region queries through the index" in r.stderr) == (index == "real")
     got = json.load(open(tmp_path / "s.bam.results.json"))
     # emulate the reference driver on the record list
     c = hb.cols
