@@ -1,11 +1,13 @@
 // synth_bam.cpp -- write the synthetic records of include/ngsq_shared.h as a real BGZF BAM
-// (+ a minimal BAI) so that the file-to-JSON path of `ngs qc` can be measured at size.
+// (+ its BAI: binning and linear index, SAM spec 5.2) so that the file-to-JSON path of `ngs qc`,
+// including the region queries of `-n`, can be measured at size.
 // Bench / test utility (the reference's `ngs generate` writes FASTQ from a FASTA with an
 // unseeded RNG, src/generate/command.rs:59-131, and cannot produce these files).
 #include <zlib.h>
 
 #include <atomic>
 #include <cstdio>
+#include <map>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -33,14 +35,23 @@ uint32_t reg2bin(int64_t beg, int64_t end) { // SAM spec 5.3
     return 0;
 }
 
-void append_record(std::vector<uint8_t> &out, const ngsq_synth_config &cfg, uint64_t i) {
+struct RecIdx { // what the index needs to know about one record
+    int32_t ref, pos, end; // end: exclusive, at least pos + 1
+    uint32_t uoff;         // offset of the record in its block's data
+};
+
+void append_record(std::vector<uint8_t> &out, const ngsq_synth_config &cfg, uint64_t i, RecIdx *ix) {
     ngsq_synth_record r;
     ngsq_synth_record_at(&cfg, i, &r);
+    ix->uoff = (uint32_t)out.size();
     char name[32];
     const int ln = snprintf(name, sizeof name, "r%llu", (unsigned long long)i) + 1;
     uint64_t span = 0;
     for (uint32_t k = 0; k < r.n_cigar; k++)
         if ((0x18Du >> (r.cigar[k] & 15)) & 1u) span += r.cigar[k] >> 4;
+    ix->ref = r.ref_id;
+    ix->pos = r.pos;
+    ix->end = r.pos + (int32_t)(span ? span : 1);
     const uint32_t l = r.l_seq;
     const uint32_t block = 32 + (uint32_t)ln + 4 * r.n_cigar + (l + 1) / 2 + l;
     put32(out, block);
@@ -111,6 +122,27 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
         put32(head, lens[r]);
     }
     bool ok = bgzf_write(f, head.data(), head.size(), level, scratch);
+    // ---- index under construction (records arrive in file order)
+    std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins(n_refs);
+    std::vector<std::vector<uint64_t>> linear(n_refs);
+    uint64_t n_no_coor = 0;
+    uint64_t file_off = (uint64_t)ftello(f); // where the next block starts
+    auto index_record = [&](const RecIdx &x, uint64_t v0, uint64_t v1) {
+        if (x.ref < 0 || (uint32_t)x.ref >= n_refs || x.pos < 0) {
+            n_no_coor += 1;
+            return;
+        }
+        auto &chunks = bins[x.ref][reg2bin(x.pos, x.end)];
+        if (!chunks.empty() && chunks.back().second == v0)
+            chunks.back().second = v1; // the records of a bin that follow each other share a chunk
+        else
+            chunks.emplace_back(v0, v1);
+        auto &lin = linear[x.ref];
+        const size_t w1 = (size_t)((x.end - 1) >> 14);
+        if (lin.size() <= w1) lin.resize(w1 + 1, 0);
+        for (size_t w = (size_t)(x.pos >> 14); w <= w1; w++)
+            if (lin[w] == 0) lin[w] = v0; // file order: the first record that overlaps the window
+    };
     // ---- records: groups of records rendered and deflated in parallel, written in order
     const int nt = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
     const uint64_t group = 100; // records per BGZF block (100 x ~270 B < 64 KiB even at 300 bp)
@@ -119,6 +151,7 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
     for (uint64_t g0 = 0; g0 < n_groups && ok; g0 += wave) {
         const uint64_t g1 = std::min(n_groups, g0 + wave);
         std::vector<std::vector<uint8_t>> blocks(g1 - g0);
+        std::vector<std::vector<RecIdx>> recs(g1 - g0);
         std::atomic<uint64_t> next{g0};
         std::atomic<int> bad{0};
         auto worker = [&]() {
@@ -127,7 +160,11 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
                 const uint64_t g = next.fetch_add(1);
                 if (g >= g1) break;
                 raw.clear();
-                for (uint64_t i = g * group; i < std::min(n_records, (g + 1) * group); i++) append_record(raw, *cfg, i);
+                auto &rx = recs[g - g0];
+                for (uint64_t i = g * group; i < std::min(n_records, (g + 1) * group); i++) {
+                    rx.emplace_back();
+                    append_record(raw, *cfg, i, &rx.back());
+                }
                 // deflate into a memory "file"
                 z_stream zs;
                 memset(&zs, 0, sizeof zs);
@@ -157,24 +194,47 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
         worker();
         for (auto &t : pool) t.join();
         if (bad) ok = false;
-        for (auto &b : blocks)
-            if (ok && fwrite(b.data(), 1, b.size(), f) != b.size()) ok = false;
+        for (size_t k = 0; k < blocks.size() && ok; k++) {
+            const auto &b = blocks[k];
+            if (fwrite(b.data(), 1, b.size(), f) != b.size()) ok = false;
+            const uint64_t next_off = file_off + b.size();
+            const auto &rx = recs[k];
+            for (size_t j = 0; j < rx.size(); j++)
+                index_record(rx[j], (file_off << 16) | rx[j].uoff, j + 1 < rx.size() ? (file_off << 16) | rx[j + 1].uoff : next_off << 16);
+            file_off = next_off;
+        }
     }
     static const uint8_t eof_block[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0,
                                           0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (ok && fwrite(eof_block, 1, 28, f) != 28) ok = false;
     fclose(f);
     if (!ok) return NGSQ_ERR_INVALID_ARGUMENT;
-    // ---- minimal, well-formed BAI (the scan reads the file once; the index must exist and parse)
+    // ---- the BAI: per reference the bins with their chunks, then the 16 kb linear index (gaps carry the previous value)
     FILE *bi = fopen((std::string(path) + ".bai").c_str(), "wb");
     if (!bi) return NGSQ_ERR_INVALID_ARGUMENT;
     std::vector<uint8_t> idx = {'B', 'A', 'I', 1};
+    auto put64 = [&](uint64_t x) {
+        for (int k = 0; k < 8; k++) idx.push_back((uint8_t)(x >> (8 * k)));
+    };
     put32(idx, n_refs);
     for (uint32_t r = 0; r < n_refs; r++) {
-        put32(idx, 0);
-        put32(idx, 0);
+        put32(idx, (uint32_t)bins[r].size());
+        for (const auto &kv : bins[r]) {
+            put32(idx, kv.first);
+            put32(idx, (uint32_t)kv.second.size());
+            for (const auto &c : kv.second) {
+                put64(c.first);
+                put64(c.second);
+            }
+        }
+        put32(idx, (uint32_t)linear[r].size());
+        uint64_t last = 0;
+        for (uint64_t v : linear[r]) {
+            if (v) last = v;
+            put64(last);
+        }
     }
-    for (int k = 0; k < 8; k++) idx.push_back(0);
+    put64(n_no_coor);
     fwrite(idx.data(), 1, idx.size(), bi);
     fclose(bi);
     return NGSQ_OK;

@@ -173,3 +173,82 @@ def test_index_region_query_by_seek(lib, tmp_path):
     # an index without bins: nothing to look up
     bamio.write_bam(p, hb, names, ref_len)
     assert lib.ngsq_bam_index_ref_starts(p.encode(), 4, starts, C.byref(bins)) == 0 and bins.value == 0
+
+
+def _parse_bai(path, n_refs):
+    import struct
+    d = open(path, "rb").read()
+    assert d[:4] == b"BAI\1" and struct.unpack_from("<i", d, 4)[0] == n_refs
+    q, out = 8, []
+    for _ in range(n_refs):
+        (n_bin,) = struct.unpack_from("<i", d, q)
+        q += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", d, q)
+            q += 8
+            bins[b] = [struct.unpack_from("<QQ", d, q + 16 * k) for k in range(n_chunk)]
+            q += 16 * n_chunk
+        (n_intv,) = struct.unpack_from("<i", d, q)
+        q += 4
+        lin = list(struct.unpack_from(f"<{n_intv}Q", d, q))
+        q += 8 * n_intv
+        out.append((bins, lin))
+    assert q + 8 == len(d)
+    return out, struct.unpack_from("<Q", d, q)[0]
+
+
+def test_synthetic_bam_writer_index_follows_the_spec(lib, tmp_path):
+    """The BAI of ngsq_synth_write_bam (SAM spec 5.2): every placed record lies inside a chunk of ITS bin
+    (reg2bin of [pos, end)), chunks are record-aligned and ordered, and the linear index of a 16 kb window holds the
+    virtual offset of the first record that overlaps it."""
+    import struct
+    import zlib
+    n = 12_000
+    cfg = host.synth_config(n, mode=ffi.SYNTH_MIXED, ref_len=700_000)
+    p = str(tmp_path / "i.bam")
+    assert lib.ngsq_synth_write_bam(C.byref(cfg), p.encode(), n, 1, 3) == 0
+    # virtual offset of every record: walk the BGZF blocks and the records inside them (whole records per block here)
+    raw = open(p, "rb").read()
+    voffs, off, first = [], 0, True
+    while off < len(raw):
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        data = zlib.decompress(raw[off + 18:off + bsize - 8], -15)
+        u = 0
+        if first:   # header block: magic, text, references
+            first = False
+            u = len(data)
+        while u < len(data):
+            voffs.append((off << 16) | u)
+            u += 4 + struct.unpack_from("<i", data, u)[0]
+        off += bsize
+    assert len(voffs) == n
+    hb = host.synth_host_batch(cfg, 0, n, lib)
+    index, n_no_coor = _parse_bai(p + ".bai", 2)
+    c = hb.cols
+    placed = 0
+    first_in_window = {}
+    for i in range(n):
+        r, pos = int(c["ref_id"][i]), int(c["pos"][i])
+        if r < 0 or pos < 0:
+            continue
+        placed += 1
+        end = pos + max(bamio._ref_span(hb, i), 1)
+        chunks = index[r][0].get(bamio.reg2bin(pos, end))
+        assert chunks and any(c0 <= voffs[i] < c1 for c0, c1 in chunks), f"record {i} is not in its bin"
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            first_in_window.setdefault((r, w), voffs[i])
+    assert n_no_coor == n - placed
+    vset = set(voffs) | {off << 16 for off in range(0)}  # chunk borders are record starts (or the end of the data)
+    for r in range(2):
+        bins, lin = index[r]
+        for b, chunks in bins.items():
+            assert all(c0 < c1 and c0 in vset for c0, c1 in chunks) and chunks == sorted(chunks)
+        for w, v in enumerate(lin):
+            if (r, w) in first_in_window:
+                assert v == first_in_window[(r, w)]
+    # and the reader's region query finds the first record of chr1 through it
+    starts = (C.c_uint64 * 2)()
+    bins_n = C.c_uint64()
+    assert lib.ngsq_bam_index_ref_starts(p.encode(), 2, starts, C.byref(bins_n)) == 0 and bins_n.value > 10
+    assert starts[0] == voffs[int(np.argmax((c["ref_id"] == 0) & (c["pos"] >= 0)))]
