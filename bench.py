@@ -47,7 +47,7 @@ def main() -> int:
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--workload", choices=["fixed", "mixed"], default="fixed")
     ap.add_argument("--mixed-max-len", type=int, default=300, help="longest read of --workload mixed (50..N bp)")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="records of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP event brackets")
     ap.add_argument("--force-dist", action="store_true",
