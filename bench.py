@@ -57,6 +57,9 @@ def main() -> int:
                          "array: difference arrays + teardown scan (any record order); auto: stream up to 0.5 records per "
                          "reference position in the whole file (whole-genome depths: measured faster there), array above "
                          "(the weak-scaling runs pile N x 100 M reads on chr1: DESIGN.md section 5.4)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 exchange (nccl = RCCL; "
+                    "gloo stages the small collectives through the host: test boxes)")
+    ap.add_argument("--same-gpu", action="store_true", help="all ranks on GPU 0 (boxes with one GPU; needs --backend gloo)")
     ap.add_argument("--emulate-shard", default="",
                     help="R/W: on ONE GPU, scan the records shard R of a W-GPU run would scan (the W x --records file's "
                          "slice, W times the depth, head guard as for rank R) -- kernel cost of a shard without the exchange")
@@ -86,8 +89,13 @@ def main() -> int:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        if args.same_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
         dist.barrier()
     lib = ffi.load_library()
     if lib.ngsq_device_count() < 1:
@@ -134,7 +142,7 @@ def main() -> int:
             # every facet state is an integer sum over records -> one RCCL
             # sum of the packed counter block and of the coverage difference arrays
             # (ngs_amd/shard.py: counters all-reduced; coverage by owner-computes halo exchange)
-            shard.owner_teardown(ctx, dist, torch, views)
+            shard.owner_teardown(ctx, dist, torch, views, coll_device=None if args.backend == "nccl" else "cpu")
         ctx.finalize()
 
     for _ in range(args.warmup):
@@ -147,7 +155,7 @@ def main() -> int:
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
