@@ -337,8 +337,11 @@ void usage() {
             "  -r, --reference-fasta <PATH>    Reference FASTA file (enables the Edits facet)\n"
             "      --only <FACET>              Only process one QC facet\n"
             "      --vaf-file <PATH>           Write the VAF of every covered position (Edits facet, needs -r)\n"
-            "      --five-prime-utr-feature-name, --three-prime-utr-feature-name, --coding-sequence-feature-name,\n"
-            "      --exon-feature-name, --gene-feature-name <STRING>   accepted for compatibility\n"
+            "      --five-prime-utr-feature-name <STRING>    GFF feature of a five prime UTR [default: five_prime_UTR]\n"
+            "      --three-prime-utr-feature-name <STRING>   GFF feature of a three prime UTR [default: three_prime_UTR]\n"
+            "      --coding-sequence-feature-name <STRING>   GFF feature of a coding sequence [default: CDS]\n"
+            "      --exon-feature-name <STRING>              GFF feature of an exon [default: exon]\n"
+            "      --gene-feature-name <STRING>              GFF feature of a gene [default: gene]\n"
             "      --device <N> --batch-records <N> --threads <N> --gc-seed <N> --ingest host|device   (additive, this build)\n"
             "      --coverage auto|stream|array   Coverage finished while sorted records stream by / on depth arrays (additive)\n");
 }

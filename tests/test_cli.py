@@ -68,6 +68,34 @@ def test_error_texts(ngs, tmp_path):
     assert r.returncode == 1
 
 
+def test_cli_surface_is_the_reference_s(ngs, tmp_path):
+    """tests/golden/qc_cli_surface.json is derived from the reference's clap definition (src/qc/command.rs:36-102):
+    every option there -- long name, short letter, value name, default -- is in this build's `ngs qc --help`, and the
+    parser accepts it (with everything given but the BAM, what is missing is a positional, not an unknown option)."""
+    surface = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qc_cli_surface.json")))
+    r = run(ngs, "qc", "--help")
+    assert r.returncode == 0
+    usage = r.stderr + r.stdout
+    assert [p["value_name"] for p in surface["positionals"]] == ["BAM", "REFERENCE_GENOME"]
+    assert "<BAM> <REFERENCE_GENOME>" in usage
+    args = []
+    for o in surface["options"]:
+        flag = f"--{o['long']} <{o['value_name']}>"
+        line = next((ln for ln in usage.splitlines() if flag in ln), None)
+        assert line is not None, f"{flag} missing from the usage text"
+        if o["short"]:
+            assert f"-{o['short']}, --{o['long']}" in line
+        if o["default"]:
+            assert f"[default: {o['default']}]" in line
+        args += [f"--{o['long']}", "7" if o["value_name"] == "USIZE" else str(tmp_path / "x")]
+        if o["short"]:
+            args += [f"-{o['short']}", "7" if o["value_name"] == "USIZE" else str(tmp_path / "x")]
+    r = run(ngs, "qc", *args)
+    assert r.returncode == 1 and "required arguments" in r.stderr and "unexpected argument" not in r.stderr
+    r = run(ngs, "qc", "--no-such-option", "x")
+    assert r.returncode == 1 and "unexpected argument '--no-such-option' found" in r.stderr
+
+
 def oracle_json(oracle_mod, hb, facets=ffi.FACETS_DEFAULT, ref_bases=None, pass1=None, pass2=None):
     o = oracle_mod.Oracle(LENS, PRIMARY, facets=facets, max_read_len=1024, gc_seed=0x4E4753, ref_bases=ref_bases)
     if pass1 is None:
