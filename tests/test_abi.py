@@ -116,3 +116,50 @@ def test_synthetic_distributions(lib):
     t = hb.cols["tlen"][(f & 0x41) == 0x41]
     t = t[(t > 0) & (t <= 1024)]
     assert abs(t.mean() - 350) < 2 and abs(t.std() - 50) < 2
+
+
+def test_fixed_shapes_are_the_reference_s(lib):
+    """tests/golden/reference_constants.json is read out of the reference's source by
+    tests/golden/make_reference_constants.py: facet names, histogram capacities, the GC window, the coverage bin, the
+    MAPQ that counts as high quality.  include/ngsq.h, the library and the oracle must carry the same numbers."""
+    import json
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constants.json")))
+    header = open(os.path.join(ROOT, "include", "ngsq.h")).read()
+
+    def macro(name):
+        return int(re.search(rf"#define {name}\s+(\d+)", header).group(1))
+
+    assert macro("NGSQ_MAX_SCORE") == want["max_quality_score"]
+    assert macro("NGSQ_GC_WINDOW") == want["gc_truncation_length"]
+    assert macro("NGSQ_GC_BINS") == 101                                   # percentages 0..=100 (gc_content.rs:129-138)
+    assert macro("NGSQ_EDITS_BINS") == want["default_histogram_capacity"] + 1
+    assert macro("NGSQ_VAF_BINS") == want["vaf_histogram_capacity"] + 1
+    names = want["facet_names"]
+    for bit, key in ((ffi.FACET_GENERAL, "general"), (ffi.FACET_TEMPLATE_LENGTH, "template_length"),
+                     (ffi.FACET_GC_CONTENT, "gc_content"), (ffi.FACET_QUALITY_SCORE, "quality_score"),
+                     (ffi.FACET_COVERAGE, "coverage"), (ffi.FACET_EDITS, "edits"), (ffi.FACET_FEATURES, "features")):
+        assert lib.ngsq_facet_name(bit).decode() == names[key]
+    # defaults of ngsq_create (0 = the reference's value) as documented in the header, and in the sources that apply them
+    ctx_src = open(os.path.join(ROOT, "ngs_amd", "csrc", "context.cpp")).read()
+    assert f"bin_size = {want['coverage_bin_size']}" in ctx_src and f"tlen_cap = {want['template_length_capacity']}" in ctx_src
+    assert f"cov_cap = {want['coverage_histogram_capacity']}" in ctx_src
+    res_src = open(os.path.join(ROOT, "ngs_amd", "csrc", "results.cpp")).read()
+    assert all(f"{c}" in res_src for c in want["genome_covered_by"])
+    fields = open(os.path.join(ROOT, "ngs_amd", "csrc", "fields_kernel.hip")).read()
+    assert f"mq >= {want['high_quality_mapq']}u" in fields
+    oracle_src = open(os.path.join(ROOT, "oracle", "oracle.c")).read()
+    assert f">= {want['high_quality_mapq']}" in oracle_src
+
+
+def test_oracle_defaults_are_the_reference_s(oracle_mod):
+    """The same constants, observed in the oracle's behaviour: an empty run reports the reference's histogram shapes."""
+    import json
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constants.json")))
+    orc = oracle_mod.Oracle([1000], facets=ffi.FACETS_DEFAULT)
+    orc.finalize()
+    doc = orc.results(["chr1"])
+    assert doc["template_length"]["histogram"]["range_stop"] == want["template_length_capacity"]
+    assert len(doc["template_length"]["histogram"]["values"]) == want["template_length_capacity"] + 1
+    assert doc["gc_content"]["histogram"]["range_stop"] == 100
+    assert doc["coverage"]["coverage_distribution"]["range_stop"] == want["coverage_histogram_capacity"]
+    assert sorted(doc["coverage"]["genome_covered_by"]) == sorted(f"{c}x" for c in want["genome_covered_by"])
