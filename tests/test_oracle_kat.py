@@ -188,3 +188,31 @@ def test_facet_names_from_library(lib):
     assert names == {1: "General", 2: "Template Length", 4: "GC Content", 8: "Quality Score",
                      16: "Coverage", 32: "Edits", 64: "Genomic Features"}   # qc.rs:138-139 names, features.rs:107
     assert lib.ngsq_facet_name(128) is None
+
+
+def test_genome_table_known_answers():  # utils/genome/ncbi/grch38_no_alt.rs:287-354 (the reference's own tests)
+    """The sequence table the CLI and tools/qc_sharded.py load (ngs_amd/data/GRCh38_no_alt_AnalysisSet.tsv) against
+    every known-answer test the reference holds for this genome: 22 autosomes, 2 sex chromosomes, chrM and chrEBV
+    present, 42 unlocalized and 127 unplaced sequences, no alternative contigs / decoys / others, and 193 sequences in
+    the primary assembly (autosomes + sex + alt + unlocalized + unplaced: utils/genome.rs:59-83) -- the set Coverage
+    supports (coverage.rs:133-138)."""
+    import collections
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ngs_amd", "data",
+                        "GRCh38_no_alt_AnalysisSet.tsv")
+    groups = collections.Counter()
+    names = set()
+    for line in open(path):
+        if line.startswith("#") or not line.strip():
+            continue
+        name, group = line.rstrip("\n").split("\t")
+        assert name not in names
+        names.add(name)
+        groups[group] += 1
+    assert groups["autosome"] == 22 and groups["sex"] == 2
+    assert groups["mitochondrion"] == 1 and "chrM" in names
+    assert groups["ebv"] == 1 and "chrEBV" in names
+    assert groups["unlocalized"] == 42 and groups["unplaced"] == 127
+    assert groups["alt"] == 0 and groups["decoy"] == 0 and groups["other"] == 0
+    primary = sum(groups[g] for g in ("autosome", "sex", "alt", "unlocalized", "unplaced"))
+    assert primary == 193
