@@ -96,6 +96,47 @@ def test_cli_surface_is_the_reference_s(ngs, tmp_path):
     assert r.returncode == 1 and "unexpected argument '--no-such-option' found" in r.stderr
 
 
+# messages of the reference this build does not print, and why (everything else in the fixture must be carried)
+NOT_CARRIED = {
+    "Too many facets matched": "cannot happen: facet names are distinct",
+    "incompatible formats: required BAM": "the reference sniffs other known extensions first; here any non-.bam extension is 'Not able to determine filetype'",
+    "incompatible formats: required GFF": "same, for the GFF",
+    "constructing BAM index filepath": "string concatenation cannot fail",
+    "parsing BAM header": "the header is read and parsed in one step ('reading BAM header')",
+    "writing VAF file header": "written with the file's creation ('creating VAF file')",
+    "writing VAF file": "stdio errors surface at close",
+    "Could not parse read name": "noodles decode step; read names are not decoded on this path",
+    "could not lookup reference sequence for read": "counted on the device (ngsq_error_counts.edits_bad_ref), reported by ngsq_finalize",
+    "Could not parse reference sequence id for read": "counted on the device (features_missing_reference_id)",
+    "Could not map reference sequence id to header for read": "ids outside the header are refused when the file is read",
+    "Could not parse record's start position.": "counted on the device (features_missing_position)",
+}
+
+
+def test_error_texts_are_the_reference_s():
+    """tests/golden/qc_error_texts.json lists every bail!/anyhow!/with_context literal on the reference's `ngs qc` path
+    (tests/golden/make_error_texts.py).  Each is either in this build's sources word for word (formatted values
+    aside) or named above with the reason it cannot occur here."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = ""
+    for rel in ("ngs_amd/csrc/cli/ngs_main.cpp", "ngs_amd/csrc/bam_reader.cpp", "oracle/oracle.c", "oracle/histogram.c"):
+        src = open(os.path.join(root, rel)).read()
+        src = re.sub(r'"\s*\n\s*"', "", src)          # adjacent C string literals are one string
+        text += src.replace('\\"', '"')
+    msgs = json.load(open(os.path.join(root, "tests", "golden", "qc_error_texts.json")))["messages"]
+    assert len(msgs) >= 25
+    carried = 0
+    for m in msgs:
+        skip = next((why for key, why in NOT_CARRIED.items() if m["text"].startswith(key) or key in m["text"]), None)
+        parts = [p for p in m["text"].split("{}") if p.strip(" .")]
+        have = all(p in text or p.rstrip(".") in text for p in parts)
+        if skip is None:
+            assert have, f"{m['file']}:{m['line']}: {m['text']!r} is not in this build's sources"
+            carried += 1
+    assert carried >= 15
+
+
 def oracle_json(oracle_mod, hb, facets=ffi.FACETS_DEFAULT, ref_bases=None, pass1=None, pass2=None):
     o = oracle_mod.Oracle(LENS, PRIMARY, facets=facets, max_read_len=1024, gc_seed=0x4E4753, ref_bases=ref_bases)
     if pass1 is None:
