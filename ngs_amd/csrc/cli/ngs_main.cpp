@@ -230,17 +230,48 @@ struct GeneModel {
 
 // formats/gff.rs:19-47 (open by extension) + noodles-gff records(): nine tab-separated columns,
 // '#' lines are comments/directives, "##FASTA" ends the records.
-GeneModel load_gff(const std::string &path, const std::string (&feature_name)[5], const std::set<std::string> &primary,
-                   const std::map<std::string, uint32_t> &ref_index) {
+// utils/formats.rs:117-186  BioinformaticsFileFormat::try_detect, with the names its Display prints (:79-101).
+// "" = no format (the callers then report the extension).  `.gz` / `.bgz` look at the whole name, case-sensitively,
+// the other extensions are matched case-insensitively -- as the reference does.
+std::string detect_format(const std::string &path) {
     auto ends_with = [&](const char *suf) {
         const size_t n = strlen(suf);
         return path.size() >= n && path.compare(path.size() - n, n, suf) == 0;
     };
+    const size_t slash = path.rfind('/');
+    const size_t dot = path.rfind('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash) || dot + 1 == path.size() ||
+        dot == (slash == std::string::npos ? 0 : slash + 1))
+        return ""; // no extension (a leading dot is not one)
+    std::string ext = path.substr(dot + 1);
+    for (auto &c : ext) c = (char)tolower((unsigned char)c);
+    if (ext == "bgz") {
+        if (ends_with("gff.bgz") || ends_with("gff3.bgz")) return "Block-gzipped GFF";
+    } else if (ext == "gz") {
+        if (ends_with("fasta.gz") || ends_with("fna.gz") || ends_with("fa.gz")) return "Gzipped FASTA";
+        if (ends_with("fq.gz") || ends_with("fastq.gz")) return "Gzipped FASTQ";
+        if (ends_with("vcf.gz")) return "Gzipped VCF";
+        if (ends_with("gff.gz") || ends_with("gff3.gz")) return "Gzipped GFF";
+        if (ends_with("gtf.gz")) return "Gzipped GTF";
+        return "";
+    }
+    static const struct { const char *ext, *name; } table[] = {
+        {"fasta", "FASTA"}, {"fna", "FASTA"}, {"fa", "FASTA"}, {"fastq", "FASTQ"}, {"fq", "FASTQ"}, {"sam", "SAM"},
+        {"ubam", "Unaligned BAM"}, {"bam", "BAM"}, {"cram", "CRAM"}, {"vcf", "VCF"}, {"bcf", "BCF"}, {"gff", "GFF"},
+        {"gff3", "GFF"}, {"gtf", "GTF"}, {"bed", "BED"}};
+    for (const auto &t : table)
+        if (ext == t.ext) return t.name;
+    return "";
+}
+
+GeneModel load_gff(const std::string &path, const std::string (&feature_name)[5], const std::set<std::string> &primary,
+                   const std::map<std::string, uint32_t> &ref_index) {
     const size_t dot = path.rfind('.');
     const std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
-    const bool gz = ends_with("gff.gz") || ends_with("gff3.gz");
-    if (!gz && !ieq(ext, "gff") && !ieq(ext, "gff3"))
-        bail("opening GFF file: " + path + ": Not able to determine filetype for extension: " + ext);
+    const std::string format = detect_format(path); // utils/formats/gff.rs:19-47
+    if (format.empty()) bail("opening GFF file: " + path + ": Not able to determine filetype for extension: " + ext);
+    if (format != "GFF" && format != "Gzipped GFF")
+        bail("opening GFF file: " + path + ": incompatible formats: required GFF, found " + format);
     gzFile f = gzopen(path.c_str(), "rb"); // reads plain text as well
     if (!f) bail("opening GFF file: " + path + ": No such file or directory (os error 2)");
     GeneModel m;
@@ -437,7 +468,9 @@ int main(int argc, char **argv) {
     {
         const size_t dot = a.src.rfind('.');
         const std::string ext = dot == std::string::npos ? "" : a.src.substr(dot + 1);
-        if (!ieq(ext, "bam")) bail("Not able to determine filetype for extension: " + ext);
+        const std::string format = detect_format(a.src); // utils/formats/bam.rs:32-56
+        if (format.empty()) bail("Not able to determine filetype for extension: " + ext);
+        if (format != "BAM") bail("incompatible formats: required BAM, found " + format);
     }
     ngsq_bam *bam = nullptr;
     if (ngsq_bam_open(a.src.c_str(), a.threads, &bam) != NGSQ_OK) bail(ngsq_bam_last_error());

@@ -96,11 +96,31 @@ def test_cli_surface_is_the_reference_s(ngs, tmp_path):
     assert r.returncode == 1 and "unexpected argument '--no-such-option' found" in r.stderr
 
 
+def test_format_sniffing_known_answers(ngs):
+    """tests/golden/format_sniffing.json holds the reference's own tests of BioinformaticsFileFormat::try_detect
+    (utils/formats.rs:192-322) and its Display names.  `ngs qc` opens its BAM through the same sniffing
+    (formats/bam.rs:32-56): a BAM name passes (and the missing file is then reported), every other known format is
+    'incompatible formats: required BAM, found <name>', an unknown extension is reported as such."""
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "format_sniffing.json")))
+    assert len(fx["cases"]) >= 20
+    for case in fx["cases"]:
+        r = run(ngs, "qc", "/nonexistent/" + case["file"], GENOME)
+        assert r.returncode == 1
+        if case["format"] == "BAM":
+            assert "opening BAM file" in r.stderr, r.stderr
+        else:
+            assert f"incompatible formats: required BAM, found {fx['display'][case['format']]}" in r.stderr, (case, r.stderr)
+    r = run(ngs, "qc", "/nonexistent/sample.SAM", GENOME)             # extensions match case-insensitively ...
+    assert "required BAM, found SAM" in r.stderr
+    r = run(ngs, "qc", "/nonexistent/sample.FA.GZ", GENOME)           # ... the names in front of .gz do not
+    assert "Not able to determine filetype for extension: GZ" in r.stderr
+    r = run(ngs, "qc", "/nonexistent/sample.txt", GENOME)
+    assert "Not able to determine filetype for extension: txt" in r.stderr
+
+
 # messages of the reference this build does not print, and why (everything else in the fixture must be carried)
 NOT_CARRIED = {
     "Too many facets matched": "cannot happen: facet names are distinct",
-    "incompatible formats: required BAM": "the reference sniffs other known extensions first; here any non-.bam extension is 'Not able to determine filetype'",
-    "incompatible formats: required GFF": "same, for the GFF",
     "constructing BAM index filepath": "string concatenation cannot fail",
     "parsing BAM header": "the header is read and parsed in one step ('reading BAM header')",
     "writing VAF file header": "written with the file's creation ('creating VAF file')",
