@@ -16,8 +16,12 @@
  *     files or fixtures in the reference, and the
  *     reference is Rust, which cannot be built here (no cargo/rustc, crates
  *     not vendored, no network): for them this oracle is PARITY UNPINNED --
- *     a line-by-line restatement checked only against hand-derived goldens
- *     (tests/golden/).
+ *     a line-by-line restatement checked against hand-derived goldens
+ *     (tests/golden/hand_six_records.json) for the arithmetic, and, for what the
+ *     reference's SOURCE fixes without running it, against fixtures derived from
+ *     that source by scripts committed next to them (tests/golden/make_*.py):
+ *     the shape of the Results document (field names, declaration order, types),
+ *     the fixed capacities / thresholds / facet names, the error texts.
  *   - The record decode the reference delegates to noodles-bam 0.28.0 /
  *     noodles-sam 0.25.0 (Cargo.lock:902-905,1057-1059) is not in the tree;
  *     the accessor semantics used here are restated from the SAM/BAM
