@@ -108,6 +108,19 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
     uint32_t one[9], two[9]; // per-lane CIGAR-op tallies
 #pragma unroll
     for (int k = 0; k < 9; k++) one[k] = two[k] = 0;
+    // ... accumulated as nine 7-bit fields of a 64-bit word each (field q = op code q): one shift and two adds per
+    // op instead of eighteen compare-and-adds; unpacked into one[] / two[] before a field can wrap
+    u64 pk1 = 0, pk2 = 0;
+    uint32_t pk_n = 0; // ops added to the packed words since they were last unpacked
+    auto unpack_ops = [&]() {
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            one[q] += (uint32_t)(pk1 >> (7 * q)) & 127u;
+            two[q] += (uint32_t)(pk2 >> (7 * q)) & 127u;
+        }
+        pk1 = pk2 = 0;
+        pk_n = 0;
+    };
     uint32_t bad_op = 0;
     u64 nonsensical = 0;
     int32_t seen_ref = -1; // run-length tally of records Coverage processed, per sequence
@@ -302,12 +315,10 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                     }
                     if ((0x18Du >> op) & 1u) span += len; // utils/cigar.rs:6-11  M D N = X
                     if (a.do_general) {
-                        const uint32_t o1 = r1 ? op : 15u, o2 = r1 ? 15u : op;
-#pragma unroll
-                        for (int q = 0; q < 9; q++) {
-                            one[q] += (o1 == (uint32_t)q);
-                            two[q] += (o2 == (uint32_t)q);
-                        }
+                        const u64 inc = 1ull << (7u * op);
+                        pk1 += r1 ? inc : 0ull;
+                        pk2 += r1 ? 0ull : inc;
+                        if (++pk_n == 127u) unpack_ops(); // per lane; a record can hold more ops than a field counts
                     }
                 }
                 if (a.do_cov) {
@@ -511,6 +522,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             if (g[k]) atomicAdd(&s_acc[k], (u64)g[k]);
         if (g[19]) atomicAdd(&s_acc[38], (u64)g[19]);
     }
+    unpack_ops();
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const uint32_t r1 = ft_wave_sum(one[k]), r2 = ft_wave_sum(two[k]);
