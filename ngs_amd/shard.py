@@ -11,9 +11,10 @@ coordinate-sorted file a shard writes only its own stretch of the reference axis
   2. the axis is cut at the sorted `lo`s: rank k OWNS [lo_k, lo_next) -- a disjoint cover;
   3. entries a rank wrote inside another rank's range (the read-length halo at a shard
      boundary, a few KB) are sent to the owner and added there;
-  4. owners all-gather the sum of their range; the carry of owner k is the sum of the
-     ranges in front of it (every difference array sums to zero per sequence, so one
-     running sum over the whole block is enough);
+  4. the carry of owner k is the sum of the ranges in front of it (every difference array sums
+     to zero per sequence, so one running sum over the whole block is enough): the sum of a
+     rank's own range before the halos travels in the halo message of step 3, and since every
+     rank sees every halo it adds the incoming parts itself -- no further collective;
   5. every rank tears down only its own chunks (ngsq_set_scan_range) -- the scan is split
      N ways -- and the small teardown results (depth histograms, bin totals) are all-reduced.
 
@@ -153,21 +154,23 @@ def owner_teardown(ctx, dist, torch, views, coll_device=None) -> dict:
     diff = depth[:n_diff]
     sums = depth[n_diff:n_diff + n_chunks]
 
-    # streaming contexts: no exchanged entry may fall into a chunk this rank has already finished
+    # streaming contexts: no exchanged entry may fall into a chunk this rank has already finished (the verdict
+    # travels with the halo message below; with the all-reduce fallback it needs a message of its own)
     flags = views.get("flags")
+    bad = 0
     if flags is not None and flags.numel():
-        bad = 0
         for (s, d), (c0, c1) in xfer.items():
             if d == rank and bool(flags[c0:c1].any().item()):
                 bad = 1
         if max(out_bytes) > HALO_LIMIT_BYTES and bool(flags.any().item()):
             bad = 1
-        if max(b for row in _all_gather_ints([bad], dist, torch, cdev) for b in row):
-            raise RuntimeError("sorted_input shards overlap: records of another shard reach into positions this shard "
-                               "already finished (cov_head_guard too small, or the shards are not in coordinate "
-                               "order); re-run without sorted_input")
+    overlap = RuntimeError("sorted_input shards overlap: records of another shard reach into positions this shard "
+                           "already finished (cov_head_guard too small, or the shards are not in coordinate "
+                           "order); re-run without sorted_input")
 
     if max(out_bytes) > HALO_LIMIT_BYTES:
+        if flags is not None and flags.numel() and max(b for row in _all_gather_ints([bad], dist, torch, cdev) for b in row):
+            raise overlap
         # unsorted shards: the written ranges overlap -- sum the whole block, every rank scans all
         allreduce_(depth)
         report["mode"] = "allreduce"
@@ -183,32 +186,46 @@ def owner_teardown(ctx, dist, torch, views, coll_device=None) -> dict:
     for d, c0, c1 in mine:
         parts.append(diff[c0 * COV_CHUNK:c1 * COV_CHUNK])
         parts.append(sums[c0:c1])
+    # The same message carries two more words: the sum of this rank's owned range BEFORE the halos arrive (step 4
+    # needs the sums after; every rank sees every halo, so it can add the incoming parts itself -- one collective and
+    # one device-to-host sync less per step) and the verdict of the check above.
+    b0, b1 = own[rank]
+    pre_total = int(sums[b0:b1].sum().item()) & 0xFFFFFFFF if b1 > b0 else 0
     max_len = max(max(out_bytes) // 4, 1)
-    buf = torch.zeros(max_len, dtype=torch.int32, device=cdev)
+    buf = torch.zeros(max_len + 2, dtype=torch.int32, device=cdev)
     if parts:
         flat = torch.cat([p.to(cdev) for p in parts])
         buf[:flat.numel()] = flat
+    buf[max_len] = pre_total - (1 << 32) if pre_total >= (1 << 31) else pre_total  # two's complement: the same bits
+    buf[max_len + 1] = bad
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf)
+    moved = []  # (owner, device scalar: sum of the chunk sums one halo carries), read back in one transfer below
     for s in range(world):
-        if s == rank:
-            continue
         off = 0
         for (s2, d), (c0, c1) in sorted(xfer.items()):
             if s2 != s:
                 continue
             n_e, n_c = (c1 - c0) * COV_CHUNK, c1 - c0
-            if d == rank:
+            part_sums = gathered[s][off + n_e:off + n_e + n_c]
+            moved.append((d, part_sums.sum()))
+            if d == rank and s != rank:
                 diff[c0 * COV_CHUNK:c1 * COV_CHUNK] += gathered[s][off:off + n_e].to(dev)
-                sums[c0:c1] += gathered[s][off + n_e:off + n_e + n_c].to(dev)
+                sums[c0:c1] += part_sums.to(dev)
             off += n_e + n_c
+    words = torch.stack([g[max_len:max_len + 2] for g in gathered]).flatten()
+    if moved:
+        words = torch.cat([words, torch.stack([m[1] for m in moved]).to(words.dtype)])
+    words = [int(x) for x in words.tolist()]  # the one read-back of this step
+    if any(words[2 * r + 1] for r in range(world)):
+        raise overlap
+    totals = [words[2 * r] & 0xFFFFFFFF for r in range(world)]
+    for k, (d, _) in enumerate(moved):
+        totals[d] = (totals[d] + words[2 * world + k]) & 0xFFFFFFFF  # what owner d's range sums to once the halos are in
     report["mode"] = "owner"
     report["halo_bytes"] = out_bytes[rank]
 
     # ---- step 4: carry of each owner = sum of the owned ranges in front of it (mod 2^32)
-    b0, b1 = own[rank]
-    total = int(sums[b0:b1].sum().item()) & 0xFFFFFFFF if b1 > b0 else 0
-    totals = [t[0] for t in _all_gather_ints([total], dist, torch, cdev)]
     carry = 0
     for r in owners:
         if r == rank:
