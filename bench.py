@@ -1,27 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- `ngs qc` record-scanning hot path on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (launches its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     (same ranks, launched by torchrun)
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on
 that fits one GPU): per GPU 100 M synthetic 150 bp reads resident in HBM as SoA
 columns, coordinate-sorted over a chr1-sized reference (L = 248 956 422), ALL
 default QC facets (General, Template Length, GC Content, Quality Score,
 Coverage).  One step = one full pass of the hot path over the resident shard:
-reset -> the facet kernels over every record -> (N > 1: RCCL sum of the shard
-states) -> coverage teardown scan -> integer results on the host.
+reset -> the facet kernels over every record -> (N > 1: ngsq_exchange -- RCCL
+called from the library: counters all-reduce, point-to-point coverage halos,
+teardown split N ways, all-reduce of the partial results) -> integer results on
+the host.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the
 `roofline` of the dominant kernel (Quality Score: 150 of the 254 algorithmic
-bytes per record) and the `cpu_baseline` (the C oracle, 1 core, bounded sample).
+bytes per record), the `cpu_baseline` (the C oracle, 1 core, bounded sample; an
+all-cores figure beside it), and -- at N = 1 -- the two other rates the metric
+is about: `h2d_inclusive` (pinned host SoA batches through ngsq_process_batch)
+and `file_end_to_end` (a synthetic BGZF BAM through `ngs qc` to the JSON), with
+`ingest_roofline` for the device inflate kernel that bounds the latter.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,18 +38,14 @@ sys.path.insert(0, ROOT)
 CHR1 = 248_956_422
 CHR2 = 242_193_529
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GC_SEED = 0x4E4753
 
 
-def algorithmic_bytes_per_record(read_len: int, n_ops: float) -> float:
-    """25 B fixed + 4 B per CIGAR op + ceil(l/2) SEQ + l QUAL."""
-    return 25.0 + 4.0 * n_ops + (read_len + 1) // 2 + read_len
-
-
-def main() -> int:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--records", type=int, default=100_000_000, help="records per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--workload", choices=["fixed", "mixed"], default="fixed")
@@ -51,56 +54,101 @@ def main() -> int:
                     help="records of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-timing", action="store_true", help="no per-kernel HIP event brackets")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the torch.distributed/RCCL path even with one rank (plumbing check)")
+                    help="run ngsq_exchange over RCCL even with one rank (plumbing check)")
     ap.add_argument("--coverage", choices=["auto", "stream", "array"], default="auto",
                     help="stream: sorted_input context, Coverage finishes positions while the sorted records stream by; "
                          "array: difference arrays + teardown scan (any record order); auto: stream up to 0.5 records per "
                          "reference position in the whole file (whole-genome depths: measured faster there), array above "
                          "(the weak-scaling runs pile N x 100 M reads on chr1: DESIGN.md section 5.4)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 exchange (nccl = RCCL; "
-                    "gloo stages the small collectives through the host: test boxes)")
-    ap.add_argument("--same-gpu", action="store_true", help="all ranks on GPU 0 (boxes with one GPU; needs --backend gloo)")
+    ap.add_argument("--transport", choices=["rccl", "shm"], default="rccl",
+                    help="transport of the N > 1 exchange: rccl = RCCL over xGMI called from the library; shm = its "
+                         "shared-memory host transport (test boxes: ranks sharing one GPU)")
+    ap.add_argument("--same-gpu", action="store_true", help="all ranks on GPU 0 (boxes with one GPU; needs --transport shm)")
     ap.add_argument("--emulate-shard", default="",
                     help="R/W: on ONE GPU, scan the records shard R of a W-GPU run would scan (the W x --records file's "
                          "slice, W times the depth, head guard as for rank R) -- kernel cost of a shard without the exchange")
     ap.add_argument("--facets", type=lambda x: int(x, 0), default=0x1F,
-                    help="facet mask (default 0x1F = all default facets; 0x0E = BASELINE configs[1])")
-    args = ap.parse_args()
+                    help="facet mask (default 0x1F = all default facets; 0x0E = BASELINE configs[1]; 0x20 adds Edits with "
+                         "a synthetic reference resident in HBM, 0x40 Genomic Features with a synthetic gene model)")
+    ap.add_argument("--file-records", type=int, default=60_000_000,
+                    help="records of the synthetic BAM of the file_end_to_end leg (N = 1 only; 0 = skip that leg)")
+    ap.add_argument("--file-level", type=int, default=6, help="zlib level of that BAM")
+    ap.add_argument("--h2d-batch", type=int, default=4_000_000, help="records per host batch of the h2d_inclusive leg (0 = skip)")
+    ap.add_argument("--extra-facet-legs", type=int, default=1,
+                    help="1: also time the Edits and Genomic Features kernels on a 10 M-record slice (N = 1 only)")
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own ranks.  Nothing in this function touches HIP.
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    import socket
+    from ngs_amd import build
+    build.build(verbose=False)  # once, before the ranks start
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()  # exactly the processes started above
+        time.sleep(0.05)
+    return rc
+
+
+def build_once():
+    """Every rank may be the first to arrive on a fresh checkout: serialise the (usually no-op) build."""
+    import fcntl
+    from ngs_amd import build
+    with open(os.path.join(ROOT, "ngs_amd", ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        build.build(verbose=False)
+
+
+def main() -> int:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            return 2
-        args.gpus = world
+    args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
 
-    from ngs_amd import build, ffi, host
+    import numpy as np
+    from ngs_amd import ffi, host, shard
 
-    if rank == 0:
-        build.build(verbose=False)
-    lib = None
-    dist = None
-    torch = None
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch  # noqa: F811
-        import torch.distributed as dist  # noqa: F811
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if args.same_gpu:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-        dist.barrier()
+    build_once()
     lib = ffi.load_library()
     if lib.ngsq_device_count() < 1:
         print("bench.py: no HIP device visible; the hot path has no CPU fallback", file=sys.stderr)
         return 3
+    device = 0 if args.same_gpu else local_rank
+    use_dist = world > 1 or args.force_dist
+    comm = None
+    if use_dist:
+        if world > 1:
+            comm = shard.comm_from_env(device, args.transport, lib)
+        else:
+            comm = shard.Comm.rccl(0, 1, shard.unique_id(lib), device, lib)
 
     n = args.records
     mixed = args.workload == "mixed"
@@ -113,36 +161,31 @@ def main() -> int:
                              read_len=args.read_len, max_len=args.mixed_max_len, ref_len=CHR1, n_refs=2)
     if args.coverage == "auto":
         args.coverage = "stream" if emu_world * n / CHR1 <= 0.5 else "array"
-    ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=local_rank,
-                         max_read_len=max_len, gc_seed=0x4E4753, timing=not args.no_timing,
-                         sorted_input=args.coverage == "stream",
+    ref_bases = synthetic_reference(np) if args.facets & ffi.FACET_EDITS else None
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=device,
+                         max_read_len=max_len, gc_seed=GC_SEED, timing=not args.no_timing,
+                         sorted_input=args.coverage == "stream", ref_bases=ref_bases,
                          # shards behind the first: positions a read of the shard in front may still cover
-                         # (the synthetic reads span at most 5.3 kb; real files: tools/qc_sharded.py keeps 1 Mi)
+                         # (the synthetic reads span at most 5.3 kb; real files: `ngs qc --gpus` keeps 1 Mi)
                          cov_head_guard=(1 << 16) if emu_rank > 0 else 0, lib=lib)
+    if args.facets & ffi.FACET_FEATURES:
+        ctx.set_features(*synthetic_gene_model(np))
     t_gen = time.perf_counter()
     db = ctx.synth_device_batch(scfg, emu_rank * n, n)
     t_gen = time.perf_counter() - t_gen
 
-    views = None
-    if use_dist:
-        from ngs_amd import shard
-        views = shard.device_views(ctx, torch, local_rank)
-
     def sync():
         ctx.synchronize()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+
+    report = {}
 
     def step():
         ctx.reset()
         ctx.process_batch(db)
-        if use_dist:
-            # every facet state is an integer sum over records -> one RCCL
-            # sum of the packed counter block and of the coverage difference arrays
-            # (ngs_amd/shard.py: counters all-reduced; coverage by owner-computes halo exchange)
-            shard.owner_teardown(ctx, dist, torch, views, coll_device=None if args.backend == "nccl" else "cpu")
+        if comm is not None:
+            report.update(comm.exchange(ctx))   # include/ngsq_comm.h: the one exchange of a sharded scan
         ctx.finalize()
 
     for _ in range(args.warmup):
@@ -154,19 +197,14 @@ def main() -> int:
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = float(comm.allgather(np.array([elapsed], dtype=np.float64)).max())
 
     total_records = n * world
-    ok = True
-    if args.facets & ffi.FACET_GENERAL:
-        ok = ctx.general()["total"] == total_records
-    elif args.facets & ffi.FACET_QUALITY_SCORE:
-        ok = int(ctx.quality_scores()[0].sum()) == total_records
+    parity = check_invariants(ctx, ffi, total_records, args, mixed, emu_world > world)
     timing = ctx.kernel_timing()
 
+    rc = 0 if parity.startswith("ok") else 1
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_records * args.steps / elapsed
@@ -178,18 +216,13 @@ def main() -> int:
         if q["launches"] and q["total_ms"] > 0:
             avg_ms = q["total_ms"] / q["launches"]
             achieved = (q["algo_bytes"] / q["launches"]) / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_qual_perm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            roofline = {"bound": "hbm", "kernel": "k_qual_ragged" if mixed else "k_qual_perm", "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_ms": round(avg_ms, 4),
                         "algo_bytes_per_launch": q["algo_bytes"] // q["launches"]}
-        kernels = {k: {"avg_ms": round(v["total_ms"] / v["launches"], 4),
-                       "GBps": round(v["algo_bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)}
-                   for k, v in timing.items() if v["launches"] and v["total_ms"] > 0}
-        if roofline is not None:
             roofline["traffic"], roofline["traffic_source"] = pmc_traffic(n, args)
-        cpu = None
-        if world == 1 and args.cpu_sample > 0:
-            cpu = cpu_baseline(lib, host, ffi, scfg, min(args.cpu_sample, n), max_len)
+            roofline["traffic_measured_in_this_run"] = False  # PMC passes are separate rocprofv3 runs (tools/profile_round.sh)
+        kernels = kernel_table(timing)
         out = {
             "metric": "BAM records/sec (whole node), all qc facets, 150 bp reads",
             "value": round(value, 1), "unit": "records/s", "n_gpus": world, "steps": args.steps,
@@ -200,25 +233,102 @@ def main() -> int:
                                     "all default facets incl. CIGAR coverage over chr1 (L=248956422)"
                                     % (n // 1_000_000, "50-300 bp mixed-CIGAR" if mixed else f"{args.read_len} bp")),
                        "records_per_gpu": n, "read_len": max_len if mixed else args.read_len,
-                       "facets": ",".join(n for b_, n in ((1, "General"), (2, "Template Length"), (4, "GC Content"),
-                                                           (8, "Quality Score"), (16, "Coverage")) if args.facets & b_),
-                       "sharding": ("contiguous record (BGZF block) ranges; RCCL all-reduce of counters, owner-computes "
-                                    "coverage teardown with halo exchange") if world > 1 else "single GPU",
+                       "facets": ",".join(nm for b_, nm in ((1, "General"), (2, "Template Length"), (4, "GC Content"),
+                                                            (8, "Quality Score"), (16, "Coverage"), (32, "Edits"),
+                                                            (64, "Genomic Features")) if args.facets & b_),
+                       "sharding": ("contiguous record (BGZF block) ranges; ngsq_exchange over %s: all-reduce of counters, "
+                                    "owner-computes coverage teardown with point-to-point halos (mode %s, %d halo bytes from "
+                                    "rank 0, %d host syncs per step)"
+                                    % (comm.kind, report.get("mode"), report.get("halo_bytes", 0), report.get("host_syncs", 0)))
+                       if comm is not None else "single GPU",
                        "coverage": ("streamed from the coordinate-sorted records (sorted_input)" if args.coverage == "stream"
                                     else "difference arrays + teardown scan"),
                        "algorithmic_bytes_per_record": round(algo_rec, 2),
                        "hbm_frac_whole_pass": round(value / world * algo_rec / (HBM_PEAK_GBS * 1e9), 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
-            "parity_check": "total==records" if ok else "FAILED total!=records",
-            "generate_s": round(t_gen, 2),
+            "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+            "parity_check": parity, "generate_s": round(t_gen, 2),
         }
-        print(json.dumps(out), flush=True)
     ctx.free_batch(db)
     ctx.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0 if ok else 1
+    if comm is not None:
+        comm.barrier()
+        comm.destroy()
+    if rank == 0:
+        # ---- the legs beside the headline number: rank 0 at N = 1 only, each bounded to seconds
+        if world == 1 and not args.emulate_shard:
+            if args.cpu_sample > 0:
+                out["cpu_baseline"] = cpu_baseline(lib, host, ffi, scfg, min(args.cpu_sample, n), max_len)
+            if args.h2d_batch > 0 and not mixed:
+                out["h2d_inclusive"] = guarded(leg_h2d, lib, host, ffi, args)
+            if args.file_records > 0 and not mixed:
+                fe = guarded(leg_file, lib, host, ffi, args)
+                out["ingest_roofline"] = fe.pop("ingest_roofline", None) if isinstance(fe, dict) else None
+                out["file_end_to_end"] = fe
+            if args.extra_facet_legs and not mixed and args.facets == 0x1F:
+                out["extra_facets"] = guarded(leg_extra_facets, lib, host, ffi, np)
+        print(json.dumps(out), flush=True)
+    return rc
+
+
+def guarded(fn, *a):
+    try:
+        return fn(*a)
+    except Exception as e:  # these legs are reported, never required
+        import traceback
+        traceback.print_exc()
+        return {"failed": f"{type(e).__name__}: {e}"}
+
+
+def kernel_table(timing):
+    return {k: {"avg_ms": round(v["total_ms"] / v["launches"], 4),
+                "GBps": round(v["algo_bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)}
+            for k, v in timing.items() if v["launches"] and v["total_ms"] > 0}
+
+
+def check_invariants(ctx, ffi, total: int, args, mixed: bool, emulated: bool) -> str:
+    """Size-independent properties of the whole-file result (tests/test_parity_gpu.py::test_full_size_properties):
+    every rank holds the whole-file integers after ngsq_exchange + ngsq_finalize."""
+    bad = []
+
+    def need(cond, what):
+        if not cond:
+            bad.append(what)
+    f = args.facets
+    checked = 0
+    if f & ffi.FACET_GENERAL:
+        g = ctx.general()
+        need(g["total"] == total, "general.total == records")
+        need(g["primary"] + g["secondary"] + g["supplementary"] == total, "designations partition the records")
+        checked += 2
+    if f & ffi.FACET_QUALITY_SCORE:
+        q = ctx.quality_scores()
+        rows = q.sum(axis=1)
+        if mixed:
+            need(int(rows[0]) == total and (rows[:-1] >= rows[1:]).all(), "quality rows start at records and never grow")
+        else:
+            need((rows[:args.read_len] == total).all(), "every record reaches every cycle exactly once")
+        checked += 1
+    if f & ffi.FACET_TEMPLATE_LENGTH:
+        h, processed, ignored = ctx.template_length()
+        need(processed + ignored == total and int(h.sum()) == processed, "template length conserves records")
+        checked += 1
+    if f & ffi.FACET_GC_CONTENT:
+        gc = ctx.gc_content()
+        need(gc["processed"] + gc["ignored_flags"] + gc["ignored_too_short"] == total, "GC conserves records")
+        need(int(gc["histogram"].sum()) == gc["processed"], "GC histogram sums to processed")
+        need(gc["total_gc_count"] + gc["total_at_count"] + gc["total_other_count"] == 100 * gc["processed"],
+             "GC window is 100 bases per processed read")
+        checked += 3
+    if f & ffi.FACET_COVERAGE and not emulated:
+        seen, hist, ign, bins = ctx.coverage_sequence(0)
+        need(seen and int(hist.sum()) + ign == CHR1 + 1, "depth histogram counts L+1 positions")
+        need(ctx.coverage_nonsensical() == 0, "no position beyond the sequence")
+        need(not ctx.coverage_sequence(1)[0], "chr2 has no entry")
+        if not mixed and f & ffi.FACET_GENERAL:
+            need(int(bins.sum()) == args.read_len * (total - g["unmapped"]), "depth total == read_len x mapped reads")
+            checked += 1
+        checked += 3
+    return ("ok: %d full-size invariants" % checked) if not bad else "FAILED: " + "; ".join(bad)
 
 
 def pmc_traffic(n: int, args):
@@ -242,28 +352,276 @@ def pmc_traffic(n: int, args):
     return None, "kernel not in summary"
 
 
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (test infrastructure) timed on the host cores -- a reported baseline
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(lib, host, ffi, scfg, sample: int, max_len: int):
-    """The CPU restatement of the reference loop (oracle/, single thread, record at a
-    time, two passes) on a bounded sample of the same workload.  Reported baseline only."""
+    """The CPU restatement of the reference loop (oracle/, single thread, record at a time, two passes) on a
+    bounded sample of the same workload: 1 warm + 3 timed runs of a 1/4 sample for the scan rate (median), one run
+    of the full sample including the O(L) chr1 teardown.  Beside it, the same scan spread over all host cores
+    (private state per thread, one teardown) -- NOT reference behaviour: the reference is one thread
+    (src/qc/command.rs:226-421)."""
     try:
+        from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle_py
-        hb = host.synth_host_batch(scfg, 0, sample, lib)
-        orc = oracle_py.Oracle([CHR1, CHR2], [1, 1], facets=ffi.FACETS_DEFAULT, max_read_len=max_len,
-                               gc_seed=0x4E4753)
+        kw = dict(facets=ffi.FACETS_DEFAULT, max_read_len=max_len, gc_seed=GC_SEED)
         chunk = 250_000
-        for lo in range(0, sample, chunk):
-            orc.process_batch(hb.slice(lo, min(sample, lo + chunk)))
-        t_scan = orc.elapsed_seconds()
+
+        def scan(orc, hb):
+            for lo in range(0, hb.n, chunk):
+                orc.process_batch(hb.slice(lo, min(hb.n, lo + chunk)))
+            return orc.elapsed_seconds()
+
+        hb = host.synth_host_batch(scfg, 0, sample, lib)
+        orc = oracle_py.Oracle([CHR1, CHR2], [1, 1], **kw)
+        t_scan = scan(orc, hb)
         orc.finalize()
         t_all = orc.elapsed_seconds()
         orc.close()
+        # repeatability of the scan rate: 3 runs on a quarter of the sample
+        quarter = hb.slice(0, max(1, sample // 4))
+        rates = []
+        for _ in range(3):
+            o = oracle_py.Oracle([CHR1, CHR2], [1, 1], **kw)
+            rates.append(quarter.n / scan(o, quarter))
+            o.close()
+        rates.sort()
+        # all cores: threads (the C calls release the GIL), private state each, disjoint contiguous slices
+        cores = os.cpu_count() or 1
+        workers = max(1, min(cores, 64))
+        per = max(100_000, min(1_000_000, sample // 2))
+
+        def work(w):
+            b = host.synth_host_batch(scfg, w * per, per, lib)
+            o = oracle_py.Oracle([CHR1, CHR2], [1, 1], **kw)
+            t0 = time.perf_counter()
+            scan(o, b)
+            dt = time.perf_counter() - t0
+            o.close()
+            return dt
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(work, range(workers)))
+        t_par = time.perf_counter() - t0
         return {"value": round(sample / t_all, 1), "unit": "records/s", "cores": 1, "kind": "port",
                 "sample": ("first %d records of the workload, all default facets; %.1f s facet loop + %.1f s chr1 "
                            "coverage teardown (O(L), not amortised over the full file)"
                            % (sample, t_scan, t_all - t_scan)),
-                "scan_only_value": round(sample / t_scan, 1)}
+                "scan_only_value": round(sample / t_scan, 1),
+                "scan_only_runs_median_of_3": round(rates[1], 1),
+                "all_cores": {"value": round(workers * per / t_par, 1), "unit": "records/s", "cores": workers,
+                              "host_cores": cores,
+                              "note": ("NOT reference behaviour (the reference is single-threaded): %d threads x %d records "
+                                       "each with private facet state, wall clock incl. batch generation, no merge and no "
+                                       "teardown" % (workers, per))}}
     except Exception as e:  # the baseline is reported, never required
         return {"value": None, "unit": "records/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+
+
+# ---------------------------------------------------------------------------------------------
+# the other two rates of SURVEY 8d: H2D-inclusive and from the BAM file
+# ---------------------------------------------------------------------------------------------
+def pinned_copy(lib, host, np, C, hb):
+    """Copy a HostBatch's columns into hipHostMalloc'd memory (the pointers are returned for freeing)."""
+    keep, cols = [], {}
+    for k, a in hb.cols.items():
+        if a is None:
+            cols[k] = None
+            continue
+        p = C.c_void_p()
+        assert lib.ngsq_host_malloc_pinned(max(a.nbytes, 64), C.byref(p)) == 0
+        dst = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(a.nbytes, 64),))
+        dst[:a.nbytes] = a.view(np.uint8).reshape(-1)
+        cols[k] = dst[:a.nbytes].view(a.dtype)
+        keep.append(p)
+    return host.HostBatch(hb.n, cols, hb.seq_stride, hb.qual_stride, hb.cigar_stride, hb.first_record_index), keep
+
+
+def leg_h2d(lib, host, ffi, args):
+    """Pinned host SoA batches through ngsq_process_batch: H2D copy + all default facet kernels per batch."""
+    import ctypes as C
+    import numpy as np
+    scfg = host.synth_config(100_000_000, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+    hb = host.synth_host_batch(scfg, 0, args.h2d_batch, lib)
+    pb, keep = pinned_copy(lib, host, np, C, hb)
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=args.read_len, gc_seed=GC_SEED, sorted_input=True, lib=lib)
+    try:
+        ctx.process_batch(pb)
+        ctx.synchronize()
+        ctx.reset()
+        reps = 8
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.process_batch(pb)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        ctx.finalize()
+        bytes_rec = 254.0 if args.read_len == 150 else 25 + 4 + (args.read_len + 1) // 2 + args.read_len
+        return {"value": round(reps * pb.n / dt, 1), "unit": "records/s", "GB_per_s": round(reps * pb.n * bytes_rec / dt / 1e9, 1),
+                "batch_records": pb.n, "batches": reps, "memory": "pinned host SoA (hipHostMalloc), the same batch re-sent",
+                "note": "PCIe Gen5 x16 bound (~63 GB/s); never `value`"}
+    finally:
+        ctx.close()
+        for p in keep:
+            lib.ngsq_host_free_pinned(p)
+
+
+def leg_file(lib, host, ffi, args):
+    """A synthetic BGZF BAM written once -> (a) `ngs qc` as a child process, wall clock including process start and HIP
+    initialisation, device ingest (the default) and host ingest; (b) the same file through the same entry points inside
+    this process (HIP already initialised): the steady-state rate.  JSON of (a) device == (a) host == (b)."""
+    import ctypes as C
+    import tempfile
+    from ngs_amd import build
+    n = args.file_records
+    tmp = tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    bam = os.path.join(tmp, "synth.bam")
+    out = {"records": n, "zlib_level": args.file_level, "host_cores": os.cpu_count()}
+    try:
+        fcfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+        t0 = time.perf_counter()
+        assert lib.ngsq_synth_write_bam(C.byref(fcfg), bam.encode(), n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+        out["bam_write_s"] = round(time.perf_counter() - t0, 2)
+        out["bam_bytes"] = os.path.getsize(bam)
+        ngs = build.build_cli(verbose=False)
+        docs = {}
+        for ingest, runs in (("device", 2), ("host", 1)):
+            best = None
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                r = subprocess.run([ngs, "-q", "qc", bam, "GRCh38_no_alt_AnalysisSet", "-o", tmp, "--ingest", ingest],
+                                   capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError(f"ngs qc --ingest {ingest}: {r.stderr[-400:]}")
+                best = dt if best is None else min(best, dt)
+            with open(os.path.join(tmp, "synth.bam.results.json")) as f:
+                docs[ingest] = json.load(f)
+            out[f"cli_{ingest}_ingest"] = {"seconds": round(best, 3), "records_per_s": round(n / best, 1),
+                                           "compressed_GB_per_s": round(out["bam_bytes"] / best / 1e9, 2),
+                                           "includes": "process start, HIP initialisation, header + index checks, JSON write"}
+        # (b) in process: ngsq_bam_open -> ngsq_bam_next_batch_device -> ngsq_process_batch -> ngsq_finalize
+        ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=1024, gc_seed=GC_SEED, sorted_input=True, timing=True, lib=lib)
+        try:
+            names = ["chr1", "chr2"]
+            best, doc = None, None
+            for rep in range(2):
+                ctx.reset()
+                ctx.kernel_timing_reset()
+                t0 = time.perf_counter()
+                h = C.c_void_p()
+                if lib.ngsq_bam_open(bam.encode(), 0, C.byref(h)) != 0:
+                    raise RuntimeError(lib.ngsq_bam_last_error().decode())
+                got = 0
+                while True:
+                    b = ffi.Batch()
+                    if lib.ngsq_bam_next_batch_device(h, ctx._ctx, 1 << 22, C.byref(b)) != 0:
+                        raise RuntimeError(lib.ngsq_bam_last_error().decode())
+                    if b.n_records == 0:
+                        break
+                    got += int(b.n_records)
+                    if lib.ngsq_process_batch(ctx._ctx, C.byref(b), ffi.PASS_BOTH) != 0:
+                        raise RuntimeError(lib.ngsq_last_error(ctx._ctx).decode())
+                lib.ngsq_bam_close(h)
+                ctx.finalize()
+                dt = time.perf_counter() - t0
+                assert got == n, (got, n)
+                if best is None or dt < best:
+                    best, timing = dt, ctx.kernel_timing()
+                doc = ctx.results(names)
+            docs["in_process"] = doc
+            out["value"] = round(n / best, 1)
+            out["unit"] = "records/s"
+            out["in_process_device_ingest"] = {"seconds": round(best, 3), "records_per_s": round(n / best, 1),
+                                               "compressed_GB_per_s": round(out["bam_bytes"] / best / 1e9, 2),
+                                               "includes": "file open, reads, H2D of the compressed bytes, inflate, parse, "
+                                                           "all default facets, finalize",
+                                               "kernels": kernel_table(timing)}
+            inf = timing.get("bgzf_inflate")
+            if inf and inf["launches"] and inf["total_ms"] > 0:
+                gbs = inf["algo_bytes"] / inf["total_ms"] / 1e6
+                out["ingest_roofline"] = {"bound": "hbm", "kernel": "k_bgzf_inflate", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                          "avg_launch_ms": round(inf["total_ms"] / inf["launches"], 3),
+                                          "algo_bytes_per_launch": inf["algo_bytes"] // inf["launches"],
+                                          "note": "algorithmic bytes = compressed bytes read + inflated bytes written; the kernel is "
+                                                  "bound by instruction latency (one decoder wave per BGZF block), not by HBM"}
+        finally:
+            ctx.close()
+        def strip(d):  # the GC window offsets are a function of (seed, record index): identical across the runs
+            return json.dumps(d, sort_keys=True)
+        out["json_equal_device_host_inprocess"] = strip(docs["device"]) == strip(docs["host"]) == strip(docs["in_process"])
+        out["check_total"] = docs["device"]["general"]["records"]["total"]
+        return out
+    finally:
+        for f in os.listdir(tmp):
+            os.remove(os.path.join(tmp, f))
+        os.rmdir(tmp)
+
+
+# ---------------------------------------------------------------------------------------------
+# Edits and Genomic Features (optional facets of the reference: -r FASTA, -f GFF)
+# ---------------------------------------------------------------------------------------------
+def synthetic_reference(np):
+    """4-bit base codes (A C G T = 1 2 4 8), one per byte, for chr1 and chr2: the reference FASTA resident in HBM."""
+    rng = np.random.default_rng(0x4E4753)
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)
+    return [codes[rng.integers(0, 4, L, dtype=np.uint8)] for L in (CHR1, CHR2)]
+
+
+def synthetic_gene_model(np):
+    """A GENCODE-shaped gene model on chr1/chr2: ~20 k genes per sequence, ~10 exons each, CDS inside exons, UTRs
+    at the ends (columns of ngsq_features: sequence index, name id = role, GFF start, GFF end)."""
+    rng = np.random.default_rng(0x47464633)
+    ref, name, start, stop = [], [], [], []
+    for r, L in enumerate((CHR1, CHR2)):
+        n_genes = 20_000
+        g0 = np.sort(rng.integers(1, L - 200_000, n_genes))
+        glen = rng.integers(2_000, 150_000, n_genes)
+        for a, ln in zip(g0.tolist(), glen.tolist()):
+            ref.append(r); name.append(4); start.append(a); stop.append(a + ln)          # gene
+            k = int(rng.integers(2, 18))
+            cuts = np.sort(rng.integers(a, a + ln, 2 * k))
+            for e in range(k):
+                s, t = int(cuts[2 * e]), int(cuts[2 * e + 1])
+                ref.append(r); name.append(3); start.append(s); stop.append(t)            # exon
+                if 0 < e < k - 1:
+                    ref.append(r); name.append(2); start.append(s); stop.append(t)        # CDS
+            ref.append(r); name.append(0); start.append(int(cuts[0])); stop.append(int(cuts[1]))      # 5' UTR
+            ref.append(r); name.append(1); start.append(int(cuts[-2])); stop.append(int(cuts[-1]))   # 3' UTR
+    return (np.asarray(ref, dtype=np.uint32), np.asarray(name, dtype=np.uint32), np.asarray(start, dtype=np.uint32),
+            np.asarray(stop, dtype=np.uint32))
+
+
+def leg_extra_facets(lib, host, ffi, np):
+    """Kernel times of the two optional facets on the first 10 M records of the workload (reference bases of chr1
+    and chr2 and a 400 k-interval gene model resident in HBM)."""
+    n = 10_000_000
+    scfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2)
+    out = {"records": n}
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=ffi.FACET_EDITS | ffi.FACET_FEATURES, max_read_len=150, gc_seed=GC_SEED,
+                         timing=True, ref_bases=synthetic_reference(np), lib=lib)
+    try:
+        ctx.set_features(*synthetic_gene_model(np))
+        db = ctx.synth_device_batch(scfg, 0, n)
+        for rep in range(2):
+            ctx.reset()
+            ctx.kernel_timing_reset()
+            ctx.process_batch(db)
+            ctx.finalize()
+        t = ctx.kernel_timing()
+        f = ctx.features()
+        out["kernels"] = kernel_table(t)
+        for k in ("edits", "edits_vaf", "features"):
+            if k in out["kernels"]:
+                out["kernels"][k]["hbm_frac"] = round(out["kernels"][k]["GBps"] / HBM_PEAK_GBS, 4)
+        out["features_processed"] = f["processed"]
+        r1, r2, vaf = ctx.edits()
+        out["edits_reads"] = int(r1.sum() + r2.sum())
+        ctx.free_batch(db)
+        return out
+    finally:
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
 SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "cov_stream.hip", "synth.hip", "bgzf_inflate.hip",
-           "bam_device.hip", "features_kernel.hip", "context.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
-HEADERS = ["kernels.h", "context.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h",
+           "bam_device.hip", "features_kernel.hip", "exchange_kernels.hip", "comm.cpp", "exchange.cpp", "context.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
+HEADERS = ["kernels.h", "context.h", "comm.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h", "../../include/ngsq_comm.h",
            "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-gpu-rdc"]
 FLAGS += os.environ.get("NGSQ_EXTRA_FLAGS", "").split()  # measurement builds, e.g. -DNGSQ_INFLATE_PROFILE (use --force)
@@ -77,7 +77,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + objs + ["-lz", "-lpthread", "-o", OUT + ".tmp"]
+    cmd = [cc, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + objs + ["-lz", "-lpthread", "-ldl", "-lrt", "-o", OUT + ".tmp"]
     if verbose:
         print("[ngs_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

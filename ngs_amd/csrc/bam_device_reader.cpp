@@ -283,7 +283,10 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
     BHIP(d->d_seg.reserve((size_t)n_seg * 2));
     BHIP(d->d_small.reserve(16));
-    BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+    {
+        KernelTimer kt(d->ctx, K_REC_INDEX, d->raw_len);
+        BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+    }
     d->cand.resize((size_t)n_seg * REC_CANDIDATES);
     BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
     BHIP(hipStreamSynchronize(st));
@@ -371,7 +374,14 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
             BHIP(hipMemsetAsync(d->d_comp_slot[slot].p + consumed, 0, INFLATE_IN_SLACK, st));
         }
         BHIP(hipMemcpyAsync(d->d_blocks.p, c.blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
-        BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, true, st));
+        {   // algorithmic bytes of the inflate: compressed bytes read + inflated bytes written
+            KernelTimer kt(d->ctx, K_INFLATE, consumed + total);
+            BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, false, st));
+        }
+        {
+            KernelTimer kt(d->ctx, K_INFLATE_CRC, total);
+            BHIP(launch_bgzf_crc(d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, st));
+        }
         d->status.resize(n_blk);
         BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         BHIP(hipStreamSynchronize(st));
@@ -730,7 +740,10 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     col.tlen = d->d_tlen.p;
     col.l_seq = d->d_l_seq.p;
     BHIP(hipMemsetAsync(d->d_small.p + 1, 0, 3 * sizeof(unsigned long long), st));
-    BHIP(launch_rec_fixed(d->d_raw.p, rec, n, col, d->d_small.p + 1, st));
+    {
+        KernelTimer kt(d->ctx, K_REC_COLUMNS, n * 36);
+        BHIP(launch_rec_fixed(d->d_raw.p, rec, n, col, d->d_small.p + 1, st));
+    }
     unsigned long long stats[3] = {0, 0, 0};
     BHIP(hipMemcpyAsync(stats, d->d_small.p + 1, sizeof stats, hipMemcpyDeviceToHost, st));
     BHIP(hipStreamSynchronize(st));
@@ -776,7 +789,10 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     col.cigar = d->d_cigar.p;
     col.seq_pitch = pitch_s;
     col.qual_pitch = pitch_q;
-    BHIP(launch_rec_var(d->d_raw.p, rec, n, col, so, qo, st));
+    {
+        KernelTimer kt(d->ctx, K_REC_COLUMNS, 2 * (so + qo + co * 4));
+        BHIP(launch_rec_var(d->d_raw.p, rec, n, col, so, qo, st));
+    }
     d->cursor += n;
     b->n_read += n;
     out->n_records = n;

@@ -727,6 +727,12 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ ou
     if (!isize && lane == 0 && blocks[bi].crc != 0) status[bi] = INF_CRC_MISMATCH;
 }
 
+hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s) {
+    if (!n_blocks) return hipSuccess;
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, s, out, blocks, n_blocks, status);
+    return hipGetLastError();
+}
+
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
                                uint32_t *status, bool check_crc, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
@@ -738,7 +744,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         attr = true;
     }
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks), dim3(64), sizeof(Lds), s, comp, blocks, n_blocks, out, status);
-    if (check_crc) hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, s, out, blocks, n_blocks, status);
+    if (check_crc) (void)launch_bgzf_crc(blocks, n_blocks, out, status, s);
 #ifdef NGSQ_INFLATE_PROFILE
     {
         unsigned long long h[16];

@@ -1,0 +1,592 @@
+// comm.cpp -- transports of the multi-GPU exchange (include/ngsq_comm.h):
+//   RcclComm    RCCL called directly (dlopen'ed: a one-GPU run never loads the 500 MB library),
+//               collectives enqueued on the caller's HIP stream, point-to-point halos as one
+//               ncclGroup of ncclSend/ncclRecv -- xGMI is point to point, a halo has one receiver
+//   ShmComm     POSIX shared memory: one slot per rank + a sense-reversing barrier
+//   CustomComm  callbacks of the host program
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "comm.h"
+
+static thread_local std::string g_comm_err;
+
+namespace ngsq {
+int comm_fail(ngsq_comm *c, int code, const char *fmt, ...) {
+    char buf[640];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_comm_err = buf;
+    if (c) c->err = buf;
+    return code;
+}
+} // namespace ngsq
+using ngsq::comm_fail;
+
+// ---------------------------------------------------------------------------------------------
+// RCCL
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;
+};
+
+RcclApi *rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a library of that soname already in the process (e.g. PyTorch's copy) is the one dlopen returns
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+            api.why = dlerror() ? dlerror() : "dlopen failed";
+        }
+        if (!api.handle) return;
+#define SYM(field, name)                                                             \
+    do {                                                                             \
+        api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, name));   \
+        if (!api.field) {                                                            \
+            api.why = std::string("symbol missing: ") + name;                        \
+            api.handle = nullptr;                                                    \
+            return;                                                                  \
+        }                                                                            \
+    } while (0)
+        SYM(GetUniqueId, "ncclGetUniqueId");
+        SYM(CommInitRank, "ncclCommInitRank");
+        SYM(CommDestroy, "ncclCommDestroy");
+        SYM(AllReduce, "ncclAllReduce");
+        SYM(AllGather, "ncclAllGather");
+        SYM(Send, "ncclSend");
+        SYM(Recv, "ncclRecv");
+        SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd");
+        SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    });
+    return api.handle ? &api : nullptr;
+}
+
+#define NCCL_TRY(c, expr)                                                                              \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return comm_fail((c), NGSQ_ERR_DEVICE, "%s failed: %s", #expr, api->GetErrorString(r_));   \
+    } while (0)
+#define HIPC_TRY(c, expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return comm_fail((c), NGSQ_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+struct RcclComm : ngsq_comm {
+    RcclApi *api = nullptr;
+    ncclComm_t comm = nullptr;
+    int dev = 0;
+    hipStream_t own_stream = nullptr; // host-buffer collectives
+    uint8_t *scratch = nullptr;
+    uint64_t scratch_cap = 0;
+
+    ~RcclComm() override {
+        (void)hipSetDevice(dev);
+        if (own_stream) {
+            (void)hipStreamSynchronize(own_stream);
+            (void)hipStreamDestroy(own_stream);
+        }
+        if (scratch) (void)hipFree(scratch);
+        if (comm && api) (void)api->CommDestroy(comm);
+    }
+    int allreduce(void *buf, uint64_t count, uint32_t eb, hipStream_t s) override {
+        if (!count) return NGSQ_OK;
+        NCCL_TRY(this, api->AllReduce(buf, buf, count, eb == 8 ? ncclUint64 : ncclUint32, ncclSum, comm, s));
+        return NGSQ_OK;
+    }
+    int allgather(const void *send, void *recv, uint64_t bytes, hipStream_t s) override {
+        if (!bytes) return NGSQ_OK;
+        NCCL_TRY(this, api->AllGather(send, recv, bytes, ncclUint8, comm, s));
+        return NGSQ_OK;
+    }
+    int sendrecv(const ngsq_p2p *sends, uint32_t ns, const ngsq_p2p *recvs, uint32_t nr, hipStream_t s) override {
+        if (!ns && !nr) return NGSQ_OK;
+        NCCL_TRY(this, api->GroupStart());
+        for (uint32_t i = 0; i < nr; i++)
+            if (recvs[i].bytes) NCCL_TRY(this, api->Recv(recvs[i].buf, recvs[i].bytes, ncclUint8, recvs[i].peer, comm, s));
+        for (uint32_t i = 0; i < ns; i++)
+            if (sends[i].bytes) NCCL_TRY(this, api->Send(sends[i].buf, sends[i].bytes, ncclUint8, sends[i].peer, comm, s));
+        NCCL_TRY(this, api->GroupEnd());
+        return NGSQ_OK;
+    }
+    int need(uint64_t bytes) {
+        if (scratch_cap >= bytes) return NGSQ_OK;
+        HIPC_TRY(this, hipStreamSynchronize(own_stream));
+        if (scratch) (void)hipFree(scratch);
+        scratch = nullptr;
+        scratch_cap = 0;
+        const uint64_t cap = std::max<uint64_t>(bytes, 1 << 16);
+        HIPC_TRY(this, hipMalloc((void **)&scratch, cap));
+        scratch_cap = cap;
+        return NGSQ_OK;
+    }
+    int allgather_host(const void *send, void *recv, uint64_t bytes) override {
+        if (!bytes) return NGSQ_OK;
+        HIPC_TRY(this, hipSetDevice(dev));
+        const uint64_t pad = (bytes + 15) & ~15ull;
+        int rc = need(pad * (world + 1));
+        if (rc) return rc;
+        HIPC_TRY(this, hipMemcpyAsync(scratch, send, bytes, hipMemcpyHostToDevice, own_stream));
+        rc = allgather(scratch, scratch + pad, bytes, own_stream);
+        if (rc) return rc;
+        HIPC_TRY(this, hipMemcpyAsync(recv, scratch + pad, bytes * world, hipMemcpyDeviceToHost, own_stream));
+        HIPC_TRY(this, hipStreamSynchronize(own_stream));
+        return NGSQ_OK;
+    }
+    int allreduce_host(void *buf, uint64_t count, uint32_t eb) override {
+        if (!count) return NGSQ_OK;
+        HIPC_TRY(this, hipSetDevice(dev));
+        int rc = need(count * eb);
+        if (rc) return rc;
+        HIPC_TRY(this, hipMemcpyAsync(scratch, buf, count * eb, hipMemcpyHostToDevice, own_stream));
+        rc = allreduce(scratch, count, eb, own_stream);
+        if (rc) return rc;
+        HIPC_TRY(this, hipMemcpyAsync(buf, scratch, count * eb, hipMemcpyDeviceToHost, own_stream));
+        HIPC_TRY(this, hipStreamSynchronize(own_stream));
+        return NGSQ_OK;
+    }
+    int sendrecv_host(const ngsq_p2p *sends, uint32_t ns, const ngsq_p2p *recvs, uint32_t nr) override {
+        HIPC_TRY(this, hipSetDevice(dev));
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < ns; i++) total += (sends[i].bytes + 15) & ~15ull;
+        for (uint32_t i = 0; i < nr; i++) total += (recvs[i].bytes + 15) & ~15ull;
+        int rc = need(total);
+        if (rc) return rc;
+        std::vector<ngsq_p2p> ds(sends, sends + ns), dr(recvs, recvs + nr);
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < ns; i++) {
+            ds[i].buf = scratch + off;
+            if (sends[i].bytes)
+                HIPC_TRY(this, hipMemcpyAsync(ds[i].buf, sends[i].buf, sends[i].bytes, hipMemcpyHostToDevice, own_stream));
+            off += (sends[i].bytes + 15) & ~15ull;
+        }
+        for (uint32_t i = 0; i < nr; i++) {
+            dr[i].buf = scratch + off;
+            off += (recvs[i].bytes + 15) & ~15ull;
+        }
+        rc = sendrecv(ds.data(), ns, dr.data(), nr, own_stream);
+        if (rc) return rc;
+        for (uint32_t i = 0; i < nr; i++)
+            if (recvs[i].bytes)
+                HIPC_TRY(this, hipMemcpyAsync(recvs[i].buf, dr[i].buf, recvs[i].bytes, hipMemcpyDeviceToHost, own_stream));
+        HIPC_TRY(this, hipStreamSynchronize(own_stream));
+        return NGSQ_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// shared memory
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SHM_MAGIC = 0x4E475351u; // "NGSQ"
+constexpr uint32_t SHM_MAX_MSGS = 4 * NGSQ_COMM_MAX_WORLD;
+
+struct ShmHeader {
+    std::atomic<uint32_t> magic;
+    uint32_t world;
+    uint64_t slot_bytes;
+    std::atomic<uint32_t> arrived, generation, attached, failed;
+};
+struct ShmMsg {
+    int32_t peer;
+    uint32_t pad;
+    uint64_t bytes, off;
+};
+struct ShmSlot {
+    uint64_t total_out;
+    uint32_t n_msgs, pad;
+    ShmMsg dir[SHM_MAX_MSGS];
+};
+
+static double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+struct ShmComm : ngsq_comm {
+    std::string name;
+    uint8_t *base = nullptr;
+    uint64_t map_bytes = 0, S = 0;
+    ShmHeader *hdr = nullptr;
+    double timeout_s = 300.0;
+
+    ShmSlot *slot(int r) const { return reinterpret_cast<ShmSlot *>(base + 4096 + (uint64_t)r * slot_stride()); }
+    uint8_t *data(int r) const { return reinterpret_cast<uint8_t *>(slot(r)) + ((sizeof(ShmSlot) + 4095) & ~4095ull); }
+    uint64_t slot_stride() const { return ((sizeof(ShmSlot) + 4095) & ~4095ull) + S; }
+
+    ~ShmComm() override {
+        if (base) munmap(base, map_bytes);
+        if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
+    }
+    int barrier() {
+        if (world == 1) return NGSQ_OK;
+        const uint32_t gen = hdr->generation.load(std::memory_order_acquire);
+        if (hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
+            hdr->arrived.store(0, std::memory_order_relaxed);
+            hdr->generation.fetch_add(1, std::memory_order_acq_rel);
+            return NGSQ_OK;
+        }
+        const double t0 = now_s();
+        for (uint64_t spins = 0;; spins++) {
+            if (hdr->generation.load(std::memory_order_acquire) != gen) return NGSQ_OK;
+            if (hdr->failed.load(std::memory_order_relaxed))
+                return comm_fail(this, NGSQ_ERR_STATE, "shm transport: another rank failed");
+            if (spins < 2000) continue;
+            if (spins < 20000) {
+                sched_yield();
+                continue;
+            }
+            timespec ts{0, 50000};
+            nanosleep(&ts, nullptr);
+            if ((spins & 1023) == 0 && now_s() - t0 > timeout_s) {
+                hdr->failed.store(1);
+                return comm_fail(this, NGSQ_ERR_STATE, "shm transport: rank %d waited %.0f s at a barrier (a rank died?)", rank,
+                                 timeout_s);
+            }
+        }
+    }
+    int allgather(const void *send, void *recv, uint64_t bytes, hipStream_t) override {
+        const uint8_t *src = static_cast<const uint8_t *>(send);
+        uint8_t *dst = static_cast<uint8_t *>(recv);
+        for (uint64_t o = 0; o < bytes; o += S) {
+            const uint64_t n = std::min(S, bytes - o);
+            memcpy(data(rank), src + o, n);
+            int rc = barrier();
+            if (rc) return rc;
+            for (int r = 0; r < world; r++) memcpy(dst + (uint64_t)r * bytes + o, data(r), n);
+            rc = barrier();
+            if (rc) return rc;
+        }
+        return NGSQ_OK;
+    }
+    int allreduce(void *buf, uint64_t count, uint32_t eb, hipStream_t) override {
+        uint8_t *p = static_cast<uint8_t *>(buf);
+        const uint64_t bytes = count * eb;
+        for (uint64_t o = 0; o < bytes; o += S) {
+            const uint64_t n = std::min(S, bytes - o);
+            memcpy(data(rank), p + o, n);
+            int rc = barrier();
+            if (rc) return rc;
+            if (eb == 8) {
+                uint64_t *d = reinterpret_cast<uint64_t *>(p + o);
+                for (uint64_t i = 0; i < n / 8; i++) d[i] = 0;
+                for (int r = 0; r < world; r++) {
+                    const uint64_t *s = reinterpret_cast<const uint64_t *>(data(r));
+                    for (uint64_t i = 0; i < n / 8; i++) d[i] += s[i];
+                }
+            } else {
+                uint32_t *d = reinterpret_cast<uint32_t *>(p + o);
+                for (uint64_t i = 0; i < n / 4; i++) d[i] = 0;
+                for (int r = 0; r < world; r++) {
+                    const uint32_t *s = reinterpret_cast<const uint32_t *>(data(r));
+                    for (uint64_t i = 0; i < n / 4; i++) d[i] += s[i];
+                }
+            }
+            rc = barrier();
+            if (rc) return rc;
+        }
+        return NGSQ_OK;
+    }
+    int sendrecv(const ngsq_p2p *sends, uint32_t ns, const ngsq_p2p *recvs, uint32_t nr, hipStream_t) override {
+        if (ns > SHM_MAX_MSGS) return comm_fail(this, NGSQ_ERR_UNSUPPORTED, "shm transport: more than %u messages", SHM_MAX_MSGS);
+        ShmSlot *me = slot(rank);
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < ns; i++) {
+            me->dir[i] = {sends[i].peer, 0, sends[i].bytes, off};
+            off += sends[i].bytes;
+        }
+        me->n_msgs = ns;
+        me->total_out = off;
+        int rc = barrier();
+        if (rc) return rc;
+        uint64_t longest = 0;
+        for (int r = 0; r < world; r++) longest = std::max(longest, slot(r)->total_out);
+        // my receives from rank s, in list order, matched to s's messages for me in its list order
+        std::vector<std::vector<std::pair<const ShmMsg *, const ngsq_p2p *>>> in(world);
+        for (int s = 0; s < world; s++) {
+            uint32_t k = 0;
+            const ShmSlot *sl = slot(s);
+            for (uint32_t i = 0; i < sl->n_msgs; i++) {
+                if (sl->dir[i].peer != rank) continue;
+                while (k < nr && recvs[k].peer != s) k++;
+                if (k == nr || recvs[k].bytes != sl->dir[i].bytes) {
+                    hdr->failed.store(1);
+                    return comm_fail(this, NGSQ_ERR_STATE, "shm transport: rank %d sends a message rank %d does not expect", s, rank);
+                }
+                in[s].push_back({&sl->dir[i], &recvs[k]});
+                k++;
+            }
+        }
+        for (uint64_t w0 = 0; w0 < longest; w0 += S) {
+            const uint64_t w1 = w0 + S;
+            for (uint32_t i = 0; i < ns; i++) {
+                const uint64_t a = std::max(w0, me->dir[i].off), b = std::min(w1, me->dir[i].off + me->dir[i].bytes);
+                if (a < b) memcpy(data(rank) + (a - w0), static_cast<const uint8_t *>(sends[i].buf) + (a - me->dir[i].off), b - a);
+            }
+            rc = barrier();
+            if (rc) return rc;
+            for (int s = 0; s < world; s++)
+                for (auto &m : in[s]) {
+                    const uint64_t a = std::max(w0, m.first->off), b = std::min(w1, m.first->off + m.first->bytes);
+                    if (a < b) memcpy(static_cast<uint8_t *>(m.second->buf) + (a - m.first->off), data(s) + (a - w0), b - a);
+                }
+            rc = barrier();
+            if (rc) return rc;
+        }
+        return barrier(); // directories stay valid until every rank has read them
+    }
+};
+
+struct CustomComm : ngsq_comm {
+    ngsq_comm_ops ops{};
+    int allreduce(void *buf, uint64_t count, uint32_t eb, hipStream_t) override {
+        if (!count) return NGSQ_OK;
+        const int rc = ops.allreduce_sum(ops.user, buf, count, eb);
+        return rc ? comm_fail(this, NGSQ_ERR_STATE, "custom transport: allreduce_sum returned %d", rc) : NGSQ_OK;
+    }
+    int allgather(const void *send, void *recv, uint64_t bytes, hipStream_t) override {
+        if (!bytes) return NGSQ_OK;
+        const int rc = ops.allgather(ops.user, send, recv, bytes);
+        return rc ? comm_fail(this, NGSQ_ERR_STATE, "custom transport: allgather returned %d", rc) : NGSQ_OK;
+    }
+    int sendrecv(const ngsq_p2p *sends, uint32_t ns, const ngsq_p2p *recvs, uint32_t nr, hipStream_t) override {
+        if (!ns && !nr) return NGSQ_OK;
+        const int rc = ops.sendrecv(ops.user, sends, ns, recvs, nr);
+        return rc ? comm_fail(this, NGSQ_ERR_STATE, "custom transport: sendrecv returned %d", rc) : NGSQ_OK;
+    }
+};
+
+int check_rank(int rank, int world) {
+    if (world < 1 || world > NGSQ_COMM_MAX_WORLD || rank < 0 || rank >= world)
+        return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "rank %d of %d: need 0 <= rank < world <= %d", rank, world,
+                         NGSQ_COMM_MAX_WORLD);
+    return NGSQ_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *ngsq_comm_last_error(const ngsq_comm *c) { return c ? c->err.c_str() : g_comm_err.c_str(); }
+
+int ngsq_comm_unique_id(uint8_t id[NGSQ_COMM_ID_BYTES]) {
+    if (!id) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    RcclApi *api = rccl_api();
+    if (!api) return comm_fail(nullptr, NGSQ_ERR_UNSUPPORTED, "RCCL is not available (librccl.so.1 could not be loaded)");
+    static_assert(sizeof(ncclUniqueId) == NGSQ_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    NCCL_TRY(nullptr, api->GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return NGSQ_OK;
+}
+
+int ngsq_comm_create_rccl(int rank, int world, const uint8_t id[NGSQ_COMM_ID_BYTES], int device, ngsq_comm **out) {
+    if (!id || !out) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int rc = check_rank(rank, world);
+    if (rc) return rc;
+    RcclApi *api = rccl_api();
+    if (!api) return comm_fail(nullptr, NGSQ_ERR_UNSUPPORTED, "RCCL is not available (librccl.so.1 could not be loaded)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return comm_fail(nullptr, NGSQ_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "device %d out of range", device);
+    HIPC_TRY(nullptr, hipSetDevice(device));
+    RcclComm *c = new RcclComm();
+    c->rank = rank;
+    c->world = world;
+    c->kind = "rccl";
+    c->device = true;
+    c->api = api;
+    c->dev = device;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t r = api->CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        delete c;
+        return comm_fail(nullptr, NGSQ_ERR_DEVICE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device,
+                         api->GetErrorString(r));
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return comm_fail(nullptr, NGSQ_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return NGSQ_OK;
+}
+
+int ngsq_comm_create_shm(const char *name, int rank, int world, uint64_t slot_bytes, ngsq_comm **out) {
+    if (!name || !out) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int rc = check_rank(rank, world);
+    if (rc) return rc;
+    if (name[0] != '/') return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "shm name must start with '/'");
+    if (!slot_bytes) slot_bytes = 4ull << 20;
+    slot_bytes = (slot_bytes + 4095) & ~4095ull;
+    ShmComm *c = new ShmComm();
+    c->rank = rank;
+    c->world = world;
+    c->kind = "shm";
+    c->name = rank == 0 ? name : ""; // only rank 0 unlinks
+    c->S = slot_bytes;
+    if (const char *t = getenv("NGSQ_COMM_TIMEOUT_S")) c->timeout_s = atof(t) > 0 ? atof(t) : c->timeout_s;
+    c->map_bytes = 4096 + (uint64_t)world * c->slot_stride();
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(name); // a stale segment of a crashed run
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)c->map_bytes) != 0) {
+            const int e = errno;
+            if (fd >= 0) close(fd);
+            delete c;
+            return comm_fail(nullptr, NGSQ_ERR_STATE, "shm_open/ftruncate(%s): %s", name, strerror(e));
+        }
+    } else {
+        const double t0 = now_s();
+        for (;;) {
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) == 0 && (uint64_t)st.st_size >= c->map_bytes) break;
+                close(fd);
+                fd = -1;
+            }
+            if (now_s() - t0 > c->timeout_s) {
+                delete c;
+                return comm_fail(nullptr, NGSQ_ERR_STATE, "shm transport: rank %d found no segment %s within %.0f s", rank, name,
+                                 c->timeout_s);
+            }
+            timespec ts{0, 2000000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    void *p = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        const int e = errno;
+        delete c;
+        return comm_fail(nullptr, NGSQ_ERR_STATE, "mmap(%s): %s", name, strerror(e));
+    }
+    c->base = static_cast<uint8_t *>(p);
+    c->hdr = reinterpret_cast<ShmHeader *>(p);
+    if (rank == 0) {
+        c->hdr->world = (uint32_t)world;
+        c->hdr->slot_bytes = slot_bytes;
+        c->hdr->arrived.store(0);
+        c->hdr->generation.store(0);
+        c->hdr->failed.store(0);
+        c->hdr->attached.store(1);
+        c->hdr->magic.store(SHM_MAGIC, std::memory_order_release);
+    } else {
+        const double t0 = now_s();
+        while (c->hdr->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+            if (now_s() - t0 > c->timeout_s) {
+                delete c;
+                return comm_fail(nullptr, NGSQ_ERR_STATE, "shm transport: segment %s was never initialised", name);
+            }
+            sched_yield();
+        }
+        if (c->hdr->world != (uint32_t)world || c->hdr->slot_bytes != slot_bytes) {
+            delete c;
+            return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "shm transport: segment %s belongs to a job of another shape", name);
+        }
+        c->hdr->attached.fetch_add(1);
+    }
+    rc = c->barrier(); // nobody proceeds (and rank 0 cannot unlink) before all ranks are attached
+    if (rc) {
+        g_comm_err = c->err;
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return NGSQ_OK;
+}
+
+int ngsq_comm_create_custom(int rank, int world, const ngsq_comm_ops *ops, ngsq_comm **out) {
+    if (!ops || !out) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int rc = check_rank(rank, world);
+    if (rc) return rc;
+    if (ops->struct_size != sizeof(ngsq_comm_ops) || !ops->allreduce_sum || !ops->allgather || !ops->sendrecv)
+        return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "ngsq_comm_ops: struct_size %u != %zu or a null callback", ops->struct_size,
+                         sizeof(ngsq_comm_ops));
+    CustomComm *c = new CustomComm();
+    c->rank = rank;
+    c->world = world;
+    c->kind = "custom";
+    c->ops = *ops;
+    *out = c;
+    return NGSQ_OK;
+}
+
+void ngsq_comm_destroy(ngsq_comm *c) { delete c; }
+int ngsq_comm_rank(const ngsq_comm *c) { return c ? c->rank : -1; }
+int ngsq_comm_world(const ngsq_comm *c) { return c ? c->world : 0; }
+const char *ngsq_comm_kind(const ngsq_comm *c) { return c ? c->kind : ""; }
+
+int ngsq_comm_allgather_host(ngsq_comm *c, const void *send, void *recv, uint64_t bytes) {
+    if (!c || (bytes && (!send || !recv))) return comm_fail(c, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    return c->allgather_host(send, recv, bytes);
+}
+int ngsq_comm_allreduce_host(ngsq_comm *c, void *buf, uint64_t count, uint32_t eb) {
+    if (!c || (count && !buf)) return comm_fail(c, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (eb != 4 && eb != 8) return comm_fail(c, NGSQ_ERR_INVALID_ARGUMENT, "elem_bytes must be 4 or 8");
+    return c->allreduce_host(buf, count, eb);
+}
+int ngsq_comm_sendrecv_host(ngsq_comm *c, const ngsq_p2p *sends, uint32_t ns, const ngsq_p2p *recvs, uint32_t nr) {
+    if (!c || (ns && !sends) || (nr && !recvs)) return comm_fail(c, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t i = 0; i < ns; i++)
+        if (sends[i].peer < 0 || sends[i].peer >= c->world) return comm_fail(c, NGSQ_ERR_INVALID_ARGUMENT, "send to rank %d", sends[i].peer);
+    for (uint32_t i = 0; i < nr; i++)
+        if (recvs[i].peer < 0 || recvs[i].peer >= c->world) return comm_fail(c, NGSQ_ERR_INVALID_ARGUMENT, "receive from rank %d", recvs[i].peer);
+    return c->sendrecv_host(sends, ns, recvs, nr);
+}
+int ngsq_comm_barrier(ngsq_comm *c) {
+    if (!c) return comm_fail(c, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    uint32_t one = 1;
+    int rc = c->allreduce_host(&one, 1, 4);
+    if (rc) return rc;
+    return one == (uint32_t)c->world ? NGSQ_OK : comm_fail(c, NGSQ_ERR_STATE, "barrier: %u of %d ranks", one, c->world);
+}
+
+} // extern "C"

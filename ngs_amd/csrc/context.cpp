@@ -20,6 +20,10 @@
 
 using namespace ngsq;
 
+namespace ngsq {
+void free_exchange_scratch(void *p); // exchange.cpp
+}
+
 static thread_local std::string g_err;
 
 static int fail(ngsq_ctx *c, int code, const char *fmt, ...) {
@@ -43,7 +47,8 @@ static int fail(ngsq_ctx *c, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits", "cov_scan", "edits_vaf", "h2d", "features", "cov_stream"};
+static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits", "cov_scan", "edits_vaf", "h2d", "features", "cov_stream", "bgzf_inflate", "bgzf_crc",
+                                                 "rec_index", "rec_columns"};
 
 extern "C" {
 
@@ -308,6 +313,7 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_stream_u32);
     (void)hipFree(c->d_last_key);
     (void)hipFree(c->d_chunk_flags);
+    if (c->xchg_scratch) ngsq::free_exchange_scratch(c->xchg_scratch);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -325,26 +331,22 @@ static hipEvent_t get_event(ngsq_ctx *c) {
     return e;
 }
 
-struct Bracket {
-    ngsq_ctx *c;
-    int id;
-    hipEvent_t a = nullptr, b = nullptr;
-    Bracket(ngsq_ctx *c_, int id_, uint64_t bytes) : c(c_), id(id_) {
-        c->timing[id].launches += 1;
-        c->timing[id].algo_bytes += bytes;
-        if (c->cfg.timing) {
-            a = get_event(c);
-            b = get_event(c);
-            (void)hipEventRecord(a, c->stream);
-        }
+ngsq::KernelTimer::KernelTimer(ngsq_ctx *c_, int id_, uint64_t bytes) : c(c_), id(id_) {
+    c->timing[id].launches += 1;
+    c->timing[id].algo_bytes += bytes;
+    if (c->cfg.timing) {
+        a = get_event(c);
+        b = get_event(c);
+        (void)hipEventRecord(a, c->stream);
     }
-    ~Bracket() {
-        if (c->cfg.timing) {
-            (void)hipEventRecord(b, c->stream);
-            c->pending.push_back({id, a, b});
-        }
+}
+ngsq::KernelTimer::~KernelTimer() {
+    if (c->cfg.timing) {
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({id, a, b});
     }
-};
+}
+typedef ngsq::KernelTimer Bracket;
 
 static void resolve_timing(ngsq_ctx *c) {
     for (auto &p : c->pending) {
@@ -648,6 +650,8 @@ int ngsq_teardown(ngsq_ctx *c) {
         a.c_begin = c->scan_lo;
         a.c_end = c->scan_hi;
         a.carry_in = c->scan_carry;
+        a.carry_words = c->scan_words;
+        a.carry_mask = c->scan_front;
         a.chunk_sums = c->st.chunk_sums;
         a.super_sums = c->st.super_sums;
         a.ref_first_chunk = c->d_first_chunk;
@@ -667,10 +671,14 @@ int ngsq_teardown(ngsq_ctx *c) {
     if (facets & NGSQ_FACET_EDITS) {
         for (uint32_t r = 0; r < nr; r++) {
             if (c->edits_off[r] == NO_DEPTH) continue;
+            // a sharded run splits the positions of every sequence evenly over the ranks (ngsq_exchange);
+            // the partial histograms are summed with the other teardown results
+            const uint64_t L1 = (uint64_t)c->ref_len[r] + 1;
+            const uint64_t p0 = L1 * c->vaf_part / c->vaf_parts, p1 = L1 * (c->vaf_part + 1) / c->vaf_parts;
+            if (p1 <= p0) continue;
             const uint32_t *refs = c->st.edits + c->edits_off[r];
-            Bracket br(c, K_EDITS_VAF, ((uint64_t)c->ref_len[r] + 1) * 8);
-            HIP_TRY(c, launch_edits_vaf(c->li, refs, refs + (uint64_t)c->ref_len[r] + 1, c->ref_len[r], c->d_vaf,
-                                        c->stream));
+            Bracket br(c, K_EDITS_VAF, (p1 - p0) * 8);
+            HIP_TRY(c, launch_edits_vaf(c->li, refs + p0, refs + L1 + p0, (uint32_t)(p1 - p0 - 1), c->d_vaf, c->stream));
         }
     }
     c->torn_down = true;
@@ -753,6 +761,8 @@ int ngsq_set_scan_range(ngsq_ctx *c, uint64_t chunk_lo, uint64_t chunk_hi, uint3
     c->scan_lo = chunk_lo;
     c->scan_hi = chunk_hi;
     c->scan_carry = carry_in;
+    c->scan_words = nullptr;
+    c->scan_front = 0;
     c->scan_partial = !(chunk_lo == 0 && chunk_hi == c->n_chunks && carry_in == 0);
     return NGSQ_OK;
 }
@@ -807,6 +817,10 @@ int ngsq_reset(ngsq_ctx *c) {
     c->scan_hi = c->n_chunks;
     c->scan_carry = 0;
     c->scan_partial = false;
+    c->scan_words = nullptr;
+    c->scan_front = 0;
+    c->vaf_part = 0;
+    c->vaf_parts = 1;
     return NGSQ_OK;
 }
 

@@ -9,13 +9,26 @@
 #include "../../include/ngsq.h"
 #include "kernels.h"
 
+struct ngsq_ctx;
+
 namespace ngsq {
 
-enum KernelId { K_FIELDS = 0, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_FEATURES, K_COV_STREAM, K_COUNT };
+enum KernelId { K_FIELDS = 0, K_GC, K_QUAL, K_EDITS, K_COV_SCAN, K_EDITS_VAF, K_H2D, K_FEATURES, K_COV_STREAM, K_INFLATE, K_INFLATE_CRC,
+                K_REC_INDEX, K_REC_COLUMNS, K_COUNT };
 
 struct PendingTime {
     int id;
     hipEvent_t a, b;
+};
+
+// HIP-event bracket around the launches of one kernel family on the context's stream (cfg.timing);
+// always counts launches and algorithmic bytes.  context.cpp
+struct KernelTimer {
+    ngsq_ctx *c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    KernelTimer(ngsq_ctx *c, int id, uint64_t algo_bytes);
+    ~KernelTimer();
 };
 
 struct Staging {
@@ -52,6 +65,10 @@ struct ngsq_ctx {
     unsigned long long h_touched[2] = {~0ull, 0};
     uint64_t scan_lo = 0, scan_hi = 0; // chunk range this context tears down (default: all)
     uint32_t scan_carry = 0;
+    const uint32_t *scan_words = nullptr; // shard exchange: per-rank words on the device; carry += words[2r] for r in scan_front
+    uint64_t scan_front = 0;
+    uint32_t vaf_part = 0, vaf_parts = 1; // Edits teardown: this context does slice vaf_part of vaf_parts of every sequence
+    void *xchg_scratch = nullptr;         // exchange.cpp
     bool scan_partial = false, torn_down = false;
     unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
     std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cov_scan(CovScanArgs a) {
         } else {
             for (uint64_t i = a.c_begin + lane; i < c_lo; i += 64) part += a.chunk_sums[i];
         }
+        if (a.carry_words && ((a.carry_mask >> lane) & 1)) part += a.carry_words[2 * lane]; // owners in front (exchange.cpp)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         carry = a.carry_in + part;

@@ -38,6 +38,10 @@ constexpr uint32_t INFLATE_IN_SLACK = 1024;
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
                                uint32_t *status, bool check_crc, hipStream_t s);
 
+// CRC32 of every block's inflated bytes against its gzip trailer (status[k] = INF_CRC_MISMATCH); what
+// launch_bgzf_inflate(check_crc = true) runs second
+hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s);
+
 // ---- BAM record parse (csrc/bam_device.hip) -------------------------------------------------------
 constexpr uint64_t REC_SEGMENT = 65536;  // bytes of the inflated stream walked by one lane / wave
 constexpr uint32_t REC_CANDIDATES = 2;   // chain starts kept per segment (the walks are serial: each one costs)

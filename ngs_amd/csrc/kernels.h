@@ -184,6 +184,8 @@ struct CovScanArgs {
     uint64_t n_chunks;               // chunks of all sequences
     uint64_t c_begin, c_end;         // chunk range to tear down (shards own disjoint ranges)
     uint32_t carry_in;               // sum of every difference entry in front of c_begin
+    const uint32_t *carry_words;     // shard exchange: null, or [world][2] words in device memory; the sum of
+    uint64_t carry_mask;             //   carry_words[2r] over the set bits r of carry_mask joins carry_in
     uint32_t *chunk_sums, *super_sums;
     const uint32_t *ref_first_chunk; // [n_refs + 1]
     const uint32_t *ref_len;         // [n_refs]

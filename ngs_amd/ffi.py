@@ -197,6 +197,51 @@ class SynthConfig(C.Structure):
 
 ctx_p = C.c_void_p
 
+# ---- include/ngsq_comm.h ----------------------------------------------------------------------
+COMM_ID_BYTES = 128
+COMM_MAX_WORLD = 64
+HALO_LIMIT_BYTES = 64 << 20
+EXCHANGE_NONE, EXCHANGE_OWNER, EXCHANGE_ALLREDUCE = 0, 1, 2
+EXCHANGE_MODES = {0: "none", 1: "owner", 2: "allreduce"}
+
+
+class P2P(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("reserved", C.c_uint32), ("buf", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(P2P), C.c_uint32, C.POINTER(P2P), C.c_uint32)
+
+
+class CommOps(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("user", C.c_void_p),
+                ("allreduce_sum", ALLREDUCE_FN), ("allgather", ALLGATHER_FN), ("sendrecv", SENDRECV_FN)]
+
+
+class ExchangeReport(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_uint32), ("halo_bytes_sent", C.c_uint64),
+                ("halo_bytes_received", C.c_uint64), ("owned_chunk_lo", C.c_uint64), ("owned_chunk_hi", C.c_uint64),
+                ("host_syncs", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+STATE_SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+STATE_HALO_ADD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p)
+STATE_SUMMARY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p)
+STATE_TEARDOWN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32)
+
+
+class ShardState(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("memory", C.c_uint32), ("user", C.c_void_p), ("stream", C.c_void_p),
+                ("counters", C.c_void_p), ("n_counters", C.c_uint64), ("depth", C.c_void_p), ("n_depth", C.c_uint64),
+                ("n_diff", C.c_uint64), ("n_chunks", C.c_uint64), ("teardown", C.c_void_p), ("n_teardown", C.c_uint64),
+                ("edits", C.c_void_p), ("n_edits", C.c_uint64), ("chunk_flags", C.c_void_p), ("touched", C.c_void_p),
+                ("synchronize", STATE_SYNC_FN), ("halo_add", STATE_HALO_ADD_FN), ("summary", STATE_SUMMARY_FN),
+                ("teardown_range", STATE_TEARDOWN_FN)]
+
+
+comm_p = C.c_void_p
+
 # name -> (restype, argtypes): every symbol include/ngsq.h and include/ngsq_synth.h declare
 PROTOTYPES = {
     "ngsq_abi_version": (C.c_uint32, []),
@@ -268,6 +313,24 @@ PROTOTYPES = {
     "ngsq_bam_shard_prepare": (C.c_int, [C.c_void_p, ctx_p, C.c_uint32, C.c_uint32, C.POINTER(ShardInfo)]),
     "ngsq_bam_shard_commit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(ShardInfo)]),
     "ngsq_bgzf_inflate_device": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_int]),
+    # include/ngsq_comm.h
+    "ngsq_comm_last_error": (C.c_char_p, [comm_p]),
+    "ngsq_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ngsq_comm_create_rccl": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(comm_p)]),
+    "ngsq_comm_create_shm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.POINTER(comm_p)]),
+    "ngsq_comm_create_custom": (C.c_int, [C.c_int, C.c_int, C.POINTER(CommOps), C.POINTER(comm_p)]),
+    "ngsq_comm_destroy": (None, [comm_p]),
+    "ngsq_comm_rank": (C.c_int, [comm_p]),
+    "ngsq_comm_world": (C.c_int, [comm_p]),
+    "ngsq_comm_kind": (C.c_char_p, [comm_p]),
+    "ngsq_comm_allgather_host": (C.c_int, [comm_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ngsq_comm_allreduce_host": (C.c_int, [comm_p, C.c_void_p, C.c_uint64, C.c_uint32]),
+    "ngsq_comm_sendrecv_host": (C.c_int, [comm_p, C.POINTER(P2P), C.c_uint32, C.POINTER(P2P), C.c_uint32]),
+    "ngsq_comm_barrier": (C.c_int, [comm_p]),
+    "ngsq_exchange": (C.c_int, [ctx_p, comm_p, C.POINTER(ExchangeReport)]),
+    "ngsq_exchange_plan": (C.c_int64, [u64p, C.c_uint32, C.c_uint64, u64p, u32p, u32p, u64p, C.c_uint64]),
+    "ngsq_exchange_state": (C.c_int, [C.POINTER(ShardState), comm_p, C.POINTER(ExchangeReport)]),
+    "ngsq_bam_shard_open": (C.c_int, [C.c_void_p, ctx_p, comm_p, C.POINTER(ShardInfo)]),
     "ngsq_synth_fill_device": (
         C.c_int, [ctx_p, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
 }

@@ -1,11 +1,13 @@
 """A numpy stand-in for the state blocks and the ranged teardown of a QcContext, used ONLY
-to drive ngs_amd/shard.py's exchange protocol on CPU (gloo) where no GPU exists.  It follows the
-library's depth-block layout (per sequence: L+2 difference entries padded to 4096, then one sum
-per chunk) and the teardown semantics of coverage.rs:182-246 on a chunk range with a carry."""
+to drive the library's exchange protocol (ngs_amd/csrc/exchange.cpp, through ngsq_exchange_state with
+host memory) on CPU where no GPU exists.  It follows the library's depth-block layout (per sequence:
+L+2 difference entries padded to 4096, then one sum per chunk) and the teardown semantics of
+coverage.rs:182-246 on a chunk range with a carry."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
-import torch
 
 CH = 4096
 
@@ -42,16 +44,59 @@ class FakeCtx:
                 self.t_hi = g + 1 if self.t_hi is None else max(self.t_hi, g + 1)
             self.counters[8 + ref] += 1
 
-    def views(self):
-        v = {"counters": torch.from_numpy(self.counters.view(np.int64)),
-             "depth": torch.from_numpy(self.depth.view(np.int32)),
-             "teardown": torch.from_numpy(self.td.view(np.int64))}
-        if self.flags is not None:
-            v["flags"] = torch.from_numpy(self.flags)
-        return v
+    def shard_state(self):
+        """ffi.ShardState over the numpy blocks (host memory) with the four operations as callbacks."""
+        from ngs_amd import ffi
 
-    def synchronize(self):
-        pass
+        def u32(ptr, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(int(n),))
+
+        def sync(_u):
+            return 0
+
+        def halo_add(_u, c0, c1, diff, sums):
+            with np.errstate(over="ignore"):
+                self.depth[c0 * CH:c1 * CH] += u32(diff, (c1 - c0) * CH)
+                self.depth[self.n_diff + c0:self.n_diff + c1] += u32(sums, c1 - c0)
+            return 0
+
+        def summary(_u, b0, b1, in_ranges, n_in, out2):
+            out = u32(out2, 2)
+            out[0] = int(self.depth[self.n_diff + b0:self.n_diff + b1].astype(np.uint64).sum()) & 0xFFFFFFFF
+            bad = 0
+            if self.flags is not None:
+                for k in range(n_in):
+                    bad |= int(self.flags[in_ranges[2 * k]:in_ranges[2 * k + 1]].any())
+            out[1] = bad
+            return 0
+
+        def teardown_range(_u, b0, b1, words, front, part, parts):
+            carry = 0
+            if front:
+                w = u32(words, 2 * 64)
+                for r in range(64):
+                    if (front >> r) & 1:
+                        carry = (carry + int(w[2 * r])) & 0xFFFFFFFF
+            self.set_scan_range(b0, b1, carry)
+            self.teardown()
+            self.vaf_part = (part, parts)
+            return 0
+
+        self._touched = np.array([self.t_lo if self.t_lo is not None else 0xFFFFFFFFFFFFFFFF,
+                                  self.t_hi if self.t_lo is not None else 0], dtype=np.uint64)
+        st = ffi.ShardState()
+        st.struct_size = C.sizeof(ffi.ShardState)
+        st.memory = ffi.MEM_HOST
+        st.counters, st.n_counters = self.counters.ctypes.data, self.counters.size
+        st.depth, st.n_depth = self.depth.ctypes.data, self.depth.size
+        st.n_diff, st.n_chunks = self.n_diff, self.n_chunks
+        st.teardown, st.n_teardown = self.td.ctypes.data, self.td.size
+        st.chunk_flags = self.flags.ctypes.data if self.flags is not None else None
+        st.touched = self._touched.ctypes.data
+        self._cb = (ffi.STATE_SYNC_FN(sync), ffi.STATE_HALO_ADD_FN(halo_add), ffi.STATE_SUMMARY_FN(summary),
+                    ffi.STATE_TEARDOWN_FN(teardown_range))
+        st.synchronize, st.halo_add, st.summary, st.teardown_range = self._cb
+        return st
 
     def depth_layout(self):
         return self.n_diff, self.n_chunks, self.t_lo or 0, (self.t_hi or 0) if self.t_lo is not None else 0

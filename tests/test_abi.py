@@ -16,7 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("ngsq.h", "ngsq_synth.h", "ngsq_bam.h"):
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not h.endswith(".h") or h == "ngsq_shared.h":  # ngsq_shared.h: inline host/device functions, no exports
+            continue
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(ngsq_[a-z0-9_]+)\s*\(", text))
@@ -40,11 +42,15 @@ def test_struct_layouts_match_the_header(tmp_path):
 #include <stddef.h>
 #include "ngsq.h"
 #include "ngsq_synth.h"
+#include "ngsq_comm.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ngsq_config), sizeof(ngsq_batch), sizeof(ngsq_general_metrics),
          sizeof(ngsq_gc_metrics), sizeof(ngsq_error_counts), sizeof(ngsq_kernel_time), sizeof(ngsq_synth_config));
   printf("%zu %zu %zu %zu\n", offsetof(ngsq_config, gc_seed), offsetof(ngsq_config, stream),
          offsetof(ngsq_batch, seq_stride), offsetof(ngsq_batch, cigar_ops));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ngsq_p2p), sizeof(ngsq_comm_ops), sizeof(ngsq_exchange_report),
+         sizeof(ngsq_shard_state), offsetof(ngsq_shard_state, touched), offsetof(ngsq_shard_state, teardown_range),
+         offsetof(ngsq_exchange_report, host_syncs));
   return 0;
 }''')
     exe = tmp_path / "probe"
@@ -54,8 +60,11 @@ int main(void) {
     assert sizes[:7] == [C.sizeof(ffi.Config), C.sizeof(ffi.Batch), C.sizeof(ffi.GeneralMetrics),
                          C.sizeof(ffi.GcMetrics), C.sizeof(ffi.ErrorCounts), C.sizeof(ffi.KernelTime),
                          C.sizeof(ffi.SynthConfig)]
-    assert sizes[7:] == [ffi.Config.gc_seed.offset, ffi.Config.stream.offset, ffi.Batch.seq_stride.offset,
-                         ffi.Batch.cigar_ops.offset]
+    assert sizes[7:11] == [ffi.Config.gc_seed.offset, ffi.Config.stream.offset, ffi.Batch.seq_stride.offset,
+                           ffi.Batch.cigar_ops.offset]
+    assert sizes[11:] == [C.sizeof(ffi.P2P), C.sizeof(ffi.CommOps), C.sizeof(ffi.ExchangeReport), C.sizeof(ffi.ShardState),
+                          ffi.ShardState.touched.offset, ffi.ShardState.teardown_range.offset,
+                          ffi.ExchangeReport.host_syncs.offset]
 
 
 def test_abi_version_and_pure_functions(lib):

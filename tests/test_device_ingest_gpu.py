@@ -309,13 +309,10 @@ def _file_shard_worker(rank, world, port, q, bam, writer):
         import os
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        import torch
-        import torch.distributed as dist
         from ngs_amd import ffi as F, host as H, shard
+        from tests.test_shard_gloo import _make_comm
 
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm, done = _make_comm("shm" if writer == "synth" else "gloo", rank, world, port)
         lib = F.load_library()
         ref_len = [3_000_000, 3_000_000] if writer == "synth" else [50_000, 7_000]
         names = ["chr1", "chr2"]
@@ -341,8 +338,7 @@ def _file_shard_worker(rank, world, port, q, bam, writer):
 
         want, n_total = whole_file() if rank == 0 else (None, None)
         ctx = H.QcContext(ref_len, device=0, lib=lib, **kw)
-        views = shard.device_views(ctx, torch, 0)
-        h, info = shard.open_file_shard(lib, ctx._ctx, bam, rank, world, dist, torch, coll_device="cpu")
+        h, info = comm.open_file_shard(ctx, bam)
         mine = 0
         first_seen = None
         while True:
@@ -356,23 +352,22 @@ def _file_shard_worker(rank, world, port, q, bam, writer):
             assert lib.ngsq_process_batch(ctx._ctx, C.byref(b), F.PASS_BOTH) == 0, lib.ngsq_last_error(ctx._ctx)
         assert mine == info.n_records
         lib.ngsq_bam_close(h)
-        counts = [None] * world
-        dist.all_gather_object(counts, (mine, first_seen))
+        none = (1 << 64) - 1
+        counts = comm.allgather_ints([mine, none if first_seen is None else first_seen])
         if rank == 0:
             assert sum(c for c, _ in counts) == n_total, (counts, n_total)
             run = 0
             for c, f in counts:   # first_record_index continues across the shards
-                assert f is None or f == run
+                assert f == none or f == run
                 run += c
-        shard.owner_teardown(ctx, dist, torch, views, coll_device="cpu")
+        comm.exchange(ctx)
         ctx.finalize()
         got = ctx.results(names)
         if rank == 0:
             from tests.util import json_equal as jeq
             jeq(got, want)
         ctx.close()
-        dist.barrier()
-        dist.destroy_process_group()
+        done()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
@@ -396,20 +391,8 @@ def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer):
         c = hb.cols
         c["flag"] &= np.uint16(0xFFFF ^ 0x1)
         bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=3000)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mpc = mp.get_context("spawn")
-    q = mpc.Queue()
-    procs = [mpc.Process(target=_file_shard_worker, args=(r, 3, port, q, bam, writer)) for r in range(3)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in results:
-        assert msg == "ok", f"rank {rank}: {msg}"
+    from tests.test_shard_gloo import _run_ranks
+    _run_ranks(_file_shard_worker, 3, bam, writer)
 
 
 def test_shard_prepare_commit_api(gpu_lib, ctx, tmp_path):

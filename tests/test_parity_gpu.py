@@ -318,22 +318,21 @@ def test_full_size_properties(gpu_lib):
 
 
 # ---------------------------------------------------------------------------------------------
-# N > 1 with REAL contexts: three processes share the one GPU of the box, collectives over gloo
-# (small tensors staged through the host), owner-computes coverage teardown (ngs_amd/shard.py)
+# N > 1 with REAL contexts: three processes share the one GPU of the box and run ngsq_exchange (the C++
+# protocol of ngs_amd/csrc/exchange.cpp) over a host transport -- the library's shared-memory transport, or
+# callbacks over torch.distributed/gloo; the device blocks are staged through the host.  (RCCL refuses two
+# ranks on one device; its entry points are exercised with one rank below.)
 # ---------------------------------------------------------------------------------------------
-def _rank_worker(rank, world, port, q, mode):
+def _rank_worker(rank, world, port, q, mode, transport):
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        import torch
-        import torch.distributed as dist
         from ngs_amd import ffi as F, host as H, shard
         from oracle import oracle_py
+        from tests.test_shard_gloo import _make_comm
         from tests.util import json_equal as jeq
 
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm, done = _make_comm(transport, rank, world, port)
         lib = F.load_library()
         n, L = 90_000, 700_000
         ref_len = [L, 50_000]
@@ -342,68 +341,88 @@ def _rank_worker(rank, world, port, q, mode):
         whole = H.synth_host_batch(scfg, 0, n, lib)
         first, cnt = shard.shard_range(n, rank, world)
         kw = dict(facets=F.FACETS_DEFAULT, bin_size=50_000, max_read_len=300, gc_seed=5)
-        ctx = H.QcContext(ref_len, device=0, lib=lib, sorted_input=stream,
+        ref_bases = None
+        if mode == "edits":   # Edits: refs/alts all-reduced, VAF split over the ranks
+            rng = np.random.default_rng(77)
+            ref_bases = [rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), size=x) for x in ref_len]
+            kw["facets"] = F.FACETS_DEFAULT | F.FACET_EDITS
+            scfg = H.synth_config(n, mode=F.SYNTH_FIXED, ref_len=L, n_refs=2)
+        ctx = H.QcContext(ref_len, device=0, lib=lib, sorted_input=stream, ref_bases=ref_bases,
                           cov_head_guard=8192 if stream and rank else 0, **kw)
-        views = shard.device_views(ctx, torch, 0)
         names = ["chr1", "chr2"]
         if mode == "stream-overlap":  # every rank scans the same records: the exchange must refuse, on every rank
             ctx.process_batch(whole.slice(0, cnt))
             try:
-                shard.owner_teardown(ctx, dist, torch, views, coll_device="cpu")
+                comm.exchange(ctx)
                 q.put((rank, "FAIL overlapping sorted_input shards were accepted"))
-            except RuntimeError as e:
-                q.put((rank, "ok" if "overlap" in str(e) else "FAIL " + str(e)))
+            except shard.CommError as e:
+                q.put((rank, "ok" if e.code == F.ERR_UNSORTED and "overlap" in str(e) else "FAIL " + str(e)))
             ctx.close()
-            dist.barrier()
-            dist.destroy_process_group()
+            done()
             return
         want = None
         if rank == 0:
-            orc = oracle_py.Oracle(ref_len, **kw)
+            orc = oracle_py.Oracle(ref_len, ref_bases=ref_bases, **kw)
             orc.process_batch(whole)
             orc.finalize()
             want = orc.results(names)
         for step in range(2):  # the second pass checks reset after a partial teardown
             ctx.process_batch(whole.slice(first, first + cnt))
-            rep = shard.owner_teardown(ctx, dist, torch, views, coll_device="cpu")
+            rep = comm.exchange(ctx)
             assert rep["mode"] == "owner", rep
             if stream:
-                assert int(views["flags"].sum().item()) > 30   # most of this shard's chunks never touched the array
+                assert int(ctx.state_download(4).sum()) > 30   # most of this shard's chunks never touched the array
             ctx.finalize()
             got = ctx.results(names)
             if rank == 0:
                 jeq(got, want)
-            blob = [got if rank == 0 else None]
-            dist.broadcast_object_list(blob, src=0)
-            jeq(got, blob[0])  # every rank holds the whole-file result
+            import hashlib
+            import json as _json
+            digest = np.frombuffer(hashlib.sha256(_json.dumps(got, sort_keys=True).encode()).digest(), dtype=np.uint64)
+            assert (comm.allgather(digest) == digest).all()  # every rank holds the whole-file result
             ctx.reset()
         ctx.close()
-        dist.barrier()
-        dist.destroy_process_group()
+        done()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, "FAIL " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("mode", ["fixed", "mixed", "fixed-stream", "mixed-stream", "stream-overlap"])
-def test_three_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode):
-    import multiprocessing as mp
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mpc = mp.get_context("spawn")
-    q = mpc.Queue()
-    procs = [mpc.Process(target=_rank_worker, args=(r, 3, port, q, mode)) for r in range(3)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in results:
-        assert msg == "ok", f"rank {rank}: {msg}"
+@pytest.mark.parametrize("mode,transport", [("fixed", "shm"), ("mixed", "gloo"), ("fixed-stream", "gloo"), ("mixed-stream", "shm"),
+                                            ("stream-overlap", "shm"), ("edits", "shm")])
+def test_three_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode, transport):
+    from tests.test_shard_gloo import _run_ranks
+    _run_ranks(_rank_worker, 3, mode, transport)
+
+
+def test_rccl_entry_points_with_one_rank(gpu_lib, oracle_mod):
+    """ncclGetUniqueId / ncclCommInitRank / the collectives of one exchange on the context's stream, world = 1
+    (a one-GPU box cannot hold more RCCL ranks): the result must equal the plain finalize."""
+    from ngs_amd import shard
+    n, L = 60_000, 500_000
+    ref_len = [L, 40_000]
+    scfg = host.synth_config(n, mode=ffi.SYNTH_MIXED, ref_len=L, n_refs=2)
+    hb = host.synth_host_batch(scfg, 0, n, gpu_lib)
+    comm = shard.Comm.rccl(0, 1, shard.unique_id(gpu_lib), 0, gpu_lib)
+    assert comm.kind == "rccl" and comm.world == 1
+    assert comm.allgather_ints([5, 6]) == [[5, 6]]
+    assert (comm.allreduce(np.arange(10, dtype=np.uint64)) == np.arange(10, dtype=np.uint64)).all()
+    comm.barrier()
+    kw = dict(bin_size=50_000, max_read_len=300, gc_seed=5)
+    for sorted_input in (False, True):
+        with host.QcContext(ref_len, lib=gpu_lib, sorted_input=sorted_input, **kw) as plain, \
+                host.QcContext(ref_len, lib=gpu_lib, sorted_input=sorted_input, **kw) as ex:
+            plain.process_batch(hb)
+            plain.finalize()
+            for _ in range(2):
+                ex.process_batch(hb)
+                rep = comm.exchange(ex)
+                assert rep["mode"] == "owner" and rep["halo_bytes"] == 0 and rep["host_syncs"] <= 3, rep
+                ex.finalize()
+                json_equal(ex.results(["a", "b"]), plain.results(["a", "b"]))
+                ex.reset()
+    comm.destroy()
 
 
 # ---- Genomic Features facet (features.rs) ------------------------------------------------------

@@ -1,7 +1,9 @@
-"""N > 1 path on CPU (gloo, world_size 2): the shard ranges and the state exchange of
-ngs_amd/shard.py, and shard invariance of the facets: records split
-over ranks + element-wise integer sums == the whole file, including the GC window
-offsets (pure function of the record's index in the whole file)."""
+"""N > 1 path on CPU (world_size 2-3, no GPU): the shard ranges; the transports of the exchange
+(ngs_amd/csrc/comm.cpp: POSIX shared memory, and callbacks over torch.distributed/gloo) on host buffers;
+the exchange protocol itself (ngs_amd/csrc/exchange.cpp through ngsq_exchange_state) over a numpy shard
+state; and shard invariance of the facets: records split over ranks + element-wise integer
+sums == the whole file, including the GC window offsets (pure function of the record's index in the
+whole file)."""
 import os
 import socket
 import sys
@@ -34,35 +36,106 @@ def _free_port():
     return p
 
 
+def _make_comm(transport, rank, world, port):
+    """(comm, cleanup): 'gloo' = callbacks over torch.distributed, 'shm' = the library's shared-memory transport
+    (small slots so that every collective takes several rounds)."""
+    from ngs_amd import shard
+    if transport == "gloo":
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = shard.Comm.torch_dist(dist, torch)
+
+        def done():
+            comm.destroy()
+            dist.barrier()
+            dist.destroy_process_group()
+        return comm, done
+    comm = shard.Comm.shm(f"/ngsq-test-{port}", rank, world, slot_bytes=8192)
+
+    def done():
+        comm.barrier()
+        comm.destroy()
+    return comm, done
+
+
+def _run_ranks(target, world, *args):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _transport_worker(rank, world, port, q, transport):
+    try:
+        sys.path.insert(0, ROOT)
+        comm, done = _make_comm(transport, rank, world, port)
+        assert (comm.rank, comm.world) == (rank, world) and comm.kind == ("custom" if transport == "gloo" else "shm")
+
+        def block(r, dtype, n):
+            g = np.random.default_rng(100 + r)
+            x = g.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) if dtype == np.uint32 else \
+                g.integers(0, 2 ** 63, n, dtype=np.uint64) * 2 + 1
+            x[:10] = np.iinfo(dtype).max   # the -1 of a coverage difference array: sums wrap around
+            return x
+        for dtype, n in ((np.uint32, 1000), (np.uint64, 500), (np.uint32, 70_001), (np.uint64, 1)):
+            got = comm.allreduce(block(rank, dtype, n))
+            want = np.zeros(n, dtype=dtype)
+            with np.errstate(over="ignore"):
+                for r in range(world):
+                    want += block(r, dtype, n)
+            assert (got == want).all(), (dtype, n)
+        rows = comm.allgather_ints([rank, 7 * rank + 1, 2 ** 63 + rank])
+        assert rows == [[r, 7 * r + 1, 2 ** 63 + r] for r in range(world)]
+        big = comm.allgather(np.arange(30_000, dtype=np.uint8) + rank)
+        assert all((big[r] == (np.arange(30_000, dtype=np.uint8) + r)).all() for r in range(world))
+        # grouped point to point: every rank sends two messages of different sizes to every other rank
+        def msg(s, d, k):
+            return (np.arange(5000 * (k + 1) + 13 * s + d, dtype=np.uint32) * (s + 1) + d + 1000 * k).astype(np.uint32)
+        sends = [(d, msg(rank, d, k)) for d in range(world) if d != rank for k in range(2)]
+        recvs = [(s, np.zeros_like(msg(s, rank, k))) for s in range(world) if s != rank for k in range(2)]
+        comm.sendrecv(sends, recvs)
+        i = 0
+        for s in range(world):
+            if s == rank:
+                continue
+            for k in range(2):
+                assert (recvs[i][1] == msg(s, rank, k)).all(), (s, k)
+                i += 1
+        comm.sendrecv([], [])
+        comm.barrier()
+        done()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (2, "shm"), (3, "shm")])
+def test_transports_on_host_buffers(world, transport):
+    _run_ranks(_transport_worker, world, transport)
+
+
 def _worker(rank, world, port, q):
     try:
         sys.path.insert(0, ROOT)
-        import torch
-        import torch.distributed as dist
         from ngs_amd import ffi, host, shard
         from oracle import oracle_py
         from tests.util import random_batch
 
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm, done = _make_comm("gloo", rank, world, port)
 
-        # (1) wrap-around sums of uint32 / uint64 blocks through signed all_reduce
-        rng = np.random.default_rng(100 + rank)
-        b32 = rng.integers(0, 2 ** 32, 1000, dtype=np.uint64).astype(np.uint32)
-        b32[:10] = 0xFFFFFFFF  # the -1 of a coverage difference array
-        b64 = rng.integers(0, 2 ** 63, 500, dtype=np.uint64) * 2 + 1
-        got32, got64 = shard.allreduce_blocks_cpu([b32, b64], dist, torch)
-        want32, want64 = np.zeros_like(b32), np.zeros_like(b64)
-        for r in range(world):
-            g = np.random.default_rng(100 + r)
-            x = g.integers(0, 2 ** 32, 1000, dtype=np.uint64).astype(np.uint32)
-            x[:10] = 0xFFFFFFFF
-            want32 += x
-            want64 += g.integers(0, 2 ** 63, 500, dtype=np.uint64) * 2 + 1
-        assert (got32 == want32).all() and (got64 == want64).all()
-
-        # (2) shard invariance: each rank scans its contiguous record range, the integer
+        # shard invariance: each rank scans its contiguous record range, the integer
         # results are summed, and must equal the scan of the whole file
         ref_len = [30_000, 4_000]
         whole = random_batch(np.random.default_rng(7), 6001, ref_len, weird=True)
@@ -83,7 +156,7 @@ def _worker(rank, world, port, q):
             [gc[k] for k in ("total_gc_count", "total_at_count", "total_other_count", "processed",
                              "ignored_flags", "ignored_too_short")], dtype=np.uint64)]))
         blocks.append(o.quality_scores().reshape(-1))
-        summed = shard.allreduce_blocks_cpu(blocks, dist, torch)
+        summed = [comm.allreduce(b) for b in blocks]
         if rank == 0:
             w = oracle_py.Oracle(ref_len, **kw)
             w.process_batch(whole)
@@ -100,8 +173,7 @@ def _worker(rank, world, port, q):
             want.append(w.quality_scores().reshape(-1))
             for a, b in zip(summed, want):
                 assert (a == b).all()
-        dist.barrier()
-        dist.destroy_process_group()
+        done()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -109,22 +181,11 @@ def _worker(rank, world, port, q):
 
 
 def test_world_size_2_gloo():
-    import multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in results:
-        assert msg == "ok", f"rank {rank}: {msg}"
+    _run_ranks(_worker, 2)
 
 
 # ---------------------------------------------------------------------------------------------
-# owner-computes coverage teardown (ngs_amd/shard.py owner_teardown) with a numpy context
+# owner-computes coverage teardown (ngs_amd/csrc/exchange.cpp) over a numpy shard state
 # ---------------------------------------------------------------------------------------------
 def test_plan_owners_is_a_disjoint_cover():
     from ngs_amd.shard import plan_owners
@@ -156,17 +217,15 @@ def test_plan_owners_is_a_disjoint_cover():
             assert (reach[lo:hi] == 1).all() and reach.sum() == max(0, hi - lo)
 
 
-def _owner_worker(rank, world, port, q, layout):
+def _owner_worker(rank, world, port, q, layout, transport):
     try:
         sys.path.insert(0, ROOT)
-        import torch
-        import torch.distributed as dist
-        from ngs_amd import shard
+        from ngs_amd import ffi, shard
         from tests.fake_ctx import FakeCtx
 
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if layout == "unsorted":
+            os.environ["NGSQ_HALO_LIMIT_BYTES"] = "1024"  # force the all-reduce fallback
+        comm, done = _make_comm(transport, rank, world, port)
         ref_len = [30_000, 9_000, 12_345]
         rng = np.random.default_rng(5)
         n = 4000
@@ -195,8 +254,6 @@ def _owner_worker(rank, world, port, q, layout):
             first, cnt = shard.shard_range(n, rank, world)
         mine = FakeCtx(ref_len)
         fill(mine, first, first + cnt)
-        if layout == "unsorted":
-            shard.HALO_LIMIT_BYTES = 1 << 10  # force the all-reduce fallback
         if layout.startswith("flags"):
             # streaming contexts flag the chunks they finished on their own.  "flags_ok": a chunk no other rank
             # wrote to; "flags_overlap": the first chunk this rank wrote -- the halo of the rank in front lands there
@@ -208,38 +265,30 @@ def _owner_worker(rank, world, port, q, layout):
             elif rank > 0:
                 mine.flags[t_lo // 4096] = 1
             try:
-                rep = shard.owner_teardown(mine, dist, torch, mine.views())
+                rep = comm.exchange_state(mine.shard_state())
                 assert layout == "flags_ok", "an exchanged entry in a finished chunk was accepted"
-            except RuntimeError as e:
-                assert layout == "flags_overlap" and "overlap" in str(e), e
-                dist.barrier()
-                dist.destroy_process_group()
+            except shard.CommError as e:
+                assert layout == "flags_overlap" and e.code == ffi.ERR_UNSORTED and "overlap" in str(e), e
+                done()
                 q.put((rank, "ok"))
                 return
-        rep = shard.owner_teardown(mine, dist, torch, mine.views()) if not layout.startswith("flags") else rep
+        rep = comm.exchange_state(mine.shard_state()) if not layout.startswith("flags") else rep
         assert rep["mode"] == ("allreduce" if layout == "unsorted" else "owner"), rep
         assert (mine.td == whole.td).all(), "teardown results differ from the single-context scan"
         assert (mine.counters == whole.counters).all()
-        dist.barrier()
-        dist.destroy_process_group()
+        if layout == "sorted" and world > 1:
+            assert sum(comm.allgather_ints([rep["halo_bytes"]])[r][0] for r in range(world)) > 0
+            assert mine.vaf_part == (rank, world)
+        done()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, "FAIL " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,layout", [(2, "sorted"), (3, "sorted"), (3, "empty_rank"), (2, "unsorted"),
-                                          (3, "flags_ok"), (3, "flags_overlap")])
-def test_owner_teardown_gloo(world, layout):
-    import multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, q, layout)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in results:
-        assert msg == "ok", f"rank {rank}: {msg}"
+@pytest.mark.parametrize("world,layout,transport", [(2, "sorted", "gloo"), (3, "sorted", "gloo"), (3, "sorted", "shm"),
+                                                    (3, "empty_rank", "gloo"), (2, "unsorted", "gloo"), (3, "unsorted", "shm"),
+                                                    (3, "flags_ok", "gloo"), (3, "flags_overlap", "gloo"),
+                                                    (3, "flags_overlap", "shm")])
+def test_owner_teardown_world_2_3(world, layout, transport):
+    _run_ranks(_owner_worker, world, layout, transport)
