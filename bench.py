@@ -444,7 +444,8 @@ def leg_h2d(lib, host, ffi, args):
     scfg = host.synth_config(100_000_000, read_len=args.read_len, ref_len=CHR1, n_refs=2)
     hb = host.synth_host_batch(scfg, 0, args.h2d_batch, lib)
     pb, keep = pinned_copy(lib, host, np, C, hb)
-    ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=args.read_len, gc_seed=GC_SEED, sorted_input=True, lib=lib)
+    # the same batch is re-sent: not a sorted stream, so Coverage runs on the difference arrays here
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=args.read_len, gc_seed=GC_SEED, lib=lib)
     try:
         ctx.process_batch(pb)
         ctx.synchronize()

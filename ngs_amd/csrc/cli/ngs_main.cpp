@@ -7,8 +7,11 @@
 // The per-record facet loops are replaced by SoA batches through the C ABI (include/ngsq.h);
 // ingest is include/ngsq_bam.h.  Additive flags: --device, --batch-records, --threads, --gc-seed,
 // --ingest host|device (default device: the GPU inflates and parses the BAM; runs with -n
-// always ingest on the host).
+// always ingest on the host), --coverage auto|stream|array, and --gpus N: one worker process per
+// GPU, each ingesting its BGZF block range of the file on its own device, one ngsq_exchange
+// (include/ngsq_comm.h; RCCL over xGMI) before the teardown, rank 0 writes the JSON.
 // Not built (out of scope this round): the other subcommands.
+#include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -23,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <filesystem>
 #include <fstream>
 #include <map>
 #include <set>
@@ -31,6 +35,7 @@
 
 #include "../../../include/ngsq.h"
 #include "../../../include/ngsq_bam.h"
+#include "../../../include/ngsq_comm.h"
 
 namespace {
 
@@ -354,6 +359,10 @@ struct Args {
     int coverage = 0; // --coverage auto|stream|array: 0 auto (stream when @HD says SO:coordinate), 1 stream, 2 array
     bool ingest_device = true; // --ingest host|device: where BGZF inflate + BAM parse run (ngsq_bam_next_batch[_device])
     unsigned long long batch_records = 1ull << 21, gc_seed = 0x4E4753;
+    int gpus = 1;             // --gpus N: one worker process per GPU (devices --device .. --device + N - 1)
+    bool same_device = false; // --same-device: all workers on --device, exchange through shared memory (one-GPU boxes)
+    int rank = -1, world = 0; // --worker R/W:NAME (set by the launching process)
+    std::string shm;
 };
 
 void usage() {
@@ -374,7 +383,8 @@ void usage() {
             "      --exon-feature-name <STRING>              GFF feature of an exon [default: exon]\n"
             "      --gene-feature-name <STRING>              GFF feature of a gene [default: gene]\n"
             "      --device <N> --batch-records <N> --threads <N> --gc-seed <N> --ingest host|device   (additive, this build)\n"
-            "      --coverage auto|stream|array   Coverage finished while sorted records stream by / on depth arrays (additive)\n");
+            "      --coverage auto|stream|array   Coverage finished while sorted records stream by / on depth arrays (additive)\n"
+            "      --gpus <N>                  One worker per GPU over BGZF block ranges of the file, one RCCL exchange (additive)\n");
 }
 
 #define CHECK(ctx, expr)                                                                                   \
@@ -429,6 +439,16 @@ int main(int argc, char **argv) {
             }
             a.coverage = v == "auto" ? 0 : v == "stream" ? 1 : 2;
         }
+        else if (s == "--gpus") a.gpus = atoi(val("--gpus").c_str());
+        else if (s == "--same-device") a.same_device = true;
+        else if (s == "--worker") { // R/W:NAME, appended by the launching process
+            const std::string v = val("--worker");
+            const size_t sl = v.find('/'), co = v.find(':');
+            if (sl == std::string::npos || co == std::string::npos || co < sl) bail("malformed --worker");
+            a.rank = atoi(v.substr(0, sl).c_str());
+            a.world = atoi(v.substr(sl + 1, co - sl - 1).c_str());
+            a.shm = v.substr(co + 1);
+        }
         else if (s == "--batch-records") a.batch_records = strtoull(val("--batch-records").c_str(), nullptr, 10);
         else if (s == "--gc-seed") a.gc_seed = strtoull(val("--gc-seed").c_str(), nullptr, 0);
         else if (!s.empty() && s[0] == '-') bail("unexpected argument '" + s + "' found");
@@ -476,12 +496,48 @@ int main(int argc, char **argv) {
     if (ngsq_bam_open(a.src.c_str(), a.threads, &bam) != NGSQ_OK) bail(ngsq_bam_last_error());
     if (ngsq_bam_check_index(a.src.c_str()) != NGSQ_OK) bail(ngsq_bam_last_error());
     {
-        struct stat st;
-        if (stat(a.out_dir.c_str(), &st) != 0) {
-            std::string cmd = "mkdir -p '" + a.out_dir + "'";
-            if (system(cmd.c_str()) != 0) bail("Could not create output directory.");
-        }
+        std::error_code ec;
+        std::filesystem::create_directories(a.out_dir, ec); // command.rs:186-190
+        if (ec || !std::filesystem::is_directory(a.out_dir)) bail("Could not create output directory.");
     }
+    const bool worker = a.world > 1;
+    if (a.gpus < 1 || a.gpus > NGSQ_COMM_MAX_WORLD) bail("--gpus takes a number between 1 and 64");
+    if (a.gpus > 1 && !worker) {
+        // ---- launch one worker per GPU.  Nothing above has touched HIP, and nothing here does: the workers
+        // are fresh processes (posix_spawn of this executable), each initialises its own device.
+        if (a.has_n) bail("--gpus cannot be combined with -n/--num-records (the reference's truncation rules are sequential)");
+        if (!a.ingest_device) bail("--gpus needs --ingest device");
+        ngsq_bam_close(bam);
+        char shm[128];
+        snprintf(shm, sizeof shm, "/ngsq-cli-%d-%lld", (int)getpid(), (long long)time(nullptr));
+        std::vector<pid_t> pids;
+        for (int r = 0; r < a.gpus; r++) {
+            std::vector<char *> av(argv, argv + argc);
+            char opt[] = "--worker";
+            std::string spec = std::to_string(r) + "/" + std::to_string(a.gpus) + ":" + shm;
+            av.push_back(opt);
+            av.push_back(spec.data());
+            av.push_back(nullptr);
+            pid_t pid;
+            if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, av.data(), environ) != 0) bail("could not start a worker process");
+            pids.push_back(pid);
+        }
+        int worst = 0;
+        for (size_t left = pids.size(); left;) {
+            int status = 0;
+            const pid_t p = wait(&status);
+            if (p < 0) break;
+            left--;
+            const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 1;
+            if (code && !worst) { // a failed worker leaves the others waiting in a collective: stop exactly those
+                worst = code;
+                for (pid_t q : pids)
+                    if (q != p) kill(q, SIGTERM);
+            }
+        }
+        return worst;
+    }
+    if (worker && a.rank > 0) g_level = std::min(g_level, 1); // rank 0 narrates
     const uint32_t n_refs = ngsq_bam_n_refs(bam);
     std::vector<std::string> names(n_refs);
     std::vector<uint32_t> ref_len(n_refs);
@@ -532,7 +588,7 @@ int main(int argc, char **argv) {
     // EditsFacet::try_from (edits.rs:134-151) creates the VAF file while the facets are built -- before
     // --only filters them -- and refuses to overwrite one
     FILE *vaf_file = nullptr;
-    if (!a.fasta.empty() && !a.vaf.empty()) {
+    if (!a.fasta.empty() && !a.vaf.empty() && (a.world <= 1 || a.rank == 0)) { // one writer in a --gpus run
         struct stat st;
         if (stat(a.vaf.c_str(), &st) == 0)
             bail("refusing to overwrite existing VAF file: " + a.vaf + ". Please delete and rerun if you'd like to replace it.");
@@ -569,8 +625,38 @@ int main(int argc, char **argv) {
             header_sorted = text.substr(hd, eol == std::string::npos ? std::string::npos : eol - hd).find("SO:coordinate") != std::string::npos;
         }
     }
-    cfg.sorted_input = (!a.has_n && (facets & NGSQ_FACET_COVERAGE) && (a.coverage == 1 || (a.coverage == 0 && header_sorted))) ? 1 : 0;
+    // ---- the communicator of a --gpus run: the workers meet in the shared-memory segment the launcher named;
+    // with one device per worker rank 0's RCCL unique id travels through it and the exchange runs over xGMI
+    ngsq_comm *comm = nullptr;
+    if (worker) {
+        const int ndev = ngsq_device_count();
+        if (ndev < 1) bail("no HIP device available; the ngs qc hot path has no CPU fallback");
+        ngsq_comm *boot = nullptr;
+        if (ngsq_comm_create_shm(a.shm.c_str(), a.rank, a.world, 0, &boot) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
+        if (a.same_device) {
+            comm = boot;
+        } else {
+            if (a.device + a.world > ndev)
+                bail("--gpus " + std::to_string(a.world) + " from --device " + std::to_string(a.device) + ": only " + std::to_string(ndev) +
+                     " device(s) visible (--same-device shares one)");
+            a.device += a.rank;
+            uint8_t uid[NGSQ_COMM_ID_BYTES] = {0};
+            if (a.rank == 0 && ngsq_comm_unique_id(uid) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
+            std::vector<uint8_t> all((size_t)a.world * NGSQ_COMM_ID_BYTES);
+            if (ngsq_comm_allgather_host(boot, uid, all.data(), NGSQ_COMM_ID_BYTES) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
+            if (ngsq_comm_create_rccl(a.rank, a.world, all.data(), a.device, &comm) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
+            if (ngsq_comm_barrier(boot) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
+            ngsq_comm_destroy(boot);
+        }
+        cfg.device = a.device;
+        logf(2, "Worker %d of %d on device %d, exchange over %s.", a.rank, a.world, a.device, ngsq_comm_kind(comm));
+    }
     ngsq_ctx *ctx = nullptr;
+    unsigned long long n_pass1 = 0;
+    for (bool force_array = false;;) { // at most twice: again on the depth arrays when the records break the promised order
+    cfg.sorted_input = (!force_array && !a.has_n && (facets & NGSQ_FACET_COVERAGE) && (a.coverage == 1 || (a.coverage == 0 && header_sorted))) ? 1 : 0;
+    // shards behind the first: a read of the shard in front may reach this far into this shard's first positions
+    cfg.cov_head_guard = (worker && a.rank > 0 && cfg.sorted_input) ? (1u << 20) : 0;
     if (ngsq_create(&cfg, &ctx) != NGSQ_OK) bail(ngsq_last_global_error());
     if (facets & NGSQ_FACET_FEATURES) {
         ngsq_features f;
@@ -597,8 +683,19 @@ int main(int argc, char **argv) {
         logf(2, "No facets specified that require first pass. Skipping...");
     }
 
-    unsigned long long n_pass1 = 0;
-    if (!a.has_n) {
+    n_pass1 = 0;
+    if (worker) {
+        // this worker's BGZF block range, resident on its device; record boundaries agreed with the neighbours
+        ngsq_bam_shard_info info;
+        if (ngsq_bam_shard_open(bam, ctx, comm, &info) != NGSQ_OK) bail(ngsq_comm_last_error(comm));
+        for (;;) {
+            ngsq_batch b;
+            if (ngsq_bam_next_batch_device(bam, ctx, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
+            if (!b.n_records) break;
+            CHECK(ctx, ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH));
+            n_pass1 += b.n_records;
+        }
+    } else if (!a.has_n) {
         // no truncation: both passes see every record -> one scan
         for (;;) {
             ngsq_batch b;
@@ -730,28 +827,32 @@ int main(int argc, char **argv) {
         logf(2, "No facets specified that require second pass. Skipping...");
     }
     {
-        const int rc = ngsq_finalize(ctx);
-        if (rc == NGSQ_ERR_UNSORTED && a.coverage == 0) {
-            // the header promised coordinate order and the records broke it: run again on the depth arrays
-            logf(1, "records are not in coordinate order although the header says so: re-running with --coverage array");
+        int rc = NGSQ_OK;
+        std::string why;
+        if (worker && (rc = ngsq_exchange(ctx, comm, nullptr)) != NGSQ_OK) why = ngsq_comm_last_error(comm);
+        if (rc == NGSQ_OK && (rc = ngsq_finalize(ctx)) != NGSQ_OK) why = ngsq_last_error(ctx);
+        if (rc == NGSQ_ERR_UNSORTED && a.coverage == 0 && !force_array) {
+            // the header promised coordinate order and the records broke it (every worker of a --gpus run sees the
+            // same verdict: the counters are summed): scan again, in this process, on the depth arrays
+            logf(1, "records are not in coordinate order although the header says so: scanning again with --coverage array");
             ngsq_destroy(ctx);
+            ctx = nullptr;
             ngsq_bam_close(bam);
-            if (vaf_file) {
-                fclose(vaf_file);
-                unlink(a.vaf.c_str());
-            }
-            std::vector<char *> av(argv, argv + argc);
-            char opt[] = "--coverage", valv[] = "array";
-            av.push_back(opt);
-            av.push_back(valv);
-            av.push_back(nullptr);
-            pid_t pid;
-            if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, av.data(), environ) != 0) bail("could not re-run");
-            int status = 0;
-            waitpid(pid, &status, 0);
-            return WIFEXITED(status) ? WEXITSTATUS(status) : 1;
+            if (ngsq_bam_open(a.src.c_str(), a.threads, &bam) != NGSQ_OK) bail(ngsq_bam_last_error());
+            force_array = true;
+            continue;
         }
-        if (rc != NGSQ_OK) bail(ngsq_last_error(ctx));
+        if (rc != NGSQ_OK) bail(why);
+        break;
+    }
+    } // scan attempts
+    if (worker && a.rank != 0) { // every rank holds the whole-file result; rank 0 writes it
+        if (vaf_file) fclose(vaf_file);
+        ngsq_destroy(ctx);
+        ngsq_bam_close(bam);
+        ngsq_comm_barrier(comm);
+        ngsq_comm_destroy(comm);
+        return 0;
     }
     if (vaf_file && (facets & NGSQ_FACET_EDITS)) {
         // edits.rs:320-341, per sequence in header order: one line per position any record covered; the
@@ -789,5 +890,9 @@ int main(int argc, char **argv) {
     fclose(of);
     ngsq_destroy(ctx);
     ngsq_bam_close(bam);
+    if (comm) {
+        ngsq_comm_barrier(comm);
+        ngsq_comm_destroy(comm);
+    }
     return 0;
 }

@@ -368,7 +368,42 @@ def test_coverage_modes_and_unsorted_fallback(ngs, gpu_lib, oracle_mod, tmp_path
     r = run(ngs, "qc", ubam, GENOME, "-o", str(tmp_path / "u1"), "--coverage", "stream")
     assert r.returncode == 1 and "coordinate order" in r.stderr
     r = run(ngs, "qc", ubam, GENOME, "-o", str(tmp_path / "u2"))
-    assert r.returncode == 0 and "re-running with --coverage array" in r.stderr, r.stderr
+    assert r.returncode == 0 and "scanning again with --coverage array" in r.stderr, r.stderr
     got = json.load(open(tmp_path / "u2" / "u.bam.results.json"))
     json_equal(got["coverage"], docs["array"]["coverage"])          # coverage does not depend on the record order
     json_equal(got["general"], docs["array"]["general"])
+
+
+@pytest.mark.gpu
+def test_gpus_flag_workers_share_one_file(ngs, gpu_lib, oracle_mod, tmp_path):
+    """`ngs qc --gpus 3`: three worker processes (here on one device, exchange through shared memory; with one
+    device each it is RCCL), each ingesting its BGZF block range; the document equals the single-process run.
+    A file that breaks the promised order is scanned again on the depth arrays by every worker alike."""
+    hb = sorted_batch(13, 30_000, max_len=200, min_len=40)
+    bam = str(tmp_path / "g.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=9_000)
+    want = oracle_json(oracle_mod, hb)
+    for mode in ("auto", "array"):
+        out = tmp_path / ("w_" + mode)
+        r = run(ngs, "qc", bam, GENOME, "-o", str(out), "--gpus", "3", "--same-device", "--coverage", mode,
+                "--batch-records", "4001")
+        assert r.returncode == 0, r.stderr
+        assert "Worker 0 of 3 on device 0, exchange over shm." in r.stderr
+        json_equal(json.load(open(out / "g.bam.results.json")), want)
+    # the reference's -n rules are sequential: refused with --gpus
+    r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path), "--gpus", "2", "-n", "10")
+    assert r.returncode == 1 and "--gpus cannot be combined with -n" in r.stderr
+    # more workers than devices without --same-device
+    if gpu_lib.ngsq_device_count() < 3:
+        r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path), "--gpus", "3")
+        assert r.returncode == 1 and "device(s) visible" in r.stderr
+    from tests.util import take_records
+    order = np.arange(hb.n)
+    order[[7000, 23000]] = [23000, 7000]
+    ubam = str(tmp_path / "gu.bam")
+    bamio.write_bam(ubam, take_records(hb, order), NAMES, LENS, block_payload=9_000)
+    r = run(ngs, "qc", ubam, GENOME, "-o", str(tmp_path / "wu"), "--gpus", "3", "--same-device")
+    assert r.returncode == 0 and "scanning again with --coverage array" in r.stderr, r.stderr
+    got = json.load(open(tmp_path / "wu" / "gu.bam.results.json"))
+    json_equal(got["coverage"], want["coverage"])
+    json_equal(got["general"], want["general"])

@@ -1,5 +1,5 @@
-# One BAM file, several ranks (tools/qc_sharded.py) against the single-process `ngs qc`: same JSON.
-# Run on the GPU box:  bash tools/check_sharded.sh [records]   (ranks share GPU 0 over gloo when there is one GPU)
+# One BAM file, several ranks (`ngs qc --gpus 3 --same-device` through tools/qc_sharded.py) against the single-process `ngs qc`: same JSON.
+# Run on the GPU box:  bash tools/check_sharded.sh [records]   (the workers share GPU 0 and exchange through shared memory)
 set -u
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -23,19 +23,16 @@ for other in ("cli_array", "cli_host"):
         print("$kind: cli stream !=", other, str(e)[:200])
 PY
   for cov in stream array; do
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29571 \
-      tools/qc_sharded.py $D/$kind.bam GRCh38_no_alt_AnalysisSet -o $D/sh_${kind}_$cov --backend gloo --same-gpu --coverage $cov 2>&1 | tail -n 1
+    python tools/qc_sharded.py $D/$kind.bam GRCh38_no_alt_AnalysisSet -o $D/sh_${kind}_$cov --gpus 3 --same-device --coverage $cov 2>&1 | tail -n 1
     python - <<PY
 import json, sys
 sys.path.insert(0, "$GRAFT_REPO_ROOT")
 from tests.util import json_equal
 a = json.load(open("$D/cli_$kind/$kind.bam.results.json")); b = json.load(open("$D/sh_${kind}_$cov/$kind.bam.results.json"))
 try:
-    json_equal(a, b); print("$kind $cov: sharded == single process")
+    json_equal(a, b); print("$kind $cov: 3 workers == single process")
 except AssertionError as e:
     print("$kind $cov: MISMATCH", str(e)[:200])
 PY
   done
 done
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29572 \
-  tools/qc_sharded.py $D/fixed.bam GRCh38_no_alt_AnalysisSet -o $D/sh_rccl --backend nccl 2>&1 | tail -n 1
