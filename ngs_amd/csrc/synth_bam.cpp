@@ -127,12 +127,22 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
     std::vector<std::vector<uint64_t>> linear(n_refs);
     uint64_t n_no_coor = 0;
     uint64_t file_off = (uint64_t)ftello(f); // where the next block starts
+    // consecutive records of a sorted file mostly fall into the same bin: one map lookup per run, not per record
+    int32_t cached_ref = -1;
+    uint32_t cached_bin = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> *cached = nullptr;
     auto index_record = [&](const RecIdx &x, uint64_t v0, uint64_t v1) {
         if (x.ref < 0 || (uint32_t)x.ref >= n_refs || x.pos < 0) {
             n_no_coor += 1;
             return;
         }
-        auto &chunks = bins[x.ref][reg2bin(x.pos, x.end)];
+        const uint32_t bin = reg2bin(x.pos, x.end);
+        if (!cached || cached_ref != x.ref || cached_bin != bin) {
+            cached = &bins[x.ref][bin];
+            cached_ref = x.ref;
+            cached_bin = bin;
+        }
+        auto &chunks = *cached;
         if (!chunks.empty() && chunks.back().second == v0)
             chunks.back().second = v1; // the records of a bin that follow each other share a chunk
         else
