@@ -197,6 +197,7 @@ void reader_main(DeviceIngest *d, std::string path) {
             d->cv.wait(g, [&] { return d->stop || !c.ready; });
             if (d->stop) return;
         }
+        const double tr0 = now_ms();
         memcpy(c.h, leftover.data(), leftover.size());
         c.fill = leftover.size();
         c.err.clear();
@@ -239,6 +240,7 @@ void reader_main(DeviceIngest *d, std::string path) {
             file_pos += got;
             c.fill += got;
         }
+        const double tr1 = now_ms();
         c.blocks.clear();
         c.consumed = 0;
         c.total = 0;
@@ -264,6 +266,9 @@ void reader_main(DeviceIngest *d, std::string path) {
                       hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
             d->h2d_issued[k] = ok; // on failure the consumer copies on its own stream (and reports errors)
         }
+        if (trace_on())
+            fprintf(stderr, "[ingest] reader: slot %d, read %.1f MB in %.1f ms, framed %zu blocks in %.1f ms\n", k, c.fill / 1e6, tr1 - tr0,
+                    c.blocks.size(), now_ms() - tr1);
         {
             std::lock_guard<std::mutex> g(d->mu);
             c.ready = true;
@@ -367,6 +372,11 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         BHIP(d->d_blocks.reserve(n_blk));
         BHIP(d->d_status.reserve(n_blk));
         if (d->h2d_issued[slot]) { // already on its way: the reader thread issued the copy
+            if (trace_on()) {
+                const double tw = now_ms();
+                BHIP(hipEventSynchronize(d->h2d_done[slot]));
+                fprintf(stderr, "[ingest] waited %.1f ms for the host-to-device copy of slot %d\n", now_ms() - tw, slot);
+            }
             BHIP(hipStreamWaitEvent(st, d->h2d_done[slot], 0));
         } else {
             BHIP(d->d_comp_slot[slot].reserve(consumed + INFLATE_IN_SLACK));

@@ -67,36 +67,56 @@ constexpr uint32_t LB = 10, DB = 8; // bits of the primary lookup tables
 // 2048 (15) 41 ms.  8192 is the default: within 15 % of the best here and less exposed to files whose
 // matches reach further.  (-DNGSQ_INFLATE_RING=... to rebuild with another size, tools/ring_sweep.sh)
 #ifndef NGSQ_INFLATE_RING
-#define NGSQ_INFLATE_RING 8192
+#define NGSQ_INFLATE_RING 4096
 #endif
 constexpr uint32_t RING = NGSQ_INFLATE_RING, RMASK = RING - 1;
 constexpr uint32_t PIECE = RING / 4;  // bytes that leave the ring together
 constexpr uint32_t MAXWIN = RING / 4; // most output one window may produce on the fast path
 
-// table entry: value << 16 | extra_bits << 8 | kind << 5 | code_bits
-constexpr uint32_t K_LIT = 0, K_EOB = 1, K_BASE = 2, K_ESC = 3, K_INVALID = 7;
-__device__ __forceinline__ constexpr uint32_t mk_entry(uint32_t value, uint32_t extra, uint32_t kind, uint32_t bits) {
-    return value << 16 | extra << 8 | kind << 5 | bits;
+// Table entries are 16 bits (LDS per decoder is what limits the decoders per CU):
+//   literal/length table:  bit 15 = 0: [14:12] kind (LIT / EOB / ESC = code longer than the table / INVALID),
+//                                      [11:4] the literal byte, [3:0] code bits
+//                          bit 15 = 1: a length code: [14:12] extra bits (0..5), [11:4] base length - 3, [3:0] code bits
+//   distance table:        [11:10] kind (BASE / ESC / INVALID), [9:8] m, [7:4] extra bits (0..13), [3:0] code bits;
+//                          base distance = 1 + (m << extra bits)  (codes 0, 1: m = 0, 1; code c >= 2: m = 2 + (c & 1))
+// The code-length code of a dynamic header uses the literal format (symbol in the byte field).
+constexpr uint32_t LK_LIT = 0, LK_EOB = 1, LK_ESC = 2, LK_INVALID = 3;
+constexpr uint32_t DK_BASE = 0, DK_ESC = 1, DK_INVALID = 2;
+__device__ __forceinline__ constexpr uint32_t lit_entry(uint32_t byte, uint32_t kind, uint32_t bits) {
+    return kind << 12 | byte << 4 | bits;
 }
+__device__ __forceinline__ constexpr uint32_t len_entry(uint32_t base, uint32_t extra, uint32_t bits) {
+    return 0x8000u | extra << 12 | (base - 3u) << 4 | bits;
+}
+__device__ __forceinline__ constexpr uint32_t dist_entry(uint32_t code, uint32_t bits) {
+    return code < 2 ? (DK_BASE << 10 | code << 8 | bits) : (DK_BASE << 10 | (2u + (code & 1u)) << 8 | ((code >> 1) - 1u) << 4 | bits);
+}
+__device__ __forceinline__ constexpr uint32_t dist_special(uint32_t kind, uint32_t bits) { return kind << 10 | bits; }
+// fields
+__device__ __forceinline__ uint32_t e_bits(uint32_t e) { return e & 15u; }
+__device__ __forceinline__ bool e_is_len(uint32_t e) { return (e & 0x8000u) != 0; }
+__device__ __forceinline__ uint32_t e_kind(uint32_t e) { return (e >> 12) & 7u; } // of a non-length entry
+__device__ __forceinline__ bool e_is_lit(uint32_t e) { return (e & 0xF000u) == 0; }
+__device__ __forceinline__ uint32_t e_byte(uint32_t e) { return (e >> 4) & 255u; }
+__device__ __forceinline__ uint32_t e_len_extra(uint32_t e) { return e_is_len(e) ? (e >> 12) & 7u : 0u; }
+__device__ __forceinline__ uint32_t d_kind(uint32_t d) { return (d >> 10) & 3u; }
+__device__ __forceinline__ uint32_t d_extra(uint32_t d) { return (d >> 4) & 15u; }
+__device__ __forceinline__ uint32_t d_base(uint32_t d) { return 1u + (((d >> 8) & 3u) << d_extra(d)); }
 
 __constant__ uint16_t c_len_base[31] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27, 31,
                                         35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0,  0};
 __constant__ uint8_t c_len_extra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
                                         3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
-__constant__ uint16_t c_dist_base[32] = {1,   2,   3,   4,   5,   7,    9,    13,   17,   25,   33,   49,   65,    97,    129, 193,
-                                         257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0,   0};
-__constant__ uint8_t c_dist_extra[32] = {0, 0, 0, 0, 1, 1, 2, 2,  3,  3,  4,  4,  5,  5,  6, 6,
-                                         7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct Lds {
     uint8_t ring[RING];
-    uint32_t lit_tab[1u << LB];
-    uint32_t dist_tab[1u << DB]; // also the code-length-code table while a dynamic header is read
+    uint16_t lit_tab[1u << LB];
+    uint16_t dist_tab[1u << DB]; // also the code-length-code table while a dynamic header is read
     uint32_t in_ring[128]; // two 256-byte chunks of the compressed stream (chunk c in slot c & 1)
     uint32_t cnt[2][16];   // codes per length: [0] literal/length, [1] distance (or code-length code)
-    uint32_t start[2][16]; // first index in syms of each length
-    uint32_t fcode[2][16]; // first canonical code of each length
+    uint16_t start[2][16]; // first index in syms of each length
+    uint16_t fcode[2][16]; // first canonical code of each length
     uint16_t syms[2][288]; // symbols in canonical order
     uint8_t lens[320];
 };
@@ -215,10 +235,11 @@ struct HeadBits {
 // lens[0..n) -> primary table of TB bits + (cnt, syms) for codes longer than TB.  which: 0 = lit/len, 1 = dist/cl.
 // kind_of: 0 literal/length alphabet, 1 distance alphabet, 2 code-length alphabet.
 // Returns false for an over-subscribed set.
-__device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t which, uint32_t TB, uint32_t *tab,
+__device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t which, uint32_t TB, uint16_t *tab,
                             uint32_t alphabet, uint32_t lane) {
     if (lane < 16) L.cnt[which][lane] = 0;
-    for (uint32_t i = lane; i < (1u << TB); i += 64) tab[i] = mk_entry(0, 0, K_INVALID, 0);
+    for (uint32_t i = lane; i < (1u << TB); i += 64)
+        tab[i] = (uint16_t)(alphabet == 1 ? dist_special(DK_INVALID, 0) : lit_entry(0, LK_INVALID, 0));
     __syncthreads();
     for (uint32_t i = lane; i < n; i += 64) atomicAdd(&L.cnt[which][lens[i]], 1u);
     __syncthreads();
@@ -234,8 +255,8 @@ __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t wh
         code <<= 1;
         off[l] = index;
         if (lane == 0) {
-            L.start[which][l] = index;
-            L.fcode[which][l] = code;
+            L.start[which][l] = (uint16_t)index;
+            L.fcode[which][l] = (uint16_t)code;
         }
         code += c;
         index += c;
@@ -260,19 +281,19 @@ __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t wh
         const uint32_t rev = __brev(c) >> (32 - l);
         uint32_t e;
         if (alphabet == 0) {
-            if (s < 256) e = mk_entry(s, 0, K_LIT, l);
-            else if (s == 256) e = mk_entry(0, 0, K_EOB, l);
-            else if (s < 286) e = mk_entry(c_len_base[s - 257], c_len_extra[s - 257], K_BASE, l);
-            else e = mk_entry(0, 0, K_INVALID, l);
+            if (s < 256) e = lit_entry(s, LK_LIT, l);
+            else if (s == 256) e = lit_entry(0, LK_EOB, l);
+            else if (s < 286) e = len_entry(c_len_base[s - 257], c_len_extra[s - 257], l);
+            else e = lit_entry(0, LK_INVALID, l);
         } else if (alphabet == 1) {
-            e = s < 30 ? mk_entry(c_dist_base[s], c_dist_extra[s], K_BASE, l) : mk_entry(0, 0, K_INVALID, l);
+            e = s < 30 ? dist_entry(s, l) : dist_special(DK_INVALID, l);
         } else {
-            e = mk_entry(s, 0, K_LIT, l);
+            e = lit_entry(s, LK_LIT, l);
         }
         if (l <= TB) {
-            for (uint32_t k = rev; k < (1u << TB); k += 1u << l) tab[k] = e;
+            for (uint32_t k = rev; k < (1u << TB); k += 1u << l) tab[k] = (uint16_t)e;
         } else {
-            tab[rev & ((1u << TB) - 1u)] = mk_entry(0, 0, K_ESC, 0);
+            tab[rev & ((1u << TB) - 1u)] = (uint16_t)(alphabet == 1 ? dist_special(DK_ESC, 0) : lit_entry(0, LK_ESC, 0));
         }
     }
     __syncthreads();
@@ -301,14 +322,14 @@ __device__ uint32_t slow_symbol(const Lds &L, uint32_t which, uint32_t TB, uint3
 __device__ __noinline__ uint32_t resolve_long(const Lds &L, uint32_t alphabet, uint32_t x) {
     uint32_t bits;
     const uint32_t s = slow_symbol(L, alphabet, alphabet == 0 ? LB : DB, x, &bits);
-    if (s == 0xFFFFu) return mk_entry(0, 0, K_INVALID, 15);
+    if (s == 0xFFFFu) return alphabet == 0 ? lit_entry(0, LK_INVALID, 15) : dist_special(DK_INVALID, 15);
     if (alphabet == 0) {
-        if (s < 256) return mk_entry(s, 0, K_LIT, bits);
-        if (s == 256) return mk_entry(0, 0, K_EOB, bits);
-        if (s < 286) return mk_entry(c_len_base[s - 257], c_len_extra[s - 257], K_BASE, bits);
-        return mk_entry(0, 0, K_INVALID, bits);
+        if (s < 256) return lit_entry(s, LK_LIT, bits);
+        if (s == 256) return lit_entry(0, LK_EOB, bits);
+        if (s < 286) return len_entry(c_len_base[s - 257], c_len_extra[s - 257], bits);
+        return lit_entry(0, LK_INVALID, bits);
     }
-    return s < 30 ? mk_entry(c_dist_base[s], c_dist_extra[s], K_BASE, bits) : mk_entry(0, 0, K_INVALID, bits);
+    return s < 30 ? dist_entry(s, bits) : dist_special(DK_INVALID, bits);
 }
 
 // ---- CRC32 (gzip): GF(2) helpers in the reflected representation -----------------------------
@@ -464,12 +485,12 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             uint32_t i = 0, prev = 0;
             while (i < total) {
                 const uint32_t x = hb.peek(14); // a code (<= 7 bits) and its repeat count (<= 7 bits)
-                const uint32_t e = uni(L.dist_tab[x & 127u]);
-                if (((e >> 5) & 7u) != K_LIT) { // the code-length code has at most 7 bits: no long codes
+                const uint32_t e = uni((uint32_t)L.dist_tab[x & 127u]);
+                if (!e_is_lit(e)) { // the code-length code has at most 7 bits: no long codes
                     err = INF_BAD_CODE_LENGTHS;
                     break;
                 }
-                const uint32_t nb = e & 31u, s = e >> 16;
+                const uint32_t nb = e_bits(e), s = e_byte(e);
                 if (s < 16) {
                     hb.drop(nb);
                     if (lane == 0) cl[i] = (uint8_t)s;
@@ -526,15 +547,15 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             br.sync();
             const uint32_t x = br.lane_bits32(lane);
             uint32_t E = L.lit_tab[x & ((1u << LB) - 1u)];
-            const uint32_t nb = E & 31u, lex = (E >> 8) & 15u;
-            const uint32_t len = (E >> 16) + ((x >> nb) & ((1u << lex) - 1u));
+            const uint32_t nb = e_bits(E), lex = e_len_extra(E);
+            const uint32_t len = e_byte(E) + 3u + ((x >> nb) & ((1u << lex) - 1u));
             const uint32_t s2 = lane + nb + lex; // bit offset of the distance code
             const uint32_t xd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s2 << 2), (int)x);
             const uint32_t D = L.dist_tab[xd & ((1u << DB) - 1u)];
-            const uint32_t db = D & 31u, dex = (D >> 8) & 15u;
-            const uint32_t dist = (D >> 16) + ((xd >> db) & ((1u << dex) - 1u));
-            bool is_lit = (E & (7u << 5)) == (K_LIT << 5);
-            const bool is_match = (E & (7u << 5)) == (K_BASE << 5) && s2 < 64 && (D & (7u << 5)) == (K_BASE << 5);
+            const uint32_t db = e_bits(D), dex = d_extra(D);
+            const uint32_t dist = d_base(D) + ((xd >> db) & ((1u << dex) - 1u));
+            bool is_lit = e_is_lit(E);
+            const bool is_match = e_is_len(E) && s2 < 64 && d_kind(D) == DK_BASE;
             // bits to the next symbol, or a stop mark: end of block, long codes, a distance code beyond lane 63
             uint32_t step = is_lit ? nb : is_match ? nb + lex + db + dex : 0x80u;
             PROF(2); // window bits + gathers
@@ -547,13 +568,13 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 if (s >= 64) break;
                 // a literal with a long code is patched into its lane and the chain goes on
                 uint32_t e = __builtin_amdgcn_readlane(E, s);
-                if (((e >> 5) & 7u) != K_ESC) break;
+                if (e_is_len(e) || e_kind(e) != LK_ESC) break;
                 e = uni(resolve_long(L, 0, __builtin_amdgcn_readlane(x, s)));
                 PROF_COUNT(5, 1);
-                if (((e >> 5) & 7u) != K_LIT) break;
+                if (!e_is_lit(e)) break;
                 if (lane == s) {
                     E = e;
-                    step = e & 31u;
+                    step = e_bits(e);
                     is_lit = true;
                 }
             }
@@ -566,7 +587,17 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             PROF_COUNT(1, __popcll(__ballot(on_chain && is_lit)));
             uint64_t mm = __ballot(on_chain && !is_lit);
-            if (__ballot(on_chain && !is_lit && dist > at)) err = INF_BAD_DISTANCE; // sticky; accesses stay in the ring
+            // a corrupt stream stops here, before anything of this window is stored or copied: a distance beyond the
+            // start of the output would read in front of the block's buffer, and output beyond ISIZE would be flushed
+            // past its end
+            if (__ballot(on_chain && !is_lit && dist > at)) {
+                err = INF_BAD_DISTANCE;
+                break;
+            }
+            if (pos + total > isize) {
+                err = INF_OUTPUT_OVERRUN;
+                break;
+            }
             // All literals of the window go out in one store BEFORE the matches are copied in stream order (a
             // match may read what an earlier symbol of this window wrote).  A source byte is still in the ring,
             // and untouched by this window's stores, iff its position is >= pos + total - RING; older bytes
@@ -574,7 +605,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             const bool strict = total > MAXWIN; // very long output of one window: one symbol at a time
             const uint32_t bound = pos + total - RING; // (wraps below RING bytes of output: then everything is in the ring)
             if (__builtin_expect(strict, 0)) mm = syms;
-            else if (on_chain && is_lit) L.ring[at & RMASK] = (uint8_t)(E >> 16);
+            else if (on_chain && is_lit) L.ring[at & RMASK] = (uint8_t)e_byte(E);
             PROF(4); // literal store
             while (mm) {
                 const uint32_t m = (uint32_t)__builtin_ctzll(mm);
@@ -584,7 +615,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 if (strict) {
                     while (o - flushed >= PIECE) flush_piece(PIECE);
                     if ((__ballot(is_lit) >> m) & 1ull) {
-                        if (lane == m) L.ring[o & RMASK] = (uint8_t)(E >> 16);
+                        if (lane == m) L.ring[o & RMASK] = (uint8_t)e_byte(E);
                         continue;
                     }
                 }
@@ -609,42 +640,38 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             }
             pos += total;
             br.consume(s);
-            if (pos > isize) { // also bounds the work on a corrupt stream
-                err = INF_OUTPUT_OVERRUN;
-                break;
-            }
             PROF(5); // matches
             // A chain that stopped at a length code whose distance code lies beyond lane 63 just ends the
             // window there: the next window starts at that length code and sees all of the match.
-            const bool resume = s > 0 && s < 64 && ((__builtin_amdgcn_readlane(E, s & 63u) >> 5) & 7u) == K_BASE;
+            const bool resume = s > 0 && s < 64 && e_is_len(__builtin_amdgcn_readlane(E, s & 63u));
             if (s < 64 && !resume && err == INF_OK) {
                 // The chain stopped at a symbol the lanes could not finish: end of block, a long code (or a
                 // distance code with one), or an invalid code.  One symbol the plain way.
                 PROF_COUNT(6, 1);
                 br.sync();
                 const uint32_t x0 = br.bits32();
-                uint32_t e = uni(L.lit_tab[x0 & ((1u << LB) - 1u)]);
-                if (((e >> 5) & 7u) == K_ESC) e = uni(resolve_long(L, 0, x0));
-                const uint32_t kind = (e >> 5) & 7u, eb = e & 31u;
-                if (kind == K_LIT) {
-                    if (lane == 0) L.ring[pos & RMASK] = (uint8_t)(e >> 16);
+                uint32_t e = uni((uint32_t)L.lit_tab[x0 & ((1u << LB) - 1u)]);
+                if (!e_is_len(e) && e_kind(e) == LK_ESC) e = uni(resolve_long(L, 0, x0));
+                const uint32_t eb = e_bits(e);
+                if (e_is_lit(e)) {
+                    if (lane == 0) L.ring[pos & RMASK] = (uint8_t)e_byte(e);
                     pos += 1;
                     br.consume(eb);
-                } else if (kind == K_EOB) {
+                } else if (!e_is_len(e) && e_kind(e) == LK_EOB) {
                     br.consume(eb);
                     end_of_block = true;
-                } else if (kind == K_BASE) {
-                    const uint32_t ex = (e >> 8) & 15u;
-                    const uint32_t l = (e >> 16) + ((x0 >> eb) & ((1u << ex) - 1u));
+                } else if (e_is_len(e)) {
+                    const uint32_t ex = e_len_extra(e);
+                    const uint32_t l = e_byte(e) + 3u + ((x0 >> eb) & ((1u << ex) - 1u));
                     br.consume(eb + ex);
                     br.sync();
                     const uint32_t x1 = br.bits32();
-                    uint32_t d = uni(L.dist_tab[x1 & ((1u << DB) - 1u)]);
-                    if (((d >> 5) & 7u) == K_ESC) d = uni(resolve_long(L, 1, x1));
-                    const uint32_t b2 = d & 31u, ex2 = (d >> 8) & 15u;
-                    const uint32_t dd0 = (d >> 16) + ((x1 >> b2) & ((1u << ex2) - 1u));
+                    uint32_t d = uni((uint32_t)L.dist_tab[x1 & ((1u << DB) - 1u)]);
+                    if (d_kind(d) == DK_ESC) d = uni(resolve_long(L, 1, x1));
+                    const uint32_t b2 = e_bits(d), ex2 = d_extra(d);
+                    const uint32_t dd0 = d_base(d) + ((x1 >> b2) & ((1u << ex2) - 1u));
                     br.consume(b2 + ex2);
-                    if (((d >> 5) & 7u) != K_BASE) err = INF_BAD_SYMBOL;
+                    if (d_kind(d) != DK_BASE) err = INF_BAD_SYMBOL;
                     else if (dd0 > pos) err = INF_BAD_DISTANCE;
                     else if (pos + l > isize) err = INF_OUTPUT_OVERRUN;
                     else {
