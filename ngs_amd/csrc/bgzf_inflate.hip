@@ -71,7 +71,6 @@ constexpr uint32_t LB = 10, DB = 8; // bits of the primary lookup tables
 #endif
 constexpr uint32_t RING = NGSQ_INFLATE_RING, RMASK = RING - 1;
 constexpr uint32_t PIECE = RING / 4;  // bytes that leave the ring together
-constexpr uint32_t MAXWIN = RING / 4; // most output one window may produce on the fast path
 
 // Table entries are 16 bits (LDS per decoder is what limits the decoders per CU):
 //   literal/length table:  bit 15 = 0: [14:12] kind (LIT / EOB / ESC = code longer than the table / INVALID),
@@ -119,6 +118,7 @@ struct Lds {
     uint16_t fcode[2][16]; // first canonical code of each length
     uint16_t syms[2][288]; // symbols in canonical order
     uint8_t lens[320];
+    uint8_t mark[64];      // emit: the symbol that starts at each byte of a 64-byte output chunk
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -150,6 +150,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); // row_shr:8
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// inclusive prefix maximum over the 64 lanes (same DPP steps; lanes without a source keep their value)
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
     return v;
 }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
@@ -407,7 +417,13 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         const uint32_t tail0 = head + 4 * body;
         if (tail0 + lane < n) dst[tail0 + lane] = L.ring[(flushed + tail0 + lane) & RMASK];
         flushed += n;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // far matches read these bytes back
+        // Far matches read these bytes back, much later (a byte leaves the ring 3 pieces after it was flushed) and
+        // from this same wave: its stores and its L1-bypassing loads (sc1: served by this XCD's L2) take the same
+        // path in order, so no fence is needed -- an agent-scope release here cost a write-back of the XCD's L2
+        // (buffer_wbl2) and a drain of the wave's stores per KiB of output.
+#ifdef NGSQ_INFLATE_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
     };
 
     PROF_DECL;
@@ -586,7 +602,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             const uint32_t at = pos + incl - olen;
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             PROF_COUNT(1, __popcll(__ballot(on_chain && is_lit)));
-            uint64_t mm = __ballot(on_chain && !is_lit);
             // a corrupt stream stops here, before anything of this window is stored or copied: a distance beyond the
             // start of the output would read in front of the block's buffer, and output beyond ISIZE would be flushed
             // past its end
@@ -598,45 +613,59 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 err = INF_OUTPUT_OVERRUN;
                 break;
             }
-            // All literals of the window go out in one store BEFORE the matches are copied in stream order (a
-            // match may read what an earlier symbol of this window wrote).  A source byte is still in the ring,
-            // and untouched by this window's stores, iff its position is >= pos + total - RING; older bytes
-            // have left for HBM (pos - flushed < PIECE at every window start) and are read back from there.
-            const bool strict = total > MAXWIN; // very long output of one window: one symbol at a time
-            const uint32_t bound = pos + total - RING; // (wraps below RING bytes of output: then everything is in the ring)
-            if (__builtin_expect(strict, 0)) mm = syms;
-            else if (on_chain && is_lit) L.ring[at & RMASK] = (uint8_t)e_byte(E);
-            PROF(4); // literal store
-            while (mm) {
-                const uint32_t m = (uint32_t)__builtin_ctzll(mm);
-                mm &= mm - 1;
-                const uint32_t l = __builtin_amdgcn_readlane(olen, m), d = __builtin_amdgcn_readlane(dist, m);
-                const uint32_t o = __builtin_amdgcn_readlane(at, m), from = o - d;
-                if (strict) {
-                    while (o - flushed >= PIECE) flush_piece(PIECE);
-                    if ((__ballot(is_lit) >> m) & 1ull) {
-                        if (lane == m) L.ring[o & RMASK] = (uint8_t)e_byte(E);
-                        continue;
+            // ---- emit: every output byte of the window is produced by one lane, 64 bytes at a time; no loop over
+            // the matches (a serial copy per match cost ~35 scalar instructions each, and the scalar unit -- one per
+            // CU -- was what bounded this kernel).  Per chunk of 64 bytes:
+            //   (1) the symbol that owns each byte: symbols mark the byte they start at, a max-scan spreads the marks;
+            //   (2) the owner's literal byte or distance arrives by ds_bpermute; a match byte's source is T - distance;
+            //   (3) a source inside this chunk is a pointer to another lane: pointer jumping (p = p[p], at most six
+            //       rounds, none for the usual match that reaches behind the window) until every pointer ends at a byte
+            //       whose value is known -- a literal, a byte already in the ring, or one that has left the ring and is
+            //       read back from HBM (all such bytes of a chunk in one round trip);
+            //   (4) the values travel back along the pointers and the chunk is stored.
+            // A source byte S is still in the ring iff S >= base - RING (base = first byte of the chunk: everything in
+            // front of it has been written); older bytes have been flushed, because base - flushed < PIECE at every
+            // chunk start and PIECE + 64 <= RING.
+            const uint32_t rel = incl - olen; // offset of this lane's symbol in the window's output
+            const uint32_t info = is_lit ? 0x80000000u | e_byte(E) : dist;
+            for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+                const uint32_t base = pos + c0;
+                // (volatile: the marks are read by OTHER lanes than wrote them; without it the compiler forwards this
+                // lane's own zero to its read -- LDS operations of one wave execute in order, no barrier is needed)
+                volatile uint8_t *const mark = L.mark;
+                mark[lane] = 0;
+                if (on_chain && rel - c0 < 64u) mark[rel - c0] = (uint8_t)(lane + 1);
+                uint32_t own = mark[lane];
+                if (c0) { // a symbol that started in an earlier chunk owns the first bytes of this one
+                    const uint64_t before = __ballot(on_chain && rel < c0);
+                    if (lane == 0 && own == 0) own = 64u - (uint32_t)__builtin_clzll(before);
+                }
+                own = wave_inclusive_max(own);
+                const uint32_t oi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((own - 1u) << 2), (int)info);
+                const bool active = c0 + lane < total;
+                const bool lit = (oi >> 31) != 0;
+                const uint32_t T = base + lane, src = T - (oi & 0xFFFFFu);
+                const bool inchunk = active && !lit && (int32_t)(src - base) >= 0;
+                uint32_t val = oi & 255u;
+                if (active && !lit && !inchunk) {
+                    if (__builtin_expect((int32_t)(src - base + RING) < 0, 0))
+                        val = __hip_atomic_load(gdst + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        val = L.ring[src & RMASK];
+                }
+                if (__ballot(inchunk)) {
+                    uint32_t p = inchunk ? src - base : lane;
+                    for (;;) {
+                        const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)p);
+                        if (!__ballot(q != p)) break;
+                        p = q;
                     }
+                    val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)val);
                 }
-                const bool in_ring = strict ? d <= RING - 512 && (int32_t)(from - (o - (RING - 512))) >= 0
-                                            : pos + total < RING || (int32_t)(from - bound) >= 0;
-                if (__builtin_expect(!in_ring, 0)) {
-                    // far match: the source left the ring (d > l here, no overlap)
-                    const uint8_t *g = gdst + from;
-                    for (uint32_t i = lane; i < l; i += 64)
-                        L.ring[(o + i) & RMASK] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (__builtin_expect(d >= l, 1)) {
-                    // the source run [o - d, o) is final: byte i of the match is its byte i mod d
-                    for (uint32_t i = lane; i < l; i += 64) L.ring[(o + i) & RMASK] = L.ring[(from + i) & RMASK];
-                } else {
-                    const uint32_t dd = max(d, 1u);
-                    for (uint32_t i = lane; i < l; i += 64) L.ring[(o + i) & RMASK] = L.ring[(from + i % dd) & RMASK];
-                }
+                if (active) L.ring[T & RMASK] = (uint8_t)val;
+                const uint32_t wr = base + min(64u, total - c0);
+                while (wr - flushed >= PIECE) flush_piece(PIECE);
                 PROF_COUNT(2, 1);
-                PROF_COUNT(3, l);
-                PROF_COUNT(4, d > 4096 ? 1 : 0);
-                PROF_COUNT(7, d > 16384 ? 1 : 0);
             }
             pos += total;
             br.consume(s);
