@@ -60,14 +60,14 @@ namespace {
 
 constexpr uint32_t LB = 10, DB = 8; // bits of the primary lookup tables
 // The most recent RING bytes of output live in LDS; older ones (already written to HBM) are read back
-// from there when a match reaches that far.  A decoder alone on its SIMD is bound by instruction
-// latency, so decoders per CU matter more than the 1-2 us a far match costs: measured on the synthetic
-// BAM (19 % of the matches reach beyond 4 KiB, 10 % beyond 8 KiB, 2.6 % beyond 16 KiB), kernel time for
-// 1.09 GB: ring 32768 (4 decoders per CU) 67 ms, 16384 (6) 46 ms, 8192 (10) 33 ms, 4096 (13) 29 ms,
-// 2048 (15) 41 ms.  8192 is the default: within 15 % of the best here and less exposed to files whose
-// matches reach further.  (-DNGSQ_INFLATE_RING=... to rebuild with another size, tools/ring_sweep.sh)
+// from there when a match reaches that far.  A decoder wave spends most of its time waiting (LDS round
+// trips of the dependent window steps, the far reads), so what counts is how many decoders a CU holds, and
+// that is set by the LDS per decoder in 1280-byte granules: measured on the synthetic BAM (1.09 GB out,
+// 35 % of the matches reach beyond 2 KiB, 19 % beyond 4 KiB, 10 % beyond 8 KiB), same box, kernel time:
+// ring 8192 (12 decoders per CU) 24.6 ms, 4096 (17-19) 17.3 ms, 2048 (25) 14.7 ms, 1024 with a 7-bit distance
+// table (28, the register limit) 15.7 ms.  (-DNGSQ_INFLATE_RING=... to rebuild with another size, tools/ring_sweep.sh)
 #ifndef NGSQ_INFLATE_RING
-#define NGSQ_INFLATE_RING 4096
+#define NGSQ_INFLATE_RING 2048
 #endif
 constexpr uint32_t RING = NGSQ_INFLATE_RING, RMASK = RING - 1;
 constexpr uint32_t PIECE = RING / 4;  // bytes that leave the ring together
@@ -116,9 +116,14 @@ struct Lds {
     uint32_t cnt[2][16];   // codes per length: [0] literal/length, [1] distance (or code-length code)
     uint16_t start[2][16]; // first index in syms of each length
     uint16_t fcode[2][16]; // first canonical code of each length
-    uint16_t syms[2][288]; // symbols in canonical order
-    uint8_t lens[320];
-    uint8_t mark[64];      // emit: the symbol that starts at each byte of a 64-byte output chunk
+    uint16_t syms0[288];   // literal/length symbols in canonical order
+    uint16_t syms1[32];    // distance (or code-length) symbols in canonical order
+    union {
+        uint8_t lens[320]; // code lengths while a block's tables are built
+        uint8_t mark[64];  // emit: the symbol that starts at each byte of a 64-byte output chunk
+    };
+    __device__ __forceinline__ uint16_t *syms(uint32_t which) { return which ? syms1 : syms0; }
+    __device__ __forceinline__ const uint16_t *syms(uint32_t which) const { return which ? syms1 : syms0; }
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -279,14 +284,14 @@ __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t wh
 #pragma unroll
         for (uint32_t k = 1; k < 16; k++) {
             const uint64_t m = __ballot(l == k);
-            if (l == k) L.syms[which][off[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
+            if (l == k) L.syms(which)[off[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
             off[k] += __popcll(m);
         }
     }
     __syncthreads();
     // fill: every code of length <= TB owns 2^(TB-len) slots; longer codes mark their prefix slot
     for (uint32_t i = lane; i < index; i += 64) {
-        const uint32_t s = L.syms[which][i], l = lens[s];
+        const uint32_t s = L.syms(which)[i], l = lens[s];
         const uint32_t c = L.fcode[which][l] + (i - L.start[which][l]);
         const uint32_t rev = __brev(c) >> (32 - l);
         uint32_t e;
@@ -320,7 +325,7 @@ __device__ uint32_t slow_symbol(const Lds &L, uint32_t which, uint32_t TB, uint3
         const uint32_t f = uni(L.fcode[which][l]), c = uni(L.cnt[which][l]);
         if (code - f < c) {
             *bits = l;
-            return uni(L.syms[which][uni(L.start[which][l]) + (code - f)]);
+            return uni(L.syms(which)[uni(L.start[which][l]) + (code - f)]);
         }
     }
     *bits = 15;
