@@ -124,6 +124,24 @@ struct DeviceIngest {
     bool stop = false;
     bool file_done = false; // the consumer has taken the last chunk
     bool first_chunk = true;
+    // The inflate of chunk k+1 runs on its own stream while chunk k is indexed, cut into columns and scanned on the
+    // context's stream: two raw buffers, each with CARRY_MAX bytes of headroom in front of the inflated data for the
+    // record the previous chunk ended in (so where a chunk is inflated to does not depend on the chunk before it).
+    struct Pending {
+        bool issued = false, last = false;
+        size_t n_blk = 0, consumed = 0;
+        uint64_t total = 0;
+        std::vector<BgzfBlock> blocks;
+        std::vector<uint32_t> status;
+        std::string err;
+    } pend[2];
+    DevBuf<uint8_t> d_raw2;
+    DevBuf<BgzfBlock> d_blocks_s[2];
+    DevBuf<uint32_t> d_status_s[2];
+    hipStream_t inf_stream = nullptr;
+    hipEvent_t inf_done[2] = {nullptr, nullptr}, raw_free[2] = {nullptr, nullptr};
+    bool raw_free_set[2] = {false, false};
+    uint8_t *raw = nullptr; // the inflated bytes being indexed / cut into batches: d_raw (sharded mode) or a view into a raw buffer
     // device
     DevBuf<uint8_t> d_comp, d_raw, d_seq, d_qual, d_scan_tmp;
     DevBuf<BgzfBlock> d_blocks;
@@ -160,7 +178,15 @@ struct DeviceIngest {
             (void)hipStreamSynchronize(copy_stream);
             (void)hipStreamDestroy(copy_stream);
         }
+        if (inf_stream) {
+            (void)hipStreamSynchronize(inf_stream);
+            (void)hipStreamDestroy(inf_stream);
+        }
         for (auto &e : h2d_done)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : inf_done)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : raw_free)
             if (e) (void)hipEventDestroy(e);
         for (auto &c : hc)
             if (c.h) (void)hipHostFree(c.h);
@@ -183,13 +209,22 @@ void free_ingest(DeviceIngest *d) { delete d; }
     } while (0)
 
 // Reader thread: fill the pinned buffers alternately with whole BGZF blocks (the bytes of a block
-// cut by the end of a buffer start the next one).
+// cut by the end of a chunk start the next one).  A chunk is as many blocks as inflate to `out_limit`
+// bytes; the file is read in steps of 64 MiB -- sixteen pread()s in parallel, one thread copying out
+// of the page cache into pinned memory (~7 GB/s) would be slower than the GPU inflates -- and each step is
+// framed while the next one is being read.  How many compressed bytes a chunk needs is estimated from the
+// ratio seen so far, so that only a few blocks' worth of bytes are left over (they are copied to the other
+// buffer: reading a fixed amount left 150 MB per chunk to copy twice).
 void reader_main(DeviceIngest *d, std::string path) {
     std::vector<uint8_t> leftover;
     bool eof = false;
     uint64_t file_pos = 0; // next byte of the file to read
     const size_t cap = 2 * d->comp_chunk;
     const uint64_t out_limit = d->raw_cap > 2 * CARRY_MAX ? d->raw_cap - CARRY_MAX : d->raw_cap / 2;
+    constexpr size_t STEP = (size_t)64 << 20;
+    constexpr int NT = 16;
+    double ratio = 0.0; // compressed bytes per inflated byte, from the chunks framed so far
+    const int fd = fileno(d->f);
     for (int k = 0;; k ^= 1) {
         DeviceIngest::HostChunk &c = d->hc[k];
         {
@@ -198,15 +233,62 @@ void reader_main(DeviceIngest *d, std::string path) {
             if (d->stop) return;
         }
         const double tr0 = now_ms();
+        double t_frame = 0;
         memcpy(c.h, leftover.data(), leftover.size());
         c.fill = leftover.size();
         c.err.clear();
-        if (!eof && c.fill < cap) {
-            // several pread()s in parallel: one thread copying out of the page cache into pinned memory
-            // (~7 GB/s) would be slower than the GPU inflates
-            const size_t want = cap - c.fill;
-            const int fd = fileno(d->f);
-            constexpr int NT = 16;
+        c.blocks.clear();
+        c.consumed = 0;
+        c.total = 0;
+        bool full = false; // the chunk holds all the blocks it may
+        // the framed bytes cross PCIe step by step, on the copy stream, while the next step is read: the device
+        // buffer of this slot is free (the consumer released the slot only after the kernels that read it had finished)
+        size_t sent = 0;
+        bool h2d_ok = d->copy_stream && hipSetDevice(d->ctx->device) == hipSuccess &&
+                      d->d_comp_slot[k].reserve(cap + INFLATE_IN_SLACK) == hipSuccess;
+        auto send = [&]() {
+            if (h2d_ok && c.err.empty() && c.consumed > sent) {
+                h2d_ok = hipMemcpyAsync(d->d_comp_slot[k].p + sent, c.h + sent, c.consumed - sent, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess;
+                sent = c.consumed;
+            }
+        };
+        auto frame = [&]() { // blocks of c.h[consumed, fill) that fit the chunk
+            const double tf = now_ms();
+            const size_t n0 = c.blocks.size();
+            size_t used = 0;
+            std::string err;
+            if (!bgzf_split(c.h + c.consumed, c.fill - c.consumed, &c.blocks, &used, &c.total, &err, out_limit)) {
+                c.err = path + ": " + err;
+                return;
+            }
+            for (size_t i = n0; i < c.blocks.size(); i++) c.blocks[i].in_off += c.consumed;
+            c.consumed += used;
+            // bgzf_split stops in front of the block that would pass the limit, or of an incomplete block
+            if (c.fill - c.consumed >= 18) {
+                const uint8_t *h = c.h + c.consumed;
+                const uint32_t xlen = bgzf_rd16(h + 10);
+                if (c.fill - c.consumed >= 18 + (size_t)xlen) { // the whole header is there: which of the two was it?
+                    uint32_t bs = 0;
+                    for (size_t q = 12; q + 6 <= 12 + (size_t)xlen;) {
+                        const uint32_t sl = bgzf_rd16(h + q + 2);
+                        if (h[q] == 'B' && h[q + 1] == 'C' && sl == 2) bs = bgzf_rd16(h + q + 4) + 1;
+                        q += 4 + sl;
+                    }
+                    if (bs && c.fill - c.consumed >= bs) full = true; // complete, yet not taken: the limit
+                }
+            }
+            t_frame += now_ms() - tf;
+        };
+        while (c.err.empty() && !full && !eof && c.fill < cap) {
+            // bytes this chunk still needs, by the ratio so far (unknown at first: one step, then look again)
+            size_t want = STEP;
+            if (ratio > 0) {
+                const double need = (double)(out_limit - c.total) * ratio * 1.02 + 2 * 65536.0;
+                const size_t have = c.fill - c.consumed;
+                want = need > (double)have ? (size_t)(need - (double)have) : 65536;
+                want = std::min(want, STEP);
+            }
+            want = std::min(want, cap - c.fill);
             size_t got_part[NT] = {};
             bool bad_part[NT] = {};
             const size_t per = (want + NT - 1) / NT;
@@ -227,6 +309,8 @@ void reader_main(DeviceIngest *d, std::string path) {
                     got_part[t] = done;
                 });
             }
+            frame(); // what the previous step brought, while this one is on its way
+            send();
             size_t got = 0;
             bool short_read = false;
             for (int t = 0; t < NT; t++) {
@@ -239,14 +323,12 @@ void reader_main(DeviceIngest *d, std::string path) {
             if (got < want) eof = true;
             file_pos += got;
             c.fill += got;
+            if (c.total) ratio = (double)c.consumed / (double)c.total;
         }
+        if (c.err.empty() && !full) frame();
+        send();
+        if (c.total) ratio = (double)c.consumed / (double)c.total;
         const double tr1 = now_ms();
-        c.blocks.clear();
-        c.consumed = 0;
-        c.total = 0;
-        std::string err;
-        if (c.err.empty() && !bgzf_split(c.h, c.fill, &c.blocks, &c.consumed, &c.total, &err, out_limit))
-            c.err = path + ": " + err;
         leftover.assign(c.h + c.consumed, c.h + c.fill);
         if (c.err.empty() && c.blocks.empty()) {
             if (eof && !leftover.empty()) c.err = path + ": truncated BGZF block at end of file";
@@ -254,21 +336,15 @@ void reader_main(DeviceIngest *d, std::string path) {
         }
         c.last = !c.err.empty() || (eof && leftover.empty());
         const bool last = c.last;
-        // start the host-to-device copy right away, on the copy stream: it overlaps whatever the GPU is
-        // doing for the previous chunk (its device buffer is free: the consumer released this slot only
-        // after the kernels that read it had finished)
         d->h2d_issued[k] = false;
-        if (c.err.empty() && !c.blocks.empty() && d->copy_stream) {
-            bool ok = hipSetDevice(d->ctx->device) == hipSuccess &&
-                      d->d_comp_slot[k].reserve(c.consumed + INFLATE_IN_SLACK) == hipSuccess &&
-                      hipMemcpyAsync(d->d_comp_slot[k].p, c.h, c.consumed, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess &&
-                      hipMemsetAsync(d->d_comp_slot[k].p + c.consumed, 0, INFLATE_IN_SLACK, d->copy_stream) == hipSuccess &&
-                      hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
+        if (c.err.empty() && !c.blocks.empty() && h2d_ok && sent == c.consumed) {
+            const bool ok = hipMemsetAsync(d->d_comp_slot[k].p + c.consumed, 0, INFLATE_IN_SLACK, d->copy_stream) == hipSuccess &&
+                            hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
             d->h2d_issued[k] = ok; // on failure the consumer copies on its own stream (and reports errors)
         }
         if (trace_on())
-            fprintf(stderr, "[ingest] reader: slot %d, read %.1f MB in %.1f ms, framed %zu blocks in %.1f ms\n", k, c.fill / 1e6, tr1 - tr0,
-                    c.blocks.size(), now_ms() - tr1);
+            fprintf(stderr, "[ingest] reader: slot %d, %.1f MB read and %zu blocks framed in %.1f ms (framing %.1f ms of it), %.1f MB left over\n",
+                    k, c.fill / 1e6, c.blocks.size(), tr1 - tr0, t_frame, leftover.size() / 1e6);
         {
             std::lock_guard<std::mutex> g(d->mu);
             c.ready = true;
@@ -278,7 +354,7 @@ void reader_main(DeviceIngest *d, std::string path) {
     }
 }
 
-// Offsets of every complete record of d_raw[0, raw_len) whose chain starts at `first` -> d_rec_off; sets
+// Offsets of every complete record of d->raw[0, raw_len) whose chain starts at `first` -> d_rec_off; sets
 // d->tail_off to the offset of the cut record (or raw_len).  DESIGN.md section 9 "Record boundaries".
 int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_total) {
     hipStream_t st = d->ctx->stream;
@@ -290,7 +366,7 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     BHIP(d->d_small.reserve(16));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, d->raw_len);
-        BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+        BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
     }
     d->cand.resize((size_t)n_seg * REC_CANDIDATES);
     BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
@@ -310,7 +386,7 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
         RecCandidate one{};
         if (!c) {
             RecCandidate *d_one = reinterpret_cast<RecCandidate *>(d->d_small.p + 4);
-            BHIP(launch_walk_one(d->d_raw.p, d->raw_len, cur, s1, d_one, st));
+            BHIP(launch_walk_one(d->raw, d->raw_len, cur, s1, d_one, st));
             BHIP(hipMemcpyAsync(&one, d_one, sizeof one, hipMemcpyDeviceToHost, st));
             BHIP(hipStreamSynchronize(st));
             c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
@@ -324,7 +400,7 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     BHIP(d->d_rec_off.reserve(total_rec + 1));
     BHIP(hipMemcpyAsync(d->d_seg.p, d->seg.data(), d->seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     BHIP(hipMemsetAsync(d->d_small.p, 0xFF, sizeof(unsigned long long), st));
-    BHIP(launch_rec_offsets(d->d_raw.p, d->raw_len, n_seg, d->d_seg.p, d->d_seg.p + n_seg, d->d_rec_off.p, d->d_small.p, st));
+    BHIP(launch_rec_offsets(d->raw, d->raw_len, n_seg, d->d_seg.p, d->d_seg.p + n_seg, d->d_rec_off.p, d->d_small.p, st));
     unsigned long long bad = 0;
     BHIP(hipMemcpyAsync(&bad, d->d_small.p, sizeof bad, hipMemcpyDeviceToHost, st));
     BHIP(hipStreamSynchronize(st));
@@ -335,75 +411,85 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     return NGSQ_OK;
 }
 
-// Inflate the next run of BGZF blocks behind the unparsed tail of d_raw and index its records.
+// Queue the inflate (+ CRC check) of the framed chunk in host slot `slot` on the inflate stream, into raw buffer
+// `slot` behind its headroom.  The caller has made sure the reader thread marked the slot ready.
+int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
+    DeviceIngest::HostChunk &c = d->hc[slot];
+    DeviceIngest::Pending &p = d->pend[slot];
+    p.issued = true;
+    p.err = c.err;
+    p.last = c.last;
+    p.n_blk = c.blocks.size();
+    p.consumed = c.consumed;
+    p.total = c.total;
+    if (!p.err.empty() || !p.n_blk) return NGSQ_OK;
+    p.blocks = c.blocks; // the table is copied to the device asynchronously: keep it while the host slot is reused
+    hipStream_t sb = d->inf_stream;
+    BHIP(d->d_blocks_s[slot].reserve(p.n_blk));
+    BHIP(d->d_status_s[slot].reserve(p.n_blk));
+    if (d->h2d_issued[slot]) { // already on its way: the reader thread issued the copy
+        if (trace_on()) {
+            const double tw = now_ms();
+            BHIP(hipEventSynchronize(d->h2d_done[slot]));
+            fprintf(stderr, "[ingest] waited %.1f ms for the host-to-device copy of slot %d\n", now_ms() - tw, slot);
+        }
+        BHIP(hipStreamWaitEvent(sb, d->h2d_done[slot], 0));
+    } else {
+        BHIP(d->d_comp_slot[slot].reserve(p.consumed + INFLATE_IN_SLACK));
+        BHIP(hipMemcpyAsync(d->d_comp_slot[slot].p, c.h, p.consumed, hipMemcpyHostToDevice, sb));
+        BHIP(hipMemsetAsync(d->d_comp_slot[slot].p + p.consumed, 0, INFLATE_IN_SLACK, sb));
+    }
+    if (d->raw_free_set[slot]) BHIP(hipStreamWaitEvent(sb, d->raw_free[slot], 0)); // the chunk before last has left this buffer
+    BHIP(hipMemcpyAsync(d->d_blocks_s[slot].p, p.blocks.data(), p.n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, sb));
+    uint8_t *out = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX;
+    {   // algorithmic bytes of the inflate: compressed bytes read + inflated bytes written
+        KernelTimer kt(d->ctx, K_INFLATE, p.consumed + p.total, sb);
+        BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks_s[slot].p, (uint32_t)p.n_blk, out, d->d_status_s[slot].p, false, sb));
+    }
+    {
+        KernelTimer kt(d->ctx, K_INFLATE_CRC, p.total, sb);
+        BHIP(launch_bgzf_crc(d->d_blocks_s[slot].p, (uint32_t)p.n_blk, out, d->d_status_s[slot].p, sb));
+    }
+    p.status.resize(p.n_blk);
+    BHIP(hipMemcpyAsync(p.status.data(), d->d_status_s[slot].p, p.n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, sb));
+    BHIP(hipEventRecord(d->inf_done[slot], sb));
+    (void)b;
+    return NGSQ_OK;
+}
+
+// The next chunk: wait for its inflate (queued one call earlier, while the chunk before it was parsed and scanned),
+// move the record the previous chunk ended in to its front, queue the inflate of the chunk after it, index its records.
 int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     hipStream_t st = d->ctx->stream;
     const double t0 = now_ms();
     static thread_local double last_end = 0;
     const double batches_ms = last_end ? t0 - last_end : 0.0; // time the caller spent on the previous chunk's batches
-    // ---- 1. keep the cut record at the end of the previous chunk
-    const uint64_t carry = d->raw_len - d->tail_off;
-    if (carry > CARRY_MAX || carry + REC_SEGMENT > d->raw_cap)
-        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest carry space (%llu MiB)",
-                             b->path.c_str(), (unsigned long long)(std::min<uint64_t>(CARRY_MAX, d->raw_cap) >> 20));
-    if (carry && d->tail_off) {
-        if (carry <= d->tail_off) {
-            BHIP(hipMemcpyAsync(d->d_raw.p, d->d_raw.p + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
-        } else { // overlapping ranges: through the (idle) compressed buffer
-            BHIP(d->d_comp.reserve(carry));
-            BHIP(hipMemcpyAsync(d->d_comp.p, d->d_raw.p + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
-            BHIP(hipMemcpyAsync(d->d_raw.p, d->d_comp.p, carry, hipMemcpyDeviceToDevice, st));
-        }
-    }
-    // ---- 2. the next framed chunk from the reader thread
     const int slot = d->cur;
     DeviceIngest::HostChunk &c = d->hc[slot];
-    {
-        std::unique_lock<std::mutex> g(d->mu);
-        d->cv.wait(g, [&] { return c.ready; });
+    DeviceIngest::Pending &p = d->pend[slot];
+    // ---- 1. this chunk's inflate: queued during the previous call unless the reader thread was late (or this is the first)
+    if (!p.issued) {
+        {
+            std::unique_lock<std::mutex> g(d->mu);
+            d->cv.wait(g, [&] { return c.ready; });
+        }
+        const int rc = issue_inflate(b, d, slot);
+        if (rc) return rc;
     }
     const double t1 = now_ms();
-    if (!c.err.empty()) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s", c.err.c_str());
-    const size_t n_blk = c.blocks.size(), consumed = c.consumed;
-    const uint64_t total = c.total;
-    // ---- 3. inflate
-    for (auto &bl : c.blocks) bl.out_off += carry;
-    if (n_blk) {
-        BHIP(d->d_blocks.reserve(n_blk));
-        BHIP(d->d_status.reserve(n_blk));
-        if (d->h2d_issued[slot]) { // already on its way: the reader thread issued the copy
-            if (trace_on()) {
-                const double tw = now_ms();
-                BHIP(hipEventSynchronize(d->h2d_done[slot]));
-                fprintf(stderr, "[ingest] waited %.1f ms for the host-to-device copy of slot %d\n", now_ms() - tw, slot);
-            }
-            BHIP(hipStreamWaitEvent(st, d->h2d_done[slot], 0));
-        } else {
-            BHIP(d->d_comp_slot[slot].reserve(consumed + INFLATE_IN_SLACK));
-            BHIP(hipMemcpyAsync(d->d_comp_slot[slot].p, c.h, consumed, hipMemcpyHostToDevice, st));
-            BHIP(hipMemsetAsync(d->d_comp_slot[slot].p + consumed, 0, INFLATE_IN_SLACK, st));
-        }
-        BHIP(hipMemcpyAsync(d->d_blocks.p, c.blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
-        {   // algorithmic bytes of the inflate: compressed bytes read + inflated bytes written
-            KernelTimer kt(d->ctx, K_INFLATE, consumed + total);
-            BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, false, st));
-        }
-        {
-            KernelTimer kt(d->ctx, K_INFLATE_CRC, total);
-            BHIP(launch_bgzf_crc(d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, st));
-        }
-        d->status.resize(n_blk);
-        BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        BHIP(hipStreamSynchronize(st));
-        for (size_t k = 0; k < n_blk; k++)
-            if (d->status[k] != INF_OK)
+    if (!p.err.empty()) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s", p.err.c_str());
+    if (p.n_blk) {
+        BHIP(hipEventSynchronize(d->inf_done[slot]));
+        for (size_t k = 0; k < p.n_blk; k++)
+            if (p.status[k] != INF_OK)
                 return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: BGZF block %llu: %s", b->path.c_str(),
-                                     (unsigned long long)(d->blocks_done + k), inflate_status_text(d->status[k]));
-        d->blocks_done += n_blk;
+                                     (unsigned long long)(d->blocks_done + k), inflate_status_text(p.status[k]));
+        d->blocks_done += p.n_blk;
     }
-    // the pinned buffer goes back to the reader thread
-    d->file_done = c.last;
+    // the pinned buffer and the device copy of the compressed bytes go back to the reader thread
+    d->file_done = p.last;
     d->h2d_issued[slot] = false;
+    p.issued = false;
     {
         std::lock_guard<std::mutex> g(d->mu);
         c.ready = false;
@@ -411,7 +497,30 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     d->cv.notify_all();
     d->cur ^= 1;
     const double t3 = now_ms();
-    d->raw_len = carry + total;
+    // ---- 2. the cut record at the end of the previous chunk moves in front of this chunk's data
+    const uint64_t carry = d->raw_len - d->tail_off;
+    if (carry > CARRY_MAX)
+        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest carry space (%llu MiB)", b->path.c_str(),
+                             (unsigned long long)(CARRY_MAX >> 20));
+    uint8_t *const view = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX - carry;
+    if (carry) BHIP(hipMemcpyAsync(view, d->raw + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
+    // everything that reads the previous chunk's buffer has been queued on the context's stream by now
+    BHIP(hipEventRecord(d->raw_free[slot ^ 1], st));
+    d->raw_free_set[slot ^ 1] = true;
+    // ---- 3. the chunk after this one, if the reader thread has it: its inflate overlaps this chunk's parse and scan
+    if (!p.last) {
+        bool ready;
+        {
+            std::lock_guard<std::mutex> g(d->mu);
+            ready = d->hc[slot ^ 1].ready;
+        }
+        if (ready) {
+            const int rc = issue_inflate(b, d, slot ^ 1);
+            if (rc) return rc;
+        }
+    }
+    d->raw = view;
+    d->raw_len = carry + p.total;
     d->n_rec = d->cursor = 0;
     d->tail_off = 0;
     const uint64_t first = d->first_chunk ? b->header_bytes : 0;
@@ -431,8 +540,8 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     d->n_rec = total_rec;
     if (trace_on())
         fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | batches of the previous chunk %.1f ms, "
-                        "wait for reader %.1f ms, inflate %.1f ms, index %.1f ms\n",
-                n_blk, consumed / 1e6, total / 1e6, (unsigned long long)total_rec, batches_ms, t1 - t0, t3 - t1, now_ms() - t3);
+                        "wait for reader %.1f ms, wait for inflate %.1f ms, index %.1f ms\n",
+                p.n_blk, p.consumed / 1e6, p.total / 1e6, (unsigned long long)total_rec, batches_ms, t1 - t0, t3 - t1, now_ms() - t3);
     last_end = now_ms();
     return NGSQ_OK;
 }
@@ -611,6 +720,7 @@ extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, 
     d->raw_cap = total + 64;
     d->raw_len = total;
     BHIP(d->d_raw.reserve(d->raw_cap));
+    d->raw = d->d_raw.p;
     if (n_blk) {
         BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
         BHIP(d->d_blocks.reserve(n_blk));
@@ -618,7 +728,7 @@ extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, 
         BHIP(hipMemcpyAsync(d->d_comp.p, h, consumed, hipMemcpyHostToDevice, st));
         BHIP(hipMemsetAsync(d->d_comp.p + consumed, 0, INFLATE_IN_SLACK, st));
         BHIP(hipMemcpyAsync(d->d_blocks.p, d->shard_blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
-        BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->d_raw.p, d->d_status.p, true, st));
+        BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->raw, d->d_status.p, true, st));
         d->status.resize(n_blk);
         BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         BHIP(hipStreamSynchronize(st));
@@ -637,7 +747,7 @@ extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, 
         d->entry = d->raw_len;
         if (n_seg) {
             BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
-            BHIP(launch_rec_candidates(d->d_raw.p, d->raw_len, 0, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+            BHIP(launch_rec_candidates(d->raw, d->raw_len, 0, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
             d->cand.resize((size_t)n_seg * REC_CANDIDATES);
             BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
             BHIP(hipStreamSynchronize(st));
@@ -709,9 +819,13 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         b->dev = d;
         b->dev_free = free_ingest;
         for (auto &c : d->hc) BHIP(hipHostMalloc((void **)&c.h, 2 * d->comp_chunk, hipHostMallocDefault));
-        BHIP(d->d_raw.reserve(d->raw_cap + 64));
+        BHIP(d->d_raw.reserve(CARRY_MAX + d->raw_cap + 64)); // headroom for the carried record | one chunk's inflated bytes
+        BHIP(d->d_raw2.reserve(CARRY_MAX + d->raw_cap + 64));
         BHIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+        BHIP(hipStreamCreateWithFlags(&d->inf_stream, hipStreamNonBlocking));
         for (auto &e : d->h2d_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : d->inf_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : d->raw_free) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         d->reader = std::thread(reader_main, d, b->path);
         // the host side of this handle is done: release its buffers
         std::vector<uint8_t>().swap(b->comp);
@@ -752,7 +866,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     BHIP(hipMemsetAsync(d->d_small.p + 1, 0, 3 * sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_COLUMNS, n * 36);
-        BHIP(launch_rec_fixed(d->d_raw.p, rec, n, col, d->d_small.p + 1, st));
+        BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_small.p + 1, st));
     }
     unsigned long long stats[3] = {0, 0, 0};
     BHIP(hipMemcpyAsync(stats, d->d_small.p + 1, sizeof stats, hipMemcpyDeviceToHost, st));
@@ -767,7 +881,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         BHIP(d->d_len.reserve(3 * (n + 1)));
         uint64_t *sl = d->d_len.p, *ql = sl + (n + 1), *cl = ql + (n + 1);
         BHIP(hipMemsetAsync(d->d_len.p, 0, 3 * (n + 1) * sizeof(uint64_t), st));
-        BHIP(launch_rec_lengths(d->d_raw.p, rec, n, sl, ql, cl, st));
+        BHIP(launch_rec_lengths(d->raw, rec, n, sl, ql, cl, st));
         size_t tmp_bytes = 0;
         BHIP(launch_exclusive_scan_u64(sl, n + 1, nullptr, &tmp_bytes, st));
         BHIP(d->d_scan_tmp.reserve(tmp_bytes + 256));
@@ -801,7 +915,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     col.qual_pitch = pitch_q;
     {
         KernelTimer kt(d->ctx, K_REC_COLUMNS, 2 * (so + qo + co * 4));
-        BHIP(launch_rec_var(d->d_raw.p, rec, n, col, so, qo, st));
+        BHIP(launch_rec_var(d->raw, rec, n, col, so, qo, st));
     }
     d->cursor += n;
     b->n_read += n;

@@ -331,18 +331,18 @@ static hipEvent_t get_event(ngsq_ctx *c) {
     return e;
 }
 
-ngsq::KernelTimer::KernelTimer(ngsq_ctx *c_, int id_, uint64_t bytes) : c(c_), id(id_) {
+ngsq::KernelTimer::KernelTimer(ngsq_ctx *c_, int id_, uint64_t bytes, hipStream_t stream) : c(c_), id(id_), s(stream ? stream : c_->stream) {
     c->timing[id].launches += 1;
     c->timing[id].algo_bytes += bytes;
     if (c->cfg.timing) {
         a = get_event(c);
         b = get_event(c);
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, s);
     }
 }
 ngsq::KernelTimer::~KernelTimer() {
     if (c->cfg.timing) {
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, s);
         c->pending.push_back({id, a, b});
     }
 }

@@ -27,7 +27,8 @@ struct KernelTimer {
     ngsq_ctx *c;
     int id;
     hipEvent_t a = nullptr, b = nullptr;
-    KernelTimer(ngsq_ctx *c, int id, uint64_t algo_bytes);
+    hipStream_t s; // the stream the bracketed launches go to (default: the context's)
+    KernelTimer(ngsq_ctx *c, int id, uint64_t algo_bytes, hipStream_t stream = nullptr);
     ~KernelTimer();
 };
 
