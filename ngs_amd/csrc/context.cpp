@@ -264,7 +264,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         CTX_TRY(hipMalloc((void **)&st.edits, ne * 4));
         CTX_TRY(hipMemsetAsync(st.edits, 0, ne * 4, c->stream));
         uint8_t *bases = nullptr;
-        CTX_TRY(hipMalloc((void **)&bases, nbases));
+        CTX_TRY(hipMalloc((void **)&bases, nbases + 64)); // k_edits reads reference bytes eight at a time
         st.ref_bases = bases;
         c->d_ref_bases = bases;
         for (uint32_t r = 0; r < nr; r++)

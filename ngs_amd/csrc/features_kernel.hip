@@ -9,6 +9,13 @@
 // (an interval fails `s < qe && e > qs` either by s >= qe or by e <= qs, never both), so two binary
 // searches per name on the separately sorted starts and stops give the EXACT count -- no interval
 // tree, no max-length scan: 10 searches per record over L2-resident lists.
+//
+// The 256 records a block takes at a time are neighbours in a coordinate-sorted file: their query bounds span a
+// few hundred positions, between which hardly any interval starts or ends.  Twenty threads first search the lists
+// for the tile's smallest and largest bounds (per name: starts at the smallest / largest query end, stops at the
+// smallest / largest query start); every record's own searches then run inside those brackets -- one or two steps
+// instead of eighteen.  Records on another sequence than the tile's first (and any order of records) stay
+// correct: their brackets are the whole lists.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -36,8 +43,14 @@ __device__ __forceinline__ uint32_t upper_bound(const uint32_t *a, uint32_t lo, 
     return lo;
 }
 
-// intervals of name id k on sequence r overlapping [qs, qe)
-__device__ __forceinline__ uint32_t count_overlaps(const FeatureTables &ft, uint32_t k, uint32_t r, uint32_t qs, uint32_t qe) {
+// intervals of name id k on sequence r overlapping [qs, qe); br = brackets of the tile for this name, or null
+__device__ __forceinline__ uint32_t count_overlaps(const FeatureTables &ft, uint32_t k, uint32_t r, uint32_t qs, uint32_t qe,
+                                                   const uint32_t *br) {
+    if (br) {
+        const uint32_t started = lower_bound(ft.starts, br[0], br[1], qe); // s < qe
+        const uint32_t ended = upper_bound(ft.stops, br[2], br[3], qs);    // e <= qs
+        return started - ended;
+    }
     const uint32_t b = ft.idx[k * ft.n_refs + r], e = ft.idx[k * ft.n_refs + r + 1];
     if (b == e) return 0;
     const uint32_t started = lower_bound(ft.starts, b, e, qe) - b; // s < qe
@@ -45,23 +58,40 @@ __device__ __forceinline__ uint32_t count_overlaps(const FeatureTables &ft, uint
     return started - ended;
 }
 
-__device__ __forceinline__ void tally(unsigned long long *counter, bool pred) {
-    const uint64_t m = __ballot(pred);
-    if (m && (threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned long long)__popcll(m));
-}
+// per-wave count kept in a (uniform) register over the block's whole loop: one global atomic per counter and
+// BLOCK at the end -- an atomic per wave and tile on the same eleven addresses serialised at the L2 (~9 ns each)
+// and was what this kernel's time consisted of
+__device__ __forceinline__ void tally(uint32_t &counter, bool pred) { counter += (uint32_t)__popcll(__ballot(pred)); }
 
 } // namespace
 
 __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b, FeatureTables ft) {
+    __shared__ unsigned long long s_key; // (sequence << 32 | smallest query start) of the tile's processed records
+    __shared__ uint32_t s_mm[3];         // largest query start, smallest / largest query end on that sequence
+    __shared__ uint32_t s_br[5][4];      // per name id: brackets of the searches (see the head of this file)
+    __shared__ uint32_t s_cnt[11];
+    if (threadIdx.x < 11) s_cnt[threadIdx.x] = 0;
+    uint32_t cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t n_round = (b.n + 63) & ~63ull; // whole waves take part in the ballots
+    const uint64_t n_round = (b.n + 255) & ~255ull; // whole blocks take part in the barriers and ballots
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool live = i < b.n;
         bool ign_flags = false, ign_nonprimary = false, err_ref = false, err_pos = false, processed = false;
         bool utr5 = false, utr3 = false, cds = false, intergenic = false, exonic = false, intronic = false;
+        if (threadIdx.x == 0) {
+            s_key = ~0ull;
+            s_mm[0] = 0;
+            s_mm[1] = 0xFFFFFFFFu;
+            s_mm[2] = 0;
+        }
+        __syncthreads();
+        uint32_t qs = 0, qe = 0;
+        int32_t ref = -1;
+        bool look = false; // the record reaches the lookups
         if (live) {
             const uint32_t flag = b.flag[i];
-            const int32_t ref = b.ref_id[i], pos = b.pos[i];
+            ref = b.ref_id[i];
+            const int32_t pos = b.pos[i];
             if (flag & 0x4u) { // features.rs:127-130
                 ign_flags = true;
             } else if (ref < 0 || (uint32_t)ref >= ft.n_refs) { // :132-155
@@ -80,7 +110,42 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                     // M, D, N, =, X consume the reference
                     if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) span += op >> 4;
                 }
-                const uint32_t qs = (uint32_t)pos + 1u, qe = qs + span + 1u; // find(start, end + 1)
+                qs = (uint32_t)pos + 1u;
+                qe = qs + span + 1u; // find(start, end + 1)
+                look = true;
+                atomicMin(&s_key, (unsigned long long)(uint32_t)ref << 32 | qs);
+            }
+        }
+        __syncthreads();
+        const unsigned long long key = s_key;
+        const int32_t r0 = key == ~0ull ? -1 : (int32_t)(key >> 32);
+        if (look && ref == r0) {
+            atomicMax(&s_mm[0], qs);
+            atomicMin(&s_mm[1], qe);
+            atomicMax(&s_mm[2], qe);
+        }
+        __syncthreads();
+        if (r0 >= 0 && threadIdx.x < 20) {
+            const uint32_t k = threadIdx.x >> 2, which = threadIdx.x & 3;
+            const uint32_t lo = ft.idx[k * ft.n_refs + r0], hi = ft.idx[k * ft.n_refs + r0 + 1];
+            uint32_t v;
+            if (which == 0) v = lower_bound(ft.starts, lo, hi, s_mm[1]) - lo;                          // fewest starts below a query end
+            else if (which == 1) v = lower_bound(ft.starts, lo, hi, s_mm[2]) - lo;                     // most
+            else if (which == 2) v = upper_bound(ft.stops, lo, hi, (uint32_t)(key & 0xFFFFFFFFu)) - lo; // fewest stops at or below a query start
+            else v = upper_bound(ft.stops, lo, hi, s_mm[0]) - lo;                                      // most
+            // kept relative to the list's begin, so that counts come out directly; the searches add the begin back
+            s_br[k][which] = v;
+        }
+        __syncthreads();
+        if (look) {
+            const bool narrow = ref == r0;
+            auto count = [&](uint32_t name) -> uint32_t {
+                if (!narrow) return count_overlaps(ft, name, (uint32_t)ref, qs, qe, nullptr);
+                const uint32_t lo = ft.idx[name * ft.n_refs + ref];
+                const uint32_t br[4] = {lo + s_br[name][0], lo + s_br[name][1], lo + s_br[name][2], lo + s_br[name][3]};
+                return count_overlaps(ft, name, (uint32_t)ref, qs, qe, br);
+            };
+            {
                 // :186-214  UTR / CDS store: the if / else-if chain over the overlapping intervals only
                 // depends on how many there are of each name (roles may share a name)
                 bool c5 = false, c3 = false, cc = false;
@@ -92,7 +157,7 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                     bool seen = false; // count each distinct name once
                     for (uint32_t q = 0; q < role; q++) seen |= ft.role_name[q] == name;
                     if (seen) continue;
-                    uint32_t cnt = min(count_overlaps(ft, name, (uint32_t)ref, qs, qe), 3u);
+                    uint32_t cnt = min(count(name), 3u);
                     for (; cnt; cnt--) {
                         if (!c5 && name == n5) c5 = true;
                         else if (!c3 && name == n3) c3 = true;
@@ -105,8 +170,8 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                 const uint32_t ne = ft.role_name[NGSQ_ROLE_EXON], ng = ft.role_name[NGSQ_ROLE_GENE];
                 const bool gene_in_store = ng != n5 && ng != n3 && ng != nc;
                 const bool exon_in_store = ne != n5 && ne != n3 && ne != nc && ne != ng;
-                const bool has_gene = gene_in_store && count_overlaps(ft, ng, (uint32_t)ref, qs, qe) > 0;
-                const bool has_exon = exon_in_store && count_overlaps(ft, ne, (uint32_t)ref, qs, qe) > 0;
+                const bool has_gene = gene_in_store && count(ng) > 0;
+                const bool has_exon = exon_in_store && count(ne) > 0;
                 if (has_gene) {
                     if (has_exon) exonic = true;
                     else intronic = true;
@@ -116,18 +181,27 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                 processed = true; // :240
             }
         }
-        unsigned long long *c = st.counters + C_FEAT;
-        tally(c + F_UTR5, utr5);
-        tally(c + F_UTR3, utr3);
-        tally(c + F_CDS, cds);
-        tally(c + F_INTERGENIC, intergenic);
-        tally(c + F_EXONIC, exonic);
-        tally(c + F_INTRONIC, intronic);
-        tally(c + F_PROCESSED, processed);
-        tally(c + F_IGN_FLAGS, ign_flags);
-        tally(c + F_IGN_NONPRIMARY, ign_nonprimary);
-        tally(st.counters + C_FEAT_ERR_REF, err_ref);
-        tally(st.counters + C_FEAT_ERR_POS, err_pos);
+        tally(cnt[F_UTR5], utr5);
+        tally(cnt[F_UTR3], utr3);
+        tally(cnt[F_CDS], cds);
+        tally(cnt[F_INTERGENIC], intergenic);
+        tally(cnt[F_EXONIC], exonic);
+        tally(cnt[F_INTRONIC], intronic);
+        tally(cnt[F_PROCESSED], processed);
+        tally(cnt[F_IGN_FLAGS], ign_flags);
+        tally(cnt[F_IGN_NONPRIMARY], ign_nonprimary);
+        tally(cnt[9], err_ref);
+        tally(cnt[10], err_pos);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 11; k++)
+            if (cnt[k]) atomicAdd(&s_cnt[k], cnt[k]);
+    __syncthreads();
+    if (threadIdx.x < 11 && s_cnt[threadIdx.x]) {
+        unsigned long long *dst = threadIdx.x < 9 ? st.counters + C_FEAT + threadIdx.x
+                                                  : st.counters + (threadIdx.x == 9 ? C_FEAT_ERR_REF : C_FEAT_ERR_POS);
+        atomicAdd(dst, (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 

@@ -203,101 +203,175 @@ __global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBat
 // ---------------------------------------------------------------------------
 // Edits process, one thread per record
 // reference: edits.rs:217-303, utils/alignment.rs:48-107, utils/cigar.rs
+//
+// refs/alts per position are what the reference keeps per sequence (edits.rs:59-63).  One global atomic per
+// compared base (150 per read, ~60 of them on every position at whole-genome depth) ran at the L2's atomic rate:
+// 18 ms per 10 M reads.  A block works through consecutive tiles of 256 records; in a coordinate-sorted file they
+// cover a few hundred positions, so the block tallies into an LDS window of EW positions anchored at the tile's
+// first placed record and adds the window to the global arrays once per tile (positions outside the window, other
+// sequences, unsorted input: straight to the global arrays -- always correct).
 // ---------------------------------------------------------------------------
+constexpr uint32_t EW = 4096; // positions per LDS window: tile of 256 sorted reads (~650 positions at 60x) + the longest read / skip
 __global__ __launch_bounds__(256) void k_edits(DeviceState st, DeviceBatch b) {
     __shared__ uint32_t s_h1[NGSQ_EDITS_BINS], s_h2[NGSQ_EDITS_BINS];
+    __shared__ uint32_t w_refs[EW], w_alts[EW];
     __shared__ u64 s_acc[4];
+    __shared__ u64 s_key;      // (sequence << 32 | first position) of the tile's window
+    __shared__ uint32_t s_whi; // one past the last window offset the tile touched
     for (uint32_t i = threadIdx.x; i < NGSQ_EDITS_BINS; i += blockDim.x) s_h1[i] = s_h2[i] = 0;
+    for (uint32_t i = threadIdx.x; i < EW; i += blockDim.x) w_refs[i] = w_alts[i] = 0;
     if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
-    __syncthreads();
     uint32_t c[4] = {0, 0, 0, 0}; // bad_ref, record_short, not_consumed, too_many
 
     uint64_t lo, hi;
     block_slice(b.n, lo, hi);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t f = b.flag[i];
-        const int32_t ref = b.ref_id[i];
-        const int32_t pos = b.pos[i];
-        if (ref < 0 || (uint32_t)ref >= st.n_refs || pos < 0) continue;
-        const uint32_t n_ops = b.n_cigar[i];
-        const uint64_t cbase = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
-        uint64_t span = 0;
-        for (uint32_t k = 0; k < n_ops; k++) {
-            const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu;
-            if (op <= 8u && ((0x18Du >> op) & 1u)) span += cg >> 4;
+    for (uint64_t t0 = lo; t0 < hi; t0 += blockDim.x) {
+        const uint64_t i = t0 + threadIdx.x;
+        const bool live = i < hi;
+        if (threadIdx.x == 0) {
+            s_key = ~0ull;
+            s_whi = 0;
         }
-        const uint64_t L = st.ref_len[ref];
-        const uint64_t s = (uint64_t)pos + 1, e = s + span - 1;
-        if (e == 0 || s > L) continue;  // not yielded by query()
-        if (f & 0x404u) continue;       // unmapped | duplicate  edits.rs:227-229
-        const uint64_t boff = st.ref_bases_off[ref];
-        if (boff == NO_DEPTH || s + span - 1 > L) { // edits.rs:245-261
-            c[0] += 1;
-            continue;
-        }
-        const uint8_t *rb = st.ref_bases + boff + (s - 1);
-        uint32_t *refs = st.edits + st.ref_edits_off[ref];
-        uint32_t *alts = refs + (L + 1);
-        const uint8_t *sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
-        const uint32_t l = b.l_seq[i];
-        uint64_t rp = 0;  // reference_ptr
-        uint32_t qp = 0;  // record_ptr
-        uint32_t edits = 0;
-        int err = 0;
-        for (uint32_t k = 0; k < n_ops && !err; k++) {
-            const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu, len = cg >> 4;
-            if (op > 8u) continue;
-            const bool c_ref = (0x18Du >> op) & 1u;  // M D N = X
-            const bool c_seq = (0x193u >> op) & 1u;  // M I S = X
-            if (op == 0u) { // only Kind::Match compares (edits.rs:277)
-                for (uint32_t j = 0; j < len; j++) {
-                    if (qp >= l) { // alignment.rs:84-87
-                        err = 2;
-                        break;
-                    }
-                    const uint32_t byte = sq[qp >> 1];
-                    const uint32_t rec = (qp & 1u) ? (byte & 0xFu) : (byte >> 4);
-                    const uint32_t rbase = rb[rp];
-                    if (rbase != rec) {
-                        edits += 1;
-                        atomicAdd(&alts[s + rp], 1u);
-                    } else {
-                        atomicAdd(&refs[s + rp], 1u);
-                    }
-                    rp += 1;
-                    qp += 1;
+        __syncthreads();
+        // ---- the record's placement (query() filter, flags, reference slice): edits.rs:227-261
+        uint32_t f = 0, n_ops = 0;
+        int32_t ref = -1;
+        uint64_t cbase = 0, L = 0, s = 0, span = 0;
+        bool go = false;
+        if (live) {
+            f = b.flag[i];
+            ref = b.ref_id[i];
+            const int32_t pos = b.pos[i];
+            if (ref >= 0 && (uint32_t)ref < st.n_refs && pos >= 0) {
+                n_ops = b.n_cigar[i];
+                cbase = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
+                for (uint32_t k = 0; k < n_ops; k++) {
+                    const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu;
+                    if (op <= 8u && ((0x18Du >> op) & 1u)) span += cg >> 4;
                 }
-            } else {
-                if (c_seq) {
-                    if ((uint64_t)qp + len > l) {
-                        err = 2;
-                        break;
-                    }
-                    qp += len;
+                L = st.ref_len[ref];
+                s = (uint64_t)pos + 1;
+                const uint64_t e = s + span - 1;
+                go = !(e == 0 || s > L)     // not yielded by query()
+                     && !(f & 0x404u);      // unmapped | duplicate  edits.rs:227-229
+                if (go && (st.ref_bases_off[ref] == NO_DEPTH || s + span - 1 > L)) { // edits.rs:245-261
+                    c[0] += 1;
+                    go = false;
                 }
-                if (c_ref) rp += len;
             }
         }
-        // NOTE: like the reference, positions visited before an error stay counted;
-        // the error aborts the run anyway.
-        if (err == 2) {
-            c[1] += 1;
-            continue;
+        if (go) atomicMin(&s_key, (u64)(uint32_t)ref << 32 | s);
+        __syncthreads();
+        const u64 key = s_key;
+        const int32_t wref = key == ~0ull ? -1 : (int32_t)(key >> 32);
+        const uint64_t wbase = key & 0xFFFFFFFFull;
+        if (go) {
+            const uint8_t *rb = st.ref_bases + st.ref_bases_off[ref] + (s - 1);
+            uint32_t *refs = st.edits + st.ref_edits_off[ref];
+            uint32_t *alts = refs + (L + 1);
+            const bool in_seq = ref == wref;
+            const uint8_t *sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
+            const uint32_t l = b.l_seq[i];
+            uint64_t rp = 0;  // reference_ptr
+            uint32_t qp = 0;  // record_ptr
+            uint32_t edits = 0, top = 0;
+            int err = 0;
+            uint32_t k0 = 0;
+            if (n_ops == 1 && b.cigar[cbase] == (l << 4)) {
+                // the usual read, one M over all its bases: eight bases per step -- one dword of packed sequence against
+                // eight reference bytes, no per-base loads and no exits inside the loop (rows and the reference
+                // slices may be read a few bytes past their end: both buffers carry slack)
+                k0 = 1;
+                for (uint32_t j0 = 0; j0 < l; j0 += 8) {
+                    uint32_t sw;
+                    uint64_t rw;
+                    __builtin_memcpy(&sw, sq + (j0 >> 1), 4);
+                    __builtin_memcpy(&rw, rb + j0, 8);
+                    const uint32_t nb = min(8u, l - j0);
+#pragma unroll
+                    for (uint32_t t = 0; t < 8; t++) {
+                        if (t < nb) {
+                            const uint32_t byte = (sw >> (8 * (t >> 1))) & 0xFFu;
+                            const uint32_t rec = (t & 1u) ? (byte & 0xFu) : (byte >> 4);
+                            const uint32_t rbase = (uint32_t)(rw >> (8 * t)) & 0xFFu;
+                            const uint64_t off = s + j0 + t - wbase;
+                            if (in_seq && off < EW) {
+                                atomicAdd(rbase != rec ? &w_alts[off] : &w_refs[off], 1u);
+                                top = (uint32_t)off + 1;
+                            } else {
+                                atomicAdd(rbase != rec ? &alts[s + j0 + t] : &refs[s + j0 + t], 1u);
+                            }
+                            edits += rbase != rec;
+                        }
+                    }
+                }
+                qp = l;
+            }
+            for (uint32_t k = k0; k < n_ops && !err; k++) {
+                const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu, len = cg >> 4;
+                if (op > 8u) continue;
+                const bool c_ref = (0x18Du >> op) & 1u;  // M D N = X
+                const bool c_seq = (0x193u >> op) & 1u;  // M I S = X
+                if (op == 0u) { // only Kind::Match compares (edits.rs:277)
+                    for (uint32_t j = 0; j < len; j++) {
+                        if (qp >= l) { // alignment.rs:84-87
+                            err = 2;
+                            break;
+                        }
+                        const uint32_t byte = sq[qp >> 1];
+                        const uint32_t rec = (qp & 1u) ? (byte & 0xFu) : (byte >> 4);
+                        const uint32_t rbase = rb[rp];
+                        const uint64_t off = s + rp - wbase;
+                        if (in_seq && off < EW) {
+                            atomicAdd(rbase != rec ? &w_alts[off] : &w_refs[off], 1u);
+                            top = (uint32_t)off + 1;
+                        } else {
+                            atomicAdd(rbase != rec ? &alts[s + rp] : &refs[s + rp], 1u);
+                        }
+                        edits += rbase != rec;
+                        rp += 1;
+                        qp += 1;
+                    }
+                } else {
+                    if (c_seq) {
+                        if ((uint64_t)qp + len > l) {
+                            err = 2;
+                            break;
+                        }
+                        qp += len;
+                    }
+                    if (c_ref) rp += len;
+                }
+            }
+            if (top) atomicMax(&s_whi, top);
+            // NOTE: like the reference, positions visited before an error stay counted;
+            // the error aborts the run anyway.
+            if (err == 2) c[1] += 1;
+            else if (qp != l) c[2] += 1;     // alignment.rs:102-103 (reference side is consumed by construction)
+            else if (edits > 512u) c[3] += 1; // edits.rs:296-300 unwrap()
+            else if (f & 0x40u) atomicAdd(&s_h1[edits], 1u);
+            else atomicAdd(&s_h2[edits], 1u);
         }
-        if (qp != l) { // alignment.rs:102-103 (reference side is consumed by construction)
-            c[2] += 1;
-            continue;
+        __syncthreads();
+        // ---- the window goes to the global arrays (and is zero again for the next tile)
+        const uint32_t whi = s_whi;
+        if (whi) {
+            uint32_t *refs = st.edits + st.ref_edits_off[wref];
+            uint32_t *alts = refs + ((uint64_t)st.ref_len[wref] + 1);
+            for (uint32_t o = threadIdx.x; o < whi; o += blockDim.x) {
+                const uint32_t r = w_refs[o], a = w_alts[o];
+                if (r) {
+                    atomicAdd(&refs[wbase + o], r);
+                    w_refs[o] = 0;
+                }
+                if (a) {
+                    atomicAdd(&alts[wbase + o], a);
+                    w_alts[o] = 0;
+                }
+            }
         }
-        if (edits > 512u) { // edits.rs:296-300 unwrap()
-            c[3] += 1;
-            continue;
-        }
-        if (f & 0x40u)
-            atomicAdd(&s_h1[edits], 1u);
-        else
-            atomicAdd(&s_h2[edits], 1u);
+        __syncthreads(); // the next tile resets the window's anchor and tallies into the same cells
     }
-    __syncthreads();
     for (uint32_t i = threadIdx.x; i < NGSQ_EDITS_BINS; i += blockDim.x) {
         uint32_t v = s_h1[i];
         if (v) atomicAdd(&st.counters[st.off_edits1 + i], (u64)v);
