@@ -40,7 +40,14 @@ typedef unsigned long long u64;
 constexpr uint32_t ST_THREADS = 256;
 constexpr uint32_t ST_WAVES = ST_THREADS / 64;
 constexpr uint32_t ST_W = 1024; // positions of one wave's LDS window
-constexpr uint32_t ST_LIST = 448;  // entries of a wave's list of open ends (a deeper pile walks back instead)
+constexpr uint32_t ST_LIST = 192;  // entries of a wave's list of open ends (a deeper pile walks back instead)
+// The depths of neighbouring positions are a dozen values around the running depth: 64 lanes adding to the
+// histogram word of their depth serialise on those few words (74 % of this kernel's LDS time were same-address
+// conflicts).  So the tally goes to a HOT window first: ST_HOT_BINS bins around the running depth, ST_HOT_REP
+// copies of each (lane & 3 picks the copy), re-anchored when the depth at the start of a pass drifts out of its
+// middle three quarters -- the copies are then summed into the wave's histogram.  Depths outside the window go to the
+// histogram directly, in the same instruction (one address select per lane, no branch).
+constexpr uint32_t ST_HOT_BINS = 64, ST_HOT_REP = 4, ST_HOT = ST_HOT_BINS * ST_HOT_REP;
 #ifndef ST_EXP
 #define ST_EXP 0 // measurement builds only (tools/exp_stream.sh): 1 no look-back, 2 no prefix passes, 3 no histogram atomics, 4 neither
 #endif
@@ -152,10 +159,11 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
     // wave-private window + depth histogram: no block barrier anywhere.  The histogram holds 16-bit
     // counters, two per word (st_hist_words); it is flushed before any counter can reach 2^16 (`since_flush`).
     const uint32_t hw = st_hist_words(a.cov_cap);
-    uint32_t *const win = s_dyn + wave * (ST_W + hw + ST_LIST);
+    uint32_t *const win = s_dyn + wave * (ST_W + hw + ST_HOT + ST_LIST);
     uint32_t *const hist = win + ST_W;
-    uint32_t *const lst = hist + hw;
-    for (uint32_t i = lane; i < ST_W + hw + ST_LIST; i += 64) win[i] = 0;
+    uint32_t *const hot = hist + hw; // [ST_HOT_REP][ST_HOT_BINS]: depth hot_base + o, copy r at hot[r * ST_HOT_BINS + o]
+    uint32_t *const lst = hot + ST_HOT;
+    for (uint32_t i = lane; i < ST_W + hw + ST_HOT + ST_LIST; i += 64) win[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
     const uint64_t t_end = t_begin + per < n_wt ? t_begin + per : n_wt;
     const uint32_t maxspan = *st.batch_span;
 
+    uint32_t hot_base = 0;  // depth of the hot window's first bin (wave-uniform)
     int32_t hist_ref = -1;  // sequence the wave's histogram and bin accumulator belong to
     uint32_t since_flush = 0; // positions tallied since the histogram was last flushed (< 2^16 - ST_PASS)
     u64 zero_run = 0;         // positions of depth 0 skipped in closed form (wave-uniform)
@@ -191,8 +200,22 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
         if (lane == 0 && v) atomicAdd(&bins[bin_q], v);
         lane_bin = 0;
     };
+    auto flush_hot = [&]() { // the copies of each hot bin -> the wave's histogram (lane = bin of the window)
+        uint32_t t = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < ST_HOT_REP; r++) {
+            t += hot[r * ST_HOT_BINS + lane];
+            hot[r * ST_HOT_BINS + lane] = 0;
+        }
+        const uint32_t depth = hot_base + lane;
+        const uint32_t bin = depth <= a.cov_cap ? depth : a.cov_cap + 1;
+        if (t) atomicAdd(&hist[bin < hw ? bin : bin - hw], bin < hw ? t : t << 16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     auto flush_hist = [&]() {
         if (hist_ref < 0) return;
+        flush_hot();
         u64 *dst = a.hist + (u64)hist_ref * nb;
         for (uint32_t i = lane; i < hw; i += 64) {
             const uint32_t v = hist[i];
@@ -416,6 +439,15 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                 }
 #pragma unroll
                 for (uint32_t k = 1; k < PL; k++) x[k] += x[k - 1];
+                // the hot window follows the running depth: keep the depth at the start of the pass off its outer eighths
+                if (carry - hot_base - ST_HOT_BINS / 8 >= 3 * ST_HOT_BINS / 4) { // wave-uniform
+                    const uint32_t nb0 = carry > ST_HOT_BINS / 2 ? carry - ST_HOT_BINS / 2 : 0u;
+                    if (nb0 != hot_base) { // (shallow stretches keep the window at depth 0)
+                        flush_hot();
+                        hot_base = nb0;
+                    }
+                }
+                const uint32_t hot_lane = (uint32_t)(hot - hist) + (lane & (ST_HOT_REP - 1)) * ST_HOT_BINS - hot_base;
                 const uint32_t inc = st_wave_scan(x[PL - 1]);
                 const uint32_t before = carry + inc - x[PL - 1];
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -443,8 +475,9 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                     // for all of them would serialise just the same.
                     lane_zero += i < len && depth == 0;
                     const uint32_t one = i < len && depth != 0 ? 1u : 0u;
-                    const uint32_t word = one ? (bin < hw ? bin : bin - hw) : lane;
-                    if (ST_EXP != 3) atomicAdd(&hist[word], bin < hw ? one : one << 16);
+                    const bool in_hot = depth - hot_base < ST_HOT_BINS;
+                    const uint32_t word = !one ? lane : in_hot ? hot_lane + depth : bin < hw ? bin : bin - hw;
+                    if (ST_EXP != 3) atomicAdd(&hist[word], in_hot || bin < hw ? one : one << 16);
                     lsum += i < len ? depth : 0u;
                 }
                 if (in_acc) {
@@ -577,7 +610,7 @@ hipError_t launch_cov_stream(const LaunchInfo &li, const DeviceState &st, const 
     const uint64_t n_wt = (b.n + CS_TILE - 1) / CS_TILE;
     hipLaunchKernelGGL(k_cov_plan_tiles, dim3((uint32_t)((n_wt + 255) / 256)), dim3(256), 0, s, st, b, a);
     hipLaunchKernelGGL(k_cov_plan_refs, dim3((st.n_refs + 255) / 256), dim3(256), 0, s, st, a);
-    const size_t lds = (size_t)ST_WAVES * (ST_W + st_hist_words(a.cov_cap) + ST_LIST) * sizeof(uint32_t);
+    const size_t lds = (size_t)ST_WAVES * (ST_W + st_hist_words(a.cov_cap) + ST_HOT + ST_LIST) * sizeof(uint32_t);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cov_stream),
