@@ -407,3 +407,28 @@ def test_gpus_flag_workers_share_one_file(ngs, gpu_lib, oracle_mod, tmp_path):
     got = json.load(open(tmp_path / "wu" / "gu.bam.results.json"))
     json_equal(got["coverage"], want["coverage"])
     json_equal(got["general"], want["general"])
+
+
+@pytest.mark.gpu
+def test_baseline_config_0_general_only(ngs, gpu_lib, oracle_mod, tmp_path):
+    """BASELINE.json configs[0] verbatim: `ngs qc` general-metrics-only (--only General) on a 10k-record 150 bp
+    single-reference BAM (one @SQ chr1 LN:248956422, the synthetic workload's records written as a real BGZF BAM +
+    BAI by ngsq_synth_write_bam), host ingest and device ingest, against the oracle on the same records."""
+    import ctypes as C
+    n, L = 10_000, 248_956_422
+    cfg = host.synth_config(n, ref_len=L, n_refs=1)
+    bam = str(tmp_path / "cfg0.bam")
+    assert gpu_lib.ngsq_synth_write_bam(C.byref(cfg), bam.encode(), n, 6, 2) == 0
+    hb = host.synth_host_batch(cfg, 0, n, gpu_lib)
+    o = oracle_mod.Oracle([L], [1], facets=ffi.FACET_GENERAL, max_read_len=1024, gc_seed=0x4E4753)
+    o.process_batch(hb)
+    o.finalize()
+    want = o.results(["chr1"])
+    assert want["general"]["records"]["total"] == n and all(want[k] is None for k in want if k != "general")
+    for ingest in ("host", "device"):
+        out = tmp_path / ingest
+        r = run(ngs, "qc", bam, GENOME, "--only", "General", "-o", str(out), "--ingest", ingest)
+        assert r.returncode == 0, r.stderr
+        assert "Processed 10,000 records in the first pass." in r.stderr
+        assert "No facets specified that require second pass. Skipping..." in r.stderr
+        json_equal(json.load(open(out / "cfg0.bam.results.json")), want)

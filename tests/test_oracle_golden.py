@@ -28,6 +28,37 @@ def test_oracle_matches_hand_golden(oracle_mod):
     json_equal(got, g["expected"])
 
 
+BASE_CODE = {"A": 1, "C": 2, "G": 4, "T": 8, "N": 15}  # BAM 4-bit codes, one per byte (ngsq_config.ref_bases)
+
+
+def load_gold_edits():
+    with open(os.path.join(os.path.dirname(GOLD), "hand_edits_multiseq.json")) as f:
+        g = json.load(f)
+    g["config"]["ref_bases"] = [np.array([BASE_CODE[c] for c in s], dtype=np.uint8) for s in g["config"]["ref_bases"]]
+    return g
+
+
+def test_oracle_matches_hand_golden_edits_multiseq(oracle_mod):
+    """Second hand-derived case: the Edits walk over M I D N S H P = X with a mismatch under `=`, the read-1 / read-2
+    split, a VAF on the f32 truncation edge (53/100 -> bin 52), two covered sequences + a non-primary one + one
+    without records, a position deeper than the coverage capacity (tests/golden/make_hand_goldens_edits.py)."""
+    g = load_gold_edits()
+    cfg = g["config"]
+    for cut in (None, 1000):   # one batch, and the same records in two (state carried across batches)
+        o = oracle_mod.Oracle(cfg["ref_len"], cfg["ref_is_primary"], facets=cfg["facets"], bin_size=cfg["bin_size"],
+                              max_read_len=cfg["max_read_len"], ref_bases=cfg["ref_bases"])
+        hb = batch_from_records(g["records"])
+        if cut is None:
+            o.process_batch(hb)
+        else:
+            o.process_batch(hb.slice(0, cut))
+            o.process_batch(hb.slice(cut, hb.n))
+        o.finalize()
+        json_equal(o.results(cfg["ref_names"]), g["expected"])
+    text = o.results_json(cfg["ref_names"])
+    assert '"10x": 0.9803922,' in text and '"chrB": 88.12' not in text and "88.12" in text
+
+
 def test_json_text_layout(oracle_mod):
     """serde_json pretty layout: two-space indent, `"k": v`, no trailing newline,
     shortest round-trip floats with a trailing .0 on integers (results.rs:55)."""

@@ -54,6 +54,23 @@ def test_hand_golden(gpu_lib, oracle_mod):
     json_equal(gpu.results(cfg["ref_names"]), g["expected"])
 
 
+@pytest.mark.parametrize("sorted_input", [False, True])
+def test_hand_golden_edits_multiseq(gpu_lib, sorted_input):
+    """The second hand-derived case through the HIP path: Edits over every CIGAR operation, multi-sequence Coverage
+    (arrays and streamed), a pileup deeper than the capacity, the f32 VAF edge (make_hand_goldens_edits.py)."""
+    from tests.test_oracle_golden import load_gold_edits
+    g = load_gold_edits()
+    cfg = g["config"]
+    hb = batch_from_records(g["records"])
+    gpu = host.QcContext(cfg["ref_len"], cfg["ref_is_primary"], facets=cfg["facets"], bin_size=cfg["bin_size"],
+                         max_read_len=cfg["max_read_len"], ref_bases=cfg["ref_bases"], sorted_input=sorted_input, lib=gpu_lib)
+    gpu.process_batch(hb.slice(0, 1000))
+    gpu.process_batch(hb.slice(1000, hb.n))
+    gpu.finalize()
+    json_equal(gpu.results(cfg["ref_names"]), g["expected"])
+    gpu.close()
+
+
 @pytest.mark.parametrize("on_device", [False, True])
 def test_synthetic_fixed_150bp(gpu_lib, oracle_mod, on_device):
     """configs[1]/[2] shape at a size the oracle finishes in seconds."""
