@@ -271,6 +271,7 @@ void reader_main(DeviceIngest *d, std::string path) {
                     uint32_t bs = 0;
                     for (size_t q = 12; q + 6 <= 12 + (size_t)xlen;) {
                         const uint32_t sl = bgzf_rd16(h + q + 2);
+                        if (q + 4 + sl > 12 + (size_t)xlen) break; // corrupt: the next bgzf_split reports it
                         if (h[q] == 'B' && h[q + 1] == 'C' && sl == 2) bs = bgzf_rd16(h + q + 4) + 1;
                         q += 4 + sl;
                     }
@@ -576,6 +577,7 @@ int find_block_start(FILE *f, uint64_t from, uint64_t file_size, uint64_t *out, 
         if (p + 12 + xlen > buf.size()) return false;
         for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {
             const uint32_t slen = bgzf_rd16(buf.data() + q + 2);
+            if (q + 4 + slen > p + 12 + xlen) return false;
             if (buf[q] == 'B' && buf[q + 1] == 'C' && slen == 2) {
                 *bsize = bgzf_rd16(buf.data() + q + 4) + 1;
                 return *bsize >= 12 + xlen + 8;

@@ -90,8 +90,10 @@ int inflate_more(ngsq_bam *b, size_t want_compressed) {
         if (n - p < 12 + (size_t)xlen) break;
         uint32_t bsize = 0;
         bool found = false;
-        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) { // a subfield (SI1 SI2 SLEN data) must end inside the extra field
             const uint32_t slen = rd16(c + q + 2);
+            if (q + 4 + slen > p + 12 + xlen)
+                return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: corrupt BGZF extra field", b->path.c_str());
             if (c[q] == 'B' && c[q + 1] == 'C' && slen == 2) {
                 bsize = (uint32_t)rd16(c + q + 4) + 1;
                 found = true;

@@ -33,8 +33,12 @@ inline bool bgzf_split(const uint8_t *c, size_t n, std::vector<BgzfBlock> *block
         if (n - p < 12 + (size_t)xlen) break;
         uint32_t bsize = 0;
         bool found = false;
-        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) { // a subfield (SI1 SI2 SLEN data) must end inside the extra field
             const uint32_t slen = bgzf_rd16(c + q + 2);
+            if (q + 4 + slen > p + 12 + xlen) {
+                *err = "corrupt BGZF extra field";
+                return false;
+            }
             if (c[q] == 'B' && c[q + 1] == 'C' && slen == 2) {
                 bsize = bgzf_rd16(c + q + 4) + 1;
                 found = true;

@@ -236,17 +236,18 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     c->stream_cov = c->cfg.sorted_input && nd;
     if (c->stream_cov) {
         const uint64_t nr4 = round_up(nr ? nr : 1, 4);
-        CTX_TRY(hipMalloc((void **)&c->d_stream_u32, (6 * nr4 + 4) * 4));
+        CTX_TRY(hipMalloc((void **)&c->d_stream_u32, (7 * nr4 + 4) * 4));
         CTX_TRY(hipMalloc((void **)&c->d_last_key, 8));
         CTX_TRY(hipMalloc((void **)&c->d_chunk_flags, c->n_chunks ? c->n_chunks : 1));
         st.end_acc = c->d_stream_u32;
-        st.batch_span = c->d_stream_u32 + 6 * nr4;
+        st.batch_span = c->d_stream_u32 + 7 * nr4;
         CovStreamArgs &sa = c->csa;
         sa.prev_end = c->d_stream_u32 + nr4;
         sa.plan_a = c->d_stream_u32 + 2 * nr4;
         sa.plan_z = c->d_stream_u32 + 3 * nr4;
         sa.plan_h = c->d_stream_u32 + 4 * nr4;
         sa.plan_t = c->d_stream_u32 + 5 * nr4;
+        sa.guard_until = c->d_stream_u32 + 6 * nr4;
         sa.last_key = c->d_last_key;
         sa.chunk_flags = c->d_chunk_flags;
         sa.hist = c->d_cov_hist;
@@ -255,7 +256,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         sa.bin_size = c->cfg.bin_size;
         sa.cov_cap = c->cfg.cov_cap;
         sa.head_guard = c->cfg.cov_head_guard;
-        CTX_TRY(hipMemsetAsync(c->d_stream_u32, 0, (6 * nr4 + 4) * 4, c->stream));
+        CTX_TRY(hipMemsetAsync(c->d_stream_u32, 0, (7 * nr4 + 4) * 4, c->stream));
         CTX_TRY(hipMemsetAsync(sa.plan_a, 0xFF, nr4 * 4, c->stream));
         CTX_TRY(hipMemsetAsync(c->d_last_key, 0, 8, c->stream));
         CTX_TRY(hipMemsetAsync(c->d_chunk_flags, 0, c->n_chunks ? c->n_chunks : 1, c->stream));
@@ -802,7 +803,7 @@ int ngsq_reset(ngsq_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->d_td, 0, c->n_td * 8, c->stream));
     if (c->stream_cov) {
         const uint64_t nr4 = round_up(c->st.n_refs ? c->st.n_refs : 1, 4);
-        HIP_TRY(c, hipMemsetAsync(c->d_stream_u32, 0, (6 * nr4 + 4) * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_stream_u32, 0, (7 * nr4 + 4) * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->csa.plan_a, 0xFF, nr4 * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_last_key, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_chunk_flags, 0, c->n_chunks ? c->n_chunks : 1, c->stream));

@@ -78,7 +78,7 @@ struct ngsq_ctx {
     bool stream_cov = false;
     uint32_t *d_cov_end = nullptr;
     uint64_t cov_end_cap = 0;
-    uint32_t *d_stream_u32 = nullptr; // end_acc | prev_end | plan_a | plan_z | plan_h | plan_t (n_refs each) | batch_span
+    uint32_t *d_stream_u32 = nullptr; // end_acc | prev_end | plan_a | plan_z | plan_h | plan_t | guard_until (n_refs each) | batch_span
     unsigned long long *d_last_key = nullptr;
     uint8_t *d_chunk_flags = nullptr;
     ngsq::CovStreamArgs csa{};

@@ -100,10 +100,21 @@ __global__ __launch_bounds__(256) void k_cov_plan_refs(DeviceState st, CovStream
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= st.n_refs) return;
     const uint32_t pa = a.plan_a[r], pz = a.plan_z[r], prev = a.prev_end[r];
+    const uint32_t acc = st.end_acc[r];
+    // Head guard of a shard behind the first: records of the shard in front may cover the first head_guard positions
+    // after this context's first record on the sequence, so they stay on the exchanged depth array -- in whichever
+    // batch they come.  The bound is fixed when the sequence is first met: from the first streamable start, or (a
+    // first batch too small to stream anything) from the largest end seen, which lies beyond every start so far.
+    uint32_t guard = a.guard_until[r];
+    if (a.head_guard && guard == 0 && (pa != CS_NONE || acc != 0)) {
+        const uint64_t g = (uint64_t)(pa != CS_NONE ? pa : acc) + a.head_guard;
+        guard = g > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)g;
+        a.guard_until[r] = guard;
+    }
     uint32_t H = CS_NONE, T = CS_NONE;
     if (pa != CS_NONE && pz > pa) {
         uint64_t base = pa > prev + 1 ? pa : (uint64_t)prev + 1; // entry `prev` may hold an earlier batch's -1
-        if (prev == 0 && a.head_guard) base = (uint64_t)pa + a.head_guard > base ? (uint64_t)pa + a.head_guard : base;
+        if (guard > base) base = guard;
         const uint64_t h = (base + COV_CHUNK - 1) / COV_CHUNK * COV_CHUNK;
         const uint64_t lim = pz < (uint64_t)st.ref_len[r] + 1 ? pz : (uint64_t)st.ref_len[r] + 1;
         const uint64_t tt = lim / COV_CHUNK * COV_CHUNK;
@@ -114,7 +125,6 @@ __global__ __launch_bounds__(256) void k_cov_plan_refs(DeviceState st, CovStream
     }
     a.plan_h[r] = H;
     a.plan_t[r] = T;
-    const uint32_t acc = st.end_acc[r];
     a.prev_end[r] = acc > prev ? acc : prev;
     a.plan_a[r] = CS_NONE; // ready for the next batch
     a.plan_z[r] = 0;

@@ -131,6 +131,7 @@ struct CovStreamArgs {
     uint32_t *plan_a, *plan_z;       // [n_refs] first start of the first / next start after the last streamable tile
     uint32_t *plan_h, *plan_t;       // [n_refs] streamed position range [H, T), chunk-aligned; CS_NONE = none
     uint32_t *prev_end;              // [n_refs] largest exclusive end of the batches before this one
+    uint32_t *guard_until;           // [n_refs] head guard: no position below this is streamed (0 = sequence not met yet)
     unsigned long long *last_key;    // [1] sort key of the last record of the previous batch
     uint8_t *chunk_flags;            // [n_chunks] 1 = finished by the streaming pass: the teardown scan skips it
     unsigned long long *hist;        // as CovScanArgs

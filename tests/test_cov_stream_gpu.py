@@ -104,6 +104,10 @@ def test_head_guard_keeps_the_first_positions_on_the_array(gpu_lib, oracle_mod):
     f0 = run_sorted(oracle_mod, gpu_lib, [hb], [L], bin_size=50_000, max_read_len=150)
     f1 = run_sorted(oracle_mod, gpu_lib, [hb], [L], bin_size=50_000, max_read_len=150, guard=100_000)
     assert f0[:20].sum() >= 18 and f1[:24].sum() == 0 and f1[26:].sum() == f0[26:].sum()
+    # the guard holds in whichever batch the first positions come: a first batch too small to stream anything
+    # (it used to be consumed there) and the rest in further batches
+    f2 = run_sorted(oracle_mod, gpu_lib, split(hb, [40, 300, 50_000]), [L], bin_size=50_000, max_read_len=150, guard=100_000)
+    assert f2[:24].sum() == 0 and f2[27:].sum() >= f0[27:].sum() - 3
 
 
 def test_unsorted_input_is_refused(gpu_lib):
