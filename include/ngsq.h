@@ -44,6 +44,9 @@ extern "C" {
 #define NGSQ_ERR_BUFFER_TOO_SMALL (-6)
 #define NGSQ_ERR_UNSUPPORTED (-7)
 #define NGSQ_ERR_UNSORTED (-8)         /* sorted_input was promised and a record broke the order */
+#define NGSQ_ERR_LIMIT (-9)            /* an implementation limit, not a malformed input: a read longer than
+                                          max_read_len (<= NGSQ_MAX_READ_LEN_LIMIT); the reference has no such limit
+                                          (quality_scores.rs:18 keeps a map per position) */
 
 /* ---- facets (names: `name()` of each facet under src/qc/record_based, sequence_based) ---- */
 #define NGSQ_FACET_GENERAL 0x01u         /* "General"          general.rs:23        */
@@ -205,7 +208,7 @@ typedef struct ngsq_gc_metrics {
 typedef struct ngsq_error_counts {
     uint64_t missing_reference_id;  /* general.rs:81-83 unwrap() on None                     */
     uint64_t bad_quality_score;     /* score > 93: noodles decode error / quality_scores.rs:45 */
-    uint64_t read_too_long;         /* l_seq > max_read_len (implementation limit)          */
+    uint64_t read_too_long;         /* l_seq > max_read_len: implementation limit -> NGSQ_ERR_LIMIT */
     uint64_t edits_bad_reference;   /* edits.rs:242-261 slice out of range / no sequence     */
     uint64_t edits_record_short;    /* alignment.rs:84-87 "consume a record base"            */
     uint64_t edits_not_consumed;    /* alignment.rs:100-104 not fully consumed               */
@@ -285,7 +288,8 @@ int ngsq_process_batch(ngsq_ctx *ctx, const ngsq_batch *batch, uint32_t pass_mas
 
 /* Sequence-facet teardown (coverage.rs:182-262, edits.rs:305-344) for every
  * sequence that saw a record, then copy all integer results to the host.
- * Returns NGSQ_ERR_MALFORMED_RECORD when any ngsq_error_counts field is set. */
+ * Returns NGSQ_ERR_MALFORMED_RECORD when any ngsq_error_counts field is set (NGSQ_ERR_LIMIT when the only one
+ * is read_too_long). */
 int ngsq_finalize(ngsq_ctx *ctx);
 
 /* zero every accumulator so the context can scan another file */

@@ -5,6 +5,7 @@
 // (src/qc/command.rs:288-418): process (batches) -> summarize/teardown ->
 // aggregate.  There is NO CPU fallback: without a usable GPU ngsq_create fails
 // with NGSQ_ERR_NO_DEVICE.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -332,7 +333,33 @@ static hipEvent_t get_event(ngsq_ctx *c) {
     return e;
 }
 
+// roctx ranges with the names of ngsq_kernel_timing around the same launches, so that a rocprofv3 --marker-trace
+// lines up with the library's own timing table.  The marker library is looked up once at run time; without it
+// (or without a profiler attached) the calls cost nothing worth measuring.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() {
+    static const Roctx r;
+    return r;
+}
+} // namespace
+
 ngsq::KernelTimer::KernelTimer(ngsq_ctx *c_, int id_, uint64_t bytes, hipStream_t stream) : c(c_), id(id_), s(stream ? stream : c_->stream) {
+    if (roctx().push) (void)roctx().push(KERNEL_NAMES[id]);
     c->timing[id].launches += 1;
     c->timing[id].algo_bytes += bytes;
     if (c->cfg.timing) {
@@ -342,6 +369,7 @@ ngsq::KernelTimer::KernelTimer(ngsq_ctx *c_, int id_, uint64_t bytes, hipStream_
     }
 }
 ngsq::KernelTimer::~KernelTimer() {
+    if (roctx().pop) (void)roctx().pop();
     if (c->cfg.timing) {
         (void)hipEventRecord(b, s);
         c->pending.push_back({id, a, b});
@@ -725,6 +753,15 @@ int ngsq_finalize(ngsq_ctx *c) {
                     "create the context without sorted_input for such input",
                     c->h_counters[C_COV_UNSORTED]);
     const unsigned long long *err = c->h_counters.data() + C_ERR;
+    {
+        bool other = c->h_counters[C_FEAT_ERR_REF] || c->h_counters[C_FEAT_ERR_POS];
+        for (int k = 0; k < 8; k++) other = other || (k != E_READ_TOO_LONG && err[k]);
+        if (err[E_READ_TOO_LONG] && !other)
+            return fail(c, NGSQ_ERR_LIMIT,
+                        "implementation limit: %llu read(s) longer than max_read_len = %u bases (this library handles reads of up to "
+                        "%u bases; the reference has no such limit)",
+                        err[E_READ_TOO_LONG], c->cfg.max_read_len, (unsigned)NGSQ_MAX_READ_LEN_LIMIT);
+    }
     for (int k = 0; k < 8; k++)
         if (err[k])
             return fail(c, NGSQ_ERR_MALFORMED_RECORD,

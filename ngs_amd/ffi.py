@@ -24,6 +24,7 @@ ERR_STATE = -5
 ERR_BUFFER_TOO_SMALL = -6
 ERR_UNSUPPORTED = -7
 ERR_UNSORTED = -8
+ERR_LIMIT = -9
 
 FACET_GENERAL = 0x01
 FACET_TEMPLATE_LENGTH = 0x02

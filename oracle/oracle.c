@@ -810,6 +810,15 @@ int orc_finalize(orc_ctx *c) {
     c->finalized = 1;
     c->cpu_seconds += now_seconds() - t0;
     if (any_error(&c->errors)) {
+        /* a read longer than the table of this build is an implementation limit of the HIP path (mirrored here so that
+           the two report alike), not a condition of the reference: quality_scores.rs:18 keeps a map per position */
+        ngsq_error_counts e = c->errors;
+        const uint64_t too_long = e.read_too_long;
+        e.read_too_long = 0;
+        if (too_long && !any_error(&e)) {
+            set_err(c, "implementation limit: read(s) longer than max_read_len");
+            return NGSQ_ERR_LIMIT;
+        }
         set_err(c, "malformed record(s): the reference would abort this run");
         return NGSQ_ERR_MALFORMED_RECORD;
     }

@@ -167,7 +167,7 @@ class Oracle:
 
     def finalize(self, allow_malformed: bool = False) -> int:
         rc = self.lib.orc_finalize(self._ctx)
-        if rc == ffi.ERR_MALFORMED_RECORD and allow_malformed:
+        if rc in (ffi.ERR_MALFORMED_RECORD, ffi.ERR_LIMIT) and allow_malformed:
             return rc
         if rc:
             raise OracleError(rc, self.lib.orc_last_error(self._ctx).decode())

@@ -140,6 +140,12 @@ def test_fixed_pitch_row_longer_than_table(gpu_lib, oracle_mod):
     fixed2 = to_fixed_stride(random_batch(rng, 500, [5000], max_len=80, min_len=70, weird=False))
     g, _ = run_both(oracle_mod, gpu_lib, [fixed2], [5000], max_read_len=64, facets=ffi.FACET_QUALITY_SCORE)
     assert g.error_counts()["read_too_long"] == 500
+    # ... reported as what it is: a limit of this implementation (the reference keeps a map per position), not a malformed input
+    with host.QcContext([5000], lib=gpu_lib, max_read_len=64, facets=ffi.FACET_QUALITY_SCORE) as c:
+        c.process_batch(fixed2)
+        with pytest.raises(host.NgsqError) as ei:
+            c.finalize()
+        assert ei.value.code == ffi.ERR_LIMIT and "implementation limit: 500 read(s) longer than max_read_len = 64" in ei.value.message
 
 
 def test_many_batches_equal_one_batch(gpu_lib, oracle_mod):
