@@ -27,6 +27,32 @@ void free_exchange_scratch(void *p); // exchange.cpp
 
 static thread_local std::string g_err;
 
+// roctx ranges with the names of ngsq_kernel_timing around the same launches, so that a rocprofv3 --marker-trace
+// lines up with the library's own timing table.  The marker library is looked up once at run time; without it
+// (or without a profiler attached) the calls cost nothing worth measuring.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() {
+    static const Roctx r;
+    return r;
+}
+} // namespace
+
+
 static int fail(ngsq_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -332,31 +358,6 @@ static hipEvent_t get_event(ngsq_ctx *c) {
     (void)hipEventCreate(&e);
     return e;
 }
-
-// roctx ranges with the names of ngsq_kernel_timing around the same launches, so that a rocprofv3 --marker-trace
-// lines up with the library's own timing table.  The marker library is looked up once at run time; without it
-// (or without a profiler attached) the calls cost nothing worth measuring.
-namespace {
-struct Roctx {
-    int (*push)(const char *) = nullptr;
-    int (*pop)() = nullptr;
-    Roctx() {
-        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
-            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
-                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
-                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
-                if (push && pop) return;
-                push = nullptr;
-                pop = nullptr;
-            }
-        }
-    }
-};
-const Roctx &roctx() {
-    static const Roctx r;
-    return r;
-}
-} // namespace
 
 ngsq::KernelTimer::KernelTimer(ngsq_ctx *c_, int id_, uint64_t bytes, hipStream_t stream) : c(c_), id(id_), s(stream ? stream : c_->stream) {
     if (roctx().push) (void)roctx().push(KERNEL_NAMES[id]);
