@@ -270,6 +270,32 @@ def main() -> int:
     return rc
 
 
+def effective_cores() -> int:
+    """Cores this process may really use: the cgroup's CPU quota (cpu.max) when there is one, else the online count.
+    (The MI355X boxes of this pool show 256 online CPUs under a quota of 16.)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def guarded(fn, *a):
     try:
         return fn(*a)
@@ -387,7 +413,7 @@ def cpu_baseline(lib, host, ffi, scfg, sample: int, max_len: int):
             o.close()
         rates.sort()
         # all cores: threads (the C calls release the GIL), private state each, disjoint contiguous slices
-        cores = os.cpu_count() or 1
+        cores = effective_cores()
         workers = max(1, min(cores, 64))
         per = max(100_000, min(1_000_000, sample // 2))
 
@@ -410,7 +436,7 @@ def cpu_baseline(lib, host, ffi, scfg, sample: int, max_len: int):
                 "scan_only_value": round(sample / t_scan, 1),
                 "scan_only_runs_median_of_3": round(rates[1], 1),
                 "all_cores": {"value": round(workers * per / t_par, 1), "unit": "records/s", "cores": workers,
-                              "host_cores": cores,
+                              "host_cpus_online": os.cpu_count(), "cpu_quota_cores": cores,
                               "note": ("NOT reference behaviour (the reference is single-threaded): %d threads x %d records "
                                        "each with private facet state, wall clock incl. batch generation, no merge and no "
                                        "teardown" % (workers, per))}}
@@ -477,7 +503,7 @@ def leg_file(lib, host, ffi, args):
     n = args.file_records
     tmp = tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
     bam = os.path.join(tmp, "synth.bam")
-    out = {"records": n, "zlib_level": args.file_level, "host_cores": os.cpu_count()}
+    out = {"records": n, "zlib_level": args.file_level, "host_cores": effective_cores()}
     try:
         fcfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
         t0 = time.perf_counter()

@@ -106,7 +106,9 @@ def test_head_guard_keeps_the_first_positions_on_the_array(gpu_lib, oracle_mod):
     assert f0[:20].sum() >= 18 and f1[:24].sum() == 0 and f1[26:].sum() == f0[26:].sum()
     # the guard holds in whichever batch the first positions come: a first batch too small to stream anything
     # (it used to be consumed there) and the rest in further batches
-    f2 = run_sorted(oracle_mod, gpu_lib, split(hb, [40, 300, 50_000]), [L], bin_size=50_000, max_read_len=150, guard=100_000)
+    cuts = [0, 40, 300, 50_000, hb.n]
+    parts = [hb.slice(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    f2 = run_sorted(oracle_mod, gpu_lib, parts, [L], bin_size=50_000, max_read_len=150, guard=100_000)
     assert f2[:24].sum() == 0 and f2[27:].sum() >= f0[27:].sum() - 3
 
 
