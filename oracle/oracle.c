@@ -276,11 +276,11 @@ static void general_process(orc_ctx *c, const orc_record *r) {
                 } else {
                     m->mate_mapped += 1;
                     /* :81-83 reference_sequence_id().unwrap(): None (-1) panics */
-                    if (r->ref_id < 0 || r->mate_ref_id < 0) {
+                    if (r->ref_id < 0 || r->mate_ref_id < 0) { /* [N1] */
                         c->errors.missing_reference_id += 1;
                     } else if (r->ref_id != r->mate_ref_id) {
                         m->mate_reference_sequence_id_mismatch += 1;
-                        /* :88-91 missing MAPQ (255) maps to MISSING = 255 */
+                        /* :88-91 [N2] missing MAPQ (255) maps to MISSING = 255 */
                         uint8_t mapq = r->mapq;
                         if (mapq >= 5) m->mate_reference_sequence_id_mismatch_hq += 1;
                     }
@@ -396,7 +396,7 @@ static void quality_process(orc_ctx *c, const orc_record *r) {
 
 /* ------------------------------------------ pass 2: query + Coverage + Edits */
 
-/* noodles bam::Reader::query over Region(name, 1..=L) (command.rs:369-373):
+/* [N3] [N4] [N5] (oracle.h) noodles bam::Reader::query over Region(name, 1..=L) (command.rs:369-373):
  * a record is yielded iff reference_sequence_id == id, alignment_start and
  * alignment_end are Some, and [start, end] intersects [1, L].
  * alignment_end = start + span - 1, None when that is 0. */

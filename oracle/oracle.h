@@ -17,7 +17,10 @@
  *     reference is Rust, which cannot be built here (no cargo/rustc, crates
  *     not vendored, no network): for them this oracle is PARITY UNPINNED --
  *     a line-by-line restatement checked against hand-derived goldens
- *     (tests/golden/hand_six_records.json) for the arithmetic, and, for what the
+ *     (tests/golden/hand_six_records.json: the record facets and one covered
+ *     sequence; tests/golden/hand_edits_multiseq.json: the Edits walk over every
+ *     CIGAR operation, several sequences, a pileup beyond the capacity, the f32
+ *     VAF edge) for the arithmetic, and, for what the
  *     reference's SOURCE fixes without running it, against fixtures derived from
  *     that source by scripts committed next to them (tests/golden/make_*.py):
  *     the shape of the Results document (field names, declaration order, types),
@@ -25,7 +28,31 @@
  *   - The record decode the reference delegates to noodles-bam 0.28.0 /
  *     noodles-sam 0.25.0 (Cargo.lock:902-905,1057-1059) is not in the tree;
  *     the accessor semantics used here are restated from the SAM/BAM
- *     specification and listed in DESIGN.md.
+ *     specification.  ALL of them, in one place (each is UNVERIFIED against the
+ *     crate's source, which is not in this container; oracle.c marks the lines that
+ *     rely on one with its tag):
+ *       [N1] reference_sequence_id() / mate_reference_sequence_id(): None for -1
+ *            (general.rs:81-83 unwrap()s them: counted as missing_reference_id);
+ *       [N2] mapping_quality(): None for 255; general.rs:88-95 maps None to 255,
+ *            so a missing MAPQ counts as high quality;
+ *       [N3] alignment_start(): None for pos -1, else pos + 1 (1-based);
+ *       [N4] alignment_end() = start + span - 1 with span = sum of the lengths of
+ *            M D N = X; None when that is 0 (start 1, no reference-consuming op);
+ *       [N5] Reader::query(region = whole sequence) yields a record iff its
+ *            reference id is the sequence, start and end are Some and [start, end]
+ *            meets [1, L]: a placed read without CIGAR (span 0) at start >= 2 is
+ *            yielded and covers nothing; a read starting beyond L is not;
+ *       [N6] quality scores: BAM's 0xFF-filled QUAL decodes to an EMPTY score list
+ *            (no increments, quality_scores.rs:38); a score above 93 is a decode
+ *            error that aborts the run (counted as bad_quality_score);
+ *       [N7] sequence bases decode to the 16 codes "=ACMGRSVTWYHKDBN"; GC Content
+ *            counts C/G, A/T and "other" on them (gc_content.rs:77-87);
+ *       [N8] CIGAR op codes 0..8 = MIDNSHP=X; a code above 8 is a decode error
+ *            (counted as bad_cigar_op);
+ *       [N9] FASTA bases compare as upper-case A C G T N codes (edits.rs:265:
+ *            Base::try_from; the synthetic references are upper case).
+ *     The hand goldens and the synthetic workloads stay away from the corner cases
+ *     of [N4] and [N5] (span 0, start beyond L) except where a test names them.
  */
 #ifndef ORC_ORACLE_H
 #define ORC_ORACLE_H
