@@ -40,14 +40,20 @@ typedef unsigned long long u64;
 constexpr uint32_t ST_THREADS = 256;
 constexpr uint32_t ST_WAVES = ST_THREADS / 64;
 constexpr uint32_t ST_W = 1024; // positions of one wave's LDS window
-constexpr uint32_t ST_LIST = 192;  // entries of a wave's list of open ends (a deeper pile walks back instead)
+#ifndef ST_LIST_N
+#define ST_LIST_N 232
+#endif
+#ifndef ST_HOT_BINS_N
+#define ST_HOT_BINS_N 64
+#endif
+constexpr uint32_t ST_LIST = ST_LIST_N;  // entries of a wave's list of open ends (a deeper pile walks back instead)
 // The depths of neighbouring positions are a dozen values around the running depth: 64 lanes adding to the
 // histogram word of their depth serialise on those few words (74 % of this kernel's LDS time were same-address
 // conflicts).  So the tally goes to a HOT window first: ST_HOT_BINS bins around the running depth, ST_HOT_REP
 // copies of each (lane & 3 picks the copy), re-anchored when the depth at the start of a pass drifts out of its
 // middle three quarters -- the copies are then summed into the wave's histogram.  Depths outside the window go to the
 // histogram directly, in the same instruction (one address select per lane, no branch).
-constexpr uint32_t ST_HOT_BINS = 64, ST_HOT_REP = 4, ST_HOT = ST_HOT_BINS * ST_HOT_REP;
+constexpr uint32_t ST_HOT_BINS = ST_HOT_BINS_N, ST_HOT_REP = 4, ST_HOT = ST_HOT_BINS * ST_HOT_REP;
 #ifndef ST_EXP
 #define ST_EXP 0 // measurement builds only (tools/exp_stream.sh): 1 no look-back, 2 no prefix passes, 3 no histogram atomics, 4 neither
 #endif
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
     const uint32_t hw = st_hist_words(a.cov_cap);
     uint32_t *const win = s_dyn + wave * (ST_W + hw + ST_HOT + ST_LIST);
     uint32_t *const hist = win + ST_W;
-    uint32_t *const hot = hist + hw; // [ST_HOT_REP][ST_HOT_BINS]: depth hot_base + o, copy r at hot[r * ST_HOT_BINS + o]
+    uint32_t *const hot = hist + hw; // [ST_HOT_BINS][ST_HOT_REP]: depth hot_base + o, copy r at hot[o * ST_HOT_REP + r] (the copies of a
+                                     // bin lie in neighbouring LDS banks: copy-major they shared one bank and serialised there instead)
     uint32_t *const lst = hot + ST_HOT;
     for (uint32_t i = lane; i < ST_W + hw + ST_HOT + ST_LIST; i += 64) win[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -211,12 +218,14 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
         lane_bin = 0;
     };
     auto flush_hot = [&]() { // the copies of each hot bin -> the wave's histogram (lane = bin of the window)
-        uint32_t t = 0;
-#pragma unroll
-        for (uint32_t r = 0; r < ST_HOT_REP; r++) {
-            t += hot[r * ST_HOT_BINS + lane];
-            hot[r * ST_HOT_BINS + lane] = 0;
+        static_assert(ST_HOT_REP == 4 && ST_HOT_BINS <= 64, "one uint4 per lane");
+        uint4 *const cell = reinterpret_cast<uint4 *>(hot) + (lane < ST_HOT_BINS ? lane : 0u);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lane < ST_HOT_BINS) {
+            v = *cell;
+            *cell = make_uint4(0, 0, 0, 0);
         }
+        const uint32_t t = v.x + v.y + v.z + v.w;
         const uint32_t depth = hot_base + lane;
         const uint32_t bin = depth <= a.cov_cap ? depth : a.cov_cap + 1;
         if (t) atomicAdd(&hist[bin < hw ? bin : bin - hw], bin < hw ? t : t << 16);
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                         hot_base = nb0;
                     }
                 }
-                const uint32_t hot_lane = (uint32_t)(hot - hist) + (lane & (ST_HOT_REP - 1)) * ST_HOT_BINS - hot_base;
+                const uint32_t hot_lane = (uint32_t)(hot - hist) + (lane & (ST_HOT_REP - 1)) - hot_base * ST_HOT_REP;
                 const uint32_t inc = st_wave_scan(x[PL - 1]);
                 const uint32_t before = carry + inc - x[PL - 1];
                 carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
                     lane_zero += i < len && depth == 0;
                     const uint32_t one = i < len && depth != 0 ? 1u : 0u;
                     const bool in_hot = depth - hot_base < ST_HOT_BINS;
-                    const uint32_t word = !one ? lane : in_hot ? hot_lane + depth : bin < hw ? bin : bin - hw;
+                    const uint32_t word = !one ? lane : in_hot ? hot_lane + depth * ST_HOT_REP : bin < hw ? bin : bin - hw;
                     if (ST_EXP != 3) atomicAdd(&hist[word], in_hot || bin < hw ? one : one << 16);
                     lsum += i < len ? depth : 0u;
                 }

@@ -24,5 +24,5 @@ python3 tools/collect_traffic.py "$F" "$W" "$S" gpurun_out/$P
 cp "$(find $O/mixed -name '*kernel_stats.csv' | head -n 1)" gpurun_out/${P}_mixed_kernel_stats.csv
 cp "$(find $O/extra -name '*kernel_stats.csv' | head -n 1)" gpurun_out/${P}_extra_kernel_stats.csv
 cp "$(find $O/file -name '*kernel_stats.csv' | head -n 1)" gpurun_out/${P}_ingest_kernel_stats.csv
-for f in stats mixed extra file; do tail -n 1 $O/$f.log > gpurun_out/${P}_bench_$f.json; done
+for f in stats mixed extra file; do grep '^{"metric"' $O/$f.log | tail -n 1 > gpurun_out/${P}_bench_$f.json; done
 head -n 12 "$S" | cut -c1-160
