@@ -131,7 +131,7 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    # (NCCL_DEBUG is left alone: at WARN and above RCCL prints its version banner on stdout, in front of the JSON line)
 
     import numpy as np
     from ngs_amd import ffi, host, shard

@@ -86,6 +86,23 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// cores this process may really use: the cgroup's CPU quota when there is one (the MI355X boxes of this pool show 256
+// online CPUs under a quota of 16: more runnable threads than that get throttled for the rest of the period)
+int effective_cores() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = atol(quota) / period;
+            if (q >= 1 && q < n) n = (int)q;
+        }
+        fclose(f);
+    }
+    return n;
+}
+
 size_t env_mb(const char *name, size_t dflt_mb) {
     const char *e = getenv(name);
     const long v = e ? atol(e) : 0;
@@ -222,7 +239,9 @@ void reader_main(DeviceIngest *d, std::string path) {
     const size_t cap = 2 * d->comp_chunk;
     const uint64_t out_limit = d->raw_cap > 2 * CARRY_MAX ? d->raw_cap - CARRY_MAX : d->raw_cap / 2;
     constexpr size_t STEP = (size_t)64 << 20;
-    constexpr int NT = 16;
+    constexpr int NT_MAX = 16;
+    // leave two cores of the quota to the thread that drives the GPU and to this one (it frames while the others read)
+    const int NT = std::max(4, std::min(NT_MAX, effective_cores() - 2));
     double ratio = 0.0; // compressed bytes per inflated byte, from the chunks framed so far
     const int fd = fileno(d->f);
     for (int k = 0;; k ^= 1) {
@@ -290,10 +309,10 @@ void reader_main(DeviceIngest *d, std::string path) {
                 want = std::min(want, STEP);
             }
             want = std::min(want, cap - c.fill);
-            size_t got_part[NT] = {};
-            bool bad_part[NT] = {};
+            size_t got_part[NT_MAX] = {};
+            bool bad_part[NT_MAX] = {};
             const size_t per = (want + NT - 1) / NT;
-            std::thread workers[NT];
+            std::thread workers[NT_MAX];
             for (int t = 0; t < NT; t++) {
                 workers[t] = std::thread([&, t]() {
                     const size_t lo = std::min(want, per * (size_t)t), hi = std::min(want, lo + per);

@@ -125,6 +125,26 @@ def test_inflate_errors(gpu_lib, ctx):
     bad[first_len - 4:first_len] = struct.pack("<I", 100)
     with pytest.raises(RuntimeError, match="block 0"):
         device_inflate(gpu_lib, ctx, bytes(bad))
+    # a match that reaches in front of the block's output, met after 12 KiB of literals (beyond the 2 KiB LDS ring, where a
+    # wrapped source offset used to be read from HBM): a raw-deflate stream made with a preset dictionary, inflated without it
+    rng = np.random.default_rng(9)
+    zdict = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+    payload = rng.integers(0, 256, 12_000, dtype=np.uint8).tobytes() + zdict[200:2600] + b"end"
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=zdict)
+    raw = co.compress(payload) + co.flush()
+    assert zlib.decompressobj(-15, zdict=zdict).decompress(raw) == payload
+    blk = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(raw) + 8 - 1) + raw +
+           struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+    with pytest.raises(RuntimeError, match="block 0"):
+        device_inflate(gpu_lib, ctx, blk + bgzf_block(b""))
+    # output longer than ISIZE says, in the LAST block with data (nothing behind it but the buffer's end): the decoder must stop
+    # at ISIZE instead of flushing its ring past it
+    long_data = rng.integers(0, 4, 30_000, dtype=np.uint8).tobytes()
+    lying = bytearray(bgzf_block(long_data))
+    lying[-4:] = struct.pack("<I", 9000)
+    with pytest.raises(RuntimeError, match="block 1"):
+        device_inflate(gpu_lib, ctx, bgzf_block(data[:5000]) + bytes(lying) + bgzf_block(b""), check_crc=False)
+    assert device_inflate(gpu_lib, ctx, good) == data   # and the context still works
     # framing
     with pytest.raises(RuntimeError, match="not a BGZF block"):
         device_inflate(gpu_lib, ctx, b"\x00" * 64)
