@@ -510,6 +510,9 @@ def leg_file(lib, host, ffi, args):
         assert lib.ngsq_synth_write_bam(C.byref(fcfg), bam.encode(), n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
         out["bam_write_s"] = round(time.perf_counter() - t0, 2)
         out["bam_bytes"] = os.path.getsize(bam)
+        t0 = time.perf_counter()
+        os.sync()   # let the write-back of the fresh file finish: it otherwise competes with the timed reads a few seconds later
+        out["sync_s"] = round(time.perf_counter() - t0, 2)
         ngs = build.build_cli(verbose=False)
         docs = {}
         for ingest, runs in (("device", 2), ("host", 1)):

@@ -72,14 +72,61 @@ def sorted_sweep(lib, seeds):
     print("sorted sweep ok")
 
 
+def extra_sweep(lib, seeds):
+    """Edits (LDS window per tile of sorted reads, eight bases per step) and Genomic Features (bracketed searches per
+    tile) against the oracle: sorted and unsorted batches, long skips that leave the window, several sequences with
+    and without reference bases / intervals, roles that share names."""
+    for seed in range(seeds):
+        rng = np.random.default_rng(7000 + seed)
+        n_refs = int(rng.integers(1, 4))
+        ref_len = [int(rng.integers(300, 60_000)) for _ in range(n_refs)]
+        primary = [int(rng.random() < 0.8) for _ in range(n_refs)]
+        bases = [rng.choice(np.array([1, 2, 4, 8, 15], dtype=np.uint8), size=L, p=[.24, .24, .24, .24, .04]) for L in ref_len]
+        n = int(rng.integers(1, 30_000))
+        max_len = int(rng.choice([36, 100, 150, 250]))
+        hb = random_batch(rng, n, ref_len, max_len=max_len, min_len=int(rng.integers(0, max_len + 1)), weird=bool(rng.integers(0, 2)))
+        if rng.random() < 0.7:
+            hb = coordinate_sorted(hb)
+        m = int(rng.integers(0, 3000))
+        fr = rng.integers(0, n_refs, m).astype(np.uint32)
+        fs = np.array([rng.integers(1, ref_len[r] + 1) for r in fr], dtype=np.uint32)
+        fe = fs + np.where(rng.random(m) < 0.1, 0, rng.integers(0, 5000, m)).astype(np.uint32)
+        fn = rng.choice(5, m).astype(np.uint32)
+        roles = tuple(int(x) for x in rng.choice([0, 1, 2, 3, 4], 5)) if rng.random() < 0.3 else (0, 1, 2, 3, 4)
+        kw = dict(facets=ffi.FACET_EDITS | ffi.FACET_FEATURES | ffi.FACET_GENERAL, max_read_len=320, gc_seed=seed, ref_bases=bases)
+        orc = oracle_py.Oracle(ref_len, primary, **kw)
+        gpu = host.QcContext(ref_len, primary, lib=lib, **kw)
+        orc.set_features(fr, fn, fs, fe, roles)
+        gpu.set_features(fr, fn, fs, fe, roles)
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, 3)]))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = hb.slice(lo, hi) if hb.cols.get("seq_off") is None else take_records(hb, np.arange(lo, hi))
+            part.first_record_index = lo
+            orc.process_batch(part)
+            gpu.process_batch(gpu.upload(part) if rng.random() < 0.5 else part)
+        assert orc.finalize(allow_malformed=True) == gpu.finalize(allow_malformed=True)
+        for a, b in zip(orc.edits(), gpu.edits()):
+            assert (a == b).all()
+        assert orc.features() == gpu.features() and orc.error_counts() == gpu.error_counts()
+        names = [f"s{i}" for i in range(n_refs)]
+        if not any(orc.error_counts().values()):
+            json_equal(gpu.results(names), orc.results(names))
+        gpu.close()
+        print(f"extra seed {seed}: n={n} refs={n_refs} intervals={m} roles={roles} ok", flush=True)
+    print("extra sweep ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--extra", type=int, default=0, help="seeds of the Edits + Genomic Features sweep")
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--sorted", type=int, default=0, help="seeds of the sorted_input (streaming Coverage) sweep")
     a = ap.parse_args()
     lib = ffi.load_library()
     if a.sorted:
         sorted_sweep(lib, a.sorted)
+    if a.extra:
+        extra_sweep(lib, a.extra)
     td = tempfile.mkdtemp(prefix="ngsq_fuzz_")
     for seed in range(a.seeds):
         rng = np.random.default_rng(1000 + seed)

@@ -17,6 +17,7 @@ t = time.time()
 assert lib.ngsq_synth_write_bam(C.byref(cfg), b"/tmp/trace.bam", $N, $LV, 0) == 0
 print("bam_write_s", round(time.time() - t, 2), "bytes", os.path.getsize("/tmp/trace.bam"))
 PY
+sync
 echo "nproc $(nproc); cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null); mem $(free -g | sed -n 2p)"
 for i in 1 2; do
   T0=$(date +%s.%N)
