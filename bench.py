@@ -239,7 +239,8 @@ def main() -> int:
                        "sharding": ("contiguous record (BGZF block) ranges; ngsq_exchange over %s: all-reduce of counters, "
                                     "owner-computes coverage teardown with point-to-point halos (mode %s, %d halo bytes from "
                                     "rank 0, %d host syncs per step)"
-                                    % (comm.kind, report.get("mode"), report.get("halo_bytes", 0), report.get("host_syncs", 0)))
+                                    % (comm.kind + (" (RCCL asked for, not available: %s)" % comm.fallback_reason
+                                                    if comm.fallback_reason else ""), report.get("mode"), report.get("halo_bytes", 0), report.get("host_syncs", 0)))
                        if comm is not None else "single GPU",
                        "coverage": ("streamed from the coordinate-sorted records (sorted_input)" if args.coverage == "stream"
                                     else "difference arrays + teardown scan"),
@@ -542,7 +543,7 @@ def leg_file(lib, host, ffi, args):
                 h = C.c_void_p()
                 if lib.ngsq_bam_open(bam.encode(), 0, C.byref(h)) != 0:
                     raise RuntimeError(lib.ngsq_bam_last_error().decode())
-                got = 0
+                got, first = 0, None
                 while True:
                     b = ffi.Batch()
                     if lib.ngsq_bam_next_batch_device(h, ctx._ctx, 1 << 22, C.byref(b)) != 0:
@@ -550,6 +551,8 @@ def leg_file(lib, host, ffi, args):
                     if b.n_records == 0:
                         break
                     got += int(b.n_records)
+                    if first is None:   # start-up (buffers allocated and pinned, first chunk read and inflated) ends here
+                        first = (time.perf_counter(), got)
                     if lib.ngsq_process_batch(ctx._ctx, C.byref(b), ffi.PASS_BOTH) != 0:
                         raise RuntimeError(lib.ngsq_last_error(ctx._ctx).decode())
                 lib.ngsq_bam_close(h)
@@ -558,6 +561,7 @@ def leg_file(lib, host, ffi, args):
                 assert got == n, (got, n)
                 if best is None or dt < best:
                     best, timing = dt, ctx.kernel_timing()
+                    after_first = ((n - first[1]) / max(t0 + dt - first[0], 1e-9), first[0] - t0) if first and n > first[1] else None
                 doc = ctx.results(names)
             docs["in_process"] = doc
             out["value"] = round(n / best, 1)
@@ -567,6 +571,9 @@ def leg_file(lib, host, ffi, args):
                                                "includes": "file open, reads, H2D of the compressed bytes, inflate, parse, "
                                                            "all default facets, finalize",
                                                "kernels": kernel_table(timing)}
+            if after_first:
+                out["in_process_device_ingest"]["first_batch_after_s"] = round(after_first[1], 3)
+                out["in_process_device_ingest"]["records_per_s_after_first_batch"] = round(after_first[0], 1)
             inf = timing.get("bgzf_inflate")
             if inf and inf["launches"] and inf["total_ms"] > 0:
                 gbs = inf["algo_bytes"] / inf["total_ms"] / 1e6

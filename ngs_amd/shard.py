@@ -52,6 +52,7 @@ class Comm:
         self.lib, self._h, self._keep = lib, handle, keep
         self.rank, self.world = lib.ngsq_comm_rank(handle), lib.ngsq_comm_world(handle)
         self.kind = lib.ngsq_comm_kind(handle).decode()
+        self.fallback_reason: Optional[str] = None   # comm_from_env: why this is not the transport asked for
 
     # -- constructors
     @staticmethod
@@ -248,12 +249,30 @@ def comm_from_env(device: int, kind: str = "rccl", lib=None) -> "Comm":
     No torch, no process group."""
     lib = lib or ffi.load_library()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    boot = Comm.shm(f"/ngsq-{_launcher_tag()}", rank, world, slot_bytes=1 << 16, lib=lib)
-    if kind == "shm":
-        return boot
-    uid = np.frombuffer(unique_id(lib) if rank == 0 else bytes(ffi.COMM_ID_BYTES), dtype=np.uint8)
-    uid = boot.allgather(uid)[0].tobytes()
-    comm = Comm.rccl(rank, world, uid, device, lib)
+    tag = _launcher_tag()
+    boot = Comm.shm(f"/ngsq-{tag}", rank, world, slot_bytes=1 << 16, lib=lib)
+    why = None
+    comm = None
+    if kind == "rccl":
+        uid = np.frombuffer(unique_id(lib) if rank == 0 else bytes(ffi.COMM_ID_BYTES), dtype=np.uint8)
+        uid = boot.allgather(uid)[0].tobytes()
+        try:
+            comm = Comm.rccl(rank, world, uid, device, lib)
+        except CommError as e:      # e.g. two ranks on one GPU: RCCL refuses that
+            why = str(e)
+        ok = boot.allgather_ints([0 if why else 1])
+        if all(int(v[0]) for v in ok):
+            boot.barrier()
+            boot.destroy()
+            return comm
+        # the ranks agree: not every one of them has an RCCL communicator.  The exchange still runs natively,
+        # host-staged through shared memory; whoever reports numbers must say so (Comm.fallback_reason).
+        if comm is not None:
+            comm.destroy()
+        bad = [r for r, v in enumerate(ok) if not int(v[0])]
+        why = why or f"ncclCommInitRank failed on rank(s) {bad}"
+    big = Comm.shm(f"/ngsq-{tag}-x", rank, world, slot_bytes=32 << 20, lib=lib)
+    big.fallback_reason = why
     boot.barrier()
     boot.destroy()
-    return comm
+    return big
