@@ -18,6 +18,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 #include "ingest_kernels.h"
 
 namespace ngsq {
@@ -28,6 +30,15 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
     uint32_t v;
     __builtin_memcpy(&v, p, 4);
     return v;
+}
+// the 32 bytes at p (any alignment), both loads in flight together.  Written out because hipcc narrows two 16-byte
+// memcpy()s to the fields used and sinks them behind the conditions that need them: three dependent memory latencies
+// per record of a chain instead of one.
+__device__ __forceinline__ void ld2x16(const uint8_t *p, uint4 &a, uint4 &b) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(p)
+                 : "memory");
 }
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
@@ -40,93 +51,174 @@ __device__ __forceinline__ bool record_valid(const uint8_t *r /* at block_size *
     return l_read_name != 0 && need <= bs;
 }
 
-// stricter test used only to FIND chains quickly (never to reject a record)
-__device__ __forceinline__ bool record_plausible(const uint8_t *r, uint32_t bs, int32_t n_ref) {
-    if (!record_valid(r, bs)) return false;
-    const int32_t ref = (int32_t)ld32(r + 4), pos = (int32_t)ld32(r + 8);
-    const int32_t mref = (int32_t)ld32(r + 24), mpos = (int32_t)ld32(r + 28);
-    return ref >= -1 && ref < n_ref && mref >= -1 && mref < n_ref && pos >= -1 && mpos >= -1;
-}
+constexpr uint32_t SUB_NONE = 0xFFFFFFFFu;
 
 // Walk the chain from `o` until it reaches `end` (segment end) or the record at the cursor is not
-// completely inside [0, n_bytes).  plausible: apply the strict test.  Returns false on an invalid
-// record.  *landing = cursor at the stop, *count = records passed.
-__device__ bool walk(const uint8_t *raw, uint64_t n_bytes, uint64_t o, uint64_t end, int32_t n_ref, bool strict,
-                     uint64_t *landing, uint32_t *count) {
-    uint32_t n = 0;
+// completely inside [0, n_bytes).  STRICT: apply the plausibility test.  Returns false on an invalid
+// record.  *landing = cursor at the stop, *count = records passed.  put(j, rel, cnt) is called once for
+// every 4 KiB piece j of the segment the chain reaches a record start in or behind: rel = offset of the first
+// record of the chain at or behind the piece's start (relative to s0), cnt = records of the chain before it.
+// The fixed part of a record is fetched with two 16-byte loads issued together: one memory latency per record.
+template <bool STRICT, typename Put>
+__device__ __forceinline__ bool walk(const uint8_t *raw, uint64_t n_bytes, uint64_t o, uint64_t s0, uint64_t end, int32_t n_ref,
+                                     uint64_t *landing, uint32_t *count, Put put) {
+    uint32_t n = 0, j = 0;
+    bool ok = true;
     while (o < end) {
-        if (o + 4 > n_bytes) break; // block_size itself is cut
-        const uint32_t bs = ld32(raw + o);
-        if (o + 4 + (uint64_t)bs > n_bytes) {
-            // incomplete record at the end of the buffer: only its fixed part can be tested
-            if (bs < 32) return false;
+        while (j < REC_PIECES && s0 + (uint64_t)j * REC_PIECE <= o) {
+            put(j, (uint32_t)(o - s0), n);
+            j++;
+        }
+        if (o + 36 > n_bytes) { // the fixed part itself is cut by the end of the buffer
+            if (o + 4 > n_bytes) break; // block_size itself is cut
+            const uint32_t bs = ld32(raw + o);
+            // a complete record here would be shorter than its fixed part; of an incomplete one only block_size can be tested
+            if (o + 4 + (uint64_t)bs <= n_bytes || bs < 32) ok = false;
             break;
         }
-        if (strict ? !record_plausible(raw + o, bs, n_ref) : !record_valid(raw + o, bs)) return false;
+        uint4 a, b; // block_size, refID, pos, l_read_name | mapq | bin;  n_cigar_op | flag, l_seq, next_refID, next_pos
+        ld2x16(raw + o, a, b);
+        const uint32_t bs = a.x;
+        if (o + 4 + (uint64_t)bs > n_bytes) {
+            if (bs < 32) ok = false;
+            break;
+        }
+        // the host reader's validity rule (bam_reader.cpp): block_size >= 32, l_read_name != 0 and the
+        // variable-length fields fit the block
+        const uint32_t l_read_name = a.w & 0xFFu, n_ops = b.x & 0xFFFFu, l = b.y;
+        const uint64_t need = 32ull + l_read_name + 4ull * n_ops + ((uint64_t)l + 1) / 2 + l;
+        bool good = bs >= 32 && l_read_name != 0 && need <= bs;
+        if (STRICT) { // used only to FIND chains quickly (never to reject a record)
+            const int32_t ref = (int32_t)a.y, pos = (int32_t)a.z, mref = (int32_t)b.z, mpos = (int32_t)b.w;
+            good = good && ref >= -1 && ref < n_ref && mref >= -1 && mref < n_ref && pos >= -1 && mpos >= -1;
+        }
+        if (!good) {
+            ok = false;
+            break;
+        }
         o += 4 + (uint64_t)bs;
         n += 1;
     }
+    if (ok && o >= end) // the pieces behind the last record start: the landing offset is not inside them
+        while (j < REC_PIECES && s0 + (uint64_t)j * REC_PIECE <= o && s0 + (uint64_t)j * REC_PIECE < end) {
+            put(j, (uint32_t)(o - s0), n);
+            j++;
+        }
     *landing = o;
     *count = n;
-    return true;
+    return ok;
 }
 
 } // namespace
 
 // ---- 1. candidates ----------------------------------------------------------------------------
+// One wave per segment.  A window of up to 1 KiB is screened 64 offsets at a time (a complete, plausible record:
+// bytes inside a record read as a huge block_size look like "the record cut by the end of the buffer" -- never a
+// candidate; the one true cut record of a chunk is found by k_walk_one), then the offsets that passed (REC_CANDIDATES
+// per round) are walked at once, a lane each: the chain of a segment is ~240 dependent loads long, and walking the candidates
+// one after the other made this kernel four such chains long.
 __global__ __launch_bounds__(64) void k_rec_candidates(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint64_t first,
-                                                       uint32_t n_seg, int32_t n_ref, RecCandidate *__restrict__ cand) {
+                                                       uint32_t n_seg, int32_t n_ref, RecCandidate *__restrict__ cand,
+                                                       RecPieces *__restrict__ pieces) {
+    // chains walked at once: each extra one costs (divergent loads), and the screening resumes right behind the last
+    // offset taken, so no candidate is skipped
+    constexpr uint32_t LIST = REC_CANDIDATES;
+    __shared__ uint64_t s_list[LIST];
+    __shared__ uint32_t s_rel[REC_PIECES * LIST], s_cnt[REC_PIECES * LIST];
     const uint32_t seg = blockIdx.x, lane = threadIdx.x;
     if (seg >= n_seg) return;
     const uint64_t s0 = (uint64_t)seg * REC_SEGMENT, s1 = min(s0 + REC_SEGMENT, n_bytes);
     RecCandidate *out = cand + (uint64_t)seg * REC_CANDIDATES;
     uint32_t found = 0;
-    // offsets before `first` (the BAM header) are never record starts
-    for (uint64_t b = max(s0, first); b < s1 && found < REC_CANDIDATES; b += 64) {
-        const uint64_t o = b + lane;
-        uint64_t landing = 0;
+    uint64_t pos = max(s0, first); // offsets before `first` (the BAM header) are never record starts
+    while (pos < s1 && found < REC_CANDIDATES) {
+        uint32_t list_n = 0;
+        for (int it = 0; it < 16 && pos < s1 && list_n < LIST; it++) {
+            const uint64_t o = pos + lane;
+            bool pass = false;
+            if (o < s1 && o + 36 <= n_bytes) {
+                uint4 a, b;
+                ld2x16(raw + o, a, b);
+                const uint32_t bs = a.x, l_read_name = a.w & 0xFFu, n_ops = b.x & 0xFFFFu, l = b.y;
+                const uint64_t need = 32ull + l_read_name + 4ull * n_ops + ((uint64_t)l + 1) / 2 + l;
+                const int32_t ref = (int32_t)a.y, p = (int32_t)a.z, mref = (int32_t)b.z, mpos = (int32_t)b.w;
+                pass = o + 4 + (uint64_t)bs <= n_bytes && bs >= 32 && l_read_name != 0 && need <= bs && ref >= -1 && ref < n_ref &&
+                       mref >= -1 && mref < n_ref && p >= -1 && mpos >= -1;
+            }
+            const uint64_t m = __ballot(pass);
+            const uint32_t k = (uint32_t)__popcll(m), room = LIST - list_n;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (pass && rank < room) s_list[list_n + rank] = o;
+            if (k > room) { // the list is full: go on behind the last offset taken, after the walk
+                uint64_t mm = m;
+                for (uint32_t q = 1; q < room; q++) mm &= mm - 1;
+                pos += (uint32_t)__builtin_ctzll(mm) + 1;
+                list_n = LIST;
+            } else {
+                list_n += k;
+                pos += 64;
+            }
+        }
+        if (!list_n) continue;
+        __syncthreads();
+        uint64_t o = 0, landing = 0;
         uint32_t count = 0;
         bool ok = false;
-        if (o < s1 && o + 4 <= n_bytes) {
-            const uint32_t bs = ld32(raw + o);
-            // cheap screen before the walk: a complete, plausible record.  (Bytes inside a record read as a
-            // huge block_size look like "the record cut by the end of the buffer": never a candidate.  The
-            // one true cut record of a chunk is then found by k_walk_one.)
-            if (o + 4 + (uint64_t)bs <= n_bytes && record_plausible(raw + o, bs, n_ref))
-                ok = walk(raw, n_bytes, o, s1, n_ref, true, &landing, &count);
+        if (lane < list_n) {
+            o = s_list[lane];
+            for (uint32_t j = 0; j < REC_PIECES; j++) s_rel[j * LIST + lane] = SUB_NONE;
+            ok = walk<true>(raw, n_bytes, o, s0, s1, n_ref, &landing, &count, [&](uint32_t j, uint32_t rel, uint32_t cnt) {
+                s_rel[j * LIST + lane] = rel;
+                s_cnt[j * LIST + lane] = cnt;
+            });
         }
-        uint64_t m = __ballot(ok);
-        while (m && found < REC_CANDIDATES) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1;
-            if (lane == l) out[found] = RecCandidate{o, landing, count, 1u};
-            found += 1;
+        const uint64_t m = __ballot(ok);
+        const uint32_t slot = found + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (ok && slot < REC_CANDIDATES) {
+            out[slot] = RecCandidate{o, landing, count, 1u};
+            RecPieces &pc = pieces[(uint64_t)seg * REC_CANDIDATES + slot];
+            for (uint32_t j = 0; j < REC_PIECES; j++) {
+                pc.rel[j] = s_rel[j * LIST + lane];
+                pc.cnt[j] = s_cnt[j * LIST + lane];
+            }
         }
+        found += (uint32_t)__popcll(m);
+        __syncthreads();
     }
+    found = min(found, REC_CANDIDATES);
     for (uint32_t k = found + lane; k < REC_CANDIDATES; k += 64) out[k] = RecCandidate{0, 0, 0, 0u};
 }
 
 // ---- 2b. the rare segment whose entry is not in the table ---------------------------------------
-__global__ void k_walk_one(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint64_t start, uint64_t end,
-                           RecCandidate *__restrict__ out) {
+__global__ void k_walk_one(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint64_t start, uint64_t s0, uint64_t end,
+                           RecCandidate *__restrict__ out, RecPieces *__restrict__ pc) {
     if (threadIdx.x || blockIdx.x) return;
     uint64_t landing = start;
     uint32_t count = 0;
-    const bool ok = walk(raw, n_bytes, start, end, 0, false, &landing, &count);
+    for (uint32_t j = 0; j < REC_PIECES; j++) pc->rel[j] = SUB_NONE;
+    const bool ok = walk<false>(raw, n_bytes, start, s0, end, 0, &landing, &count, [&](uint32_t j, uint32_t rel, uint32_t cnt) {
+        pc->rel[j] = rel;
+        pc->cnt[j] = cnt;
+    });
     *out = RecCandidate{start, landing, count, ok ? 1u : 0u};
 }
 
 // ---- 3. offsets -------------------------------------------------------------------------------
-// seg_entry[s] = offset of the first record that starts in segment s (or >= its end: none);
-// seg_base[s] = index of that record.  bad[0] = smallest index of an invalid record (or ~0).
-__global__ __launch_bounds__(256) void k_rec_offsets(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t n_seg,
-                                                     const uint64_t *__restrict__ seg_entry,
-                                                     const uint64_t *__restrict__ seg_base, uint64_t *__restrict__ rec_off,
+// One lane per 4 KiB piece.  chosen[s] = the candidate of segment s whose chain is the file's (REC_NO_CHAIN: no record
+// starts in s), seg_base[s] = index of its first record; the piece's own entry comes from the candidate's piece table.
+// bad[0] = smallest index of an invalid record (or ~0).
+__global__ __launch_bounds__(256) void k_rec_offsets(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t n_pieces,
+                                                     const uint32_t *__restrict__ chosen, const uint64_t *__restrict__ seg_base,
+                                                     const RecPieces *__restrict__ pieces, uint64_t *__restrict__ rec_off,
                                                      unsigned long long *__restrict__ bad) {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= n_seg) return;
-    const uint64_t s1 = min(((uint64_t)seg + 1) * REC_SEGMENT, n_bytes);
-    uint64_t o = seg_entry[seg], i = seg_base[seg];
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pieces) return;
+    const uint32_t seg = g / REC_PIECES, j = g % REC_PIECES, ch = chosen[seg];
+    if (ch == REC_NO_CHAIN) return;
+    const RecPieces &pc = pieces[(uint64_t)seg * REC_CANDIDATES + ch];
+    if (pc.rel[j] == SUB_NONE) return;
+    const uint64_t s1 = min(((uint64_t)g + 1) * REC_PIECE, n_bytes);
+    uint64_t o = (uint64_t)seg * REC_SEGMENT + pc.rel[j], i = seg_base[seg] + pc.cnt[j];
     while (o < s1) {
         if (o + 4 > n_bytes) break;
         const uint32_t bs = ld32(raw + o);
@@ -144,37 +236,54 @@ __global__ __launch_bounds__(256) void k_rec_offsets(const uint8_t *__restrict__
 }
 
 // ---- 4. fixed-width columns + the numbers the layout decision needs ----------------------------
-// stats: [0] max l_seq, [1] max n_cigar, [2] sum l_seq (u64 in [2..3])
+// stats: [0] max l_seq, [1] max n_cigar, [2] sum l_seq.  var_base[i] / seq_src[i] = offset of record i's CIGAR / SEQ
+// in raw (k_rec_var and k_rec_rows start from them).  The fixed part of a record is 32 contiguous bytes at any byte
+// offset: two unaligned 16-byte loads.  The three totals are reduced per block first: one atomic per wave on
+// the same three words was most of this kernel's time (same-address atomics serialise in L2, ~9 ns each).
 __global__ __launch_bounds__(256) void k_rec_fixed(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ rec_off,
-                                                   uint64_t n, RecColumns c, unsigned long long *__restrict__ stats) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t l = 0, n_ops = 0;
-    if (i < n) {
-        const uint8_t *r = raw + rec_off[i] + 4;
-        n_ops = ld16(r + 12);
-        l = ld32(r + 16);
-        c.ref_id[i] = (int32_t)ld32(r);
-        c.pos[i] = (int32_t)ld32(r + 4);
-        c.mapq[i] = r[9];
+                                                   uint64_t n, RecColumns c, uint64_t *__restrict__ var_base,
+                                                   uint64_t *__restrict__ seq_src, unsigned long long *__restrict__ stats) {
+    __shared__ uint32_t s_ml[4], s_mo[4];
+    __shared__ unsigned long long s_sl[4];
+    uint32_t ml = 0, mo = 0;
+    unsigned long long sl = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t o = rec_off[i] + 4;
+        uint4 a, b;
+        __builtin_memcpy(&a, raw + o, 16);      // refID, pos, l_read_name | mapq | bin, n_cigar_op | flag
+        __builtin_memcpy(&b, raw + o + 16, 16); // l_seq, next_refID, next_pos, tlen
+        const uint32_t l_read_name = a.z & 0xFFu, n_ops = a.w & 0xFFFFu, l = b.x;
+        c.ref_id[i] = (int32_t)a.x;
+        c.pos[i] = (int32_t)a.y;
+        c.mapq[i] = (uint8_t)(a.z >> 8);
         c.n_cigar[i] = (uint16_t)n_ops;
-        c.flag[i] = (uint16_t)ld16(r + 14);
+        c.flag[i] = (uint16_t)(a.w >> 16);
         c.l_seq[i] = l;
-        c.mate_ref_id[i] = (int32_t)ld32(r + 20);
-        c.tlen[i] = (int32_t)ld32(r + 28);
+        c.mate_ref_id[i] = (int32_t)b.y;
+        c.tlen[i] = (int32_t)b.w;
+        var_base[i] = o + 32 + l_read_name;
+        seq_src[i] = o + 32 + l_read_name + 4ull * n_ops;
+        ml = max(ml, l);
+        mo = max(mo, n_ops);
+        sl += l;
     }
-    // block reduce (wave shuffles, then one atomic per wave)
-    uint32_t ml = l, mo = n_ops;
-    unsigned long long sl = l;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         ml = max(ml, (uint32_t)__shfl_xor((int)ml, o, 64));
         mo = max(mo, (uint32_t)__shfl_xor((int)mo, o, 64));
         sl += __shfl_xor(sl, o, 64);
     }
+    const uint32_t w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&stats[0], (unsigned long long)ml);
-        atomicMax(&stats[1], (unsigned long long)mo);
-        atomicAdd(&stats[2], sl);
+        s_ml[w] = ml;
+        s_mo[w] = mo;
+        s_sl[w] = sl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&stats[0], (unsigned long long)max(max(s_ml[0], s_ml[1]), max(s_ml[2], s_ml[3])));
+        atomicMax(&stats[1], (unsigned long long)max(max(s_mo[0], s_mo[1]), max(s_mo[2], s_mo[3])));
+        atomicAdd(&stats[2], s_sl[0] + s_sl[1] + s_sl[2] + s_sl[3]);
     }
 }
 
@@ -196,25 +305,94 @@ __global__ __launch_bounds__(256) void k_rec_lengths(const uint8_t *__restrict__
 }
 
 // ---- 6. variable-width columns -----------------------------------------------------------------
-// 16 lanes per record.  Fixed-pitch rows are padded (zero nibbles for SEQ, 0xFF for QUAL) exactly as
-// bam_reader.cpp pads them; the offsets layout copies l_seq / (l_seq+1)/2 / n_ops units.
-__global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ rec_off,
-                                                 uint64_t n, RecColumns c) {
+// Fixed-pitch rows (the common case: reads of one length) are written a DWORD of the destination per lane:
+// the rows of consecutive records are one contiguous region, dword d of it belongs to record d*4/pitch, and
+// unless it holds the end of a row its four bytes are four consecutive bytes of the source: one unaligned load,
+// one aligned store per four bytes (a byte per lane, sixteen lanes per record, was 4 + 4 instructions).
+// Padding as bam_reader.cpp pads: zero nibbles for SEQ, 0xFF for QUAL.
+template <bool QUAL>
+__device__ __forceinline__ uint32_t row_tail(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
+                                             const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t r, uint32_t k, uint32_t pitch,
+                                             uint32_t len, const uint8_t *src) {
+    // the end of a row (its padding, and perhaps the first bytes of the next row)
+    constexpr uint32_t FILL = QUAL ? 0xFFu : 0u;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) {
+        uint32_t byte = FILL;
+        if (k + b < pitch) {
+            if (k + b < len) byte = src[k + b];
+        } else if (r + 1 < n) {
+            const uint32_t k2 = k + b - pitch, l2 = l_seq[r + 1], sb2 = (l2 + 1) / 2;
+            if (k2 < (QUAL ? l2 : sb2)) byte = raw[seq_src[r + 1] + (QUAL ? sb2 : 0u) + k2];
+        }
+        v |= byte << (8 * b);
+    }
+    return v;
+}
+
+// seq_src[i] = offset of record i's SEQ in raw.  Four destination dwords per thread, their loads issued together:
+// record index -> (seq_src, l_seq) -> source bytes is two dependent memory latencies, and with one dword per thread
+// the kernel did nothing but wait for them (1 TB/s).
+template <bool QUAL>
+__global__ __launch_bounds__(256) void k_rec_rows(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
+                                                  const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t *__restrict__ dst,
+                                                  uint32_t pitch, uint64_t n_dwords) {
+    constexpr uint32_t FILL = QUAL ? 0xFFu : 0u;
+    constexpr int U = 4;
+    for (uint64_t d0 = (uint64_t)blockIdx.x * (256 * U) + threadIdx.x; d0 < n_dwords; d0 += (uint64_t)gridDim.x * (256 * U)) {
+        uint32_t r[U], k[U], len[U], v[U];
+        const uint8_t *src[U];
+        bool in[U], fast[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t d = d0 + (uint64_t)u * 256;
+            const uint32_t a = (uint32_t)d * 4u; // pitch * n < 2^32 (launcher)
+            r[u] = a / pitch;
+            k[u] = a - r[u] * pitch;
+            in[u] = d < n_dwords && r[u] < n;
+            const uint32_t rr = in[u] ? r[u] : 0u;
+            const uint32_t l = l_seq[rr], sb = (l + 1) / 2;
+            len[u] = QUAL ? l : sb;
+            src[u] = raw + seq_src[rr] + (QUAL ? sb : 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            fast[u] = in[u] && k[u] + 4 <= len[u];
+            v[u] = ld32(fast[u] ? src[u] + k[u] : src[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t d = d0 + (uint64_t)u * 256;
+            if (d >= n_dwords) break;
+            if (!in[u]) v[u] = FILL * 0x01010101u;
+            else if (!fast[u]) v[u] = row_tail<QUAL>(raw, seq_src, l_seq, n, r[u], k[u], pitch, len[u], src[u]);
+            dst[d] = v[u];
+        }
+    }
+}
+
+// 16 lanes per record: the offsets layout (reads of different lengths) copies l_seq / (l_seq+1)/2 / n_ops units;
+// parts: 1 = CIGAR, 2 = SEQ and QUAL (fixed-pitch rows are k_rec_rows' unless the pitch rules it out).
+__global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base,
+                                                 uint64_t n, RecColumns c, uint32_t parts) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t t = threadIdx.x & 15u;
     if (i >= n) return;
-    const uint8_t *r = raw + rec_off[i] + 4;
-    const uint32_t l_read_name = r[8], n_ops = ld16(r + 12), l = ld32(r + 16);
-    const uint8_t *cg = r + 32 + l_read_name;
+    const uint32_t n_ops = c.n_cigar[i], l = c.l_seq[i];
+    const uint8_t *cg = raw + var_base[i];
     const uint8_t *sq = cg + 4ull * n_ops;
     const uint8_t *ql = sq + (l + 1) / 2;
     const uint32_t sb = (l + 1) / 2;
-    if (c.cigar_off) {
-        uint32_t *dst = c.cigar + c.cigar_off[i];
-        for (uint32_t k = t; k < n_ops; k += 16) dst[k] = ld32(cg + 4 * k);
-    } else if (t == 0) {
-        c.cigar[i] = n_ops ? ld32(cg) : 0u;
+    if (parts & 1u) {
+        if (c.cigar_off) {
+            uint32_t *dst = c.cigar + c.cigar_off[i];
+            for (uint32_t k = t; k < n_ops; k += 16) dst[k] = ld32(cg + 4 * k);
+        } else if (t == 0) {
+            c.cigar[i] = n_ops ? ld32(cg) : 0u;
+        }
     }
+    if (!(parts & 2u)) return;
     if (c.seq_off) {
         uint8_t *sd = c.seq + c.seq_off[i];
         for (uint32_t k = t; k < sb; k += 16) sd[k] = sq[k];
@@ -228,6 +406,13 @@ __global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw
         for (uint32_t k = t; k < c.seq_pitch; k += 16) sd[k] = k < sb ? sq[k] : (uint8_t)0;
         for (uint32_t k = t; k < c.qual_pitch; k += 16) qd[k] = k < l ? ql[k] : (uint8_t)0xFF;
     }
+}
+
+// one CIGAR operation per record (or none): the first one, or 0
+__global__ __launch_bounds__(256) void k_rec_cigar1(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base,
+                                                    const uint16_t *__restrict__ n_cigar, uint64_t n, uint32_t *__restrict__ cigar) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        cigar[i] = n_cigar[i] ? ld32(raw + var_base[i]) : 0u;
 }
 
 // slack behind the packed columns that the facet kernels' vector loads may touch
@@ -252,20 +437,20 @@ __global__ void k_count_below_u64(const uint64_t *__restrict__ a, uint64_t n, ui
 
 // ---- launchers ----------------------------------------------------------------------------------
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
-                                 RecCandidate *cand, hipStream_t s) {
+                                 RecCandidate *cand, RecPieces *pieces, hipStream_t s) {
     if (!n_seg) return hipSuccess;
-    hipLaunchKernelGGL(k_rec_candidates, dim3(n_seg), dim3(64), 0, s, raw, n_bytes, first, n_seg, n_ref, cand);
+    hipLaunchKernelGGL(k_rec_candidates, dim3(n_seg), dim3(64), 0, s, raw, n_bytes, first, n_seg, n_ref, cand, pieces);
     return hipGetLastError();
 }
-hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t end, RecCandidate *out,
-                           hipStream_t s) {
-    hipLaunchKernelGGL(k_walk_one, dim3(1), dim3(64), 0, s, raw, n_bytes, start, end, out);
+hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t seg_start, uint64_t end, RecCandidate *out,
+                           RecPieces *pieces, hipStream_t s) {
+    hipLaunchKernelGGL(k_walk_one, dim3(1), dim3(64), 0, s, raw, n_bytes, start, seg_start, end, out, pieces);
     return hipGetLastError();
 }
-hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_seg, const uint64_t *seg_entry,
-                              const uint64_t *seg_base, uint64_t *rec_off, unsigned long long *bad, hipStream_t s) {
-    if (!n_seg) return hipSuccess;
-    hipLaunchKernelGGL(k_rec_offsets, dim3((n_seg + 255) / 256), dim3(256), 0, s, raw, n_bytes, n_seg, seg_entry, seg_base,
+hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
+                              const RecPieces *pieces, uint64_t *rec_off, unsigned long long *bad, hipStream_t s) {
+    if (!n_pieces) return hipSuccess;
+    hipLaunchKernelGGL(k_rec_offsets, dim3((n_pieces + 255) / 256), dim3(256), 0, s, raw, n_bytes, n_pieces, chosen, seg_base, pieces,
                        rec_off, bad);
     return hipGetLastError();
 }
@@ -273,10 +458,11 @@ hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value,
     hipLaunchKernelGGL(k_count_below_u64, dim3(1), dim3(64), 0, s, a, n, value, out);
     return hipGetLastError();
 }
-hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c,
+hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
                             unsigned long long *stats, hipStream_t s) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_rec_fixed, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, raw, rec_off, n, c, stats);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_rec_fixed, dim3(blocks), dim3(256), 0, s, raw, rec_off, n, c, var_base, var_base + n, stats);
     return hipGetLastError();
 }
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,
@@ -289,9 +475,26 @@ hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint6
 hipError_t launch_exclusive_scan_u64(uint64_t *data, uint64_t n_plus_1, void *tmp, size_t *tmp_bytes, hipStream_t s) {
     return hipcub::DeviceScan::ExclusiveSum(tmp, *tmp_bytes, data, data, (int)n_plus_1, s);
 }
-hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t seq_bytes,
+hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t n, const RecColumns &c, uint64_t seq_bytes,
                           uint64_t qual_bytes, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_rec_var, dim3((uint32_t)((n * 16 + 255) / 256)), dim3(256), 0, s, raw, rec_off, n, c);
+    if (n) {
+        // fixed-pitch rows by destination dword (byte offsets must fit 32 bits), everything else 16 lanes per record
+        const bool rows = !c.seq_off && (uint64_t)c.qual_pitch * n < ((uint64_t)1 << 32) - 64 && c.seq_pitch && c.qual_pitch;
+        uint32_t parts = rows ? 0u : 2u;
+        if (c.cigar_off) parts |= 1u;
+        if (rows) {
+            const uint64_t ds = ((uint64_t)c.seq_pitch * n + 3) / 4, dq = ((uint64_t)c.qual_pitch * n + 3) / 4;
+            hipLaunchKernelGGL(k_rec_rows<false>, dim3((uint32_t)std::min<uint64_t>((ds + 1023) / 1024, 1u << 16)), dim3(256), 0, s, raw,
+                               var_base + n, c.l_seq, n, reinterpret_cast<uint32_t *>(c.seq), c.seq_pitch, ds);
+            hipLaunchKernelGGL(k_rec_rows<true>, dim3((uint32_t)std::min<uint64_t>((dq + 1023) / 1024, 1u << 16)), dim3(256), 0, s, raw,
+                               var_base + n, c.l_seq, n, reinterpret_cast<uint32_t *>(c.qual), c.qual_pitch, dq);
+        }
+        if (!c.cigar_off)
+            hipLaunchKernelGGL(k_rec_cigar1, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, raw, var_base,
+                               c.n_cigar, n, c.cigar);
+        if (parts)
+            hipLaunchKernelGGL(k_rec_var, dim3((uint32_t)((n * 16 + 255) / 256)), dim3(256), 0, s, raw, var_base, n, c, parts);
+    }
     hipLaunchKernelGGL(k_fill_slack, dim3(1), dim3(64), 0, s, c.seq + seq_bytes, c.qual + qual_bytes);
     return hipGetLastError();
 }

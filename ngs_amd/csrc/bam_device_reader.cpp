@@ -212,7 +212,9 @@ struct DeviceIngest {
     DevBuf<BgzfBlock> d_blocks;
     DevBuf<uint32_t> d_status, d_l_seq, d_cigar;
     DevBuf<RecCandidate> d_cand;
-    DevBuf<uint64_t> d_seg, d_rec_off, d_len; // d_seg: entry | base; d_len: seq | qual | cigar lengths -> offsets
+    DevBuf<RecPieces> d_pieces;
+    DevBuf<uint64_t> d_var_base;              // per record of the batch: offset of its CIGAR in raw
+    DevBuf<uint64_t> d_seg, d_rec_off, d_len; // d_seg: per segment, index of its first record | chosen candidate (u32); d_len: seq | qual | cigar lengths -> offsets
     DevBuf<unsigned long long> d_small;       // [0] bad record, [1..3] stats, [4..] walk_one result
     DevBuf<uint16_t> d_flag, d_n_cigar;
     DevBuf<uint8_t> d_mapq;
@@ -273,6 +275,84 @@ void free_ingest(DeviceIngest *d) { delete d; }
         if (e_ != hipSuccess) return ngsq_bam_fail(NGSQ_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// The reader's pread workers: started once (they inherit the reader thread's CPU affinity), woken per step.
+// Threads created anew for every 64 MiB step spent a quarter of the step getting onto CPUs of their own.
+struct ReadPool {
+    static constexpr int NT_MAX = 16;
+    int nt = 0, fd = -1;
+    std::thread th[NT_MAX];
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0;
+    int running = 0;
+    bool quit = false;
+    uint8_t *dst = nullptr;
+    uint64_t pos = 0;
+    size_t want = 0, per = 0;
+    size_t got_part[NT_MAX] = {};
+    bool bad_part[NT_MAX] = {};
+
+    void open(int n, int file) {
+        nt = n;
+        fd = file;
+        for (int t = 0; t < nt; t++) th[t] = std::thread([this, t] { work(t); });
+    }
+    void work(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_go.wait(g, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen;
+            }
+            const size_t lo = std::min(want, per * (size_t)t), hi = std::min(want, lo + per);
+            size_t done = 0;
+            bool bad = false;
+            while (lo + done < hi) {
+                const ssize_t r = pread(fd, dst + lo + done, hi - lo - done, (off_t)(pos + lo + done));
+                if (r < 0) {
+                    bad = true;
+                    break;
+                }
+                if (r == 0) break; // end of file
+                done += (size_t)r;
+            }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                got_part[t] = done;
+                bad_part[t] = bad;
+                if (--running == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void start(uint8_t *to, uint64_t file_pos, size_t n, size_t piece) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            dst = to;
+            pos = file_pos;
+            want = n;
+            per = piece;
+            running = nt;
+            gen++;
+        }
+        cv_go.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return running == 0; });
+    }
+    ~ReadPool() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (int t = 0; t < nt; t++)
+            if (th[t].joinable()) th[t].join();
+    }
+};
+
 // Reader thread: fill the pinned buffers alternately with whole BGZF blocks (the bytes of a block
 // cut by the end of a chunk start the next one).  A chunk is as many blocks as inflate to `out_limit`
 // bytes; the file is read in steps of 64 MiB -- sixteen pread()s in parallel, one thread copying out
@@ -287,13 +367,15 @@ void reader_main(DeviceIngest *d, std::string path) {
     const size_t cap = 2 * d->comp_chunk;
     const uint64_t out_limit = d->raw_cap > 2 * CARRY_MAX ? d->raw_cap - CARRY_MAX : d->raw_cap / 2;
     constexpr size_t STEP = (size_t)64 << 20;
-    constexpr int NT_MAX = 16;
+    constexpr int NT_MAX = ReadPool::NT_MAX;
     // leave two cores of the quota to the thread that drives the GPU and to this one (it frames while the others read)
     const int NT = std::max(4, std::min(NT_MAX, effective_cores() - 2));
     double ratio = 0.0; // compressed bytes per inflated byte, from the chunks framed so far
     const int fd = fileno(d->f);
     // this thread, its pread workers and the pinned buffers they fill: all on the device's NUMA node
     pin_to_device_node(d->ctx->device);
+    ReadPool pool;
+    pool.open(NT, fd);
     // (pinning 2 x 512 MiB costs ~0.2 s: the second buffer is allocated by a helper while this thread fills the first)
     std::thread alloc1;
     std::string alloc1_err;
@@ -343,7 +425,8 @@ void reader_main(DeviceIngest *d, std::string path) {
             }
         }
         const double tr0 = now_ms();
-        double t_frame = 0;
+        double t_frame = 0, t_send = 0, t_join = 0, t_spawn = 0;
+        int n_steps = 0;
         memcpy(c.h, leftover.data(), leftover.size());
         c.fill = leftover.size();
         c.err.clear();
@@ -358,8 +441,10 @@ void reader_main(DeviceIngest *d, std::string path) {
                       d->d_comp_slot[k].reserve(cap + INFLATE_IN_SLACK) == hipSuccess;
         auto send = [&]() {
             if (h2d_ok && c.err.empty() && c.consumed > sent) {
+                const double ts = now_ms();
                 h2d_ok = hipMemcpyAsync(d->d_comp_slot[k].p + sent, c.h + sent, c.consumed - sent, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess;
                 sent = c.consumed;
+                t_send += now_ms() - ts;
             }
         };
         auto frame = [&]() { // blocks of c.h[consumed, fill) that fit the chunk
@@ -400,37 +485,24 @@ void reader_main(DeviceIngest *d, std::string path) {
                 want = std::min(want, STEP);
             }
             want = std::min(want, cap - c.fill);
-            size_t got_part[NT_MAX] = {};
-            bool bad_part[NT_MAX] = {};
             const size_t per = (want + NT - 1) / NT;
-            std::thread workers[NT_MAX];
-            for (int t = 0; t < NT; t++) {
-                workers[t] = std::thread([&, t]() {
-                    const size_t lo = std::min(want, per * (size_t)t), hi = std::min(want, lo + per);
-                    size_t done = 0;
-                    while (lo + done < hi) {
-                        const ssize_t r = pread(fd, c.h + c.fill + lo + done, hi - lo - done, (off_t)(file_pos + lo + done));
-                        if (r < 0) {
-                            bad_part[t] = true;
-                            break;
-                        }
-                        if (r == 0) break; // end of file
-                        done += (size_t)r;
-                    }
-                    got_part[t] = done;
-                });
-            }
+            const double tsp = now_ms();
+            n_steps++;
+            pool.start(c.h + c.fill, file_pos, want, per);
+            t_spawn += now_ms() - tsp;
             frame(); // what the previous step brought, while this one is on its way
             send();
             size_t got = 0;
             bool short_read = false;
+            const double tj = now_ms();
+            pool.wait();
             for (int t = 0; t < NT; t++) {
-                workers[t].join();
-                if (bad_part[t]) c.err = "read error on " + path;
+                if (pool.bad_part[t]) c.err = "read error on " + path;
                 const size_t lo = std::min(want, per * (size_t)t), hi = std::min(want, lo + per);
-                if (!short_read) got += got_part[t];
-                if (got_part[t] < hi - lo) short_read = true;
+                if (!short_read) got += pool.got_part[t];
+                if (pool.got_part[t] < hi - lo) short_read = true;
             }
+            t_join += now_ms() - tj;
             if (got < want) eof = true;
             file_pos += got;
             c.fill += got;
@@ -454,8 +526,9 @@ void reader_main(DeviceIngest *d, std::string path) {
             d->h2d_issued[k] = ok; // on failure the consumer copies on its own stream (and reports errors)
         }
         if (trace_on())
-            fprintf(stderr, "[ingest] reader: slot %d, %.1f MB read and %zu blocks framed in %.1f ms (framing %.1f ms of it), %.1f MB left over\n",
-                    k, c.fill / 1e6, c.blocks.size(), tr1 - tr0, t_frame, leftover.size() / 1e6);
+            fprintf(stderr, "[ingest] reader: slot %d, %.1f MB read and %zu blocks framed in %.1f ms (%d steps: starting the read threads %.1f, framing %.1f, "
+                            "queueing the copies %.1f, waiting for the reads %.1f ms), %.1f MB left over\n",
+                    k, c.fill / 1e6, c.blocks.size(), tr1 - tr0, n_steps, t_spawn, t_frame, t_send, t_join, leftover.size() / 1e6);
         {
             std::lock_guard<std::mutex> g(d->mu);
             c.ready = true;
@@ -476,45 +549,57 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     *out_total = 0;
     if (!n_seg) return NGSQ_OK;
     BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
-    BHIP(d->d_seg.reserve((size_t)n_seg * 2));
+    const uint32_t n_pieces = (uint32_t)((d->raw_len + REC_PIECE - 1) / REC_PIECE);
+    BHIP(d->d_pieces.reserve((size_t)n_seg * REC_CANDIDATES));
+    BHIP(d->d_seg.reserve((size_t)n_seg * 2)); // seg_base | chosen (32-bit words in the second half)
     BHIP(d->d_small.reserve(16));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, d->raw_len);
-        BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+        BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, d->d_pieces.p, st));
     }
     d->cand.resize((size_t)n_seg * REC_CANDIDATES);
     BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
     BHIP(hipStreamSynchronize(st));
-    d->seg.resize((size_t)n_seg * 2);
+    d->seg.assign((size_t)n_seg * 2, 0);
+    uint32_t *chosen = reinterpret_cast<uint32_t *>(d->seg.data() + n_seg);
     uint64_t cur = first, total_rec = 0;
     for (uint32_t s = 0; s < n_seg; s++) {
-        const uint64_t s1 = std::min<uint64_t>(((uint64_t)s + 1) * REC_SEGMENT, d->raw_len);
-        d->seg[s] = cur;
-        d->seg[n_seg + s] = total_rec;
+        const uint64_t s0 = (uint64_t)s * REC_SEGMENT, s1 = std::min<uint64_t>(s0 + REC_SEGMENT, d->raw_len);
+        chosen[s] = REC_NO_CHAIN;
+        d->seg[s] = total_rec;
         if (cur >= s1) continue;
         const RecCandidate *c = nullptr;
         for (uint32_t k = 0; k < REC_CANDIDATES; k++) {
             const RecCandidate &x = d->cand[(size_t)s * REC_CANDIDATES + k];
-            if (x.valid && x.start == cur) c = &x;
+            if (x.valid && x.start == cur) {
+                c = &x;
+                chosen[s] = k;
+            }
         }
         RecCandidate one{};
         if (!c) {
-            RecCandidate *d_one = reinterpret_cast<RecCandidate *>(d->d_small.p + 4);
-            BHIP(launch_walk_one(d->raw, d->raw_len, cur, s1, d_one, st));
+            // not in the table: one thread walks the segment with the host reader's rules (its piece table replaces candidate 0's)
+            RecCandidate *d_one = reinterpret_cast<RecCandidate *>(d->d_small.p + 8);
+            BHIP(launch_walk_one(d->raw, d->raw_len, cur, s0, s1, d_one, d->d_pieces.p + (size_t)s * REC_CANDIDATES, st));
             BHIP(hipMemcpyAsync(&one, d_one, sizeof one, hipMemcpyDeviceToHost, st));
             BHIP(hipStreamSynchronize(st));
             c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
+            chosen[s] = 0;
         }
         total_rec += c->count;
         // an invalid record ends the chain: the later segments get no entry (k_rec_offsets then reports
-        // the record's index from this segment)
+        // the record's index from the piece it lies in)
         cur = c->valid ? c->landing : d->raw_len;
     }
     d->tail_off = std::min(cur, d->raw_len);
     BHIP(d->d_rec_off.reserve(total_rec + 1));
     BHIP(hipMemcpyAsync(d->d_seg.p, d->seg.data(), d->seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     BHIP(hipMemsetAsync(d->d_small.p, 0xFF, sizeof(unsigned long long), st));
-    BHIP(launch_rec_offsets(d->raw, d->raw_len, n_seg, d->d_seg.p, d->d_seg.p + n_seg, d->d_rec_off.p, d->d_small.p, st));
+    {
+        KernelTimer kt(d->ctx, K_REC_INDEX, 0);
+        BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, reinterpret_cast<const uint32_t *>(d->d_seg.p + n_seg), d->d_seg.p,
+                                d->d_pieces.p, d->d_rec_off.p, d->d_small.p, st));
+    }
     unsigned long long bad = 0;
     BHIP(hipMemcpyAsync(&bad, d->d_small.p, sizeof bad, hipMemcpyDeviceToHost, st));
     BHIP(hipStreamSynchronize(st));
@@ -862,7 +947,8 @@ extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, 
         d->entry = d->raw_len;
         if (n_seg) {
             BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
-            BHIP(launch_rec_candidates(d->raw, d->raw_len, 0, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, st));
+            BHIP(d->d_pieces.reserve((size_t)n_seg * REC_CANDIDATES));
+            BHIP(launch_rec_candidates(d->raw, d->raw_len, 0, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, d->d_pieces.p, st));
             d->cand.resize((size_t)n_seg * REC_CANDIDATES);
             BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
             BHIP(hipStreamSynchronize(st));
@@ -948,7 +1034,14 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         b->dev_free = free_ingest;
         // (the two pinned buffers are allocated by the reader thread, on the device's NUMA node)
         BHIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
-        BHIP(hipStreamCreateWithFlags(&d->inf_stream, hipStreamNonBlocking));
+        {   // the inflate of the NEXT chunk runs beside the parse and the scan of this one, and it takes every
+            // wave slot its LDS allows: give it the lowest priority so that the short kernels of the context's stream get
+            // the slots its decoders free, instead of queueing behind all of them
+            int lo = 0, hi = 0;
+            BHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const char *e = getenv("NGSQ_INFLATE_PRIORITY");
+            BHIP(hipStreamCreateWithPriority(&d->inf_stream, hipStreamNonBlocking, e && atoi(e) == 0 ? 0 : lo)); // =0: normal priority (A/B measurements)
+        }
         for (auto &e : d->h2d_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : d->inf_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : d->raw_free) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -983,6 +1076,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     BHIP(d->d_mate.reserve(n + 64));
     BHIP(d->d_tlen.reserve(n + 64));
     BHIP(d->d_l_seq.reserve(n + 64));
+    BHIP(d->d_var_base.reserve(2 * n + 64));
     RecColumns col{};
     col.flag = d->d_flag.p;
     col.n_cigar = d->d_n_cigar.p;
@@ -995,7 +1089,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     BHIP(hipMemsetAsync(d->d_small.p + 1, 0, 3 * sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_COLUMNS, n * 36);
-        BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_small.p + 1, st));
+        BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_var_base.p, d->d_small.p + 1, st));
     }
     unsigned long long stats[3] = {0, 0, 0};
     BHIP(hipMemcpyAsync(stats, d->d_small.p + 1, sizeof stats, hipMemcpyDeviceToHost, st));
@@ -1044,7 +1138,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     col.qual_pitch = pitch_q;
     {
         KernelTimer kt(d->ctx, K_REC_COLUMNS, 2 * (so + qo + co * 4));
-        BHIP(launch_rec_var(d->raw, rec, n, col, so, qo, st));
+        BHIP(launch_rec_var(d->raw, d->d_var_base.p, n, col, so, qo, st));
     }
     d->cursor += n;
     b->n_read += n;

@@ -349,18 +349,29 @@ __device__ __noinline__ uint32_t resolve_long(const Lds &L, uint32_t alphabet, u
 
 // ---- CRC32 (gzip): GF(2) helpers in the reflected representation -----------------------------
 constexpr uint32_t CRC_POLY = 0xEDB88320u;
+// Slicing tables: t[k][b] = register after byte b followed by k zero bytes.  Sixteen bytes are then folded with sixteen
+// INDEPENDENT lookups (one LDS round trip) where the byte-wise table needs sixteen dependent ones: k_bgzf_crc was bound
+// by exactly that latency (0.98 ms per 520 MB; 16 KiB of tables per workgroup instead of 1 KiB).
+constexpr uint32_t CRC_SLICES = 16;
 struct CrcTable {
-    uint32_t t[256];
+    uint32_t t[CRC_SLICES][256];
     constexpr CrcTable() : t() {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
-            t[i] = c;
+            t[0][i] = c;
         }
+        for (uint32_t k = 1; k < CRC_SLICES; k++)
+            for (uint32_t i = 0; i < 256; i++) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFFu];
     }
 };
-// byte-wise table (copied to LDS by k_bgzf_crc)
+// (copied to LDS by k_bgzf_crc)
 __constant__ CrcTable c_crc;
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
 __device__ uint32_t crc_mul(uint32_t a, uint32_t b) { // a * b mod P
     uint32_t p = 0;
     for (uint32_t m = 1u << 31; m; m >>= 1) {
@@ -746,13 +757,14 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 // accounted for, and leading zero bytes leave a zero register at zero): the lane that holds byte 0
 // starts from 0xFFFFFFFF, the others from 0, and the slices are combined pairwise in six steps,
 // register(A || B) = register(A) * x^(8 |B|) + register(B), with |B| the same for every pair of a step.
-__global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ out, const BgzfBlock *__restrict__ blocks,
-                                                  uint32_t n_blocks, uint32_t *__restrict__ status) {
-    __shared__ uint32_t s_tab[256];
-    s_tab[threadIdx.x] = c_crc.t[threadIdx.x];
+constexpr uint32_t CRC_WAVES = 8; // BGZF blocks per workgroup: the tables are loaded once for all of them
+__global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__restrict__ out, const BgzfBlock *__restrict__ blocks,
+                                                             uint32_t n_blocks, uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_tab[CRC_SLICES * 256];
+    for (uint32_t k = threadIdx.x; k < CRC_SLICES * 256; k += 64 * CRC_WAVES) s_tab[k] = c_crc.t[k >> 8][k & 0xFFu];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t bi = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t bi = blockIdx.x * CRC_WAVES + (threadIdx.x >> 6);
     if (bi >= n_blocks) return;
     const uint32_t isize = uni(blocks[bi].isize);
     if (uni(status[bi]) != INF_OK) return;
@@ -769,11 +781,19 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ ou
         uint32_t w[16];
         __builtin_memcpy(w, p + i, 64);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            c ^= w[k];
-#pragma unroll
-            for (int q = 0; q < 4; q++) c = s_tab[c & 0xFFu] ^ (c >> 8);
+        for (int k = 0; k < 16; k += 4) {
+            const uint32_t x0 = c ^ w[k], x1 = w[k + 1], x2 = w[k + 2], x3 = w[k + 3];
+            c = s_tab[15 * 256 + (x0 & 0xFFu)] ^ s_tab[14 * 256 + ((x0 >> 8) & 0xFFu)] ^ s_tab[13 * 256 + ((x0 >> 16) & 0xFFu)] ^
+                s_tab[12 * 256 + (x0 >> 24)] ^ s_tab[11 * 256 + (x1 & 0xFFu)] ^ s_tab[10 * 256 + ((x1 >> 8) & 0xFFu)] ^
+                s_tab[9 * 256 + ((x1 >> 16) & 0xFFu)] ^ s_tab[8 * 256 + (x1 >> 24)] ^ s_tab[7 * 256 + (x2 & 0xFFu)] ^
+                s_tab[6 * 256 + ((x2 >> 8) & 0xFFu)] ^ s_tab[5 * 256 + ((x2 >> 16) & 0xFFu)] ^ s_tab[4 * 256 + (x2 >> 24)] ^
+                s_tab[3 * 256 + (x3 & 0xFFu)] ^ s_tab[2 * 256 + ((x3 >> 8) & 0xFFu)] ^ s_tab[1 * 256 + ((x3 >> 16) & 0xFFu)] ^
+                s_tab[x3 >> 24];
         }
+    }
+    for (; i + 4 <= b; i += 4) {
+        const uint32_t x = c ^ ld32u(p + i);
+        c = s_tab[3 * 256 + (x & 0xFFu)] ^ s_tab[2 * 256 + ((x >> 8) & 0xFFu)] ^ s_tab[1 * 256 + ((x >> 16) & 0xFFu)] ^ s_tab[x >> 24];
     }
     for (; i < b; i++) c = s_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
     // pairwise combination: after step j the lanes whose low j+1 bits are ones hold 2^(j+1) slices
@@ -790,7 +810,7 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const uint8_t *__restrict__ ou
 
 hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
-    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, s, out, blocks, n_blocks, status);
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + CRC_WAVES - 1) / CRC_WAVES), dim3(64 * CRC_WAVES), 0, s, out, blocks, n_blocks, status);
     return hipGetLastError();
 }
 

@@ -43,8 +43,10 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
 hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s);
 
 // ---- BAM record parse (csrc/bam_device.hip) -------------------------------------------------------
-constexpr uint64_t REC_SEGMENT = 65536;  // bytes of the inflated stream walked by one lane / wave
-constexpr uint32_t REC_CANDIDATES = 2;   // chain starts kept per segment (the walks are serial: each one costs)
+constexpr uint64_t REC_SEGMENT = 65536;  // bytes of the inflated stream whose record chain one wave finds
+constexpr uint32_t REC_CANDIDATES = 2;   // chain starts kept per segment
+constexpr uint32_t REC_PIECES = 16;      // a segment's chain is written out by 16 lanes, 4 KiB each
+constexpr uint64_t REC_PIECE = REC_SEGMENT / REC_PIECES;
 
 struct RecCandidate {
     uint64_t start;   // offset of a plausible record start inside the segment
@@ -52,6 +54,13 @@ struct RecCandidate {
     uint32_t count;   // records on the chain inside the segment
     uint32_t valid;
 };
+// a candidate's chain per 4 KiB piece of the segment (stays on the device): the first record start of the chain at or
+// behind the piece's start, relative to the segment's start (0xFFFFFFFF: the chain has ended before), and the number of
+// records of the chain in front of it
+struct RecPieces {
+    uint32_t rel[REC_PIECES], cnt[REC_PIECES];
+};
+constexpr uint32_t REC_NO_CHAIN = 0xFFFFFFFFu;
 
 // device columns of one batch (include/ngsq.h layout rules)
 struct RecColumns {
@@ -65,21 +74,28 @@ struct RecColumns {
     uint32_t seq_pitch, qual_pitch;
 };
 
+// cand / pieces: REC_CANDIDATES entries per segment
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
-                                 RecCandidate *cand, hipStream_t s);
-hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t end, RecCandidate *out,
-                           hipStream_t s);
-hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_seg, const uint64_t *seg_entry,
-                              const uint64_t *seg_base, uint64_t *rec_off, unsigned long long *bad, hipStream_t s);
+                                 RecCandidate *cand, RecPieces *pieces, hipStream_t s);
+// the chain from `start` inside the segment [seg_start, end), walked by one thread with the host reader's rules
+hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t seg_start, uint64_t end, RecCandidate *out,
+                           RecPieces *pieces, hipStream_t s);
+// chosen[s]: which candidate of segment s is on the file's chain (REC_NO_CHAIN: none starts there); seg_base[s]: index of
+// its first record.  One lane per REC_PIECE bytes writes the offsets of the records that start there.
+hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
+                              const RecPieces *pieces, uint64_t *rec_off, unsigned long long *bad, hipStream_t s);
 // out[0] = number of entries of the ascending array a[0, n) that are < value (one thread)
 hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value, unsigned long long *out, hipStream_t s);
-hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c,
+// also writes var_base[i] = offset of record i's CIGAR in raw and var_base[n + i] = offset of its SEQ (2 n entries:
+// what launch_rec_var starts from)
+hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
                             unsigned long long *stats, hipStream_t s);
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,
                               uint64_t *qual_len, uint64_t *cig_len, hipStream_t s);
 // exclusive prefix sums of n+1 entries in place (entry n = total); tmp: scratch of *tmp_bytes
 hipError_t launch_exclusive_scan_u64(uint64_t *data, uint64_t n_plus_1, void *tmp, size_t *tmp_bytes, hipStream_t s);
-hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t seq_bytes,
+// c.flag .. c.l_seq filled by launch_rec_fixed, var_base from it
+hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t n, const RecColumns &c, uint64_t seq_bytes,
                           uint64_t qual_bytes, hipStream_t s);
 
 } // namespace ngsq
