@@ -271,6 +271,10 @@ int ngsq_device_count(void);
 const char *ngsq_facet_name(uint32_t facet_bit);
 /* thread-local message of the last failing call that had no context */
 const char *ngsq_last_global_error(void);
+/* A finished device ingest (ngsq_bam_close) leaves its GiB-sized device and pinned buffers in a process-wide cache for
+ * the next file: allocating and freeing them costs about as much as scanning 4 GB of BAM.  This gives them back to the
+ * driver (ngsq_destroy does it too) and returns the bytes released.  NGSQ_POOL_MB=0 in the environment disables the cache. */
+uint64_t ngsq_release_cached_memory(void);
 
 int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out);
 void ngsq_destroy(ngsq_ctx *ctx);

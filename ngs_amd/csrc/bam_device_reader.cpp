@@ -25,6 +25,7 @@
 #include "bgzf.h"
 #include "context.h"
 #include "ingest_kernels.h"
+#include "mem_pool.h"
 
 using namespace ngsq;
 
@@ -63,22 +64,26 @@ const char *inflate_status_text(uint32_t s) {
 
 
 // growable device buffer
+// a device array that only grows; its memory comes from (and goes back to) the process's block cache (mem_pool.h)
 template <typename T> struct DevBuf {
     T *p = nullptr;
-    size_t cap = 0; // elements
+    size_t cap = 0;   // elements
+    size_t bytes = 0; // of the block behind p
     hipError_t reserve(size_t n, bool keep = false) {
         if (n <= cap) return hipSuccess;
         const size_t want = n + n / 8 + 64;
-        T *q = nullptr;
-        hipError_t e = hipMalloc((void **)&q, want * sizeof(T));
+        void *q = nullptr;
+        size_t got = 0;
+        hipError_t e = ngsq::pool_device_alloc(&q, want * sizeof(T), &got);
         if (e != hipSuccess) return e;
         if (keep && p && cap) (void)hipMemcpy(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
-        (void)hipFree(p);
-        p = q;
-        cap = want;
+        ngsq::pool_device_free(p, bytes);
+        p = static_cast<T *>(q);
+        cap = got / sizeof(T);
+        bytes = got;
         return hipSuccess;
     }
-    ~DevBuf() { (void)hipFree(p); }
+    ~DevBuf() { ngsq::pool_device_free(p, bytes); }
 };
 
 // NGSQ_INGEST_TRACE=1: wall-clock of the ingest stages on stderr (measurement aid)
@@ -170,6 +175,7 @@ struct DeviceIngest {
     // thread reads and frames chunk k+1 into the other pinned buffer.
     struct HostChunk {
         uint8_t *h = nullptr; // pinned, 2 x comp_chunk
+        size_t h_bytes = 0;   // of the block behind h (mem_pool.h)
         size_t fill = 0, consumed = 0;
         uint64_t total = 0; // decompressed bytes of `blocks`
         std::vector<BgzfBlock> blocks;
@@ -256,7 +262,7 @@ struct DeviceIngest {
         for (auto &e : raw_free)
             if (e) (void)hipEventDestroy(e);
         for (auto &c : hc)
-            if (c.h) (void)hipHostFree(c.h);
+            if (c.h) pool_pinned_free(c.h, c.h_bytes);
     }
 };
 
@@ -384,10 +390,11 @@ void reader_main(DeviceIngest *d, std::string path) {
         const double ta = now_ms();
         if (hipSetDevice(d->ctx->device) != hipSuccess) err = "hipSetDevice failed in the reader thread";
         alloc1 = std::thread([&]() {
-            if (hipSetDevice(d->ctx->device) != hipSuccess || hipHostMalloc((void **)&d->hc[1].h, cap, hipHostMallocDefault) != hipSuccess)
+            if (hipSetDevice(d->ctx->device) != hipSuccess ||
+                ngsq::pool_pinned_alloc((void **)&d->hc[1].h, cap, &d->hc[1].h_bytes) != hipSuccess)
                 alloc1_err = "hipHostMalloc of the ingest buffers failed";
         });
-        if (err.empty() && hipHostMalloc((void **)&d->hc[0].h, cap, hipHostMallocDefault) != hipSuccess) err = "hipHostMalloc of the ingest buffers failed";
+        if (err.empty() && ngsq::pool_pinned_alloc((void **)&d->hc[0].h, cap, &d->hc[0].h_bytes) != hipSuccess) err = "hipHostMalloc of the ingest buffers failed";
         if (trace_on()) fprintf(stderr, "[ingest] reader: first pinned buffer after %.1f ms\n", now_ms() - ta);
         if (!err.empty()) {
             alloc1.join();
@@ -891,7 +898,7 @@ extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, 
     // the shard's blocks + up to four more, which hold the end of its last record
     const uint64_t want = std::min<uint64_t>(file_size, hi + ((uint64_t)4 << 16)) - lo;
     uint8_t *h = nullptr;
-    BHIP(hipHostMalloc((void **)&h, want + 64, hipHostMallocDefault));
+    BHIP(ngsq::pool_pinned_alloc((void **)&h, want + 64, &d->hc[0].h_bytes));
     d->hc[0].h = h; // freed with the ingest state
     if (fseeko(d->f, (off_t)lo, SEEK_SET) != 0 || fread(h, 1, want, d->f) != want)
         return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "read error on %s", b->path.c_str());

@@ -395,7 +395,15 @@ void usage() {
 
 } // namespace
 
+// NGSQ_INGEST_TRACE=1: wall clock of the command's stages on stderr (measurement aid)
+static void milestone(const char *what) {
+    static const bool on = getenv("NGSQ_INGEST_TRACE") && atoi(getenv("NGSQ_INGEST_TRACE"));
+    static const auto t0 = std::chrono::steady_clock::now();
+    if (on) fprintf(stderr, "[ngs] %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+}
+
 int main(int argc, char **argv) {
+    milestone("main");
     Args a;
     std::vector<std::string> pos;
     bool saw_qc = false;
@@ -494,6 +502,7 @@ int main(int argc, char **argv) {
     }
     ngsq_bam *bam = nullptr;
     if (ngsq_bam_open(a.src.c_str(), a.threads, &bam) != NGSQ_OK) bail(ngsq_bam_last_error());
+    milestone("header read");
     if (ngsq_bam_check_index(a.src.c_str()) != NGSQ_OK) bail(ngsq_bam_last_error());
     {
         std::error_code ec;
@@ -657,7 +666,9 @@ int main(int argc, char **argv) {
     cfg.sorted_input = (!force_array && !a.has_n && (facets & NGSQ_FACET_COVERAGE) && (a.coverage == 1 || (a.coverage == 0 && header_sorted))) ? 1 : 0;
     // shards behind the first: a read of the shard in front may reach this far into this shard's first positions
     cfg.cov_head_guard = (worker && a.rank > 0 && cfg.sorted_input) ? (1u << 20) : 0;
+    milestone("checks done");
     if (ngsq_create(&cfg, &ctx) != NGSQ_OK) bail(ngsq_last_global_error());
+    milestone("context created (HIP initialised)");
     if (facets & NGSQ_FACET_FEATURES) {
         ngsq_features f;
         memset(&f, 0, sizeof f);
@@ -830,7 +841,9 @@ int main(int argc, char **argv) {
         int rc = NGSQ_OK;
         std::string why;
         if (worker && (rc = ngsq_exchange(ctx, comm, nullptr)) != NGSQ_OK) why = ngsq_comm_last_error(comm);
+        milestone("records scanned");
         if (rc == NGSQ_OK && (rc = ngsq_finalize(ctx)) != NGSQ_OK) why = ngsq_last_error(ctx);
+        milestone("finalized");
         if (rc == NGSQ_ERR_UNSORTED && a.coverage == 0 && !force_array) {
             // the header promised coordinate order and the records broke it (every worker of a --gpus run sees the
             // same verdict: the counters are summed): scan again, in this process, on the depth arrays
@@ -888,8 +901,10 @@ int main(int argc, char **argv) {
     FILE *of = fopen(out_path.c_str(), "wb");
     if (!of || fwrite(buf.data(), 1, (size_t)need, of) != (size_t)need) bail("could not write " + out_path);
     fclose(of);
+    milestone("results written");
     ngsq_destroy(ctx);
     ngsq_bam_close(bam);
+    milestone("context and reader released");
     if (comm) {
         ngsq_comm_barrier(comm);
         ngsq_comm_destroy(comm);

@@ -18,6 +18,7 @@
 #include "../../include/ngsq.h"
 #include "../../include/ngsq_shared.h"
 #include "context.h"
+#include "mem_pool.h"
 
 using namespace ngsq;
 
@@ -80,6 +81,8 @@ static const char *const KERNEL_NAMES[K_COUNT] = {"fields", "gc", "qual", "edits
 extern "C" {
 
 uint32_t ngsq_abi_version(void) { return NGSQ_ABI_VERSION; }
+
+uint64_t ngsq_release_cached_memory(void) { return (uint64_t)ngsq::pool_trim(); }
 
 int ngsq_device_count(void) {
     int n = 0;
@@ -310,6 +313,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
 void ngsq_destroy(ngsq_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)ngsq::pool_trim(); // blocks a finished device ingest left for the next file (mem_pool.h)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_ft_idx);
     (void)hipFree(c->d_ft_starts);

@@ -251,6 +251,7 @@ PROTOTYPES = {
     "ngsq_last_global_error": (C.c_char_p, []),
     "ngsq_create": (C.c_int, [C.POINTER(Config), C.POINTER(ctx_p)]),
     "ngsq_destroy": (None, [ctx_p]),
+    "ngsq_release_cached_memory": (C.c_uint64, []),
     "ngsq_last_error": (C.c_char_p, [ctx_p]),
     "ngsq_process_batch": (C.c_int, [ctx_p, C.POINTER(Batch), C.c_uint32]),
     "ngsq_finalize": (C.c_int, [ctx_p]),

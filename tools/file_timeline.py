@@ -58,6 +58,13 @@ def show(d):
     busy += cur_e - cur_s
     print("last scan: %d kernels, %.1f ms from the first inflate to the last kernel, GPU busy %.1f ms (%.0f %%), %d inflate launches"
           % (len(scan), (t_hi - t_lo) / 1e6, busy / 1e6, 100.0 * busy / (t_hi - t_lo), len(last)))
+    # cadence: start of every inflate launch and the idle time of the GPU in front of it
+    prev_end, line = None, []
+    for s_, e_, nm, *_ in scan:
+        if "bgzf_inflate" in nm:
+            line.append("%.1f(+%.1f)" % ((s_ - t_lo) / 1e6, (s_ - prev_end) / 1e6 if prev_end else 0.0))
+        prev_end = max(prev_end or 0, e_)
+    print("inflate starts, ms (idle in front):", " ".join(line))
     mid = sorted(last)[len(last) // 2][0]
     end = sorted(last)[min(len(last) - 1, len(last) // 2 + 2)][1]
     print("  start_ms   dur_ms  queue stream kernel")
