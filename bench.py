@@ -535,8 +535,9 @@ def leg_file(lib, host, ffi, args):
         ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=1024, gc_seed=GC_SEED, sorted_input=True, timing=True, lib=lib)
         try:
             names = ["chr1", "chr2"]
-            best, doc = None, None
-            for rep in range(2):
+            best, doc, times = None, None, []
+            lib.ngsq_release_cached_memory()   # the first file of a process finds no cached blocks
+            for rep in range(3):
                 ctx.reset()
                 ctx.kernel_timing_reset()
                 t0 = time.perf_counter()
@@ -559,6 +560,7 @@ def leg_file(lib, host, ffi, args):
                 ctx.finalize()
                 dt = time.perf_counter() - t0
                 assert got == n, (got, n)
+                times.append(round(dt, 3))
                 if best is None or dt < best:
                     best, timing = dt, ctx.kernel_timing()
                     after_first = ((n - first[1]) / max(t0 + dt - first[0], 1e-9), first[0] - t0) if first and n > first[1] else None
@@ -569,7 +571,11 @@ def leg_file(lib, host, ffi, args):
             out["in_process_device_ingest"] = {"seconds": round(best, 3), "records_per_s": round(n / best, 1),
                                                "compressed_GB_per_s": round(out["bam_bytes"] / best / 1e9, 2),
                                                "includes": "file open, reads, H2D of the compressed bytes, inflate, parse, "
-                                                           "all default facets, finalize",
+                                                           "all default facets, finalize, close",
+                                               "seconds_each_scan": times,
+                                               "note": "scan 0 allocates and pins the pipeline's buffers (and frees them in close "
+                                                       "without the cache); later files of a process take them from the block "
+                                                       "cache (mem_pool.cpp; NGSQ_POOL_MB=0 disables it)",
                                                "kernels": kernel_table(timing)}
             if after_first:
                 out["in_process_device_ingest"]["first_batch_after_s"] = round(after_first[1], 3)

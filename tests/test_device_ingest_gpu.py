@@ -265,6 +265,31 @@ def test_device_reader_synthetic_bam_and_results(gpu_lib, ctx, tmp_path):
     assert run(True) == run(False)
 
 
+def test_block_cache_serves_the_next_file(gpu_lib, ctx, tmp_path):
+    """mem_pool.cpp: the buffers of a finished device ingest are kept for the next file of the process --
+    same batches from recycled blocks, ngsq_release_cached_memory() gives them back, and a third scan
+    (fresh allocations again) still reads the same."""
+    cfg = host.synth_config(40_000, mode=ffi.SYNTH_FIXED, ref_len=3_000_000)
+    p = str(tmp_path / "c.bam")
+    assert gpu_lib.ngsq_synth_write_bam(C.byref(cfg), p.encode(), 40_000, 6, 4) == 0
+    gpu_lib.ngsq_release_cached_memory()
+    first, n1 = read_all_device(gpu_lib, ctx, p, 15_000)
+    again, n2 = read_all_device(gpu_lib, ctx, p, 15_000)       # from the cache
+    released = int(gpu_lib.ngsq_release_cached_memory())
+    assert released >= 2 << 20, released                        # at least the raw buffers of the 1 MiB.. chunk were parked
+    assert int(gpu_lib.ngsq_release_cached_memory()) == 0       # nothing left
+    third, n3 = read_all_device(gpu_lib, ctx, p, 15_000)
+    assert n1 == n2 == n3 == 40_000
+    same_batches(first, again)
+    same_batches(first, third)
+    # a different shape next: blocks of the wrong size are not handed out for it
+    hb = random_batch(np.random.default_rng(5), 3000, [50_000, 7_000], max_len=300, weird=True)
+    q = str(tmp_path / "r.bam")
+    bamio.write_bam(q, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=5000)
+    dbatches, dn = read_all_device(gpu_lib, ctx, q, 1 << 20)
+    assert dn == hb.n and [r for b in dbatches for r in records_of(b)] == records_of(hb)
+
+
 def test_device_reader_errors(gpu_lib, ctx, tmp_path):
     rng = np.random.default_rng(1)
     hb = random_batch(rng, 2000, [9000], max_len=80)
