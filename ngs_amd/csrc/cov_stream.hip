@@ -39,7 +39,10 @@ typedef unsigned long long u64;
 
 constexpr uint32_t ST_THREADS = 256;
 constexpr uint32_t ST_WAVES = ST_THREADS / 64;
-constexpr uint32_t ST_W = 1024; // positions of one wave's LDS window
+#ifndef ST_W_N
+#define ST_W_N 1024
+#endif
+constexpr uint32_t ST_W = ST_W_N; // positions of one wave's LDS window
 #ifndef ST_LIST_N
 #define ST_LIST_N 232
 #endif
