@@ -116,17 +116,52 @@ def extra_sweep(lib, seeds):
     print("extra sweep ok")
 
 
+def ingest_sweep(lib, seeds):
+    """Device reader against the host reader, batch for batch and byte for byte, on shapes that stress the record index
+    and the column kernels: reads from 1 base to 20 kb (records longer than a 4 KiB piece and than a 64 KiB segment),
+    BGZF blocks of 0.7-60 kB, ingest chunks of 1 MiB to 1 GiB (cut records carried over), batches of 257 records to
+    everything, the block cache on (buffers of the previous seed recycled)."""
+    from tests.test_bam_ingest import read_all
+    from tests.test_device_ingest_gpu import read_all_device, same_batches
+    td = tempfile.mkdtemp(prefix="ngsq_fuzz_ingest_")
+    ctx = host.QcContext([100_000, 50_000], [1, 1], lib=lib)
+    for seed in range(seeds):
+        rng = np.random.default_rng(7000 + seed)
+        max_len = int(rng.choice([1, 36, 150, 151, 300, 1000, 5000, 20_000]))
+        n = int(rng.integers(1, max(2, min(30_000, 6_000_000 // max(max_len, 40)))))
+        ref_len = [100_000, 50_000]
+        uniform = rng.random() < 0.4
+        hb = random_batch(rng, n, ref_len, max_len=max_len, min_len=max_len if uniform else int(rng.integers(0, max_len + 1)),
+                          weird=bool(rng.integers(0, 2)))
+        p = os.path.join(td, "f.bam")
+        bamio.write_bam(p, hb, ["chr1", "chr2"], ref_len, block_payload=int(rng.choice([700, 4000, 60000])))
+        os.environ["NGSQ_INGEST_RAW_MB"] = str(int(rng.choice([1, 4, 1024])))
+        max_records = int(rng.choice([257, 2500, 1 << 20]))
+        _, hbatches, hn = read_all(lib, p, max_records)
+        dbatches, dn = read_all_device(lib, ctx, p, max_records)
+        assert dn == hn == hb.n, (dn, hn, hb.n)
+        same_batches(dbatches, hbatches)
+        print(f"ingest seed {seed}: n={n} max_len={max_len} uniform={uniform} chunk={os.environ['NGSQ_INGEST_RAW_MB']} MiB "
+              f"batch={max_records} ok", flush=True)
+    os.environ.pop("NGSQ_INGEST_RAW_MB", None)
+    ctx.close()
+    print("ingest sweep ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--extra", type=int, default=0, help="seeds of the Edits + Genomic Features sweep")
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--sorted", type=int, default=0, help="seeds of the sorted_input (streaming Coverage) sweep")
+    ap.add_argument("--ingest", type=int, default=0, help="seeds of the device-reader-against-host-reader sweep")
     a = ap.parse_args()
     lib = ffi.load_library()
     if a.sorted:
         sorted_sweep(lib, a.sorted)
     if a.extra:
         extra_sweep(lib, a.extra)
+    if a.ingest:
+        ingest_sweep(lib, a.ingest)
     td = tempfile.mkdtemp(prefix="ngsq_fuzz_")
     for seed in range(a.seeds):
         rng = np.random.default_rng(1000 + seed)
