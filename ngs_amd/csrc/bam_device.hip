@@ -314,17 +314,22 @@ template <bool QUAL>
 __device__ __forceinline__ uint32_t row_tail(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
                                              const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t r, uint32_t k, uint32_t pitch,
                                              uint32_t len, const uint8_t *src) {
-    // the end of a row (its padding, and perhaps the first bytes of the next row)
+    // the end of a row: its padding, and the first bytes of the next row -- of the next THREE rows when the pitch is
+    // below four bytes (reads of one to three bases)
     constexpr uint32_t FILL = QUAL ? 0xFFu : 0u;
     uint32_t v = 0;
 #pragma unroll
     for (uint32_t b = 0; b < 4; b++) {
-        uint32_t byte = FILL;
-        if (k + b < pitch) {
-            if (k + b < len) byte = src[k + b];
-        } else if (r + 1 < n) {
-            const uint32_t k2 = k + b - pitch, l2 = l_seq[r + 1], sb2 = (l2 + 1) / 2;
-            if (k2 < (QUAL ? l2 : sb2)) byte = raw[seq_src[r + 1] + (QUAL ? sb2 : 0u) + k2];
+        uint32_t byte = FILL, rb = r, kb = k + b;
+        while (kb >= pitch) {
+            kb -= pitch;
+            rb += 1;
+        }
+        if (rb == r) {
+            if (kb < len) byte = src[kb];
+        } else if (rb < n) {
+            const uint32_t l2 = l_seq[rb], sb2 = (l2 + 1) / 2;
+            if (kb < (QUAL ? l2 : sb2)) byte = raw[seq_src[rb] + (QUAL ? sb2 : 0u) + kb];
         }
         v |= byte << (8 * b);
     }

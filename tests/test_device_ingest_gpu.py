@@ -208,7 +208,7 @@ def same_batches(a, b):
                 assert np.array_equal(x.cols[k], y.cols[k]), k
 
 
-@pytest.mark.parametrize("case", ["ragged", "uniform150", "long", "multiop150"])
+@pytest.mark.parametrize("case", ["ragged", "uniform150", "long", "multiop150", "one_base", "three_bases"])
 def test_device_reader_matches_host_reader(gpu_lib, ctx, tmp_path, monkeypatch, case):
     rng = np.random.default_rng(19)
     ref_len = [50_000, 7_000]
@@ -218,6 +218,10 @@ def test_device_reader_matches_host_reader(gpu_lib, ctx, tmp_path, monkeypatch, 
         hb = random_batch(rng, 6000, ref_len, max_len=150, min_len=150, weird=False)
     elif case == "multiop150":
         hb = random_batch(rng, 6000, ref_len, max_len=150, min_len=140, weird=True)
+    elif case == "one_base":      # fixed-pitch rows narrower than the dword the column kernel writes (found by fuzz_parity --ingest)
+        hb = random_batch(rng, 6000, ref_len, max_len=1, min_len=0, weird=False)
+    elif case == "three_bases":
+        hb = random_batch(rng, 6000, ref_len, max_len=3, min_len=1, weird=True)
     else:
         hb = random_batch(rng, 700, ref_len, max_len=900, min_len=321, weird=False)
     path = str(tmp_path / "t.bam")
