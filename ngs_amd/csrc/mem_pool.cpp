@@ -79,12 +79,15 @@ hipError_t pool_device_alloc(void **p, size_t bytes, size_t *got) {
 
 void pool_device_free(void *p, size_t got) {
     if (!p) return;
-    int dev = 0;
-    if (got >= POOL_MIN && hipGetDevice(&dev) == hipSuccess) {
+    int cur = 0;
+    if (got >= POOL_MIN && hipGetDevice(&cur) == hipSuccess) {
+        int dev = cur;
         hipPointerAttribute_t attr{};
         if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
         // hipFree() waits for the device; a block that goes to the cache may be handed to another stream next
+        if (dev != cur) (void)hipSetDevice(dev);
         (void)hipDeviceSynchronize();
+        if (dev != cur) (void)hipSetDevice(cur);
         if (pool().put(Block{p, got, dev})) return;
     }
     (void)hipFree(p);
