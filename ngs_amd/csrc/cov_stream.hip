@@ -56,7 +56,10 @@ constexpr uint32_t ST_LIST = ST_LIST_N;  // entries of a wave's list of open end
 // copies of each (lane & 3 picks the copy), re-anchored when the depth at the start of a pass drifts out of its
 // middle three quarters -- the copies are then summed into the wave's histogram.  Depths outside the window go to the
 // histogram directly, in the same instruction (one address select per lane, no branch).
-constexpr uint32_t ST_HOT_BINS = ST_HOT_BINS_N, ST_HOT_REP = 4, ST_HOT = ST_HOT_BINS * ST_HOT_REP;
+#ifndef ST_HOT_REP_N
+#define ST_HOT_REP_N 4
+#endif
+constexpr uint32_t ST_HOT_BINS = ST_HOT_BINS_N, ST_HOT_REP = ST_HOT_REP_N, ST_HOT = ST_HOT_BINS * ST_HOT_REP;
 #ifndef ST_EXP
 #define ST_EXP 0 // measurement builds only (tools/exp_stream.sh): 1 no look-back, 2 no prefix passes, 3 no histogram atomics, 4 neither
 #endif
@@ -221,14 +224,17 @@ __global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, De
         lane_bin = 0;
     };
     auto flush_hot = [&]() { // the copies of each hot bin -> the wave's histogram (lane = bin of the window)
-        static_assert(ST_HOT_REP == 4 && ST_HOT_BINS <= 64, "one uint4 per lane");
-        uint4 *const cell = reinterpret_cast<uint4 *>(hot) + (lane < ST_HOT_BINS ? lane : 0u);
-        uint4 v = make_uint4(0, 0, 0, 0);
+        static_assert((ST_HOT_REP == 4 || ST_HOT_REP == 8) && ST_HOT_BINS <= 64, "one or two uint4 per lane");
+        uint4 *const cell = reinterpret_cast<uint4 *>(hot) + (lane < ST_HOT_BINS ? lane : 0u) * (ST_HOT_REP / 4);
+        uint32_t t = 0;
         if (lane < ST_HOT_BINS) {
-            v = *cell;
-            *cell = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t q = 0; q < ST_HOT_REP / 4; q++) {
+                const uint4 v = cell[q];
+                cell[q] = make_uint4(0, 0, 0, 0);
+                t += v.x + v.y + v.z + v.w;
+            }
         }
-        const uint32_t t = v.x + v.y + v.z + v.w;
         const uint32_t depth = hot_base + lane;
         const uint32_t bin = depth <= a.cov_cap ? depth : a.cov_cap + 1;
         if (t) atomicAdd(&hist[bin < hw ? bin : bin - hw], bin < hw ? t : t << 16);
