@@ -337,12 +337,13 @@ __device__ __forceinline__ uint32_t row_tail(const uint8_t *__restrict__ raw, co
 }
 
 // seq_src[i] = offset of record i's SEQ in raw.  Four destination dwords per thread, their loads issued together:
-// record index -> (seq_src, l_seq) -> source bytes is two dependent memory latencies, and with one dword per thread
-// the kernel did nothing but wait for them (1 TB/s).
+// record index -> (seq_src, l_seq) -> source bytes is two dependent memory latencies.  This kernel serves rows
+// narrower than a dword (reads of one to three bases / one to six bases: a dword then spans up to four rows);
+// k_rec_rows below is the one for everything else.
 template <bool QUAL>
-__global__ __launch_bounds__(256) void k_rec_rows(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
-                                                  const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t *__restrict__ dst,
-                                                  uint32_t pitch, uint64_t n_dwords) {
+__global__ __launch_bounds__(256) void k_rec_rows_narrow(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
+                                                         const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t *__restrict__ dst,
+                                                         uint32_t pitch, uint64_t n_dwords) {
     constexpr uint32_t FILL = QUAL ? 0xFFu : 0u;
     constexpr int U = 4;
     for (uint64_t d0 = (uint64_t)blockIdx.x * (256 * U) + threadIdx.x; d0 < n_dwords; d0 += (uint64_t)gridDim.x * (256 * U)) {
@@ -373,6 +374,62 @@ __global__ __launch_bounds__(256) void k_rec_rows(const uint8_t *__restrict__ ra
             if (!in[u]) v[u] = FILL * 0x01010101u;
             else if (!fast[u]) v[u] = row_tail<QUAL>(raw, seq_src, l_seq, n, r[u], k[u], pitch, len[u], src[u]);
             dst[d] = v[u];
+        }
+    }
+}
+
+// The kernel for rows of four bytes and more.  A destination dword holds bytes of at most two rows: its own row's bytes
+// and the first bytes of the next row are BOTH fetched (one unaligned dword each) and the result is put together with
+// byte masks -- no branch.  With the end of a row handled on a path of its own, every wave held a few such lanes and
+// walked that path's dependent loads with the others idle: 0.64 ms for the two columns of a 512 MiB chunk, 0.36 ms this
+// way (a plain copy of the same bytes: 0.15 ms; tools/cand_probe.hip's sibling measurements in DESIGN.md section 9).
+__device__ __forceinline__ uint32_t byte_mask(uint32_t n_bytes) { return n_bytes >= 4 ? 0xFFFFFFFFu : (1u << (8 * n_bytes)) - 1u; }
+
+template <bool QUAL>
+__global__ __launch_bounds__(256) void k_rec_rows(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
+                                                  const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t *__restrict__ dst,
+                                                  uint32_t pitch, uint64_t n_dwords) {
+    constexpr uint32_t FILLW = QUAL ? 0xFFFFFFFFu : 0u;
+    constexpr int U = 4;
+    for (uint64_t d0 = (uint64_t)blockIdx.x * (256 * U) + threadIdx.x; d0 < n_dwords; d0 += (uint64_t)gridDim.x * (256 * U)) {
+        uint32_t k[U], len_a[U], len_b[U];
+        const uint8_t *pa[U], *pb[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t d = d0 + (uint64_t)u * 256;
+            const uint32_t a = (uint32_t)d * 4u; // pitch * n < 2^32 (launcher)
+            const uint32_t r = a / pitch;
+            k[u] = a - r * pitch;
+            in[u] = d < n_dwords && r < n;
+            const bool next = in[u] && (uint64_t)r + 1 < n;
+            const uint32_t r0 = in[u] ? r : 0u, r1 = next ? r + 1 : r0;
+            const uint32_t l0 = l_seq[r0], l1 = l_seq[r1];
+            const uint32_t sb0 = (l0 + 1) / 2, sb1 = (l1 + 1) / 2;
+            len_a[u] = QUAL ? l0 : sb0;
+            len_b[u] = next ? (QUAL ? l1 : sb1) : 0u;
+            // (a dword in a short read's padding reads the row's first bytes instead of bytes far behind it: nothing of it
+            // is kept; the raw buffer has slack for the three bytes a dword may reach behind the data)
+            pa[u] = raw + seq_src[r0] + (QUAL ? sb0 : 0u) + (k[u] < len_a[u] ? k[u] : 0u);
+            pb[u] = raw + seq_src[r1] + (QUAL ? sb1 : 0u);
+        }
+        uint32_t va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            va[u] = ld32(pa[u]);
+            vb[u] = ld32(pb[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t d = d0 + (uint64_t)u * 256;
+            if (d >= n_dwords) break;
+            const uint32_t t = pitch - k[u];                                 // bytes of this dword that lie in row r (>= 1)
+            const uint32_t n_a = len_a[u] > k[u] ? len_a[u] - k[u] : 0u;     // ... of them inside the row's data
+            const uint32_t m_a = in[u] ? byte_mask(n_a < t ? n_a : t) : 0u;
+            const uint32_t n_b = t < 4 ? (len_b[u] < 4 - t ? len_b[u] : 4 - t) : 0u; // bytes of the next row's data
+            const uint32_t m_b = t < 4 ? byte_mask(n_b) << (8 * t) : 0u;
+            const uint32_t sh_b = t < 4 ? vb[u] << (8 * t) : 0u;
+            dst[d] = (va[u] & m_a) | (sh_b & m_b) | (FILLW & ~(m_a | m_b));
         }
     }
 }
@@ -489,10 +546,12 @@ hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t
         if (c.cigar_off) parts |= 1u;
         if (rows) {
             const uint64_t ds = ((uint64_t)c.seq_pitch * n + 3) / 4, dq = ((uint64_t)c.qual_pitch * n + 3) / 4;
-            hipLaunchKernelGGL(k_rec_rows<false>, dim3((uint32_t)std::min<uint64_t>((ds + 1023) / 1024, 1u << 16)), dim3(256), 0, s, raw,
-                               var_base + n, c.l_seq, n, reinterpret_cast<uint32_t *>(c.seq), c.seq_pitch, ds);
-            hipLaunchKernelGGL(k_rec_rows<true>, dim3((uint32_t)std::min<uint64_t>((dq + 1023) / 1024, 1u << 16)), dim3(256), 0, s, raw,
-                               var_base + n, c.l_seq, n, reinterpret_cast<uint32_t *>(c.qual), c.qual_pitch, dq);
+            const dim3 gs((uint32_t)std::min<uint64_t>((ds + 1023) / 1024, 1u << 16)), gq((uint32_t)std::min<uint64_t>((dq + 1023) / 1024, 1u << 16));
+            uint32_t *const seq32 = reinterpret_cast<uint32_t *>(c.seq), *const qual32 = reinterpret_cast<uint32_t *>(c.qual);
+            if (c.seq_pitch >= 4) hipLaunchKernelGGL(k_rec_rows<false>, gs, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, seq32, c.seq_pitch, ds);
+            else hipLaunchKernelGGL(k_rec_rows_narrow<false>, gs, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, seq32, c.seq_pitch, ds);
+            if (c.qual_pitch >= 4) hipLaunchKernelGGL(k_rec_rows<true>, gq, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, qual32, c.qual_pitch, dq);
+            else hipLaunchKernelGGL(k_rec_rows_narrow<true>, gq, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, qual32, c.qual_pitch, dq);
         }
         if (!c.cigar_off)
             hipLaunchKernelGGL(k_rec_cigar1, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, raw, var_base,
