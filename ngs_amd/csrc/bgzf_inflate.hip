@@ -646,11 +646,15 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
             const uint32_t info = is_lit ? 0x80000000u | e_byte(E) : dist;
             for (uint32_t c0 = 0; c0 < total; c0 += 64) {
                 const uint32_t base = pos + c0;
-                // (volatile: the marks are read by OTHER lanes than wrote them; without it the compiler forwards this
-                // lane's own zero to its read -- LDS operations of one wave execute in order, no barrier is needed)
-                volatile uint8_t *const mark = L.mark;
+                // (the marks are read by OTHER lanes than wrote them: the wavefront-scope fence makes the compiler reload
+                // instead of forwarding this lane's own zero; LDS operations of one wave execute in order, nothing else is
+                // needed.  A `volatile` pointer did that too, but it lost the LDS address space: flat_store_byte /
+                // flat_load_ubyte with a full s_waitcnt after each, three round trips per 64 bytes of output.)
+                uint8_t *const mark = L.mark;
                 mark[lane] = 0;
                 if (on_chain && rel - c0 < 64u) mark[rel - c0] = (uint8_t)(lane + 1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 uint32_t own = mark[lane];
                 if (c0) { // a symbol that started in an earlier chunk owns the first bytes of this one
                     const uint64_t before = __ballot(on_chain && rel < c0);
