@@ -173,7 +173,10 @@ struct StTileIn {
     int32_t rf_t, ps_t, rf_n, ps_n;  // first record of the tile and of its successor
 };
 
-__global__ __launch_bounds__(ST_THREADS, 4) void k_cov_stream(DeviceState st, DeviceBatch b, CovStreamArgs a) {
+#ifndef ST_MIN_BLOCKS
+#define ST_MIN_BLOCKS 4
+#endif
+__global__ __launch_bounds__(ST_THREADS, ST_MIN_BLOCKS) void k_cov_stream(DeviceState st, DeviceBatch b, CovStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const uint32_t nb = a.cov_cap + 2;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
