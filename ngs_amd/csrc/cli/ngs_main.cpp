@@ -361,6 +361,7 @@ struct Args {
     unsigned long long batch_records = 1ull << 21, gc_seed = 0x4E4753;
     int gpus = 1;             // --gpus N: one worker process per GPU (devices --device .. --device + N - 1)
     bool same_device = false; // --same-device: all workers on --device, exchange through shared memory (one-GPU boxes)
+    std::string transport;    // --transport rccl|shm: override (tests: --same-device --transport rccl with NGSQ_RCCL_LIB = tests/rccl_double)
     int rank = -1, world = 0; // --worker R/W:NAME (set by the launching process)
     std::string shm;
 };
@@ -449,6 +450,7 @@ int main(int argc, char **argv) {
         }
         else if (s == "--gpus") a.gpus = atoi(val("--gpus").c_str());
         else if (s == "--same-device") a.same_device = true;
+        else if (s == "--transport") a.transport = val("--transport");
         else if (s == "--worker") { // R/W:NAME, appended by the launching process
             const std::string v = val("--worker");
             const size_t sl = v.find('/'), co = v.find(':');
@@ -642,13 +644,17 @@ int main(int argc, char **argv) {
         if (ndev < 1) bail("no HIP device available; the ngs qc hot path has no CPU fallback");
         ngsq_comm *boot = nullptr;
         if (ngsq_comm_create_shm(a.shm.c_str(), a.rank, a.world, 0, &boot) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
-        if (a.same_device) {
+        if (!a.transport.empty() && a.transport != "rccl" && a.transport != "shm") bail("--transport must be rccl or shm");
+        if (a.transport.empty() ? a.same_device : a.transport == "shm") {
+            if (!a.same_device) a.device += a.rank;
             comm = boot;
         } else {
-            if (a.device + a.world > ndev)
-                bail("--gpus " + std::to_string(a.world) + " from --device " + std::to_string(a.device) + ": only " + std::to_string(ndev) +
-                     " device(s) visible (--same-device shares one)");
-            a.device += a.rank;
+            if (!a.same_device) {
+                if (a.device + a.world > ndev)
+                    bail("--gpus " + std::to_string(a.world) + " from --device " + std::to_string(a.device) + ": only " + std::to_string(ndev) +
+                         " device(s) visible (--same-device shares one)");
+                a.device += a.rank;
+            }
             uint8_t uid[NGSQ_COMM_ID_BYTES] = {0};
             if (a.rank == 0 && ngsq_comm_unique_id(uid) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
             std::vector<uint8_t> all((size_t)a.world * NGSQ_COMM_ID_BYTES);

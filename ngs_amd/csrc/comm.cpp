@@ -66,8 +66,10 @@ RcclApi *rccl_api() {
     static std::once_flag once;
     std::call_once(once, [] {
         // a library of that soname already in the process (e.g. PyTorch's copy) is the one dlopen returns
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // NGSQ_RCCL_LIB: another build of the library (or tests/rccl_double, which lets three ranks share one GPU)
+        const char *names[] = {getenv("NGSQ_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
+            if (!n || !*n) continue;
             api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
             api.why = dlerror() ? dlerror() : "dlopen failed";

@@ -23,8 +23,8 @@ def ngs(lib):
     return build.build_cli(verbose=False)
 
 
-def run(ngs, *args, cwd=None):
-    return subprocess.run([ngs, *args], capture_output=True, text=True, cwd=cwd)
+def run(ngs, *args, cwd=None, env=None):
+    return subprocess.run([ngs, *args], capture_output=True, text=True, cwd=cwd, env=env)
 
 
 def sorted_batch(seed, n, max_len=150, min_len=150):
@@ -390,6 +390,15 @@ def test_gpus_flag_workers_share_one_file(ngs, gpu_lib, oracle_mod, tmp_path):
         assert r.returncode == 0, r.stderr
         assert "Worker 0 of 3 on device 0, exchange over shm." in r.stderr
         json_equal(json.load(open(out / "g.bam.results.json")), want)
+    # the RCCL transport (what a node with a device per worker uses), librccl replaced by tests/rccl_double so that the
+    # three workers can share this box's GPU
+    from tests.test_shard_gloo import rccl_double_path
+    out = tmp_path / "w_rccl"
+    r = run(ngs, "qc", bam, GENOME, "-o", str(out), "--gpus", "3", "--same-device", "--transport", "rccl", "--batch-records", "4001",
+            env=dict(os.environ, NGSQ_RCCL_LIB=rccl_double_path()))
+    assert r.returncode == 0, r.stderr
+    assert "Worker 0 of 3 on device 0, exchange over rccl." in r.stderr
+    json_equal(json.load(open(out / "g.bam.results.json")), want)
     # the reference's -n rules are sequential: refused with --gpus
     r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path), "--gpus", "2", "-n", "10")
     assert r.returncode == 1 and "--gpus cannot be combined with -n" in r.stderr

@@ -343,8 +343,9 @@ def test_full_size_properties(gpu_lib):
 # ---------------------------------------------------------------------------------------------
 # N > 1 with REAL contexts: three processes share the one GPU of the box and run ngsq_exchange (the C++
 # protocol of ngs_amd/csrc/exchange.cpp) over a host transport -- the library's shared-memory transport, or
-# callbacks over torch.distributed/gloo; the device blocks are staged through the host.  (RCCL refuses two
-# ranks on one device; its entry points are exercised with one rank below.)
+# callbacks over torch.distributed/gloo; the device blocks are staged through the host.  RCCL refuses two
+# ranks on one device: its entry points are exercised with one rank below, and the library's RCCL transport itself
+# (no staging: collectives and grouped sends / receives on device buffers) with three ranks over tests/rccl_double.
 # ---------------------------------------------------------------------------------------------
 def _rank_worker(rank, world, port, q, mode, transport):
     try:
@@ -413,10 +414,21 @@ def _rank_worker(rank, world, port, q, mode, transport):
 
 
 @pytest.mark.parametrize("mode,transport", [("fixed", "shm"), ("mixed", "gloo"), ("fixed-stream", "gloo"), ("mixed-stream", "shm"),
-                                            ("stream-overlap", "shm"), ("edits", "shm")])
+                                            ("stream-overlap", "shm"), ("edits", "shm"),
+                                            # the RCCL transport's own code path (device buffers, no host staging) with three
+                                            # ranks, librccl replaced by tests/rccl_double
+                                            ("fixed", "rccl-double"), ("mixed-stream", "rccl-double"), ("edits", "rccl-double"),
+                                            ("stream-overlap", "rccl-double")])
 def test_three_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode, transport):
     from tests.test_shard_gloo import _run_ranks
     _run_ranks(_rank_worker, 3, mode, transport)
+
+
+def test_rccl_transport_host_collectives_three_ranks(gpu_lib):
+    """RcclComm's host-buffer collectives (own stream + device scratch) and multi-round sendrecv with three ranks,
+    librccl replaced by tests/rccl_double: the transport checks of tests/test_shard_gloo.py, on the GPU."""
+    from tests.test_shard_gloo import _run_ranks, _transport_worker
+    _run_ranks(_transport_worker, 3, "rccl-double")
 
 
 def test_rccl_entry_points_with_one_rank(gpu_lib, oracle_mod):

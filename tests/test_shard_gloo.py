@@ -53,12 +53,42 @@ def _make_comm(transport, rank, world, port):
             dist.barrier()
             dist.destroy_process_group()
         return comm, done
+    if transport == "rccl-double":
+        # the library's RCCL transport (device buffers, collectives on the context's stream, grouped ncclSend/ncclRecv)
+        # bound to tests/rccl_double instead of librccl: three ranks on ONE GPU, which RCCL itself refuses
+        os.environ["NGSQ_RCCL_LIB"] = rccl_double_path()
+        boot = shard.Comm.shm(f"/ngsq-test-{port}", rank, world, slot_bytes=8192)
+        uid = np.frombuffer(shard.unique_id() if rank == 0 else bytes(128), dtype=np.uint8)
+        uid = boot.allgather(uid)[0].tobytes()
+        comm = shard.Comm.rccl(rank, world, uid, 0)
+        assert comm.kind == "rccl"
+
+        def done():
+            boot.barrier()
+            comm.destroy()
+            boot.destroy()
+        return comm, done
     comm = shard.Comm.shm(f"/ngsq-test-{port}", rank, world, slot_bytes=8192)
 
     def done():
         comm.barrier()
         comm.destroy()
     return comm, done
+
+
+def rccl_double_path() -> str:
+    """tests/rccl_double/librccl_double.so, compiled on demand (hipcc; host code only, links the HIP runtime)."""
+    import fcntl
+    import subprocess
+    d = os.path.join(ROOT, "tests", "rccl_double")
+    src, out = os.path.join(d, "rccl_double.cpp"), os.path.join(d, "librccl_double.so")
+    with open(os.path.join(d, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", out + ".tmp", "-lrt"],
+                           check=True, capture_output=True)
+            os.replace(out + ".tmp", out)
+    return out
 
 
 def _run_ranks(target, world, *args):
@@ -80,7 +110,7 @@ def _transport_worker(rank, world, port, q, transport):
     try:
         sys.path.insert(0, ROOT)
         comm, done = _make_comm(transport, rank, world, port)
-        assert (comm.rank, comm.world) == (rank, world) and comm.kind == ("custom" if transport == "gloo" else "shm")
+        assert (comm.rank, comm.world) == (rank, world) and comm.kind == {"gloo": "custom", "shm": "shm", "rccl-double": "rccl"}[transport]
 
         def block(r, dtype, n):
             g = np.random.default_rng(100 + r)
