@@ -353,7 +353,7 @@ def test_device_reader_empty_bam(gpu_lib, ctx, tmp_path):
 
 
 # ---- one BAM file, three ranks (sharded device ingest + owner-computes teardown) -----------------
-def _file_shard_worker(rank, world, port, q, bam, writer):
+def _file_shard_worker(rank, world, port, q, bam, writer, transport=None):
     try:
         import os
         import sys
@@ -361,7 +361,7 @@ def _file_shard_worker(rank, world, port, q, bam, writer):
         from ngs_amd import ffi as F, host as H, shard
         from tests.test_shard_gloo import _make_comm
 
-        comm, done = _make_comm("shm" if writer == "synth" else "gloo", rank, world, port)
+        comm, done = _make_comm(transport or ("shm" if writer == "synth" else "gloo"), rank, world, port)
         lib = F.load_library()
         ref_len = [3_000_000, 3_000_000] if writer == "synth" else [50_000, 7_000]
         names = ["chr1", "chr2"]
@@ -423,8 +423,8 @@ def _file_shard_worker(rank, world, port, q, bam, writer):
         q.put((rank, "FAIL " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("writer", ["synth", "straddling"])
-def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer):
+@pytest.mark.parametrize("writer,transport", [("synth", None), ("straddling", None), ("straddling", "rccl-double")])
+def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport):
     """Each rank ingests its BGZF block range of the same file; record boundaries at the shard edges are
     agreed by exchange; results equal the single-reader run.  "straddling": a file whose records cross
     every block boundary, so no shard starts at a record start."""
@@ -441,7 +441,7 @@ def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer):
         c["flag"] &= np.uint16(0xFFFF ^ 0x1)
         bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=3000)
     from tests.test_shard_gloo import _run_ranks
-    _run_ranks(_file_shard_worker, 3, bam, writer)
+    _run_ranks(_file_shard_worker, 3, bam, writer, transport)   # rccl-double: the RCCL transport over tests/rccl_double
 
 
 def test_shard_prepare_commit_api(gpu_lib, ctx, tmp_path):
