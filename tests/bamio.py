@@ -103,6 +103,9 @@ def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], b
     for n, l in zip(ref_names, ref_len):
         head += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
     out: List[bytes] = []
+    while len(head) > block_payload:  # a long header (thousands of @SQ lines) takes blocks of its own
+        out.append(bgzf_block(head[:block_payload]))
+        head = head[block_payload:]
     cur = bytearray(head)
     rec_at = []  # (block number, offset in the block's data) of every record
     for i in range(hb.n):

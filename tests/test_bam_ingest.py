@@ -95,6 +95,20 @@ def test_round_trip(lib, tmp_path, case):
         assert batches[0].qual_stride == 0 and batches[0].cols["qual_off"] is not None
 
 
+def test_header_of_many_blocks(lib, tmp_path):
+    """20 000 @SQ lines: the header (text + reference table, ~1.3 MB) spans twenty BGZF blocks."""
+    rng = np.random.default_rng(41)
+    n_refs = 20_000
+    names = [f"contig_{i:05d}_of_a_fragmented_assembly" for i in range(n_refs)]
+    ref_len = [3000] * n_refs
+    hb = random_batch(rng, 3000, ref_len[:7], max_len=120, weird=False)
+    path = str(tmp_path / "h.bam")
+    bamio.write_bam(path, hb, names, ref_len, block_payload=30_000)
+    refs, batches, n = read_all(lib, path, 1000)
+    assert refs == list(zip(names, ref_len)) and n == hb.n
+    assert [r for b in batches for r in records_of(b)] == records_of(hb)
+
+
 def test_errors(lib, tmp_path):
     p = str(tmp_path / "x.bam")
     h = C.c_void_p()

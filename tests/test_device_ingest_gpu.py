@@ -294,6 +294,24 @@ def test_block_cache_serves_the_next_file(gpu_lib, ctx, tmp_path):
     assert dn == hb.n and [r for b in dbatches for r in records_of(b)] == records_of(hb)
 
 
+def test_device_reader_header_larger_than_segments_and_chunks(gpu_lib, tmp_path, monkeypatch):
+    """A header with 20 000 reference sequences (~1.3 MB of BAM header): the first record lies behind twenty 64 KiB
+    index segments, and -- with the ingest buffer shrunk to 1 MiB -- behind the whole first chunk."""
+    rng = np.random.default_rng(41)
+    n_refs = 20_000
+    names = [f"contig_{i:05d}_of_a_fragmented_assembly" for i in range(n_refs)]
+    ref_len = [3000] * n_refs
+    hb = random_batch(rng, 5000, ref_len[:7], max_len=120, weird=False)
+    path = str(tmp_path / "h.bam")
+    bamio.write_bam(path, hb, names, ref_len, block_payload=30_000)
+    with host.QcContext(ref_len, facets=ffi.FACET_GENERAL, lib=gpu_lib) as ctx:
+        for raw_mb in ("1024", "1"):
+            monkeypatch.setenv("NGSQ_INGEST_RAW_MB", raw_mb)
+            dbatches, dn = read_all_device(gpu_lib, ctx, path, 1 << 20)
+            assert dn == hb.n
+            assert [r for b in dbatches for r in records_of(b)] == records_of(hb)
+
+
 def test_device_reader_errors(gpu_lib, ctx, tmp_path):
     rng = np.random.default_rng(1)
     hb = random_batch(rng, 2000, [9000], max_len=80)
