@@ -449,7 +449,7 @@ void reader_main(DeviceIngest *d, std::string path) {
         auto send = [&]() {
             if (h2d_ok && c.err.empty() && c.consumed > sent) {
                 const double ts = now_ms();
-                h2d_ok = hipMemcpyAsync(d->d_comp_slot[k].p + sent, c.h + sent, c.consumed - sent, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess;
+                h2d_ok = ngsq::pool_pinned_h2d(d->d_comp_slot[k].p + sent, c.h, sent, c.consumed - sent, d->copy_stream) == hipSuccess;
                 sent = c.consumed;
                 t_send += now_ms() - ts;
             }
@@ -642,7 +642,7 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
         BHIP(hipStreamWaitEvent(sb, d->h2d_done[slot], 0));
     } else {
         BHIP(d->d_comp_slot[slot].reserve(p.consumed + INFLATE_IN_SLACK));
-        BHIP(hipMemcpyAsync(d->d_comp_slot[slot].p, c.h, p.consumed, hipMemcpyHostToDevice, sb));
+        BHIP(ngsq::pool_pinned_h2d(d->d_comp_slot[slot].p, c.h, 0, p.consumed, sb));
         BHIP(hipMemsetAsync(d->d_comp_slot[slot].p + p.consumed, 0, INFLATE_IN_SLACK, sb));
     }
     if (d->raw_free_set[slot]) BHIP(hipStreamWaitEvent(sb, d->raw_free[slot], 0)); // the chunk before last has left this buffer
@@ -932,7 +932,7 @@ extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, 
         BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
         BHIP(d->d_blocks.reserve(n_blk));
         BHIP(d->d_status.reserve(n_blk));
-        BHIP(hipMemcpyAsync(d->d_comp.p, h, consumed, hipMemcpyHostToDevice, st));
+        BHIP(ngsq::pool_pinned_h2d(d->d_comp.p, h, 0, consumed, st));
         BHIP(hipMemsetAsync(d->d_comp.p + consumed, 0, INFLATE_IN_SLACK, st));
         BHIP(hipMemcpyAsync(d->d_blocks.p, d->shard_blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
         BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->raw, d->d_status.p, true, st));

@@ -2,8 +2,11 @@
 #include "mem_pool.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -12,15 +15,19 @@ namespace {
 
 constexpr size_t POOL_MIN = (size_t)1 << 20; // smaller blocks are not worth keeping
 
+constexpr size_t PIN_PIECE = (size_t)32 << 20; // pinned host blocks are registered with HIP in pieces of this size
+
 struct Block {
     void *p;
     size_t bytes;
     int device; // >= 0: memory of that device; < 0: pinned host memory filled for device -(device + 1) (its NUMA node)
+    std::vector<uint8_t> reg; // pinned blocks: which pieces are registered
 };
 
 struct Pool {
     std::mutex mu;
     std::vector<Block> blocks;
+    std::map<const void *, Block> pinned_live; // pinned blocks handed out, by base address
     size_t cached[2] = {0, 0}; // device | pinned
     size_t limit;
     Pool() {
@@ -88,35 +95,76 @@ void pool_device_free(void *p, size_t got) {
         if (dev != cur) (void)hipSetDevice(dev);
         (void)hipDeviceSynchronize();
         if (dev != cur) (void)hipSetDevice(cur);
-        if (pool().put(Block{p, got, dev})) return;
+        if (pool().put(Block{p, got, dev, {}})) return;
     }
     (void)hipFree(p);
+}
+
+static void release_pinned(Block &b) {
+    for (size_t k = 0; k < b.reg.size(); k++)
+        if (b.reg[k]) (void)hipHostUnregister(static_cast<uint8_t *>(b.p) + k * PIN_PIECE);
+    munmap(b.p, b.bytes);
 }
 
 hipError_t pool_pinned_alloc(void **p, size_t bytes, size_t *got) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     Block b{};
-    if (bytes >= POOL_MIN && pool().take(-(dev + 1), bytes, &b)) {
-        *p = b.p;
-        *got = b.bytes;
-        return hipSuccess;
+    if (!(bytes >= POOL_MIN && pool().take(-(dev + 1), bytes, &b))) {
+        const size_t rounded = (bytes + PIN_PIECE - 1) / PIN_PIECE * PIN_PIECE;
+        void *m = mmap(nullptr, rounded, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return hipErrorOutOfMemory;
+        b = Block{m, rounded, -(dev + 1), std::vector<uint8_t>(rounded / PIN_PIECE, 0)};
     }
-    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
-    if (e != hipSuccess && pool_trim()) {
-        (void)hipGetLastError();
-        e = hipHostMalloc(p, bytes, hipHostMallocDefault);
-    }
-    *got = bytes;
-    return e;
+    *p = b.p;
+    *got = b.bytes;
+    std::lock_guard<std::mutex> g(pool().mu);
+    pool().pinned_live[b.p] = std::move(b);
+    return hipSuccess;
 }
 
-void pool_pinned_free(void *p, size_t got) {
+void pool_pinned_free(void *p, size_t) {
     if (!p) return;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (got >= POOL_MIN && pool().put(Block{p, got, -(dev + 1)})) return;
-    (void)hipHostFree(p);
+    Block b{};
+    {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto it = pool().pinned_live.find(p);
+        if (it == pool().pinned_live.end()) return; // not one of ours
+        b = std::move(it->second);
+        pool().pinned_live.erase(it);
+    }
+    if (b.bytes >= POOL_MIN && pool().put(b)) return;
+    release_pinned(b);
+}
+
+hipError_t pool_pinned_h2d(void *dst, const void *block, size_t off, size_t len, hipStream_t s) {
+    if (!len) return hipSuccess;
+    uint8_t *base = nullptr;
+    size_t bytes = 0;
+    std::vector<size_t> todo; // pieces to register (this block is filled and copied from by ONE thread)
+    {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto it = pool().pinned_live.find(block);
+        if (it == pool().pinned_live.end() || off + len > it->second.bytes) return hipErrorInvalidValue;
+        base = static_cast<uint8_t *>(it->second.p);
+        bytes = it->second.bytes;
+        for (size_t k = off / PIN_PIECE; k <= (off + len - 1) / PIN_PIECE; k++)
+            if (!it->second.reg[k]) todo.push_back(k);
+    }
+    for (size_t k : todo) {
+        hipError_t e = hipHostRegister(base + k * PIN_PIECE, std::min(PIN_PIECE, bytes - k * PIN_PIECE), hipHostRegisterDefault);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto it = pool().pinned_live.find(block);
+        if (it != pool().pinned_live.end()) it->second.reg[k] = 1;
+    }
+    for (size_t o = off; o < off + len;) { // a copy may not span two registrations
+        const size_t n = std::min(off + len, (o / PIN_PIECE + 1) * PIN_PIECE) - o;
+        hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(dst) + (o - off), base + o, n, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        o += n;
+    }
+    return hipSuccess;
 }
 
 size_t pool_trim() {
@@ -127,9 +175,9 @@ size_t pool_trim() {
         pool().cached[0] = pool().cached[1] = 0;
     }
     size_t n = 0;
-    for (const Block &b : take) {
+    for (Block &b : take) {
         n += b.bytes;
-        if (b.device < 0) (void)hipHostFree(b.p);
+        if (b.device < 0) release_pinned(b);
         else (void)hipFree(b.p); // hipFree takes any device's pointer
     }
     return n;

@@ -78,7 +78,7 @@ struct ncclComm {
         const double t0 = now_s();
         for (uint64_t spins = 0; sh->generation.load(std::memory_order_acquire) == gen; spins++) {
             if (spins > 1000) sched_yield();
-            if ((spins & 0xFFFF) == 0 && now_s() - t0 > 120.0) return false;
+            if ((spins & 0xFFFF) == 0 && now_s() - t0 > 300.0) return false;
         }
         return true;
     }
@@ -126,7 +126,7 @@ static ncclResult_t run_p2p(std::vector<std::pair<ncclComm *, P2p>> &ops) {
         if (all) return ncclSuccess;
         if (!moved) {
             if (spins > 1000) sched_yield();
-            if ((spins & 0xFFFF) == 0 && now_s() - t0 > 120.0) return ncclSystemError;
+            if ((spins & 0xFFFF) == 0 && now_s() - t0 > 300.0) return ncclSystemError;
         }
     }
 }
@@ -152,13 +152,13 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
         if (fd < 0 || ftruncate(fd, sizeof(Shared)) != 0) return ncclSystemError;
     } else {
         while ((fd = shm_open(name, O_RDWR, 0600)) < 0) {
-            if (now_s() - t0 > 60.0) return ncclSystemError;
+            if (now_s() - t0 > 300.0) return ncclSystemError;
             usleep(1000);
         }
         for (;;) { // wait for rank 0's ftruncate
             const off_t sz = lseek(fd, 0, SEEK_END);
             if (sz >= (off_t)sizeof(Shared)) break;
-            if (now_s() - t0 > 60.0) return ncclSystemError;
+            if (now_s() - t0 > 300.0) return ncclSystemError;
             usleep(1000);
         }
     }
@@ -172,7 +172,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     if (rank == 0) c->sh->world = (uint32_t)nranks;
     c->sh->attached.fetch_add(1, std::memory_order_acq_rel);
     while (c->sh->attached.load(std::memory_order_acquire) < (uint32_t)nranks) {
-        if (now_s() - t0 > 60.0) return ncclSystemError;
+        if (now_s() - t0 > 300.0) return ncclSystemError;
         usleep(200);
     }
     if (rank == 0) shm_unlink(name); // everyone has it mapped

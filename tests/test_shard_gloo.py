@@ -93,6 +93,8 @@ def rccl_double_path() -> str:
 
 def _run_ranks(target, world, *args):
     import multiprocessing as mp
+    if "rccl-double" in args:
+        rccl_double_path()   # compiled once here, not by three workers racing for the lock
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
