@@ -52,6 +52,10 @@ __device__ __forceinline__ bool record_valid(const uint8_t *r /* at block_size *
 }
 
 constexpr uint32_t SUB_NONE = 0xFFFFFFFFu;
+#ifndef NGSQ_PARSE_THREADS
+#define NGSQ_PARSE_THREADS 256
+#endif
+constexpr uint32_t PT = NGSQ_PARSE_THREADS; // threads per block of the fixed-pitch parse kernels
 
 // Walk the chain from `o` until it reaches `end` (segment end) or the record at the cursor is not
 // completely inside [0, n_bytes).  STRICT: apply the plausibility test.  Returns false on an invalid
@@ -207,7 +211,7 @@ __global__ void k_walk_one(const uint8_t *__restrict__ raw, uint64_t n_bytes, ui
 // One lane per 4 KiB piece.  chosen[s] = the candidate of segment s whose chain is the file's (REC_NO_CHAIN: no record
 // starts in s), seg_base[s] = index of its first record; the piece's own entry comes from the candidate's piece table.
 // bad[0] = smallest index of an invalid record (or ~0).
-__global__ __launch_bounds__(256) void k_rec_offsets(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t n_pieces,
+__global__ __launch_bounds__(PT) void k_rec_offsets(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t n_pieces,
                                                      const uint32_t *__restrict__ chosen, const uint64_t *__restrict__ seg_base,
                                                      const RecPieces *__restrict__ pieces, uint64_t *__restrict__ rec_off,
                                                      unsigned long long *__restrict__ bad) {
@@ -240,14 +244,15 @@ __global__ __launch_bounds__(256) void k_rec_offsets(const uint8_t *__restrict__
 // in raw (k_rec_var and k_rec_rows start from them).  The fixed part of a record is 32 contiguous bytes at any byte
 // offset: two unaligned 16-byte loads.  The three totals are reduced per block first: one atomic per wave on
 // the same three words was most of this kernel's time (same-address atomics serialise in L2, ~9 ns each).
-__global__ __launch_bounds__(256) void k_rec_fixed(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ rec_off,
+__global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ rec_off,
                                                    uint64_t n, RecColumns c, uint64_t *__restrict__ var_base,
                                                    uint64_t *__restrict__ seq_src, unsigned long long *__restrict__ stats) {
-    __shared__ uint32_t s_ml[4], s_mo[4];
-    __shared__ unsigned long long s_sl[4];
+    constexpr uint32_t NW = PT / 64;
+    __shared__ uint32_t s_ml[NW], s_mo[NW];
+    __shared__ unsigned long long s_sl[NW];
     uint32_t ml = 0, mo = 0;
     unsigned long long sl = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    for (uint64_t i = (uint64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PT) {
         const uint64_t o = rec_off[i] + 4;
         uint4 a, b;
         __builtin_memcpy(&a, raw + o, 16);      // refID, pos, l_read_name | mapq | bin, n_cigar_op | flag
@@ -281,9 +286,16 @@ __global__ __launch_bounds__(256) void k_rec_fixed(const uint8_t *__restrict__ r
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicMax(&stats[0], (unsigned long long)max(max(s_ml[0], s_ml[1]), max(s_ml[2], s_ml[3])));
-        atomicMax(&stats[1], (unsigned long long)max(max(s_mo[0], s_mo[1]), max(s_mo[2], s_mo[3])));
-        atomicAdd(&stats[2], s_sl[0] + s_sl[1] + s_sl[2] + s_sl[3]);
+        uint32_t a = 0, b = 0;
+        unsigned long long t = 0;
+        for (uint32_t k = 0; k < NW; k++) {
+            a = max(a, s_ml[k]);
+            b = max(b, s_mo[k]);
+            t += s_sl[k];
+        }
+        atomicMax(&stats[0], (unsigned long long)a);
+        atomicMax(&stats[1], (unsigned long long)b);
+        atomicAdd(&stats[2], t);
     }
 }
 
@@ -386,18 +398,18 @@ __global__ __launch_bounds__(256) void k_rec_rows_narrow(const uint8_t *__restri
 __device__ __forceinline__ uint32_t byte_mask(uint32_t n_bytes) { return n_bytes >= 4 ? 0xFFFFFFFFu : (1u << (8 * n_bytes)) - 1u; }
 
 template <bool QUAL>
-__global__ __launch_bounds__(256) void k_rec_rows(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
+__global__ __launch_bounds__(PT) void k_rec_rows(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
                                                   const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t *__restrict__ dst,
                                                   uint32_t pitch, uint64_t n_dwords) {
     constexpr uint32_t FILLW = QUAL ? 0xFFFFFFFFu : 0u;
     constexpr int U = 4;
-    for (uint64_t d0 = (uint64_t)blockIdx.x * (256 * U) + threadIdx.x; d0 < n_dwords; d0 += (uint64_t)gridDim.x * (256 * U)) {
+    for (uint64_t d0 = (uint64_t)blockIdx.x * (PT * U) + threadIdx.x; d0 < n_dwords; d0 += (uint64_t)gridDim.x * (PT * U)) {
         uint32_t k[U], len_a[U], len_b[U];
         const uint8_t *pa[U], *pb[U];
         bool in[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint64_t d = d0 + (uint64_t)u * 256;
+            const uint64_t d = d0 + (uint64_t)u * PT;
             const uint32_t a = (uint32_t)d * 4u; // pitch * n < 2^32 (launcher)
             const uint32_t r = a / pitch;
             k[u] = a - r * pitch;
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(256) void k_rec_rows(const uint8_t *__restrict__ ra
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint64_t d = d0 + (uint64_t)u * 256;
+            const uint64_t d = d0 + (uint64_t)u * PT;
             if (d >= n_dwords) break;
             const uint32_t t = pitch - k[u];                                 // bytes of this dword that lie in row r (>= 1)
             const uint32_t n_a = len_a[u] > k[u] ? len_a[u] - k[u] : 0u;     // ... of them inside the row's data
@@ -471,9 +483,9 @@ __global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw
 }
 
 // one CIGAR operation per record (or none): the first one, or 0
-__global__ __launch_bounds__(256) void k_rec_cigar1(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base,
+__global__ __launch_bounds__(PT) void k_rec_cigar1(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base,
                                                     const uint16_t *__restrict__ n_cigar, uint64_t n, uint32_t *__restrict__ cigar) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    for (uint64_t i = (uint64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PT)
         cigar[i] = n_cigar[i] ? ld32(raw + var_base[i]) : 0u;
 }
 
@@ -512,7 +524,7 @@ hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start,
 hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
                               const RecPieces *pieces, uint64_t *rec_off, unsigned long long *bad, hipStream_t s) {
     if (!n_pieces) return hipSuccess;
-    hipLaunchKernelGGL(k_rec_offsets, dim3((n_pieces + 255) / 256), dim3(256), 0, s, raw, n_bytes, n_pieces, chosen, seg_base, pieces,
+    hipLaunchKernelGGL(k_rec_offsets, dim3((n_pieces + PT - 1) / PT), dim3(PT), 0, s, raw, n_bytes, n_pieces, chosen, seg_base, pieces,
                        rec_off, bad);
     return hipGetLastError();
 }
@@ -523,8 +535,8 @@ hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value,
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
                             unsigned long long *stats, hipStream_t s) {
     if (!n) return hipSuccess;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_rec_fixed, dim3(blocks), dim3(256), 0, s, raw, rec_off, n, c, var_base, var_base + n, stats);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + PT - 1) / PT, 2048 * (256 / PT));
+    hipLaunchKernelGGL(k_rec_fixed, dim3(blocks), dim3(PT), 0, s, raw, rec_off, n, c, var_base, var_base + n, stats);
     return hipGetLastError();
 }
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,
@@ -546,15 +558,16 @@ hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t
         if (c.cigar_off) parts |= 1u;
         if (rows) {
             const uint64_t ds = ((uint64_t)c.seq_pitch * n + 3) / 4, dq = ((uint64_t)c.qual_pitch * n + 3) / 4;
-            const dim3 gs((uint32_t)std::min<uint64_t>((ds + 1023) / 1024, 1u << 16)), gq((uint32_t)std::min<uint64_t>((dq + 1023) / 1024, 1u << 16));
+            const uint64_t per_block = (uint64_t)PT * 4, cap_blocks = (uint64_t)(1u << 16) * (256 / PT);
+            const dim3 gs((uint32_t)std::min<uint64_t>((ds + per_block - 1) / per_block, cap_blocks)), gq((uint32_t)std::min<uint64_t>((dq + per_block - 1) / per_block, cap_blocks));
             uint32_t *const seq32 = reinterpret_cast<uint32_t *>(c.seq), *const qual32 = reinterpret_cast<uint32_t *>(c.qual);
-            if (c.seq_pitch >= 4) hipLaunchKernelGGL(k_rec_rows<false>, gs, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, seq32, c.seq_pitch, ds);
+            if (c.seq_pitch >= 4) hipLaunchKernelGGL(k_rec_rows<false>, gs, dim3(PT), 0, s, raw, var_base + n, c.l_seq, n, seq32, c.seq_pitch, ds);
             else hipLaunchKernelGGL(k_rec_rows_narrow<false>, gs, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, seq32, c.seq_pitch, ds);
-            if (c.qual_pitch >= 4) hipLaunchKernelGGL(k_rec_rows<true>, gq, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, qual32, c.qual_pitch, dq);
+            if (c.qual_pitch >= 4) hipLaunchKernelGGL(k_rec_rows<true>, gq, dim3(PT), 0, s, raw, var_base + n, c.l_seq, n, qual32, c.qual_pitch, dq);
             else hipLaunchKernelGGL(k_rec_rows_narrow<true>, gq, dim3(256), 0, s, raw, var_base + n, c.l_seq, n, qual32, c.qual_pitch, dq);
         }
         if (!c.cigar_off)
-            hipLaunchKernelGGL(k_rec_cigar1, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, raw, var_base,
+            hipLaunchKernelGGL(k_rec_cigar1, dim3((uint32_t)std::min<uint64_t>((n + PT - 1) / PT, 2048 * (256 / PT))), dim3(PT), 0, s, raw, var_base,
                                c.n_cigar, n, c.cigar);
         if (parts)
             hipLaunchKernelGGL(k_rec_var, dim3((uint32_t)((n * 16 + 255) / 256)), dim3(256), 0, s, raw, var_base, n, c, parts);

@@ -21,6 +21,6 @@ sync
 echo "nproc $(nproc); cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null); mem $(free -g | sed -n 2p)"
 for i in 1 2; do
   T0=$(date +%s.%N)
-  NGSQ_INGEST_TRACE=1 ./ngs_amd/ngs -v qc /tmp/trace.bam GRCh38_no_alt_AnalysisSet -o /tmp 2>&1 | grep -v "Processed\|ngs::qc" | grep "\[ngs\]\|first pinned\|NUMA" ; true
+  NGSQ_INGEST_TRACE=1 ./ngs_amd/ngs -v qc /tmp/trace.bam GRCh38_no_alt_AnalysisSet -o /tmp 2>&1 | grep -v "Processed\|ngs::qc" | grep "\[ngs\]\|first pinned\|NUMA\|chunk:" | head -n 14 ; true
   python3 -c "import time; print('cli wall %.3f s' % (time.time() - $T0))"
 done
