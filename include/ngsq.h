@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGSQ_ABI_VERSION 3u
+#define NGSQ_ABI_VERSION 4u
 
 /* ---- status codes (reference: anyhow::Result<()> / panic) ---- */
 #define NGSQ_OK 0
@@ -127,6 +127,12 @@ typedef struct ngsq_config {
  *               byte 0xFF means "no score at this cycle" (row padding beyond l_seq, or a
  *               whole 0xFF row = missing qualities, exactly BAM's own encoding)
  *   cigar       BAM encoding len<<4|op, op in 0..8 = MIDNSHP=X
+ *   record_id   optional: one 64-bit identity per record, the only input of the GC window offset besides gc_seed and
+ *               l_seq (ngsq_gc_offset).  NULL -> first_record_index + i, the record's ordinal in the file.  The
+ *               readers of ngsq_bam.h fill it with the record's BAM virtual offset (file offset of the BGZF block
+ *               its first byte lies in << 16 | offset in that block's data): the same for every way of cutting a
+ *               file into shards, known to a shard without counting the records in front of it (a noodles host
+ *               has it as reader.virtual_position() before each record)
  * Variable-length columns are addressed either by an offsets array
  * (`*_off[i] .. *_off[i+1]`, n_records+1 entries, units: bytes for seq/qual,
  * ops for cigar) or, when the offsets pointer is NULL, by a fixed stride
@@ -136,7 +142,7 @@ typedef struct ngsq_batch {
     uint32_t struct_size;       /* = sizeof(ngsq_batch)                               */
     uint32_t location;          /* NGSQ_MEM_HOST or NGSQ_MEM_DEVICE                   */
     uint64_t n_records;
-    uint64_t first_record_index; /* index of record 0 in the whole file (GC offset fn) */
+    uint64_t first_record_index; /* index of record 0 in the whole file (GC offset fn when record_id == NULL) */
     const uint16_t *flag;
     const uint8_t *mapq;
     const int32_t *ref_id;
@@ -160,6 +166,7 @@ typedef struct ngsq_batch {
     uint64_t seq_bytes;
     uint64_t qual_bytes;
     uint64_t cigar_ops;
+    const uint64_t *record_id;  /* NULL -> first_record_index + i */
 } ngsq_batch;
 
 /* Which pass of the reference driver a batch belongs to (command.rs:288-400).

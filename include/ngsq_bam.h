@@ -53,7 +53,8 @@ const char *ngsq_bam_header_text(const ngsq_bam *bam, uint64_t *len);
 
 /* Decode up to max_records further records into `out` (host SoA columns owned
  * by the reader, valid until the next call / close).  out->n_records == 0 at end
- * of file.  out->first_record_index = index of the first record in the file.
+ * of file.  out->first_record_index = index of the first record in the file; out->record_id[i] = the record's BAM
+ * virtual offset (include/ngsq.h: what the GC window offset is drawn from).
  * Layout: fixed-pitch rows (pitch = longest read of the batch) when that wastes
  * little, else offsets arrays; cigar pitch 1 when every record has <= 1 op. */
 int ngsq_bam_next_batch(ngsq_bam *bam, uint64_t max_records, ngsq_batch *out);
@@ -69,30 +70,43 @@ uint64_t ngsq_bam_records_read(const ngsq_bam *bam);
  * call / close; work is enqueued on the context's stream.  Same records, same layout rules and
  * the same errors as the host reader; a call may return fewer than max_records before the end of
  * the file (out->n_records == 0 only at the end).  One handle serves either the host or the device
- * calls, not both (NGSQ_ERR_STATE).  Needs a GPU. */
+ * calls, not both (NGSQ_ERR_STATE).  out->record_id (device memory) holds the records' virtual offsets, as the host
+ * reader's batches do.  Needs a GPU. */
 int ngsq_bam_next_batch_device(ngsq_bam *bam, ngsq_ctx *ctx, uint64_t max_records, ngsq_batch *out);
 
 /* ---- sharded device ingest: one BAM file, several GPUs -----------------
- * Shard s of n reads the BGZF blocks that start in [split(s), split(s+1)), split(k) = the first
- * block start at or after k * file_size / n (found the same way by every shard), inflates and
- * indexes them at once -- the shard stays resident in device memory -- and then hands out batches
- * with ngsq_bam_next_batch_device.  A record belongs to the shard its first byte lies in; the blocks
- * that complete a shard's last record are read too.
+ * Shard s of n scans the BGZF blocks that start in [split(s), split(s+1)), split(k) = the first block start at or
+ * after k * file_size / n (found the same way by every shard), through the same pipeline as a whole file: bounded
+ * chunks, a reader thread with its pread workers (the node's cores divided by n), two raw buffers, the inflate of
+ * chunk k+1 beside the parse of chunk k.  A record belongs to the shard its first byte lies in; the blocks that
+ * complete a shard's last record (up to 17 MiB of them) are read too.  Pinned and device memory per shard are bounded
+ * by the chunk size, not by the shard.
  *
- * Shards other than 0 do not know where their first record starts: prepare() assumes the first
- * plausible record chain, and reports what it assumed (begin_voffset) and where its own chain enters
- * the next shard (end_voffset).  The caller compares neighbours (shard s+1's begin must equal shard
- * s's end; ngs_amd/shard.py does it with one all-gather) and calls commit() with the confirmed begin
- * (re-indexing if it differs) and with the number of records in front of the shard, which
- * first_record_index needs.  Virtual offsets are the BAM index's: block file offset << 16 | offset in
- * the block's data; end_voffset is 0 at the end of the file. */
+ * Shards other than 0 do not know where their first record starts.  ngsq_bam_shard_begin(begin_voffset = 0) assumes
+ * the first plausible record chain of the shard's first chunk and the scan runs on that assumption; afterwards
+ * ngsq_bam_shard_end reports what was assumed (begin_voffset) and where the shard's own chain enters the next shard
+ * (end_voffset; at the end of the file: file size << 16).  Shard s+1's begin must equal shard s's end: by induction from the header
+ * the boundaries are then exact.  ngsq_bam_shard_verify (ngsq_comm.h) does the comparison with one all-gather and
+ * re-arms a shard whose assumption was wrong with the confirmed offset (ngsq_bam_shard_begin again: the caller resets
+ * its facets and scans that shard again).
+ *
+ * Records are numbered from 0 within the shard (first_record_index of the batches); what identifies a record for the
+ * GC window is its record_id = BAM virtual offset (block file offset << 16 | offset in the block's data), the same in
+ * every sharding.  first_key / last_key: sort keys of the shard's first and last record, for the order check between
+ * neighbouring shards of a coordinate-sorted file. */
 typedef struct ngsq_bam_shard_info {
-    uint64_t n_records;     /* records starting in this shard */
-    uint64_t begin_voffset; /* first record of this shard */
-    uint64_t end_voffset;   /* first record after this shard */
+    uint64_t n_records;          /* records starting in this shard */
+    uint64_t begin_voffset;      /* first record of this shard */
+    uint64_t end_voffset;        /* first record after this shard (file size << 16: none) */
+    uint64_t first_record_index; /* records of the shards in front (set by ngsq_bam_shard_verify) */
+    uint64_t first_key, last_key; /* refID << 32 | pos + 1 of the first / last record, ~0 for an unplaced one (n_records > 0) */
+    uint32_t rescan;             /* ngsq_bam_shard_verify: 1 = this shard was re-armed, reset the facets and scan it again */
+    uint32_t reserved;
 } ngsq_bam_shard_info;
-int ngsq_bam_shard_prepare(ngsq_bam *bam, ngsq_ctx *ctx, uint32_t shard, uint32_t n_shards, ngsq_bam_shard_info *out);
-int ngsq_bam_shard_commit(ngsq_bam *bam, uint64_t begin_voffset, uint64_t first_record_index, ngsq_bam_shard_info *out);
+/* begin_voffset = 0: shard 0 starts behind the header, the others assume (see above); else the confirmed first record */
+int ngsq_bam_shard_begin(ngsq_bam *bam, ngsq_ctx *ctx, uint32_t shard, uint32_t n_shards, uint64_t begin_voffset);
+/* after ngsq_bam_next_batch_device has returned 0 records */
+int ngsq_bam_shard_end(ngsq_bam *bam, ngsq_bam_shard_info *out);
 
 /* Inflate a buffer of WHOLE BGZF blocks (host memory) on the context's device and copy the
  * decompressed bytes back: one wavefront per block (csrc/bgzf_inflate.hip).  *out_len receives

@@ -69,6 +69,8 @@ int ngsq_comm_rank(const ngsq_comm *comm);
 int ngsq_comm_world(const ngsq_comm *comm);
 /* "rccl", "shm" or "custom" */
 const char *ngsq_comm_kind(const ngsq_comm *comm);
+/* ncclGetVersion of the library the rccl transport bound (e.g. 22605), 0 when none could be loaded */
+int ngsq_comm_rccl_version(void);
 
 /* Collectives on HOST buffers over any transport (rccl: staged through device memory): what the host side
  * of a sharded run needs -- agreeing on record boundaries, record counts, timings. */
@@ -158,11 +160,20 @@ typedef struct ngsq_shard_state {
 
 int ngsq_exchange_state(const ngsq_shard_state *state, ngsq_comm *comm, ngsq_exchange_report *report);
 
-/* ---- one BAM file, several GPUs: ngsq_bam_shard_prepare + the agreement on record boundaries +
- * ngsq_bam_shard_commit in one collective call (include/ngsq_bam.h "sharded device ingest").  Shard =
- * ngsq_comm_rank of ngsq_comm_world.  Afterwards ngsq_bam_next_batch_device hands out this shard's records,
- * numbered from the records of the shards in front. */
-int ngsq_bam_shard_open(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *comm, ngsq_bam_shard_info *out);
+/* ---- one BAM file, several GPUs (include/ngsq_bam.h "sharded device ingest"); shard = ngsq_comm_rank of ngsq_comm_world.
+ *   ngsq_bam_shard_open    ngsq_bam_shard_begin for this rank (no communication): ngsq_bam_next_batch_device then streams
+ *                          this shard's records
+ *   ngsq_bam_shard_verify  collective, after the last batch and BEFORE ngsq_exchange: one all-gather of (records, assumed
+ *                          begin, found end, failure flag, first / last sort key).  *again = 0: the boundaries are exact,
+ *                          out->first_record_index = records of the shards in front; a sorted_input context whose
+ *                          neighbours are out of coordinate order gets NGSQ_ERR_UNSORTED (on every rank).  *again = 1 (on
+ *                          every rank): some shard's assumption was wrong; the ranks with out->rescan = 1 have been re-armed
+ *                          from the confirmed offset -- ngsq_reset the context, scan again -- the others keep their state
+ *                          (their reader is at its end); then everybody calls ngsq_bam_shard_verify again.
+ * A rank whose scan failed calls ngsq_bam_shard_verify all the same: every rank then returns an error instead of
+ * waiting for it. */
+int ngsq_bam_shard_open(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *comm);
+int ngsq_bam_shard_verify(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *comm, ngsq_bam_shard_info *out, int *again);
 
 #ifdef __cplusplus
 }

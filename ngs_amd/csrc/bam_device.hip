@@ -240,13 +240,17 @@ __global__ __launch_bounds__(PT) void k_rec_offsets(const uint8_t *__restrict__ 
 }
 
 // ---- 4. fixed-width columns + the numbers the layout decision needs ----------------------------
-// stats: [0] max l_seq, [1] max n_cigar, [2] sum l_seq.  var_base[i] / seq_src[i] = offset of record i's CIGAR / SEQ
+// stats: [0] max l_seq, [1] max n_cigar, [2] sum l_seq, [3] / [4] (refID << 32 | pos) of the first / last record.
+// record_id (include/ngsq.h): the record's BAM virtual offset -- the block whose data holds its first byte is found
+// by bisection over the chunk's block table (out_off ascending; blocks without data never hold a byte), the record
+// carried over from the previous chunk (view offset < carry) has the id it was given there.  var_base[i] / seq_src[i] = offset of record i's CIGAR / SEQ
 // in raw (k_rec_var and k_rec_rows start from them).  The fixed part of a record is 32 contiguous bytes at any byte
 // offset: two unaligned 16-byte loads.  The three totals are reduced per block first: one atomic per wave on
 // the same three words was most of this kernel's time (same-address atomics serialise in L2, ~9 ns each).
 __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ rec_off,
                                                    uint64_t n, RecColumns c, uint64_t *__restrict__ var_base,
-                                                   uint64_t *__restrict__ seq_src, unsigned long long *__restrict__ stats) {
+                                                   uint64_t *__restrict__ seq_src, unsigned long long *__restrict__ stats,
+                                                   RecOrigin org) {
     constexpr uint32_t NW = PT / 64;
     __shared__ uint32_t s_ml[NW], s_mo[NW];
     __shared__ unsigned long long s_sl[NW];
@@ -268,6 +272,23 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
         c.tlen[i] = (int32_t)b.w;
         var_base[i] = o + 32 + l_read_name;
         seq_src[i] = o + 32 + l_read_name + 4ull * n_ops;
+        if (org.record_id) {
+            const uint64_t at = o - 4; // view offset of the record's first byte
+            uint64_t id = org.carry_id;
+            if (at >= org.carry) {
+                const uint64_t u = at - org.carry;
+                uint32_t lo_k = 0, hi_k = org.n_blocks; // last block with out_off <= u
+                while (hi_k - lo_k > 1) {
+                    const uint32_t mid = (lo_k + hi_k) >> 1;
+                    if (org.blocks[mid].out_off <= u) lo_k = mid;
+                    else hi_k = mid;
+                }
+                id = org.coff[lo_k] << 16 | (u - org.blocks[lo_k].out_off);
+            }
+            org.record_id[i] = id;
+        }
+        if (i == 0) stats[3] = (unsigned long long)a.x << 32 | a.y;
+        if (i == n - 1) stats[4] = (unsigned long long)a.x << 32 | a.y;
         ml = max(ml, l);
         mo = max(mo, n_ops);
         sl += l;
@@ -533,10 +554,10 @@ hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value,
     return hipGetLastError();
 }
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
-                            unsigned long long *stats, hipStream_t s) {
+                            unsigned long long *stats, const RecOrigin &org, hipStream_t s) {
     if (!n) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + PT - 1) / PT, 2048 * (256 / PT));
-    hipLaunchKernelGGL(k_rec_fixed, dim3(blocks), dim3(PT), 0, s, raw, rec_off, n, c, var_base, var_base + n, stats);
+    hipLaunchKernelGGL(k_rec_fixed, dim3(blocks), dim3(PT), 0, s, raw, rec_off, n, c, var_base, var_base + n, stats, org);
     return hipGetLastError();
 }
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,
@@ -547,6 +568,7 @@ hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint6
     return hipGetLastError();
 }
 hipError_t launch_exclusive_scan_u64(uint64_t *data, uint64_t n_plus_1, void *tmp, size_t *tmp_bytes, hipStream_t s) {
+    if (n_plus_1 > 0x7FFFFFFFull) return hipErrorInvalidValue; // hipCUB counts in int: the caller cuts its batches below that
     return hipcub::DeviceScan::ExclusiveSum(tmp, *tmp_bytes, data, data, (int)n_plus_1, s);
 }
 hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t n, const RecColumns &c, uint64_t seq_bytes,

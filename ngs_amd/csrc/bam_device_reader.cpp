@@ -179,7 +179,9 @@ struct DeviceIngest {
         size_t fill = 0, consumed = 0;
         uint64_t total = 0; // decompressed bytes of `blocks`
         std::vector<BgzfBlock> blocks;
-        bool ready = false, last = false; // last: the file ends with this chunk
+        uint64_t file_off = 0;      // file offset of h[0] (a block start)
+        std::vector<uint64_t> coff; // file offset of every block of `blocks`
+        bool ready = false, last = false; // last: the byte range ends with this chunk
         std::string err;
     } hc[2];
     int cur = 0; // chunk the consumer takes next
@@ -201,11 +203,13 @@ struct DeviceIngest {
     struct Pending {
         bool issued = false, last = false;
         size_t n_blk = 0, consumed = 0;
-        uint64_t total = 0;
+        uint64_t total = 0, next_coff = 0; // next_coff: file offset behind the last block
         std::vector<BgzfBlock> blocks;
+        std::vector<uint64_t> coff;
         std::vector<uint32_t> status;
         std::string err;
     } pend[2];
+    DevBuf<uint64_t> d_coff_s[2], d_record_id;
     DevBuf<uint8_t> d_raw2;
     DevBuf<BgzfBlock> d_blocks_s[2];
     DevBuf<uint32_t> d_status_s[2];
@@ -228,15 +232,29 @@ struct DeviceIngest {
     uint64_t raw_len = 0, tail_off = 0;
     uint64_t n_rec = 0, cursor = 0; // records indexed in the current chunk / handed out
     uint64_t blocks_done = 0;
-    // sharded mode (ngsq_bam_shard_prepare): the shard's blocks are inflated at once and stay resident
-    bool sharded = false, committed = false;
-    uint64_t c_lo = 0;                   // file offset of the shard's first block
-    uint64_t u_hi = 0;                   // raw offset where the next shard's first block starts
-    bool last_shard = false;
-    std::vector<BgzfBlock> shard_blocks; // out_off / isize of every inflated block
-    std::vector<uint64_t> blk_start;     // file offset of every block
-    uint64_t entry = 0, n_all = 0, own = 0, base_index = 0;
-    std::vector<uint32_t> status;
+    // The byte range of the file this ingest scans.  The whole file: [0, size).  A shard (ngsq_bam_shard_begin): the
+    // blocks that start in [pos_lo, pos_hi) are its own -- a record belongs to the shard its first byte lies in --
+    // and the reader goes on to pos_end for the blocks that complete its last record.
+    uint64_t file_size = 0, pos_lo = 0, pos_hi = 0, pos_end = 0;
+    bool sharded = false;
+    int reader_threads = 0; // 0: the cgroup's quota less two
+    // where the first record starts: behind the header (shard 0), at a given offset of the first block's data (a
+    // confirmed virtual offset), or wherever the first plausible record chain of the first chunk starts (an
+    // assumption the neighbour shard confirms after the scan: ngsq_bam_shard_verify)
+    enum EntryMode { ENTRY_HEADER, ENTRY_KNOWN, ENTRY_FIND } entry_mode = ENTRY_HEADER;
+    uint64_t entry_uoff = 0;
+    bool boundary_passed = false; // a block at or behind pos_hi has been seen
+    bool carry_owned = true;      // the record cut by the previous chunk's end started in front of the boundary
+    bool complete = false;        // every record of the range has been handed out
+    uint64_t carry_id = 0, tail_id = 0; // virtual offset of the record carried into / cut by the end of the current chunk
+    uint64_t begin_voffset = 0, end_voffset = 0;
+    bool have_begin = false;
+    uint64_t n_own = 0;           // records handed out
+    uint64_t header_bytes0 = 0;   // the handle's header_bytes when the ingest began (load_chunk consumes it)
+    unsigned long long first_key = 0, last_key = 0; // refID << 32 | pos of the first / last record handed out
+    int cur_slot = 0;             // slot of the chunk being handed out
+    uint64_t carry_len = 0;       // bytes of the view in front of the current chunk's first byte
+    bool last_chunk = false;      // the chunk being handed out is the range's last
     std::vector<RecCandidate> cand;
     std::vector<uint64_t> seg;
     ~DeviceIngest() {
@@ -268,6 +286,11 @@ struct DeviceIngest {
 
 // a record cut by a chunk boundary is carried into the next chunk: room kept for it in the ingest buffer
 constexpr uint64_t CARRY_MAX = (uint64_t)1 << 24;
+// index_records: the chain starts at the first plausible record chain of the view (a shard that does not know yet)
+constexpr uint64_t FIND_ENTRY = ~0ull;
+// compressed bytes a shard's reader goes on behind its boundary for the end of its last record (any record the carry
+// space can hold fits, stored blocks included)
+constexpr uint64_t SHARD_EXTRA = CARRY_MAX + ((uint64_t)1 << 20);
 
 } // namespace ngsq
 
@@ -368,14 +391,16 @@ struct ReadPool {
 // buffer: reading a fixed amount left 150 MB per chunk to copy twice).
 void reader_main(DeviceIngest *d, std::string path) {
     std::vector<uint8_t> leftover;
-    bool eof = false;
-    uint64_t file_pos = 0; // next byte of the file to read
+    uint64_t file_pos = d->pos_lo; // next byte of the file to read
+    bool eof = file_pos >= d->pos_end;
+    const bool range_cut = d->pos_end < d->file_size; // the range ends inside the file: its last block may be cut, by design
     const size_t cap = 2 * d->comp_chunk;
     const uint64_t out_limit = d->raw_cap > 2 * CARRY_MAX ? d->raw_cap - CARRY_MAX : d->raw_cap / 2;
     constexpr size_t STEP = (size_t)64 << 20;
     constexpr int NT_MAX = ReadPool::NT_MAX;
     // leave two cores of the quota to the thread that drives the GPU and to this one (it frames while the others read)
-    const int NT = std::max(4, std::min(NT_MAX, effective_cores() - 2));
+    // (the workers of a sharded run share the quota: ngsq_bam_shard_begin sets reader_threads)
+    const int NT = d->reader_threads > 0 ? std::min(NT_MAX, d->reader_threads) : std::max(4, std::min(NT_MAX, effective_cores() - 2));
     double ratio = 0.0; // compressed bytes per inflated byte, from the chunks framed so far
     const int fd = fileno(d->f);
     // this thread, its pread workers and the pinned buffers they fill: all on the device's NUMA node
@@ -436,6 +461,7 @@ void reader_main(DeviceIngest *d, std::string path) {
         int n_steps = 0;
         memcpy(c.h, leftover.data(), leftover.size());
         c.fill = leftover.size();
+        c.file_off = file_pos - leftover.size();
         c.err.clear();
         c.blocks.clear();
         c.consumed = 0;
@@ -492,6 +518,7 @@ void reader_main(DeviceIngest *d, std::string path) {
                 want = std::min(want, STEP);
             }
             want = std::min(want, cap - c.fill);
+            want = (size_t)std::min<uint64_t>(want, d->pos_end - file_pos);
             const size_t per = (want + NT - 1) / NT;
             const double tsp = now_ms();
             n_steps++;
@@ -513,6 +540,7 @@ void reader_main(DeviceIngest *d, std::string path) {
             if (got < want) eof = true;
             file_pos += got;
             c.fill += got;
+            if (file_pos >= d->pos_end) eof = true;
             if (c.total) ratio = (double)c.consumed / (double)c.total;
         }
         if (c.err.empty() && !full) frame();
@@ -520,7 +548,16 @@ void reader_main(DeviceIngest *d, std::string path) {
         if (c.total) ratio = (double)c.consumed / (double)c.total;
         const double tr1 = now_ms();
         leftover.assign(c.h + c.consumed, c.h + c.fill);
-        if (c.err.empty() && c.blocks.empty()) {
+        if (eof && range_cut && !full) leftover.clear(); // the block the range was cut in: the next shard's
+        {   // file offset of every block (the blocks of a chunk are contiguous from h[0])
+            c.coff.resize(c.blocks.size());
+            uint64_t start = 0;
+            for (size_t k = 0; k < c.blocks.size(); k++) {
+                c.coff[k] = c.file_off + start;
+                start = c.blocks[k].in_off + c.blocks[k].in_len + 8;
+            }
+        }
+        if (c.err.empty() && c.blocks.empty() && !(eof && leftover.empty())) {
             if (eof && !leftover.empty()) c.err = path + ": truncated BGZF block at end of file";
             else if (!eof) c.err = path + ": BGZF block does not fit the ingest buffer";
         }
@@ -550,10 +587,13 @@ void reader_main(DeviceIngest *d, std::string path) {
 
 // Offsets of every complete record of d->raw[0, raw_len) whose chain starts at `first` -> d_rec_off; sets
 // d->tail_off to the offset of the cut record (or raw_len).  DESIGN.md section 9 "Record boundaries".
-int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_total) {
+int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_total, uint64_t *out_entry) {
     hipStream_t st = d->ctx->stream;
     const uint32_t n_seg = (uint32_t)((d->raw_len + REC_SEGMENT - 1) / REC_SEGMENT);
+    const bool find = first == FIND_ENTRY;
+    if (find) first = 0;
     *out_total = 0;
+    *out_entry = find ? d->raw_len : first;
     if (!n_seg) return NGSQ_OK;
     BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
     const uint32_t n_pieces = (uint32_t)((d->raw_len + REC_PIECE - 1) / REC_PIECE);
@@ -569,6 +609,27 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     BHIP(hipStreamSynchronize(st));
     d->seg.assign((size_t)n_seg * 2, 0);
     uint32_t *chosen = reinterpret_cast<uint32_t *>(d->seg.data() + n_seg);
+    if (find) { // the first plausible chain of the view: an assumption (ngsq_bam_shard_verify confirms or corrects it)
+        // -- preferably one whose landing offset is itself a candidate of the segment it lands in
+        first = d->raw_len;
+        bool any = false;
+        for (const RecCandidate &x : d->cand) {
+            if (!x.valid) continue;
+            if (!any) first = x.start; // fallback: the very first
+            any = true;
+            const uint64_t sl = x.landing / REC_SEGMENT;
+            bool agrees = sl >= n_seg;
+            for (uint32_t k = 0; k < REC_CANDIDATES && !agrees; k++) {
+                const RecCandidate &y = d->cand[(size_t)sl * REC_CANDIDATES + k];
+                agrees = y.valid && y.start == x.landing;
+            }
+            if (agrees) {
+                first = x.start;
+                break;
+            }
+        }
+        *out_entry = first;
+    }
     uint64_t cur = first, total_rec = 0;
     for (uint32_t s = 0; s < n_seg; s++) {
         const uint64_t s0 = (uint64_t)s * REC_SEGMENT, s1 = std::min<uint64_t>(s0 + REC_SEGMENT, d->raw_len);
@@ -628,10 +689,15 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
     p.n_blk = c.blocks.size();
     p.consumed = c.consumed;
     p.total = c.total;
+    p.next_coff = c.file_off + c.consumed;
+    p.blocks.clear();
+    p.coff.clear();
     if (!p.err.empty() || !p.n_blk) return NGSQ_OK;
     p.blocks = c.blocks; // the table is copied to the device asynchronously: keep it while the host slot is reused
+    p.coff = c.coff;
     hipStream_t sb = d->inf_stream;
     BHIP(d->d_blocks_s[slot].reserve(p.n_blk));
+    BHIP(d->d_coff_s[slot].reserve(p.n_blk));
     BHIP(d->d_status_s[slot].reserve(p.n_blk));
     if (d->h2d_issued[slot]) { // already on its way: the reader thread issued the copy
         if (trace_on()) {
@@ -647,6 +713,7 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
     }
     if (d->raw_free_set[slot]) BHIP(hipStreamWaitEvent(sb, d->raw_free[slot], 0)); // the chunk before last has left this buffer
     BHIP(hipMemcpyAsync(d->d_blocks_s[slot].p, p.blocks.data(), p.n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, sb));
+    BHIP(hipMemcpyAsync(d->d_coff_s[slot].p, p.coff.data(), p.n_blk * sizeof(uint64_t), hipMemcpyHostToDevice, sb));
     uint8_t *out = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX;
     {   // algorithmic bytes of the inflate: compressed bytes read + inflated bytes written
         KernelTimer kt(d->ctx, K_INFLATE, p.consumed + p.total, sb);
@@ -693,7 +760,6 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         d->blocks_done += p.n_blk;
     }
     // the pinned buffer and the device copy of the compressed bytes go back to the reader thread
-    d->file_done = p.last;
     d->h2d_issued[slot] = false;
     p.issued = false;
     {
@@ -729,21 +795,102 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     d->raw_len = carry + p.total;
     d->n_rec = d->cursor = 0;
     d->tail_off = 0;
-    const uint64_t first = d->first_chunk ? b->header_bytes : 0;
-    d->first_chunk = d->first_chunk && d->raw_len < first; // the header may span the first chunk(s)
-    if (d->raw_len < first) {
-        // nothing but header bytes so far: drop them and carry on
-        b->header_bytes -= d->raw_len;
-        d->tail_off = d->raw_len;
-        return NGSQ_OK;
+    d->cur_slot = slot;
+    d->carry_len = carry;
+    d->carry_id = d->tail_id;
+    // view offset -> virtual offset, by this chunk's block table (blocks without data hold no byte)
+    auto voffset_of = [&](uint64_t o) -> uint64_t {
+        if (o < carry) return d->carry_id;
+        const uint64_t u = o - carry;
+        size_t lo_k = 0, hi_k = p.blocks.size();
+        if (!hi_k || u >= p.total) return p.next_coff << 16; // behind the chunk's last byte: the next block's first
+        while (hi_k - lo_k > 1) {
+            const size_t mid = (lo_k + hi_k) / 2;
+            if (p.blocks[mid].out_off <= u) lo_k = mid;
+            else hi_k = mid;
+        }
+        return p.coff[lo_k] << 16 | (u - p.blocks[lo_k].out_off);
+    };
+    // records that start below `limit` are this range's own: everything in front of the first block at or behind pos_hi
+    uint64_t limit = d->raw_len;
+    if (d->boundary_passed) {
+        limit = carry && d->carry_owned ? 1 : 0;
+    } else {
+        const size_t kb = (size_t)(std::lower_bound(p.coff.begin(), p.coff.end(), d->pos_hi) - p.coff.begin());
+        if (kb < p.coff.size()) {
+            limit = carry + p.blocks[kb].out_off;
+            d->boundary_passed = true;
+        } else if (p.last && d->sharded && d->pos_hi < d->file_size) {
+            d->boundary_passed = true; // the range ended before a block of the next shard was seen (cut inside one)
+        }
+    }
+    uint64_t first = 0;
+    if (d->first_chunk) {
+        if (d->entry_mode == DeviceIngest::ENTRY_HEADER) {
+            first = b->header_bytes;
+            if (d->raw_len < first) { // nothing but header bytes so far (the header may span the first chunks): drop them
+                if (p.last) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: the file ends inside the BAM header", b->path.c_str());
+                if (limit < d->raw_len) return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: the BAM header is larger than the first shard", b->path.c_str());
+                b->header_bytes -= d->raw_len;
+                d->tail_off = d->raw_len;
+                return NGSQ_OK;
+            }
+        } else if (d->entry_mode == DeviceIngest::ENTRY_KNOWN) {
+            first = d->entry_uoff;
+            if (first > d->raw_len) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: virtual offset outside its block", b->path.c_str());
+        } else {
+            first = FIND_ENTRY;
+        }
+        d->first_chunk = false;
     }
     // ---- 4. record index
-    uint64_t total_rec = 0;
+    uint64_t total_rec = 0, entry = first;
     {
-        const int rc = index_records(b, d, first, &total_rec);
+        const int rc = index_records(b, d, first, &total_rec, &entry);
         if (rc) return rc;
     }
-    d->n_rec = total_rec;
+    if (!d->have_begin) {
+        d->begin_voffset = voffset_of(entry);
+        d->have_begin = true;
+    }
+    d->tail_id = d->tail_off < d->raw_len ? voffset_of(d->tail_off) : 0;
+    // ---- 5. which of them are this range's
+    uint64_t own = total_rec;
+    if (limit < d->raw_len && total_rec) {
+        unsigned long long below = 0;
+        BHIP(launch_count_below_u64(d->d_rec_off.p, total_rec, limit, d->d_small.p + 8, st));
+        BHIP(hipMemcpyAsync(&below, d->d_small.p + 8, sizeof below, hipMemcpyDeviceToHost, st));
+        BHIP(hipStreamSynchronize(st));
+        own = below;
+    }
+    d->n_rec = own;
+    const bool cut = d->tail_off < d->raw_len; // the chunk ends inside a record
+    if (own < total_rec) { // the first record of the next range
+        uint64_t next = 0;
+        BHIP(hipMemcpyAsync(&next, d->d_rec_off.p + own, sizeof next, hipMemcpyDeviceToHost, st));
+        BHIP(hipStreamSynchronize(st));
+        d->end_voffset = voffset_of(next);
+        d->last_chunk = true;
+    } else if (d->boundary_passed && cut && d->tail_off >= limit) { // the cut record is the next range's first
+        d->end_voffset = d->tail_id;
+        d->last_chunk = true;
+    } else if (p.last) {
+        if (cut)
+            return ngsq_bam_fail(d->pos_end >= d->file_size ? NGSQ_ERR_INVALID_ARGUMENT : NGSQ_ERR_UNSUPPORTED,
+                                 d->pos_end >= d->file_size ? "%s: truncated record" : "%s: a record reaches more than 17 MiB of BGZF blocks past its shard",
+                                 b->path.c_str());
+        d->end_voffset = p.next_coff << 16; // no record follows in what was read (the end of the file: file size << 16)
+        d->last_chunk = true;
+    } else {
+        d->carry_owned = !d->boundary_passed || d->tail_off < limit;
+    }
+    if (d->last_chunk && !p.last) { // nothing behind this chunk is wanted: the reader thread may stop
+        {
+            std::lock_guard<std::mutex> g(d->mu);
+            d->stop = true;
+        }
+        d->cv.notify_all();
+    }
     if (trace_on())
         fprintf(stderr, "[ingest] chunk: %zu blocks, %.1f MB -> %.1f MB, %llu records | batches of the previous chunk %.1f ms, "
                         "wait for reader %.1f ms, wait for inflate %.1f ms, index %.1f ms\n",
@@ -817,187 +964,128 @@ int find_block_start(FILE *f, uint64_t from, uint64_t file_size, uint64_t *out, 
     return -1;
 }
 
-uint64_t raw_to_voffset(const DeviceIngest *d, uint64_t o) {
-    // the block whose data holds raw offset o (blocks without data are skipped)
-    size_t lo = 0, hi = d->shard_blocks.size();
-    while (lo < hi) {
-        const size_t mid = (lo + hi) / 2;
-        if (d->shard_blocks[mid].out_off + d->shard_blocks[mid].isize <= o) lo = mid + 1;
-        else hi = mid;
+// Streams, events, the reader thread and the two raw buffers of an ingest over d's byte range.
+int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
+    // Chunk size: every buffer of the pipeline (two raw buffers, two pinned and two device buffers for the compressed
+    // bytes) is proportional to it and costs ~175 ms of allocation and pinning per GiB of chunk before the first record
+    // is seen, while the inflate launch runs ~13 % better with 1 GiB of blocks than with 256 MiB (fewer partial waves of
+    // decoders).  Measured on a 6 GB file (60 M records): 0.55 / 0.58 / 0.61 s with 256 / 512 / 1024 MiB; the big
+    // chunks win from roughly 50 GiB of inflated data on.  NGSQ_INGEST_RAW_MB overrides.
+    const uint64_t sz = d->pos_end > d->pos_lo ? d->pos_end - d->pos_lo : 0;
+    const size_t dflt_mb = sz > ((uint64_t)16 << 30) ? 1024 : sz > ((uint64_t)4 << 30) ? 512 : 256;
+    d->raw_cap = env_mb("NGSQ_INGEST_RAW_MB", dflt_mb);
+    d->comp_chunk = std::max<size_t>(d->raw_cap / 4, (size_t)1 << 17);
+    // (the two pinned buffers are allocated by the reader thread, on the device's NUMA node)
+    BHIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    {   // the inflate of the NEXT chunk runs beside the parse and the scan of this one, and it takes every
+        // wave slot its LDS allows: give it the lowest priority so that the short kernels of the context's stream get
+        // the slots its decoders free, instead of queueing behind all of them
+        int lo = 0, hi = 0;
+        BHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char *e = getenv("NGSQ_INFLATE_PRIORITY");
+        BHIP(hipStreamCreateWithPriority(&d->inf_stream, hipStreamNonBlocking, e && atoi(e) == 0 ? 0 : lo)); // =0: normal priority (A/B measurements)
     }
-    if (lo == d->shard_blocks.size()) return 0; // behind the last byte: end of file
-    return d->blk_start[lo] << 16 | (o - d->shard_blocks[lo].out_off);
-}
-
-bool voffset_to_raw(const DeviceIngest *d, uint64_t v, uint64_t *o) {
-    const uint64_t coff = v >> 16, uoff = v & 0xFFFF;
-    const auto it = std::lower_bound(d->blk_start.begin(), d->blk_start.end(), coff);
-    if (it == d->blk_start.end() || *it != coff) return false;
-    const BgzfBlock &bl = d->shard_blocks[(size_t)(it - d->blk_start.begin())];
-    if (uoff > bl.isize) return false;
-    *o = bl.out_off + uoff;
-    return true;
-}
-
-// index from d->entry, count the shard's own records, fill `out`
-int shard_index(ngsq_bam *b, DeviceIngest *d, ngsq_bam_shard_info *out) {
-    hipStream_t st = d->ctx->stream;
-    uint64_t total = 0;
-    const int rc = index_records(b, d, d->entry, &total);
-    if (rc) return rc;
-    d->n_all = total;
-    unsigned long long own = 0;
-    if (total) {
-        BHIP(launch_count_below_u64(d->d_rec_off.p, total, d->u_hi, d->d_small.p + 8, st));
-        BHIP(hipMemcpyAsync(&own, d->d_small.p + 8, sizeof own, hipMemcpyDeviceToHost, st));
-        BHIP(hipStreamSynchronize(st));
-    }
-    d->own = own;
-    // where the chain enters the next shard: the record after the last own one, or the cut tail
-    uint64_t next = d->tail_off;
-    if (own < total) {
-        BHIP(hipMemcpyAsync(&next, d->d_rec_off.p + own, sizeof next, hipMemcpyDeviceToHost, st));
-        BHIP(hipStreamSynchronize(st));
-    } else if (d->tail_off < d->u_hi) {
-        // the cut record itself starts inside the shard: its end lies beyond the blocks that were read
-        return ngsq_bam_fail(d->last_shard ? NGSQ_ERR_INVALID_ARGUMENT : NGSQ_ERR_UNSUPPORTED,
-                             d->last_shard ? "%s: truncated record" : "%s: a record reaches more than four BGZF blocks past its shard",
-                             b->path.c_str());
-    }
-    if (d->entry >= d->u_hi) next = d->entry; // no record starts here: the chain only passes through
-    out->n_records = own;
-    out->begin_voffset = raw_to_voffset(d, d->entry);
-    out->end_voffset = d->last_shard ? 0 : raw_to_voffset(d, next);
-    d->n_rec = own;
-    d->cursor = 0;
+    for (auto &e : d->h2d_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : d->inf_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : d->raw_free) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // the reader starts pinning and reading at once; the two raw buffers are allocated meanwhile
+    d->reader = std::thread(reader_main, d, b->path);
+    BHIP(d->d_raw.reserve(CARRY_MAX + d->raw_cap + 64)); // headroom for the carried record | one chunk's inflated bytes
+    BHIP(d->d_raw2.reserve(CARRY_MAX + d->raw_cap + 64));
+    BHIP(d->d_small.reserve(16));
+    // the host side of this handle is done: release its buffers
+    std::vector<uint8_t>().swap(b->comp);
+    std::vector<uint8_t>().swap(b->data);
+    (void)c;
     return NGSQ_OK;
+}
+
+int open_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest **out) {
+    DeviceIngest *d = new DeviceIngest();
+    d->ctx = c;
+    d->f = fopen(b->path.c_str(), "rb");
+    if (!d->f) {
+        delete d;
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "opening BAM file: %s", b->path.c_str());
+    }
+    struct stat fst;
+    if (fstat(fileno(d->f), &fst) != 0) {
+        delete d;
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "cannot stat %s", b->path.c_str());
+    }
+    d->file_size = (uint64_t)fst.st_size;
+    d->pos_lo = 0;
+    d->pos_hi = d->pos_end = d->file_size;
+    *out = d;
+    return NGSQ_OK;
+}
+
+unsigned long long sort_key(unsigned long long ref_pos) { // refID << 32 | pos -> ascending in a coordinate-sorted file
+    const int32_t ref = (int32_t)(ref_pos >> 32), pos = (int32_t)(uint32_t)ref_pos;
+    return ref < 0 ? ~0ull : (unsigned long long)(uint32_t)ref << 32 | (uint32_t)(pos + 1);
 }
 
 } // namespace
 
-extern "C" int ngsq_bam_shard_prepare(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, uint32_t n_shards, ngsq_bam_shard_info *out) {
-    if (!b || !c || !out || !n_shards || shard >= n_shards) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "bad argument");
-    if (b->host_mode || b->dev) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: the reader is already in use", b->path.c_str());
+// ---- one file, several GPUs (include/ngsq_bam.h "sharded device ingest") ---------------------------------------
+extern "C" int ngsq_bam_shard_begin(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, uint32_t n_shards, uint64_t begin_voffset) {
+    if (!b || !c || !n_shards || shard >= n_shards) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "bad argument");
+    if (b->host_mode) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: the reader is in host ingest mode", b->path.c_str());
     BHIP(hipSetDevice(c->device));
-    DeviceIngest *d = new DeviceIngest();
-    d->ctx = c;
-    d->sharded = true;
+    uint64_t header_bytes = b->header_bytes;
+    if (b->dev) { // again, from a confirmed first record (ngsq_bam_shard_verify): the previous scan's state goes
+        if (!b->dev->sharded || b->dev->ctx != c) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: the reader is already in use", b->path.c_str());
+        header_bytes = b->dev->header_bytes0;
+        b->dev_free(b->dev);
+        b->dev = nullptr;
+    }
+    DeviceIngest *d = nullptr;
+    int rc = open_ingest(b, c, &d);
+    if (rc) return rc;
     b->dev = d;
     b->dev_free = free_ingest;
-    d->f = fopen(b->path.c_str(), "rb");
-    if (!d->f) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "opening BAM file: %s", b->path.c_str());
-    if (fseeko(d->f, 0, SEEK_END) != 0) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "cannot seek in %s", b->path.c_str());
-    const uint64_t file_size = (uint64_t)ftello(d->f);
+    b->n_read = 0;
+    b->header_bytes = header_bytes;
+    d->header_bytes0 = header_bytes;
+    d->sharded = true;
     std::string err;
-    uint64_t lo = 0, hi = file_size;
-    if (find_block_start(d->f, file_size / n_shards * shard, file_size, &lo, &err) ||
-        find_block_start(d->f, shard + 1 == n_shards ? file_size : file_size / n_shards * (shard + 1), file_size, &hi, &err))
+    uint64_t lo = 0, hi = d->file_size;
+    if (find_block_start(d->f, d->file_size / n_shards * shard, d->file_size, &lo, &err) ||
+        find_block_start(d->f, shard + 1 == n_shards ? d->file_size : d->file_size / n_shards * (shard + 1), d->file_size, &hi, &err))
         return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: %s", b->path.c_str(), err.c_str());
-    d->c_lo = lo;
-    d->last_shard = hi >= file_size;
-    // the shard's blocks + up to four more, which hold the end of its last record
-    const uint64_t want = std::min<uint64_t>(file_size, hi + ((uint64_t)4 << 16)) - lo;
-    uint8_t *h = nullptr;
-    BHIP(ngsq::pool_pinned_alloc((void **)&h, want + 64, &d->hc[0].h_bytes));
-    d->hc[0].h = h; // freed with the ingest state
-    if (fseeko(d->f, (off_t)lo, SEEK_SET) != 0 || fread(h, 1, want, d->f) != want)
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "read error on %s", b->path.c_str());
-    size_t consumed = 0;
-    uint64_t total = 0;
-    if (!bgzf_split(h, want, &d->shard_blocks, &consumed, &total, &err))
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: %s", b->path.c_str(), err.c_str());
-    if (d->last_shard && consumed != want)
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated BGZF block at end of file", b->path.c_str());
-    const size_t n_blk = d->shard_blocks.size();
-    d->blk_start.resize(n_blk);
-    d->u_hi = total;
-    bool hit = d->last_shard;
-    for (size_t k = 0; k < n_blk; k++) {
-        const uint64_t start = lo + (k ? d->shard_blocks[k - 1].in_off + d->shard_blocks[k - 1].in_len + 8 : 0);
-        d->blk_start[k] = start;
-        if (start == hi) {
-            d->u_hi = d->shard_blocks[k].out_off;
-            hit = true;
-        }
+    d->pos_lo = lo;
+    d->pos_hi = hi;
+    d->pos_end = std::min(d->file_size, hi + SHARD_EXTRA);
+    d->entry_mode = shard == 0 ? DeviceIngest::ENTRY_HEADER : DeviceIngest::ENTRY_FIND;
+    if (begin_voffset) {
+        if (shard == 0) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "shard 0 starts behind the header");
+        const uint64_t coff = begin_voffset >> 16;
+        if (coff < lo || coff > d->file_size)
+            return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: virtual offset %llu lies in front of shard %u", b->path.c_str(),
+                                 (unsigned long long)begin_voffset, shard);
+        d->pos_lo = coff; // a block start, by the neighbour's word: the block chain is followed from there
+        d->pos_end = std::max(d->pos_end, std::min(d->file_size, coff + SHARD_EXTRA));
+        d->entry_mode = DeviceIngest::ENTRY_KNOWN;
+        d->entry_uoff = begin_voffset & 0xFFFFu;
+        if (coff >= hi) d->boundary_passed = true; // nothing of this shard's own (the first record lies behind it)
     }
-    if (!hit && !(n_blk && lo + consumed == hi))
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: the BGZF block chain from offset %llu does not reach the shard boundary at %llu",
-                             b->path.c_str(), (unsigned long long)lo, (unsigned long long)hi);
-    hipStream_t st = c->stream;
-    d->raw_cap = total + 64;
-    d->raw_len = total;
-    BHIP(d->d_raw.reserve(d->raw_cap));
-    d->raw = d->d_raw.p;
-    if (n_blk) {
-        BHIP(d->d_comp.reserve(consumed + INFLATE_IN_SLACK));
-        BHIP(d->d_blocks.reserve(n_blk));
-        BHIP(d->d_status.reserve(n_blk));
-        BHIP(ngsq::pool_pinned_h2d(d->d_comp.p, h, 0, consumed, st));
-        BHIP(hipMemsetAsync(d->d_comp.p + consumed, 0, INFLATE_IN_SLACK, st));
-        BHIP(hipMemcpyAsync(d->d_blocks.p, d->shard_blocks.data(), n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, st));
-        BHIP(launch_bgzf_inflate(d->d_comp.p, d->d_blocks.p, (uint32_t)n_blk, d->raw, d->d_status.p, true, st));
-        d->status.resize(n_blk);
-        BHIP(hipMemcpyAsync(d->status.data(), d->d_status.p, n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        BHIP(hipStreamSynchronize(st));
-        for (size_t k = 0; k < n_blk; k++)
-            if (d->status[k] != INF_OK)
-                return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: BGZF block at offset %llu: %s", b->path.c_str(),
-                                     (unsigned long long)d->blk_start[k], inflate_status_text(d->status[k]));
-    }
-    BHIP(d->d_small.reserve(16));
-    // the first record: known for shard 0 (behind the header), assumed elsewhere -- the first candidate chain
-    if (shard == 0) {
-        if (b->header_bytes > total) return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: the BAM header is larger than the first shard", b->path.c_str());
-        d->entry = b->header_bytes;
-    } else {
-        const uint32_t n_seg = (uint32_t)((d->raw_len + REC_SEGMENT - 1) / REC_SEGMENT);
-        d->entry = d->raw_len;
-        if (n_seg) {
-            BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
-            BHIP(d->d_pieces.reserve((size_t)n_seg * REC_CANDIDATES));
-            BHIP(launch_rec_candidates(d->raw, d->raw_len, 0, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, d->d_pieces.p, st));
-            d->cand.resize((size_t)n_seg * REC_CANDIDATES);
-            BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
-            BHIP(hipStreamSynchronize(st));
-            for (const RecCandidate &x : d->cand)
-                if (x.valid) {
-                    d->entry = x.start;
-                    break;
-                }
-        }
-    }
-    // the host side of this handle is done: release its buffers
-    std::vector<uint8_t>().swap(b->comp);
-    std::vector<uint8_t>().swap(b->data);
-    return shard_index(b, d, out);
+    // the workers of one node share its cores: quota less one driving thread and one framing thread per worker
+    if (const char *e = getenv("NGSQ_READER_THREADS")) d->reader_threads = atoi(e);
+    if (d->reader_threads <= 0) d->reader_threads = std::max(2, (effective_cores() - 2 * (int)n_shards) / (int)n_shards);
+    return start_ingest(b, c, d);
 }
 
-extern "C" int ngsq_bam_shard_commit(ngsq_bam *b, uint64_t begin_voffset, uint64_t first_record_index, ngsq_bam_shard_info *out) {
-    if (!b || !b->dev || !b->dev->sharded || !out) return ngsq_bam_fail(NGSQ_ERR_STATE, "ngsq_bam_shard_prepare first");
+extern "C" int ngsq_bam_shard_end(ngsq_bam *b, ngsq_bam_shard_info *out) {
+    if (!b || !out) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (!b->dev || !b->dev->sharded) return ngsq_bam_fail(NGSQ_ERR_STATE, "ngsq_bam_shard_begin first");
     DeviceIngest *d = b->dev;
-    BHIP(hipSetDevice(d->ctx->device));
-    uint64_t entry = d->entry;
-    if (begin_voffset && !voffset_to_raw(d, begin_voffset, &entry))
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: virtual offset %llu is not inside this shard", b->path.c_str(),
-                             (unsigned long long)begin_voffset);
-    if (entry != d->entry) { // the assumed first record was not the real one: index again from the confirmed start
-        d->entry = entry;
-        const int rc = shard_index(b, d, out);
-        if (rc) return rc;
-    } else {
-        out->n_records = d->own;
-        out->begin_voffset = raw_to_voffset(d, d->entry);
-        uint64_t next = d->tail_off;
-        if (d->own < d->n_all) {
-            BHIP(hipMemcpy(&next, d->d_rec_off.p + d->own, sizeof next, hipMemcpyDeviceToHost));
-        }
-        if (d->entry >= d->u_hi) next = d->entry;
-        out->end_voffset = d->last_shard ? 0 : raw_to_voffset(d, next);
-    }
-    d->base_index = first_record_index;
-    b->n_read = first_record_index;
-    d->committed = true;
-    d->file_done = true; // nothing more to load: the batches come from the resident shard
+    if (!d->complete) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: the shard has not been scanned to its end", b->path.c_str());
+    memset(out, 0, sizeof *out);
+    out->n_records = d->n_own;
+    out->begin_voffset = d->begin_voffset;
+    out->end_voffset = d->end_voffset;
+    out->first_key = d->n_own ? sort_key(d->first_key) : 0;
+    out->last_key = d->n_own ? sort_key(d->last_key) : 0;
     return NGSQ_OK;
 }
 
@@ -1012,62 +1100,23 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     out->first_record_index = b->n_read;
     BHIP(hipSetDevice(c->device));
     DeviceIngest *d = b->dev;
-    if (d && d->sharded && !d->committed)
-        return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: ngsq_bam_shard_commit before the first batch", b->path.c_str());
-    if (!d) {
-        d = new DeviceIngest();
-        d->ctx = c;
-        d->f = fopen(b->path.c_str(), "rb");
-        if (!d->f) {
-            delete d;
-            return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "opening BAM file: %s", b->path.c_str());
-        }
-        // Chunk size: every buffer of the pipeline (two raw buffers, two pinned and two device buffers for the compressed
-        // bytes) is proportional to it and costs ~175 ms of allocation and pinning per GiB of chunk before the first record
-        // is seen, while the inflate launch runs ~13 % better with 1 GiB of blocks than with 256 MiB (fewer partial waves of
-        // decoders).  Measured on a 6 GB file (60 M records): 0.55 / 0.58 / 0.61 s with 256 / 512 / 1024 MiB; the big
-        // chunks win from roughly 50 GiB of inflated data on.  NGSQ_INGEST_RAW_MB overrides.
-        size_t dflt_mb = 256;
-        {
-            struct stat fst;
-            if (fstat(fileno(d->f), &fst) == 0) {
-                const uint64_t sz = (uint64_t)fst.st_size;
-                dflt_mb = sz > ((uint64_t)16 << 30) ? 1024 : sz > ((uint64_t)4 << 30) ? 512 : 256;
-            }
-        }
-        d->raw_cap = env_mb("NGSQ_INGEST_RAW_MB", dflt_mb);
-        d->comp_chunk = std::max<size_t>(d->raw_cap / 4, (size_t)1 << 17);
+    if (!d) { // the whole file
+        int rc = open_ingest(b, c, &d);
+        if (rc) return rc;
         b->dev = d;
         b->dev_free = free_ingest;
-        // (the two pinned buffers are allocated by the reader thread, on the device's NUMA node)
-        BHIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
-        {   // the inflate of the NEXT chunk runs beside the parse and the scan of this one, and it takes every
-            // wave slot its LDS allows: give it the lowest priority so that the short kernels of the context's stream get
-            // the slots its decoders free, instead of queueing behind all of them
-            int lo = 0, hi = 0;
-            BHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            const char *e = getenv("NGSQ_INFLATE_PRIORITY");
-            BHIP(hipStreamCreateWithPriority(&d->inf_stream, hipStreamNonBlocking, e && atoi(e) == 0 ? 0 : lo)); // =0: normal priority (A/B measurements)
-        }
-        for (auto &e : d->h2d_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto &e : d->inf_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto &e : d->raw_free) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        // the reader starts pinning and reading at once; the two 1 GiB raw buffers are allocated meanwhile
-        d->reader = std::thread(reader_main, d, b->path);
-        BHIP(d->d_raw.reserve(CARRY_MAX + d->raw_cap + 64)); // headroom for the carried record | one chunk's inflated bytes
-        BHIP(d->d_raw2.reserve(CARRY_MAX + d->raw_cap + 64));
-        // the host side of this handle is done: release its buffers
-        std::vector<uint8_t>().swap(b->comp);
-        std::vector<uint8_t>().swap(b->data);
+        d->header_bytes0 = b->header_bytes;
+        rc = start_ingest(b, c, d);
+        if (rc) return rc;
     }
     if (d->ctx != c) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: device ingest is bound to another context", b->path.c_str());
     if (max_records == 0) return NGSQ_OK;
     hipStream_t st = c->stream;
     while (d->cursor == d->n_rec) {
-        if (d->file_done) {
-            if (!d->sharded && d->tail_off != d->raw_len)
-                return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: truncated record", b->path.c_str());
-            return NGSQ_OK; // clean end of file (of the shard)
+        if (d->complete) return NGSQ_OK; // clean end of the file (of the shard)
+        if (d->last_chunk) {
+            d->complete = true;
+            return NGSQ_OK;
         }
         const int rc = load_chunk(b, d);
         if (rc) return rc;
@@ -1084,6 +1133,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     BHIP(d->d_tlen.reserve(n + 64));
     BHIP(d->d_l_seq.reserve(n + 64));
     BHIP(d->d_var_base.reserve(2 * n + 64));
+    BHIP(d->d_record_id.reserve(n + 64));
     RecColumns col{};
     col.flag = d->d_flag.p;
     col.n_cigar = d->d_n_cigar.p;
@@ -1096,11 +1146,23 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     BHIP(hipMemsetAsync(d->d_small.p + 1, 0, 3 * sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_COLUMNS, n * 36);
-        BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_var_base.p, d->d_small.p + 1, st));
+        // the records' ids: their virtual offsets, by the block table of the chunk they come from
+        const DeviceIngest::Pending &cp = d->pend[d->cur_slot];
+        RecOrigin org{};
+        org.record_id = d->d_record_id.p;
+        org.blocks = d->d_blocks_s[d->cur_slot].p;
+        org.coff = d->d_coff_s[d->cur_slot].p;
+        org.n_blocks = (uint32_t)cp.blocks.size();
+        org.carry = d->carry_len;
+        org.carry_id = d->carry_id;
+        BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_var_base.p, d->d_small.p + 1, org, st));
     }
-    unsigned long long stats[3] = {0, 0, 0};
+    unsigned long long stats[5] = {0, 0, 0, 0, 0};
     BHIP(hipMemcpyAsync(stats, d->d_small.p + 1, sizeof stats, hipMemcpyDeviceToHost, st));
     BHIP(hipStreamSynchronize(st));
+    if (!d->n_own) d->first_key = stats[3];
+    d->last_key = stats[4];
+    d->n_own += n;
     const uint32_t max_l = (uint32_t)stats[0], max_ops = (uint32_t)stats[1];
     const uint64_t sum_qual = stats[2];
     const uint32_t pitch_q = max_l, pitch_s = (max_l + 1) / 2;
@@ -1161,6 +1223,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     out->seq = col.seq;
     out->qual = col.qual;
     out->cigar = col.cigar;
+    out->record_id = d->d_record_id.p;
     out->seq_bytes = so;
     out->qual_bytes = qo;
     out->cigar_ops = co;

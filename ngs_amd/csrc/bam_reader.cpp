@@ -59,6 +59,7 @@ struct Block {
     size_t in_off, in_len; // deflate payload inside the compressed buffer
     size_t out_off;
     uint32_t isize, crc;
+    size_t start; // of the gzip member inside the compressed buffer
 };
 
 } // namespace
@@ -104,6 +105,7 @@ int inflate_more(ngsq_bam *b, size_t want_compressed) {
         if (bsize < 12 + xlen + 8) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: corrupt BGZF block size", b->path.c_str());
         if (n - p < bsize) break; // incomplete block: wait for more bytes
         Block bl;
+        bl.start = p;
         bl.in_off = p + 12 + xlen;
         bl.in_len = bsize - 12 - xlen - 8;
         bl.crc = rd32(c + p + bsize - 8);
@@ -122,6 +124,13 @@ int inflate_more(ngsq_bam *b, size_t want_compressed) {
     }
     const size_t base = b->data.size();
     b->data.resize(base + out_total);
+    {   // origins of the bytes `data` holds: forget the blocks that have been parsed completely, note the new ones
+        size_t k = 0;
+        while (k + 1 < b->origin.size() && b->origin[k + 1].abs_off <= b->data_base) k++;
+        b->origin.erase(b->origin.begin(), b->origin.begin() + (ptrdiff_t)k);
+        for (const Block &bl : blocks)
+            if (bl.isize) b->origin.push_back({b->data_base + base + bl.out_off, b->comp_file_off + bl.start});
+    }
     std::atomic<size_t> next{0};
     std::atomic<int> bad{0};
     auto worker = [&]() {
@@ -156,6 +165,7 @@ int inflate_more(ngsq_bam *b, size_t want_compressed) {
     for (auto &t : pool) t.join();
     if (bad) return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: BGZF %s", b->path.c_str(), bad == 2 ? "CRC mismatch" : "inflate failed");
     b->comp.erase(b->comp.begin(), b->comp.begin() + (ptrdiff_t)p);
+    b->comp_file_off += p;
     return NGSQ_OK;
 }
 
@@ -304,6 +314,7 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     const bool cig1 = max_ops <= 1;
     b->flag.resize(n); b->n_cigar.resize(n); b->mapq.resize(n + 16);
     b->ref_id.resize(n); b->pos.resize(n); b->mate_ref_id.resize(n); b->tlen.resize(n); b->l_seq.resize(n);
+    b->record_id.resize(n);
     const uint8_t *const D = b->data.data() + b->data_pos;
     uint64_t so = 0, qo = 0, co = 0;
     if (!fixed || !cig1) {
@@ -355,6 +366,16 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
             b->l_seq[i] = l;
             b->mate_ref_id[i] = (int32_t)rd32(r + 20);
             b->tlen[i] = (int32_t)rd32(r + 28);
+            {   // the record's identity: its BAM virtual offset (include/ngsq.h record_id)
+                const uint64_t abs = b->data_base + b->data_pos + recs[i];
+                size_t lo_k = 0, hi_k = b->origin.size(); // last origin with abs_off <= abs
+                while (hi_k - lo_k > 1) {
+                    const size_t mid = (lo_k + hi_k) / 2;
+                    if (b->origin[mid].abs_off <= abs) lo_k = mid;
+                    else hi_k = mid;
+                }
+                b->record_id[i] = b->origin[lo_k].coff << 16 | (abs - b->origin[lo_k].abs_off);
+            }
             const uint8_t *cg = r + 32 + l_read_name;
             const uint8_t *sq = cg + 4ull * n_ops;
             const uint8_t *ql = sq + (l + 1) / 2;
@@ -394,6 +415,7 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     out->seq = b->seq.p;
     out->qual = b->qual.p;
     out->cigar = b->cigar.data();
+    out->record_id = b->record_id.data();
     if (fixed) {
         out->seq_stride = pitch_s;
         out->qual_stride = pitch_q;
@@ -482,6 +504,8 @@ int ngsq_bam_seek(ngsq_bam *b, uint64_t voffset) {
     if (fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET) != 0)
         return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: cannot seek to block %llu", b->path.c_str(), (unsigned long long)(voffset >> 16));
     b->comp.clear();
+    b->comp_file_off = voffset >> 16;
+    b->origin.clear();
     b->data.clear();
     b->data_pos = 0;
     b->data_base = 0;

@@ -50,7 +50,15 @@ struct ngsq_bam {
     ngsq::RawBuf seq, qual; // large: grown without initialisation, padded by the fill threads
     std::vector<int32_t> ref_id, pos, mate_ref_id, tlen;
     std::vector<uint32_t> l_seq, cigar;
-    std::vector<uint64_t> seq_off, qual_off, cigar_off;
+    std::vector<uint64_t> seq_off, qual_off, cigar_off, record_id;
+    // where the decompressed bytes came from: one entry per BGZF block with data that `data` still holds any of,
+    // ascending; a record's id is its virtual offset, coff << 16 | (offset in the decompressed stream - abs_off)
+    struct BlockOrigin {
+        uint64_t abs_off; // offset of the block's first byte in the decompressed stream (data_base + index into data)
+        uint64_t coff;    // file offset of the block
+    };
+    std::vector<BlockOrigin> origin;
+    uint64_t comp_file_off = 0; // file offset of comp[0]
     // bookkeeping shared with the device ingest
     size_t read_chunk = (size_t)64 << 20; // compressed bytes per read
     uint64_t data_base = 0;               // offset in the decompressed stream of data[0]

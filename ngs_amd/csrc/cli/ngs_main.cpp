@@ -167,8 +167,9 @@ struct Compact { // offsets-layout batch assembled from picked records
     std::vector<uint8_t> mapq, seq, qual;
     std::vector<int32_t> ref_id, pos, mate_ref_id, tlen;
     std::vector<uint32_t> l_seq, cigar;
-    std::vector<uint64_t> seq_off{0}, qual_off{0}, cigar_off{0};
+    std::vector<uint64_t> seq_off{0}, qual_off{0}, cigar_off{0}, record_id;
     void push(const ngsq_batch &b, uint64_t i) {
+        record_id.push_back(b.record_id ? b.record_id[i] : b.first_record_index + i); // the record keeps its identity (GC window)
         flag.push_back(b.flag[i]);
         mapq.push_back(b.mapq[i]);
         ref_id.push_back(b.ref_id[i]);
@@ -208,6 +209,7 @@ struct Compact { // offsets-layout batch assembled from picked records
         o.mate_ref_id = mate_ref_id.data(); o.tlen = tlen.data(); o.l_seq = l_seq.data(); o.n_cigar = n_cigar.data();
         o.seq = seq.data(); o.seq_off = seq_off.data(); o.qual = qual.data(); o.qual_off = qual_off.data();
         o.cigar = cigar.data(); o.cigar_off = cigar_off.data();
+        o.record_id = record_id.data();
         o.seq_bytes = seq_off.back(); o.qual_bytes = qual_off.back(); o.cigar_ops = cigar_off.back();
         return o;
     }
@@ -655,13 +657,25 @@ int main(int argc, char **argv) {
                          " device(s) visible (--same-device shares one)");
                 a.device += a.rank;
             }
-            uint8_t uid[NGSQ_COMM_ID_BYTES] = {0};
-            if (a.rank == 0 && ngsq_comm_unique_id(uid) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
-            std::vector<uint8_t> all((size_t)a.world * NGSQ_COMM_ID_BYTES);
-            if (ngsq_comm_allgather_host(boot, uid, all.data(), NGSQ_COMM_ID_BYTES) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
-            if (ngsq_comm_create_rccl(a.rank, a.world, all.data(), a.device, &comm) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
-            if (ngsq_comm_barrier(boot) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
-            ngsq_comm_destroy(boot);
+            // rank 0's unique id + "I have one": a rank 0 that cannot load librccl must not leave the others waiting
+            uint8_t uid[NGSQ_COMM_ID_BYTES + 8] = {0};
+            std::string no_rccl;
+            if (a.rank == 0) {
+                if (ngsq_comm_unique_id(uid) == NGSQ_OK) uid[NGSQ_COMM_ID_BYTES] = 1;
+                else no_rccl = ngsq_comm_last_error(nullptr);
+            }
+            std::vector<uint8_t> all((size_t)a.world * sizeof uid);
+            if (ngsq_comm_allgather_host(boot, uid, all.data(), sizeof uid) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
+            if (!all[NGSQ_COMM_ID_BYTES]) {
+                if (!a.transport.empty()) bail(a.rank == 0 ? no_rccl : std::string("RCCL is not available on rank 0"));
+                // not asked for by name: the same exchange, host-staged through the shared-memory segment
+                if (a.rank == 0) logf(1, "%s; the exchange runs over shared memory instead", no_rccl.c_str());
+                comm = boot;
+            } else {
+                if (ngsq_comm_create_rccl(a.rank, a.world, all.data(), a.device, &comm) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
+                if (ngsq_comm_barrier(boot) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
+                ngsq_comm_destroy(boot);
+            }
         }
         cfg.device = a.device;
         logf(2, "Worker %d of %d on device %d, exchange over %s.", a.rank, a.world, a.device, ngsq_comm_kind(comm));
@@ -701,16 +715,46 @@ int main(int argc, char **argv) {
     }
 
     n_pass1 = 0;
+    bool shard_unsorted = false;
     if (worker) {
-        // this worker's BGZF block range, resident on its device; record boundaries agreed with the neighbours
-        ngsq_bam_shard_info info;
-        if (ngsq_bam_shard_open(bam, ctx, comm, &info) != NGSQ_OK) bail(ngsq_comm_last_error(comm));
+        // this worker's BGZF block range, streamed through the same chunked pipeline as a whole file; the shards
+        // compare the record boundaries they assumed when all have reached their end (ngsq_bam_shard_verify), and
+        // a shard whose assumption was wrong scans again from the confirmed offset
+        if (ngsq_bam_shard_open(bam, ctx, comm) != NGSQ_OK) bail(ngsq_comm_last_error(comm));
         for (;;) {
-            ngsq_batch b;
-            if (ngsq_bam_next_batch_device(bam, ctx, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
-            if (!b.n_records) break;
-            CHECK(ctx, ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH));
-            n_pass1 += b.n_records;
+            std::string scan_error; // a worker that fails still meets the others in the collective: nobody waits for it
+            n_pass1 = 0;
+            for (;;) {
+                ngsq_batch b;
+                if (ngsq_bam_next_batch_device(bam, ctx, a.batch_records, &b) != NGSQ_OK) {
+                    scan_error = ngsq_bam_last_error();
+                    break;
+                }
+                if (!b.n_records) break;
+                if (ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH) != NGSQ_OK) {
+                    scan_error = ngsq_last_error(ctx);
+                    break;
+                }
+                n_pass1 += b.n_records;
+            }
+            ngsq_bam_shard_info info;
+            int again = 0;
+            const int vrc = ngsq_bam_shard_verify(bam, ctx, comm, &info, &again);
+            if (!scan_error.empty()) bail(scan_error);
+            if (vrc == NGSQ_ERR_UNSORTED) { // neighbouring shards out of coordinate order: same verdict on every worker
+                shard_unsorted = true;
+                break;
+            }
+            if (vrc != NGSQ_OK) bail(ngsq_comm_last_error(comm));
+            if (!again) {
+                logf(3, "  [*] Worker %d: %llu records, records in front of it: %llu.", a.rank, (unsigned long long)info.n_records,
+                     (unsigned long long)info.first_record_index);
+                break;
+            }
+            if (info.rescan) {
+                logf(1, "worker %d: the assumed first record of its shard was not one; scanning the shard again from the confirmed offset", a.rank);
+                CHECK(ctx, ngsq_reset(ctx));
+            }
         }
     } else if (!a.has_n) {
         // no truncation: both passes see every record -> one scan
@@ -846,7 +890,10 @@ int main(int argc, char **argv) {
     {
         int rc = NGSQ_OK;
         std::string why;
-        if (worker && (rc = ngsq_exchange(ctx, comm, nullptr)) != NGSQ_OK) why = ngsq_comm_last_error(comm);
+        if (shard_unsorted) {
+            rc = NGSQ_ERR_UNSORTED;
+            why = ngsq_comm_last_error(comm);
+        } else if (worker && (rc = ngsq_exchange(ctx, comm, nullptr)) != NGSQ_OK) why = ngsq_comm_last_error(comm);
         milestone("records scanned");
         if (rc == NGSQ_OK && (rc = ngsq_finalize(ctx)) != NGSQ_OK) why = ngsq_last_error(ctx);
         milestone("finalized");

@@ -58,13 +58,16 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr; // optional
     std::string why;
 };
 
+RcclApi g_rccl; // g_rccl.why: every candidate's dlerror when nothing could be loaded
+
 RcclApi *rccl_api() {
-    static RcclApi api;
+    RcclApi &api = g_rccl;
     static std::once_flag once;
-    std::call_once(once, [] {
+    std::call_once(once, [&api] {
         // a library of that soname already in the process (e.g. PyTorch's copy) is the one dlopen returns
         // NGSQ_RCCL_LIB: another build of the library (or tests/rccl_double, which lets three ranks share one GPU)
         const char *names[] = {getenv("NGSQ_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -72,7 +75,9 @@ RcclApi *rccl_api() {
             if (!n || !*n) continue;
             api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
-            api.why = dlerror() ? dlerror() : "dlopen failed";
+            // dlerror() clears the message it returns: ask once
+            const char *e = dlerror();
+            api.why += std::string(api.why.empty() ? "" : "; ") + (e ? e : "dlopen failed");
         }
         if (!api.handle) return;
 #define SYM(field, name)                                                             \
@@ -95,6 +100,7 @@ RcclApi *rccl_api() {
         SYM(GroupEnd, "ncclGroupEnd");
         SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.handle, "ncclGetVersion"));
     });
     return api.handle ? &api : nullptr;
 }
@@ -142,11 +148,22 @@ struct RcclComm : ngsq_comm {
     int sendrecv(const ngsq_p2p *sends, uint32_t ns, const ngsq_p2p *recvs, uint32_t nr, hipStream_t s) override {
         if (!ns && !nr) return NGSQ_OK;
         NCCL_TRY(this, api->GroupStart());
-        for (uint32_t i = 0; i < nr; i++)
-            if (recvs[i].bytes) NCCL_TRY(this, api->Recv(recvs[i].buf, recvs[i].bytes, ncclUint8, recvs[i].peer, comm, s));
-        for (uint32_t i = 0; i < ns; i++)
-            if (sends[i].bytes) NCCL_TRY(this, api->Send(sends[i].buf, sends[i].bytes, ncclUint8, sends[i].peer, comm, s));
-        NCCL_TRY(this, api->GroupEnd());
+        // an error inside the group must not leave it open: remember the first one, close the group, then report
+        ncclResult_t first = ncclSuccess;
+        const char *what = "";
+        for (uint32_t i = 0; i < nr && first == ncclSuccess; i++)
+            if (recvs[i].bytes) {
+                first = api->Recv(recvs[i].buf, recvs[i].bytes, ncclUint8, recvs[i].peer, comm, s);
+                what = "ncclRecv";
+            }
+        for (uint32_t i = 0; i < ns && first == ncclSuccess; i++)
+            if (sends[i].bytes) {
+                first = api->Send(sends[i].buf, sends[i].bytes, ncclUint8, sends[i].peer, comm, s);
+                what = "ncclSend";
+            }
+        const ncclResult_t end = api->GroupEnd();
+        if (first != ncclSuccess) return comm_fail(this, NGSQ_ERR_DEVICE, "%s failed: %s", what, api->GetErrorString(first));
+        if (end != ncclSuccess) return comm_fail(this, NGSQ_ERR_DEVICE, "ncclGroupEnd failed: %s", api->GetErrorString(end));
         return NGSQ_OK;
     }
     int need(uint64_t bytes) {
@@ -412,7 +429,7 @@ const char *ngsq_comm_last_error(const ngsq_comm *c) { return c ? c->err.c_str()
 int ngsq_comm_unique_id(uint8_t id[NGSQ_COMM_ID_BYTES]) {
     if (!id) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
     RcclApi *api = rccl_api();
-    if (!api) return comm_fail(nullptr, NGSQ_ERR_UNSUPPORTED, "RCCL is not available (librccl.so.1 could not be loaded)");
+    if (!api) return comm_fail(nullptr, NGSQ_ERR_UNSUPPORTED, "RCCL is not available (librccl.so.1 could not be loaded: %s)", g_rccl.why.c_str());
     static_assert(sizeof(ncclUniqueId) == NGSQ_COMM_ID_BYTES, "unique id size");
     ncclUniqueId u;
     NCCL_TRY(nullptr, api->GetUniqueId(&u));
@@ -426,7 +443,7 @@ int ngsq_comm_create_rccl(int rank, int world, const uint8_t id[NGSQ_COMM_ID_BYT
     int rc = check_rank(rank, world);
     if (rc) return rc;
     RcclApi *api = rccl_api();
-    if (!api) return comm_fail(nullptr, NGSQ_ERR_UNSUPPORTED, "RCCL is not available (librccl.so.1 could not be loaded)");
+    if (!api) return comm_fail(nullptr, NGSQ_ERR_UNSUPPORTED, "RCCL is not available (librccl.so.1 could not be loaded: %s)", g_rccl.why.c_str());
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return comm_fail(nullptr, NGSQ_ERR_NO_DEVICE, "no HIP device available");
@@ -559,6 +576,13 @@ int ngsq_comm_create_custom(int rank, int world, const ngsq_comm_ops *ops, ngsq_
     c->ops = *ops;
     *out = c;
     return NGSQ_OK;
+}
+
+int ngsq_comm_rccl_version(void) {
+    RcclApi *api = rccl_api();
+    int v = 0;
+    if (!api || !api->GetVersion || api->GetVersion(&v) != ncclSuccess) return 0;
+    return v;
 }
 
 void ngsq_comm_destroy(ngsq_comm *c) { delete c; }

@@ -601,6 +601,7 @@ int ngsq_process_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
         db.qual_off = b->qual_off;
         db.cigar = b->cigar;
         db.cigar_off = b->cigar_off;
+        db.record_id = b->record_id;
         return launch_all(c, db, cs, pass_mask);
     }
 
@@ -608,7 +609,7 @@ int ngsq_process_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
     const uint64_t need = round_up(n * 2, 256) + round_up(n, 256) + 5 * round_up(n * 4, 256) +
                           round_up(n * 2, 256) + round_up(cs.seq_bytes + 16, 256) +
                           round_up(cs.qual_bytes + 16, 256) + round_up(cs.cigar_ops * 4 + 16, 256) +
-                          3 * round_up((n + 1) * 8, 256) + 4096;
+                          3 * round_up((n + 1) * 8, 256) + round_up(n * 8, 256) + 4096;
     Staging &sg = c->stage[c->stage_next];
     c->stage_next ^= 1;
     if (sg.done) HIP_TRY(c, hipEventSynchronize(sg.done)); // kernels of its previous batch finished
@@ -648,6 +649,7 @@ int ngsq_process_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
         STAGE(qual_off, uint64_t, n + 1);
         STAGE(cigar, uint32_t, cs.cigar_ops);
         STAGE(cigar_off, uint64_t, n + 1);
+        STAGE(record_id, uint64_t, n);
 #undef STAGE
         c->timing[K_H2D].algo_bytes += copied;
     }

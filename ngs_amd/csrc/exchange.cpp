@@ -484,39 +484,66 @@ void free_exchange_scratch(void *p) { delete static_cast<Scratch *>(p); }
 } // namespace ngsq
 
 // ---------------------------------------------------------------------------------------------
-// one BAM file, several GPUs: agree on the record boundaries between neighbouring shards
+// one BAM file, several GPUs: the shards scan on an assumption about their first record and compare notes afterwards
 // ---------------------------------------------------------------------------------------------
-extern "C" int ngsq_bam_shard_open(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *comm, ngsq_bam_shard_info *out) {
-    if (!bam || !ctx || !comm || !out) return comm_fail(comm, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+extern "C" int ngsq_bam_shard_open(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *comm) {
+    if (!bam || !ctx || !comm) return comm_fail(comm, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    const int rc = ngsq_bam_shard_begin(bam, ctx, (uint32_t)comm->rank, (uint32_t)comm->world, 0);
+    return rc ? comm_fail(comm, rc, "%s", ngsq_bam_last_error()) : NGSQ_OK;
+}
+
+extern "C" int ngsq_bam_shard_verify(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *comm, ngsq_bam_shard_info *out, int *again) {
+    if (!bam || !ctx || !comm || !out || !again) return comm_fail(comm, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
     const uint32_t world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
+    *again = 0;
     ngsq_bam_shard_info info{};
-    int rc = ngsq_bam_shard_prepare(bam, ctx, rank, world, &info);
-    // a rank that failed still takes part in the collectives (with a poison value) so that nobody hangs
-    std::vector<uint64_t> rows(4 * (size_t)world);
-    for (uint32_t round = 0; round <= world + 1; round++) {
-        const uint64_t mine[4] = {info.n_records, info.begin_voffset, info.end_voffset, (uint64_t)(rc != NGSQ_OK)};
-        const int rc2 = ngsq_comm_allgather_host(comm, mine, rows.data(), sizeof mine);
-        if (rc2) return rc2;
-        if (rc) return comm_fail(comm, rc, "%s", ngsq_bam_last_error());
-        for (uint32_t k = 0; k < world; k++)
-            if (rows[4 * k + 3]) return comm_fail(comm, NGSQ_ERR_STATE, "shard %u of the file failed to open", k);
-        // shard k+1 must begin where shard k's record chain ends; shards without a record start pass it on
-        std::vector<uint64_t> want(world);
-        want[0] = rows[1];
-        for (uint32_t k = 1; k < world; k++) want[k] = rows[4 * (k - 1) + 2] ? rows[4 * (k - 1) + 2] : rows[4 * k + 1];
-        bool stable = true;
-        uint64_t first = 0;
-        for (uint32_t k = 0; k < world; k++) {
-            stable = stable && want[k] == rows[4 * k + 1];
-            if (k < rank) first += rows[4 * k];
-        }
-        const uint64_t begin = want[rank] != rows[4 * rank + 1] ? want[rank] : 0; // 0 = keep the assumption
-        rc = ngsq_bam_shard_commit(bam, begin, first, &info);
-        if (stable) {
+    // a rank whose scan failed still takes part in the collective (with a poison value) so that nobody hangs
+    const int rc_end = ngsq_bam_shard_end(bam, &info);
+    const std::string why = rc_end ? ngsq_bam_last_error() : "";
+    constexpr size_t W = 6;
+    std::vector<uint64_t> rows(W * (size_t)world);
+    const uint64_t mine[W] = {info.n_records, info.begin_voffset, info.end_voffset, (uint64_t)(rc_end != NGSQ_OK), info.first_key, info.last_key};
+    const int rc2 = ngsq_comm_allgather_host(comm, mine, rows.data(), sizeof mine);
+    if (rc2) return rc2;
+    if (rc_end) return comm_fail(comm, rc_end, "%s", why.c_str());
+    for (uint32_t k = 0; k < world; k++)
+        if (rows[W * k + 3]) return comm_fail(comm, NGSQ_ERR_STATE, "shard %u of the file failed", k);
+    // shard k+1 must begin where shard k's record chain ends (shards without a record start pass it on: begin == end)
+    bool stable = true;
+    uint64_t first = 0;
+    for (uint32_t k = 0; k < world; k++) {
+        if (k) stable = stable && rows[W * (k - 1) + 2] == rows[W * k + 1];
+        if (k < rank) first += rows[W * k];
+    }
+    if (!stable) {
+        // By induction from the header shard 0 is right, hence its end, hence shard 1's begin once corrected, ...: a
+        // shard whose begin differs from its predecessor's end scans again from there (its end may change with it, so
+        // everybody compares again afterwards; at most `world` rounds).
+        *again = 1;
+        *out = info;
+        if (rank && rows[W * (rank - 1) + 2] != info.begin_voffset) {
+            out->rescan = 1;
+            const int rc = ngsq_bam_shard_begin(bam, ctx, rank, world, rows[W * (rank - 1) + 2]);
+            // (a failure shows in the next round: the handle has no finished scan, every rank gets the error)
             if (rc) return comm_fail(comm, rc, "%s", ngsq_bam_last_error());
-            *out = info;
-            return NGSQ_OK;
+        }
+        return NGSQ_OK;
+    }
+    info.first_record_index = first;
+    *out = info;
+    // a coordinate-sorted file stays sorted across the cuts (sorted_input contexts finish positions while they stream:
+    // what the shard in front still covers is exchanged as a halo, a shard that starts EARLIER than its predecessor
+    // ended would be tallied twice)
+    if (ctx->stream_cov) {
+        uint64_t prev_last = 0;
+        bool have = false;
+        for (uint32_t k = 0; k < world; k++) {
+            if (!rows[W * k]) continue;
+            if (have && rows[W * k + 4] < prev_last)
+                return comm_fail(comm, NGSQ_ERR_UNSORTED, "sorted_input: shard %u begins in front of the last record of the shard before it", k);
+            prev_last = rows[W * k + 5];
+            have = true;
         }
     }
-    return comm_fail(comm, NGSQ_ERR_STATE, "shard boundaries did not settle");
+    return NGSQ_OK;
 }

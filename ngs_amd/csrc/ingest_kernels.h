@@ -74,6 +74,16 @@ struct RecColumns {
     uint32_t seq_pitch, qual_pitch;
 };
 
+// where the bytes of the current view came from, for the records' ids (include/ngsq.h record_id = BAM virtual offset)
+struct RecOrigin {
+    uint64_t *record_id;     // [n] out; null: no ids wanted
+    const BgzfBlock *blocks; // the chunk's block table (device), out_off relative to the chunk's first byte
+    const uint64_t *coff;    // [n_blocks] file offset of every block
+    uint32_t n_blocks;
+    uint64_t carry;          // view bytes in front of the chunk's first byte (the record cut by the previous chunk's end)
+    uint64_t carry_id;       // id of that record
+};
+
 // cand / pieces: REC_CANDIDATES entries per segment
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
                                  RecCandidate *cand, RecPieces *pieces, hipStream_t s);
@@ -88,8 +98,10 @@ hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_p
 hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value, unsigned long long *out, hipStream_t s);
 // also writes var_base[i] = offset of record i's CIGAR in raw and var_base[n + i] = offset of its SEQ (2 n entries:
 // what launch_rec_var starts from)
+// stats[0..2]: max l_seq, max n_cigar, sum l_seq (zeroed by the caller); stats[3], stats[4]: refID << 32 | pos of the first
+// and the last record of the batch
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
-                            unsigned long long *stats, hipStream_t s);
+                            unsigned long long *stats, const RecOrigin &org, hipStream_t s);
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,
                               uint64_t *qual_len, uint64_t *cig_len, hipStream_t s);
 // exclusive prefix sums of n+1 entries in place (entry n = total); tmp: scratch of *tmp_bytes

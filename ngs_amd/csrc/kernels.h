@@ -112,6 +112,7 @@ struct DeviceBatch {
     const uint32_t *cigar;
     const uint64_t *cigar_off;
     uint32_t seq_stride, qual_stride, cigar_stride;
+    const uint64_t *record_id; // null: first_record_index + i
 };
 
 struct LaunchInfo {

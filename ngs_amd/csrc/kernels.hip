@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b, uint6
             c[5] += 1;
             continue;
         }
-        const uint32_t off = ngsq_gc_offset_fn(st.gc_seed, b.first_record_index + i, l); // :68-74
+        const uint32_t off = ngsq_gc_offset_fn(st.gc_seed, b.record_id ? b.record_id[i] : b.first_record_index + i, l); // :68-74
         const uint64_t row = b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride;
         const uint64_t p = row + (off >> 1);
         const uint32_t odd = off & 1u;

@@ -13,7 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libngsq.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -108,6 +108,7 @@ class Batch(C.Structure):
         ("seq_bytes", C.c_uint64),
         ("qual_bytes", C.c_uint64),
         ("cigar_ops", C.c_uint64),
+        ("record_id", C.c_void_p),
     ]
 
 
@@ -151,7 +152,9 @@ ROLE_FIVE_PRIME_UTR, ROLE_THREE_PRIME_UTR, ROLE_CODING_SEQUENCE, ROLE_EXON, ROLE
 
 
 class ShardInfo(C.Structure):
-    _fields_ = [("n_records", C.c_uint64), ("begin_voffset", C.c_uint64), ("end_voffset", C.c_uint64)]
+    _fields_ = [("n_records", C.c_uint64), ("begin_voffset", C.c_uint64), ("end_voffset", C.c_uint64),
+                ("first_record_index", C.c_uint64), ("first_key", C.c_uint64), ("last_key", C.c_uint64),
+                ("rescan", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class FeaturesMetrics(C.Structure):
@@ -312,8 +315,8 @@ PROTOTYPES = {
     "ngsq_bam_next_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(Batch)]),
     "ngsq_bam_records_read": (C.c_uint64, [C.c_void_p]),
     "ngsq_bam_next_batch_device": (C.c_int, [C.c_void_p, ctx_p, C.c_uint64, C.POINTER(Batch)]),
-    "ngsq_bam_shard_prepare": (C.c_int, [C.c_void_p, ctx_p, C.c_uint32, C.c_uint32, C.POINTER(ShardInfo)]),
-    "ngsq_bam_shard_commit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(ShardInfo)]),
+    "ngsq_bam_shard_begin": (C.c_int, [C.c_void_p, ctx_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "ngsq_bam_shard_end": (C.c_int, [C.c_void_p, C.POINTER(ShardInfo)]),
     "ngsq_bgzf_inflate_device": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_int]),
     # include/ngsq_comm.h
     "ngsq_comm_last_error": (C.c_char_p, [comm_p]),
@@ -325,6 +328,7 @@ PROTOTYPES = {
     "ngsq_comm_rank": (C.c_int, [comm_p]),
     "ngsq_comm_world": (C.c_int, [comm_p]),
     "ngsq_comm_kind": (C.c_char_p, [comm_p]),
+    "ngsq_comm_rccl_version": (C.c_int, []),
     "ngsq_comm_allgather_host": (C.c_int, [comm_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ngsq_comm_allreduce_host": (C.c_int, [comm_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     "ngsq_comm_sendrecv_host": (C.c_int, [comm_p, C.POINTER(P2P), C.c_uint32, C.POINTER(P2P), C.c_uint32]),
@@ -332,7 +336,8 @@ PROTOTYPES = {
     "ngsq_exchange": (C.c_int, [ctx_p, comm_p, C.POINTER(ExchangeReport)]),
     "ngsq_exchange_plan": (C.c_int64, [u64p, C.c_uint32, C.c_uint64, u64p, u32p, u32p, u64p, C.c_uint64]),
     "ngsq_exchange_state": (C.c_int, [C.POINTER(ShardState), comm_p, C.POINTER(ExchangeReport)]),
-    "ngsq_bam_shard_open": (C.c_int, [C.c_void_p, ctx_p, comm_p, C.POINTER(ShardInfo)]),
+    "ngsq_bam_shard_open": (C.c_int, [C.c_void_p, ctx_p, comm_p]),
+    "ngsq_bam_shard_verify": (C.c_int, [C.c_void_p, ctx_p, comm_p, C.POINTER(ShardInfo), C.POINTER(C.c_int)]),
     "ngsq_synth_fill_device": (
         C.c_int, [ctx_p, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
 }

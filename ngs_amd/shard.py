@@ -189,19 +189,48 @@ class Comm:
         self._check(self.lib.ngsq_exchange_state(C.byref(state), self._h, C.byref(rep)))
         return _report(rep)
 
-    def open_file_shard(self, ctx, path: str, threads: int = 2):
-        """ngsq_bam_open + ngsq_bam_shard_open: shard `rank` of `world` of one BAM file, resident on the
-        context's GPU, record boundaries agreed with the neighbours.  Returns (bam handle, ffi.ShardInfo);
-        close with lib.ngsq_bam_close."""
+    def scan_file_shard(self, ctx, path: str, batch_records: int = 1 << 20, threads: int = 2, on_batch=None,
+                        pass_mask: int = ffi.PASS_BOTH, begin_hook=None):
+        """The loop of one `ngs qc --gpus N` worker: ngsq_bam_shard_open (this rank's BGZF block range of the
+        file, streamed through the chunked pipeline), every batch through ngsq_process_batch, then
+        ngsq_bam_shard_verify (collective) -- and, when a shard's assumed first record turns out wrong, ngsq_reset
+        and one more scan of that shard.  Returns (ffi.ShardInfo, rounds of re-scanning, records this rank scanned)."""
         h = C.c_void_p()
         if self.lib.ngsq_bam_open(path.encode(), threads, C.byref(h)) != 0:
             raise RuntimeError(self.lib.ngsq_bam_last_error().decode())
-        info = ffi.ShardInfo()
-        rc = self.lib.ngsq_bam_shard_open(h, ctx._ctx, self._h, C.byref(info))
-        if rc:
+        try:
+            self._check(self.lib.ngsq_bam_shard_open(h, ctx._ctx, self._h))
+            if begin_hook is not None:
+                begin_hook(h)          # tests: plant a wrong assumption (ngsq_bam_shard_begin with another offset)
+            rounds = 0
+            while True:
+                n, err = 0, None
+                while True:
+                    b = ffi.Batch()
+                    if self.lib.ngsq_bam_next_batch_device(h, ctx._ctx, batch_records, C.byref(b)) != 0:
+                        err = self.lib.ngsq_bam_last_error().decode()
+                        break
+                    if b.n_records == 0:
+                        break
+                    if on_batch is not None:
+                        on_batch(b)
+                    if self.lib.ngsq_process_batch(ctx._ctx, C.byref(b), pass_mask) != 0:
+                        err = (self.lib.ngsq_last_error(ctx._ctx) or b"").decode()
+                        break
+                    n += int(b.n_records)
+                info, again = ffi.ShardInfo(), C.c_int(0)
+                # (a rank that failed calls it all the same: every rank then gets an error instead of waiting)
+                rc = self.lib.ngsq_bam_shard_verify(h, ctx._ctx, self._h, C.byref(info), C.byref(again))
+                if err is not None:
+                    raise RuntimeError(err)
+                self._check(rc)
+                if not again.value:
+                    return info, rounds, n
+                rounds += 1
+                if info.rescan:
+                    ctx.reset()
+        finally:
             self.lib.ngsq_bam_close(h)
-            self._check(rc)
-        return h, info
 
 
 def _report(rep) -> dict:
@@ -254,12 +283,21 @@ def comm_from_env(device: int, kind: str = "rccl", lib=None) -> "Comm":
     why = None
     comm = None
     if kind == "rccl":
-        uid = np.frombuffer(unique_id(lib) if rank == 0 else bytes(ffi.COMM_ID_BYTES), dtype=np.uint8)
-        uid = boot.allgather(uid)[0].tobytes()
-        try:
-            comm = Comm.rccl(rank, world, uid, device, lib)
-        except CommError as e:      # e.g. two ranks on one GPU: RCCL refuses that
-            why = str(e)
+        uid = bytes(ffi.COMM_ID_BYTES)
+        if rank == 0:
+            try:
+                uid = unique_id(lib)
+            except CommError as e:  # librccl could not be loaded: the others must hear of it, not wait for an id
+                why = str(e)
+        msg = np.frombuffer(uid + bytes([0 if why else 1]), dtype=np.uint8)
+        got = boot.allgather(msg)[0].tobytes()
+        if not got[ffi.COMM_ID_BYTES]:
+            why = why or "rank 0 could not load RCCL"
+        else:
+            try:
+                comm = Comm.rccl(rank, world, got[:ffi.COMM_ID_BYTES], device, lib)
+            except CommError as e:      # e.g. two ranks on one GPU: RCCL refuses that
+                why = str(e)
         ok = boot.allgather_ints([0 if why else 1])
         if all(int(v[0]) for v in ok):
             boot.barrier()

@@ -736,7 +736,7 @@ static int fetch_record(const ngsq_batch *b, uint64_t i, orc_record *r) {
     r->n_cigar = b->n_cigar ? b->n_cigar[i] : 0;
     r->cigar = b->cigar ? b->cigar + (b->cigar_off ? b->cigar_off[i] : i * (uint64_t)b->cigar_stride)
                         : NULL;
-    r->index = b->first_record_index + i;
+    r->index = b->record_id ? b->record_id[i] : b->first_record_index + i; /* include/ngsq.h: the record's identity */
     return 0;
 }
 

@@ -97,7 +97,9 @@ def write_bai(path: str, hb, n_refs: int, rec_voff: Sequence[int], end_voff: int
 
 
 def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], block_payload: int = 60000,
-              with_index: bool = True, sort_order: str = "coordinate", real_index: bool = False) -> None:
+              with_index: bool = True, sort_order: str = "coordinate", real_index: bool = False) -> np.ndarray:
+    """Returns the records' BAM virtual offsets (block file offset << 16 | offset in the block's data): the ids the
+    readers of include/ngsq_bam.h give them (ngsq_batch.record_id)."""
     text = f"@HD\tVN:1.6\tSO:{sort_order}\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(ref_names, ref_len))
     head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(ref_names))
     for n, l in zip(ref_names, ref_len):
@@ -126,10 +128,11 @@ def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], b
     out.append(EOF_BLOCK)
     with open(path, "wb") as f:
         f.write(b"".join(out))
+    starts = [0]
+    for blk in out:
+        starts.append(starts[-1] + len(blk))
+    voff = np.array([(starts[k] << 16) | u for k, u in rec_at], dtype=np.uint64)
     if with_index and real_index:
-        starts = [0]
-        for blk in out:
-            starts.append(starts[-1] + len(blk))
         write_bai(path + ".bai", hb, len(ref_names), [(starts[k] << 16) | u for k, u in rec_at], starts[len(out) - 1] << 16)
     elif with_index:
         # a structurally valid BAI without bins (the hot path scans the file once; the index is
@@ -139,3 +142,14 @@ def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], b
             for _ in ref_names:
                 f.write(struct.pack("<ii", 0, 0))
             f.write(struct.pack("<Q", 0))
+    return voff
+
+
+def with_ids(hb, ids):
+    """`hb` with the record_id column set (what the oracle must be given to see the records as a file reader does)."""
+    import copy
+    out = copy.copy(hb)
+    out.cols = dict(hb.cols)
+    out.cols["record_id"] = np.ascontiguousarray(ids, dtype=np.uint64)
+    assert out.cols["record_id"].size == hb.n
+    return out

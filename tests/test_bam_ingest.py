@@ -38,6 +38,7 @@ def copy_batch(b: ffi.Batch) -> host.HostBatch:
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(count,)).copy()
 
     cols = {k: arr(getattr(b, k), n, host.COLUMN_DTYPES[k]) for k in host.FIXED_COLUMNS}
+    cols["record_id"] = arr(b.record_id, n, np.uint64)
     for data, off, stride, tot in (("seq", "seq_off", b.seq_stride, b.seq_bytes), ("qual", "qual_off", b.qual_stride, b.qual_bytes),
                                    ("cigar", "cigar_off", b.cigar_stride, b.cigar_ops)):
         cols[off] = arr(getattr(b, off), n + 1, np.uint64) if getattr(b, off) else None
@@ -80,7 +81,7 @@ def test_round_trip(lib, tmp_path, case):
         hb = random_batch(rng, 400, ref_len, max_len=900, min_len=321, weird=False)
     # qualities == 0xFF for a whole read mean "absent" in BAM: keep real scores <= 93 (random_batch does)
     path = str(tmp_path / "t.bam")
-    bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000)
+    voff = bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000)
     assert lib.ngsq_bam_check_index(path.encode()) == 0
     want = records_of(hb)
     for max_records in (1 << 20, 257):
@@ -88,6 +89,8 @@ def test_round_trip(lib, tmp_path, case):
         assert refs == [("chr1", 50_000), ("chr2", 7_000)] and n == hb.n
         got = [r for b in batches for r in records_of(b)]
         assert got == want
+        # ngsq_batch.record_id: every record's BAM virtual offset, as the writer laid the records out
+        assert np.array_equal(np.concatenate([b.cols["record_id"] for b in batches]), voff)
         assert [b.first_record_index for b in batches] == list(np.cumsum([0] + [b.n for b in batches[:-1]]))
     if case == "uniform150":
         assert batches[0].seq_stride == 75 and batches[0].qual_stride == 150
@@ -162,7 +165,7 @@ def test_index_region_query_by_seek(lib, tmp_path):
     hb = coordinate_sorted(hb)
     names = [f"s{i}" for i in range(4)]
     p = str(tmp_path / "q.bam")
-    bamio.write_bam(p, hb, names, ref_len, block_payload=2500, real_index=True)   # records straddle many small blocks
+    voff = bamio.write_bam(p, hb, names, ref_len, block_payload=2500, real_index=True)   # records straddle many small blocks
     assert lib.ngsq_bam_check_index(p.encode()) == 0
     starts = (C.c_uint64 * 4)()
     bins = C.c_uint64()
@@ -180,6 +183,8 @@ def test_index_region_query_by_seek(lib, tmp_path):
         n_same = min(50, int((ref[first:first + 50] == r).sum()))
         for col in ("ref_id", "pos", "flag", "tlen"):
             np.testing.assert_array_equal(got.cols[col][:n_same], hb.cols[col][first:first + n_same], err_msg=f"{col} of sequence {r}")
+        # a record's id does not depend on how the reader got to it
+        np.testing.assert_array_equal(got.cols["record_id"][:n_same], voff[first:first + n_same])
     assert lib.ngsq_bam_seek(h, (10 ** 9) << 16) == 0     # beyond the end of the file: nothing follows
     b = ffi.Batch()
     assert lib.ngsq_bam_next_batch(h, 50, C.byref(b)) == 0 and b.n_records == 0
@@ -266,3 +271,22 @@ def test_synthetic_bam_writer_index_follows_the_spec(lib, tmp_path):
     bins_n = C.c_uint64()
     assert lib.ngsq_bam_index_ref_starts(p.encode(), 2, starts, C.byref(bins_n)) == 0 and bins_n.value > 10
     assert starts[0] == voffs[int(np.argmax((c["ref_id"] == 0) & (c["pos"] >= 0)))]
+
+
+def test_record_id_is_what_the_gc_window_is_drawn_from(lib, oracle_mod):
+    """include/ngsq.h: record_id == NULL means first_record_index + i; with the column the oracle takes the ids it is
+    given (the readers' virtual offsets) -- same ids, same document; other ids, another GC histogram."""
+    rng = np.random.default_rng(77)
+    hb = random_batch(rng, 3000, [50_000, 7_000], max_len=240, min_len=120, weird=False)
+    hb.first_record_index = 1000
+
+    def gc(batch):
+        o = oracle_mod.Oracle([50_000, 7_000], facets=ffi.FACET_GC_CONTENT, max_read_len=1024, gc_seed=3)
+        o.process_batch(batch)
+        o.finalize()
+        return o.results(["chr1", "chr2"])["gc_content"]
+
+    base = gc(hb)
+    assert gc(bamio.with_ids(hb, np.arange(1000, 1000 + hb.n))) == base
+    other = gc(bamio.with_ids(hb, (np.arange(hb.n, dtype=np.uint64) << np.uint64(16)) | np.uint64(5)))
+    assert other["histogram"] != base["histogram"] and other["records"] == base["records"]

@@ -174,7 +174,7 @@ def oracle_json(oracle_mod, hb, facets=ffi.FACETS_DEFAULT, ref_bases=None, pass1
 def test_end_to_end(ngs, gpu_lib, oracle_mod, tmp_path, shape):
     hb = sorted_batch(3, 6000) if shape == "uniform150" else sorted_batch(4, 6000, max_len=260, min_len=30)
     bam = str(tmp_path / "sample.bam")
-    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=20_000)
+    hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS, block_payload=20_000))
     out = tmp_path / "out"
     r = run(ngs, "-v", "qc", bam, GENOME, "-o", str(out), "--batch-records", "1700")
     assert r.returncode == 0, r.stderr
@@ -199,7 +199,7 @@ def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n, index):
     that holds no bins it scans the file: same document."""
     hb = sorted_batch(5, 2500)
     bam = str(tmp_path / "s.bam")
-    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=3000 if index == "real" else 60000, real_index=index == "real")
+    hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS, block_payload=3000 if index == "real" else 60000, real_index=index == "real"))
     r = run(ngs, "-v", "qc", bam, GENOME, "-n", str(n), "-o", str(tmp_path), "--batch-records", "999")
     assert r.returncode == 0, r.stderr
     assert ("region queries through the index" in r.stderr) == (index == "real")
@@ -243,7 +243,7 @@ def test_edits_with_reference_fasta(ngs, gpu_lib, oracle_mod, tmp_path):
     recs.sort(key=lambda r: (r["ref_id"], r["pos"]))
     hb = batch_from_records(recs)
     bam = str(tmp_path / "e.bam")
-    bamio.write_bam(bam, hb, NAMES, LENS)
+    hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS))
     fa = tmp_path / "ref.fa"
     with open(fa, "w") as f:
         for name, b in zip(NAMES, bases):
@@ -293,7 +293,7 @@ def test_genomic_features_with_gff(ngs, gpu_lib, oracle_mod, tmp_path):
     c = hb.cols   # a mapped record needs a sequence and a position here (features.rs:132-140,171-174 bail otherwise)
     c["flag"][(c["pos"] < 0) | (c["ref_id"] < 0)] |= np.uint16(0x4)
     bam = str(tmp_path / "g.bam")
-    bamio.write_bam(bam, hb, NAMES, LENS)
+    hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS))
     rng = np.random.default_rng(8)
     types = ["five_prime_UTR", "three_prime_UTR", "CDS", "exon", "gene", "transcript", "start_codon"]
     rows, model = ["##gff-version 3", "#comment"], []
@@ -348,7 +348,7 @@ def test_coverage_modes_and_unsorted_fallback(ngs, gpu_lib, oracle_mod, tmp_path
     SO:coordinate but whose records are not in order is re-run on the depth arrays (auto) or refused (stream)."""
     hb = sorted_batch(9, 20_000)
     bam = str(tmp_path / "s.bam")
-    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=30_000)
+    hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS, block_payload=30_000))
     docs = {}
     for mode in ("auto", "stream", "array"):
         out = tmp_path / mode
@@ -381,7 +381,7 @@ def test_gpus_flag_workers_share_one_file(ngs, gpu_lib, oracle_mod, tmp_path):
     A file that breaks the promised order is scanned again on the depth arrays by every worker alike."""
     hb = sorted_batch(13, 30_000, max_len=200, min_len=40)
     bam = str(tmp_path / "g.bam")
-    bamio.write_bam(bam, hb, NAMES, LENS, block_payload=9_000)
+    hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS, block_payload=9_000))
     want = oracle_json(oracle_mod, hb)
     for mode in ("auto", "array"):
         out = tmp_path / ("w_" + mode)

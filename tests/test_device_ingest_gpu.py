@@ -1,6 +1,7 @@
 """Device ingest: the HIP BGZF inflate and BAM record parse against
 zlib / the host reader on the same bytes.  Bit-exact."""
 import ctypes as C
+import os
 import struct
 import zlib
 
@@ -171,6 +172,7 @@ def download_batch(lib, ctx, b: ffi.Batch) -> host.HostBatch:
 
     assert b.location == ffi.MEM_DEVICE
     cols = {k: arr(getattr(b, k), n, host.COLUMN_DTYPES[k]) for k in host.FIXED_COLUMNS}
+    cols["record_id"] = arr(b.record_id, n, np.uint64)
     for data, off, tot in (("seq", "seq_off", b.seq_bytes), ("qual", "qual_off", b.qual_bytes), ("cigar", "cigar_off", b.cigar_ops)):
         cols[off] = arr(getattr(b, off), n + 1, np.uint64) if getattr(b, off) else None
         cols[data] = arr(getattr(b, data), int(tot), host.COLUMN_DTYPES[data])
@@ -371,7 +373,7 @@ def test_device_reader_empty_bam(gpu_lib, ctx, tmp_path):
 
 
 # ---- one BAM file, three ranks (sharded device ingest + owner-computes teardown) -----------------
-def _file_shard_worker(rank, world, port, q, bam, writer, transport=None):
+def _file_shard_worker(rank, world, port, q, bam, writer, transport=None, wrong_guess=False):
     try:
         import os
         import sys
@@ -405,27 +407,29 @@ def _file_shard_worker(rank, world, port, q, bam, writer, transport=None):
 
         want, n_total = whole_file() if rank == 0 else (None, None)
         ctx = H.QcContext(ref_len, device=0, lib=lib, **kw)
-        h, info = comm.open_file_shard(ctx, bam)
-        mine = 0
-        first_seen = None
-        while True:
-            b = F.Batch()
-            assert lib.ngsq_bam_next_batch_device(h, ctx._ctx, 7_000, C.byref(b)) == 0, lib.ngsq_bam_last_error()
-            if b.n_records == 0:
-                break
-            if first_seen is None:
-                first_seen = int(b.first_record_index)
-            mine += int(b.n_records)
-            assert lib.ngsq_process_batch(ctx._ctx, C.byref(b), F.PASS_BOTH) == 0, lib.ngsq_last_error(ctx._ctx)
+        # "wrong-guess": rank 1 starts from a deliberately wrong first record (one record too late): the shards notice
+        # when they compare notes, rank 1 is re-armed from rank 0's end and scans again
+        hook = None
+        if wrong_guess and rank == 1:
+            def hook(h):
+                probe = C.c_void_p()
+                assert lib.ngsq_bam_open(bam.encode(), 1, C.byref(probe)) == 0
+                assert lib.ngsq_bam_shard_begin(probe, ctx._ctx, 1, world, 0) == 0, lib.ngsq_bam_last_error()
+                b = F.Batch()
+                assert lib.ngsq_bam_next_batch_device(probe, ctx._ctx, 2, C.byref(b)) == 0 and b.n_records == 2
+                ids = np.empty(2, dtype=np.uint64)
+                assert lib.ngsq_memcpy_d2h(ctx._ctx, ids.ctypes.data, b.record_id, 16) == 0
+                lib.ngsq_bam_close(probe)
+                assert lib.ngsq_bam_shard_begin(h, ctx._ctx, 1, world, int(ids[1])) == 0, lib.ngsq_bam_last_error()
+        info, rounds, mine = comm.scan_file_shard(ctx, bam, batch_records=7_000, begin_hook=hook)
         assert mine == info.n_records
-        lib.ngsq_bam_close(h)
-        none = (1 << 64) - 1
-        counts = comm.allgather_ints([mine, none if first_seen is None else first_seen])
+        assert rounds == (1 if wrong_guess else 0), rounds
+        counts = comm.allgather_ints([mine, int(info.first_record_index)])
         if rank == 0:
             assert sum(c for c, _ in counts) == n_total, (counts, n_total)
             run = 0
-            for c, f in counts:   # first_record_index continues across the shards
-                assert f == none or f == run
+            for c, f in counts:   # first_record_index: the records of the shards in front
+                assert f == run
                 run += c
         comm.exchange(ctx)
         ctx.finalize()
@@ -441,11 +445,13 @@ def _file_shard_worker(rank, world, port, q, bam, writer, transport=None):
         q.put((rank, "FAIL " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("writer,transport", [("synth", None), ("straddling", None), ("straddling", "rccl-double")])
-def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport):
-    """Each rank ingests its BGZF block range of the same file; record boundaries at the shard edges are
-    agreed by exchange; results equal the single-reader run.  "straddling": a file whose records cross
-    every block boundary, so no shard starts at a record start."""
+@pytest.mark.parametrize("writer,transport,wrong", [("synth", None, False), ("straddling", None, False), ("straddling", "rccl-double", False),
+                                                    ("straddling", None, True)])
+def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport, wrong):
+    """Each rank streams its BGZF block range of the same file through the chunked pipeline; the record boundaries the
+    shards assumed are compared afterwards (ngsq_bam_shard_verify); results equal the single-reader run.
+    "straddling": a file whose records cross every block boundary, so no shard starts at a record start.
+    wrong: a shard that started from a wrong first record is found out and scanned again."""
     import multiprocessing as mp
     import socket
     bam = str(tmp_path / "f.bam")
@@ -459,54 +465,66 @@ def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport):
         c["flag"] &= np.uint16(0xFFFF ^ 0x1)
         bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=3000)
     from tests.test_shard_gloo import _run_ranks
-    _run_ranks(_file_shard_worker, 3, bam, writer, transport)   # rccl-double: the RCCL transport over tests/rccl_double
+    _run_ranks(_file_shard_worker, 3, bam, writer, transport, wrong)   # rccl-double: the RCCL transport over tests/rccl_double
 
 
-def test_shard_prepare_commit_api(gpu_lib, ctx, tmp_path):
-    """Neighbouring shards agree on the record at their boundary; a confirmed begin that differs from
-    the assumed one re-indexes the shard (here: pushed to the next shard's first record, so the shard
-    keeps no record and only passes the chain through)."""
+def test_shard_begin_end_api(gpu_lib, ctx, tmp_path, monkeypatch):
+    """Neighbouring shards agree on the record at their boundary (each found on its own: the assumed first record of
+    shard k+1 is where shard k's chain ends), the shards' records add up to the file, their ids are the records'
+    virtual offsets whatever the number of shards; a confirmed begin that differs from the assumed one scans the
+    shard from there (pushed to the next shard's first record, the shard keeps no record and only passes the chain
+    through).  The ingest buffer is shrunk so that every shard spans several chunks."""
+    monkeypatch.setenv("NGSQ_INGEST_RAW_MB", "1")
     rng = np.random.default_rng(29)
     hb = random_batch(rng, 8000, [50_000, 7_000], max_len=180, weird=False)
     bam = str(tmp_path / "p.bam")
-    bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=2500)
+    voff = bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=2500)
+    size = os.path.getsize(bam)
 
-    def prepare(shard, n):
-        h = C.c_void_p()
-        assert gpu_lib.ngsq_bam_open(bam.encode(), 1, C.byref(h)) == 0
+    def scan(shard, n, begin=0, h=None):
+        if h is None:
+            h = C.c_void_p()
+            assert gpu_lib.ngsq_bam_open(bam.encode(), 1, C.byref(h)) == 0
+        assert gpu_lib.ngsq_bam_shard_begin(h, ctx._ctx, shard, n, begin) == 0, gpu_lib.ngsq_bam_last_error()
         info = ffi.ShardInfo()
-        assert gpu_lib.ngsq_bam_shard_prepare(h, ctx._ctx, shard, n, C.byref(info)) == 0, gpu_lib.ngsq_bam_last_error()
-        return h, info
-
-    for n in (2, 5, 64):   # 64: more shards than the file has blocks to give each one something
-        parts = [prepare(k, n) for k in range(n)]
-        assert sum(i.n_records for _, i in parts) == hb.n
-        for k in range(n - 1):
-            if parts[k][1].end_voffset == 0:   # this shard already reached the end of the file
-                assert all(i.n_records == 0 for _, i in parts[k + 1:])
+        assert gpu_lib.ngsq_bam_shard_end(h, C.byref(info)) == ffi.ERR_STATE     # not before the scan has ended
+        ids = []
+        while True:
+            b = ffi.Batch()
+            assert gpu_lib.ngsq_bam_next_batch_device(h, ctx._ctx, 700, C.byref(b)) == 0, gpu_lib.ngsq_bam_last_error()
+            if b.n_records == 0:
                 break
-            assert parts[k][1].end_voffset == parts[k + 1][1].begin_voffset
-        assert parts[-1][1].end_voffset == 0
-        if n == 64:
-            for h, _ in parts:
-                gpu_lib.ngsq_bam_close(h)
-            continue
-        # batches before commit are refused
-        b = ffi.Batch()
-        assert gpu_lib.ngsq_bam_next_batch_device(parts[1][0], ctx._ctx, 10, C.byref(b)) == ffi.ERR_STATE
-        # move shard 1's begin to the first record of shard 2 (n = 5): nothing left in shard 1
+            assert b.first_record_index == sum(len(x) for x in ids)     # numbered within the shard
+            ids.append(download_batch(gpu_lib, ctx, b).cols["record_id"])
+        assert gpu_lib.ngsq_bam_shard_end(h, C.byref(info)) == 0, gpu_lib.ngsq_bam_last_error()
+        return h, info, np.concatenate(ids) if ids else np.zeros(0, np.uint64)
+
+    for n in (1, 2, 5, 64):   # 64: more shards than the file has blocks to give each one something
+        parts = [scan(k, n) for k in range(n)]
+        assert sum(i.n_records for _, i, _ in parts) == hb.n
+        assert np.array_equal(np.concatenate([ids for _, _, ids in parts]), voff)
+        for k in range(n - 1):
+            assert parts[k][1].end_voffset == parts[k + 1][1].begin_voffset, (n, k)
+        assert parts[-1][1].end_voffset == (size << 16)
+        for _, i, ids in parts:   # sort keys of the shard's first and last record: refID << 32 | pos + 1, unplaced = ~0
+            if i.n_records:
+                for key, v in ((i.first_key, ids[0]), (i.last_key, ids[-1])):
+                    r = int(np.searchsorted(voff, v))
+                    ref, pos = int(hb.cols["ref_id"][r]), int(hb.cols["pos"][r])
+                    assert key == ((1 << 64) - 1 if ref < 0 else (ref << 32) | (pos + 1))
         if n == 5:
-            h1, i1 = parts[1]
-            moved = ffi.ShardInfo()
-            assert gpu_lib.ngsq_bam_shard_commit(h1, i1.end_voffset, 123, C.byref(moved)) == 0, gpu_lib.ngsq_bam_last_error()
-            assert moved.n_records == 0 and moved.begin_voffset == i1.end_voffset == moved.end_voffset
-            assert gpu_lib.ngsq_bam_next_batch_device(h1, ctx._ctx, 10, C.byref(b)) == 0 and b.n_records == 0
-            # and back: the original begin gives the original shard, numbered from the given index
-            assert gpu_lib.ngsq_bam_shard_commit(h1, i1.begin_voffset, 1000, C.byref(moved)) == 0
-            assert moved.n_records == i1.n_records and moved.end_voffset == i1.end_voffset
-            assert gpu_lib.ngsq_bam_next_batch_device(h1, ctx._ctx, 10, C.byref(b)) == 0
-            assert b.n_records == 10 and b.first_record_index == 1000
-            bad = ffi.ShardInfo()
-            assert gpu_lib.ngsq_bam_shard_commit(h1, (1 << 40) | 5, 0, C.byref(bad)) != 0   # not a block of this shard
-        for h, _ in parts:
+            # move shard 1's begin to the first record of shard 2: nothing left in shard 1
+            h1, i1, ids1 = parts[1]
+            assert i1.n_records > 0
+            _, moved, ids = scan(1, 5, begin=i1.end_voffset, h=h1)
+            assert moved.n_records == 0 and ids.size == 0 and moved.begin_voffset == i1.end_voffset == moved.end_voffset
+            # and back: the original begin gives the original shard
+            _, again, ids = scan(1, 5, begin=i1.begin_voffset, h=h1)
+            assert again.n_records == i1.n_records and again.end_voffset == i1.end_voffset and np.array_equal(ids, ids1)
+            # one record too late: the shard loses exactly that record
+            _, late, ids = scan(1, 5, begin=int(ids1[1]), h=h1)
+            assert late.n_records == i1.n_records - 1 and late.begin_voffset == int(ids1[1]) and np.array_equal(ids, ids1[1:])
+            assert gpu_lib.ngsq_bam_shard_begin(h1, ctx._ctx, 1, 5, 5) != 0        # in front of the shard
+            assert gpu_lib.ngsq_bam_shard_begin(h1, ctx._ctx, 0, 5, i1.begin_voffset) != 0   # shard 0 starts behind the header
+        for h, _, _ in parts:
             gpu_lib.ngsq_bam_close(h)
