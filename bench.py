@@ -71,7 +71,12 @@ def parse_args():
                     help="facet mask (default 0x1F = all default facets; 0x0E = BASELINE configs[1]; 0x20 adds Edits with "
                          "a synthetic reference resident in HBM, 0x40 Genomic Features with a synthetic gene model)")
     ap.add_argument("--file-records", type=int, default=60_000_000,
-                    help="records of the synthetic BAM of the file_end_to_end leg (N = 1 only; 0 = skip that leg)")
+                    help="records PER GPU of the synthetic BAM of the file_end_to_end leg (0 = skip that leg); at N > 1 one file "
+                         "of N x this many records is scanned by `ngs qc --gpus N` (fewer when writing it would take longer "
+                         "than --file-write-budget seconds: the writer is zlib on the host cores)")
+    ap.add_argument("--file-write-budget", type=float, default=75.0, help="seconds the N > 1 file leg may spend writing its BAM")
+    ap.add_argument("--file-big-records", type=int, default=200_000_000,
+                    help="N = 1: a second, larger file scanned in process beside the --file-records one (0 = skip)")
     ap.add_argument("--file-level", type=int, default=6, help="zlib level of that BAM")
     ap.add_argument("--h2d-batch", type=int, default=4_000_000, help="records per host batch of the h2d_inclusive leg (0 = skip)")
     ap.add_argument("--extra-facet-legs", type=int, default=1,
@@ -203,6 +208,30 @@ def main() -> int:
     total_records = n * world
     parity = check_invariants(ctx, ffi, total_records, args, mixed, emu_world > world)
     timing = ctx.kernel_timing()
+    # N = 1: the OTHER Coverage path on the same resident records, so that the 1 -> 2 step of the scaling curve (which
+    # switches from streaming to the difference arrays: DESIGN.md section 5.4) can be read as communication only
+    coverage_paths = None
+    if world == 1 and not args.emulate_shard and (args.facets & ffi.FACET_COVERAGE) and not args.force_dist:
+        other = "array" if args.coverage == "stream" else "stream"
+        coverage_paths = {args.coverage: round(elapsed / args.steps * 1e3, 3)}
+        try:
+            ctx2 = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=device, max_read_len=max_len, gc_seed=GC_SEED,
+                                  timing=False, sorted_input=other == "stream", ref_bases=ref_bases, lib=lib)
+            if args.facets & ffi.FACET_FEATURES:
+                ctx2.set_features(*synthetic_gene_model(np))
+            k2 = max(5, min(args.steps, 40))
+            for _ in range(3):
+                ctx2.reset(); ctx2.process_batch(db); ctx2.finalize()
+            ctx2.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(k2):
+                ctx2.reset(); ctx2.process_batch(db); ctx2.finalize()
+            ctx2.synchronize()
+            coverage_paths[other] = round((time.perf_counter() - t2) / k2 * 1e3, 3)
+            coverage_paths["same_integers"] = bool((ctx2.coverage_sequence(0)[1] == ctx.coverage_sequence(0)[1]).all())
+            ctx2.close()
+        except Exception as e:  # noqa: BLE001 -- reported, never required
+            coverage_paths["failed"] = f"{type(e).__name__}: {e}"
 
     rc = 0 if parity.startswith("ok") else 1
     if rank == 0:
@@ -249,8 +278,14 @@ def main() -> int:
             "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
             "parity_check": parity, "generate_s": round(t_gen, 2),
         }
+        if coverage_paths:
+            out["coverage_paths_ms_per_step"] = coverage_paths
+        if comm is not None:
+            out["comm"] = {"kind": comm.kind, "world": comm.world, "rccl_version": int(lib.ngsq_comm_rccl_version()),
+                           "fallback_reason": comm.fallback_reason}
     ctx.free_batch(db)
     ctx.close()
+    comm_kind = comm.kind if comm is not None else None
     if comm is not None:
         comm.barrier()
         comm.destroy()
@@ -267,6 +302,10 @@ def main() -> int:
                 out["file_end_to_end"] = fe
             if args.extra_facet_legs and not mixed and args.facets == 0x1F:
                 out["extra_facets"] = guarded(leg_extra_facets, lib, host, ffi, np)
+        elif world > 1 and args.file_records > 0 and not mixed and not args.emulate_shard:
+            # the number the metric is named after, on N GPUs: ONE BAM file scanned by `ngs qc --gpus N` (the other ranks
+            # of this launch have released their devices and are on their way out)
+            out["file_end_to_end"] = guarded(leg_file_sharded, lib, host, ffi, args, world, comm_kind)
         print(json.dumps(out), flush=True)
     return rc
 
@@ -494,6 +533,93 @@ def leg_h2d(lib, host, ffi, args):
             lib.ngsq_host_free_pinned(p)
 
 
+def fs_type_of(path: str) -> str:
+    best, kind = "", "?"
+    try:
+        with open("/proc/mounts") as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 3 and os.path.abspath(path).startswith(parts[1]) and len(parts[1]) > len(best):
+                    best, kind = parts[1], parts[2]
+    except OSError:
+        pass
+    return kind
+
+
+def drop_from_page_cache(path: str) -> bool:
+    """posix_fadvise(DONTNEED) on a synced file: the next read comes from storage (a no-op on tmpfs)."""
+    try:
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        finally:
+            os.close(fd)
+        return True
+    except (OSError, AttributeError):
+        return False
+
+
+def raw_read_rate(path: str, threads: int = 8) -> float:
+    """GB/s of plain parallel pread()s over the whole file (what the storage under it delivers to this process)."""
+    from concurrent.futures import ThreadPoolExecutor
+    size = os.path.getsize(path)
+    piece = 64 << 20
+    fd = os.open(path, os.O_RDONLY)
+
+    def rd(off):
+        left, o = min(piece, size - off), off
+        while left > 0:
+            got = len(os.pread(fd, min(left, 8 << 20), o))
+            if not got:
+                break
+            left -= got
+            o += got
+    t0 = time.perf_counter()
+    try:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(rd, range(0, size, piece)))
+    finally:
+        os.close(fd)
+    return size / max(time.perf_counter() - t0, 1e-9) / 1e9
+
+
+def scan_file_in_process(lib, host, ffi, ctx, bam, n, reps):
+    """ngsq_bam_open -> ngsq_bam_next_batch_device -> ngsq_process_batch -> ngsq_finalize, `reps` times; returns
+    (seconds of every scan, kernel timing of the best one, (rate after the first batch, seconds to it), document)."""
+    import ctypes as C
+    times, best, timing, after_first, doc = [], None, None, None, None
+    for rep in range(reps):
+        ctx.reset()
+        ctx.kernel_timing_reset()
+        t0 = time.perf_counter()
+        h = C.c_void_p()
+        if lib.ngsq_bam_open(bam.encode(), 0, C.byref(h)) != 0:
+            raise RuntimeError(lib.ngsq_bam_last_error().decode())
+        got, first = 0, None
+        while True:
+            b = ffi.Batch()
+            if lib.ngsq_bam_next_batch_device(h, ctx._ctx, 1 << 22, C.byref(b)) != 0:
+                raise RuntimeError(lib.ngsq_bam_last_error().decode())
+            if b.n_records == 0:
+                break
+            got += int(b.n_records)
+            if first is None:   # start-up (buffers allocated and pinned, first chunk read and inflated) ends here
+                first = (time.perf_counter(), got)
+            if lib.ngsq_process_batch(ctx._ctx, C.byref(b), ffi.PASS_BOTH) != 0:
+                raise RuntimeError(lib.ngsq_last_error(ctx._ctx).decode())
+        lib.ngsq_bam_close(h)
+        ctx.finalize()
+        dt = time.perf_counter() - t0
+        assert got == n, (got, n)
+        times.append(round(dt, 3))
+        if best is None or dt < best:
+            best, timing = dt, ctx.kernel_timing()
+            after_first = ((n - first[1]) / max(t0 + dt - first[0], 1e-9), first[0] - t0) if first and n > first[1] else None
+    doc = ctx.results(["chr1", "chr2"])
+    return times, best, timing, after_first, doc
+
+
 def leg_file(lib, host, ffi, args):
     """A synthetic BGZF BAM written once -> (a) `ngs qc` as a child process, wall clock including process start and HIP
     initialisation, device ingest (the default) and host ingest; (b) the same file through the same entry points inside
@@ -504,7 +630,9 @@ def leg_file(lib, host, ffi, args):
     n = args.file_records
     tmp = tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
     bam = os.path.join(tmp, "synth.bam")
-    out = {"records": n, "zlib_level": args.file_level, "host_cores": effective_cores()}
+    out = {"records": n, "zlib_level": args.file_level, "host_cores": effective_cores(),
+           "source": "page cache (the file was written seconds before it is read; see cold_cache for storage)",
+           "filesystem": fs_type_of(tmp)}
     try:
         fcfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
         t0 = time.perf_counter()
@@ -534,37 +662,8 @@ def leg_file(lib, host, ffi, args):
         # (b) in process: ngsq_bam_open -> ngsq_bam_next_batch_device -> ngsq_process_batch -> ngsq_finalize
         ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=1024, gc_seed=GC_SEED, sorted_input=True, timing=True, lib=lib)
         try:
-            names = ["chr1", "chr2"]
-            best, doc, times = None, None, []
             lib.ngsq_release_cached_memory()   # the first file of a process finds no cached blocks
-            for rep in range(3):
-                ctx.reset()
-                ctx.kernel_timing_reset()
-                t0 = time.perf_counter()
-                h = C.c_void_p()
-                if lib.ngsq_bam_open(bam.encode(), 0, C.byref(h)) != 0:
-                    raise RuntimeError(lib.ngsq_bam_last_error().decode())
-                got, first = 0, None
-                while True:
-                    b = ffi.Batch()
-                    if lib.ngsq_bam_next_batch_device(h, ctx._ctx, 1 << 22, C.byref(b)) != 0:
-                        raise RuntimeError(lib.ngsq_bam_last_error().decode())
-                    if b.n_records == 0:
-                        break
-                    got += int(b.n_records)
-                    if first is None:   # start-up (buffers allocated and pinned, first chunk read and inflated) ends here
-                        first = (time.perf_counter(), got)
-                    if lib.ngsq_process_batch(ctx._ctx, C.byref(b), ffi.PASS_BOTH) != 0:
-                        raise RuntimeError(lib.ngsq_last_error(ctx._ctx).decode())
-                lib.ngsq_bam_close(h)
-                ctx.finalize()
-                dt = time.perf_counter() - t0
-                assert got == n, (got, n)
-                times.append(round(dt, 3))
-                if best is None or dt < best:
-                    best, timing = dt, ctx.kernel_timing()
-                    after_first = ((n - first[1]) / max(t0 + dt - first[0], 1e-9), first[0] - t0) if first and n > first[1] else None
-                doc = ctx.results(names)
+            times, best, timing, after_first, doc = scan_file_in_process(lib, host, ffi, ctx, bam, n, 3)
             docs["in_process"] = doc
             out["value"] = round(n / best, 1)
             out["unit"] = "records/s"
@@ -589,9 +688,40 @@ def leg_file(lib, host, ffi, args):
                                           "algo_bytes_per_launch": inf["algo_bytes"] // inf["launches"],
                                           "note": "algorithmic bytes = compressed bytes read + inflated bytes written; the kernel is "
                                                   "bound by instruction latency (one decoder wave per BGZF block), not by HBM"}
+            # ---- the same scan with the file dropped from the page cache first (storage -> pinned memory -> GPU), and what
+            # the storage under the file delivers to plain parallel pread()s
+            if drop_from_page_cache(bam):
+                t_c, best_c, _, _, doc_c = scan_file_in_process(lib, host, ffi, ctx, bam, n, 1)
+                cold = {"seconds": round(best_c, 3), "records_per_s": round(n / best_c, 1),
+                        "compressed_GB_per_s": round(out["bam_bytes"] / best_c / 1e9, 2),
+                        "how": "os.sync + fsync + posix_fadvise(POSIX_FADV_DONTNEED) on the file, then one in-process scan",
+                        "same_document": json.dumps(doc_c, sort_keys=True) == json.dumps(doc, sort_keys=True)}
+                if drop_from_page_cache(bam):
+                    cold["storage_pread_GB_per_s"] = round(raw_read_rate(bam), 2)
+                cold["page_cache_pread_GB_per_s"] = round(raw_read_rate(bam), 2)   # the file is cached again by now
+                out["cold_cache"] = cold
+            # ---- a larger file beside it (1 GiB chunks, whose inflate launches run fuller): in process only
+            if args.file_big_records > n:
+                big = os.path.join(tmp, "big.bam")
+                try:
+                    # (the writer is zlib on the host cores: keep its share of the run to about two minutes)
+                    nb = int(min(args.file_big_records, max(n, n / max(out["bam_write_s"], 1e-3) * 120.0)))
+                    bcfg = host.synth_config(nb, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+                    t0 = time.perf_counter()
+                    assert lib.ngsq_synth_write_bam(C.byref(bcfg), big.encode(), nb, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+                    tw = time.perf_counter() - t0
+                    os.sync()
+                    t_b, best_b, timing_b, after_b, doc_b = scan_file_in_process(lib, host, ffi, ctx, big, nb, 2)
+                    out["big_file"] = {"records": nb, "bam_bytes": os.path.getsize(big), "bam_write_s": round(tw, 1),
+                                       "seconds_each_scan": t_b, "records_per_s": round(nb / best_b, 1),
+                                       "compressed_GB_per_s": round(os.path.getsize(big) / best_b / 1e9, 2),
+                                       "records_per_s_after_first_batch": round(after_b[0], 1) if after_b else None,
+                                       "check_total": doc_b["general"]["records"]["total"], "source": "page cache"}
+                except Exception as e:  # noqa: BLE001
+                    out["big_file"] = {"failed": f"{type(e).__name__}: {e}"}
         finally:
             ctx.close()
-        def strip(d):  # the GC window offsets are a function of (seed, record index): identical across the runs
+        def strip(d):  # the GC window offsets are a function of (seed, record id = virtual offset): identical across the runs
             return json.dumps(d, sort_keys=True)
         out["json_equal_device_host_inprocess"] = strip(docs["device"]) == strip(docs["host"]) == strip(docs["in_process"])
         out["check_total"] = docs["device"]["general"]["records"]["total"]
@@ -665,6 +795,67 @@ def leg_extra_facets(lib, host, ffi, np):
         return out
     finally:
         ctx.close()
+
+
+def leg_file_sharded(lib, host, ffi, args, world, comm_kind):
+    """N > 1: ONE synthetic BGZF BAM of (up to) N x --file-records records scanned by `ngs qc --gpus N` -- one worker
+    process per GPU, each streaming its BGZF block range through the chunked pipeline, one exchange before the teardown
+    -- wall clock of the command (process starts and HIP initialisation included), and the document against the one
+    `ngs qc` writes for the same file on one GPU."""
+    import ctypes as C
+    import tempfile
+    from ngs_amd import build
+    tmp = tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    bam = os.path.join(tmp, "synth.bam")
+    out = {"zlib_level": args.file_level, "host_cores": effective_cores(), "source": "page cache", "filesystem": fs_type_of(tmp)}
+    try:
+        # how many records the writer (zlib on the host cores) manages inside its budget: probe, then decide
+        probe_n = 2_000_000
+        pcfg = host.synth_config(probe_n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+        t0 = time.perf_counter()
+        assert lib.ngsq_synth_write_bam(C.byref(pcfg), bam.encode(), probe_n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+        rate = probe_n / max(time.perf_counter() - t0, 1e-6)
+        n = int(min(world * args.file_records, max(world * 5_000_000, rate * args.file_write_budget)))
+        out["records"] = n
+        out["records_wanted"] = world * args.file_records
+        fcfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+        t0 = time.perf_counter()
+        assert lib.ngsq_synth_write_bam(C.byref(fcfg), bam.encode(), n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+        out["bam_write_s"] = round(time.perf_counter() - t0, 2)
+        out["bam_bytes"] = os.path.getsize(bam)
+        os.sync()
+        ngs = build.build_cli(verbose=False)
+        flags = ["--same-device"] if args.same_gpu else []
+        if comm_kind == "shm" or args.transport == "shm":
+            flags += ["--transport", "shm"]
+        docs = {}
+        for label, gp, runs in (("sharded", world, 2), ("one_gpu", 1, 1)):
+            best = None
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                r = subprocess.run([ngs, "qc", bam, "GRCh38_no_alt_AnalysisSet", "-o", tmp] + (["--gpus", str(gp)] + flags if gp > 1 else []),
+                                   capture_output=True, text=True)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError(f"ngs qc --gpus {gp}: {r.stderr[-600:]}")
+                best = dt if best is None else min(best, dt)
+            with open(os.path.join(tmp, "synth.bam.results.json")) as f:
+                docs[label] = json.load(f)
+            out[label] = {"gpus": gp, "seconds": round(best, 3), "records_per_s": round(n / best, 1),
+                          "compressed_GB_per_s": round(out["bam_bytes"] / best / 1e9, 2)}
+            if gp > 1:
+                out[label]["records_per_s_per_worker"] = round(n / best / gp, 1)
+                out[label]["transport"] = [ln for ln in r.stderr.splitlines() if "exchange over" in ln][:1]
+        out["value"] = out["sharded"]["records_per_s"]
+        out["unit"] = "records/s"
+        out["includes"] = "launcher + N worker process starts, HIP initialisation, header + index checks, the exchange, JSON write"
+        out["json_equal_sharded_one_gpu"] = json.dumps(docs["sharded"], sort_keys=True) == json.dumps(docs["one_gpu"], sort_keys=True)
+        out["check_total"] = docs["sharded"]["general"]["records"]["total"]
+        return out
+    finally:
+        for f in os.listdir(tmp):
+            os.remove(os.path.join(tmp, f))
+        os.rmdir(tmp)
 
 
 if __name__ == "__main__":

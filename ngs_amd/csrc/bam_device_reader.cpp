@@ -95,23 +95,6 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// cores this process may really use: the cgroup's CPU quota when there is one (the MI355X boxes of this pool show 256
-// online CPUs under a quota of 16: more runnable threads than that get throttled for the rest of the period)
-int effective_cores() {
-    int n = (int)std::thread::hardware_concurrency();
-    if (n < 1) n = 1;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char quota[32] = {0};
-        long period = 0;
-        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
-            const long q = atol(quota) / period;
-            if (q >= 1 && q < n) n = (int)q;
-        }
-        fclose(f);
-    }
-    return n;
-}
-
 // Keep the calling thread (and the threads it starts) on the CPUs of the NUMA node the device hangs off.  The reader
 // copies the file out of the page cache into pinned memory with a dozen threads: left to the scheduler they end up spread
 // over both sockets and the same copy takes 31 ms per chunk instead of 8-14 (measured on a two-socket MI355X host; which

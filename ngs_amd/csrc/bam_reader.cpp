@@ -197,7 +197,7 @@ int ngsq_bam_open(const char *path, int n_threads, ngsq_bam **out) {
     ngsq_bam *b = new ngsq_bam();
     b->f = f;
     b->path = path;
-    b->n_threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    b->n_threads = n_threads > 0 ? n_threads : ngsq::effective_cores();
     b->read_chunk = (size_t)1 << 20; // the header needs little; the device ingest re-reads the file itself
 #define OPEN_TRY(expr)            \
     do {                          \

@@ -6,7 +6,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ngsq_bam.h"
@@ -29,6 +32,23 @@ struct RawBuf {
 };
 
 struct DeviceIngest; // bam_device_reader.cpp
+
+// cores this process may really use: the cgroup's CPU quota when there is one (the MI355X boxes of this pool show 256
+// online CPUs under a quota of 16: more runnable threads than that get throttled for the rest of the period)
+inline int effective_cores() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = atol(quota) / period;
+            if (q >= 1 && q < n) n = (int)q;
+        }
+        fclose(f);
+    }
+    return n;
+}
 
 } // namespace ngsq
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/ngsq_synth.h"
+#include "bam_reader.h"
 
 namespace {
 
@@ -154,7 +155,7 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
             if (lin[w] == 0) lin[w] = v0; // file order: the first record that overlaps the window
     };
     // ---- records: groups of records rendered and deflated in parallel, written in order
-    const int nt = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    const int nt = n_threads > 0 ? n_threads : ngsq::effective_cores();
     const uint64_t group = 100; // records per BGZF block (100 x ~270 B < 64 KiB even at 300 bp)
     const uint64_t n_groups = (n_records + group - 1) / group;
     const uint64_t wave = (uint64_t)nt * 64;

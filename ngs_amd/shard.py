@@ -202,7 +202,7 @@ class Comm:
             self._check(self.lib.ngsq_bam_shard_open(h, ctx._ctx, self._h))
             if begin_hook is not None:
                 begin_hook(h)          # tests: plant a wrong assumption (ngsq_bam_shard_begin with another offset)
-            rounds = 0
+            rounds, mine, scanning = 0, 0, True
             while True:
                 n, err = 0, None
                 while True:
@@ -224,10 +224,13 @@ class Comm:
                 if err is not None:
                     raise RuntimeError(err)
                 self._check(rc)
+                if scanning:           # (a rank that keeps its state finds its reader at its end: no records this round)
+                    mine = n
                 if not again.value:
-                    return info, rounds, n
+                    return info, rounds, mine
                 rounds += 1
-                if info.rescan:
+                scanning = bool(info.rescan)
+                if scanning:
                     ctx.reset()
         finally:
             self.lib.ngsq_bam_close(h)

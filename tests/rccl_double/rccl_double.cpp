@@ -24,6 +24,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -100,12 +101,15 @@ static ncclResult_t run_p2p(std::vector<std::pair<ncclComm *, P2p>> &ops) {
     const double t0 = now_s();
     for (uint64_t spins = 0;; spins++) {
         bool all = true, moved = false;
+        std::vector<Mailbox *> busy; // messages between one pair of ranks match in list order: one unfinished operation per mailbox at a time
         for (auto &e : ops) {
             ncclComm *c = e.first;
             P2p &o = e.second;
             if (o.done == o.bytes) continue;
             all = false;
             Mailbox &m = o.send ? c->sh->box[c->rank][o.peer] : c->sh->box[o.peer][c->rank];
+            if (std::find(busy.begin(), busy.end(), &m) != busy.end()) continue;
+            busy.push_back(&m);
             const uint64_t w = m.written.load(std::memory_order_acquire), r = m.read.load(std::memory_order_acquire);
             if (o.send && w == r) {
                 const uint64_t n = std::min<uint64_t>(MBOX, o.bytes - o.done);

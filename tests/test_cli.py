@@ -190,9 +190,10 @@ def test_end_to_end(ngs, gpu_lib, oracle_mod, tmp_path, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [1, 3])
 @pytest.mark.parametrize("index", ["bare", "real"])
 @pytest.mark.parametrize("n", [0, 1, 7, 300, 100_000])
-def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n, index):
+def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n, index, gpus):
     """-n: pass 1 stops after n records; pass 2 shares ONE counter over all sequences, so every
     sequence after the n-th record still processes one record (command.rs:354,384-388).  With a real BAI the
     sequence pass runs as region queries through the index (seek to the sequence's first chunk); with an index
@@ -200,7 +201,9 @@ def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n, index):
     hb = sorted_batch(5, 2500)
     bam = str(tmp_path / "s.bam")
     hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS, block_payload=3000 if index == "real" else 60000, real_index=index == "real"))
-    r = run(ngs, "-v", "qc", bam, GENOME, "-n", str(n), "-o", str(tmp_path), "--batch-records", "999")
+    # --gpus 3: worker 0 applies both rules, the others bring an empty state to the exchange -- same document
+    r = run(ngs, "-v", "qc", bam, GENOME, "-n", str(n), "-o", str(tmp_path), "--batch-records", "999",
+            *(["--gpus", str(gpus), "--same-device"] if gpus > 1 else []))
     assert r.returncode == 0, r.stderr
     assert ("region queries through the index" in r.stderr) == (index == "real")
     got = json.load(open(tmp_path / "s.bam.results.json"))
@@ -399,9 +402,6 @@ def test_gpus_flag_workers_share_one_file(ngs, gpu_lib, oracle_mod, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "Worker 0 of 3 on device 0, exchange over rccl." in r.stderr
     json_equal(json.load(open(out / "g.bam.results.json")), want)
-    # the reference's -n rules are sequential: refused with --gpus
-    r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path), "--gpus", "2", "-n", "10")
-    assert r.returncode == 1 and "--gpus cannot be combined with -n" in r.stderr
     # more workers than devices without --same-device
     if gpu_lib.ngsq_device_count() < 3:
         r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path), "--gpus", "3")
