@@ -124,6 +124,7 @@ __device__ __forceinline__ bool walk(const uint8_t *raw, uint64_t n_bytes, uint6
 __global__ __launch_bounds__(64) void k_rec_candidates(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint64_t first,
                                                        uint32_t n_seg, int32_t n_ref, RecCandidate *__restrict__ cand,
                                                        RecPieces *__restrict__ pieces) {
+    NGSQ_FOREGROUND_WAVE();
     // chains walked at once: each extra one costs (divergent loads), and the screening resumes right behind the last
     // offset taken, so no candidate is skipped
     constexpr uint32_t LIST = REC_CANDIDATES;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(64) void k_rec_candidates(const uint8_t *__restrict
 // ---- 2b. the rare segment whose entry is not in the table ---------------------------------------
 __global__ void k_walk_one(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint64_t start, uint64_t s0, uint64_t end,
                            RecCandidate *__restrict__ out, RecPieces *__restrict__ pc) {
+    NGSQ_FOREGROUND_WAVE();
     if (threadIdx.x || blockIdx.x) return;
     uint64_t landing = start;
     uint32_t count = 0;
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(PT) void k_rec_offsets(const uint8_t *__restrict__ 
                                                      const uint32_t *__restrict__ chosen, const uint64_t *__restrict__ seg_base,
                                                      const RecPieces *__restrict__ pieces, uint64_t *__restrict__ rec_off,
                                                      unsigned long long *__restrict__ bad) {
+    NGSQ_FOREGROUND_WAVE();
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_pieces) return;
     const uint32_t seg = g / REC_PIECES, j = g % REC_PIECES, ch = chosen[seg];
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
                                                    uint64_t n, RecColumns c, uint64_t *__restrict__ var_base,
                                                    uint64_t *__restrict__ seq_src, unsigned long long *__restrict__ stats,
                                                    RecOrigin org) {
+    NGSQ_FOREGROUND_WAVE();
     constexpr uint32_t NW = PT / 64;
     __shared__ uint32_t s_ml[NW], s_mo[NW];
     __shared__ unsigned long long s_sl[NW];
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
 __global__ __launch_bounds__(256) void k_rec_lengths(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ rec_off,
                                                      uint64_t n, uint64_t *__restrict__ seq_len,
                                                      uint64_t *__restrict__ qual_len, uint64_t *__restrict__ cig_len) {
+    NGSQ_FOREGROUND_WAVE();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *r = raw + rec_off[i] + 4;
@@ -377,6 +382,7 @@ template <bool QUAL>
 __global__ __launch_bounds__(256) void k_rec_rows_narrow(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
                                                          const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t *__restrict__ dst,
                                                          uint32_t pitch, uint64_t n_dwords) {
+    NGSQ_FOREGROUND_WAVE();
     constexpr uint32_t FILL = QUAL ? 0xFFu : 0u;
     constexpr int U = 4;
     for (uint64_t d0 = (uint64_t)blockIdx.x * (256 * U) + threadIdx.x; d0 < n_dwords; d0 += (uint64_t)gridDim.x * (256 * U)) {
@@ -422,6 +428,7 @@ template <bool QUAL>
 __global__ __launch_bounds__(PT) void k_rec_rows(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ seq_src,
                                                   const uint32_t *__restrict__ l_seq, uint64_t n, uint32_t *__restrict__ dst,
                                                   uint32_t pitch, uint64_t n_dwords) {
+    NGSQ_FOREGROUND_WAVE();
     constexpr uint32_t FILLW = QUAL ? 0xFFFFFFFFu : 0u;
     constexpr int U = 4;
     for (uint64_t d0 = (uint64_t)blockIdx.x * (PT * U) + threadIdx.x; d0 < n_dwords; d0 += (uint64_t)gridDim.x * (PT * U)) {
@@ -471,6 +478,7 @@ __global__ __launch_bounds__(PT) void k_rec_rows(const uint8_t *__restrict__ raw
 // parts: 1 = CIGAR, 2 = SEQ and QUAL (fixed-pitch rows are k_rec_rows' unless the pitch rules it out).
 __global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base,
                                                  uint64_t n, RecColumns c, uint32_t parts) {
+    NGSQ_FOREGROUND_WAVE();
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t t = threadIdx.x & 15u;
     if (i >= n) return;
@@ -506,6 +514,7 @@ __global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw
 // one CIGAR operation per record (or none): the first one, or 0
 __global__ __launch_bounds__(PT) void k_rec_cigar1(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base,
                                                     const uint16_t *__restrict__ n_cigar, uint64_t n, uint32_t *__restrict__ cigar) {
+    NGSQ_FOREGROUND_WAVE();
     for (uint64_t i = (uint64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PT)
         cigar[i] = n_cigar[i] ? ld32(raw + var_base[i]) : 0u;
 }
@@ -520,6 +529,7 @@ __global__ void k_fill_slack(uint8_t *seq_end, uint8_t *qual_end) {
 }
 
 __global__ void k_count_below_u64(const uint64_t *__restrict__ a, uint64_t n, uint64_t value, unsigned long long *out) {
+    NGSQ_FOREGROUND_WAVE();
     if (threadIdx.x || blockIdx.x) return;
     uint64_t lo = 0, hi = n;
     while (lo < hi) {
@@ -530,7 +540,24 @@ __global__ void k_count_below_u64(const uint64_t *__restrict__ a, uint64_t n, ui
     *out = lo;
 }
 
+// Small tables and results between host and device WITHOUT the DMA engines: one side is pinned host memory the device
+// addresses directly.  Every hipMemcpyAsync on any stream -- pinned or pageable, either direction -- queues behind the
+// reader thread's 64 MiB host-to-device copies of the next chunk's compressed bytes (in-order DMA: up to 1.2 ms each,
+// tools/stream_order_probe.hip); a dozen such copies per chunk sat on the pipeline's critical path and were what kept
+// the parse of one chunk from running beside the inflate of the next.
+__global__ __launch_bounds__(256) void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
+    NGSQ_FOREGROUND_WAVE();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 // ---- launchers ----------------------------------------------------------------------------------
+hipError_t launch_copy_words(void *dst, const void *src, uint64_t n_bytes, hipStream_t s) {
+    const uint64_t n = (n_bytes + 3) / 4; // (the buffers are allocated in whole words)
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_words, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 1024)), dim3(256), 0, s,
+                       static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), n);
+    return hipGetLastError();
+}
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
                                  RecCandidate *cand, RecPieces *pieces, hipStream_t s) {
     if (!n_seg) return hipSuccess;

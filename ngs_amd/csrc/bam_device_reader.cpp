@@ -86,6 +86,28 @@ template <typename T> struct DevBuf {
     ~DevBuf() { ngsq::pool_device_free(p, bytes); }
 };
 
+// pinned host memory the device addresses directly (hipHostMalloc: mapped and coherent), grown on demand
+struct PinBuf {
+    void *h = nullptr, *dev = nullptr; // the same memory as the host and as the device see it
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (h) (void)hipHostFree(h);
+        h = dev = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&h, want, hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        e = hipHostGetDevicePointer(&dev, h, 0);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    ~PinBuf() {
+        if (h) (void)hipHostFree(h);
+    }
+};
+
 // NGSQ_INGEST_TRACE=1: wall-clock of the ingest stages on stderr (measurement aid)
 bool trace_on() {
     static const bool on = getenv("NGSQ_INGEST_TRACE") && atoi(getenv("NGSQ_INGEST_TRACE"));
@@ -189,9 +211,20 @@ struct DeviceIngest {
         uint64_t total = 0, next_coff = 0; // next_coff: file offset behind the last block
         std::vector<BgzfBlock> blocks;
         std::vector<uint64_t> coff;
-        std::vector<uint32_t> status;
+        // the decoders' verdicts come back into PINNED memory: an "asynchronous" copy into pageable memory makes the
+        // calling thread wait for everything queued on the stream in front of it -- here the whole inflate of the next
+        // chunk, so that the parse kernels of this chunk were launched only when it had finished (the two streams never
+        // overlapped, rounds 1 and 2)
+        // (the block table and the file offsets travel the other way through the same pinned block: a copy FROM pageable
+        // memory is staged, and waits for the stream too when the staging buffers are in use)
+        PinBuf pin; // [status | block table | file offsets]
+        uint32_t *status = nullptr;
+        BgzfBlock *pin_blocks = nullptr;
+        uint64_t *pin_coff = nullptr;
+        size_t status_cap = 0;
         std::string err;
     } pend[2];
+    PinBuf h_cand, h_seg, h_small; // the candidate table, the segments' verdicts, a few result words: host <-> device without DMA
     DevBuf<uint64_t> d_coff_s[2], d_record_id;
     DevBuf<uint8_t> d_raw2;
     DevBuf<BgzfBlock> d_blocks_s[2];
@@ -204,7 +237,6 @@ struct DeviceIngest {
     DevBuf<uint8_t> d_comp, d_raw, d_seq, d_qual, d_scan_tmp;
     DevBuf<BgzfBlock> d_blocks;
     DevBuf<uint32_t> d_status, d_l_seq, d_cigar;
-    DevBuf<RecCandidate> d_cand;
     DevBuf<RecPieces> d_pieces;
     DevBuf<uint64_t> d_var_base;              // per record of the batch: offset of its CIGAR in raw
     DevBuf<uint64_t> d_seg, d_rec_off, d_len; // d_seg: per segment, index of its first record | chosen candidate (u32); d_len: seq | qual | cigar lengths -> offsets
@@ -238,8 +270,6 @@ struct DeviceIngest {
     int cur_slot = 0;             // slot of the chunk being handed out
     uint64_t carry_len = 0;       // bytes of the view in front of the current chunk's first byte
     bool last_chunk = false;      // the chunk being handed out is the range's last
-    std::vector<RecCandidate> cand;
-    std::vector<uint64_t> seg;
     ~DeviceIngest() {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -264,6 +294,7 @@ struct DeviceIngest {
             if (e) (void)hipEventDestroy(e);
         for (auto &c : hc)
             if (c.h) pool_pinned_free(c.h, c.h_bytes);
+
     }
 };
 
@@ -578,32 +609,40 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     *out_total = 0;
     *out_entry = find ? d->raw_len : first;
     if (!n_seg) return NGSQ_OK;
-    BHIP(d->d_cand.reserve((size_t)n_seg * REC_CANDIDATES));
+    // (the candidate table is written straight into pinned host memory and the segments' verdicts are read from it: see
+    // k_copy_words in bam_device.hip for why nothing here is a hipMemcpyAsync)
+    BHIP(d->h_cand.reserve((size_t)n_seg * REC_CANDIDATES * sizeof(RecCandidate)));
+    BHIP(d->h_seg.reserve((size_t)n_seg * 2 * sizeof(uint64_t)));
+    BHIP(d->h_small.reserve(64 * sizeof(uint64_t)));
     const uint32_t n_pieces = (uint32_t)((d->raw_len + REC_PIECE - 1) / REC_PIECE);
     BHIP(d->d_pieces.reserve((size_t)n_seg * REC_CANDIDATES));
     BHIP(d->d_seg.reserve((size_t)n_seg * 2)); // seg_base | chosen (32-bit words in the second half)
     BHIP(d->d_small.reserve(16));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, d->raw_len);
-        BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), d->d_cand.p, d->d_pieces.p, st));
+        BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), static_cast<RecCandidate *>(d->h_cand.dev),
+                                   d->d_pieces.p, st));
     }
-    d->cand.resize((size_t)n_seg * REC_CANDIDATES);
-    BHIP(hipMemcpyAsync(d->cand.data(), d->d_cand.p, d->cand.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost, st));
     BHIP(hipStreamSynchronize(st));
-    d->seg.assign((size_t)n_seg * 2, 0);
-    uint32_t *chosen = reinterpret_cast<uint32_t *>(d->seg.data() + n_seg);
+    const RecCandidate *const cand = static_cast<const RecCandidate *>(d->h_cand.h);
+    uint64_t *const seg = static_cast<uint64_t *>(d->h_seg.h); // [n_seg] index of each segment's first record | [n_seg] (32-bit words) its chain
+    memset(seg, 0, (size_t)n_seg * 2 * sizeof(uint64_t));
+    uint32_t *chosen = reinterpret_cast<uint32_t *>(seg + n_seg);
+    uint64_t *const h_small = static_cast<uint64_t *>(d->h_small.h);
+    uint64_t *const h_small_dev = static_cast<uint64_t *>(d->h_small.dev);
     if (find) { // the first plausible chain of the view: an assumption (ngsq_bam_shard_verify confirms or corrects it)
         // -- preferably one whose landing offset is itself a candidate of the segment it lands in
         first = d->raw_len;
         bool any = false;
-        for (const RecCandidate &x : d->cand) {
+        for (size_t xi = 0; xi < (size_t)n_seg * REC_CANDIDATES; xi++) {
+            const RecCandidate &x = cand[xi];
             if (!x.valid) continue;
             if (!any) first = x.start; // fallback: the very first
             any = true;
             const uint64_t sl = x.landing / REC_SEGMENT;
             bool agrees = sl >= n_seg;
             for (uint32_t k = 0; k < REC_CANDIDATES && !agrees; k++) {
-                const RecCandidate &y = d->cand[(size_t)sl * REC_CANDIDATES + k];
+                const RecCandidate &y = cand[(size_t)sl * REC_CANDIDATES + k];
                 agrees = y.valid && y.start == x.landing;
             }
             if (agrees) {
@@ -617,11 +656,11 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     for (uint32_t s = 0; s < n_seg; s++) {
         const uint64_t s0 = (uint64_t)s * REC_SEGMENT, s1 = std::min<uint64_t>(s0 + REC_SEGMENT, d->raw_len);
         chosen[s] = REC_NO_CHAIN;
-        d->seg[s] = total_rec;
+        seg[s] = total_rec;
         if (cur >= s1) continue;
         const RecCandidate *c = nullptr;
         for (uint32_t k = 0; k < REC_CANDIDATES; k++) {
-            const RecCandidate &x = d->cand[(size_t)s * REC_CANDIDATES + k];
+            const RecCandidate &x = cand[(size_t)s * REC_CANDIDATES + k];
             if (x.valid && x.start == cur) {
                 c = &x;
                 chosen[s] = k;
@@ -630,10 +669,10 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
         RecCandidate one{};
         if (!c) {
             // not in the table: one thread walks the segment with the host reader's rules (its piece table replaces candidate 0's)
-            RecCandidate *d_one = reinterpret_cast<RecCandidate *>(d->d_small.p + 8);
-            BHIP(launch_walk_one(d->raw, d->raw_len, cur, s0, s1, d_one, d->d_pieces.p + (size_t)s * REC_CANDIDATES, st));
-            BHIP(hipMemcpyAsync(&one, d_one, sizeof one, hipMemcpyDeviceToHost, st));
+            BHIP(launch_walk_one(d->raw, d->raw_len, cur, s0, s1, reinterpret_cast<RecCandidate *>(h_small_dev + 8),
+                                 d->d_pieces.p + (size_t)s * REC_CANDIDATES, st));
             BHIP(hipStreamSynchronize(st));
+            memcpy(&one, h_small + 8, sizeof one);
             c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
             chosen[s] = 0;
         }
@@ -644,16 +683,16 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     }
     d->tail_off = std::min(cur, d->raw_len);
     BHIP(d->d_rec_off.reserve(total_rec + 1));
-    BHIP(hipMemcpyAsync(d->d_seg.p, d->seg.data(), d->seg.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    BHIP(launch_copy_words(d->d_seg.p, d->h_seg.dev, (size_t)n_seg * 2 * sizeof(uint64_t), st));
     BHIP(hipMemsetAsync(d->d_small.p, 0xFF, sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, 0);
         BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, reinterpret_cast<const uint32_t *>(d->d_seg.p + n_seg), d->d_seg.p,
                                 d->d_pieces.p, d->d_rec_off.p, d->d_small.p, st));
     }
-    unsigned long long bad = 0;
-    BHIP(hipMemcpyAsync(&bad, d->d_small.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    BHIP(launch_copy_words(h_small_dev, d->d_small.p, sizeof(unsigned long long), st));
     BHIP(hipStreamSynchronize(st));
+    const unsigned long long bad = h_small[0];
     if (bad != ~0ull)
         return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
                              (unsigned long long)(b->n_read + bad));
@@ -681,7 +720,18 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
     hipStream_t sb = d->inf_stream;
     BHIP(d->d_blocks_s[slot].reserve(p.n_blk));
     BHIP(d->d_coff_s[slot].reserve(p.n_blk));
-    BHIP(d->d_status_s[slot].reserve(p.n_blk));
+    BHIP(d->d_status_s[slot].reserve(p.n_blk + 1)); // + the decoders' block counter
+    if (p.status_cap < p.n_blk) {
+        const size_t cap = p.n_blk + p.n_blk / 4 + 1024;
+        BHIP(p.pin.reserve((cap + 2) * (sizeof(uint32_t) + sizeof(BgzfBlock) + sizeof(uint64_t))));
+        p.status_cap = cap;
+        p.status = static_cast<uint32_t *>(p.pin.h);
+        p.pin_blocks = reinterpret_cast<BgzfBlock *>(p.status + cap + (cap & 1)); // 8-byte aligned
+        p.pin_coff = reinterpret_cast<uint64_t *>(p.pin_blocks + cap);
+    }
+    auto dev_of = [&](const void *host) { return static_cast<uint8_t *>(p.pin.dev) + (static_cast<const uint8_t *>(host) - static_cast<const uint8_t *>(p.pin.h)); };
+    memcpy(p.pin_blocks, p.blocks.data(), p.n_blk * sizeof(BgzfBlock));
+    memcpy(p.pin_coff, p.coff.data(), p.n_blk * sizeof(uint64_t));
     if (d->h2d_issued[slot]) { // already on its way: the reader thread issued the copy
         if (trace_on()) {
             const double tw = now_ms();
@@ -695,19 +745,19 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
         BHIP(hipMemsetAsync(d->d_comp_slot[slot].p + p.consumed, 0, INFLATE_IN_SLACK, sb));
     }
     if (d->raw_free_set[slot]) BHIP(hipStreamWaitEvent(sb, d->raw_free[slot], 0)); // the chunk before last has left this buffer
-    BHIP(hipMemcpyAsync(d->d_blocks_s[slot].p, p.blocks.data(), p.n_blk * sizeof(BgzfBlock), hipMemcpyHostToDevice, sb));
-    BHIP(hipMemcpyAsync(d->d_coff_s[slot].p, p.coff.data(), p.n_blk * sizeof(uint64_t), hipMemcpyHostToDevice, sb));
+    BHIP(launch_copy_words(d->d_blocks_s[slot].p, dev_of(p.pin_blocks), p.n_blk * sizeof(BgzfBlock), sb));
+    BHIP(launch_copy_words(d->d_coff_s[slot].p, dev_of(p.pin_coff), p.n_blk * sizeof(uint64_t), sb));
     uint8_t *out = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX;
     {   // algorithmic bytes of the inflate: compressed bytes read + inflated bytes written
         KernelTimer kt(d->ctx, K_INFLATE, p.consumed + p.total, sb);
-        BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks_s[slot].p, (uint32_t)p.n_blk, out, d->d_status_s[slot].p, false, sb));
+        BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks_s[slot].p, (uint32_t)p.n_blk, out, d->d_status_s[slot].p,
+                                 d->d_status_s[slot].p + p.n_blk, false, sb));
     }
     {
         KernelTimer kt(d->ctx, K_INFLATE_CRC, p.total, sb);
         BHIP(launch_bgzf_crc(d->d_blocks_s[slot].p, (uint32_t)p.n_blk, out, d->d_status_s[slot].p, sb));
     }
-    p.status.resize(p.n_blk);
-    BHIP(hipMemcpyAsync(p.status.data(), d->d_status_s[slot].p, p.n_blk * sizeof(uint32_t), hipMemcpyDeviceToHost, sb));
+    BHIP(launch_copy_words(dev_of(p.status), d->d_status_s[slot].p, p.n_blk * sizeof(uint32_t), sb));
     BHIP(hipEventRecord(d->inf_done[slot], sb));
     (void)b;
     return NGSQ_OK;
@@ -733,6 +783,34 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
         if (rc) return rc;
     }
     const double t1 = now_ms();
+    // ---- 2. the cut record at the end of the previous chunk moves in front of this chunk's data (into the headroom of this
+    // chunk's buffer: the inflate, which may still be running, writes behind it)
+    const uint64_t carry = d->raw_len - d->tail_off;
+    if (carry > CARRY_MAX)
+        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest carry space (%llu MiB)", b->path.c_str(),
+                             (unsigned long long)(CARRY_MAX >> 20));
+    uint8_t *const view = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX - carry;
+    if (carry) BHIP(hipMemcpyAsync(view, d->raw + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
+    // everything that reads the previous chunk's buffer has been queued on the context's stream by now
+    BHIP(hipEventRecord(d->raw_free[slot ^ 1], st));
+    d->raw_free_set[slot ^ 1] = true;
+    // ---- 3. the chunk after this one goes onto the inflate stream BEFORE this thread waits for this chunk's inflate: the
+    // decoders then go from one chunk to the next without waiting for the host (the other buffer is free as soon as the
+    // kernels queued above have run, which the stream waits for by itself)
+    auto issue_next = [&]() -> int {
+        if (p.last || d->pend[slot ^ 1].issued) return NGSQ_OK;
+        bool ready;
+        {
+            std::lock_guard<std::mutex> g(d->mu);
+            ready = d->hc[slot ^ 1].ready;
+        }
+        return ready ? issue_inflate(b, d, slot ^ 1) : NGSQ_OK;
+    };
+    {
+        const int rc = issue_next();
+        if (rc) return rc;
+    }
+    // ---- 4. this chunk's inflate
     if (!p.err.empty()) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s", p.err.c_str());
     if (p.n_blk) {
         BHIP(hipEventSynchronize(d->inf_done[slot]));
@@ -752,27 +830,9 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     d->cv.notify_all();
     d->cur ^= 1;
     const double t3 = now_ms();
-    // ---- 2. the cut record at the end of the previous chunk moves in front of this chunk's data
-    const uint64_t carry = d->raw_len - d->tail_off;
-    if (carry > CARRY_MAX)
-        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest carry space (%llu MiB)", b->path.c_str(),
-                             (unsigned long long)(CARRY_MAX >> 20));
-    uint8_t *const view = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX - carry;
-    if (carry) BHIP(hipMemcpyAsync(view, d->raw + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
-    // everything that reads the previous chunk's buffer has been queued on the context's stream by now
-    BHIP(hipEventRecord(d->raw_free[slot ^ 1], st));
-    d->raw_free_set[slot ^ 1] = true;
-    // ---- 3. the chunk after this one, if the reader thread has it: its inflate overlaps this chunk's parse and scan
-    if (!p.last) {
-        bool ready;
-        {
-            std::lock_guard<std::mutex> g(d->mu);
-            ready = d->hc[slot ^ 1].ready;
-        }
-        if (ready) {
-            const int rc = issue_inflate(b, d, slot ^ 1);
-            if (rc) return rc;
-        }
+    {   // (the reader thread was late a moment ago: look again)
+        const int rc = issue_next();
+        if (rc) return rc;
     }
     d->raw = view;
     d->raw_len = carry + p.total;
@@ -840,19 +900,16 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     // ---- 5. which of them are this range's
     uint64_t own = total_rec;
     if (limit < d->raw_len && total_rec) {
-        unsigned long long below = 0;
-        BHIP(launch_count_below_u64(d->d_rec_off.p, total_rec, limit, d->d_small.p + 8, st));
-        BHIP(hipMemcpyAsync(&below, d->d_small.p + 8, sizeof below, hipMemcpyDeviceToHost, st));
+        BHIP(launch_count_below_u64(d->d_rec_off.p, total_rec, limit, static_cast<unsigned long long *>(d->h_small.dev) + 12, st));
         BHIP(hipStreamSynchronize(st));
-        own = below;
+        own = static_cast<const uint64_t *>(d->h_small.h)[12];
     }
     d->n_rec = own;
     const bool cut = d->tail_off < d->raw_len; // the chunk ends inside a record
     if (own < total_rec) { // the first record of the next range
-        uint64_t next = 0;
-        BHIP(hipMemcpyAsync(&next, d->d_rec_off.p + own, sizeof next, hipMemcpyDeviceToHost, st));
+        BHIP(launch_copy_words(static_cast<uint64_t *>(d->h_small.dev) + 13, d->d_rec_off.p + own, sizeof(uint64_t), st));
         BHIP(hipStreamSynchronize(st));
-        d->end_voffset = voffset_of(next);
+        d->end_voffset = voffset_of(static_cast<const uint64_t *>(d->h_small.h)[13]);
         d->last_chunk = true;
     } else if (d->boundary_passed && cut && d->tail_off >= limit) { // the cut record is the next range's first
         d->end_voffset = d->tail_id;
@@ -1141,8 +1198,10 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_var_base.p, d->d_small.p + 1, org, st));
     }
     unsigned long long stats[5] = {0, 0, 0, 0, 0};
-    BHIP(hipMemcpyAsync(stats, d->d_small.p + 1, sizeof stats, hipMemcpyDeviceToHost, st));
+    BHIP(d->h_small.reserve(64 * sizeof(uint64_t)));
+    BHIP(launch_copy_words(static_cast<uint64_t *>(d->h_small.dev) + 16, d->d_small.p + 1, sizeof stats, st));
     BHIP(hipStreamSynchronize(st));
+    memcpy(stats, static_cast<const uint64_t *>(d->h_small.h) + 16, sizeof stats);
     if (!d->n_own) d->first_key = stats[3];
     d->last_key = stats[4];
     d->n_own += n;
@@ -1166,9 +1225,11 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
             uint64_t *arr = d->d_len.p + (size_t)k * (n + 1);
             size_t tb = d->d_scan_tmp.cap;
             BHIP(launch_exclusive_scan_u64(arr, n + 1, d->d_scan_tmp.p, &tb, st));
-            BHIP(hipMemcpyAsync(&totals[k], arr + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            BHIP(launch_copy_words(static_cast<uint64_t *>(d->h_small.dev) + 24 + k, arr + n, sizeof(uint64_t), st));
         }
         BHIP(hipStreamSynchronize(st));
+        for (int k = 0; k < 3; k++)
+            if (!(k < 2 ? fixed : cig1)) totals[k] = static_cast<const uint64_t *>(d->h_small.h)[24 + k];
         if (!fixed) {
             so = totals[0];
             qo = totals[1];
@@ -1258,11 +1319,11 @@ int ngsq_bgzf_inflate_device(ngsq_ctx *c, const uint8_t *comp, uint64_t comp_len
     TRY(hipMalloc((void **)&d_comp, comp_len + INFLATE_IN_SLACK));
     TRY(hipMalloc((void **)&d_out, total + 64));
     TRY(hipMalloc((void **)&d_blocks, blocks.size() * sizeof(BgzfBlock)));
-    TRY(hipMalloc((void **)&d_status, blocks.size() * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&d_status, (blocks.size() + 1) * sizeof(uint32_t)));
     TRY(hipMemcpyAsync(d_comp, comp, comp_len, hipMemcpyHostToDevice, c->stream));
     TRY(hipMemsetAsync(d_comp + comp_len, 0, INFLATE_IN_SLACK, c->stream));
     TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(BgzfBlock), hipMemcpyHostToDevice, c->stream));
-    TRY(launch_bgzf_inflate(d_comp, d_blocks, (uint32_t)blocks.size(), d_out, d_status, check_crc != 0, c->stream));
+    TRY(launch_bgzf_inflate(d_comp, d_blocks, (uint32_t)blocks.size(), d_out, d_status, d_status + blocks.size(), check_crc != 0, c->stream));
     TRY(hipMemcpyAsync(status.data(), d_status, blocks.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (total) TRY(hipMemcpyAsync(out, d_out, total, hipMemcpyDeviceToHost, c->stream));
     TRY(hipStreamSynchronize(c->stream));

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "ingest_kernels.h"
 
@@ -108,6 +109,14 @@ __constant__ uint8_t c_len_extra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2
                                         3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// Decoded symbols wait in a queue until 64 bytes of output can be produced at once: a 64-bit window holds ~4.6
+// symbols = ~17 bytes of output on BAM data, and emitting them window by window ran the 64-lane emit at a quarter of
+// its width (a third of all instructions of the kernel).  Entry: [15:0] output offset of the symbol's first byte
+// (ISIZE <= 65536), [16] literal, [31:17] the literal byte or distance - 1.
+constexpr uint32_t QCAP = 64;
+__device__ __forceinline__ uint32_t q_lit(uint32_t at, uint32_t byte) { return at | 0x10000u | byte << 17; }
+__device__ __forceinline__ uint32_t q_match(uint32_t at, uint32_t dist) { return at | (dist - 1u) << 17; }
+
 struct Lds {
     uint8_t ring[RING];
     uint16_t lit_tab[1u << LB];
@@ -120,7 +129,10 @@ struct Lds {
     uint16_t syms1[32];    // distance (or code-length) symbols in canonical order
     union {
         uint8_t lens[320]; // code lengths while a block's tables are built
-        uint8_t mark[64];  // emit: the symbol that starts at each byte of a 64-byte output chunk
+        struct {
+            uint8_t mark[64]; // emit: the queued symbol that starts at each byte of a 64-byte output chunk
+            uint32_t q[QCAP]; // decoded symbols not yet written out (a circular queue, drained before the tables change)
+        } e;
     };
     __device__ __forceinline__ uint16_t *syms(uint32_t which) { return which ? syms1 : syms0; }
     __device__ __forceinline__ const uint16_t *syms(uint32_t which) const { return which ? syms1 : syms0; }
@@ -391,14 +403,9 @@ __device__ uint32_t crc_xpow8(uint32_t n_bytes) { // x^(8 n) mod P
 
 } // namespace
 
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
-                                                     const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
-    extern __shared__ __align__(16) uint8_t s_raw[];
-    Lds &L = *reinterpret_cast<Lds *>(s_raw);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t bi = blockIdx.x;
-    if (bi >= n_blocks) return;
+// one BGZF block, by one wavefront
+__device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict__ comp, const BgzfBlock *__restrict__ blocks,
+                                              uint32_t bi, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t lane) {
     // the descriptor, forced uniform: everything derived from it (the whole bit stream state) stays in SGPRs
     BgzfBlock blk = blocks[bi];
     blk.in_off = uni64(blk.in_off);
@@ -443,6 +450,79 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     };
 
     PROF_DECL;
+    // ---- the symbol queue and the emit
+    // [0, pos) has been written (ring / HBM); the queued symbols cover [pos, dpos) without gaps, in order
+    uint32_t dpos = 0, qhead = 0, qn = 0;
+    // Write the next n <= 64 bytes: every output byte is produced by one lane, no loop over the symbols (a serial copy
+    // per match cost ~35 scalar instructions each, and the scalar unit -- one per CU -- is what bounds this kernel):
+    //   (1) the symbol that owns each byte: the queued symbols mark the byte they start at, a max-scan spreads the marks
+    //       (byte 0 may belong to the queue's first symbol, begun in an earlier chunk);
+    //   (2) the owner's literal byte or distance is read from the queue; a match byte's source is T - distance;
+    //   (3) a source inside this chunk is a pointer to another lane: pointer jumping (p = p[p], at most six
+    //       rounds, none for the usual match that reaches behind the chunk) until every pointer ends at a byte
+    //       whose value is known -- a literal, a byte already in the ring, or one that has left the ring and is
+    //       read back from HBM (all such bytes of a chunk in one round trip);
+    //   (4) the values travel back along the pointers and the chunk is stored.
+    // A source byte S is still in the ring iff S >= base - RING (base = first byte of the chunk: everything in
+    // front of it has been written); older bytes have been flushed, because base - flushed < PIECE at every
+    // chunk start and PIECE + 64 <= RING.
+    auto emit_chunk = [&](uint32_t n) {
+        const uint32_t base = pos;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // queue entries are read by other lanes than wrote them
+        const uint32_t qe = L.e.q[(qhead + lane) & (QCAP - 1u)];
+        const uint32_t st = qe & 0xFFFFu;
+        const bool queued = lane < qn;
+        // (the marks are read by OTHER lanes than wrote them: the wavefront-scope fence makes the compiler reload
+        // instead of forwarding this lane's own zero; LDS operations of one wave execute in order, nothing else is
+        // needed.  A `volatile` pointer did that too, but it lost the LDS address space: flat_store_byte /
+        // flat_load_ubyte with a full s_waitcnt after each, three round trips per 64 bytes of output.)
+        uint8_t *const mark = L.e.mark;
+        mark[lane] = 0;
+        if (queued && st - base < 64u) mark[st - base] = (uint8_t)(lane + 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t own = mark[lane];
+        if (lane == 0 && own == 0) own = 1u;
+        own = wave_inclusive_max(own);
+        const uint32_t oe = L.e.q[(qhead + own - 1u) & (QCAP - 1u)];
+        const bool active = lane < n;
+        const bool lit = (oe & 0x10000u) != 0;
+        const uint32_t T = base + lane, src = T - (oe >> 17) - 1u;
+        const bool inchunk = active && !lit && (int32_t)(src - base) >= 0;
+        uint32_t val = (oe >> 17) & 255u;
+        if (active && !lit && !inchunk) {
+            if (__builtin_expect((int32_t)(src - base + RING) < 0, 0))
+                val = __hip_atomic_load(gdst + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                val = L.ring[src & RMASK];
+        }
+        if (__ballot(inchunk)) {
+            uint32_t p = inchunk ? src - base : lane;
+            for (;;) {
+                const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)p);
+                if (!__ballot(q != p)) break;
+                p = q;
+            }
+            val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)val);
+        }
+        if (active) L.ring[T & RMASK] = (uint8_t)val;
+        pos += n;
+        while (pos - flushed >= PIECE) flush_piece(PIECE);
+        // symbols that are written out completely leave the queue: all that start in front of the new position, but
+        // the last of them if it reaches beyond it (a symbol ends where the next one starts)
+        const uint32_t k = (uint32_t)__popcll(__ballot(queued && st < pos));
+        const uint32_t nxt = k < qn ? (uint32_t)__builtin_amdgcn_readlane((int)st, (int)k) : dpos;
+        const uint32_t drop = k - (nxt > pos ? 1u : 0u);
+        qhead = (qhead + drop) & (QCAP - 1u);
+        qn -= drop;
+        PROF_COUNT(2, 1);
+    };
+    // whole 64-byte chunks while there are any; all = everything decoded so far (before the tables or the ring change hands)
+    auto drain = [&](bool all) {
+        while (dpos - pos >= 64u) emit_chunk(64u);
+        if (all && dpos != pos) emit_chunk(dpos - pos);
+    };
+
     bool last = false;
     while (!last && err == INF_OK) {
         PROF(0); // other
@@ -476,6 +556,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                 done += n;
                 if (pos - flushed >= PIECE) flush_piece(PIECE);
             }
+            dpos = pos;
             br.seek(byte0 + len);
             continue;
         }
@@ -573,7 +654,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
         // ---- the symbol windows
         bool end_of_block = false;
         while (!end_of_block && err == INF_OK) {
-            PROF(6); // tail of the previous window (piece flush, loop)
+            PROF(6); // tail of the previous window (loop)
+            drain(false); // (also makes room in the queue: fewer than 64 bytes pending = fewer than 64 symbols)
+            PROF(5); // emit
             // Lane j decodes what would start j bits from here: a literal, or a whole match -- length code,
             // its extra bits, and (from the lane at that bit offset) the distance code and its extra bits.
             br.sync();
@@ -610,102 +693,64 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                     is_lit = true;
                 }
             }
+            // the queue takes QCAP - qn more symbols: a window with more (short codes, a nearly full queue) ends early, the
+            // next one starts at the first symbol left out
+            bool trimmed = false;
+            if (__builtin_expect((uint32_t)__popcll(syms) > QCAP - qn, 0)) {
+                uint64_t m = syms;
+                for (uint32_t k = QCAP - qn; k; k--) m &= m - 1; // drop the symbols that fit
+                s = (uint32_t)__builtin_ctzll(m);
+                syms &= (1ull << s) - 1ull;
+                trimmed = true;
+            }
             PROF(3); // chain
             // where each symbol on the chain writes: prefix sum of the output lengths
             const bool on_chain = (syms >> lane) & 1ull;
             const uint32_t olen = !on_chain ? 0u : is_lit ? 1u : len;
             const uint32_t incl = wave_inclusive_sum(olen);
-            const uint32_t at = pos + incl - olen;
+            const uint32_t at = dpos + incl - olen;
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             PROF_COUNT(1, __popcll(__ballot(on_chain && is_lit)));
-            // a corrupt stream stops here, before anything of this window is stored or copied: a distance beyond the
+            // a corrupt stream stops here, before anything of this window is queued: a distance beyond the
             // start of the output would read in front of the block's buffer, and output beyond ISIZE would be flushed
             // past its end
             if (__ballot(on_chain && !is_lit && dist > at)) {
                 err = INF_BAD_DISTANCE;
                 break;
             }
-            if (pos + total > isize) {
+            if (dpos + total > isize) {
                 err = INF_OUTPUT_OVERRUN;
                 break;
             }
-            // ---- emit: every output byte of the window is produced by one lane, 64 bytes at a time; no loop over
-            // the matches (a serial copy per match cost ~35 scalar instructions each, and the scalar unit -- one per
-            // CU -- was what bounded this kernel).  Per chunk of 64 bytes:
-            //   (1) the symbol that owns each byte: symbols mark the byte they start at, a max-scan spreads the marks;
-            //   (2) the owner's literal byte or distance arrives by ds_bpermute; a match byte's source is T - distance;
-            //   (3) a source inside this chunk is a pointer to another lane: pointer jumping (p = p[p], at most six
-            //       rounds, none for the usual match that reaches behind the window) until every pointer ends at a byte
-            //       whose value is known -- a literal, a byte already in the ring, or one that has left the ring and is
-            //       read back from HBM (all such bytes of a chunk in one round trip);
-            //   (4) the values travel back along the pointers and the chunk is stored.
-            // A source byte S is still in the ring iff S >= base - RING (base = first byte of the chunk: everything in
-            // front of it has been written); older bytes have been flushed, because base - flushed < PIECE at every
-            // chunk start and PIECE + 64 <= RING.
-            const uint32_t rel = incl - olen; // offset of this lane's symbol in the window's output
-            const uint32_t info = is_lit ? 0x80000000u | e_byte(E) : dist;
-            for (uint32_t c0 = 0; c0 < total; c0 += 64) {
-                const uint32_t base = pos + c0;
-                // (the marks are read by OTHER lanes than wrote them: the wavefront-scope fence makes the compiler reload
-                // instead of forwarding this lane's own zero; LDS operations of one wave execute in order, nothing else is
-                // needed.  A `volatile` pointer did that too, but it lost the LDS address space: flat_store_byte /
-                // flat_load_ubyte with a full s_waitcnt after each, three round trips per 64 bytes of output.)
-                uint8_t *const mark = L.mark;
-                mark[lane] = 0;
-                if (on_chain && rel - c0 < 64u) mark[rel - c0] = (uint8_t)(lane + 1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                uint32_t own = mark[lane];
-                if (c0) { // a symbol that started in an earlier chunk owns the first bytes of this one
-                    const uint64_t before = __ballot(on_chain && rel < c0);
-                    if (lane == 0 && own == 0) own = 64u - (uint32_t)__builtin_clzll(before);
-                }
-                own = wave_inclusive_max(own);
-                const uint32_t oi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((own - 1u) << 2), (int)info);
-                const bool active = c0 + lane < total;
-                const bool lit = (oi >> 31) != 0;
-                const uint32_t T = base + lane, src = T - (oi & 0xFFFFFu);
-                const bool inchunk = active && !lit && (int32_t)(src - base) >= 0;
-                uint32_t val = oi & 255u;
-                if (active && !lit && !inchunk) {
-                    if (__builtin_expect((int32_t)(src - base + RING) < 0, 0))
-                        val = __hip_atomic_load(gdst + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else
-                        val = L.ring[src & RMASK];
-                }
-                if (__ballot(inchunk)) {
-                    uint32_t p = inchunk ? src - base : lane;
-                    for (;;) {
-                        const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)p);
-                        if (!__ballot(q != p)) break;
-                        p = q;
-                    }
-                    val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p << 2), (int)val);
-                }
-                if (active) L.ring[T & RMASK] = (uint8_t)val;
-                const uint32_t wr = base + min(64u, total - c0);
-                while (wr - flushed >= PIECE) flush_piece(PIECE);
-                PROF_COUNT(2, 1);
+            if (on_chain) {
+                const uint32_t rank = (uint32_t)__popcll(syms & ((1ull << lane) - 1ull));
+                L.e.q[(qhead + qn + rank) & (QCAP - 1u)] = is_lit ? q_lit(at, e_byte(E)) : q_match(at, dist);
             }
-            pos += total;
+            qn += (uint32_t)__popcll(syms);
+            dpos += total;
             br.consume(s);
-            PROF(5); // matches
+            PROF(4); // queue
             // A chain that stopped at a length code whose distance code lies beyond lane 63 just ends the
             // window there: the next window starts at that length code and sees all of the match.
             const bool resume = s > 0 && s < 64 && e_is_len(__builtin_amdgcn_readlane(E, s & 63u));
-            if (s < 64 && !resume && err == INF_OK) {
+            if (s < 64 && !resume && !trimmed) {
                 // The chain stopped at a symbol the lanes could not finish: end of block, a long code (or a
-                // distance code with one), or an invalid code.  One symbol the plain way.
+                // distance code with one), or an invalid code.  One symbol the plain way, through the queue like the others.
                 PROF_COUNT(6, 1);
+                drain(false);
                 br.sync();
                 const uint32_t x0 = br.bits32();
                 uint32_t e = uni((uint32_t)L.lit_tab[x0 & ((1u << LB) - 1u)]);
                 if (!e_is_len(e) && e_kind(e) == LK_ESC) e = uni(resolve_long(L, 0, x0));
                 const uint32_t eb = e_bits(e);
                 if (e_is_lit(e)) {
-                    if (lane == 0) L.ring[pos & RMASK] = (uint8_t)e_byte(e);
-                    pos += 1;
-                    br.consume(eb);
+                    if (dpos + 1 > isize) err = INF_OUTPUT_OVERRUN;
+                    else {
+                        if (lane == 0) L.e.q[(qhead + qn) & (QCAP - 1u)] = q_lit(dpos, e_byte(e));
+                        qn += 1;
+                        dpos += 1;
+                        br.consume(eb);
+                    }
                 } else if (!e_is_len(e) && e_kind(e) == LK_EOB) {
                     br.consume(eb);
                     end_of_block = true;
@@ -721,27 +766,20 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
                     const uint32_t dd0 = d_base(d) + ((x1 >> b2) & ((1u << ex2) - 1u));
                     br.consume(b2 + ex2);
                     if (d_kind(d) != DK_BASE) err = INF_BAD_SYMBOL;
-                    else if (dd0 > pos) err = INF_BAD_DISTANCE;
-                    else if (pos + l > isize) err = INF_OUTPUT_OVERRUN;
+                    else if (dd0 > dpos) err = INF_BAD_DISTANCE;
+                    else if (dpos + l > isize) err = INF_OUTPUT_OVERRUN;
                     else {
-                        const uint32_t from = pos - dd0;
-                        if (dd0 > RING - 512) { // the source left the ring
-                            const uint8_t *g = gdst + from;
-                            for (uint32_t i = lane; i < l; i += 64)
-                                L.ring[(pos + i) & RMASK] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else if (dd0 >= l) {
-                            for (uint32_t i = lane; i < l; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i) & RMASK];
-                        } else {
-                            for (uint32_t i = lane; i < l; i += 64) L.ring[(pos + i) & RMASK] = L.ring[(from + i % dd0) & RMASK];
-                        }
-                        pos += l;
+                        if (lane == 0) L.e.q[(qhead + qn) & (QCAP - 1u)] = q_match(dpos, dd0);
+                        qn += 1;
+                        dpos += l;
                     }
                 } else {
                     err = INF_BAD_SYMBOL;
                 }
             }
-            while (pos - flushed >= PIECE) flush_piece(PIECE);
         }
+        // the tables (and the code-length scratch the queue shares its memory with) are about to change
+        if (err == INF_OK) drain(true);
     }
     PROF(0);
     if (err == INF_OK && pos != isize) err = pos > isize ? INF_OUTPUT_OVERRUN : INF_SIZE_MISMATCH;
@@ -755,6 +793,30 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
     if (lane == 0) status[bi] = err;
 }
 
+// The decoders are PERSISTENT: the grid is what the device holds at once (per_cu wavefronts on every CU, LDS-limited)
+// and each wavefront takes block after block from a counter.  One launch per chunk either way, but a grid of 8-16 k
+// one-block workgroups kept the dispatcher busy placing them for the whole 7 ms, and while a dispatch still has
+// workgroups waiting for a slot the workgroups of OTHER queues are not placed at all -- the record index and the
+// column kernels of the previous chunk (another stream) ran only when the inflate had finished.
+// A grid that is resident from the start leaves the dispatcher free, and the kernels of the other stream take the
+// wave slots and registers the decoders leave.  The counter also evens out the tail: no last partial round of blocks.
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
+                                                     const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                     uint8_t *__restrict__ out, uint32_t *__restrict__ status,
+                                                     uint32_t *__restrict__ next_block) {
+    extern __shared__ __align__(16) uint8_t s_raw[];
+    Lds &L = *reinterpret_cast<Lds *>(s_raw);
+    const uint32_t lane = threadIdx.x;
+    for (;;) {
+        uint32_t bi = 0;
+        if (lane == 0) bi = atomicAdd(next_block, 1u);
+        bi = uni(bi);
+        if (bi >= n_blocks) return;
+        inflate_block(L, comp, blocks, bi, out, status, lane);
+        __syncthreads(); // the next block's first LDS writes come after this block's last reads
+    }
+}
+
 // CRC32 of every inflated block against its gzip trailer: its own kernel (one wave per block, no LDS
 // ring, so many waves per CU) instead of a tax on the four decoders of a CU.  The block is cut into 64
 // equal slices, right-aligned (the CRC register is linear in the message once the initial value is
@@ -764,6 +826,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__
 constexpr uint32_t CRC_WAVES = 8; // BGZF blocks per workgroup: the tables are loaded once for all of them
 __global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__restrict__ out, const BgzfBlock *__restrict__ blocks,
                                                              uint32_t n_blocks, uint32_t *__restrict__ status) {
+    NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_tab[CRC_SLICES * 256];
     for (uint32_t k = threadIdx.x; k < CRC_SLICES * 256; k += 64 * CRC_WAVES) s_tab[k] = c_crc.t[k >> 8][k & 0xFFu];
     __syncthreads();
@@ -819,23 +882,35 @@ hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uin
 }
 
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
-                               uint32_t *status, bool check_crc, hipStream_t s) {
+                               uint32_t *status, uint32_t *counter, bool check_crc, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
     static bool attr = false;
+    static uint32_t resident = 0;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bgzf_inflate),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
         if (e != hipSuccess) return e;
+        int dev = 0, n_cu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        // decoders per CU: what the LDS holds (160 KiB / 6400-byte allocations = 25), less one so that every SIMD keeps
+        // registers and a wave slot for the other stream's kernels (NGSQ_INFLATE_PER_CU: measurement aid)
+        uint32_t per_cu = 24;
+        if (const char *v = getenv("NGSQ_INFLATE_PER_CU")) per_cu = (uint32_t)atoi(v); // 0: a workgroup per block, as before
+        resident = per_cu ? (uint32_t)n_cu * per_cu : 0xFFFFFFFFu;
         attr = true;
     }
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks), dim3(64), sizeof(Lds), s, comp, blocks, n_blocks, out, status);
+    hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < resident ? n_blocks : resident), dim3(64), sizeof(Lds), s, comp, blocks, n_blocks, out,
+                       status, counter);
     if (check_crc) (void)launch_bgzf_crc(blocks, n_blocks, out, status, s);
 #ifdef NGSQ_INFLATE_PROFILE
     {
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_inflate_prof), sizeof h);
-        static const char *names[8] = {"other", "header+tables", "window+gathers", "chain", "literals+consume", "match",
+        static const char *names[8] = {"other", "header+tables", "window+gathers", "chain", "queue", "emit",
                                        "window tail/piece flush", "final flush+crc"};
         unsigned long long tot = 0;
         for (int k = 0; k < 8; k++) tot += h[k];

@@ -73,6 +73,7 @@ __device__ __forceinline__ bool st_valid(const DeviceState &st, int32_t rf, int3
 
 // one thread per tile: first start of each run of streamable tiles (plan_a) and the start that ends it (plan_z)
 __global__ __launch_bounds__(256) void k_cov_plan_tiles(DeviceState st, DeviceBatch b, CovStreamArgs a) {
+    NGSQ_FOREGROUND_WAVE();
     const uint64_t n_wt = (b.n + CS_TILE - 1) / CS_TILE;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) { // coordinate order across the batch boundary
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void k_cov_plan_tiles(DeviceState st, DeviceBa
 
 // one thread per sequence: the streamed chunk range of this batch; rolls the per-sequence end forward
 __global__ __launch_bounds__(256) void k_cov_plan_refs(DeviceState st, CovStreamArgs a) {
+    NGSQ_FOREGROUND_WAVE();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= st.n_refs) return;
     const uint32_t pa = a.plan_a[r], pz = a.plan_z[r], prev = a.prev_end[r];
@@ -177,6 +179,7 @@ struct StTileIn {
 #define ST_MIN_BLOCKS 4
 #endif
 __global__ __launch_bounds__(ST_THREADS, ST_MIN_BLOCKS) void k_cov_stream(DeviceState st, DeviceBatch b, CovStreamArgs a) {
+    NGSQ_FOREGROUND_WAVE();
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const uint32_t nb = a.cov_cap + 2;
     const uint32_t tid = threadIdx.x, lane = tid & 63;

@@ -88,6 +88,7 @@ __device__ __forceinline__ uint32_t slot_counter(uint32_t slot) {
 // tile loop would make hipcc drain the in-order vmcnt queue, i.e. the prefetch, on every tile)
 template <bool CIG_OFF, bool STREAM>
 __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, DeviceBatch b, FieldsArgs a) {
+    NGSQ_FOREGROUND_WAVE();
     extern __shared__ uint32_t s_dyn[];
     uint32_t *const s_tlen = s_dyn;                                 // tlen_cap + 1
     uint32_t *const s_win = s_dyn + ((st.tlen_cap + 1 + 3) & ~3u);  // one FT_WINDOW per wave

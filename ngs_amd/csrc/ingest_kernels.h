@@ -5,6 +5,13 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+// The kernels of the context's stream (record index, columns, facets) share the CUs with the BGZF decoders of the next chunk
+// (another stream, persistent waves that keep the scalar and vector issue ports busy): their waves ask for the highest
+// issue priority, or a latency-bound kernel like the record-chain walk runs ten times slower beside the decoders than alone.
+#ifndef NGSQ_FOREGROUND_WAVE
+#define NGSQ_FOREGROUND_WAVE() __builtin_amdgcn_s_setprio(3)
+#endif
+
 namespace ngsq {
 
 // one BGZF block (SAM/BAM specification 4.1): the raw DEFLATE payload of one gzip member
@@ -34,9 +41,10 @@ enum InflateStatus : uint32_t {
 // The compressed buffer must be readable for INFLATE_IN_SLACK bytes past the last payload.
 constexpr uint32_t INFLATE_IN_SLACK = 1024;
 
-// Inflate blocks [0, n_blocks): one wavefront per block.  status[k] = InflateStatus of block k.
+// Inflate blocks [0, n_blocks): one wavefront per block at a time, a resident grid of decoders taking block after block
+// from *counter (device memory, 4 bytes, zeroed by the launcher on the stream).  status[k] = InflateStatus of block k.
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
-                               uint32_t *status, bool check_crc, hipStream_t s);
+                               uint32_t *status, uint32_t *counter, bool check_crc, hipStream_t s);
 
 // CRC32 of every block's inflated bytes against its gzip trailer (status[k] = INF_CRC_MISMATCH); what
 // launch_bgzf_inflate(check_crc = true) runs second
@@ -94,6 +102,9 @@ hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start,
 // its first record.  One lane per REC_PIECE bytes writes the offsets of the records that start there.
 hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
                               const RecPieces *pieces, uint64_t *rec_off, unsigned long long *bad, hipStream_t s);
+// copy n_bytes (rounded up to whole 32-bit words) with a kernel: for small tables between device memory and pinned host
+// memory, which a hipMemcpyAsync would queue behind the large transfers of other streams
+hipError_t launch_copy_words(void *dst, const void *src, uint64_t n_bytes, hipStream_t s);
 // out[0] = number of entries of the ascending array a[0, n) that are < value (one thread)
 hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value, unsigned long long *out, hipStream_t s);
 // also writes var_base[i] = offset of record i's CIGAR in raw and var_base[n + i] = offset of its SEQ (2 n entries:

@@ -25,6 +25,13 @@
 
 #include "../../include/ngsq.h"
 
+// The kernels of the context's stream (record index, columns, facets) share the CUs with the BGZF decoders of the next chunk
+// (another stream, persistent waves that keep the scalar and vector issue ports busy): their waves ask for the highest
+// issue priority, or a latency-bound kernel like the record-chain walk runs ten times slower beside the decoders than alone.
+#ifndef NGSQ_FOREGROUND_WAVE
+#define NGSQ_FOREGROUND_WAVE() __builtin_amdgcn_s_setprio(3)
+#endif
+
 namespace ngsq {
 
 enum : uint32_t {

@@ -76,6 +76,7 @@ __device__ __forceinline__ void gc_dword(uint32_t x, uint32_t mask, uint32_t &gc
 }
 
 __global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b, uint64_t seq_bytes) {
+    NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_hist[NGSQ_GC_BINS];
     __shared__ u64 s_acc[6];
     if (threadIdx.x < NGSQ_GC_BINS) s_hist[threadIdx.x] = 0;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b, uint6
 // LDS table [rows][94] u32; cycles >= rows go straight to global atomics.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBatch b, uint32_t lds_rows) {
+    NGSQ_FOREGROUND_WAVE();
     extern __shared__ uint32_t s_q[]; // lds_rows * 94
     __shared__ u64 s_acc[2];
     const uint32_t nbins = lds_rows * QUAL_BINS;

@@ -53,6 +53,7 @@ uint32_t qual_window_lds_bytes(uint32_t R) { return QUAL_BINS * qw_cp(R) * 4; }
 template <uint32_t R, uint32_t NROT>
 __global__ __launch_bounds__(1024) void k_qual_win(DeviceState st, const uint8_t *__restrict__ qual, uint64_t n_rec,
                                                    uint32_t pitch) {
+    NGSQ_FOREGROUND_WAVE();
     constexpr uint32_t RP = qw_rp(R), CP = qw_cp(R), CP4 = CP * 4, RP4 = RP * 4;
     constexpr uint32_t S4 = 4u * RP4; // table bytes between the first entries of two consecutive dwords of a window
     constexpr uint32_t magicR = R == 1 ? 0u : (uint32_t)(((1ull << 32) + R - 1) / R);
@@ -211,6 +212,7 @@ __device__ __forceinline__ uint32_t qr_from_lane(uint32_t v, uint32_t src_lane) 
 template <uint32_t R, uint32_t NROT>
 __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint8_t *__restrict__ qual,
                                                       const uint64_t *__restrict__ qual_off, uint64_t n_rec) {
+    NGSQ_FOREGROUND_WAVE();
     constexpr uint32_t RP = qw_rp(R), CP = qw_cp(R), CP4 = CP * 4, RP4 = RP * 4;
     constexpr uint32_t S4 = 4u * RP4;
     extern __shared__ uint32_t s_q[]; // QUAL_BINS x CP words: the only LDS object
@@ -444,6 +446,7 @@ static __device__ __noinline__ uint32_t qp_exact(u64 *__restrict__ qual_counters
 template <uint32_t R, uint32_t D>
 __global__ __launch_bounds__(1024) void k_qual_perm(DeviceState st, const uint8_t *__restrict__ qual, uint64_t n_rec,
                                                     uint32_t pitch) {
+    NGSQ_FOREGROUND_WAVE();
     static_assert(R >= 1 && R <= QP_MAX_R, "window index must fit the low byte of a table address");
     constexpr uint32_t T = qp_threads(R), RPB = T / R; // records per pass of the block
     constexpr uint32_t magicR = R == 1 ? 0u : (uint32_t)(((1ull << 32) + R - 1) / R);
