@@ -447,8 +447,13 @@ void reader_main(DeviceIngest *d, std::string path) {
             return;
         }
     }
-    for (int k = 0;; k ^= 1) {
+    uint64_t chunk_no = 0;
+    for (int k = 0;; k ^= 1, chunk_no++) {
         DeviceIngest::HostChunk &c = d->hc[k];
+        // the pipeline fills in three steps: nothing can be parsed before the first chunk has been read, copied and
+        // inflated, so the first one is small (32 MiB of records), the second 128 MiB, then whole chunks
+        const uint64_t limit = chunk_no == 0 ? std::min<uint64_t>(out_limit, (uint64_t)32 << 20)
+                               : chunk_no == 1 ? std::min<uint64_t>(out_limit, (uint64_t)128 << 20) : out_limit;
         {
             std::unique_lock<std::mutex> g(d->mu);
             d->cv.wait(g, [&] { return d->stop || !c.ready; });
@@ -499,7 +504,7 @@ void reader_main(DeviceIngest *d, std::string path) {
             const size_t n0 = c.blocks.size();
             size_t used = 0;
             std::string err;
-            if (!bgzf_split(c.h + c.consumed, c.fill - c.consumed, &c.blocks, &used, &c.total, &err, out_limit)) {
+            if (!bgzf_split(c.h + c.consumed, c.fill - c.consumed, &c.blocks, &used, &c.total, &err, limit)) {
                 c.err = path + ": " + err;
                 return;
             }
@@ -524,9 +529,9 @@ void reader_main(DeviceIngest *d, std::string path) {
         };
         while (c.err.empty() && !full && !eof && c.fill < cap) {
             // bytes this chunk still needs, by the ratio so far (unknown at first: one step, then look again)
-            size_t want = STEP;
+            size_t want = (size_t)std::min<uint64_t>(STEP, limit / 2);
             if (ratio > 0) {
-                const double need = (double)(out_limit - c.total) * ratio * 1.02 + 2 * 65536.0;
+                const double need = (double)(limit - c.total) * ratio * 1.02 + 2 * 65536.0;
                 const size_t have = c.fill - c.consumed;
                 want = need > (double)have ? (size_t)(need - (double)have) : 65536;
                 want = std::min(want, STEP);

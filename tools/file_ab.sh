@@ -45,6 +45,8 @@ for rep in range(3):
     res.append((t1 - t0, (got - first[1]) / (t1 - first[0]) / 1e6))
 kt = ctx.kernel_timing()
 print("%-40s" % "$V", " ".join("%.3fs/%.0fM" % r for r in res), " inflate %.2f ms" % (kt["bgzf_inflate"]["total_ms"] / kt["bgzf_inflate"]["launches"]))
+if os.environ.get("KERNELS"):
+    print("   ", "  ".join("%s %.3f x%d" % (k, v["total_ms"] / v["launches"], v["launches"]) for k, v in kt.items() if v["launches"]))
 PY
 done
 done
