@@ -44,9 +44,10 @@ extern "C" {
 #define NGSQ_ERR_BUFFER_TOO_SMALL (-6)
 #define NGSQ_ERR_UNSUPPORTED (-7)
 #define NGSQ_ERR_UNSORTED (-8)         /* sorted_input was promised and a record broke the order */
-#define NGSQ_ERR_LIMIT (-9)            /* an implementation limit, not a malformed input: a read longer than
-                                          max_read_len (<= NGSQ_MAX_READ_LEN_LIMIT); the reference has no such limit
-                                          (quality_scores.rs:18 keeps a map per position) */
+#define NGSQ_ERR_LIMIT (-9)            /* an implementation limit, not a malformed input: a read longer than the quality
+                                          table in a batch that did not say how long its reads are (device memory,
+                                          offsets layout, max_l_seq = 0), or longer than NGSQ_QUALITY_ROWS_LIMIT; the
+                                          reference has no such limit (quality_scores.rs:18 keeps a map per position) */
 
 /* ---- facets (names: `name()` of each facet under src/qc/record_based, sequence_based) ---- */
 #define NGSQ_FACET_GENERAL 0x01u         /* "General"          general.rs:23        */
@@ -68,7 +69,8 @@ extern "C" {
 #define NGSQ_EDITS_BINS 513    /* histogram.rs:394-398 Histogram::default() 0..=512     */
 #define NGSQ_VAF_BINS 101      /* edits.rs:64  zero_based_with_capacity(100)            */
 #define NGSQ_N_RECORD_COUNTERS 16
-#define NGSQ_MAX_READ_LEN_LIMIT 1024
+#define NGSQ_MAX_READ_LEN_LIMIT 1024            /* (kept for callers of ABI 3: the table is no longer limited to it) */
+#define NGSQ_QUALITY_ROWS_LIMIT (1u << 24)      /* cycles the quality table grows to (16 Mi cycles = 12.6 GB of counters) */
 
 /* where a batch's column pointers live */
 #define NGSQ_MEM_HOST 0u
@@ -92,7 +94,8 @@ typedef struct ngsq_config {
     uint32_t bin_size;      /* coverage bin, qc.rs:87 (50 000); 0 -> 50 000                */
     uint32_t tlen_cap;      /* template length capacity, qc.rs:62 (1024); 0 -> 1024        */
     uint32_t cov_cap;       /* coverage.rs:76 (2048); 0 -> 2048                            */
-    uint32_t max_read_len;  /* rows of the per-cycle quality table; 0 -> 512              */
+    uint32_t max_read_len;  /* rows the per-cycle quality table starts with (0 -> 512); it grows to the longest
+                               read of the batches (see ngsq_batch.max_l_seq)                              */
     uint64_t gc_seed;       /* seed of the deterministic GC window offset (ngsq_gc_offset) */
     const uint8_t *const *ref_bases; /* Edits only: [n_refs] pointers to ref_len[r] bytes of
                                         4-bit BAM base codes (one code per byte), host memory;
@@ -160,7 +163,12 @@ typedef struct ngsq_batch {
     uint32_t seq_stride;        /* bytes per record when seq_off == NULL  */
     uint32_t qual_stride;       /* bytes per record when qual_off == NULL */
     uint32_t cigar_stride;      /* ops per record when cigar_off == NULL  */
-    uint32_t reserved;
+    uint32_t max_l_seq;         /* the longest read of the batch, or 0 = not known.  The quality table grows to it
+                                   before the batch is scanned.  Not needed for fixed-pitch rows (the pitch says it)
+                                   nor for host batches (the library looks); a DEVICE batch in the offsets layout
+                                   that leaves it 0 must keep to the table's current rows (ngsq_max_read_len) --
+                                   longer reads are then counted as read_too_long and ngsq_finalize returns
+                                   NGSQ_ERR_LIMIT.  The readers of ngsq_bam.h fill it in. */
     /* totals of the variable-length columns; required for NGSQ_MEM_DEVICE batches
      * that use offsets arrays (the host cannot read them), otherwise 0 = derive */
     uint64_t seq_bytes;
@@ -215,7 +223,8 @@ typedef struct ngsq_gc_metrics {
 typedef struct ngsq_error_counts {
     uint64_t missing_reference_id;  /* general.rs:81-83 unwrap() on None                     */
     uint64_t bad_quality_score;     /* score > 93: noodles decode error / quality_scores.rs:45 */
-    uint64_t read_too_long;         /* l_seq > max_read_len: implementation limit -> NGSQ_ERR_LIMIT */
+    uint64_t read_too_long;         /* a read longer than the quality table's rows in a batch that did not announce it
+                                       (ngsq_batch.max_l_seq): implementation limit -> NGSQ_ERR_LIMIT */
     uint64_t edits_bad_reference;   /* edits.rs:242-261 slice out of range / no sequence     */
     uint64_t edits_record_short;    /* alignment.rs:84-87 "consume a record base"            */
     uint64_t edits_not_consumed;    /* alignment.rs:100-104 not fully consumed               */
@@ -317,11 +326,11 @@ int ngsq_get_general(const ngsq_ctx *ctx, ngsq_general_metrics *out);
 int ngsq_get_template_length(const ngsq_ctx *ctx, uint64_t *histogram, size_t n_bins,
                              uint64_t *processed, uint64_t *ignored);
 int ngsq_get_gc_content(const ngsq_ctx *ctx, ngsq_gc_metrics *out);
-/* scores: row-major [max_read_len][94]; row i is 1-based cycle i+1 (quality_scores.rs:39-42) */
+/* scores: row-major [ngsq_max_read_len(ctx)][94]; row i is 1-based cycle i+1 (quality_scores.rs:39-42) */
 int ngsq_get_quality_scores(const ngsq_ctx *ctx, uint64_t *scores, size_t n_rows);
 /* number of reference sequences / bins of one sequence's mean_coverage_per_bin */
 uint32_t ngsq_n_refs(const ngsq_ctx *ctx);
-uint32_t ngsq_max_read_len(const ngsq_ctx *ctx);
+uint32_t ngsq_max_read_len(const ngsq_ctx *ctx); /* rows of the quality table NOW (it grows) */
 uint32_t ngsq_tlen_bins(const ngsq_ctx *ctx);
 uint32_t ngsq_cov_bins(const ngsq_ctx *ctx);
 /* 1 + floor(L/bin) + (L % bin != 0)   (coverage.rs:206-230) */

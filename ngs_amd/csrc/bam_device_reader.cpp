@@ -1273,6 +1273,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     out->qual = col.qual;
     out->cigar = col.cigar;
     out->record_id = d->d_record_id.p;
+    out->max_l_seq = max_l;
     out->seq_bytes = so;
     out->qual_bytes = qo;
     out->cigar_ops = co;

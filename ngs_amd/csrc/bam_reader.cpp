@@ -416,6 +416,7 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     out->qual = b->qual.p;
     out->cigar = b->cigar.data();
     out->record_id = b->record_id.data();
+    out->max_l_seq = max_l;
     if (fixed) {
         out->seq_stride = pitch_s;
         out->qual_stride = pitch_q;

@@ -210,6 +210,7 @@ struct Compact { // offsets-layout batch assembled from picked records
         o.seq = seq.data(); o.seq_off = seq_off.data(); o.qual = qual.data(); o.qual_off = qual_off.data();
         o.cigar = cigar.data(); o.cigar_off = cigar_off.data();
         o.record_id = record_id.data();
+        for (uint32_t l : l_seq) o.max_l_seq = std::max(o.max_l_seq, l);
         o.seq_bytes = seq_off.back(); o.qual_bytes = qual_off.back(); o.cigar_ops = cigar_off.back();
         return o;
     }
@@ -622,7 +623,7 @@ int main(int argc, char **argv) {
     cfg.bin_size = 50000;  // qc.rs:87
     cfg.tlen_cap = 1024;   // qc.rs:62
     cfg.cov_cap = 2048;    // coverage.rs:76
-    cfg.max_read_len = NGSQ_MAX_READ_LEN_LIMIT;
+    cfg.max_read_len = 256; // where the quality table starts: it grows with the longest read of the file
     cfg.gc_seed = a.gc_seed;
     cfg.ref_bases = (facets & NGSQ_FACET_EDITS) ? bases.data() : nullptr;
     // Coverage while the records stream by (ngsq_config.sorted_input) needs coordinate order.  `ngs qc` only

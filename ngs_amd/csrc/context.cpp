@@ -136,7 +136,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     if (!c->cfg.tlen_cap) c->cfg.tlen_cap = 1024;
     if (!c->cfg.cov_cap) c->cfg.cov_cap = 2048;
     if (!c->cfg.max_read_len) c->cfg.max_read_len = 512;
-    if (c->cfg.max_read_len > NGSQ_MAX_READ_LEN_LIMIT || c->cfg.tlen_cap > 15000 || c->cfg.cov_cap > 15000) {
+    if (c->cfg.max_read_len > NGSQ_QUALITY_ROWS_LIMIT || c->cfg.tlen_cap > 15000 || c->cfg.cov_cap > 15000) {
         delete c;
         return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "max_read_len/tlen_cap/cov_cap too large");
     }
@@ -180,11 +180,13 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     st.cov_cap = c->cfg.cov_cap;
     st.gc_seed = c->cfg.gc_seed;
     st.off_tlen = OFF_TLEN_HIST;
-    st.off_qual = (uint32_t)round_up(st.off_tlen + st.tlen_cap + 1, 8);
-    st.off_edits1 = st.off_qual + st.max_read_len * QUAL_BINS;
+    // (the quality table comes LAST: it grows with the longest read met -- quality_scores.rs:18 keeps a map per
+    // position, any length works -- and growing then leaves every other offset where it was)
+    st.off_edits1 = (uint32_t)round_up(st.off_tlen + st.tlen_cap + 1, 8);
     st.off_edits2 = st.off_edits1 + (uint32_t)round_up(NGSQ_EDITS_BINS, 8);
     st.off_seen = st.off_edits2 + (uint32_t)round_up(NGSQ_EDITS_BINS, 8);
-    c->n_counters = round_up((uint64_t)st.off_seen + nr, 8);
+    st.off_qual = (uint32_t)round_up((uint64_t)st.off_seen + nr, 8);
+    c->n_counters = round_up((uint64_t)st.off_qual + (uint64_t)st.max_read_len * QUAL_BINS, 8);
     CTX_TRY(hipMalloc((void **)&st.counters, c->n_counters * 8));
     CTX_TRY(hipMemsetAsync(st.counters, 0, c->n_counters * 8, c->stream));
     c->h_counters.assign(c->n_counters, 0);
@@ -394,6 +396,45 @@ static void resolve_timing(ngsq_ctx *c) {
 
 // ---- batches ----------------------------------------------------------------
 
+// The per-cycle quality table has one row per cycle of the longest read met so far (the reference: a map entry per
+// position, quality_scores.rs:37-49).  Rows are added by moving the counters block into a larger allocation; nothing but
+// the block's size changes (the table is its last part).
+static int grow_rows(ngsq_ctx *c, uint64_t rows) {
+    if (rows <= c->st.max_read_len) return NGSQ_OK;
+    if (rows > NGSQ_QUALITY_ROWS_LIMIT)
+        return fail(c, NGSQ_ERR_LIMIT, "implementation limit: a read of %llu bases (the quality table holds up to %u cycles)",
+                    (unsigned long long)rows, (unsigned)NGSQ_QUALITY_ROWS_LIMIT);
+    // short reads: to the next multiple of 64 (what the fast kernels are specialised for depends on the rows); long reads: by
+    // half again, so that a file of ever longer reads does not move the block for each of them
+    const uint64_t want = std::min<uint64_t>(rows <= 1024 ? round_up(rows, 64) : round_up(rows + rows / 2, 1024), NGSQ_QUALITY_ROWS_LIMIT);
+    const uint64_t n_new = round_up((uint64_t)c->st.off_qual + want * QUAL_BINS, 8);
+    unsigned long long *bigger = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc((void **)&bigger, n_new * 8));
+    HIP_TRY(c, hipMemcpyAsync(bigger, c->st.counters, c->n_counters * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(bigger + c->n_counters, 0, (n_new - c->n_counters) * 8, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // kernels queued earlier still use the old block
+    (void)hipFree(c->st.counters);
+    c->st.counters = bigger;
+    c->st.max_read_len = (uint32_t)want;
+    c->cfg.max_read_len = (uint32_t)want;
+    c->n_counters = n_new;
+    c->h_counters.resize(n_new, 0);
+    return NGSQ_OK;
+}
+
+// the longest read of a batch, where the host can tell: fixed-pitch rows (the pitch), host columns (l_seq), or the
+// reader's word for it (ngsq_batch.max_l_seq); 0 = unknown
+static uint64_t batch_longest_read(const ngsq_batch *b) {
+    if (!b->qual) return 0;
+    if (!b->qual_off) return b->qual_stride;
+    if (b->max_l_seq) return b->max_l_seq;
+    if (b->location != NGSQ_MEM_HOST) return 0;
+    uint64_t longest = 0;
+    for (uint64_t i = 0; i < b->n_records; i++) longest = std::max<uint64_t>(longest, b->qual_off[i + 1] - b->qual_off[i]);
+    return longest;
+}
+
 static int check_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t facets) {
     if (b->struct_size != sizeof(ngsq_batch))
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "ngsq_batch.struct_size %u != %zu", b->struct_size,
@@ -578,6 +619,10 @@ int ngsq_process_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
     HIP_TRY(c, hipSetDevice(c->device));
     ColumnSizes cs;
     column_sizes(c, b, &cs);
+    if ((facets & NGSQ_FACET_QUALITY_SCORE) && (pass_mask & NGSQ_PASS_RECORD)) {
+        rc = grow_rows(c, batch_longest_read(b));
+        if (rc != NGSQ_OK) return rc;
+    }
 
     DeviceBatch db{};
     db.n = n;
@@ -765,9 +810,9 @@ int ngsq_finalize(ngsq_ctx *c) {
         for (int k = 0; k < 8; k++) other = other || (k != E_READ_TOO_LONG && err[k]);
         if (err[E_READ_TOO_LONG] && !other)
             return fail(c, NGSQ_ERR_LIMIT,
-                        "implementation limit: %llu read(s) longer than max_read_len = %u bases (this library handles reads of up to "
-                        "%u bases; the reference has no such limit)",
-                        err[E_READ_TOO_LONG], c->cfg.max_read_len, (unsigned)NGSQ_MAX_READ_LEN_LIMIT);
+                        "implementation limit: %llu read(s) longer than the quality table's %u cycles in a batch that did not "
+                        "announce them (ngsq_batch.max_l_seq; the reference has no such limit)",
+                        err[E_READ_TOO_LONG], c->cfg.max_read_len);
     }
     for (int k = 0; k < 8; k++)
         if (err[k])
@@ -1110,3 +1155,7 @@ int ngsq_host_free_pinned(void *p) {
 }
 
 } // extern "C"
+
+namespace ngsq {
+int grow_quality_table(ngsq_ctx *c, uint64_t rows) { return grow_rows(c, rows); }
+} // namespace ngsq

@@ -38,6 +38,8 @@ struct Staging {
     hipEvent_t done = nullptr;
 };
 
+int grow_quality_table(ngsq_ctx *c, uint64_t rows); // context.cpp: at least `rows` cycles in the quality table
+
 } // namespace ngsq
 
 struct ngsq_ctx {

@@ -452,6 +452,15 @@ extern "C" int ngsq_exchange(ngsq_ctx *c, ngsq_comm *comm, ngsq_exchange_report 
     if (!c || !comm) return comm_fail(comm, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
     if (c->finalized || c->torn_down) return comm_fail(comm, NGSQ_ERR_STATE, "ngsq_exchange after the teardown; call ngsq_reset");
     if (hipSetDevice(c->device) != hipSuccess) return comm_fail(comm, NGSQ_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
+    {   // the shards' quality tables have grown to the longest read each of them met: the counter blocks are summed element
+        // by element, so they take the size of the largest first
+        std::vector<uint32_t> rows((size_t)comm->world, 0);
+        const uint32_t mine = c->st.max_read_len;
+        int rc = ngsq_comm_allgather_host(comm, &mine, rows.data(), sizeof mine);
+        if (rc) return rc;
+        rc = ngsq::grow_quality_table(c, *std::max_element(rows.begin(), rows.end()));
+        if (rc) return comm_fail(comm, rc, "%s", c->err.c_str());
+    }
     ngsq_shard_state s{};
     s.struct_size = sizeof s;
     s.memory = NGSQ_MEM_DEVICE;

@@ -104,7 +104,7 @@ class Batch(C.Structure):
         ("seq_stride", C.c_uint32),
         ("qual_stride", C.c_uint32),
         ("cigar_stride", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("max_l_seq", C.c_uint32),
         ("seq_bytes", C.c_uint64),
         ("qual_bytes", C.c_uint64),
         ("cigar_ops", C.c_uint64),

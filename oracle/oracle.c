@@ -382,9 +382,19 @@ static void quality_process(orc_ctx *c, const orc_record *r) {
         /* fixed-stride rows (ngsq.h): 0xFF = no score at this cycle (BAM's own
            encoding of absent qualities; noodles yields no score for them) */
         if (r->qual_fixed_row && r->qual[i] == 0xFF) continue;
+        /* quality_scores.rs:18: a map entry per position -- no length is too long.  (max_read_len is where this array
+           starts; the HIP path's table grows the same way, include/ngsq.h ngsq_batch.max_l_seq.) */
         if (i >= c->cfg.max_read_len) {
-            c->errors.read_too_long += 1;
-            break;
+            uint32_t want = c->cfg.max_read_len;
+            while (want <= i) want += want / 2 + 64;
+            orc_histogram *bigger = (orc_histogram *)realloc(c->scores, (size_t)want * sizeof(orc_histogram));
+            if (!bigger) {
+                c->errors.read_too_long += 1;
+                break;
+            }
+            memset(bigger + c->cfg.max_read_len, 0, (size_t)(want - c->cfg.max_read_len) * sizeof(orc_histogram));
+            c->scores = bigger;
+            c->cfg.max_read_len = want;
         }
         /* :39-42 entry(i + 1).or_insert_with(zero_based_with_capacity(93)) */
         orc_histogram *h = &c->scores[i];
@@ -862,16 +872,25 @@ int orc_get_gc_content(const orc_ctx *c, ngsq_gc_metrics *out) {
     return NGSQ_OK;
 }
 
+/* rows [0, n_rows) of the table; cycles nobody reached are rows of zeros, cycles beyond n_rows must be empty */
 int orc_get_quality_scores(const orc_ctx *c, uint64_t *scores, size_t n_rows) {
-    if (n_rows < c->cfg.max_read_len) return NGSQ_ERR_BUFFER_TOO_SMALL;
-    for (uint32_t i = 0; i < c->cfg.max_read_len; i++) {
-        uint64_t *row = scores + (size_t)i * (NGSQ_MAX_SCORE + 1);
-        if (c->scores[i].values)
+    for (uint32_t i = (uint32_t)n_rows; i < c->cfg.max_read_len; i++)
+        if (c->scores[i].values) return NGSQ_ERR_BUFFER_TOO_SMALL;
+    for (size_t i = 0; i < n_rows; i++) {
+        uint64_t *row = scores + i * (NGSQ_MAX_SCORE + 1);
+        if (i < c->cfg.max_read_len && c->scores[i].values)
             memcpy(row, c->scores[i].values, (NGSQ_MAX_SCORE + 1) * sizeof(uint64_t));
         else
             memset(row, 0, (NGSQ_MAX_SCORE + 1) * sizeof(uint64_t));
     }
     return NGSQ_OK;
+}
+
+uint32_t orc_quality_rows(const orc_ctx *c) { /* 1 + the last cycle any read reached */
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < c->cfg.max_read_len; i++)
+        if (c->scores[i].values) n = i + 1;
+    return n;
 }
 
 uint64_t orc_coverage_n_bins(const orc_ctx *c, uint32_t ref) {

@@ -90,6 +90,7 @@ const char *orc_last_error(const orc_ctx *ctx);
 
 /* command.rs:305-316 (pass 1) and :356-397 (pass 2) over one SoA batch */
 int orc_process_batch(orc_ctx *ctx, const ngsq_batch *batch, uint32_t pass_mask);
+uint32_t orc_quality_rows(const orc_ctx *ctx); /* 1 + the last cycle any read reached */
 /* summarize (command.rs:328-330), teardown per sequence (:392-396), aggregate (:406-414) */
 int orc_finalize(orc_ctx *ctx);
 

@@ -58,6 +58,8 @@ def load() -> C.CDLL:
     lib.orc_get_template_length.argtypes = [P, ffi.u64p, C.c_size_t, ffi.u64p, ffi.u64p]
     lib.orc_get_gc_content.argtypes = [P, C.POINTER(ffi.GcMetrics)]
     lib.orc_get_quality_scores.argtypes = [P, ffi.u64p, C.c_size_t]
+    lib.orc_quality_rows.argtypes = [P]
+    lib.orc_quality_rows.restype = C.c_uint32
     lib.orc_coverage_n_bins.restype = C.c_uint64
     lib.orc_coverage_n_bins.argtypes = [P, C.c_uint32]
     lib.orc_get_coverage_sequence.argtypes = [P, C.c_uint32, C.POINTER(C.c_int), ffi.u64p, C.c_size_t, ffi.u64p,
@@ -218,9 +220,11 @@ class Oracle:
             d[k] = int(getattr(g, k))
         return d
 
-    def quality_scores(self) -> np.ndarray:
-        q = np.zeros((self.max_read_len, ffi.MAX_SCORE + 1), dtype=np.uint64)
-        rc = self.lib.orc_get_quality_scores(self._ctx, q.ctypes.data_as(ffi.u64p), self.max_read_len)
+    def quality_scores(self, rows: int = 0) -> np.ndarray:
+        """[rows][94]; rows = 0: the table's starting size or the longest read met, whichever is larger."""
+        rows = rows or max(self.max_read_len, int(self.lib.orc_quality_rows(self._ctx)))
+        q = np.zeros((rows, ffi.MAX_SCORE + 1), dtype=np.uint64)
+        rc = self.lib.orc_get_quality_scores(self._ctx, q.ctypes.data_as(ffi.u64p), rows)
         assert rc == 0
         return q
 

@@ -3,6 +3,7 @@ seeded inputs.  Bit-exact on every integer array; parsed-JSON equal on the
 `Results` document (the reference's HashMap order is random).
 Run on the GPU box with `pytest -m gpu`.
 """
+import ctypes as C
 import json
 import os
 
@@ -131,21 +132,88 @@ def test_fixed_pitch_rows_with_padding(gpu_lib, oracle_mod, max_len, on_device):
     json_equal(g_fixed.results(["a", "b"]), g_var.results(["a", "b"]))
 
 
-def test_fixed_pitch_row_longer_than_table(gpu_lib, oracle_mod):
-    """qual pitch > max_read_len: padding beyond the table is fine, real scores are an error."""
+def test_quality_table_grows_with_the_reads(gpu_lib, oracle_mod):
+    """quality_scores.rs:18 keeps a map per position: any read length works.  The table starts with max_read_len rows
+    and grows to the longest read of each batch -- fixed-pitch rows say it by their pitch, host batches are looked at,
+    the readers of ngsq_bam.h announce it (ngsq_batch.max_l_seq).  Only a DEVICE batch in the offsets layout that does
+    not announce its longest read must keep to the rows there are: that is the one limit left (NGSQ_ERR_LIMIT)."""
     rng = np.random.default_rng(77)
     var = random_batch(rng, 500, [5000], max_len=60, weird=False)
     fixed = to_fixed_stride(var, min_len=80)
     run_both(oracle_mod, gpu_lib, [fixed], [5000], max_read_len=64, facets=ffi.FACET_QUALITY_SCORE)
-    fixed2 = to_fixed_stride(random_batch(rng, 500, [5000], max_len=80, min_len=70, weird=False))
-    g, _ = run_both(oracle_mod, gpu_lib, [fixed2], [5000], max_read_len=64, facets=ffi.FACET_QUALITY_SCORE)
-    assert g.error_counts()["read_too_long"] == 500
-    # ... reported as what it is: a limit of this implementation (the reference keeps a map per position), not a malformed input
-    with host.QcContext([5000], lib=gpu_lib, max_read_len=64, facets=ffi.FACET_QUALITY_SCORE) as c:
-        c.process_batch(fixed2)
-        with pytest.raises(host.NgsqError) as ei:
-            c.finalize()
-        assert ei.value.code == ffi.ERR_LIMIT and "implementation limit: 500 read(s) longer than max_read_len = 64" in ei.value.message
+    var2 = random_batch(rng, 500, [5000], max_len=80, min_len=70, weird=False)
+    fixed2 = to_fixed_stride(var2)
+    for hb in (fixed2, var2):
+        g, _ = run_both(oracle_mod, gpu_lib, [hb], [5000], max_read_len=64, facets=ffi.FACET_QUALITY_SCORE)
+        assert g.error_counts()["read_too_long"] == 0 and g.quality_scores().shape[0] == 128    # 80 cycles -> the next multiple of 64
+        assert int(g.quality_scores()[64:80].sum()) > 0
+    # a device batch in the offsets layout: announced -> grows; not announced -> the limit, reported as what it is
+    for announce in (True, False):
+        with host.QcContext([5000], lib=gpu_lib, max_read_len=64, facets=ffi.FACET_QUALITY_SCORE) as c:
+            db = c.upload(var2)
+            st = db.struct()
+            st.max_l_seq = 80 if announce else 0
+            assert gpu_lib.ngsq_process_batch(c._ctx, C.byref(st), ffi.PASS_BOTH) == 0
+            if announce:
+                c.finalize()
+                o = oracle_mod.Oracle([5000], max_read_len=64, facets=ffi.FACET_QUALITY_SCORE)
+                o.process_batch(var2)
+                o.finalize()
+                assert np.array_equal(c.quality_scores()[:80], o.quality_scores(80))
+            else:
+                with pytest.raises(host.NgsqError) as ei:
+                    c.finalize()
+                assert ei.value.code == ffi.ERR_LIMIT and "implementation limit: 500 read(s) longer than the quality table's 64 cycles" in ei.value.message
+
+
+@pytest.mark.parametrize("length", [1025, 5000, 40_000])
+def test_long_reads(gpu_lib, oracle_mod, length, tmp_path):
+    """reads longer than 1024 bases used to stop `ngs qc` with NGSQ_ERR_LIMIT.  Reads of 1 025, 5 000 and 40 000
+    bases (and short ones between them) through the offsets layout on the host and on the device, through fixed-pitch
+    rows, and as a BAM file through the host reader, the device reader and the command line: the oracle's document."""
+    import json, subprocess
+    from ngs_amd import build
+    from tests import bamio
+    rng = np.random.default_rng(length)
+    n = 600 if length <= 5000 else 60
+    L = [max(3 * length, 50_000), 7_000]
+    hb = random_batch(rng, n, L, max_len=length, min_len=length - 3, weird=False)
+    short = random_batch(rng, n, L, max_len=200, min_len=30, weird=False)
+    for on_device in (False, True):
+        g, o = run_both(oracle_mod, gpu_lib, [short, hb, short], L, max_read_len=256, bin_size=5000, on_device=on_device)
+        assert g.error_counts()["read_too_long"] == 0 and int(g.quality_scores()[length - 4].sum()) == n
+    if length <= 5000:   # (a fixed-pitch batch of 40 kb rows is not what any reader would build)
+        run_both(oracle_mod, gpu_lib, [to_fixed_stride(hb)], L, max_read_len=256, bin_size=5000)
+    # as a file: coordinate-sorted, through both readers and the command line
+    from tests.util import coordinate_sorted
+    both = coordinate_sorted(bamio_concat(short, hb))
+    both.cols["flag"] &= np.uint16(0xFFFF ^ 0x1)
+    bam = str(tmp_path / "long.bam")
+    names = ["chr1", "chr2"]
+    both = bamio.with_ids(both, bamio.write_bam(bam, both, names, L, block_payload=40_000))
+    o = oracle_mod.Oracle(L, max_read_len=256, gc_seed=0x4E4753, bin_size=50_000)
+    o.process_batch(both)
+    o.finalize()
+    want = o.results(names)
+    assert str(length) in want["quality_scores"]["scores"] and str(length + 1) not in want["quality_scores"]["scores"]
+    ngs = build.build_cli(verbose=False)
+    for ingest in ("device", "host"):
+        out = tmp_path / ingest
+        r = subprocess.run([ngs, "-q", "qc", bam, "GRCh38_no_alt_AnalysisSet", "-o", str(out), "--ingest", ingest, "--batch-records", "257"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        json_equal(json.load(open(out / "long.bam.results.json")), want)
+
+
+def bamio_concat(a, b):
+    """Two offsets-layout batches as one."""
+    cols = {}
+    for k in host.FIXED_COLUMNS:
+        cols[k] = np.concatenate([a.cols[k], b.cols[k]])
+    for data, off in (("seq", "seq_off"), ("qual", "qual_off"), ("cigar", "cigar_off")):
+        cols[data] = np.concatenate([a.cols[data], b.cols[data]])
+        cols[off] = np.concatenate([a.cols[off], b.cols[off][1:] + a.cols[off][-1]]).astype(np.uint64)
+    return host.HostBatch(a.n + b.n, cols, 0, 0, 0, 0)
 
 
 def test_many_batches_equal_one_batch(gpu_lib, oracle_mod):
