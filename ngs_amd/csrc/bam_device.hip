@@ -243,7 +243,8 @@ __global__ __launch_bounds__(PT) void k_rec_offsets(const uint8_t *__restrict__ 
 }
 
 // ---- 4. fixed-width columns + the numbers the layout decision needs ----------------------------
-// stats: [0] max l_seq, [1] max n_cigar, [2] sum l_seq, [3] / [4] (refID << 32 | pos) of the first / last record.
+// stats: [0] max l_seq, [1] max n_cigar, [2] sum l_seq, [3] / [4] (refID << 32 | pos) of the first / last record, [5] index of the
+// first record with the long-CIGAR placeholder (the caller sets it to ~0).
 // record_id (include/ngsq.h): the record's BAM virtual offset -- the block whose data holds its first byte is found
 // by bisection over the chunk's block table (out_off ascending; blocks without data never hold a byte), the record
 // carried over from the previous chunk (view offset < carry) has the id it was given there.  var_base[i] / seq_src[i] = offset of record i's CIGAR / SEQ
@@ -290,6 +291,10 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
                 id = org.coff[lo_k] << 16 | (u - org.blocks[lo_k].out_off);
             }
             org.record_id[i] = id;
+        }
+        if (n_ops == 2 && l) { // the long-CIGAR placeholder <l_seq>S<span>N (specification 4.2.2): refused by name, as the host reader does
+            const uint32_t op0 = ld32(raw + o + 32 + l_read_name), op1 = ld32(raw + o + 36 + l_read_name);
+            if (op0 == (l << 4 | 4u) && (op1 & 15u) == 3u) atomicMin(&stats[5], (unsigned long long)i);
         }
         if (i == 0) stats[3] = (unsigned long long)a.x << 32 | a.y;
         if (i == n - 1) stats[4] = (unsigned long long)a.x << 32 | a.y;

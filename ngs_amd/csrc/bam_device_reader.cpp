@@ -1189,6 +1189,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     col.tlen = d->d_tlen.p;
     col.l_seq = d->d_l_seq.p;
     BHIP(hipMemsetAsync(d->d_small.p + 1, 0, 3 * sizeof(unsigned long long), st));
+    BHIP(hipMemsetAsync(d->d_small.p + 6, 0xFF, sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_COLUMNS, n * 36);
         // the records' ids: their virtual offsets, by the block table of the chunk they come from
@@ -1202,11 +1203,14 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         org.carry_id = d->carry_id;
         BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_var_base.p, d->d_small.p + 1, org, st));
     }
-    unsigned long long stats[5] = {0, 0, 0, 0, 0};
+    unsigned long long stats[6] = {0, 0, 0, 0, 0, 0};
     BHIP(d->h_small.reserve(64 * sizeof(uint64_t)));
     BHIP(launch_copy_words(static_cast<uint64_t *>(d->h_small.dev) + 16, d->d_small.p + 1, sizeof stats, st));
     BHIP(hipStreamSynchronize(st));
     memcpy(stats, static_cast<const uint64_t *>(d->h_small.h) + 16, sizeof stats);
+    if (stats[5] != ~0ull)
+        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: record %llu: a CIGAR of more than 65535 operations (CG tag, SAM specification 4.2.2) is not supported",
+                             b->path.c_str(), (unsigned long long)(b->n_read + stats[5]));
     if (!d->n_own) d->first_key = stats[3];
     d->last_key = stats[4];
     d->n_own += n;

@@ -298,6 +298,15 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
         if (l_read_name == 0 || need > block_size)
             return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
                          (unsigned long long)(b->n_read + recs.size()));
+        // SAM/BAM specification 4.2.2: a CIGAR of more than 65535 operations is stored in a CG:B,I tag and the CIGAR field
+        // holds the placeholder <l_seq>S<reference span>N.  noodles resolves the tag; the batch ABI counts the operations of
+        // a record in 16 bits, so such a record is refused by name instead of being scanned with the placeholder ([N10])
+        if (n_ops == 2 && l > 0) {
+            const uint8_t *cg = r + 32 + l_read_name;
+            if (rd32(cg) == (l << 4 | 4u) && (rd32(cg + 4) & 15u) == 3u)
+                return bfail(NGSQ_ERR_UNSUPPORTED, "%s: record %llu: a CIGAR of more than 65535 operations (CG tag, SAM specification 4.2.2) is not supported",
+                             b->path.c_str(), (unsigned long long)(b->n_read + recs.size()));
+        }
         recs.push_back(cursor);
         max_l = std::max(max_l, l);
         max_ops = std::max(max_ops, n_ops);

@@ -110,7 +110,7 @@ hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value,
 // also writes var_base[i] = offset of record i's CIGAR in raw and var_base[n + i] = offset of its SEQ (2 n entries:
 // what launch_rec_var starts from)
 // stats[0..2]: max l_seq, max n_cigar, sum l_seq (zeroed by the caller); stats[3], stats[4]: refID << 32 | pos of the first
-// and the last record of the batch
+// and the last record of the batch; stats[5] (set to ~0 by the caller): index of the first long-CIGAR placeholder
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
                             unsigned long long *stats, const RecOrigin &org, hipStream_t s);
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,

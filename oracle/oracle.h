@@ -50,7 +50,16 @@
  *       [N8] CIGAR op codes 0..8 = MIDNSHP=X; a code above 8 is a decode error
  *            (counted as bad_cigar_op);
  *       [N9] FASTA bases compare as upper-case A C G T N codes (edits.rs:265:
- *            Base::try_from; the synthetic references are upper case).
+ *            Base::try_from; the synthetic references are upper case);
+ *      [N10] a CIGAR of more than 65535 operations (SAM specification 4.2.2): the BAM record
+ *            holds the placeholder <l_seq>S<reference span>N and the real operations in a CG:B,I
+ *            tag, which noodles-bam resolves while decoding the record (as far as can be told
+ *            without its source: the crate gained this in its 0.1x releases).  The facets would
+ *            then see the real CIGAR.  This build's batch ABI counts a record's operations in 16
+ *            bits, so its readers REFUSE such a record by name (NGSQ_ERR_UNSUPPORTED) rather than
+ *            scan the placeholder as if it were the alignment: a limit, not a result
+ *            (tests/golden/hand_longcigar.bam).  Aux tags are otherwise skipped unread: no facet
+ *            looks at them.
  *     The hand goldens and the synthetic workloads stay away from the corner cases
  *     of [N4] and [N5] (span 0, start beyond L) except where a test names them.
  */
