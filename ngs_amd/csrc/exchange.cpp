@@ -294,7 +294,7 @@ struct Xchg {
         my_words = reinterpret_cast<uint32_t *>(scr.state + off_words); // reserve() may have moved the block
         all_words = reinterpret_cast<uint32_t *>(scr.state + off_all);
         std::vector<ngsq_p2p> sends, recvs;
-        std::vector<uint64_t> in_ranges;
+        std::vector<uint64_t> in_ranges, out_ranges;
         {
             uint64_t off = off_halo;
             for (auto &x : plan.xfer) {
@@ -303,6 +303,8 @@ struct Xchg {
                     sends.push_back({(int32_t)x.dst, 0, S.depth + x.c0 * CH, nc * CH * 4});
                     sends.push_back({(int32_t)x.dst, 0, S.depth + S.n_diff + x.c0, nc * 4});
                     rep.halo_bytes_sent += nc * (CH + 1) * 4;
+                    out_ranges.push_back(x.c0);
+                    out_ranges.push_back(x.c1);
                 }
                 if (x.dst == rank) {
                     recvs.push_back({(int32_t)x.src, 0, scr.state + off, nc * CH * 4});
@@ -326,7 +328,12 @@ struct Xchg {
 
         // ---- step 4: one word per rank: what its owned range sums to now (+ the verdict on the incoming ranges)
         const uint64_t b0 = plan.own[2 * rank], b1 = plan.own[2 * rank + 1];
-        rc = S.summary(S.user, b0, b1, in_ranges.data(), (uint32_t)(in_ranges.size() / 2), my_words);
+        // The verdict: no chunk this shard finished while streaming may lie in a range it RECEIVES entries for (the halo of
+        // the shard in front would come too late) -- nor in a range it SENDS (the chunk belongs to a shard that starts in
+        // front of positions this one has already tallied: shards out of coordinate order, each position counted twice)
+        std::vector<uint64_t> check(in_ranges);
+        check.insert(check.end(), out_ranges.begin(), out_ranges.end());
+        rc = S.summary(S.user, b0, b1, check.data(), (uint32_t)(check.size() / 2), my_words);
         if (rc) return comm_fail(&T, rc, "shard state: summary failed (%d)", rc);
         rc = allgather(my_words, 8, all_words, h_words.data());
         if (rc) return rc;

@@ -294,13 +294,18 @@ def _owner_worker(rank, world, port, q, layout, transport):
             if layout == "flags_ok":
                 mid = (t_lo + t_hi) // 2 // 4096
                 mine.flags[mid] = 1 if not mine.depth[mid * 4096:(mid + 1) * 4096].any() else 0
+            elif layout == "flags_sender":
+                # shards out of coordinate order at a boundary -- rank 0 has "finished while streaming" the last
+                # chunk it wrote, which lies where rank 1 starts: rank 1 owns it and would tally its positions again
+                if rank == 0:
+                    mine.flags[(t_hi - 1) // 4096] = 1
             elif rank > 0:
                 mine.flags[t_lo // 4096] = 1
             try:
                 rep = comm.exchange_state(mine.shard_state())
                 assert layout == "flags_ok", "an exchanged entry in a finished chunk was accepted"
             except shard.CommError as e:
-                assert layout == "flags_overlap" and e.code == ffi.ERR_UNSORTED and "overlap" in str(e), e
+                assert layout in ("flags_overlap", "flags_sender") and e.code == ffi.ERR_UNSORTED and "overlap" in str(e), e
                 done()
                 q.put((rank, "ok"))
                 return
@@ -321,7 +326,7 @@ def _owner_worker(rank, world, port, q, layout, transport):
 @pytest.mark.parametrize("world,layout,transport", [(2, "sorted", "gloo"), (3, "sorted", "gloo"), (3, "sorted", "shm"),
                                                     (3, "empty_rank", "gloo"), (2, "unsorted", "gloo"), (3, "unsorted", "shm"),
                                                     (3, "flags_ok", "gloo"), (3, "flags_overlap", "gloo"),
-                                                    (3, "flags_overlap", "shm")])
+                                                    (3, "flags_overlap", "shm"), (3, "flags_sender", "shm"), (2, "flags_sender", "gloo")])
 def test_owner_teardown_world_2_3(world, layout, transport):
     _run_ranks(_owner_worker, world, layout, transport)
 
