@@ -43,6 +43,27 @@ __device__ __forceinline__ uint32_t upper_bound(const uint32_t *a, uint32_t lo, 
     return lo;
 }
 
+// The same two searches started from where the previous tile's search ended: in a coordinate-sorted file the tile's bounds
+// move on by a few hundred positions, i.e. by zero to two list entries, and a search of eighteen dependent L2 loads
+// (a list holds ~10^5 entries) -- made by twenty threads while the rest of the block waits at a barrier -- was what a
+// tile's time consisted of.  `from` is only a hint: bounds that moved backwards (unsorted input, another shape of read)
+// are found by a search of the part in front of it.
+template <bool UPPER>
+__device__ __forceinline__ uint32_t bound_from(const uint32_t *a, uint32_t lo, uint32_t hi, uint32_t from, uint32_t v) {
+    auto below = [&](uint32_t x) { return UPPER ? x <= v : x < v; }; // the entries in front of the answer
+    if (from > hi) from = hi;
+    if (from < lo) from = lo;
+    if (from > lo && !below(a[from - 1])) return UPPER ? upper_bound(a, lo, from, v) : lower_bound(a, lo, from, v);
+    uint32_t at = from, step = 1;
+    while (at < hi && below(a[at])) { // gallop: from, from + 1, from + 3, from + 7, ...
+        at += step;
+        step <<= 1;
+    }
+    const uint32_t h = at < hi ? at : hi;
+    const uint32_t l = step > 1 ? at - (step >> 1) + 1 : from; // behind the last entry seen below the bound
+    return UPPER ? upper_bound(a, l < h ? l : h, h, v) : lower_bound(a, l < h ? l : h, h, v);
+}
+
 // intervals of name id k on sequence r overlapping [qs, qe); br = brackets of the tile for this name, or null
 __device__ __forceinline__ uint32_t count_overlaps(const FeatureTables &ft, uint32_t k, uint32_t r, uint32_t qs, uint32_t qe,
                                                    const uint32_t *br) {
@@ -70,12 +91,18 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
     __shared__ uint32_t s_mm[3];         // largest query start, smallest / largest query end on that sequence
     __shared__ uint32_t s_br[5][4];      // per name id: brackets of the searches (see the head of this file)
     __shared__ uint32_t s_cnt[11];
+    __shared__ uint32_t s_lo[5];         // per name id: begin of its list on the tile's sequence
+    __shared__ int32_t s_prev_ref;       // the sequence s_br belongs to (-1: none): the next tile's searches start from them
     if (threadIdx.x < 11) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_prev_ref = -1;
     uint32_t cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t n_round = (b.n + 255) & ~255ull; // whole blocks take part in the barriers and ballots
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        const bool live = i < b.n;
+    // a block takes CONSECUTIVE tiles (of a sorted file: consecutive positions), so that a tile's searches can start from
+    // the previous tile's; whole blocks take part in the barriers and ballots
+    const uint64_t per = ((b.n + gridDim.x - 1) / gridDim.x + 255) & ~255ull;
+    const uint64_t lo_i = (uint64_t)blockIdx.x * per, hi_i = lo_i + per < b.n ? lo_i + per : b.n;
+    for (uint64_t t0 = lo_i; t0 < hi_i; t0 += 256) {
+        const uint64_t i = t0 + threadIdx.x;
+        const bool live = i < hi_i;
         bool ign_flags = false, ign_nonprimary = false, err_ref = false, err_pos = false, processed = false;
         bool utr5 = false, utr3 = false, cds = false, intergenic = false, exonic = false, intronic = false;
         if (threadIdx.x == 0) {
@@ -113,35 +140,58 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                 qs = (uint32_t)pos + 1u;
                 qe = qs + span + 1u; // find(start, end + 1)
                 look = true;
-                atomicMin(&s_key, (unsigned long long)(uint32_t)ref << 32 | qs);
             }
+        }
+        {   // the tile's first (sequence, start): one LDS atomic per wave -- 256 lanes on one word serialise
+            unsigned long long k = look ? (unsigned long long)(uint32_t)ref << 32 | qs : ~0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(k, o, 64);
+                k = other < k ? other : k;
+            }
+            if ((threadIdx.x & 63) == 0 && k != ~0ull) atomicMin(&s_key, k);
         }
         __syncthreads();
         const unsigned long long key = s_key;
         const int32_t r0 = key == ~0ull ? -1 : (int32_t)(key >> 32);
-        if (look && ref == r0) {
-            atomicMax(&s_mm[0], qs);
-            atomicMin(&s_mm[1], qe);
-            atomicMax(&s_mm[2], qe);
+        {
+            const bool in = look && ref == r0;
+            uint32_t m0 = in ? qs : 0u, m1 = in ? qe : 0xFFFFFFFFu, m2 = in ? qe : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o, 64));
+                m1 = min(m1, (uint32_t)__shfl_xor((int)m1, o, 64));
+                m2 = max(m2, (uint32_t)__shfl_xor((int)m2, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMax(&s_mm[0], m0);
+                atomicMin(&s_mm[1], m1);
+                atomicMax(&s_mm[2], m2);
+            }
         }
         __syncthreads();
         if (r0 >= 0 && threadIdx.x < 20) {
             const uint32_t k = threadIdx.x >> 2, which = threadIdx.x & 3;
             const uint32_t lo = ft.idx[k * ft.n_refs + r0], hi = ft.idx[k * ft.n_refs + r0 + 1];
+            const uint32_t from = s_prev_ref == r0 ? lo + s_br[k][which] : lo; // (this thread's own word of the previous tile)
             uint32_t v;
-            if (which == 0) v = lower_bound(ft.starts, lo, hi, s_mm[1]) - lo;                          // fewest starts below a query end
-            else if (which == 1) v = lower_bound(ft.starts, lo, hi, s_mm[2]) - lo;                     // most
-            else if (which == 2) v = upper_bound(ft.stops, lo, hi, (uint32_t)(key & 0xFFFFFFFFu)) - lo; // fewest stops at or below a query start
-            else v = upper_bound(ft.stops, lo, hi, s_mm[0]) - lo;                                      // most
+            if (which == 0) v = bound_from<false>(ft.starts, lo, hi, from, s_mm[1]) - lo;                         // fewest starts below a query end
+            else if (which == 1) v = bound_from<false>(ft.starts, lo, hi, from, s_mm[2]) - lo;                    // most
+            else if (which == 2) v = bound_from<true>(ft.stops, lo, hi, from, (uint32_t)(key & 0xFFFFFFFFu)) - lo; // fewest stops at or below a query start
+            else v = bound_from<true>(ft.stops, lo, hi, from, s_mm[0]) - lo;                                      // most
             // kept relative to the list's begin, so that counts come out directly; the searches add the begin back
             s_br[k][which] = v;
+            if (which == 0) s_lo[k] = lo;
         }
         __syncthreads();
+        if (threadIdx.x == 0) s_prev_ref = r0; // (read again by the twenty only behind the next tile's barriers)
         if (look) {
             const bool narrow = ref == r0;
             auto count = [&](uint32_t name) -> uint32_t {
                 if (!narrow) return count_overlaps(ft, name, (uint32_t)ref, qs, qe, nullptr);
-                const uint32_t lo = ft.idx[name * ft.n_refs + ref];
+                // (brackets that have closed -- no interval of this name begins or ends inside the tile's span, the usual
+                // case -- give the count without touching the lists: lower_bound / upper_bound of an empty range)
+                const uint32_t lo = s_lo[name];
                 const uint32_t br[4] = {lo + s_br[name][0], lo + s_br[name][1], lo + s_br[name][2], lo + s_br[name][3]};
                 return count_overlaps(ft, name, (uint32_t)ref, qs, qe, br);
             };
