@@ -593,7 +593,7 @@ int ngsq_set_features(ngsq_ctx *c, const ngsq_features *f) {
     HIP_TRY(c, hipMalloc((void **)&c->d_ft_idx, idx.size() * 4));
     HIP_TRY(c, hipMalloc((void **)&c->d_ft_starts, starts.size() * 4));
     HIP_TRY(c, hipMalloc((void **)&c->d_ft_stops, stops.size() * 4));
-    HIP_TRY(c, hipMalloc((void **)&c->d_ft_primary, n_refs + 1));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ft_primary, n_refs + 1 + 16 + (ngsq::FT_SLOTS * 16 + 1) * 8)); // | the kernel's scratch (8-byte aligned)
     HIP_TRY(c, hipMemcpy(c->d_ft_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_ft_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_ft_stops, stops.data(), stops.size() * 4, hipMemcpyHostToDevice));
@@ -602,6 +602,8 @@ int ngsq_set_features(ngsq_ctx *c, const ngsq_features *f) {
     c->ft.starts = c->d_ft_starts;
     c->ft.stops = c->d_ft_stops;
     c->ft.primary = c->d_ft_primary;
+    c->ft.scratch = reinterpret_cast<unsigned long long *>(c->d_ft_primary + ((n_refs + 1 + 15) & ~15ull));
+    HIP_TRY(c, hipMemset(c->ft.scratch, 0, (ngsq::FT_SLOTS * 16 + 1) * 8));
     c->ft.n_refs = n_refs;
     for (int r = 0; r < 5; r++) c->ft.role_name[r] = f->role_name[r];
     c->have_features = true;

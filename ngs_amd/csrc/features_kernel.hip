@@ -18,6 +18,8 @@
 // correct: their brackets are the whole lists.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ngsq {
@@ -86,7 +88,15 @@ __device__ __forceinline__ void tally(uint32_t &counter, bool pred) { counter +=
 
 } // namespace
 
+// A TILE is F_RPT x 256 consecutive records, F_RPT per thread (record r * 256 + thread of the tile: coalesced columns): the
+// barriers, the tile's bounds and the twenty bracket searches -- a few microseconds of latency that most of the block sits
+// out -- are paid once per 1024 records instead of once per 256.
+#ifndef NGSQ_FEATURES_RPT
+#define NGSQ_FEATURES_RPT 4
+#endif
+constexpr uint32_t F_RPT = NGSQ_FEATURES_RPT;
 __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b, FeatureTables ft) {
+    NGSQ_FOREGROUND_WAVE();
     __shared__ unsigned long long s_key; // (sequence << 32 | smallest query start) of the tile's processed records
     __shared__ uint32_t s_mm[3];         // largest query start, smallest / largest query end on that sequence
     __shared__ uint32_t s_br[5][4];      // per name id: brackets of the searches (see the head of this file)
@@ -98,13 +108,10 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
     uint32_t cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // a block takes CONSECUTIVE tiles (of a sorted file: consecutive positions), so that a tile's searches can start from
     // the previous tile's; whole blocks take part in the barriers and ballots
-    const uint64_t per = ((b.n + gridDim.x - 1) / gridDim.x + 255) & ~255ull;
+    constexpr uint64_t TILE = 256ull * F_RPT;
+    const uint64_t per = ((b.n + gridDim.x - 1) / gridDim.x + TILE - 1) / TILE * TILE;
     const uint64_t lo_i = (uint64_t)blockIdx.x * per, hi_i = lo_i + per < b.n ? lo_i + per : b.n;
-    for (uint64_t t0 = lo_i; t0 < hi_i; t0 += 256) {
-        const uint64_t i = t0 + threadIdx.x;
-        const bool live = i < hi_i;
-        bool ign_flags = false, ign_nonprimary = false, err_ref = false, err_pos = false, processed = false;
-        bool utr5 = false, utr3 = false, cds = false, intergenic = false, exonic = false, intronic = false;
+    for (uint64_t t0 = lo_i; t0 < hi_i; t0 += TILE) {
         if (threadIdx.x == 0) {
             s_key = ~0ull;
             s_mm[0] = 0;
@@ -112,38 +119,66 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
             s_mm[2] = 0;
         }
         __syncthreads();
-        uint32_t qs = 0, qe = 0;
-        int32_t ref = -1;
-        bool look = false; // the record reaches the lookups
-        if (live) {
-            const uint32_t flag = b.flag[i];
-            ref = b.ref_id[i];
-            const int32_t pos = b.pos[i];
-            if (flag & 0x4u) { // features.rs:127-130
-                ign_flags = true;
-            } else if (ref < 0 || (uint32_t)ref >= ft.n_refs) { // :132-155
-                err_ref = true;
-            } else if (!ft.primary[ref]) { // :157-165
-                ign_nonprimary = true;
-            } else if (pos < 0) { // :171-174
-                err_pos = true;
-            } else {
-                // :176-178  start = alignment_start (1-based), end = start + cigar.alignment_span()
-                const uint32_t n_ops = b.n_cigar[i];
-                const uint64_t c0 = b.cigar_off ? b.cigar_off[i] : i * b.cigar_stride;
-                uint32_t span = 0;
-                for (uint32_t k = 0; k < n_ops; k++) {
-                    const uint32_t op = b.cigar[c0 + k], code = op & 15u;
-                    // M, D, N, =, X consume the reference
-                    if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) span += op >> 4;
+        uint32_t qs[F_RPT], qe[F_RPT], what[F_RPT]; // what: 0 nothing (past the end), 1 ignored flags, 2 error: reference, 3 ignored: not primary, 4 error: position, 5 looked up
+        int32_t ref[F_RPT];
+        {
+            // every column of the tile's records first, unconditionally (a record past the end reads the block's first), then
+            // what depends on them: the loads of a stage are in flight together -- one record after the other, each behind its
+            // own branches, the tile waited out a dozen memory latencies here
+            uint32_t flag[F_RPT], n_ops[F_RPT], op0[F_RPT];
+            int32_t pos[F_RPT];
+            uint64_t c0[F_RPT], idx[F_RPT];
+            uint8_t prim[F_RPT];
+#pragma unroll
+            for (uint32_t r = 0; r < F_RPT; r++) {
+                const uint64_t i = t0 + r * 256 + threadIdx.x;
+                idx[r] = i < hi_i ? i : lo_i;
+                flag[r] = b.flag[idx[r]];
+                ref[r] = b.ref_id[idx[r]];
+                pos[r] = b.pos[idx[r]];
+                n_ops[r] = b.n_cigar[idx[r]];
+                c0[r] = b.cigar_off ? b.cigar_off[idx[r]] : idx[r] * b.cigar_stride;
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < F_RPT; r++) {
+                op0[r] = b.cigar[c0[r]]; // (the column has slack behind its last operation)
+                prim[r] = ref[r] >= 0 && (uint32_t)ref[r] < ft.n_refs ? ft.primary[ref[r]] : (uint8_t)0;
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < F_RPT; r++) {
+                const uint64_t i = t0 + r * 256 + threadIdx.x;
+                qs[r] = qe[r] = what[r] = 0;
+                if (i >= hi_i) {
+                    ref[r] = -1;
+                } else if (flag[r] & 0x4u) { // features.rs:127-130
+                    what[r] = 1;
+                } else if (ref[r] < 0 || (uint32_t)ref[r] >= ft.n_refs) { // :132-155
+                    what[r] = 2;
+                } else if (!prim[r]) { // :157-165
+                    what[r] = 3;
+                } else if (pos[r] < 0) { // :171-174
+                    what[r] = 4;
+                } else {
+                    // :176-178  start = alignment_start (1-based), end = start + cigar.alignment_span()
+                    uint32_t span = 0;
+                    for (uint32_t k = 0; k < n_ops[r]; k++) {
+                        const uint32_t op = k ? b.cigar[c0[r] + k] : op0[r], code = op & 15u;
+                        // M, D, N, =, X consume the reference
+                        if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) span += op >> 4;
+                    }
+                    qs[r] = (uint32_t)pos[r] + 1u;
+                    qe[r] = qs[r] + span + 1u; // find(start, end + 1)
+                    what[r] = 5;
                 }
-                qs = (uint32_t)pos + 1u;
-                qe = qs + span + 1u; // find(start, end + 1)
-                look = true;
             }
         }
         {   // the tile's first (sequence, start): one LDS atomic per wave -- 256 lanes on one word serialise
-            unsigned long long k = look ? (unsigned long long)(uint32_t)ref << 32 | qs : ~0ull;
+            unsigned long long k = ~0ull;
+#pragma unroll
+            for (uint32_t r = 0; r < F_RPT; r++) {
+                const unsigned long long kr = what[r] == 5 ? (unsigned long long)(uint32_t)ref[r] << 32 | qs[r] : ~0ull;
+                k = kr < k ? kr : k;
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const unsigned long long other = __shfl_xor(k, o, 64);
@@ -155,8 +190,14 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
         const unsigned long long key = s_key;
         const int32_t r0 = key == ~0ull ? -1 : (int32_t)(key >> 32);
         {
-            const bool in = look && ref == r0;
-            uint32_t m0 = in ? qs : 0u, m1 = in ? qe : 0xFFFFFFFFu, m2 = in ? qe : 0u;
+            uint32_t m0 = 0u, m1 = 0xFFFFFFFFu, m2 = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < F_RPT; r++)
+                if (what[r] == 5 && ref[r] == r0) {
+                    m0 = max(m0, qs[r]);
+                    m1 = min(m1, qe[r]);
+                    m2 = max(m2, qe[r]);
+                }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o, 64));
@@ -185,17 +226,20 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
         }
         __syncthreads();
         if (threadIdx.x == 0) s_prev_ref = r0; // (read again by the twenty only behind the next tile's barriers)
-        if (look) {
-            const bool narrow = ref == r0;
-            auto count = [&](uint32_t name) -> uint32_t {
-                if (!narrow) return count_overlaps(ft, name, (uint32_t)ref, qs, qe, nullptr);
-                // (brackets that have closed -- no interval of this name begins or ends inside the tile's span, the usual
-                // case -- give the count without touching the lists: lower_bound / upper_bound of an empty range)
-                const uint32_t lo = s_lo[name];
-                const uint32_t br[4] = {lo + s_br[name][0], lo + s_br[name][1], lo + s_br[name][2], lo + s_br[name][3]};
-                return count_overlaps(ft, name, (uint32_t)ref, qs, qe, br);
-            };
-            {
+#pragma unroll
+        for (uint32_t r = 0; r < F_RPT; r++) {
+            bool utr5 = false, utr3 = false, cds = false, intergenic = false, exonic = false, intronic = false;
+            const bool look = what[r] == 5;
+            if (look) {
+                const bool narrow = ref[r] == r0;
+                auto count = [&](uint32_t name) -> uint32_t {
+                    if (!narrow) return count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], nullptr);
+                    // (brackets that have closed -- no interval of this name begins or ends inside the tile's span, the usual
+                    // case -- give the count without touching the lists: lower_bound / upper_bound of an empty range)
+                    const uint32_t lo = s_lo[name];
+                    const uint32_t br[4] = {lo + s_br[name][0], lo + s_br[name][1], lo + s_br[name][2], lo + s_br[name][3]};
+                    return count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], br);
+                };
                 // :186-214  UTR / CDS store: the if / else-if chain over the overlapping intervals only
                 // depends on how many there are of each name (roles may share a name)
                 bool c5 = false, c3 = false, cc = false;
@@ -207,8 +251,8 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                     bool seen = false; // count each distinct name once
                     for (uint32_t q = 0; q < role; q++) seen |= ft.role_name[q] == name;
                     if (seen) continue;
-                    uint32_t cnt = min(count(name), 3u);
-                    for (; cnt; cnt--) {
+                    uint32_t c = min(count(name), 3u);
+                    for (; c; c--) {
                         if (!c5 && name == n5) c5 = true;
                         else if (!c3 && name == n3) c3 = true;
                         else if (!cc && name == nc) cc = true;
@@ -228,38 +272,64 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                 } else {
                     intergenic = true;
                 }
-                processed = true; // :240
             }
+            tally(cnt[F_UTR5], utr5);
+            tally(cnt[F_UTR3], utr3);
+            tally(cnt[F_CDS], cds);
+            tally(cnt[F_INTERGENIC], intergenic);
+            tally(cnt[F_EXONIC], exonic);
+            tally(cnt[F_INTRONIC], intronic);
+            tally(cnt[F_PROCESSED], look); // :240
+            tally(cnt[F_IGN_FLAGS], what[r] == 1);
+            tally(cnt[F_IGN_NONPRIMARY], what[r] == 3);
+            tally(cnt[9], what[r] == 2);
+            tally(cnt[10], what[r] == 4);
         }
-        tally(cnt[F_UTR5], utr5);
-        tally(cnt[F_UTR3], utr3);
-        tally(cnt[F_CDS], cds);
-        tally(cnt[F_INTERGENIC], intergenic);
-        tally(cnt[F_EXONIC], exonic);
-        tally(cnt[F_INTRONIC], intronic);
-        tally(cnt[F_PROCESSED], processed);
-        tally(cnt[F_IGN_FLAGS], ign_flags);
-        tally(cnt[F_IGN_NONPRIMARY], ign_nonprimary);
-        tally(cnt[9], err_ref);
-        tally(cnt[10], err_pos);
     }
     __syncthreads();
     if ((threadIdx.x & 63) == 0)
         for (int k = 0; k < 11; k++)
             if (cnt[k]) atomicAdd(&s_cnt[k], cnt[k]);
     __syncthreads();
+    // Two thousand blocks adding to the same eleven words at their end serialise at the L2 (~9 ns each: 0.1 of this kernel's
+    // 0.33 ms).  They add to one of FT_SLOTS copies instead, and the block that finishes last -- a ticket tells it -- sums the
+    // copies into the counters and leaves the scratch zero for the next launch.
+    __shared__ bool s_last;
+    // (no __threadfence: on gfx950 an agent-scope release is a write-back of the XCD's L2, and eight thousand waves doing one
+    // cost more than the serialised atomics did.  The tallies are device-scope atomics whose RESULT is waited for, so they have
+    // been performed when the barrier lets the ticket go; the last block reads them with atomics too.)
     if (threadIdx.x < 11 && s_cnt[threadIdx.x]) {
+        const unsigned long long before = atomicAdd(&ft.scratch[(blockIdx.x % FT_SLOTS) * 16 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+        asm volatile("" ::"v"((uint32_t)before));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&ft.scratch[FT_SLOTS * 16], 1ull) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 11) {
+        unsigned long long sum = 0;
+        for (uint32_t k = 0; k < FT_SLOTS; k++) sum += atomicExch(&ft.scratch[k * 16 + threadIdx.x], 0ull);
         unsigned long long *dst = threadIdx.x < 9 ? st.counters + C_FEAT + threadIdx.x
                                                   : st.counters + (threadIdx.x == 9 ? C_FEAT_ERR_REF : C_FEAT_ERR_POS);
-        atomicAdd(dst, (unsigned long long)s_cnt[threadIdx.x]);
+        if (sum) atomicAdd(dst, sum);
     }
+    if (threadIdx.x == 0) ft.scratch[FT_SLOTS * 16] = 0;
 }
 
 hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const FeatureTables &ft,
                            hipStream_t s) {
     if (!b.n) return hipSuccess;
-    uint64_t g = (b.n + 255) / 256;
-    if (g > (uint64_t)li.n_cu * 8) g = (uint64_t)li.n_cu * 8;
+    // one round of blocks: as many as are resident at once (a grid of eight per CU at seven resident ran a second round with one
+    // block per CU -- twice the time of the first round alone).  NGSQ_FEATURES_BLOCKS_PER_CU: measurement aid.
+    static int per_cu = 0;
+    if (!per_cu) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_features), 256, 0) != hipSuccess || occ < 1) occ = 4;
+        const char *e = getenv("NGSQ_FEATURES_BLOCKS_PER_CU");
+        per_cu = e && atoi(e) > 0 ? atoi(e) : occ;
+    }
+    uint64_t g = (b.n + 256 * F_RPT - 1) / (256 * F_RPT);
+    if (g > (uint64_t)li.n_cu * (uint64_t)per_cu) g = (uint64_t)li.n_cu * (uint64_t)per_cu;
     hipLaunchKernelGGL(k_features, dim3((uint32_t)g), dim3(256), 0, s, st, b, ft);
     return hipGetLastError();
 }

@@ -169,7 +169,9 @@ struct FeatureTables {
     const uint8_t *primary; // [n_refs]
     uint32_t n_refs;
     uint32_t role_name[5]; // name id of NGSQ_ROLE_*
+    unsigned long long *scratch; // [FT_SLOTS * 16 + 1] zero between launches: per-slot partial tallies, then the launch's ticket
 };
+constexpr uint32_t FT_SLOTS = 32;
 hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const FeatureTables &ft,
                            hipStream_t s);
 // Quality Score for the offsets layout with max_read_len <= 320 (qual_kernel.hip)
