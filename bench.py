@@ -397,21 +397,41 @@ def check_invariants(ctx, ffi, total: int, args, mixed: bool, emulated: bool) ->
     return ("ok: %d full-size invariants" % checked) if not bad else "FAILED: " + "; ".join(bad)
 
 
+def inflate_traffic(algo_bytes_per_launch: int):
+    """HBM bytes per launch of k_bgzf_inflate, scaled from the committed PMC summary of tools/bench_inflate.py (one launch over
+    1.5 GB of algorithmic bytes) to this run's launch size.  Raw and with the read side doubled: the doubling is the guide's
+    correction for wide streaming reads, which the decoder's dword / byte loads are not -- the truth lies between the two."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_inflate_traffic.json")))
+    try:
+        with open(files[-1]) as f:
+            doc = json.load(f)
+        k = next(v for name, v in doc["kernels"].items() if "k_bgzf_inflate" in name)
+        ref_algo = 404_000_000 + 1_095_000_000   # the workload line of that file: 404 MB of blocks -> 1095 MB
+        scale = algo_bytes_per_launch / ref_algo
+        return {"traffic": round((k["fetch_raw"] + k["write_raw"]) * scale), "traffic_read_side_doubled": round(k["hbm_bytes_corrected"] * scale),
+                "traffic_source": os.path.relpath(files[-1], ROOT) + " scaled by the launch's algorithmic bytes",
+                "traffic_measured_in_this_run": False}
+    except Exception as e:  # noqa: BLE001
+        return {"traffic": None, "traffic_source": f"unavailable: {e}"}
+
+
 def pmc_traffic(n: int, args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/*_traffic.json, made by tools/collect_traffic.py from separate --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same command).  Only valid for the workload it was collected on."""
     import glob
-    if n != 100_000_000 or args.read_len != 150 or args.workload != "fixed":
+    mixed = args.workload == "mixed"
+    if n != 100_000_000 or (not mixed and args.read_len != 150) or (mixed and args.mixed_max_len != 300):
         return None, "no PMC summary for this workload"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_mixed_traffic.json" if mixed else "r[0-9][0-9]_traffic.json")))
     if not files:
         return None, "profiles/*_traffic.json absent"
     try:
         with open(files[-1]) as f:
             doc = json.load(f)
         for name, v in doc["kernels"].items():
-            if "k_qual_perm" in name or "k_qual_win" in name:
+            if "k_qual_perm" in name or "k_qual_win" in name or "k_qual_ragged" in name:
                 return v["hbm_bytes_corrected"], os.path.relpath(files[-1], ROOT)
     except Exception as e:  # noqa: BLE001
         return None, f"unreadable: {e}"
@@ -683,7 +703,8 @@ def leg_file(lib, host, ffi, args):
             if inf and inf["launches"] and inf["total_ms"] > 0:
                 gbs = inf["algo_bytes"] / inf["total_ms"] / 1e6
                 out["ingest_roofline"] = {"bound": "hbm", "kernel": "k_bgzf_inflate", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                          **inflate_traffic(inf["algo_bytes"] // inf["launches"]),
                                           "avg_launch_ms": round(inf["total_ms"] / inf["launches"], 3),
                                           "algo_bytes_per_launch": inf["algo_bytes"] // inf["launches"],
                                           "note": "algorithmic bytes = compressed bytes read + inflated bytes written; the kernel is "

@@ -32,9 +32,10 @@ def per_kernel(path, counter):
 
 def main():
     fetch_csv, write_csv, stats_csv, out = sys.argv[1:5]
+    workload = sys.argv[5] if len(sys.argv) > 5 else "python bench.py (default: 100 M x 150 bp records per GPU, all default facets, N=1)"
     fetch = per_kernel(fetch_csv, "FETCH_SIZE")
     write = per_kernel(write_csv, "WRITE_SIZE")
-    doc = {"workload": "python bench.py (default: 100 M x 150 bp records per GPU, all default facets, N=1)",
+    doc = {"workload": workload,
            "units": "bytes per dispatch (mean over dispatches)",
            "correction": "read side = 2 x FETCH_SIZE x 1024 (gfx950, MI355X_MICROARCH.md section HBM); write side = WRITE_SIZE x 1024",
            "kernels": {}}
