@@ -708,7 +708,9 @@ def leg_file(lib, host, ffi, args):
                                           "avg_launch_ms": round(inf["total_ms"] / inf["launches"], 3),
                                           "algo_bytes_per_launch": inf["algo_bytes"] // inf["launches"],
                                           "note": "algorithmic bytes = compressed bytes read + inflated bytes written; the kernel is "
-                                                  "bound by instruction latency (one decoder wave per BGZF block), not by HBM"}
+                                                  "bound by instruction issue (persistent decoder waves, one BGZF block at a time "
+                                                  "each; the scalar and vector ports of a CU are saturated by 20 of them), not by "
+                                                  "HBM; launches of the first chunks of a scan are smaller (32, 64, ... MiB)"}
             # ---- the same scan with the file dropped from the page cache first (storage -> pinned memory -> GPU), and what
             # the storage under the file delivers to plain parallel pread()s
             if drop_from_page_cache(bam):
@@ -725,8 +727,9 @@ def leg_file(lib, host, ffi, args):
             if args.file_big_records > n:
                 big = os.path.join(tmp, "big.bam")
                 try:
-                    # (the writer is zlib on the host cores: keep its share of the run to about two minutes)
-                    nb = int(min(args.file_big_records, max(n, n / max(out["bam_write_s"], 1e-3) * 120.0)))
+                    # (the writer is zlib on the host cores, ~1.2 M records/s on the 16 cores these boxes grant: keep its share of
+                    # the run to about a minute and a half)
+                    nb = int(min(args.file_big_records, max(n, n / max(out["bam_write_s"], 1e-3) * 90.0)))
                     bcfg = host.synth_config(nb, read_len=args.read_len, ref_len=CHR1, n_refs=2)
                     t0 = time.perf_counter()
                     assert lib.ngsq_synth_write_bam(C.byref(bcfg), big.encode(), nb, args.file_level, 0) == 0, lib.ngsq_bam_last_error()

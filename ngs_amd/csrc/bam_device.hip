@@ -51,6 +51,36 @@ __device__ __forceinline__ bool record_valid(const uint8_t *r /* at block_size *
     return l_read_name != 0 && need <= bs;
 }
 
+// bam_reader.h aux_has_cg_tag, on the device (only the rare lane whose CIGAR is the long-CIGAR placeholder walks its tags)
+__device__ bool aux_has_cg_tag(const uint8_t *p, const uint8_t *end) {
+    while (end - p >= 4) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        p += 3;
+        uint64_t n = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') n = 1;
+        else if (ty == 's' || ty == 'S') n = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') n = 4;
+        else if (ty == 'Z' || ty == 'H') {
+            while (p < end && *p) p++;
+            if (p >= end) return false;
+            n = 1;
+        } else if (ty == 'B') {
+            if (end - p < 5) return false;
+            const uint8_t sub = p[0];
+            const uint32_t cnt = (uint32_t)p[1] | (uint32_t)p[2] << 8 | (uint32_t)p[3] << 16 | (uint32_t)p[4] << 24;
+            const uint32_t w = sub == 'c' || sub == 'C' ? 1 : sub == 's' || sub == 'S' ? 2 : sub == 'i' || sub == 'I' || sub == 'f' ? 4 : 0;
+            if (!w) return false;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') return true;
+            n = 5 + (uint64_t)cnt * w;
+        } else {
+            return false;
+        }
+        if ((uint64_t)(end - p) < n) return false;
+        p += n;
+    }
+    return false;
+}
+
 constexpr uint32_t SUB_NONE = 0xFFFFFFFFu;
 #ifndef NGSQ_PARSE_THREADS
 #define NGSQ_PARSE_THREADS 256
@@ -294,7 +324,11 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
         }
         if (n_ops == 2 && l) { // the long-CIGAR placeholder <l_seq>S<span>N (specification 4.2.2): refused by name, as the host reader does
             const uint32_t op0 = ld32(raw + o + 32 + l_read_name), op1 = ld32(raw + o + 36 + l_read_name);
-            if (op0 == (l << 4 | 4u) && (op1 & 15u) == 3u) atomicMin(&stats[5], (unsigned long long)i);
+            if (op0 == (l << 4 | 4u) && (op1 & 15u) == 3u) {
+                const uint32_t bs = ld32(raw + o - 4); // block_size: the record ends at o + bs
+                const uint64_t need = 32ull + l_read_name + 8ull + ((uint64_t)l + 1) / 2 + l;
+                if (need <= bs && aux_has_cg_tag(raw + o + need, raw + o + bs)) atomicMin(&stats[5], (unsigned long long)i);
+            }
         }
         if (i == 0) stats[3] = (unsigned long long)a.x << 32 | a.y;
         if (i == n - 1) stats[4] = (unsigned long long)a.x << 32 | a.y;

@@ -303,7 +303,8 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
         // a record in 16 bits, so such a record is refused by name instead of being scanned with the placeholder ([N10])
         if (n_ops == 2 && l > 0) {
             const uint8_t *cg = r + 32 + l_read_name;
-            if (rd32(cg) == (l << 4 | 4u) && (rd32(cg + 4) & 15u) == 3u)
+            if (rd32(cg) == (l << 4 | 4u) && (rd32(cg + 4) & 15u) == 3u &&
+                ngsq::aux_has_cg_tag(r + need, r + block_size)) // (the placeholder alone could be an odd but real alignment)
                 return bfail(NGSQ_ERR_UNSUPPORTED, "%s: record %llu: a CIGAR of more than 65535 operations (CG tag, SAM specification 4.2.2) is not supported",
                              b->path.c_str(), (unsigned long long)(b->n_read + recs.size()));
         }

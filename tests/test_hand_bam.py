@@ -134,3 +134,31 @@ def test_cli_on_hand_assembled_bytes(gpu_lib, oracle_mod, tmp_path):
         r = subprocess.run([ngs, "-q", "qc", BAM, "GRCh38_no_alt_AnalysisSet", "-o", str(out)] + extra, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         json_equal(json.load(open(out / "hand_spec.bam.results.json")), want)
+
+
+def _placeholder_without_tag(tmp_path):
+    """<l_seq>S<n>N as a record's real CIGAR, no CG tag: odd, but an alignment like any other."""
+    from tests import bamio
+    from tests.util import batch_from_records
+    recs = [dict(flag=0, mapq=30, ref_id=0, pos=100 + 10 * k, mate_ref_id=-1, tlen=0, cigar="30S35N" if k == 3 else "30M",
+                 seq="ACGTAC" * 5, qual=[25] * 30) for k in range(8)]
+    hb = batch_from_records(recs)
+    p = str(tmp_path / "ph.bam")
+    bamio.write_bam(p, hb, ["chr1"], [100000])
+    return p
+
+
+def test_the_placeholder_alone_is_an_alignment(lib, tmp_path):
+    _, batches, n = read_all(lib, _placeholder_without_tag(tmp_path), 100)
+    assert n == 8 and [int(x) for x in batches[0].cols["n_cigar"]] == [1, 1, 1, 2, 1, 1, 1, 1]
+
+
+@pytest.mark.gpu
+def test_the_placeholder_alone_is_an_alignment_on_the_device(gpu_lib, tmp_path):
+    from tests.test_device_ingest_gpu import read_all_device, same_batches
+    p = _placeholder_without_tag(tmp_path)
+    with host.QcContext([100000], lib=gpu_lib) as ctx:
+        got, n = read_all_device(gpu_lib, ctx, p, 100)
+        _, want, _ = read_all(gpu_lib, p, 100)
+        assert n == 8
+        same_batches(got, want)
