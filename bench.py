@@ -840,6 +840,11 @@ def leg_file_sharded(lib, host, ffi, args, world, comm_kind):
         assert lib.ngsq_synth_write_bam(C.byref(pcfg), bam.encode(), probe_n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
         rate = probe_n / max(time.perf_counter() - t0, 1e-6)
         n = int(min(world * args.file_records, max(world * 5_000_000, rate * args.file_write_budget)))
+        try:    # and no more than a third of the free space under the temporary directory (~100 bytes per record)
+            import shutil
+            n = int(min(n, max(world * 1_000_000, shutil.disk_usage(tmp).free / 3 / 105)))
+        except OSError:
+            pass
         out["records"] = n
         out["records_wanted"] = world * args.file_records
         fcfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)

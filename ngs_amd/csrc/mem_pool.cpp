@@ -29,10 +29,14 @@ struct Pool {
     std::vector<Block> blocks;
     std::map<const void *, Block> pinned_live; // pinned blocks handed out, by base address
     size_t cached[2] = {0, 0}; // device | pinned
-    size_t limit;
+    size_t limit[2]; // device | pinned
     Pool() {
+        // what one ingest pipeline at its largest chunk size (1 GiB) gives back: two raw buffers + two device buffers for the
+        // compressed bytes + a batch's columns ~ 3.5 GiB of device memory, two pinned buffers = 1 GiB (the cache used
+        // to hold on to 12 GiB of each).  NGSQ_POOL_MB sets both.
         const char *e = getenv("NGSQ_POOL_MB");
-        limit = (size_t)(e ? strtoull(e, nullptr, 10) : 12288ull) << 20;
+        limit[0] = (size_t)(e ? strtoull(e, nullptr, 10) : 4096ull) << 20;
+        limit[1] = (size_t)(e ? strtoull(e, nullptr, 10) : 1536ull) << 20;
     }
     // smallest cached block of that kind that holds `bytes` without wasting more than it holds
     bool take(int device, size_t bytes, Block *out) {
@@ -51,7 +55,7 @@ struct Pool {
     }
     bool put(const Block &b) {
         std::lock_guard<std::mutex> g(mu);
-        if (b.bytes < POOL_MIN || cached[b.device < 0] + b.bytes > limit) return false;
+        if (b.bytes < POOL_MIN || cached[b.device < 0] + b.bytes > limit[b.device < 0]) return false;
         blocks.push_back(b);
         cached[b.device < 0] += b.bytes;
         return true;
