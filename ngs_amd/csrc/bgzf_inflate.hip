@@ -7,13 +7,13 @@
 // One WAVEFRONT per BGZF block (blocks are independent gzip members of <= 64 KiB).  A wave running
 // alone on its SIMD issues one instruction every ~5 cycles, so the design minimises instructions
 // per symbol and puts all 64 lanes to work on the one bit stream:
-//  * SYMBOL WINDOW.  Lane j looks up the Huffman code that WOULD start at bit j of the next 64
-//    bits (two LDS gathers: literal/length and distance table, every lane at once).  The real
-//    symbol boundaries are then a chain 0 -> L[0] -> L[0]+L[L[0]] ... followed with one
-//    v_readlane + add per symbol on the scalar unit; the lanes on the chain write their literals
-//    to the output ring in one store.  A length code ends the chain: its extra bits, the distance
-//    code and its extra bits are already sitting in the lanes at those bit offsets.
-//  * the bit stream lives in SGPRs (four window dwords + four prefetched by scalar loads).
+//  * SYMBOL WINDOW.  Lane j looks up the Huffman codes that WOULD start at bits j and j + 64 of the
+//    next 128 bits (LDS gathers: literal/length table, then the distance table with the stream bits
+//    behind the length code and its extra bits, every lane at once).  The real symbol boundaries are
+//    then a chain 0 -> L[0] -> L[0]+L[L[0]] ... followed with one v_readlane + add per symbol on
+//    the scalar unit, literals and whole matches alike; the symbols on the chain go into a queue and
+//    leave it 64 bytes of output at a time.
+//  * the compressed stream is staged through a small LDS ring; the only decoder state is the bit position.
 //  * Huffman tables are built by the 64 lanes (ballot-ranked canonical sort, parallel fill).
 //  * LZ77 matches are copied by the lanes, 64 bytes per step.  The last 8 KiB of output live in an
 //    LDS ring; finished 2 KiB pieces leave it as coalesced dword stores, and a match that reaches
@@ -81,6 +81,8 @@ constexpr uint32_t PIECE = RING / 4;  // bytes that leave the ring together
 //                          base distance = 1 + (m << extra bits)  (codes 0, 1: m = 0, 1; code c >= 2: m = 2 + (c & 1))
 // The code-length code of a dynamic header uses the literal format (symbol in the byte field).
 constexpr uint32_t LK_LIT = 0, LK_EOB = 1, LK_ESC = 2, LK_INVALID = 3;
+// LK_ESC in the literal/length table: [11:3] first entry of the prefix's second-level table in Lds::sub, [2:0] its index bits
+constexpr uint32_t SUB_CAP = 340;
 constexpr uint32_t DK_BASE = 0, DK_ESC = 1, DK_INVALID = 2;
 __device__ __forceinline__ constexpr uint32_t lit_entry(uint32_t byte, uint32_t kind, uint32_t bits) {
     return kind << 12 | byte << 4 | bits;
@@ -109,34 +111,42 @@ __constant__ uint8_t c_len_extra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2
                                         3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// Decoded symbols wait in a queue until 64 bytes of output can be produced at once: a 64-bit window holds ~4.6
-// symbols = ~17 bytes of output on BAM data, and emitting them window by window ran the 64-lane emit at a quarter of
-// its width (a third of all instructions of the kernel).  Entry: [15:0] output offset of the symbol's first byte
-// (ISIZE <= 65536), [16] literal, [31:17] the literal byte or distance - 1.
+// Decoded symbols wait (one per lane, in a register) until 64 bytes of output can be produced at once: emitting them window by
+// window ran the 64-lane emit at a quarter of its width.  Entry: [15:0] output offset of the symbol's first byte
+// (ISIZE <= 65536), [16] literal, [31:17] the literal byte or distance - 1.  QCAP = symbols per batch = lanes.
 constexpr uint32_t QCAP = 64;
+constexpr uint32_t WH = 2;                       // bit positions per lane and window: lane j looks at bits j, j + 64, ...
+constexpr uint32_t STOP = 0x80u;                 // a lane's "step" when the chain has to stop at it (bit 7)
+// A batch's windows start at most this many bits behind the bit position: the stream ring holds 4096 bits from the start of
+// the chunk the bit position is in (2047 at worst), a window and its second phase read 64 WH + 20 + 32 bits from their start.
+constexpr uint32_t REL_LIMIT = 4096u - 2047u - 64u * WH - 20u - 32u - 64u;
 __device__ __forceinline__ uint32_t q_lit(uint32_t at, uint32_t byte) { return at | 0x10000u | byte << 17; }
 __device__ __forceinline__ uint32_t q_match(uint32_t at, uint32_t dist) { return at | (dist - 1u) << 17; }
 
 struct Lds {
+    // two 256-byte chunks of the compressed stream (chunk c in slot c & 1); [128..130] repeat [0..2].  First member: its
+    // dwords are read in pairs at computed addresses, and from LDS address 0 the pair's place goes into the instruction.
+    uint32_t in_ring[128 + 3];
     uint8_t ring[RING];
     uint16_t lit_tab[1u << LB];
     uint16_t dist_tab[1u << DB]; // also the code-length-code table while a dynamic header is read
-    uint32_t in_ring[128]; // two 256-byte chunks of the compressed stream (chunk c in slot c & 1)
     uint32_t cnt[2][16];   // codes per length: [0] literal/length, [1] distance (or code-length code)
-    uint16_t start[2][16]; // first index in syms of each length
-    uint16_t fcode[2][16]; // first canonical code of each length
-    uint16_t syms0[288];   // literal/length symbols in canonical order
-    uint16_t syms1[32];    // distance (or code-length) symbols in canonical order
+    uint16_t start1[16];   // distance / code-length alphabet: first index in syms1 of each length,
+    uint16_t fcode1[16];   //   first canonical code of each length,
+    uint16_t syms1[32];    //   symbols in canonical order (a code longer than the table is looked up there)
+    // literal/length codes longer than LB bits: second-level tables, one per LB-bit prefix that has such codes, indexed by
+    // the following bits (as many as the prefix's longest code needs).  A complete code over 286 symbols of at most 15 bits
+    // needs at most 308 entries behind a 10-bit first level (zlib's `enough 286 10 15` = 1332 for both levels).
+    uint16_t sub[SUB_CAP];
     union {
         uint8_t lens[320]; // code lengths while a block's tables are built
         struct {
             uint8_t mark[64]; // emit: the queued symbol that starts at each byte of a 64-byte output chunk
-            uint32_t q[QCAP]; // decoded symbols not yet written out (a circular queue, drained before the tables change)
+            uint32_t q[QCAP]; // a batch's symbol starts: bit offsets from the bit position
         } e;
     };
-    __device__ __forceinline__ uint16_t *syms(uint32_t which) { return which ? syms1 : syms0; }
-    __device__ __forceinline__ const uint16_t *syms(uint32_t which) const { return which ? syms1 : syms0; }
 };
+static_assert(sizeof(Lds) <= 6400, "five 1280-byte LDS granules per decoder: 25 decoders per CU");
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // The serial core of the decoder, seven scalar instructions per symbol: starting at bit s, mark the
@@ -206,7 +216,8 @@ struct InStream {
         chunk = b >> 8;
         ring[(chunk & 1u) * 64u + lane] = src[chunk * 64u + lane];
         ring[((chunk + 1u) & 1u) * 64u + lane] = src[(chunk + 1u) * 64u + lane];
-        pre = src[(chunk + 2u) * 64u + lane];
+        if (lane < 3) ring[128 + lane] = src[(chunk + (chunk & 1u)) * 64u + lane]; // dwords 0..2 again, behind dword 127:
+        pre = src[(chunk + 2u) * 64u + lane];                                       // reads of consecutive dwords never wrap
     }
     // bring the ring up to the bit position (call before reading; at most one chunk per call in the
     // symbol loops, which consume less than 256 bytes between calls)
@@ -214,13 +225,20 @@ struct InStream {
         while ((bitpos >> 11) != chunk) {
             chunk += 1;
             ring[((chunk + 1u) & 1u) * 64u + (threadIdx.x & 63u)] = pre;
+            if ((chunk & 1u) && (threadIdx.x & 63u) < 3) ring[128 + (threadIdx.x & 63u)] = pre;
             pre = src[(chunk + 2u) * 64u + (threadIdx.x & 63u)];
         }
     }
-    // 32 bits starting `lane` bits ahead of the bit position (lane < 64), per lane
-    __device__ __forceinline__ uint32_t lane_bits32(uint32_t lane) const {
-        const uint32_t t = bitpos + lane, dw = t >> 5;
-        return __builtin_amdgcn_alignbit(ring[(dw + 1u) & 127u], ring[dw & 127u], t & 31u);
+    // 32 bits starting p bits ahead of the bit position, per lane (p + 32 bits stay inside the two chunks: p < 2000)
+    __device__ __forceinline__ uint32_t lane_bits32(uint32_t p) const {
+        const uint32_t t = bitpos + p, dw = (t >> 5) & 127u;
+        return __builtin_amdgcn_alignbit(ring[dw + 1u], ring[dw], t & 31u);
+    }
+    // the same for p and p + 64: one address, one shift
+    __device__ __forceinline__ void lane_bits32x2(uint32_t p, uint32_t &a, uint32_t &b) const {
+        const uint32_t t = bitpos + p, dw = (t >> 5) & 127u;
+        a = __builtin_amdgcn_alignbit(ring[dw + 1u], ring[dw], t & 31u);
+        b = __builtin_amdgcn_alignbit(ring[dw + 3u], ring[dw + 2u], t & 31u);
     }
     // the next 32 bits, uniform (one LDS round trip: the serial header code uses HeadBits instead)
     __device__ __forceinline__ uint32_t bits32() const { return uni(lane_bits32(0)); }
@@ -259,16 +277,14 @@ struct HeadBits {
 };
 
 // ---- canonical Huffman tables ----------------------------------------------------------------
-// lens[0..n) -> primary table of TB bits + (cnt, syms) for codes longer than TB.  which: 0 = lit/len, 1 = dist/cl.
-// kind_of: 0 literal/length alphabet, 1 distance alphabet, 2 code-length alphabet.
-// Returns false for an over-subscribed set.
-__device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t which, uint32_t TB, uint16_t *tab,
-                            uint32_t alphabet, uint32_t lane) {
-    if (lane < 16) L.cnt[which][lane] = 0;
+// Distance and code-length alphabets: lens[0..n) -> primary table of TB bits + (cnt, syms1) for codes longer than TB.
+// alphabet: 1 distance, 2 code-length.  Returns false for an over-subscribed set.
+__device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t TB, uint16_t *tab, uint32_t alphabet, uint32_t lane) {
+    if (lane < 16) L.cnt[1][lane] = 0;
     for (uint32_t i = lane; i < (1u << TB); i += 64)
         tab[i] = (uint16_t)(alphabet == 1 ? dist_special(DK_INVALID, 0) : lit_entry(0, LK_INVALID, 0));
     __syncthreads();
-    for (uint32_t i = lane; i < n; i += 64) atomicAdd(&L.cnt[which][lens[i]], 1u);
+    for (uint32_t i = lane; i < n; i += 64) atomicAdd(&L.cnt[1][lens[i]], 1u);
     __syncthreads();
     // offsets and first codes (uniform, registers)
     uint32_t off[16], code = 0, index = 0;
@@ -276,47 +292,36 @@ __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t wh
     bool ok = true;
 #pragma unroll
     for (uint32_t l = 1; l < 16; l++) {
-        const uint32_t c = uni(L.cnt[which][l]);
+        const uint32_t c = uni(L.cnt[1][l]);
         left = (left << 1) - (int32_t)c;
         if (left < 0) ok = false;
         code <<= 1;
         off[l] = index;
         if (lane == 0) {
-            L.start[which][l] = (uint16_t)index;
-            L.fcode[which][l] = (uint16_t)code;
+            L.start1[l] = (uint16_t)index;
+            L.fcode1[l] = (uint16_t)code;
         }
         code += c;
         index += c;
     }
     if (!ok) return false;
-    // canonical order: by length, then by symbol.  Rank inside a 64-symbol chunk by ballot.
-    for (uint32_t b = 0; b < n; b += 64) {
-        const uint32_t s = b + lane;
+    // canonical order: by length, then by symbol.  Rank by ballot (n <= 32: one round).
+    {
+        const uint32_t s = lane;
         const uint32_t l = s < n ? lens[s] : 0u;
 #pragma unroll
         for (uint32_t k = 1; k < 16; k++) {
             const uint64_t m = __ballot(l == k);
-            if (l == k) L.syms(which)[off[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
-            off[k] += __popcll(m);
+            if (l == k) L.syms1[off[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
         }
     }
     __syncthreads();
     // fill: every code of length <= TB owns 2^(TB-len) slots; longer codes mark their prefix slot
     for (uint32_t i = lane; i < index; i += 64) {
-        const uint32_t s = L.syms(which)[i], l = lens[s];
-        const uint32_t c = L.fcode[which][l] + (i - L.start[which][l]);
+        const uint32_t s = L.syms1[i], l = lens[s];
+        const uint32_t c = L.fcode1[l] + (i - L.start1[l]);
         const uint32_t rev = __brev(c) >> (32 - l);
-        uint32_t e;
-        if (alphabet == 0) {
-            if (s < 256) e = lit_entry(s, LK_LIT, l);
-            else if (s == 256) e = lit_entry(0, LK_EOB, l);
-            else if (s < 286) e = len_entry(c_len_base[s - 257], c_len_extra[s - 257], l);
-            else e = lit_entry(0, LK_INVALID, l);
-        } else if (alphabet == 1) {
-            e = s < 30 ? dist_entry(s, l) : dist_special(DK_INVALID, l);
-        } else {
-            e = lit_entry(s, LK_LIT, l);
-        }
+        const uint32_t e = alphabet == 1 ? (s < 30 ? dist_entry(s, l) : dist_special(DK_INVALID, l)) : lit_entry(s, LK_LIT, l);
         if (l <= TB) {
             for (uint32_t k = rev; k < (1u << TB); k += 1u << l) tab[k] = (uint16_t)e;
         } else {
@@ -327,35 +332,131 @@ __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t wh
     return true;
 }
 
-// Decode one symbol whose code is longer than TB bits.  x = the stream bits at the symbol.  For each
+__device__ __forceinline__ uint32_t litlen_entry(uint32_t s, uint32_t l) {
+    return s < 256 ? lit_entry(s, LK_LIT, l) : s == 256 ? lit_entry(0, LK_EOB, l) : s < 286 ? len_entry(c_len_base[s - 257], c_len_extra[s - 257], l) : lit_entry(0, LK_INVALID, l);
+}
+// Literal/length alphabet: lens[0..n), n <= 288 -> Lds::lit_tab (LB bits) + Lds::sub.  Every symbol is one lane's (five rounds
+// of 64): its canonical code is the first code of its length + its rank among the symbols of that length (ballots), so no
+// sorted symbol list is written.  Codes of at most LB bits fill their slots of the first level; a longer one notes its
+// length in the slot of its first LB bits (pass A), the slots so marked get a second-level table sized by their longest
+// code (pass B: 16 slots per lane, a prefix sum over the lanes), and the long codes fill those (pass C).
+// Returns false for an over-subscribed set, or (an incomplete set: zlib and miniz reject every such set with more than
+// one code) when the second-level tables do not fit.
+__device__ __noinline__ bool build_litlen_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t lane) {
+    constexpr uint32_t INV2 = lit_entry(0, LK_INVALID, 0) * 0x10001u;
+    constexpr uint32_t MARKED = 7; // kind of a first-level slot while the lengths of its long codes are collected ([4:0]: bit l - LB - 1)
+    uint32_t *const tab32 = reinterpret_cast<uint32_t *>(L.lit_tab);
+    uint32_t *const sub32 = reinterpret_cast<uint32_t *>(L.sub);
+    if (lane < 16) L.cnt[0][lane] = 0;
+    for (uint32_t i = lane; i < (1u << LB) / 2; i += 64) tab32[i] = INV2;
+    for (uint32_t i = lane; i < SUB_CAP / 2; i += 64) sub32[i] = INV2;
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += 64) atomicAdd(&L.cnt[0][lens[i]], 1u);
+    __syncthreads();
+    uint32_t first[16], code = 0; // first canonical code of each length + the codes of that length given out so far
+    int32_t left = 1;
+    bool ok = true;
+#pragma unroll
+    for (uint32_t l = 1; l < 16; l++) {
+        const uint32_t c = uni(L.cnt[0][l]);
+        left = (left << 1) - (int32_t)c;
+        if (left < 0) ok = false;
+        code <<= 1;
+        first[l] = code;
+        code += c;
+    }
+    if (!ok) return false;
+    // pass A
+    uint32_t mine[5]; // per round: the symbol's code, bit-reversed (as it comes in the stream) | length << 16
+#pragma unroll
+    for (uint32_t b = 0; b < 5; b++) {
+        const uint32_t s = b * 64 + lane;
+        const uint32_t l = s < n ? lens[s] : 0u;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < 16; k++) {
+            const uint64_t m = __ballot(l == k);
+            if (l == k) c = first[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            first[k] += (uint32_t)__popcll(m);
+        }
+        const uint32_t rev = l ? __brev(c) >> (32 - l) : 0u;
+        mine[b] = rev | l << 16;
+        if (l && l <= LB) {
+            const uint32_t e = litlen_entry(s, l);
+            for (uint32_t k = rev; k < (1u << LB); k += 1u << l) L.lit_tab[k] = (uint16_t)e;
+        } else if (l > LB) {
+            const uint32_t slot = rev & ((1u << LB) - 1u);
+            atomicOr(&tab32[slot >> 1], (MARKED << 12 | 1u << (l - LB - 1u)) << (16u * (slot & 1u))); // (on top of LK_INVALID)
+        }
+    }
+    __syncthreads();
+    // pass B  (loops kept rolled: the table is built once per DEFLATE block, and the registers are the window loop's)
+    {
+        uint32_t need = 0;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t e = L.lit_tab[lane * 16 + k];
+            if ((e & 0xF000u) == (MARKED << 12)) need += 1u << (32 - __clz((int)(e & 31u)));
+        }
+        const uint32_t incl = wave_inclusive_sum(need);
+        if ((uint32_t)__builtin_amdgcn_readlane(incl, 63) > SUB_CAP) return false;
+        uint32_t at = incl - need;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t e = L.lit_tab[lane * 16 + k];
+            if ((e & 0xF000u) == (MARKED << 12)) {
+                const uint32_t bits = 32 - __clz((int)(e & 31u));
+                L.lit_tab[lane * 16 + k] = (uint16_t)(LK_ESC << 12 | at << 3 | bits);
+                at += 1u << bits;
+            }
+        }
+    }
+    __syncthreads();
+    // pass C
+#pragma unroll
+    for (uint32_t b = 0; b < 5; b++) {
+        const uint32_t rev = mine[b] & 0xFFFFu, l = mine[b] >> 16;
+        if (l > LB) {
+            const uint32_t pe = L.lit_tab[rev & ((1u << LB) - 1u)];
+            const uint32_t at = (pe >> 3) & 511u, bits = pe & 7u;
+            const uint32_t e = litlen_entry(b * 64 + lane, l);
+            for (uint32_t k = rev >> LB; k < (1u << bits); k += 1u << (l - LB)) L.sub[at + k] = (uint16_t)e;
+        }
+    }
+    __syncthreads();
+    return true;
+}
+// the table entry of the literal/length code at the head of the stream bits x (per lane)
+__device__ __forceinline__ uint32_t litlen_lookup(const Lds &L, uint32_t x) {
+    const uint32_t E = L.lit_tab[x & ((1u << LB) - 1u)];
+    uint32_t E2 = L.sub[min(((E >> 3) & 511u) + ((x >> LB) & ((1u << (E & 7u)) - 1u)), SUB_CAP - 1u)]; // (any, for another kind of E)
+    asm volatile("" : "+v"(E2)); // (no branch around the second read: see the window loop)
+    return (E & 0xF000u) == (LK_ESC << 12) ? E2 : E;
+}
+
+// Decode one distance symbol whose code is longer than DB bits.  x = the stream bits at the symbol.  For each
 // length l the first l bits, read as a number MSB first, are a code of that length iff they fall into
 // [fcode[l], fcode[l] + cnt[l]) (canonical Huffman codes).  Returns the symbol or 0xFFFF; *bits = l.
-__device__ uint32_t slow_symbol(const Lds &L, uint32_t which, uint32_t TB, uint32_t x, uint32_t *bits) {
+__device__ uint32_t slow_symbol(const Lds &L, uint32_t x, uint32_t *bits) {
     const uint32_t rev = __brev(x);
-    for (uint32_t l = TB + 1; l < 16; l++) {
+    for (uint32_t l = DB + 1; l < 16; l++) {
         const uint32_t code = rev >> (32 - l);
-        const uint32_t f = uni(L.fcode[which][l]), c = uni(L.cnt[which][l]);
+        const uint32_t f = uni(L.fcode1[l]), c = uni(L.cnt[1][l]);
         if (code - f < c) {
             *bits = l;
-            return uni(L.syms(which)[uni(L.start[which][l]) + (code - f)]);
+            return uni(L.syms1[uni(L.start1[l]) + (code - f)]);
         }
     }
     *bits = 15;
     return 0xFFFFu;
 }
 
-// full entry of a symbol whose primary entry says "long code"
+// full entry of a distance symbol whose primary entry says "long code"
 // (out of line: rare, and bulky enough to slow the window loop down when inlined into it)
-__device__ __noinline__ uint32_t resolve_long(const Lds &L, uint32_t alphabet, uint32_t x) {
+__device__ __noinline__ uint32_t resolve_long_dist(const Lds &L, uint32_t x) {
     uint32_t bits;
-    const uint32_t s = slow_symbol(L, alphabet, alphabet == 0 ? LB : DB, x, &bits);
-    if (s == 0xFFFFu) return alphabet == 0 ? lit_entry(0, LK_INVALID, 15) : dist_special(DK_INVALID, 15);
-    if (alphabet == 0) {
-        if (s < 256) return lit_entry(s, LK_LIT, bits);
-        if (s == 256) return lit_entry(0, LK_EOB, bits);
-        if (s < 286) return len_entry(c_len_base[s - 257], c_len_extra[s - 257], bits);
-        return lit_entry(0, LK_INVALID, bits);
-    }
+    const uint32_t s = slow_symbol(L, x, &bits);
+    if (s == 0xFFFFu) return dist_special(DK_INVALID, 15);
     return s < 30 ? dist_entry(s, bits) : dist_special(DK_INVALID, bits);
 }
 
@@ -450,14 +551,16 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
     };
 
     PROF_DECL;
-    // ---- the symbol queue and the emit
-    // [0, pos) has been written (ring / HBM); the queued symbols cover [pos, dpos) without gaps, in order
-    uint32_t dpos = 0, qhead = 0, qn = 0;
+    // ---- the decoded symbols and the emit
+    // [0, pos) has been written (ring / HBM); the symbols in `qe` (lanes [0, nq), in stream order) cover [pos, dpos) without
+    // gaps.  Entry: q_lit / q_match above.
+    uint32_t dpos = 0, nq = 0;
+    uint32_t qe = 0;
     // Write the next n <= 64 bytes: every output byte is produced by one lane, no loop over the symbols (a serial copy
     // per match cost ~35 scalar instructions each, and the scalar unit -- one per CU -- is what bounds this kernel):
-    //   (1) the symbol that owns each byte: the queued symbols mark the byte they start at, a max-scan spreads the marks
-    //       (byte 0 may belong to the queue's first symbol, begun in an earlier chunk);
-    //   (2) the owner's literal byte or distance is read from the queue; a match byte's source is T - distance;
+    //   (1) the symbol that owns each byte: the symbols mark the byte they start at, a max-scan spreads the marks
+    //       (byte 0 may belong to a symbol begun in an earlier chunk: the last one that starts at or before it);
+    //   (2) the owner's literal byte or distance comes from the owner's lane; a match byte's source is T - distance;
     //   (3) a source inside this chunk is a pointer to another lane: pointer jumping (p = p[p], at most six
     //       rounds, none for the usual match that reaches behind the chunk) until every pointer ends at a byte
     //       whose value is known -- a literal, a byte already in the ring, or one that has left the ring and is
@@ -468,10 +571,8 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
     // chunk start and PIECE + 64 <= RING.
     auto emit_chunk = [&](uint32_t n) {
         const uint32_t base = pos;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // queue entries are read by other lanes than wrote them
-        const uint32_t qe = L.e.q[(qhead + lane) & (QCAP - 1u)];
         const uint32_t st = qe & 0xFFFFu;
-        const bool queued = lane < qn;
+        const bool queued = lane < nq;
         // (the marks are read by OTHER lanes than wrote them: the wavefront-scope fence makes the compiler reload
         // instead of forwarding this lane's own zero; LDS operations of one wave execute in order, nothing else is
         // needed.  A `volatile` pointer did that too, but it lost the LDS address space: flat_store_byte /
@@ -479,12 +580,13 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
         uint8_t *const mark = L.e.mark;
         mark[lane] = 0;
         if (queued && st - base < 64u) mark[st - base] = (uint8_t)(lane + 1u);
+        const uint32_t before = (uint32_t)__popcll(__ballot(queued && st <= base)); // (sorted by offset: an index)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t own = mark[lane];
-        if (lane == 0 && own == 0) own = 1u;
+        if (lane == 0 && own == 0) own = before;
         own = wave_inclusive_max(own);
-        const uint32_t oe = L.e.q[(qhead + own - 1u) & (QCAP - 1u)];
+        const uint32_t oe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((own - 1u) << 2), (int)qe);
         const bool active = lane < n;
         const bool lit = (oe & 0x10000u) != 0;
         const uint32_t T = base + lane, src = T - (oe >> 17) - 1u;
@@ -508,19 +610,22 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
         if (active) L.ring[T & RMASK] = (uint8_t)val;
         pos += n;
         while (pos - flushed >= PIECE) flush_piece(PIECE);
-        // symbols that are written out completely leave the queue: all that start in front of the new position, but
-        // the last of them if it reaches beyond it (a symbol ends where the next one starts)
-        const uint32_t k = (uint32_t)__popcll(__ballot(queued && st < pos));
-        const uint32_t nxt = k < qn ? (uint32_t)__builtin_amdgcn_readlane((int)st, (int)k) : dpos;
-        const uint32_t drop = k - (nxt > pos ? 1u : 0u);
-        qhead = (qhead + drop) & (QCAP - 1u);
-        qn -= drop;
         PROF_COUNT(2, 1);
     };
-    // whole 64-byte chunks while there are any; all = everything decoded so far (before the tables or the ring change hands)
+    // whole 64-byte chunks while there are any; all = everything decoded so far (before a stored block writes the ring, at
+    // the end).  What is not written out completely moves to the first lanes: the symbols from the one that holds byte
+    // `pos` on -- fewer than 64 bytes, so fewer than 64 symbols.
     auto drain = [&](bool all) {
+        if (dpos - pos < 64u && !(all && dpos != pos)) return;
         while (dpos - pos >= 64u) emit_chunk(64u);
         if (all && dpos != pos) emit_chunk(dpos - pos);
+        if (dpos == pos) {
+            nq = 0;
+        } else {
+            const uint32_t k0 = (uint32_t)__popcll(__ballot(lane < nq && (qe & 0xFFFFu) <= pos)) - 1u;
+            qe = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + k0) << 2), (int)qe);
+            nq -= k0;
+        }
     };
 
     bool last = false;
@@ -542,6 +647,7 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                 err = INF_BAD_STORED_LEN;
                 break;
             }
+            drain(true); // the bytes go straight into the ring: behind everything decoded so far
             if (pos + len > isize) {
                 err = INF_OUTPUT_OVERRUN;
                 break;
@@ -587,7 +693,7 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                 if (lane == 0) L.lens[c_cl_order[i]] = (uint8_t)v;
             }
             __syncthreads();
-            if (!build_table(L, L.lens, 19, 1, 7, L.dist_tab, 2, lane)) {
+            if (!build_table(L, L.lens, 19, 7, L.dist_tab, 2, lane)) {
                 err = INF_BAD_CODE_LENGTHS;
                 break;
             }
@@ -645,109 +751,153 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                 break;
             }
         }
-        if (!build_table(L, L.lens, hlit, 0, LB, L.lit_tab, 0, lane) ||
-            !build_table(L, L.lens + hlit, hdist, 1, DB, L.dist_tab, 1, lane)) {
+        if (!build_litlen_table(L, L.lens, hlit, lane) || !build_table(L, L.lens + hlit, hdist, DB, L.dist_tab, 1, lane)) {
             err = INF_BAD_CODE_LENGTHS;
             break;
         }
         PROF(1); // block header + tables
-        // ---- the symbol windows
+        // ---- the symbols of the block, in batches of up to 64
+        // A window of 128 bits holds ~12 symbols, and decoding them where they were found -- at one lane in ten -- made the
+        // decode, the prefix sum of the output lengths and the append a third of all instructions.  So it takes two phases:
+        //   (1) per WINDOW, all the lanes need is how far each symbol reaches: lane j looks up the codes that WOULD start
+        //       j and j + 64 bits from here (literal/length table, then the distance table with the stream bits behind
+        //       the length code and its extra bits) and adds up their bits; the real symbol starts are then the chain
+        //       0 -> step[0] -> ... (one v_readlane + add per symbol on the scalar unit, literals and whole matches alike),
+        //       and the lanes on the chain append their bit offset to a list;
+        //   (2) per BATCH (the list is full, or the stream ring ends, or a symbol stops the chain), lane i decodes the i-th
+        //       symbol of the list completely -- every lane a real symbol -- one prefix sum gives the output offsets, and
+        //       the entries join the symbols left over from the last batch in `qe`.
         bool end_of_block = false;
         while (!end_of_block && err == INF_OK) {
-            PROF(6); // tail of the previous window (loop)
-            drain(false); // (also makes room in the queue: fewer than 64 bytes pending = fewer than 64 symbols)
-            PROF(5); // emit
-            // Lane j decodes what would start j bits from here: a literal, or a whole match -- length code,
-            // its extra bits, and (from the lane at that bit offset) the distance code and its extra bits.
+            PROF(5);
             br.sync();
-            const uint32_t x = br.lane_bits32(lane);
-            uint32_t E = L.lit_tab[x & ((1u << LB) - 1u)];
-            const uint32_t nb = e_bits(E), lex = e_len_extra(E);
-            const uint32_t len = e_byte(E) + 3u + ((x >> nb) & ((1u << lex) - 1u));
-            const uint32_t s2 = lane + nb + lex; // bit offset of the distance code
-            const uint32_t xd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s2 << 2), (int)x);
-            const uint32_t D = L.dist_tab[xd & ((1u << DB) - 1u)];
-            const uint32_t db = e_bits(D), dex = d_extra(D);
-            const uint32_t dist = d_base(D) + ((xd >> db) & ((1u << dex) - 1u));
-            bool is_lit = e_is_lit(E);
-            const bool is_match = e_is_len(E) && s2 < 64 && d_kind(D) == DK_BASE;
-            // bits to the next symbol, or a stop mark: end of block, long codes, a distance code beyond lane 63
-            uint32_t step = is_lit ? nb : is_match ? nb + lex + db + dex : 0x80u;
-            PROF(2); // window bits + gathers
-            PROF_COUNT(0, 1);
-            // the chain of real symbol starts: readlane + add per symbol
-            uint64_t syms = 0;
-            uint32_t s = 0;
-            for (;;) {
-                chain_literals(step, s, syms);
-                if (s >= 64) break;
-                // a literal with a long code is patched into its lane and the chain goes on
-                uint32_t e = __builtin_amdgcn_readlane(E, s);
-                if (e_is_len(e) || e_kind(e) != LK_ESC) break;
-                e = uni(resolve_long(L, 0, __builtin_amdgcn_readlane(x, s)));
-                PROF_COUNT(5, 1);
-                if (!e_is_lit(e)) break;
-                if (lane == s) {
-                    E = e;
-                    step = e_bits(e);
-                    is_lit = true;
+            uint32_t np = nq, rel = 0; // symbols listed (the first nq are the ones in qe), window bits behind the bit position
+            bool stopped = false;
+            while (np < QCAP && rel <= REL_LIMIT && !stopped) {
+                uint32_t step[WH], xw[WH];
+                static_assert(WH == 2, "the stream bits of a window are read for two positions per lane");
+                br.lane_bits32x2(rel + lane, xw[0], xw[1]);
+#pragma unroll
+                for (uint32_t h = 0; h < WH; h++) {
+                    const uint32_t E = litlen_lookup(L, xw[h]);
+                    const uint32_t nb = e_bits(E), lex = e_len_extra(E);
+                    // the distance code (if E is a length code); looked up by every lane, no branch: the scalar unit is the
+                    // busier one, and a branch around these few instructions costs it nine
+                    const uint32_t xd = br.lane_bits32(rel + 64u * h + lane + nb + lex);
+                    uint32_t D = L.dist_tab[xd & ((1u << DB) - 1u)];
+                    asm volatile("" : "+v"(D));
+                    // bits to the next symbol, or a stop mark: end of block, a distance with a long code, an invalid code
+                    const uint32_t st = (e_is_len(E) && d_kind(D) == DK_BASE) ? nb + lex + e_bits(D) + d_extra(D) : STOP;
+                    step[h] = e_is_lit(E) ? nb : st;
                 }
+                PROF(2); // window bits + gathers
+                PROF_COUNT(0, 1);
+                // the chain of real symbol starts: readlane + add per symbol, position after position
+                uint64_t syms[WH];
+                uint32_t s = 0; // bits of the window consumed
+#pragma unroll
+                for (uint32_t h = 0; h < WH; h++) {
+                    syms[h] = 0;
+                    if (stopped) continue;
+                    uint32_t sl = s - 64u * h; // (a step is at most 48 bits: the chain enters every 64-bit part of the window)
+                    chain_literals(step[h], sl, syms[h]);
+                    stopped = sl < 64;
+                    s = 64u * h + sl;
+                }
+                // the list takes QCAP - np more symbols: a window with more ends early, the next batch starts at the first
+                // symbol left out
+                uint32_t n_syms = 0;
+#pragma unroll
+                for (uint32_t h = 0; h < WH; h++) n_syms += (uint32_t)__popcll(syms[h]);
+                if (__builtin_expect(n_syms > QCAP - np, 0)) {
+                    uint32_t keep = QCAP - np;
+                    bool full = false;
+                    stopped = false;
+                    n_syms = keep;
+#pragma unroll
+                    for (uint32_t h = 0; h < WH; h++) {
+                        const uint32_t c = (uint32_t)__popcll(syms[h]);
+                        if (full) {
+                            syms[h] = 0;
+                        } else if (keep >= c) {
+                            keep -= c;
+                        } else {
+                            uint64_t m = syms[h];
+                            for (uint32_t k = keep; k; k--) m &= m - 1; // drop the symbols that fit
+                            const uint32_t cut = (uint32_t)__builtin_ctzll(m);
+                            syms[h] &= (1ull << cut) - 1ull;
+                            s = 64u * h + cut;
+                            full = true;
+                        }
+                    }
+                }
+                PROF(3); // chain
+                {
+                    const uint64_t lane_bit = 1ull << lane, below = lane_bit - 1ull;
+                    uint32_t slot = np;
+#pragma unroll
+                    for (uint32_t h = 0; h < WH; h++) {
+                        if (syms[h] & lane_bit) L.e.q[slot + (uint32_t)__popcll(syms[h] & below)] = rel + 64u * h + lane;
+                        slot += (uint32_t)__popcll(syms[h]);
+                    }
+                }
+                np += n_syms;
+                rel += s;
+                PROF(4); // list append
             }
-            // the queue takes QCAP - qn more symbols: a window with more (short codes, a nearly full queue) ends early, the
-            // next one starts at the first symbol left out
-            bool trimmed = false;
-            if (__builtin_expect((uint32_t)__popcll(syms) > QCAP - qn, 0)) {
-                uint64_t m = syms;
-                for (uint32_t k = QCAP - qn; k; k--) m &= m - 1; // drop the symbols that fit
-                s = (uint32_t)__builtin_ctzll(m);
-                syms &= (1ull << s) - 1ull;
-                trimmed = true;
+            // phase 2
+            if (np > nq) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // list entries are read by other lanes than wrote them
+                const bool fresh = lane >= nq && lane < np;
+                const uint32_t v = fresh ? L.e.q[lane] : 0u;
+                const uint32_t at_bit = v;
+                const uint32_t x = br.lane_bits32(at_bit);
+                const uint32_t E = litlen_lookup(L, x);
+                const uint32_t nb = e_bits(E), lex = e_len_extra(E);
+                const uint32_t len = e_byte(E) + 3u + ((x >> nb) & ((1u << lex) - 1u));
+                const uint32_t xd = br.lane_bits32(at_bit + nb + lex);
+                const uint32_t D = L.dist_tab[xd & ((1u << DB) - 1u)];
+                const uint32_t db = e_bits(D), dex = d_extra(D);
+                const uint32_t dist = d_base(D) + ((xd >> db) & ((1u << dex) - 1u));
+                const bool is_lit = e_is_lit(E);
+                // where each symbol writes: prefix sum of the output lengths
+                const uint32_t olen = !fresh ? 0u : is_lit ? 1u : len;
+                const uint32_t incl = wave_inclusive_sum(olen);
+                const uint32_t at = dpos + incl - olen;
+                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                PROF_COUNT(1, __popcll(__ballot(fresh && is_lit)));
+                // a corrupt stream stops here, before anything of this batch is written: a distance beyond the
+                // start of the output would read in front of the block's buffer, and output beyond ISIZE would be flushed
+                // past its end
+                if (__ballot(fresh && !is_lit && dist > at)) {
+                    err = INF_BAD_DISTANCE;
+                    break;
+                }
+                if (dpos + total > isize) {
+                    err = INF_OUTPUT_OVERRUN;
+                    break;
+                }
+                if (fresh) qe = is_lit ? q_lit(at, e_byte(E)) : q_match(at, dist);
+                nq = np;
+                dpos += total;
             }
-            PROF(3); // chain
-            // where each symbol on the chain writes: prefix sum of the output lengths
-            const bool on_chain = (syms >> lane) & 1ull;
-            const uint32_t olen = !on_chain ? 0u : is_lit ? 1u : len;
-            const uint32_t incl = wave_inclusive_sum(olen);
-            const uint32_t at = dpos + incl - olen;
-            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-            PROF_COUNT(1, __popcll(__ballot(on_chain && is_lit)));
-            // a corrupt stream stops here, before anything of this window is queued: a distance beyond the
-            // start of the output would read in front of the block's buffer, and output beyond ISIZE would be flushed
-            // past its end
-            if (__ballot(on_chain && !is_lit && dist > at)) {
-                err = INF_BAD_DISTANCE;
-                break;
-            }
-            if (dpos + total > isize) {
-                err = INF_OUTPUT_OVERRUN;
-                break;
-            }
-            if (on_chain) {
-                const uint32_t rank = (uint32_t)__popcll(syms & ((1ull << lane) - 1ull));
-                L.e.q[(qhead + qn + rank) & (QCAP - 1u)] = is_lit ? q_lit(at, e_byte(E)) : q_match(at, dist);
-            }
-            qn += (uint32_t)__popcll(syms);
-            dpos += total;
-            br.consume(s);
-            PROF(4); // queue
-            // A chain that stopped at a length code whose distance code lies beyond lane 63 just ends the
-            // window there: the next window starts at that length code and sees all of the match.
-            const bool resume = s > 0 && s < 64 && e_is_len(__builtin_amdgcn_readlane(E, s & 63u));
-            if (s < 64 && !resume && !trimmed) {
+            br.consume(rel);
+            PROF(6); // phase 2
+            drain(false);
+            if (stopped) {
                 // The chain stopped at a symbol the lanes could not finish: end of block, a long code (or a
-                // distance code with one), or an invalid code.  One symbol the plain way, through the queue like the others.
+                // distance code with one), or an invalid code.  One symbol the plain way, into the next free lane of qe
+                // (fewer than 64 bytes are waiting there: fewer than 64 symbols).
                 PROF_COUNT(6, 1);
-                drain(false);
                 br.sync();
                 const uint32_t x0 = br.bits32();
-                uint32_t e = uni((uint32_t)L.lit_tab[x0 & ((1u << LB) - 1u)]);
-                if (!e_is_len(e) && e_kind(e) == LK_ESC) e = uni(resolve_long(L, 0, x0));
+                const uint32_t e = uni(litlen_lookup(L, x0));
                 const uint32_t eb = e_bits(e);
                 if (e_is_lit(e)) {
                     if (dpos + 1 > isize) err = INF_OUTPUT_OVERRUN;
                     else {
-                        if (lane == 0) L.e.q[(qhead + qn) & (QCAP - 1u)] = q_lit(dpos, e_byte(e));
-                        qn += 1;
+                        if (lane == nq) qe = q_lit(dpos, e_byte(e));
+                        nq += 1;
                         dpos += 1;
                         br.consume(eb);
                     }
@@ -761,7 +911,7 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                     br.sync();
                     const uint32_t x1 = br.bits32();
                     uint32_t d = uni((uint32_t)L.dist_tab[x1 & ((1u << DB) - 1u)]);
-                    if (d_kind(d) == DK_ESC) d = uni(resolve_long(L, 1, x1));
+                    if (d_kind(d) == DK_ESC) d = uni(resolve_long_dist(L, x1));
                     const uint32_t b2 = e_bits(d), ex2 = d_extra(d);
                     const uint32_t dd0 = d_base(d) + ((x1 >> b2) & ((1u << ex2) - 1u));
                     br.consume(b2 + ex2);
@@ -769,8 +919,8 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                     else if (dd0 > dpos) err = INF_BAD_DISTANCE;
                     else if (dpos + l > isize) err = INF_OUTPUT_OVERRUN;
                     else {
-                        if (lane == 0) L.e.q[(qhead + qn) & (QCAP - 1u)] = q_match(dpos, dd0);
-                        qn += 1;
+                        if (lane == nq) qe = q_match(dpos, dd0);
+                        nq += 1;
                         dpos += l;
                     }
                 } else {
@@ -778,9 +928,8 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                 }
             }
         }
-        // the tables (and the code-length scratch the queue shares its memory with) are about to change
-        if (err == INF_OK) drain(true);
     }
+    if (err == INF_OK) drain(true);
     PROF(0);
     if (err == INF_OK && pos != isize) err = pos > isize ? INF_OUTPUT_OVERRUN : INF_SIZE_MISMATCH;
     if (err == INF_OK && br.consumed_bits() > bit_limit) err = INF_INPUT_OVERRUN;
@@ -800,12 +949,11 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
 // column kernels of the previous chunk (another stream) ran only when the inflate had finished.
 // A grid that is resident from the start leaves the dispatcher free, and the kernels of the other stream take the
 // wave slots and registers the decoders leave.  The counter also evens out the tail: no last partial round of blocks.
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
                                                      const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
                                                      uint32_t *__restrict__ next_block) {
-    extern __shared__ __align__(16) uint8_t s_raw[];
-    Lds &L = *reinterpret_cast<Lds *>(s_raw);
+    __shared__ Lds L; // (static: with a dynamic allocation every LDS address is computed with an add of the base, zero)
     const uint32_t lane = threadIdx.x;
     for (;;) {
         uint32_t bi = 0;
@@ -887,9 +1035,6 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
     static bool attr = false;
     static uint32_t resident = 0;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bgzf_inflate),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
-        if (e != hipSuccess) return e;
         int dev = 0, n_cu = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -902,7 +1047,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
     }
     hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < resident ? n_blocks : resident), dim3(64), sizeof(Lds), s, comp, blocks, n_blocks, out,
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < resident ? n_blocks : resident), dim3(64), 0, s, comp, blocks, n_blocks, out,
                        status, counter);
     if (check_crc) (void)launch_bgzf_crc(blocks, n_blocks, out, status, s);
 #ifdef NGSQ_INFLATE_PROFILE

@@ -12,7 +12,13 @@ for v in other tree other tree; do
   NGSQ_EXTRA_FLAGS="${FLAGS:-}" python -m ngs_amd.build > /tmp/build_$v.log 2>&1 || { tail -5 /tmp/build_$v.log; }
   rm -rf /tmp/ab_$v
   (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/ab_$v -o out --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_inflate.py --records $N --reps 2 > /tmp/ab_$v.log 2>&1)
-  echo "== $v: $(grep -h k_bgzf_inflate $(find /tmp/ab_$v -name '*kernel_stats.csv') | cut -d, -f2-4,6,7 | head -1)  $(grep -c matches /tmp/ab_$v.log)"
+  python3 - $v <<'PY'
+import csv, glob, sys
+for f in glob.glob('/tmp/ab_%s/**/*kernel_stats.csv' % sys.argv[1], recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'k_bgzf_inflate' in r['Name'] or 'k_bgzf_crc' in r['Name']:
+            print('== %s: %s calls %s avg %.3f ms min %.3f max %.3f' % (sys.argv[1], r['Name'].split('(')[0][-20:], r['Calls'], float(r['AverageNs'])/1e6, float(r['MinNs'])/1e6, float(r['MaxNs'])/1e6))
+PY
   grep -h "inflate-prof" /tmp/ab_$v.log | tail -9
 done
 cp /tmp/inflate_tree.hip ngs_amd/csrc/bgzf_inflate.hip; touch ngs_amd/csrc/bgzf_inflate.hip; python -m ngs_amd.build > /dev/null 2>&1
