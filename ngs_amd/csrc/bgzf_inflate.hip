@@ -73,37 +73,55 @@ constexpr uint32_t LB = 10, DB = 8; // bits of the primary lookup tables
 constexpr uint32_t RING = NGSQ_INFLATE_RING, RMASK = RING - 1;
 constexpr uint32_t PIECE = RING / 4;  // bytes that leave the ring together
 
-// Table entries are 16 bits (LDS per decoder is what limits the decoders per CU):
-//   literal/length table:  bit 15 = 0: [14:12] kind (LIT / EOB / ESC = code longer than the table / INVALID),
-//                                      [11:4] the literal byte, [3:0] code bits
-//                          bit 15 = 1: a length code: [14:12] extra bits (0..5), [11:4] base length - 3, [3:0] code bits
-//   distance table:        [11:10] kind (BASE / ESC / INVALID), [9:8] m, [7:4] extra bits (0..13), [3:0] code bits;
+// Table entries are 16 bits (LDS per decoder is what limits the decoders per CU).  The low seven bits of every entry are
+// what the symbol windows need -- how far the symbol reaches, or 64 = "the chain stops here" (bit 6) -- so that a window's
+// lanes get from two table reads to their step with an AND and an ADD each:
+//   literal/length table:  literal          [15] 0  [14:7] the byte         [6:0] code bits
+//                          length code      [15] 1  [14:7] base length - 3  [6:0] code bits + extra bits
+//                                           (the extra bits follow from the base: 0 below 11 and for 258, else log2(base - 3) - 2)
+//                          end of block, invalid code
+//                                           [15] 0  [14:11] code bits  [8:7] which (LK_EOB / LK_INVALID)  [6:0] 64
+//                          LK_ESC, first level only: a prefix of codes longer than LB bits
+//                                           [15] 0  [14:7] first entry of its second-level table in Lds::sub / 2
+//                                                   [6:5] 11  [4:2] index bits of that table
+//   distance table:        [14:13] kind (BASE / ESC / INVALID)  [12:11] m  [10:7] extra bits (0..13)
+//                          [6:0] code bits + extra bits, or 64;
 //                          base distance = 1 + (m << extra bits)  (codes 0, 1: m = 0, 1; code c >= 2: m = 2 + (c & 1))
 // The code-length code of a dynamic header uses the literal format (symbol in the byte field).
-constexpr uint32_t LK_LIT = 0, LK_EOB = 1, LK_ESC = 2, LK_INVALID = 3;
-// LK_ESC in the literal/length table: [11:3] first entry of the prefix's second-level table in Lds::sub, [2:0] its index bits
+constexpr uint32_t LK_LIT = 0, LK_EOB = 1, LK_INVALID = 2;
 constexpr uint32_t SUB_CAP = 340;
 constexpr uint32_t DK_BASE = 0, DK_ESC = 1, DK_INVALID = 2;
+constexpr uint32_t STOP = 0x40u; // bit 6 of a step
 __device__ __forceinline__ constexpr uint32_t lit_entry(uint32_t byte, uint32_t kind, uint32_t bits) {
-    return kind << 12 | byte << 4 | bits;
+    return kind == LK_LIT ? byte << 7 | bits : bits << 11 | kind << 7 | STOP;
 }
 __device__ __forceinline__ constexpr uint32_t len_entry(uint32_t base, uint32_t extra, uint32_t bits) {
-    return 0x8000u | extra << 12 | (base - 3u) << 4 | bits;
+    return 0x8000u | (base - 3u) << 7 | (bits + extra);
 }
+__device__ __forceinline__ constexpr uint32_t esc_entry(uint32_t first, uint32_t index_bits) { return (first >> 1) << 7 | 0x60u | index_bits << 2; }
 __device__ __forceinline__ constexpr uint32_t dist_entry(uint32_t code, uint32_t bits) {
-    return code < 2 ? (DK_BASE << 10 | code << 8 | bits) : (DK_BASE << 10 | (2u + (code & 1u)) << 8 | ((code >> 1) - 1u) << 4 | bits);
+    return code < 2 ? (DK_BASE << 13 | code << 11 | bits) : (DK_BASE << 13 | (2u + (code & 1u)) << 11 | ((code >> 1) - 1u) << 7 | (bits + (code >> 1) - 1u));
 }
-__device__ __forceinline__ constexpr uint32_t dist_special(uint32_t kind, uint32_t bits) { return kind << 10 | bits; }
+__device__ __forceinline__ constexpr uint32_t dist_special(uint32_t kind) { return kind << 13 | STOP; }
 // fields
-__device__ __forceinline__ uint32_t e_bits(uint32_t e) { return e & 15u; }
 __device__ __forceinline__ bool e_is_len(uint32_t e) { return (e & 0x8000u) != 0; }
-__device__ __forceinline__ uint32_t e_kind(uint32_t e) { return (e >> 12) & 7u; } // of a non-length entry
-__device__ __forceinline__ bool e_is_lit(uint32_t e) { return (e & 0xF000u) == 0; }
-__device__ __forceinline__ uint32_t e_byte(uint32_t e) { return (e >> 4) & 255u; }
-__device__ __forceinline__ uint32_t e_len_extra(uint32_t e) { return e_is_len(e) ? (e >> 12) & 7u : 0u; }
-__device__ __forceinline__ uint32_t d_kind(uint32_t d) { return (d >> 10) & 3u; }
-__device__ __forceinline__ uint32_t d_extra(uint32_t d) { return (d >> 4) & 15u; }
-__device__ __forceinline__ uint32_t d_base(uint32_t d) { return 1u + (((d >> 8) & 3u) << d_extra(d)); }
+__device__ __forceinline__ bool e_is_lit(uint32_t e) { return (e & (0x8000u | STOP)) == 0; }
+__device__ __forceinline__ bool e_is_esc(uint32_t e) { return (e & 0x8060u) == 0x60u; }
+__device__ __forceinline__ uint32_t e_stop_kind(uint32_t e) { return (e >> 7) & 3u; } // of an entry that is neither literal nor length
+__device__ __forceinline__ uint32_t e_step(uint32_t e) { return e & 127u; }
+__device__ __forceinline__ uint32_t e_byte(uint32_t e) { return (e >> 7) & 255u; }
+__device__ __forceinline__ uint32_t e_len_extra(uint32_t e) { // of a length entry
+    const uint32_t b3 = e_byte(e);
+    return b3 < 8u || b3 == 255u ? 0u : 29u - (uint32_t)__clz((int)b3);
+}
+// code bits of any final entry
+__device__ __forceinline__ uint32_t e_bits(uint32_t e) {
+    return e_is_len(e) ? e_step(e) - e_len_extra(e) : (e & STOP) ? (e >> 11) & 15u : e_step(e);
+}
+__device__ __forceinline__ uint32_t d_kind(uint32_t d) { return (d >> 13) & 3u; }
+__device__ __forceinline__ uint32_t d_step(uint32_t d) { return d & 127u; }
+__device__ __forceinline__ uint32_t d_extra(uint32_t d) { return (d >> 7) & 15u; }
+__device__ __forceinline__ uint32_t d_base(uint32_t d) { return 1u + (((d >> 11) & 3u) << d_extra(d)); }
 
 __constant__ uint16_t c_len_base[31] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27, 31,
                                         35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0,  0};
@@ -116,7 +134,6 @@ __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 // (ISIZE <= 65536), [16] literal, [31:17] the literal byte or distance - 1.  QCAP = symbols per batch = lanes.
 constexpr uint32_t QCAP = 64;
 constexpr uint32_t WH = 2;                       // bit positions per lane and window: lane j looks at bits j, j + 64, ...
-constexpr uint32_t STOP = 0x80u;                 // a lane's "step" when the chain has to stop at it (bit 7)
 // A batch's windows start at most this many bits behind the bit position: the stream ring holds 4096 bits from the start of
 // the chunk the bit position is in (2047 at worst), a window and its second phase read 64 WH + 20 + 32 bits from their start.
 constexpr uint32_t REL_LIMIT = 4096u - 2047u - 64u * WH - 20u - 32u - 64u;
@@ -151,13 +168,13 @@ static_assert(sizeof(Lds) <= 6400, "five 1280-byte LDS granules per decoder: 25 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // The serial core of the decoder, seven scalar instructions per symbol: starting at bit s, mark the
 // symbol start in `lits` (literals and whole matches alike) and step to the next one (step[s] bits further) until a lane says stop
-// (bit 7 of its step) or the window ends (s >= 64).  Hand-scheduled: the compiler's structurised
+// (bit 6 of its step) or the window ends (s >= 64).  Hand-scheduled: the compiler's structurised
 // control flow needs about twice as many instructions for this loop.
 __device__ __forceinline__ void chain_literals(uint32_t step, uint32_t &s, uint64_t &lits) {
     uint32_t st;
     asm volatile("1:\n\t"
                  "v_readlane_b32 %[st], %[step], %[s]\n\t"
-                 "s_bitcmp1_b32 %[st], 7\n\t"
+                 "s_bitcmp1_b32 %[st], 6\n\t"
                  "s_cbranch_scc1 2f\n\t"
                  "s_bitset1_b64 %[lits], %[s]\n\t"
                  "s_add_u32 %[s], %[s], %[st]\n\t"
@@ -282,7 +299,7 @@ struct HeadBits {
 __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t TB, uint16_t *tab, uint32_t alphabet, uint32_t lane) {
     if (lane < 16) L.cnt[1][lane] = 0;
     for (uint32_t i = lane; i < (1u << TB); i += 64)
-        tab[i] = (uint16_t)(alphabet == 1 ? dist_special(DK_INVALID, 0) : lit_entry(0, LK_INVALID, 0));
+        tab[i] = (uint16_t)(alphabet == 1 ? dist_special(DK_INVALID) : lit_entry(0, LK_INVALID, 0));
     __syncthreads();
     for (uint32_t i = lane; i < n; i += 64) atomicAdd(&L.cnt[1][lens[i]], 1u);
     __syncthreads();
@@ -321,11 +338,11 @@ __device__ bool build_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t TB
         const uint32_t s = L.syms1[i], l = lens[s];
         const uint32_t c = L.fcode1[l] + (i - L.start1[l]);
         const uint32_t rev = __brev(c) >> (32 - l);
-        const uint32_t e = alphabet == 1 ? (s < 30 ? dist_entry(s, l) : dist_special(DK_INVALID, l)) : lit_entry(s, LK_LIT, l);
+        const uint32_t e = alphabet == 1 ? (s < 30 ? dist_entry(s, l) : dist_special(DK_INVALID)) : lit_entry(s, LK_LIT, l);
         if (l <= TB) {
             for (uint32_t k = rev; k < (1u << TB); k += 1u << l) tab[k] = (uint16_t)e;
         } else {
-            tab[rev & ((1u << TB) - 1u)] = (uint16_t)(alphabet == 1 ? dist_special(DK_ESC, 0) : lit_entry(0, LK_ESC, 0));
+            tab[rev & ((1u << TB) - 1u)] = (uint16_t)(alphabet == 1 ? dist_special(DK_ESC) : lit_entry(0, LK_INVALID, 0)); // (code-length codes fit)
         }
     }
     __syncthreads();
@@ -344,7 +361,9 @@ __device__ __forceinline__ uint32_t litlen_entry(uint32_t s, uint32_t l) {
 // one code) when the second-level tables do not fit.
 __device__ __noinline__ bool build_litlen_table(Lds &L, const uint8_t *lens, uint32_t n, uint32_t lane) {
     constexpr uint32_t INV2 = lit_entry(0, LK_INVALID, 0) * 0x10001u;
-    constexpr uint32_t MARKED = 7; // kind of a first-level slot while the lengths of its long codes are collected ([4:0]: bit l - LB - 1)
+    // a first-level slot while the lengths of its long codes are collected: LK_INVALID | MARK, [4:0]: bit l - LB - 1
+    constexpr uint32_t MARK = 0x80u, MARKED_MASK = 0x81C0u, MARKED = 0x1C0u;
+    static_assert((lit_entry(0, LK_INVALID, 0) | MARK) == MARKED, "marking is an OR on top of the initial entry");
     uint32_t *const tab32 = reinterpret_cast<uint32_t *>(L.lit_tab);
     uint32_t *const sub32 = reinterpret_cast<uint32_t *>(L.sub);
     if (lane < 16) L.cnt[0][lane] = 0;
@@ -386,7 +405,7 @@ __device__ __noinline__ bool build_litlen_table(Lds &L, const uint8_t *lens, uin
             for (uint32_t k = rev; k < (1u << LB); k += 1u << l) L.lit_tab[k] = (uint16_t)e;
         } else if (l > LB) {
             const uint32_t slot = rev & ((1u << LB) - 1u);
-            atomicOr(&tab32[slot >> 1], (MARKED << 12 | 1u << (l - LB - 1u)) << (16u * (slot & 1u))); // (on top of LK_INVALID)
+            atomicOr(&tab32[slot >> 1], (MARK | 1u << (l - LB - 1u)) << (16u * (slot & 1u)));
         }
     }
     __syncthreads();
@@ -396,7 +415,7 @@ __device__ __noinline__ bool build_litlen_table(Lds &L, const uint8_t *lens, uin
 #pragma unroll 1
         for (uint32_t k = 0; k < 16; k++) {
             const uint32_t e = L.lit_tab[lane * 16 + k];
-            if ((e & 0xF000u) == (MARKED << 12)) need += 1u << (32 - __clz((int)(e & 31u)));
+            if ((e & MARKED_MASK) == MARKED) need += 1u << (32 - __clz((int)(e & 31u)));
         }
         const uint32_t incl = wave_inclusive_sum(need);
         if ((uint32_t)__builtin_amdgcn_readlane(incl, 63) > SUB_CAP) return false;
@@ -404,9 +423,9 @@ __device__ __noinline__ bool build_litlen_table(Lds &L, const uint8_t *lens, uin
 #pragma unroll 1
         for (uint32_t k = 0; k < 16; k++) {
             const uint32_t e = L.lit_tab[lane * 16 + k];
-            if ((e & 0xF000u) == (MARKED << 12)) {
+            if ((e & MARKED_MASK) == MARKED) {
                 const uint32_t bits = 32 - __clz((int)(e & 31u));
-                L.lit_tab[lane * 16 + k] = (uint16_t)(LK_ESC << 12 | at << 3 | bits);
+                L.lit_tab[lane * 16 + k] = (uint16_t)esc_entry(at, bits); // (every table has at least two entries: `at` is even)
                 at += 1u << bits;
             }
         }
@@ -418,7 +437,7 @@ __device__ __noinline__ bool build_litlen_table(Lds &L, const uint8_t *lens, uin
         const uint32_t rev = mine[b] & 0xFFFFu, l = mine[b] >> 16;
         if (l > LB) {
             const uint32_t pe = L.lit_tab[rev & ((1u << LB) - 1u)];
-            const uint32_t at = (pe >> 3) & 511u, bits = pe & 7u;
+            const uint32_t at = e_byte(pe) * 2u, bits = (pe >> 2) & 7u;
             const uint32_t e = litlen_entry(b * 64 + lane, l);
             for (uint32_t k = rev >> LB; k < (1u << bits); k += 1u << (l - LB)) L.sub[at + k] = (uint16_t)e;
         }
@@ -429,9 +448,10 @@ __device__ __noinline__ bool build_litlen_table(Lds &L, const uint8_t *lens, uin
 // the table entry of the literal/length code at the head of the stream bits x (per lane)
 __device__ __forceinline__ uint32_t litlen_lookup(const Lds &L, uint32_t x) {
     const uint32_t E = L.lit_tab[x & ((1u << LB) - 1u)];
-    uint32_t E2 = L.sub[min(((E >> 3) & 511u) + ((x >> LB) & ((1u << (E & 7u)) - 1u)), SUB_CAP - 1u)]; // (any, for another kind of E)
-    asm volatile("" : "+v"(E2)); // (no branch around the second read: see the window loop)
-    return (E & 0xF000u) == (LK_ESC << 12) ? E2 : E;
+    // (read by every lane, whatever its E: no branch around the second read, see the window loop)
+    uint32_t E2 = L.sub[min(e_byte(E) * 2u + ((x >> LB) & ((1u << ((E >> 2) & 7u)) - 1u)), SUB_CAP - 1u)];
+    asm volatile("" : "+v"(E2));
+    return e_is_esc(E) ? E2 : E;
 }
 
 // Decode one distance symbol whose code is longer than DB bits.  x = the stream bits at the symbol.  For each
@@ -456,8 +476,8 @@ __device__ uint32_t slow_symbol(const Lds &L, uint32_t x, uint32_t *bits) {
 __device__ __noinline__ uint32_t resolve_long_dist(const Lds &L, uint32_t x) {
     uint32_t bits;
     const uint32_t s = slow_symbol(L, x, &bits);
-    if (s == 0xFFFFu) return dist_special(DK_INVALID, 15);
-    return s < 30 ? dist_entry(s, bits) : dist_special(DK_INVALID, bits);
+    if (s == 0xFFFFu) return dist_special(DK_INVALID);
+    return s < 30 ? dist_entry(s, bits) : dist_special(DK_INVALID);
 }
 
 // ---- CRC32 (gzip): GF(2) helpers in the reflected representation -----------------------------
@@ -780,15 +800,13 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
 #pragma unroll
                 for (uint32_t h = 0; h < WH; h++) {
                     const uint32_t E = litlen_lookup(L, xw[h]);
-                    const uint32_t nb = e_bits(E), lex = e_len_extra(E);
                     // the distance code (if E is a length code); looked up by every lane, no branch: the scalar unit is the
                     // busier one, and a branch around these few instructions costs it nine
-                    const uint32_t xd = br.lane_bits32(rel + 64u * h + lane + nb + lex);
+                    const uint32_t xd = br.lane_bits32(rel + 64u * h + lane + e_step(E));
                     uint32_t D = L.dist_tab[xd & ((1u << DB) - 1u)];
                     asm volatile("" : "+v"(D));
-                    // bits to the next symbol, or a stop mark: end of block, a distance with a long code, an invalid code
-                    const uint32_t st = (e_is_len(E) && d_kind(D) == DK_BASE) ? nb + lex + e_bits(D) + d_extra(D) : STOP;
-                    step[h] = e_is_lit(E) ? nb : st;
+                    // bits to the next symbol, or a stop mark (bit 6: end of block, a distance with a long code, an invalid code)
+                    step[h] = e_step(E) + (e_is_len(E) ? d_step(D) : 0u);
                 }
                 PROF(2); // window bits + gathers
                 PROF_COUNT(0, 1);
@@ -853,11 +871,11 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                 const uint32_t at_bit = v;
                 const uint32_t x = br.lane_bits32(at_bit);
                 const uint32_t E = litlen_lookup(L, x);
-                const uint32_t nb = e_bits(E), lex = e_len_extra(E);
+                const uint32_t lex = e_len_extra(E), nb = e_step(E) - lex; // (of a length code; the literal's byte is all it needs)
                 const uint32_t len = e_byte(E) + 3u + ((x >> nb) & ((1u << lex) - 1u));
-                const uint32_t xd = br.lane_bits32(at_bit + nb + lex);
+                const uint32_t xd = br.lane_bits32(at_bit + e_step(E));
                 const uint32_t D = L.dist_tab[xd & ((1u << DB) - 1u)];
-                const uint32_t db = e_bits(D), dex = d_extra(D);
+                const uint32_t dex = d_extra(D), db = d_step(D) - dex;
                 const uint32_t dist = d_base(D) + ((xd >> db) & ((1u << dex) - 1u));
                 const bool is_lit = e_is_lit(E);
                 // where each symbol writes: prefix sum of the output lengths
@@ -901,7 +919,7 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                         dpos += 1;
                         br.consume(eb);
                     }
-                } else if (!e_is_len(e) && e_kind(e) == LK_EOB) {
+                } else if (!e_is_len(e) && e_stop_kind(e) == LK_EOB) {
                     br.consume(eb);
                     end_of_block = true;
                 } else if (e_is_len(e)) {
@@ -912,7 +930,7 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                     const uint32_t x1 = br.bits32();
                     uint32_t d = uni((uint32_t)L.dist_tab[x1 & ((1u << DB) - 1u)]);
                     if (d_kind(d) == DK_ESC) d = uni(resolve_long_dist(L, x1));
-                    const uint32_t b2 = e_bits(d), ex2 = d_extra(d);
+                    const uint32_t ex2 = d_extra(d), b2 = d_step(d) - ex2;
                     const uint32_t dd0 = d_base(d) + ((x1 >> b2) & ((1u << ex2) - 1u));
                     br.consume(b2 + ex2);
                     if (d_kind(d) != DK_BASE) err = INF_BAD_SYMBOL;
