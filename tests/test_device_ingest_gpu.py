@@ -69,6 +69,16 @@ def payloads():
     # long codes: a very skewed alphabet forces 15-bit Huffman codes
     w = np.array([2.0 ** -(i // 8) for i in range(256)])
     yield "longcodes", rng.choice(np.arange(256, dtype=np.uint8), 400_000, p=w / w.sum()).tobytes()
+    # short codes: two byte values (1-bit codes with Z_HUFFMAN_ONLY: 128 symbols in a 128-bit window, more than a
+    # batch of 64 takes), sixteen (4-bit codes); and both with a rare third value, which gets a long code
+    yield "two_values", rng.integers(0, 2, 150_000, dtype=np.uint8).tobytes()
+    yield "sixteen_values", rng.integers(0, 16, 150_000, dtype=np.uint8).tobytes()
+    rare = rng.integers(0, 2, 200_000, dtype=np.uint8)
+    rare[rng.integers(0, rare.size, 40)] = 200
+    yield "two_values_and_a_rare_one", rare.tobytes()
+    # every literal/length code length from 1 to 15 in use, and second-level tables of several sizes
+    w = np.array([2.0 ** -min(i // 2 + 1, 16) for i in range(256)])
+    yield "all_lengths", rng.choice(np.arange(256, dtype=np.uint8), 300_000, p=w / w.sum()).tobytes()
 
 
 @pytest.mark.parametrize("level,strategy", [(1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
