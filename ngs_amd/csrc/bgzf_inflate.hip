@@ -4,21 +4,25 @@
 // (flate2 1.0.24 / miniz_oxide 0.5.4) under `reader.records(&header)`, src/qc/command.rs:305 and
 // src/utils/formats/bam.rs:32-56.  Written from RFC 1951 and the SAM/BAM specification 4.1.
 //
-// One WAVEFRONT per BGZF block (blocks are independent gzip members of <= 64 KiB).  A wave running
-// alone on its SIMD issues one instruction every ~5 cycles, so the design minimises instructions
-// per symbol and puts all 64 lanes to work on the one bit stream:
-//  * SYMBOL WINDOW.  Lane j looks up the Huffman codes that WOULD start at bits j and j + 64 of the
-//    next 128 bits (LDS gathers: literal/length table, then the distance table with the stream bits
-//    behind the length code and its extra bits, every lane at once).  The real symbol boundaries are
-//    then a chain 0 -> L[0] -> L[0]+L[L[0]] ... followed with one v_readlane + add per symbol on
-//    the scalar unit, literals and whole matches alike; the symbols on the chain go into a queue and
-//    leave it 64 bytes of output at a time.
-//  * the compressed stream is staged through a small LDS ring; the only decoder state is the bit position.
-//  * Huffman tables are built by the 64 lanes (ballot-ranked canonical sort, parallel fill).
-//  * LZ77 matches are copied by the lanes, 64 bytes per step.  The last 8 KiB of output live in an
-//    LDS ring; finished 2 KiB pieces leave it as coalesced dword stores, and a match that reaches
+// One WAVEFRONT per BGZF block (blocks are independent gzip members of <= 64 KiB); a CU holds 24 of them and is bound by
+// the instructions it can issue (one scalar and one vector instruction per cycle), so the design minimises instructions
+// per symbol and puts all 64 lanes to work on the one bit stream, in two phases:
+//  * SYMBOL WINDOWS find where the symbols start.  Lane j looks up the Huffman codes that WOULD start at bits j and
+//    j + 64 of the next 128 bits (literal/length table, then the distance table with the stream bits behind the length
+//    code and its extra bits, every lane at once; the low bits of a table entry are the number of bits the symbol takes).
+//    The real symbol starts are the chain 0 -> step[0] -> step[0] + step[step[0]] ..., followed with one v_readlane +
+//    add per symbol on the scalar unit, literals and whole matches alike; the lanes on the chain append their bit offset
+//    to a list.
+//  * BATCHES of up to 64 listed symbols are decoded one per lane -- every lane a real symbol -- and one prefix sum of
+//    their output lengths gives the offsets.  The decoded symbols wait in a register, one per lane, and leave 64 bytes
+//    of output at a time: every output byte is produced by one lane (the owner of each byte by a max-scan, match
+//    sources inside the same 64 bytes by pointer jumping).
+//  * Huffman tables are built by the 64 lanes (ballot-ranked canonical codes, parallel fill); literal/length codes longer
+//    than the 10-bit first level have second-level tables, so no code is ever resolved serially.
+//  * The compressed stream is staged through a small LDS ring; the only reader state is the bit position.  The last 2 KiB
+//    of output live in an LDS ring; finished 512-byte pieces leave it as coalesced dword stores, and a match that reaches
 //    further back than the ring reads its source from HBM (the bytes this wave wrote earlier).
-//    16 KiB of LDS per wave: ten decoders per CU.
+//    6.4 KB of LDS and 80 registers per decoder: 24 decoders per CU.
 //  * CRC32 of the block (gzip trailer) is verified on request by a second, wide kernel
 //    (k_bgzf_crc: 64 slices per block, combined with GF(2) polynomial multiplication).
 #include <hip/hip_runtime.h>
@@ -166,24 +170,33 @@ struct Lds {
 static_assert(sizeof(Lds) <= 6400, "five 1280-byte LDS granules per decoder: 25 decoders per CU");
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-// The serial core of the decoder, seven scalar instructions per symbol: starting at bit s, mark the
-// symbol start in `lits` (literals and whole matches alike) and step to the next one (step[s] bits further) until a lane says stop
-// (bit 6 of its step) or the window ends (s >= 64).  Hand-scheduled: the compiler's structurised
-// control flow needs about twice as many instructions for this loop.
-__device__ __forceinline__ void chain_literals(uint32_t step, uint32_t &s, uint64_t &lits) {
-    uint32_t st;
+// The serial core of the decoder, FOUR instructions per symbol (three scalar, one v_readlane): starting at bit s < 64 of a
+// 64-bit part of the window, mark the symbol start in `lits` (literals and whole matches alike) and step to the next one
+// (step[s] bits further) until the part ends.  The position is kept biased by 2^32 - 64: v_readlane and s_bitset1_b64 take
+// its low six bits, and the add's carry says "past bit 63" -- no compare.  A lane whose symbol cannot be stepped over (end
+// of block, long distance code, invalid code) has bit 6 set in its step: that also carries, and the loop needs no test for
+// it either; the last step read tells afterwards which it was (then the mark and the step are taken back).  Returns true
+// if the chain stopped at such a symbol; s = its position, or (not stopped) the position in the NEXT part where the chain
+// goes on.  Hand-written: the compiler's structurised control flow needs about four times as many instructions.
+__device__ __forceinline__ bool chain_literals(uint32_t step, uint32_t &s, uint64_t &lits) {
+    uint32_t st, sb = s - 64u;
     asm volatile("1:\n\t"
-                 "v_readlane_b32 %[st], %[step], %[s]\n\t"
-                 "s_bitcmp1_b32 %[st], 6\n\t"
-                 "s_cbranch_scc1 2f\n\t"
-                 "s_bitset1_b64 %[lits], %[s]\n\t"
-                 "s_add_u32 %[s], %[s], %[st]\n\t"
-                 "s_cmp_lt_u32 %[s], 64\n\t"
-                 "s_cbranch_scc1 1b\n"
-                 "2:"
-                 : [s] "+s"(s), [lits] "+s"(lits), [st] "=&s"(st)
+                 "v_readlane_b32 %[st], %[step], %[sb]\n\t"
+                 "s_bitset1_b64 %[lits], %[sb]\n\t"
+                 "s_add_u32 %[sb], %[sb], %[st]\n\t"
+                 "s_cbranch_scc0 1b\n"
+                 : [sb] "+s"(sb), [lits] "+s"(lits), [st] "=&s"(st)
                  : [step] "v"(step)
                  : "scc");
+    const bool stopped = (st & STOP) != 0;
+    if (stopped) {
+        sb -= st; // (biased again: the stop symbol's position in this part)
+        lits &= ~(1ull << (sb & 63u));
+        s = sb & 63u;
+    } else {
+        s = sb;
+    }
+    return stopped;
 }
 // inclusive prefix sum over the 64 lanes: four row_shr steps inside the rows of 16, then the two
 // row broadcasts (DPP, no LDS)
@@ -818,15 +831,15 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                     syms[h] = 0;
                     if (stopped) continue;
                     uint32_t sl = s - 64u * h; // (a step is at most 48 bits: the chain enters every 64-bit part of the window)
-                    chain_literals(step[h], sl, syms[h]);
-                    stopped = sl < 64;
-                    s = 64u * h + sl;
+                    stopped = chain_literals(step[h], sl, syms[h]);
+                    s = 64u * h + (stopped ? sl : sl + 64u);
                 }
                 // the list takes QCAP - np more symbols: a window with more ends early, the next batch starts at the first
                 // symbol left out
                 uint32_t n_syms = 0;
 #pragma unroll
                 for (uint32_t h = 0; h < WH; h++) n_syms += (uint32_t)__popcll(syms[h]);
+                np = uni(np); // (short of scalar registers the compiler keeps it in a vector one, and the branch below would be a vector one)
                 if (__builtin_expect(n_syms > QCAP - np, 0)) {
                     uint32_t keep = QCAP - np;
                     bool full = false;
@@ -850,12 +863,12 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
                     }
                 }
                 PROF(3); // chain
-                {
-                    const uint64_t lane_bit = 1ull << lane, below = lane_bit - 1ull;
+                {   // (the chain's lanes straight from the scalar mask, their rank among them by v_mbcnt: no vector compare)
                     uint32_t slot = np;
 #pragma unroll
                     for (uint32_t h = 0; h < WH; h++) {
-                        if (syms[h] & lane_bit) L.e.q[slot + (uint32_t)__popcll(syms[h] & below)] = rel + 64u * h + lane;
+                        if (__builtin_amdgcn_inverse_ballot_w64(syms[h]))
+                            L.e.q[slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(syms[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)syms[h], 0u))] = rel + 64u * h + lane;
                         slot += (uint32_t)__popcll(syms[h]);
                     }
                 }
@@ -967,7 +980,12 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
 // column kernels of the previous chunk (another stream) ran only when the inflate had finished.
 // A grid that is resident from the start leaves the dispatcher free, and the kernels of the other stream take the
 // wave slots and registers the decoders leave.  The counter also evens out the tail: no last partial round of blocks.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
+// (registers: at most 80, for six decoders per SIMD -- left alone the compiler takes 92, mostly for scalars that no longer fit the
+// scalar file: five per SIMD, 20 per CU, 9 % slower)
+#ifndef NGSQ_INFLATE_WAVES
+#define NGSQ_INFLATE_WAVES 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NGSQ_INFLATE_WAVES, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
                                                      const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
                                                      uint32_t *__restrict__ next_block) {
