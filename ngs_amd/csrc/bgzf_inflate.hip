@@ -179,24 +179,24 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 // if the chain stopped at such a symbol; s = its position, or (not stopped) the position in the NEXT part where the chain
 // goes on.  Hand-written: the compiler's structurised control flow needs about four times as many instructions.
 __device__ __forceinline__ bool chain_literals(uint32_t step, uint32_t &s, uint64_t &lits) {
-    uint32_t st, sb = s - 64u;
+    uint32_t st, stopped, sb = s - 64u;
     asm volatile("1:\n\t"
                  "v_readlane_b32 %[st], %[step], %[sb]\n\t"
                  "s_bitset1_b64 %[lits], %[sb]\n\t"
                  "s_add_u32 %[sb], %[sb], %[st]\n\t"
-                 "s_cbranch_scc0 1b\n"
-                 : [sb] "+s"(sb), [lits] "+s"(lits), [st] "=&s"(st)
+                 "s_cbranch_scc0 1b\n\t"
+                 "s_bitcmp1_b32 %[st], 6\n\t"
+                 "s_cselect_b32 %[stopped], 1, 0\n\t"
+                 "s_cbranch_scc0 2f\n\t"
+                 "s_sub_u32 %[sb], %[sb], %[st]\n\t" // (biased again: the stop symbol's position in this part)
+                 "s_bitset0_b64 %[lits], %[sb]\n\t"
+                 "s_and_b32 %[sb], %[sb], 63\n"
+                 "2:"
+                 : [sb] "+s"(sb), [lits] "+s"(lits), [st] "=&s"(st), [stopped] "=&s"(stopped)
                  : [step] "v"(step)
                  : "scc");
-    const bool stopped = (st & STOP) != 0;
-    if (stopped) {
-        sb -= st; // (biased again: the stop symbol's position in this part)
-        lits &= ~(1ull << (sb & 63u));
-        s = sb & 63u;
-    } else {
-        s = sb;
-    }
-    return stopped;
+    s = sb;
+    return stopped != 0;
 }
 // inclusive prefix sum over the 64 lanes: four row_shr steps inside the rows of 16, then the two
 // row broadcasts (DPP, no LDS)
