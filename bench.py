@@ -708,9 +708,10 @@ def leg_file(lib, host, ffi, args):
                                           "avg_launch_ms": round(inf["total_ms"] / inf["launches"], 3),
                                           "algo_bytes_per_launch": inf["algo_bytes"] // inf["launches"],
                                           "note": "algorithmic bytes = compressed bytes read + inflated bytes written; the kernel is "
-                                                  "bound by instruction issue (persistent decoder waves, one BGZF block at a time "
-                                                  "each; the scalar and vector ports of a CU are saturated by 20 of them), not by "
-                                                  "HBM; launches of the first chunks of a scan are smaller (32, 64, ... MiB)"}
+                                                  "bound by instruction issue (24 persistent decoder waves per CU, one BGZF block at a "
+                                                  "time each: ~24 instructions per DEFLATE symbol keep the scalar and vector ports "
+                                                  "of a CU 60-70 % busy), not by HBM; launches of the first chunks of a scan are "
+                                                  "smaller (32, 64, ... MiB)"}
             # ---- the same scan with the file dropped from the page cache first (storage -> pinned memory -> GPU), and what
             # the storage under the file delivers to plain parallel pread()s
             if drop_from_page_cache(bam):
