@@ -728,9 +728,14 @@ def leg_file(lib, host, ffi, args):
             if args.file_big_records > n:
                 big = os.path.join(tmp, "big.bam")
                 try:
-                    # (the writer is zlib on the host cores, ~1.2 M records/s on the 16 cores these boxes grant: keep its share of
-                    # the run to about a minute and a half)
-                    nb = int(min(args.file_big_records, max(n, n / max(out["bam_write_s"], 1e-3) * 90.0)))
+                    # (the writer is zlib on the host cores, ~1.25 M records/s on the 16 cores these boxes grant: 200 M records take
+                    # it 160 s -- the longest single item of the default run; a slower writer or a small disk gets a smaller file)
+                    nb = int(min(args.file_big_records, max(n, n / max(out["bam_write_s"], 1e-3) * 175.0)))
+                    try:
+                        import shutil
+                        nb = int(min(nb, max(n, shutil.disk_usage(tmp).free / 3 / 105)))
+                    except OSError:
+                        pass
                     bcfg = host.synth_config(nb, read_len=args.read_len, ref_len=CHR1, n_refs=2)
                     t0 = time.perf_counter()
                     assert lib.ngsq_synth_write_bam(C.byref(bcfg), big.encode(), nb, args.file_level, 0) == 0, lib.ngsq_bam_last_error()

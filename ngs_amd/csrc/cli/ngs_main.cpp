@@ -31,6 +31,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/ngsq.h"
@@ -643,6 +644,9 @@ int main(int argc, char **argv) {
     // ---- the communicator of a --gpus run: the workers meet in the shared-memory segment the launcher named;
     // with one device per worker rank 0's RCCL unique id travels through it and the exchange runs over xGMI
     ngsq_comm *comm = nullptr;
+    std::thread rccl_init;          // RCCL's initialisation, beside the scan (below)
+    ngsq_comm *rccl_comm = nullptr; // its result ...
+    std::string rccl_error;         // ... or why there is none
     if (worker) {
         const int ndev = ngsq_device_count();
         if (ndev < 1) bail("no HIP device available; the ngs qc hot path has no CPU fallback");
@@ -674,14 +678,39 @@ int main(int argc, char **argv) {
                 if (a.rank == 0) logf(1, "%s; the exchange runs over shared memory instead", no_rccl.c_str());
                 comm = boot;
             } else {
-                if (ngsq_comm_create_rccl(a.rank, a.world, all.data(), a.device, &comm) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
-                if (ngsq_comm_barrier(boot) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
-                ngsq_comm_destroy(boot);
+                // ncclCommInitRank (bootstrap over sockets, topology search, channel set-up: the better part of a second on a
+                // node of eight GPUs, several times the scan of this worker's share of a file) runs on its own thread beside
+                // the scan: the scan asks the communicator for its rank and size only (the shared-memory one answers that),
+                // the first message is the boundary check behind it (comm_ready below).
+                comm = boot;
+                const int rank = a.rank, world = a.world, device = a.device;
+                rccl_init = std::thread([&rccl_comm, &rccl_error, all, rank, world, device]() {
+                    if (ngsq_comm_create_rccl(rank, world, all.data(), device, &rccl_comm) != NGSQ_OK) {
+                        rccl_error = ngsq_comm_last_error(nullptr);
+                        if (rccl_error.empty()) rccl_error = "RCCL's communicator could not be created";
+                        rccl_comm = nullptr;
+                    }
+                });
             }
         }
         cfg.device = a.device;
-        logf(2, "Worker %d of %d on device %d, exchange over %s.", a.rank, a.world, a.device, ngsq_comm_kind(comm));
+        logf(2, "Worker %d of %d on device %d, exchange over %s.", a.rank, a.world, a.device, rccl_init.joinable() ? "rccl" : ngsq_comm_kind(comm));
     }
+    // before the first message of a --gpus run: RCCL's communicator takes the place of the one the workers met in.  Every
+    // rank says whether it has one: a rank whose initialisation failed must not leave the others waiting inside RCCL.
+    auto comm_ready = [&]() {
+        if (!rccl_init.joinable()) return;
+        rccl_init.join();
+        ngsq_comm *boot = comm;
+        const uint8_t ok = rccl_comm != nullptr;
+        std::vector<uint8_t> oks((size_t)a.world);
+        if (ngsq_comm_allgather_host(boot, &ok, oks.data(), 1) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
+        for (int r = 0; r < a.world; r++)
+            if (!oks[(size_t)r]) bail(r == a.rank ? rccl_error : "RCCL's communicator could not be created on worker " + std::to_string(r));
+        comm = rccl_comm;
+        if (ngsq_comm_barrier(boot) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
+        ngsq_comm_destroy(boot);
+    };
     ngsq_ctx *ctx = nullptr;
     unsigned long long n_pass1 = 0;
     for (bool force_array = false;;) { // at most twice: again on the depth arrays when the records break the promised order
@@ -741,6 +770,7 @@ int main(int argc, char **argv) {
             }
             ngsq_bam_shard_info info;
             int again = 0;
+            comm_ready();
             const int vrc = ngsq_bam_shard_verify(bam, ctx, comm, &info, &again);
             if (!scan_error.empty()) bail(scan_error);
             if (vrc == NGSQ_ERR_UNSORTED) { // neighbouring shards out of coordinate order: same verdict on every worker
@@ -896,6 +926,7 @@ int main(int argc, char **argv) {
     {
         int rc = NGSQ_OK;
         std::string why;
+        comm_ready();
         if (shard_unsorted) {
             rc = NGSQ_ERR_UNSORTED;
             why = ngsq_comm_last_error(comm);
