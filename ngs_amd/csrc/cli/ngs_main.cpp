@@ -11,6 +11,7 @@
 // GPU, each ingesting its BGZF block range of the file on its own device, one ngsq_exchange
 // (include/ngsq_comm.h; RCCL over xGMI) before the teardown, rank 0 writes the JSON.
 // Not built (out of scope this round): the other subcommands.
+#include <poll.h>
 #include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
@@ -524,6 +525,14 @@ int main(int argc, char **argv) {
         ngsq_bam_close(bam);
         char shm[128];
         snprintf(shm, sizeof shm, "/ngsq-cli-%d-%lld", (int)getpid(), (long long)time(nullptr));
+        // A worker says "done" through this pipe when the document is on disk and nothing of it is left to do, then leaves;
+        // the command returns when all of them have said so.  What follows in a worker is the kernel unmapping its GiB of
+        // device and pinned memory (0.1-0.35 s, serialised among the workers of one device), which nobody needs to wait for
+        // (NGSQ_WAIT_WORKERS=1 waits, as does any failure).
+        int done_fd[2] = {-1, -1};
+        const char *ww = getenv("NGSQ_WAIT_WORKERS");
+        if (!(ww && atoi(ww)) && pipe(done_fd) == 0) setenv("NGSQ_DONE_FD", std::to_string(done_fd[1]).c_str(), 1);
+        else done_fd[0] = done_fd[1] = -1;
         std::vector<pid_t> pids;
         for (int r = 0; r < a.gpus; r++) {
             std::vector<char *> av(argv, argv + argc);
@@ -537,10 +546,25 @@ int main(int argc, char **argv) {
             pids.push_back(pid);
         }
         milestone("workers started");
+        if (done_fd[1] >= 0) close(done_fd[1]);
         int worst = 0;
+        size_t done = 0;
         for (size_t left = pids.size(); left;) {
+            if (done_fd[0] >= 0) {
+                struct pollfd pf = {done_fd[0], POLLIN, 0};
+                if (poll(&pf, 1, 2) > 0 && (pf.revents & POLLIN)) {
+                    char buf[64];
+                    const ssize_t n = read(done_fd[0], buf, sizeof buf);
+                    if (n > 0) done += (size_t)n;
+                }
+                if (done >= pids.size() && !worst) {
+                    milestone("every worker has reported");
+                    return 0;
+                }
+            }
             int status = 0;
-            const pid_t p = wait(&status);
+            const pid_t p = waitpid(-1, &status, done_fd[0] >= 0 ? WNOHANG : 0);
+            if (p == 0) continue;
             if (p < 0) break;
             left--;
             const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 1;
@@ -952,6 +976,11 @@ int main(int argc, char **argv) {
     // A worker process has nothing left to do once the document is on disk: by default it leaves its GiB of device and
     // pinned memory to the kernel's process teardown instead of unmapping them block by block and running the HIP
     // runtime's exit handlers (three workers on one device: 0.37 s of the command's 1.07; NGSQ_QUICK_EXIT=0 turns it off)
+    auto report_done = [&]() { // (the launcher's pipe: see there)
+        const char *fd = worker ? getenv("NGSQ_DONE_FD") : nullptr;
+        const char ok = 0;
+        if (fd && write(atoi(fd), &ok, 1) != 1) { /* the launcher then waits for the exit status instead */ }
+    };
     const char *qe = getenv("NGSQ_QUICK_EXIT");
     const bool quick_exit = qe ? atoi(qe) != 0 : worker;
     if (worker && a.rank != 0) { // every rank holds the whole-file result; rank 0 writes it
@@ -959,6 +988,7 @@ int main(int argc, char **argv) {
         ngsq_comm_barrier(comm);
         if (quick_exit) {
             fflush(nullptr);
+            report_done();
             _exit(0);
         }
         ngsq_destroy(ctx);
@@ -1007,6 +1037,7 @@ int main(int argc, char **argv) {
         // unmapping them block by block and running the HIP runtime's exit handlers (measurement: DESIGN.md section 7)
         if (comm) ngsq_comm_destroy(comm); // rank 0 unlinks the shared-memory segment
         fflush(nullptr);
+        report_done();
         _exit(0);
     }
     ngsq_destroy(ctx);
