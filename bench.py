@@ -79,6 +79,7 @@ def parse_args():
                     help="N = 1: a second, larger file scanned in process beside the --file-records one (0 = skip)")
     ap.add_argument("--file-level", type=int, default=6, help="zlib level of that BAM")
     ap.add_argument("--h2d-batch", type=int, default=4_000_000, help="records per host batch of the h2d_inclusive leg (0 = skip)")
+    ap.add_argument("--extra-facet-records", type=int, default=100_000_000, help="records of the Edits / Genomic Features leg")
     ap.add_argument("--extra-facet-legs", type=int, default=1,
                     help="1: also time the Edits and Genomic Features kernels on a 10 M-record slice (N = 1 only)")
     return ap.parse_args()
@@ -301,7 +302,7 @@ def main() -> int:
                 out["ingest_roofline"] = fe.pop("ingest_roofline", None) if isinstance(fe, dict) else None
                 out["file_end_to_end"] = fe
             if args.extra_facet_legs and not mixed and args.facets == 0x1F:
-                out["extra_facets"] = guarded(leg_extra_facets, lib, host, ffi, np)
+                out["extra_facets"] = guarded(leg_extra_facets, lib, host, ffi, np, args.extra_facet_records)
         elif world > 1 and args.file_records > 0 and not mixed and not args.emulate_shard:
             # the number the metric is named after, on N GPUs: ONE BAM file scanned by `ngs qc --gpus N` (the other ranks
             # of this launch have released their devices and are on their way out)
@@ -796,10 +797,9 @@ def synthetic_gene_model(np):
             np.asarray(stop, dtype=np.uint32))
 
 
-def leg_extra_facets(lib, host, ffi, np):
-    """Kernel times of the two optional facets on the first 10 M records of the workload (reference bases of chr1
+def leg_extra_facets(lib, host, ffi, np, n=100_000_000):
+    """Kernel times of the two optional facets on the first n records of the workload (reference bases of chr1
     and chr2 and a 400 k-interval gene model resident in HBM)."""
-    n = 10_000_000
     scfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2)
     out = {"records": n}
     ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=ffi.FACET_EDITS | ffi.FACET_FEATURES, max_read_len=150, gc_seed=GC_SEED,
