@@ -319,14 +319,15 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
 hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const FeatureTables &ft,
                            hipStream_t s) {
     if (!b.n) return hipSuccess;
-    // one round of blocks: as many as are resident at once (a grid of eight per CU at seven resident ran a second round with one
-    // block per CU -- twice the time of the first round alone).  NGSQ_FEATURES_BLOCKS_PER_CU: measurement aid.
+    // Blocks per CU (each takes a contiguous slice of the batch), measured on 100 M records (same box, ms): 5 -> 1.99, 6 -> 1.77,
+    // 7 (what is resident at once) -> 2.33, 8 -> 2.13 (a second round with one block per CU), 9 -> 2.02, 10 -> 1.91,
+    // 11 -> 1.78, 12 -> 1.73, 14 -> 1.85, 20 -> 1.78, 24 -> 1.76; the same order on 10 M.  Seven resident blocks are slower
+    // than six (28 waves per CU wait on each other's L2 probes); a grid of nearly two rounds evens out the slices that meet
+    // long gene lists.  NGSQ_FEATURES_BLOCKS_PER_CU: measurement aid.
     static int per_cu = 0;
     if (!per_cu) {
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k_features), 256, 0) != hipSuccess || occ < 1) occ = 4;
         const char *e = getenv("NGSQ_FEATURES_BLOCKS_PER_CU");
-        per_cu = e && atoi(e) > 0 ? atoi(e) : occ;
+        per_cu = e && atoi(e) > 0 ? atoi(e) : 12;
     }
     uint64_t g = (b.n + 256 * F_RPT - 1) / (256 * F_RPT);
     if (g > (uint64_t)li.n_cu * (uint64_t)per_cu) g = (uint64_t)li.n_cu * (uint64_t)per_cu;
