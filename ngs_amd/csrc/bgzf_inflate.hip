@@ -1091,15 +1091,13 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_inflate_prof), sizeof h);
-        static const char *names[8] = {"other", "header+tables", "window+gathers", "chain", "queue", "emit",
-                                       "window tail/piece flush", "final flush+crc"};
+        static const char *names[8] = {"other", "header+tables", "window: table reads", "window: chain", "window: list append", "emit",
+                                       "batch decode", "final flush"};
         unsigned long long tot = 0;
         for (int k = 0; k < 8; k++) tot += h[k];
         for (int k = 0; k < 8; k++)
             fprintf(stderr, "[inflate-prof] %-24s %6.2f %%\n", names[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
-        fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, matches %llu (bytes %llu; distance > 4 KiB %llu, > 16 KiB %llu), "
-                        "long codes %llu, symbols taken the plain way %llu\n",
-                h[8], h[9], h[10], h[11], h[12], h[15], h[13], h[14]);
+        fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, emits %llu, symbols taken the plain way %llu\n", h[8], h[9], h[10], h[14]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_prof), z, sizeof z);
     }
