@@ -137,7 +137,12 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # (NCCL_DEBUG is left alone: at WARN and above RCCL prints its version banner on stdout, in front of the JSON line)
+    # RCCL prints a version banner on stdout through C stdio -- buffered, so it comes out when a rank exits, behind the
+    # JSON line.  The line has stdout to itself: file descriptor 1 of every rank (and of what it starts) is stderr from
+    # here on, the line is written to a copy of the original descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     from ngs_amd import ffi, host, shard
@@ -307,7 +312,7 @@ def main() -> int:
             # the number the metric is named after, on N GPUs: ONE BAM file scanned by `ngs qc --gpus N` (the other ranks
             # of this launch have released their devices and are on their way out)
             out["file_end_to_end"] = guarded(leg_file_sharded, lib, host, ffi, args, world, comm_kind)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     return rc
 
 
