@@ -146,82 +146,122 @@ __device__ __forceinline__ bool walk(const uint8_t *raw, uint64_t n_bytes, uint6
 } // namespace
 
 // ---- 1. candidates ----------------------------------------------------------------------------
-// One wave per segment.  A window of up to 1 KiB is screened 64 offsets at a time (a complete, plausible record:
-// bytes inside a record read as a huge block_size look like "the record cut by the end of the buffer" -- never a
-// candidate; the one true cut record of a chunk is found by k_walk_one), then the offsets that passed (REC_CANDIDATES
-// per round) are walked at once, a lane each: the chain of a segment is ~240 dependent loads long, and walking the candidates
-// one after the other made this kernel four such chains long.
+// One wave per REC_GROUP segments.  Per segment a window of up to 1 KiB is screened 64 offsets at a time (a complete,
+// plausible record: bytes inside a record read as a huge block_size look like "the record cut by the end of the buffer" --
+// never a candidate; the one true cut record of a chunk is found by k_walk_one), then the offsets that passed
+// (REC_CANDIDATES per segment and round) are walked at once, a lane each.  The walk is what this kernel costs: a chain
+// of dependent loads as long as the segment holds records, by one or two lanes of the wave -- so the segments are short
+// (16 KiB: ~56 records of 150 bases; 64 KiB until round 3: ~226) and a wave walks the chains of four of them at once
+// instead of holding a quarter as many resident waves' worth of latency.
 __global__ __launch_bounds__(64) void k_rec_candidates(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint64_t first,
                                                        uint32_t n_seg, int32_t n_ref, RecCandidate *__restrict__ cand,
                                                        RecPieces *__restrict__ pieces) {
     NGSQ_FOREGROUND_WAVE();
-    // chains walked at once: each extra one costs (divergent loads), and the screening resumes right behind the last
-    // offset taken, so no candidate is skipped
-    constexpr uint32_t LIST = REC_CANDIDATES;
-    __shared__ uint64_t s_list[LIST];
-    __shared__ uint32_t s_rel[REC_PIECES * LIST], s_cnt[REC_PIECES * LIST];
-    const uint32_t seg = blockIdx.x, lane = threadIdx.x;
-    if (seg >= n_seg) return;
-    const uint64_t s0 = (uint64_t)seg * REC_SEGMENT, s1 = min(s0 + REC_SEGMENT, n_bytes);
-    RecCandidate *out = cand + (uint64_t)seg * REC_CANDIDATES;
-    uint32_t found = 0;
-    uint64_t pos = max(s0, first); // offsets before `first` (the BAM header) are never record starts
-    while (pos < s1 && found < REC_CANDIDATES) {
-        uint32_t list_n = 0;
-        for (int it = 0; it < 16 && pos < s1 && list_n < LIST; it++) {
-            const uint64_t o = pos + lane;
-            bool pass = false;
-            if (o < s1 && o + 36 <= n_bytes) {
-                uint4 a, b;
-                ld2x16(raw + o, a, b);
-                const uint32_t bs = a.x, l_read_name = a.w & 0xFFu, n_ops = b.x & 0xFFFFu, l = b.y;
-                const uint64_t need = 32ull + l_read_name + 4ull * n_ops + ((uint64_t)l + 1) / 2 + l;
-                const int32_t ref = (int32_t)a.y, p = (int32_t)a.z, mref = (int32_t)b.z, mpos = (int32_t)b.w;
-                pass = o + 4 + (uint64_t)bs <= n_bytes && bs >= 32 && l_read_name != 0 && need <= bs && ref >= -1 && ref < n_ref &&
-                       mref >= -1 && mref < n_ref && p >= -1 && mpos >= -1;
+    constexpr uint32_t G = REC_GROUP, LIST = REC_CANDIDATES;
+    static_assert(G * LIST <= 64, "a lane per chain");
+    __shared__ uint64_t s_list[G * LIST];
+    __shared__ uint32_t s_rel[REC_PIECES * G * LIST], s_cnt[REC_PIECES * G * LIST];
+    const uint32_t lane = threadIdx.x;
+    uint32_t found[G];
+    uint64_t pos[G], s0[G], s1[G];
+    bool live[G];
+#pragma unroll
+    for (uint32_t g = 0; g < G; g++) {
+        const uint64_t seg = (uint64_t)blockIdx.x * G + g;
+        live[g] = seg < n_seg;
+        s0[g] = seg * REC_SEGMENT;
+        s1[g] = min(s0[g] + REC_SEGMENT, n_bytes);
+        pos[g] = max(s0[g], first); // offsets before `first` (the BAM header) are never record starts
+        found[g] = 0;
+    }
+    for (;;) {
+        // screening: up to LIST offsets per segment that still wants candidates (each extra chain costs divergent loads, and
+        // the screening resumes right behind the last offset taken, so no candidate is skipped)
+        uint32_t list_n[G];
+        bool any = false, more = false;
+#pragma unroll
+        for (uint32_t g = 0; g < G; g++) {
+            list_n[g] = 0;
+            if (!live[g]) continue;
+            for (int it = 0; it < 16 && pos[g] < s1[g] && found[g] < REC_CANDIDATES && list_n[g] < LIST; it++) {
+                const uint64_t o = pos[g] + lane;
+                bool pass = false;
+                if (o < s1[g] && o + 36 <= n_bytes) {
+                    uint4 a, b;
+                    ld2x16(raw + o, a, b);
+                    const uint32_t bs = a.x, l_read_name = a.w & 0xFFu, n_ops = b.x & 0xFFFFu, l = b.y;
+                    const uint64_t need = 32ull + l_read_name + 4ull * n_ops + ((uint64_t)l + 1) / 2 + l;
+                    const int32_t ref = (int32_t)a.y, p = (int32_t)a.z, mref = (int32_t)b.z, mpos = (int32_t)b.w;
+                    pass = o + 4 + (uint64_t)bs <= n_bytes && bs >= 32 && l_read_name != 0 && need <= bs && ref >= -1 && ref < n_ref &&
+                           mref >= -1 && mref < n_ref && p >= -1 && mpos >= -1;
+                }
+                const uint64_t m = __ballot(pass);
+                const uint32_t k = (uint32_t)__popcll(m), room = LIST - list_n[g];
+                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (pass && rank < room) s_list[g * LIST + list_n[g] + rank] = o;
+                if (k > room) { // the list is full: go on behind the last offset taken, after the walk
+                    uint64_t mm = m;
+                    for (uint32_t q = 1; q < room; q++) mm &= mm - 1;
+                    pos[g] += (uint32_t)__builtin_ctzll(mm) + 1;
+                    list_n[g] = LIST;
+                } else {
+                    list_n[g] += k;
+                    pos[g] += 64;
+                }
             }
-            const uint64_t m = __ballot(pass);
-            const uint32_t k = (uint32_t)__popcll(m), room = LIST - list_n;
-            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (pass && rank < room) s_list[list_n + rank] = o;
-            if (k > room) { // the list is full: go on behind the last offset taken, after the walk
-                uint64_t mm = m;
-                for (uint32_t q = 1; q < room; q++) mm &= mm - 1;
-                pos += (uint32_t)__builtin_ctzll(mm) + 1;
-                list_n = LIST;
-            } else {
-                list_n += k;
-                pos += 64;
-            }
+            any = any || list_n[g] != 0;
+            more = more || (pos[g] < s1[g] && found[g] < REC_CANDIDATES);
         }
-        if (!list_n) continue;
+        if (!any) {
+            if (!more) break;
+            continue;
+        }
         __syncthreads();
+        // the walk: lane g * LIST + k takes the k-th listed offset of segment g
+        const uint32_t gl = lane / LIST, kl = lane % LIST;
+        uint32_t my_n = 0;
+        uint64_t my_s0 = 0, my_s1 = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < G; g++)
+            if (gl == g) {
+                my_n = list_n[g];
+                my_s0 = s0[g];
+                my_s1 = s1[g];
+            }
         uint64_t o = 0, landing = 0;
         uint32_t count = 0;
         bool ok = false;
-        if (lane < list_n) {
+        if (lane < G * LIST && kl < my_n) {
             o = s_list[lane];
-            for (uint32_t j = 0; j < REC_PIECES; j++) s_rel[j * LIST + lane] = SUB_NONE;
-            ok = walk<true>(raw, n_bytes, o, s0, s1, n_ref, &landing, &count, [&](uint32_t j, uint32_t rel, uint32_t cnt) {
-                s_rel[j * LIST + lane] = rel;
-                s_cnt[j * LIST + lane] = cnt;
+            for (uint32_t j = 0; j < REC_PIECES; j++) s_rel[j * (G * LIST) + lane] = SUB_NONE;
+            ok = walk<true>(raw, n_bytes, o, my_s0, my_s1, n_ref, &landing, &count, [&](uint32_t j, uint32_t rel, uint32_t cnt) {
+                s_rel[j * (G * LIST) + lane] = rel;
+                s_cnt[j * (G * LIST) + lane] = cnt;
             });
         }
-        const uint64_t m = __ballot(ok);
-        const uint32_t slot = found + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (ok && slot < REC_CANDIDATES) {
-            out[slot] = RecCandidate{o, landing, count, 1u};
-            RecPieces &pc = pieces[(uint64_t)seg * REC_CANDIDATES + slot];
-            for (uint32_t j = 0; j < REC_PIECES; j++) {
-                pc.rel[j] = s_rel[j * LIST + lane];
-                pc.cnt[j] = s_cnt[j * LIST + lane];
+#pragma unroll
+        for (uint32_t g = 0; g < G; g++) {
+            const uint64_t m = __ballot(ok && gl == g);
+            const uint32_t slot = found[g] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (ok && gl == g && slot < REC_CANDIDATES) {
+                const uint64_t seg = (uint64_t)blockIdx.x * G + g;
+                cand[seg * REC_CANDIDATES + slot] = RecCandidate{o, landing, count, 1u};
+                RecPieces &pc = pieces[seg * REC_CANDIDATES + slot];
+                for (uint32_t j = 0; j < REC_PIECES; j++) {
+                    pc.rel[j] = s_rel[j * (G * LIST) + lane];
+                    pc.cnt[j] = s_cnt[j * (G * LIST) + lane];
+                }
             }
+            found[g] += (uint32_t)__popcll(m);
         }
-        found += (uint32_t)__popcll(m);
         __syncthreads();
     }
-    found = min(found, REC_CANDIDATES);
-    for (uint32_t k = found + lane; k < REC_CANDIDATES; k += 64) out[k] = RecCandidate{0, 0, 0, 0u};
+#pragma unroll
+    for (uint32_t g = 0; g < G; g++) {
+        if (!live[g]) continue;
+        const uint64_t seg = (uint64_t)blockIdx.x * G + g;
+        for (uint32_t k = min(found[g], REC_CANDIDATES) + lane; k < REC_CANDIDATES; k += 64) cand[seg * REC_CANDIDATES + k] = RecCandidate{0, 0, 0, 0u};
+    }
 }
 
 // ---- 2b. the rare segment whose entry is not in the table ---------------------------------------
@@ -600,7 +640,7 @@ hipError_t launch_copy_words(void *dst, const void *src, uint64_t n_bytes, hipSt
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
                                  RecCandidate *cand, RecPieces *pieces, hipStream_t s) {
     if (!n_seg) return hipSuccess;
-    hipLaunchKernelGGL(k_rec_candidates, dim3(n_seg), dim3(64), 0, s, raw, n_bytes, first, n_seg, n_ref, cand, pieces);
+    hipLaunchKernelGGL(k_rec_candidates, dim3((n_seg + REC_GROUP - 1) / REC_GROUP), dim3(64), 0, s, raw, n_bytes, first, n_seg, n_ref, cand, pieces);
     return hipGetLastError();
 }
 hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t seg_start, uint64_t end, RecCandidate *out,

@@ -51,9 +51,13 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
 hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s);
 
 // ---- BAM record parse (csrc/bam_device.hip) -------------------------------------------------------
-constexpr uint64_t REC_SEGMENT = 65536;  // bytes of the inflated stream whose record chain one wave finds
+#ifndef NGSQ_REC_SEGMENT
+#define NGSQ_REC_SEGMENT 16384
+#endif
+constexpr uint64_t REC_SEGMENT = NGSQ_REC_SEGMENT; // bytes of the inflated stream whose record chain is found as one (by its own lanes of a wave)
+constexpr uint32_t REC_GROUP = 4;        // segments per wave of k_rec_candidates
 constexpr uint32_t REC_CANDIDATES = 2;   // chain starts kept per segment
-constexpr uint32_t REC_PIECES = 16;      // a segment's chain is written out by 16 lanes, 4 KiB each
+constexpr uint32_t REC_PIECES = (uint32_t)(REC_SEGMENT / 4096); // a segment's chain is written out by that many lanes, 4 KiB each
 constexpr uint64_t REC_PIECE = REC_SEGMENT / REC_PIECES;
 
 struct RecCandidate {
