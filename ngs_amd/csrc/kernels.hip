@@ -225,7 +225,6 @@ __global__ __launch_bounds__(1024) void k_qual_general(DeviceState st, DeviceBat
 #endif
 constexpr uint32_t EW = 4096;          // positions per LDS window: tile of 255 sorted reads (~650 positions at 60x) + the longest read / skip
 constexpr uint32_t E_TILE = 255;       // records per tile: what an 8-bit counter holds
-constexpr uint64_t E_ONES = 0x0101010101010101ull;
 // inc: eight 0/1 bytes for positions o .. o+7 of the packed window w (4 positions per dword)
 __device__ __forceinline__ void edits_add8(uint32_t *w, uint32_t o, uint64_t inc) {
     const uint32_t d = o >> 2, sh = (o & 3u) * 8u, i0 = (uint32_t)inc, i1 = (uint32_t)(inc >> 32);
