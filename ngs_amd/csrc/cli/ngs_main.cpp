@@ -676,7 +676,10 @@ int main(int argc, char **argv) {
         if (ndev < 1) bail("no HIP device available; the ngs qc hot path has no CPU fallback");
         ngsq_comm *boot = nullptr;
         if (ngsq_comm_create_shm(a.shm.c_str(), a.rank, a.world, 0, &boot) != NGSQ_OK) bail(ngsq_comm_last_error(nullptr));
-        if (!a.transport.empty() && a.transport != "rccl" && a.transport != "shm") bail("--transport must be rccl or shm");
+        // (auto = what a run on a device per worker does without the option -- RCCL if it comes up, else shared memory -- also
+        // with --same-device, where RCCL refuses to come up: the fallback's test)
+        if (!a.transport.empty() && a.transport != "rccl" && a.transport != "shm" && a.transport != "auto") bail("--transport must be rccl, shm or auto");
+        const bool rccl_named = a.transport == "rccl";
         if (a.transport.empty() ? a.same_device : a.transport == "shm") {
             if (!a.same_device) a.device += a.rank;
             comm = boot;
@@ -697,7 +700,7 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> all((size_t)a.world * sizeof uid);
             if (ngsq_comm_allgather_host(boot, uid, all.data(), sizeof uid) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
             if (!all[NGSQ_COMM_ID_BYTES]) {
-                if (!a.transport.empty()) bail(a.rank == 0 ? no_rccl : std::string("RCCL is not available on rank 0"));
+                if (rccl_named) bail(a.rank == 0 ? no_rccl : std::string("RCCL is not available on rank 0"));
                 // not asked for by name: the same exchange, host-staged through the shared-memory segment
                 if (a.rank == 0) logf(1, "%s; the exchange runs over shared memory instead", no_rccl.c_str());
                 comm = boot;
@@ -730,7 +733,14 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> oks((size_t)a.world);
         if (ngsq_comm_allgather_host(boot, &ok, oks.data(), 1) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
         for (int r = 0; r < a.world; r++)
-            if (!oks[(size_t)r]) bail(r == a.rank ? rccl_error : "RCCL's communicator could not be created on worker " + std::to_string(r));
+            if (!oks[(size_t)r]) {
+                const std::string why = r == a.rank ? rccl_error : "RCCL's communicator could not be created on worker " + std::to_string(r);
+                if (a.transport == "rccl") bail(why);
+                // not asked for by name: the same exchange, host-staged through the shared-memory segment the workers met in
+                // (a communicator some ranks did get is left to the end of the process: destroying half of one may not return)
+                if (a.rank == 0) logf(1, "%s; the exchange runs over shared memory instead", why.c_str());
+                return;
+            }
         comm = rccl_comm;
         if (ngsq_comm_barrier(boot) != NGSQ_OK) bail(ngsq_comm_last_error(boot));
         ngsq_comm_destroy(boot);

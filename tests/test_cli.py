@@ -402,6 +402,18 @@ def test_gpus_flag_workers_share_one_file(ngs, gpu_lib, oracle_mod, tmp_path):
     assert r.returncode == 0, r.stderr
     assert "Worker 0 of 3 on device 0, exchange over rccl." in r.stderr
     json_equal(json.load(open(out / "g.bam.results.json")), want)
+    # RCCL that does not come up (the real library refuses three ranks on one device; so does a rank whose library is
+    # missing): named, the run fails on every worker; not named (auto: what a device per worker gets without the option),
+    # the workers agree on the shared-memory transport they met in and the document is the same
+    r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path / "w_fail"), "--gpus", "3", "--same-device", "--transport", "rccl")
+    assert r.returncode != 0 and ("ncclCommInitRank" in r.stderr or "RCCL" in r.stderr), r.stderr
+    for lib_env in ({}, {"NGSQ_RCCL_LIB": "/nonexistent/librccl.so"}):
+        out = tmp_path / ("w_auto%d" % len(lib_env))
+        r = run(ngs, "qc", bam, GENOME, "-o", str(out), "--gpus", "3", "--same-device", "--transport", "auto", "--batch-records", "4001",
+                env=dict(os.environ, **lib_env))
+        assert r.returncode == 0, r.stderr
+        assert "the exchange runs over shared memory instead" in r.stderr
+        json_equal(json.load(open(out / "g.bam.results.json")), want)
     # more workers than devices without --same-device
     if gpu_lib.ngsq_device_count() < 3:
         r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path), "--gpus", "3")
