@@ -97,6 +97,10 @@ def test_inflate_small_blocks_and_block_boundaries(gpu_lib, ctx):
     for block in (1, 7, 255, 4096, 65280):
         comp = bgzf(data[:block * 300], block=block)
         assert device_inflate(gpu_lib, ctx, comp) == data[:block * 300]
+    # the largest block the format allows (ISIZE = 65536: the decoder's symbol offsets are 16 bits wide), twice in a row
+    for payload in (data[:131072], bytes(131072), bytes(range(256)) * 512):
+        comp = bgzf(payload, block=65536)
+        assert device_inflate(gpu_lib, ctx, comp) == payload
 
 
 def test_inflate_mixed_deflate_blocks_in_one_member(gpu_lib, ctx):
