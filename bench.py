@@ -292,6 +292,14 @@ def main() -> int:
     ctx.free_batch(db)
     ctx.close()
     comm_kind = comm.kind if comm is not None else None
+    shared_file = None
+    if comm is not None and world > 1 and args.file_records > 0 and not mixed and not args.emulate_shard:
+        # ---- every rank: ONE BAM file, each rank streaming its BGZF block range of it inside this process (HIP is up, the
+        # communicator exists): the streaming rate of N GPUs on one file, without the process starts of `ngs qc --gpus N`
+        try:
+            shared_file = leg_file_sharded_in_process(lib, host, ffi, np, args, comm, rank, world, device)
+        except Exception as e:  # noqa: BLE001 -- reported, never required
+            shared_file = {"in_process": {"failed": f"{type(e).__name__}: {e}"}}
     if comm is not None:
         comm.barrier()
         comm.destroy()
@@ -311,7 +319,7 @@ def main() -> int:
         elif world > 1 and args.file_records > 0 and not mixed and not args.emulate_shard:
             # the number the metric is named after, on N GPUs: ONE BAM file scanned by `ngs qc --gpus N` (the other ranks
             # of this launch have released their devices and are on their way out)
-            out["file_end_to_end"] = guarded(leg_file_sharded, lib, host, ffi, args, world, comm_kind)
+            out["file_end_to_end"] = guarded(leg_file_sharded, lib, host, ffi, args, world, comm_kind, shared_file)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     return rc
 
@@ -832,38 +840,126 @@ def leg_extra_facets(lib, host, ffi, np, n=100_000_000):
         ctx.close()
 
 
-def leg_file_sharded(lib, host, ffi, args, world, comm_kind):
+def write_sharded_bam(lib, host, args, world, tmp, bam):
+    """The synthetic BAM of the N > 1 file legs: as many records as the writer (zlib on the host cores) manages inside
+    --file-write-budget seconds (probed), at most N x --file-records and a third of the free space."""
+    import ctypes as C
+    probe_n = 2_000_000
+    pcfg = host.synth_config(probe_n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+    t0 = time.perf_counter()
+    assert lib.ngsq_synth_write_bam(C.byref(pcfg), bam.encode(), probe_n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+    rate = probe_n / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(world * args.file_records, max(world * 5_000_000, rate * args.file_write_budget)))
+    try:    # and no more than a third of the free space under the temporary directory (~100 bytes per record)
+        import shutil
+        n = int(min(n, max(world * 1_000_000, shutil.disk_usage(tmp).free / 3 / 105)))
+    except OSError:
+        pass
+    fcfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+    t0 = time.perf_counter()
+    assert lib.ngsq_synth_write_bam(C.byref(fcfg), bam.encode(), n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+    tw = time.perf_counter() - t0
+    os.sync()
+    return n, tw
+
+
+def leg_file_sharded_in_process(lib, host, ffi, np, args, comm, rank, world, device):
+    """N > 1, EVERY rank: rank 0 writes one synthetic BAM (the others wait for a marker file -- no collective is left
+    waiting while zlib runs for a minute); then each rank streams its BGZF block range of it through the chunked
+    pipeline (ngs_amd/shard.py: Comm.scan_file_shard = ngsq_bam_shard_open / next_batch_device / process_batch /
+    ngsq_bam_shard_verify), one ngsq_exchange, ngsq_finalize -- bracketed by barriers, so the time is the slowest
+    rank's.  Returns {"tmp", "bam", "records", "bam_write_s", "in_process": {...}} (rank 0 keeps the file for the
+    `ngs qc --gpus N` leg); every rank returns the same verdict."""
+    import tempfile
+    # the path: rank 0's choice, learnt by everyone in one small all-gather
+    buf = np.zeros(512, dtype=np.uint8)
+    tmp = None
+    if rank == 0:
+        tmp = tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+        raw = tmp.encode()
+        buf[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+    tmp = bytes(comm.allgather(buf)[0]).rstrip(b"\0").decode()
+    bam, marker = os.path.join(tmp, "synth.bam"), os.path.join(tmp, "written.json")
+    if rank == 0:
+        try:
+            n, tw = write_sharded_bam(lib, host, args, world, tmp, bam)
+            note = {"ok": True, "records": n, "bam_write_s": round(tw, 2), "bam_bytes": os.path.getsize(bam)}
+        except Exception as e:  # noqa: BLE001 -- the others must hear of it
+            note = {"ok": False, "why": f"{type(e).__name__}: {e}"}
+        with open(marker + ".tmp", "w") as f:
+            json.dump(note, f)
+        os.rename(marker + ".tmp", marker)
+    else:
+        deadline = time.time() + 4 * args.file_write_budget + 180
+        while not os.path.exists(marker):
+            if time.time() > deadline:
+                raise RuntimeError("rank 0 did not write the shared BAM in time")
+            time.sleep(0.05)
+        with open(marker) as f:
+            note = json.load(f)
+    out = {"tmp": tmp, "bam": bam, "records": note.get("records", 0), "bam_write_s": note.get("bam_write_s"),
+           "bam_bytes": note.get("bam_bytes")}
+    if not note["ok"]:
+        out["in_process"] = {"failed": note["why"]}
+        return out
+    n = note["records"]
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], device=device, max_read_len=max(256, args.read_len), gc_seed=GC_SEED, sorted_input=True,
+                         timing=False, lib=lib)
+    # reader threads per rank: the host cores this launch may use, less two per rank for the scan loops, shared out
+    # (what `ngs qc --gpus N` gives its workers)
+    reader_threads = max(2, (effective_cores() - 2 * world) // world)
+    try:
+        times, mine, rounds = [], 0, 0
+        for rep in range(2):   # the first scan of a process allocates and pins the pipeline's buffers
+            ctx.reset()
+            comm.barrier()
+            t0 = time.perf_counter()
+            info, rounds, mine = comm.scan_file_shard(ctx, bam, batch_records=1 << 22, threads=reader_threads)
+            comm.exchange(ctx)
+            ctx.finalize()
+            comm.barrier()
+            times.append(round(time.perf_counter() - t0, 3))
+        total = ctx.results(["chr1", "chr2"])["general"]["records"]["total"]
+        per_rank = [c[0] for c in comm.allgather_ints([mine])]
+        best = min(times)
+        out["in_process"] = {"gpus": world, "seconds_each_scan": times, "records_per_s": round(n / best, 1),
+                             "compressed_GB_per_s": round(note["bam_bytes"] / best / 1e9, 2),
+                             "records_per_s_per_gpu": round(n / best / world, 1), "records_per_rank": per_rank,
+                             "rescans": rounds, "check_total": total, "reader_threads_per_rank": reader_threads,
+                             "includes": "every rank: file open, reads of its BGZF block range, H2D, inflate, parse, all default "
+                                         "facets, the boundary check, ngsq_exchange, finalize, close; slowest rank (barriers)"}
+        if rank == 0:
+            out["in_process"]["document"] = ctx.results(["chr1", "chr2"])
+        return out
+    finally:
+        ctx.close()
+
+
+def leg_file_sharded(lib, host, ffi, args, world, comm_kind, shared=None):
     """N > 1: ONE synthetic BGZF BAM of (up to) N x --file-records records scanned by `ngs qc --gpus N` -- one worker
     process per GPU, each streaming its BGZF block range through the chunked pipeline, one exchange before the teardown
     -- wall clock of the command (process starts and HIP initialisation included), and the document against the one
     `ngs qc` writes for the same file on one GPU."""
-    import ctypes as C
     import tempfile
     from ngs_amd import build
-    tmp = tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+    reuse = isinstance(shared, dict) and shared.get("records") and os.path.exists(shared.get("bam", ""))
+    tmp = shared["tmp"] if reuse else tempfile.mkdtemp(prefix="ngsq_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
     bam = os.path.join(tmp, "synth.bam")
     out = {"zlib_level": args.file_level, "host_cores": effective_cores(), "source": "page cache", "filesystem": fs_type_of(tmp)}
     try:
-        # how many records the writer (zlib on the host cores) manages inside its budget: probe, then decide
-        probe_n = 2_000_000
-        pcfg = host.synth_config(probe_n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
-        t0 = time.perf_counter()
-        assert lib.ngsq_synth_write_bam(C.byref(pcfg), bam.encode(), probe_n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
-        rate = probe_n / max(time.perf_counter() - t0, 1e-6)
-        n = int(min(world * args.file_records, max(world * 5_000_000, rate * args.file_write_budget)))
-        try:    # and no more than a third of the free space under the temporary directory (~100 bytes per record)
-            import shutil
-            n = int(min(n, max(world * 1_000_000, shutil.disk_usage(tmp).free / 3 / 105)))
-        except OSError:
-            pass
+        if reuse:   # the file the ranks have just scanned in process
+            n = shared["records"]
+            out["bam_write_s"] = shared["bam_write_s"]
+        else:
+            n, tw = write_sharded_bam(lib, host, args, world, tmp, bam)
+            out["bam_write_s"] = round(tw, 2)
         out["records"] = n
         out["records_wanted"] = world * args.file_records
-        fcfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
-        t0 = time.perf_counter()
-        assert lib.ngsq_synth_write_bam(C.byref(fcfg), bam.encode(), n, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
-        out["bam_write_s"] = round(time.perf_counter() - t0, 2)
         out["bam_bytes"] = os.path.getsize(bam)
-        os.sync()
+        inproc = dict(shared.get("in_process", {})) if isinstance(shared, dict) else {}
+        inproc_doc = inproc.pop("document", None)
+        if inproc:
+            out["in_process"] = inproc
         ngs = build.build_cli(verbose=False)
         flags = ["--same-device"] if args.same_gpu else []
         if comm_kind == "shm" or args.transport == "shm":
@@ -897,6 +993,8 @@ def leg_file_sharded(lib, host, ffi, args, world, comm_kind):
         out["unit"] = "records/s"
         out["includes"] = "launcher + N worker process starts, HIP initialisation, header + index checks, the exchange, JSON write"
         out["json_equal_sharded_one_gpu"] = json.dumps(docs["sharded"], sort_keys=True) == json.dumps(docs["one_gpu"], sort_keys=True)
+        if inproc_doc is not None:
+            out["in_process"]["json_equal_one_gpu"] = json.dumps(inproc_doc, sort_keys=True) == json.dumps(docs["one_gpu"], sort_keys=True)
         out["check_total"] = docs["sharded"]["general"]["records"]["total"]
         return out
     finally:
