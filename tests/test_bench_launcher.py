@@ -21,3 +21,36 @@ def test_launcher_without_gpu(n):
     assert r.returncode == 3, (r.returncode, r.stderr[-800:])
     assert "no HIP device visible; the hot path has no CPU fallback" in r.stderr
     assert r.stdout.strip() == ""   # no JSON line from a run that measured nothing
+
+
+def _run_bench(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--records", "2000000",
+                           "--cpu-sample", "100000", "--extra-facet-records", "1000000", "--file-big-records", "0", *flags],
+                          capture_output=True, text=True, env=env, timeout=1500)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [("--h2d-batch", "200000", "--file-records", "300000"),
+                                   ("--gpus", "2", "--same-gpu", "--file-records", "300000", "--file-write-budget", "5")])
+def test_bench_line_contract(flags):
+    """What the driver reads: stdout is ONE line of JSON (RCCL's banner and everything else on stderr), with the
+    contract's keys; at N > 1 the file legs report a document equal to the one-GPU command's."""
+    import json
+    r = _run_bench(*flags)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, lines[:3]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "parity_check"):
+        assert key in d, key
+    assert d["parity_check"].startswith("ok") and d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    fe = d["file_end_to_end"]
+    if d["n_gpus"] == 1:
+        assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+        assert fe["json_equal_device_host_inprocess"] is True and fe["check_total"] == 300000
+    else:
+        assert fe["json_equal_sharded_one_gpu"] is True and fe["in_process"]["json_equal_one_gpu"] is True
+        assert fe["check_total"] == fe["records"] == fe["in_process"]["check_total"]
