@@ -2,7 +2,7 @@
 // next file scanned by the process instead of going back to the driver: allocating and pinning the pipeline's buffers
 // costs ~130 ms per file and freeing them ~100 ms (GiB-sized hipMalloc / hipHostMalloc / hipFree are page-table work),
 // against ~300 ms of actual scanning for a 6 GB BAM.  Released by ngsq_release_cached_memory() and whenever a context
-// is destroyed; NGSQ_POOL_MB=0 turns the cache off, NGSQ_POOL_MB=<n> caps what it keeps per kind (default: 4096 of device memory, 1536 pinned).
+// is destroyed; NGSQ_POOL_MB=0 turns the cache off, NGSQ_POOL_MB=<n> caps what it keeps per kind (default: 6144 of device memory, 1536 pinned).
 #pragma once
 
 #include <hip/hip_runtime_api.h>
