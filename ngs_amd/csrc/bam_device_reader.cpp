@@ -319,72 +319,105 @@ void free_ingest(DeviceIngest *d) { delete d; }
         if (e_ != hipSuccess) return ngsq_bam_fail(NGSQ_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-// The reader's pread workers: started once (they inherit the reader thread's CPU affinity), woken per step.
-// Threads created anew for every 64 MiB step spent a quarter of the step getting onto CPUs of their own.
+// The reader's pread workers: started once (they inherit the reader thread's CPU affinity), woken per request.
+// (Threads created anew for every 64 MiB step spent a quarter of the step getting onto CPUs of their own.)  A request is a
+// run of the file cut into pieces of 4 MiB that the workers take IN ORDER, one after the other: the bytes arrive as a
+// growing prefix, the reader thread frames and sends what has arrived while the rest is on its way, and there is no point
+// at which all the workers wait for the slowest of them -- with one barrier per 64 MiB step the storage under a file that is
+// not in the page cache saw its queue drain sixty times per second (0.62 s for the cold 6 GB file, 0.53 s now).
 struct ReadPool {
-    static constexpr int NT_MAX = 16;
+    static constexpr int NT_MAX = 32;
+    static constexpr size_t PIECE = (size_t)4 << 20, MAX_PIECES = 1024; // a request is at most 4 GiB
     int nt = 0, fd = -1;
     std::thread th[NT_MAX];
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     uint64_t gen = 0;
-    int running = 0;
     bool quit = false;
     uint8_t *dst = nullptr;
     uint64_t pos = 0;
-    size_t want = 0, per = 0;
-    size_t got_part[NT_MAX] = {};
-    bool bad_part[NT_MAX] = {};
+    size_t want = 0, n_pieces = 0, next = 0, finished = 0;
+    uint32_t got[MAX_PIECES] = {};
+    bool done[MAX_PIECES] = {};
+    bool bad = false;
 
     void open(int n, int file) {
         nt = n;
         fd = file;
-        for (int t = 0; t < nt; t++) th[t] = std::thread([this, t] { work(t); });
+        for (int t = 0; t < nt; t++) th[t] = std::thread([this] { work(); });
     }
-    void work(int t) {
+    void work() {
         uint64_t seen = 0;
+        std::unique_lock<std::mutex> g(mu);
         for (;;) {
-            {
-                std::unique_lock<std::mutex> g(mu);
-                cv_go.wait(g, [&] { return quit || gen != seen; });
-                if (quit) return;
-                seen = gen;
-            }
-            const size_t lo = std::min(want, per * (size_t)t), hi = std::min(want, lo + per);
-            size_t done = 0;
-            bool bad = false;
-            while (lo + done < hi) {
-                const ssize_t r = pread(fd, dst + lo + done, hi - lo - done, (off_t)(pos + lo + done));
-                if (r < 0) {
-                    bad = true;
-                    break;
+            cv_go.wait(g, [&] { return quit || (gen != seen && next < n_pieces); });
+            if (quit) return;
+            const uint64_t my_gen = gen;
+            while (gen == my_gen && next < n_pieces) {
+                const size_t i = next++;
+                const size_t lo = i * PIECE, hi = std::min(want, lo + PIECE);
+                uint8_t *const to = dst;
+                const uint64_t from = pos;
+                g.unlock();
+                size_t n = 0;
+                bool err = false;
+                while (lo + n < hi) {
+                    const ssize_t r = pread(fd, to + lo + n, hi - lo - n, (off_t)(from + lo + n));
+                    if (r < 0) {
+                        err = true;
+                        break;
+                    }
+                    if (r == 0) break; // end of file
+                    n += (size_t)r;
                 }
-                if (r == 0) break; // end of file
-                done += (size_t)r;
+                g.lock();
+                got[i] = (uint32_t)n;
+                done[i] = true;
+                bad = bad || err;
+                finished++;
+                cv_done.notify_all();
             }
-            {
-                std::lock_guard<std::mutex> g(mu);
-                got_part[t] = done;
-                bad_part[t] = bad;
-                if (--running == 0) cv_done.notify_all();
-            }
+            seen = my_gen;
         }
     }
-    void start(uint8_t *to, uint64_t file_pos, size_t n, size_t piece) {
+    // (the previous request must have been waited out: wait_prefix(...) returned all = true)
+    void start(uint8_t *to, uint64_t file_pos, size_t n) {
         {
             std::lock_guard<std::mutex> g(mu);
             dst = to;
             pos = file_pos;
             want = n;
-            per = piece;
-            running = nt;
+            n_pieces = (n + PIECE - 1) / PIECE;
+            next = finished = 0;
+            bad = false;
+            for (size_t i = 0; i < n_pieces; i++) done[i] = false;
             gen++;
         }
         cv_go.notify_all();
     }
-    void wait() {
+    // Wait until the bytes that have arrived without a gap reach `at_least` (or every piece is in): *avail = those bytes
+    // (they end at the first short piece: the end of the file), *all = nothing is on its way any more.
+    void wait_prefix(size_t at_least, size_t *avail, bool *all, bool *short_read) {
         std::unique_lock<std::mutex> g(mu);
-        cv_done.wait(g, [&] { return running == 0; });
+        for (;;) {
+            size_t a = 0, i = 0;
+            bool cut = false;
+            for (; i < n_pieces && done[i]; i++) {
+                a += got[i];
+                if (got[i] < std::min(want, (i + 1) * PIECE) - i * PIECE) { // a short piece: nothing behind it counts
+                    cut = true;
+                    break;
+                }
+            }
+            const bool fin = finished == n_pieces;
+            if (fin || a >= at_least) {
+                *avail = a;
+                *all = fin;
+                *short_read = cut;
+                return;
+            }
+            cv_done.wait(g);
+        }
     }
     ~ReadPool() {
         {
@@ -411,7 +444,7 @@ void reader_main(DeviceIngest *d, std::string path) {
     const bool range_cut = d->pos_end < d->file_size; // the range ends inside the file: its last block may be cut, by design
     const size_t cap = 2 * d->comp_chunk;
     const uint64_t out_limit = d->raw_cap > 2 * CARRY_MAX ? d->raw_cap - CARRY_MAX : d->raw_cap / 2;
-    constexpr size_t STEP = (size_t)64 << 20;
+    constexpr size_t STEP = (size_t)32 << 20; // bytes framed and sent at a time
     constexpr int NT_MAX = ReadPool::NT_MAX;
     // leave two cores of the quota to the thread that drives the GPU and to this one (it frames while the others read)
     // (the workers of a sharded run share the quota: ngsq_bam_shard_begin sets reader_threads)
@@ -537,31 +570,31 @@ void reader_main(DeviceIngest *d, std::string path) {
                 const double need = (double)(limit - c.total) * ratio * 1.02 + 2 * 65536.0;
                 const size_t have = c.fill - c.consumed;
                 want = need > (double)have ? (size_t)(need - (double)have) : 65536;
-                want = std::min(want, STEP);
             }
             want = std::min(want, cap - c.fill);
             want = (size_t)std::min<uint64_t>(want, d->pos_end - file_pos);
-            const size_t per = (want + NT - 1) / NT;
+            want = std::min(want, ReadPool::PIECE * ReadPool::MAX_PIECES);
             const double tsp = now_ms();
             n_steps++;
-            pool.start(c.h + c.fill, file_pos, want, per);
+            pool.start(c.h + c.fill, file_pos, want);
             t_spawn += now_ms() - tsp;
-            frame(); // what the previous step brought, while this one is on its way
-            send();
-            size_t got = 0;
-            bool short_read = false;
-            const double tj = now_ms();
-            pool.wait();
-            for (int t = 0; t < NT; t++) {
-                if (pool.bad_part[t]) c.err = "read error on " + path;
-                const size_t lo = std::min(want, per * (size_t)t), hi = std::min(want, lo + per);
-                if (!short_read) got += pool.got_part[t];
-                if (pool.got_part[t] < hi - lo) short_read = true;
+            // what has arrived is framed and sent while the rest is read, STEP bytes at a time
+            const size_t fill0 = c.fill;
+            size_t avail = 0;
+            bool all = false, short_read = false;
+            while (!all) {
+                const double tj = now_ms();
+                pool.wait_prefix(std::min(want, avail + STEP), &avail, &all, &short_read);
+                t_join += now_ms() - tj;
+                c.fill = fill0 + avail;
+                if (c.err.empty() && !full) {
+                    frame();
+                    send();
+                }
             }
-            t_join += now_ms() - tj;
-            if (got < want) eof = true;
-            file_pos += got;
-            c.fill += got;
+            if (pool.bad) c.err = "read error on " + path;
+            if (avail < want || short_read) eof = true;
+            file_pos += avail;
             if (file_pos >= d->pos_end) eof = true;
             if (c.total) ratio = (double)c.consumed / (double)c.total;
         }
