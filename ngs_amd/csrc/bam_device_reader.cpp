@@ -445,6 +445,7 @@ void reader_main(DeviceIngest *d, std::string path) {
     const size_t cap = 2 * d->comp_chunk;
     const uint64_t out_limit = d->raw_cap > 2 * CARRY_MAX ? d->raw_cap - CARRY_MAX : d->raw_cap / 2;
     constexpr size_t STEP = (size_t)32 << 20; // bytes framed and sent at a time
+    const uint64_t ramp_first = env_mb("NGSQ_RAMP_FIRST_MB", 32), ramp_shift = getenv("NGSQ_RAMP_SHIFT") ? (uint64_t)atoi(getenv("NGSQ_RAMP_SHIFT")) : 2; // (measurement aids)
     constexpr int NT_MAX = ReadPool::NT_MAX;
     // leave two cores of the quota to the thread that drives the GPU and to this one (it frames while the others read)
     // (the workers of a sharded run share the quota: ngsq_bam_shard_begin sets reader_threads)
@@ -485,11 +486,11 @@ void reader_main(DeviceIngest *d, std::string path) {
     for (int k = 0;; k ^= 1, chunk_no++) {
         DeviceIngest::HostChunk &c = d->hc[k];
         // The pipeline fills gradually: nothing can be parsed before the first chunk has been read, copied and inflated, so
-        // the first one is small (32 MiB of records) and each of the next is twice its predecessor until the full size --
-        // the inflate of chunk k+1 then takes about as long as the parse of chunk k plus the inflate of chunk k did, the
-        // decoders never wait, and the first records reach the facets a few milliseconds into the scan (a trace of a 6 GB
-        // file: steady state from 41 ms with 32 / 128 / 512 MiB, the third chunk's 7.4 ms of inflate overlapping nothing)
-        const uint64_t limit = chunk_no < 5 ? std::min<uint64_t>(out_limit, (uint64_t)32 << (20 + chunk_no)) : out_limit;
+        // the first one is small (32 MiB of records) and each of the next is four times its predecessor until the full size
+        // (32 / 128 / 512 MiB): the first records reach the facets 15 ms into the scan.  (Twice its predecessor until the
+        // decoder got faster in round 3 -- a chunk's fixed costs, launches and host round trips, then weighed more than the
+        // shorter waits: 0.217-0.221 s -> 0.198-0.213 s for the 6 GB file.)
+        const uint64_t limit = chunk_no * ramp_shift < 12 ? std::min<uint64_t>(out_limit, (uint64_t)ramp_first << (chunk_no * ramp_shift)) : out_limit;
         {
             std::unique_lock<std::mutex> g(d->mu);
             d->cv.wait(g, [&] { return d->stop || !c.ready; });
