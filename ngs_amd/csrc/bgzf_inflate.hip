@@ -29,6 +29,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "ingest_kernels.h"
 
@@ -518,7 +520,7 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t *p) {
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-__device__ uint32_t crc_mul(uint32_t a, uint32_t b) { // a * b mod P
+__host__ __device__ inline uint32_t crc_mul(uint32_t a, uint32_t b) { // a * b mod P
     uint32_t p = 0;
     for (uint32_t m = 1u << 31; m; m >>= 1) {
         if (a & m) p ^= b;
@@ -526,7 +528,7 @@ __device__ uint32_t crc_mul(uint32_t a, uint32_t b) { // a * b mod P
     }
     return p;
 }
-__device__ uint32_t crc_xpow8(uint32_t n_bytes) { // x^(8 n) mod P
+__host__ __device__ inline uint32_t crc_xpow8(uint32_t n_bytes) { // x^(8 n) mod P
     uint32_t r = 1u << 31, sq = 0x00800000u;      // x^0, x^8
     for (uint32_t e = n_bytes; e; e >>= 1) {
         if (e & 1u) r = crc_mul(r, sq);
@@ -1008,8 +1010,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NGSQ_INFLATE
 // starts from 0xFFFFFFFF, the others from 0, and the slices are combined pairwise in six steps,
 // register(A || B) = register(A) * x^(8 |B|) + register(B), with |B| the same for every pair of a step.
 constexpr uint32_t CRC_WAVES = 8; // BGZF blocks per workgroup: the tables are loaded once for all of them
+constexpr uint32_t CRC_MAX_SLICE = 1024; // bytes of one of the 64 slices of a block (ISIZE <= 65536)
 __global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__restrict__ out, const BgzfBlock *__restrict__ blocks,
-                                                             uint32_t n_blocks, uint32_t *__restrict__ status) {
+                                                             uint32_t n_blocks, uint32_t *__restrict__ status,
+                                                             const uint32_t *__restrict__ pow_tab) {
     NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_tab[CRC_SLICES * 256];
     for (uint32_t k = threadIdx.x; k < CRC_SLICES * 256; k += 64 * CRC_WAVES) s_tab[k] = c_crc.t[k >> 8][k & 0xFFu];
@@ -1047,12 +1051,13 @@ __global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__re
         c = s_tab[3 * 256 + (x & 0xFFu)] ^ s_tab[2 * 256 + ((x >> 8) & 0xFFu)] ^ s_tab[1 * 256 + ((x >> 16) & 0xFFu)] ^ s_tab[x >> 24];
     }
     for (; i < b; i++) c = s_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
-    // pairwise combination: after step j the lanes whose low j+1 bits are ones hold 2^(j+1) slices
-    uint32_t mult = crc_xpow8(S); // x^(8 |B|) of this step (uniform)
+    // pairwise combination: after step j the lanes whose low j+1 bits are ones hold 2^(j+1) slices.  The multiplier of step
+    // j, x^(8 S 2^j), comes from a table (a slice has at most 1024 bytes): computed here -- a dozen GF(2) multiplications of 32
+    // scalar steps each, per block -- it was half of this kernel's scalar instructions, on the unit the decoders are short of.
+    const uint32_t *const pw = pow_tab + uni(S) * 6u;
     for (uint32_t j = 0; j < 6; j++) {
         const uint32_t left = (uint32_t)__shfl_up((int)c, 1u << j, 64);
-        if ((lane & ((2u << j) - 1u)) == (2u << j) - 1u) c = crc_mul(left, mult) ^ c;
-        mult = crc_mul(mult, mult);
+        if ((lane & ((2u << j) - 1u)) == (2u << j) - 1u) c = crc_mul(left, pw[j]) ^ c;
     }
     const uint32_t crc = ~__builtin_amdgcn_readlane(c, 63);
     if (isize && lane == 0 && crc != blocks[bi].crc) status[bi] = INF_CRC_MISMATCH;
@@ -1061,7 +1066,32 @@ __global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__re
 
 hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
-    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + CRC_WAVES - 1) / CRC_WAVES), dim3(64 * CRC_WAVES), 0, s, out, blocks, n_blocks, status);
+    // x^(8 S 2^j) mod P for every slice length S and combination step j: 25 KB, computed once per device and process
+    static std::mutex mu;
+    static uint32_t *tab[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t *pow_tab = nullptr;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!tab[dev]) {
+            std::vector<uint32_t> h((size_t)(CRC_MAX_SLICE + 1) * 6);
+            for (uint32_t S = 0; S <= CRC_MAX_SLICE; S++) {
+                uint32_t m = crc_xpow8(S);
+                for (uint32_t j = 0; j < 6; j++) {
+                    h[(size_t)S * 6 + j] = m;
+                    m = crc_mul(m, m);
+                }
+            }
+            hipError_t e = hipMalloc((void **)&tab[dev], h.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return e;
+            e = hipMemcpy(tab[dev], h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return e;
+        }
+        pow_tab = tab[dev];
+    }
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + CRC_WAVES - 1) / CRC_WAVES), dim3(64 * CRC_WAVES), 0, s, out, blocks, n_blocks, status, pow_tab);
     return hipGetLastError();
 }
 
