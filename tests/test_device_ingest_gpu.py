@@ -115,6 +115,37 @@ def test_inflate_mixed_deflate_blocks_in_one_member(gpu_lib, ctx):
     assert device_inflate(gpu_lib, ctx, comp) == a + b + c
 
 
+def test_inflate_random_corruptions(gpu_lib, ctx):
+    """A flipped byte anywhere in a block's DEFLATE data: an error, or (the flip did not matter, or the CRC is not looked at)
+    some output of the announced size -- never a hang, a crash, or a silent difference with the CRC on."""
+    rng = np.random.default_rng(77)
+    w = np.array([2.0 ** -(i // 8) for i in range(256)])
+    sources = [b"read%07d\tACGTACGTTTGACCA\tIIIIIHHHGGG#\n" * 1500,
+               rng.choice(np.array([2, 11, 25, 37], np.uint8), 60_000, p=[.05, .1, .15, .7]).tobytes(),
+               rng.choice(np.arange(256, dtype=np.uint8), 60_000, p=w / w.sum()).tobytes(),
+               rng.integers(0, 2, 50_000, dtype=np.uint8).tobytes(), bytes(40_000)]
+    n_err = n_same = 0
+    for data in sources:
+        for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY)):
+            good = bgzf(data[:60_000], level=level, strategy=strategy)
+            first_len = struct.unpack("<H", good[16:18])[0] + 1
+            for _ in range(12):
+                bad = bytearray(good)
+                off = int(rng.integers(18, first_len - 8))   # inside the first block's compressed data
+                bad[off] ^= int(rng.integers(1, 256))
+                for crc in (True, False):
+                    try:
+                        got = device_inflate(gpu_lib, ctx, bytes(bad), check_crc=crc)
+                    except RuntimeError:
+                        n_err += 1
+                        continue
+                    assert len(got) == len(data[:60_000])
+                    if crc:
+                        assert got == data[:60_000]
+                        n_same += 1
+    assert n_err > 100   # (most flips are noticed by the decoder itself or by the CRC)
+
+
 def test_inflate_errors(gpu_lib, ctx):
     data = b"The quick brown fox jumps over the lazy dog. " * 500
     good = bgzf(data)
