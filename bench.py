@@ -903,8 +903,20 @@ def leg_file_sharded_in_process(lib, host, ffi, np, args, comm, rank, world, dev
         out["in_process"] = {"failed": note["why"]}
         return out
     n = note["records"]
-    ctx = host.QcContext([CHR1, CHR2], [1, 1], device=device, max_read_len=max(256, args.read_len), gc_seed=GC_SEED, sorted_input=True,
-                         timing=False, lib=lib)
+    # (every rank says whether it is ready before the first collective of the scan: one that is not must not leave the
+    # others waiting inside it)
+    ctx, why = None, ""
+    try:
+        ctx = host.QcContext([CHR1, CHR2], [1, 1], device=device, max_read_len=max(256, args.read_len), gc_seed=GC_SEED, sorted_input=True,
+                             timing=False, lib=lib)
+    except Exception as e:  # noqa: BLE001
+        why = f"{type(e).__name__}: {e}"
+    ready = [r[0] for r in comm.allgather_ints([1 if ctx is not None else 0])]
+    if not all(ready):
+        if ctx is not None:
+            ctx.close()
+        out["in_process"] = {"failed": why or "rank(s) %s could not create a context" % [i for i, r in enumerate(ready) if not r]}
+        return out
     # reader threads per rank: the host cores this launch may use, less two per rank for the scan loops, shared out
     # (what `ngs qc --gpus N` gives its workers)
     reader_threads = max(2, (effective_cores() - 2 * world) // world)
