@@ -327,7 +327,12 @@ void free_ingest(DeviceIngest *d) { delete d; }
 // not in the page cache saw its queue drain sixty times per second (0.62 s for the cold 6 GB file, 0.53 s now).
 struct ReadPool {
     static constexpr int NT_MAX = 32;
-    static constexpr size_t PIECE = (size_t)4 << 20, MAX_PIECES = 1024; // a request is at most 4 GiB
+    // pieces of 4 MiB when the bytes come out of the page cache (the prefix grows smoothly: framing and the copies to the device
+    // keep up with the reads), of 16 MiB when they come from storage (measured on the boxes' overlay filesystem: 12 GB/s with
+    // 4 MiB requests, 15 with 16 MiB; from the page cache the large pieces cost a tenth of the scan) -- the reader thread
+    // chooses by the rate of the request before
+    static constexpr size_t PIECE = (size_t)4 << 20, PIECE_COLD = (size_t)16 << 20, MAX_PIECES = 1024; // a request is at most 4 GiB
+    size_t piece = PIECE;
     int nt = 0, fd = -1;
     std::thread th[NT_MAX];
     std::mutex mu;
@@ -355,7 +360,7 @@ struct ReadPool {
             const uint64_t my_gen = gen;
             while (gen == my_gen && next < n_pieces) {
                 const size_t i = next++;
-                const size_t lo = i * PIECE, hi = std::min(want, lo + PIECE);
+                const size_t lo = i * piece, hi = std::min(want, lo + piece);
                 uint8_t *const to = dst;
                 const uint64_t from = pos;
                 g.unlock();
@@ -381,13 +386,14 @@ struct ReadPool {
         }
     }
     // (the previous request must have been waited out: wait_prefix(...) returned all = true)
-    void start(uint8_t *to, uint64_t file_pos, size_t n) {
+    void start(uint8_t *to, uint64_t file_pos, size_t n, bool cold) {
         {
             std::lock_guard<std::mutex> g(mu);
             dst = to;
             pos = file_pos;
             want = n;
-            n_pieces = (n + PIECE - 1) / PIECE;
+            piece = cold ? PIECE_COLD : PIECE;
+            n_pieces = (n + piece - 1) / piece;
             next = finished = 0;
             bad = false;
             for (size_t i = 0; i < n_pieces; i++) done[i] = false;
@@ -404,7 +410,7 @@ struct ReadPool {
             bool cut = false;
             for (; i < n_pieces && done[i]; i++) {
                 a += got[i];
-                if (got[i] < std::min(want, (i + 1) * PIECE) - i * PIECE) { // a short piece: nothing behind it counts
+                if (got[i] < std::min(want, (i + 1) * piece) - i * piece) { // a short piece: nothing behind it counts
                     cut = true;
                     break;
                 }
@@ -451,6 +457,7 @@ void reader_main(DeviceIngest *d, std::string path) {
     // (the workers of a sharded run share the quota: ngsq_bam_shard_begin sets reader_threads)
     const int NT = d->reader_threads > 0 ? std::min(NT_MAX, d->reader_threads) : std::max(4, std::min(NT_MAX, effective_cores() - 2));
     double ratio = 0.0; // compressed bytes per inflated byte, from the chunks framed so far
+    bool cold = false;  // the last request came from storage, not from the page cache
     const int fd = fileno(d->f);
     // this thread, its pread workers and the pinned buffers they fill: all on the device's NUMA node
     pin_to_device_node(d->ctx->device);
@@ -577,7 +584,7 @@ void reader_main(DeviceIngest *d, std::string path) {
             want = std::min(want, ReadPool::PIECE * ReadPool::MAX_PIECES);
             const double tsp = now_ms();
             n_steps++;
-            pool.start(c.h + c.fill, file_pos, want);
+            pool.start(c.h + c.fill, file_pos, want, cold);
             t_spawn += now_ms() - tsp;
             // what has arrived is framed and sent while the rest is read, STEP bytes at a time
             const size_t fill0 = c.fill;
@@ -594,6 +601,8 @@ void reader_main(DeviceIngest *d, std::string path) {
                 }
             }
             if (pool.bad) c.err = "read error on " + path;
+            // below 16 GB/s the bytes did not come out of the page cache (which delivers twice that to these threads)
+            if (avail >= ((size_t)32 << 20)) cold = (double)avail / ((now_ms() - tsp) * 1e-3) < 16e9;
             if (avail < want || short_read) eof = true;
             file_pos += avail;
             if (file_pos >= d->pos_end) eof = true;
