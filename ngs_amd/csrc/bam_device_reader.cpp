@@ -601,8 +601,9 @@ void reader_main(DeviceIngest *d, std::string path) {
                 }
             }
             if (pool.bad) c.err = "read error on " + path;
-            // below 16 GB/s the bytes did not come out of the page cache (which delivers twice that to these threads)
-            if (avail >= ((size_t)32 << 20)) cold = (double)avail / ((now_ms() - tsp) * 1e-3) < 16e9;
+            // below 1.2 GB/s per read thread the bytes did not come out of the page cache (which gives each of them twice that
+            // and more; a dozen threads on storage get 0.9 each)
+            if (avail >= ((size_t)32 << 20)) cold = (double)avail / ((now_ms() - tsp) * 1e-3) < 1.2e9 * NT;
             if (avail < want || short_read) eof = true;
             file_pos += avail;
             if (file_pos >= d->pos_end) eof = true;
