@@ -108,6 +108,18 @@ int ngsq_bam_shard_begin(ngsq_bam *bam, ngsq_ctx *ctx, uint32_t shard, uint32_t 
 /* after ngsq_bam_next_batch_device has returned 0 records */
 int ngsq_bam_shard_end(ngsq_bam *bam, ngsq_bam_shard_info *out);
 
+/* What the device ingest of this handle has done so far (measurement and tests: how often the record index had to leave its
+ * fast path).  segments: 16 KiB pieces of the inflated stream whose record chain was looked for; walk_one: those whose entry
+ * was not among the chain starts the wave had kept (crowded out by bytes that look like records -- auxiliary data can -- or a
+ * record the strict test rejects) and was walked by one thread instead; one per chunk is the record cut by the chunk's end. */
+typedef struct ngsq_bam_ingest_stats {
+    uint64_t chunks, segments, walk_one;
+    uint64_t batches, batches_fixed_rows, batches_one_op; /* layout of the batches handed out: fixed-pitch SEQ/QUAL rows; <= 1 CIGAR op */
+    uint64_t long_cigar_records;                           /* records whose CIGAR came from a CG:B,I tag (SAM specification 4.2.2) */
+    uint64_t reserved;
+} ngsq_bam_ingest_stats;
+int ngsq_bam_device_stats(const ngsq_bam *bam, ngsq_bam_ingest_stats *out);
+
 /* Inflate a buffer of WHOLE BGZF blocks (host memory) on the context's device and copy the
  * decompressed bytes back: one wavefront per block (csrc/bgzf_inflate.hip).  *out_len receives
  * the total ISIZE (also when out_cap is too small).  check_crc != 0 verifies every block's CRC32.

@@ -58,7 +58,21 @@ typedef struct ngsq_synth_config {
     uint32_t max_len;   /* MIXED: 300                                                  */
     uint32_t ref_len;   /* length of reference 0 (chr1 = 248 956 422)                  */
     uint32_t n_refs;    /* 1, or 2 (reference 1 only ever appears as a mate reference) */
+    uint32_t file_style; /* ngsq_synth_write_bam only: NGSQ_SYNTH_FILE_* bits (0 = round 1-3 files)  */
+    uint32_t reserved;
 } ngsq_synth_config;
+
+/* What a record of a synthetic BAM FILE carries besides the generator's fields (ngsq_synth_write_bam; the batches of
+ * ngsq_synth_fill_* have no names or tags).  0: the name "r<index>", no auxiliary data (274 B per 150-base record) --
+ * the files of rounds 1-3, which no aligner writes.  ALIGNER: what bwa-mem + samtools fixmate/markdup leave behind --
+ * an Illumina read name (37-39 characters, shared by the two reads of a pair), NM MD MC AS XS MQ RG on every mapped
+ * record, SA on supplementary and a few other records, XA on a few per cent, a B array on a few per cent.
+ * CIGAR_MIX (FIXED mode only; MIXED has its own mix): 15 % of the mapped records get a soft clip, an insertion or a
+ * deletion instead of <l>M, so the CIGAR column of the file's batches is in the offsets layout. */
+#define NGSQ_SYNTH_FILE_PLAIN 0u
+#define NGSQ_SYNTH_FILE_ALIGNER 1u
+#define NGSQ_SYNTH_FILE_CIGAR_MIX 2u
+#define NGSQ_SYNTH_FILE_REALISTIC 3u
 
 /* fixed-width part of one synthetic record */
 typedef struct ngsq_synth_record {
@@ -82,6 +96,8 @@ typedef struct ngsq_synth_record {
 #define NGSQ_KEY_CIGAR 6ull
 #define NGSQ_KEY_SEQ 7ull
 #define NGSQ_KEY_QUAL 8ull
+#define NGSQ_KEY_NAME 9ull
+#define NGSQ_KEY_AUX 10ull
 
 NGSQ_HD uint64_t ngsq_synth_hash(uint64_t seed, uint64_t i, uint64_t key, uint64_t word) {
     return ngsq_mix64(ngsq_mix64(seed ^ (key << 56) ^ i) + word);

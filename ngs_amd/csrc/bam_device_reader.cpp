@@ -271,6 +271,7 @@ struct DeviceIngest {
     int cur_slot = 0;             // slot of the chunk being handed out
     uint64_t carry_len = 0;       // bytes of the view in front of the current chunk's first byte
     bool last_chunk = false;      // the chunk being handed out is the range's last
+    ngsq_bam_ingest_stats stats{}; // ngsq_bam_device_stats
     ~DeviceIngest() {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -661,6 +662,8 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     *out_total = 0;
     *out_entry = find ? d->raw_len : first;
     if (!n_seg) return NGSQ_OK;
+    d->stats.chunks += 1;
+    d->stats.segments += n_seg;
     // (the candidate table is written straight into pinned host memory and the segments' verdicts are read from it: see
     // k_copy_words in bam_device.hip for why nothing here is a hipMemcpyAsync)
     BHIP(d->h_cand.reserve((size_t)n_seg * REC_CANDIDATES * sizeof(RecCandidate)));
@@ -727,6 +730,7 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
             memcpy(&one, h_small + 8, sizeof one);
             c = &one; // an invalid record stops the walk: k_rec_offsets reports its index
             chosen[s] = 0;
+            d->stats.walk_one += 1;
         }
         total_rec += c->count;
         // an invalid record ends the chain: the later segments get no entry (k_rec_offsets then reports
@@ -1167,18 +1171,29 @@ extern "C" int ngsq_bam_shard_begin(ngsq_bam *b, ngsq_ctx *c, uint32_t shard, ui
     return start_ingest(b, c, d);
 }
 
-extern "C" int ngsq_bam_shard_end(ngsq_bam *b, ngsq_bam_shard_info *out) {
-    if (!b || !out) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+// What ngsq_bam_shard_verify needs of a shard whether or not its scan reached the end: *assumed = the scan ran from an
+// ASSUMED first record (not the header, not an offset a neighbour confirmed) -- a failure of such a scan may be the
+// assumption's fault (a chain of plausible records inside somebody's auxiliary data that dies later) and is forgiven
+// once: the shard is scanned again from the confirmed offset.
+int ngsq_bam_shard_peek(ngsq_bam *b, ngsq_bam_shard_info *out, int *assumed) {
+    memset(out, 0, sizeof *out);
+    *assumed = 0;
     if (!b->dev || !b->dev->sharded) return ngsq_bam_fail(NGSQ_ERR_STATE, "ngsq_bam_shard_begin first");
     DeviceIngest *d = b->dev;
+    *assumed = d->entry_mode == DeviceIngest::ENTRY_FIND;
     if (!d->complete) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: the shard has not been scanned to its end", b->path.c_str());
-    memset(out, 0, sizeof *out);
     out->n_records = d->n_own;
     out->begin_voffset = d->begin_voffset;
     out->end_voffset = d->end_voffset;
     out->first_key = d->n_own ? sort_key(d->first_key) : 0;
     out->last_key = d->n_own ? sort_key(d->last_key) : 0;
     return NGSQ_OK;
+}
+
+extern "C" int ngsq_bam_shard_end(ngsq_bam *b, ngsq_bam_shard_info *out) {
+    if (!b || !out) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    int assumed = 0;
+    return ngsq_bam_shard_peek(b, out, &assumed);
 }
 
 extern "C" {
@@ -1337,6 +1352,16 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     }
     if (cig1) out->cigar_stride = 1;
     else out->cigar_off = col.cigar_off;
+    d->stats.batches += 1;
+    d->stats.batches_fixed_rows += fixed;
+    d->stats.batches_one_op += cig1;
+    return NGSQ_OK;
+}
+
+int ngsq_bam_device_stats(const ngsq_bam *b, ngsq_bam_ingest_stats *out) {
+    if (!b || !out) return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "null argument");
+    if (!b->dev) return ngsq_bam_fail(NGSQ_ERR_STATE, "%s: no device ingest on this handle", b->path.c_str());
+    *out = b->dev->stats;
     return NGSQ_OK;
 }
 int ngsq_bgzf_inflate_device(ngsq_ctx *c, const uint8_t *comp, uint64_t comp_len, uint8_t *out, uint64_t out_cap,

@@ -123,6 +123,9 @@ struct ngsq_bam {
     void (*dev_free)(ngsq::DeviceIngest *) = nullptr;
 };
 
+// bam_device_reader.cpp: ngsq_bam_shard_end that also says whether the shard's first record was an assumption
+int ngsq_bam_shard_peek(ngsq_bam *b, ngsq_bam_shard_info *out, int *assumed);
+
 // message of this thread's last failing ngsq_bam_* call (bam_reader.cpp)
 int ngsq_bam_fail(int code, const char *fmt, ...);
 

@@ -786,27 +786,32 @@ int main(int argc, char **argv) {
         // compare the record boundaries they assumed when all have reached their end (ngsq_bam_shard_verify), and
         // a shard whose assumption was wrong scans again from the confirmed offset
         if (ngsq_bam_shard_open(bam, ctx, comm) != NGSQ_OK) bail(ngsq_comm_last_error(comm));
+        bool scanning = true;
+        std::string scan_error; // a worker that fails still meets the others in the collective: nobody waits for it
         for (;;) {
-            std::string scan_error; // a worker that fails still meets the others in the collective: nobody waits for it
-            n_pass1 = 0;
-            for (;;) {
-                ngsq_batch b;
-                if (ngsq_bam_next_batch_device(bam, ctx, a.batch_records, &b) != NGSQ_OK) {
-                    scan_error = ngsq_bam_last_error();
-                    break;
+            if (scanning) {
+                scan_error.clear();
+                n_pass1 = 0;
+                for (;;) {
+                    ngsq_batch b;
+                    if (ngsq_bam_next_batch_device(bam, ctx, a.batch_records, &b) != NGSQ_OK) {
+                        scan_error = ngsq_bam_last_error();
+                        break;
+                    }
+                    if (!b.n_records) break;
+                    if (ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH) != NGSQ_OK) {
+                        scan_error = ngsq_last_error(ctx);
+                        break;
+                    }
+                    n_pass1 += b.n_records;
                 }
-                if (!b.n_records) break;
-                if (ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH) != NGSQ_OK) {
-                    scan_error = ngsq_last_error(ctx);
-                    break;
-                }
-                n_pass1 += b.n_records;
             }
             ngsq_bam_shard_info info;
             int again = 0;
             comm_ready();
             const int vrc = ngsq_bam_shard_verify(bam, ctx, comm, &info, &again);
-            if (!scan_error.empty()) bail(scan_error);
+            // (a scan that failed while it ran from an ASSUMED first record is forgiven once: the verdict is `again`)
+            if (vrc != NGSQ_OK && !scan_error.empty()) bail(scan_error);
             if (vrc == NGSQ_ERR_UNSORTED) { // neighbouring shards out of coordinate order: same verdict on every worker
                 shard_unsorted = true;
                 break;
@@ -817,8 +822,10 @@ int main(int argc, char **argv) {
                      (unsigned long long)info.first_record_index);
                 break;
             }
-            if (info.rescan) {
-                logf(1, "worker %d: the assumed first record of its shard was not one; scanning the shard again from the confirmed offset", a.rank);
+            scanning = info.rescan != 0;
+            if (scanning) {
+                logf(1, "worker %d: the assumed first record of its shard was not one%s; scanning the shard again from the confirmed offset", a.rank,
+                     scan_error.empty() ? "" : (" (" + scan_error + ")").c_str());
                 CHECK(ctx, ngsq_reset(ctx));
             }
         }

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <vector>
 
+#include "bam_reader.h"
 #include "comm.h"
 #include "context.h"
 
@@ -513,35 +514,45 @@ extern "C" int ngsq_bam_shard_verify(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *co
     const uint32_t world = (uint32_t)comm->world, rank = (uint32_t)comm->rank;
     *again = 0;
     ngsq_bam_shard_info info{};
-    // a rank whose scan failed still takes part in the collective (with a poison value) so that nobody hangs
-    const int rc_end = ngsq_bam_shard_end(bam, &info);
+    // a rank whose scan failed still takes part in the collective so that nobody hangs
+    int assumed = 0;
+    const int rc_end = ngsq_bam_shard_peek(bam, &info, &assumed);
     const std::string why = rc_end ? ngsq_bam_last_error() : "";
-    constexpr size_t W = 6;
+    constexpr size_t W = 8;
+    enum { R_N, R_BEGIN, R_END, R_FAILED, R_FIRST_KEY, R_LAST_KEY, R_ASSUMED };
     std::vector<uint64_t> rows(W * (size_t)world);
-    const uint64_t mine[W] = {info.n_records, info.begin_voffset, info.end_voffset, (uint64_t)(rc_end != NGSQ_OK), info.first_key, info.last_key};
+    const uint64_t mine[W] = {info.n_records, info.begin_voffset, info.end_voffset, (uint64_t)(rc_end != NGSQ_OK), info.first_key, info.last_key,
+                              (uint64_t)assumed, 0};
     const int rc2 = ngsq_comm_allgather_host(comm, mine, rows.data(), sizeof mine);
     if (rc2) return rc2;
-    if (rc_end) return comm_fail(comm, rc_end, "%s", why.c_str());
+    auto row = [&](uint32_t k, int f) { return rows[W * k + (size_t)f]; };
+    // Shard k+1 must begin where shard k's record chain ends (shards without a record start pass it on: begin == end).  By
+    // induction from the header shard 0 is right, hence its end, hence shard 1's begin once corrected, ...: a shard whose begin
+    // differs from its predecessor's end scans again from there (its end may change with it, so everybody compares again
+    // afterwards; at most `world` rounds).  A shard whose scan FAILED while it ran on an assumed first record is treated the
+    // same way -- a chain of plausible records inside somebody's auxiliary data can die later (round 4) -- but only
+    // that once: a failure of shard 0, or of a scan from a confirmed offset, is the file's and every rank returns it.
     for (uint32_t k = 0; k < world; k++)
-        if (rows[W * k + 3]) return comm_fail(comm, NGSQ_ERR_STATE, "shard %u of the file failed", k);
-    // shard k+1 must begin where shard k's record chain ends (shards without a record start pass it on: begin == end)
+        if (row(k, R_FAILED) && (k == 0 || !row(k, R_ASSUMED))) {
+            if (k == rank) return comm_fail(comm, rc_end, "%s", why.c_str());
+            return comm_fail(comm, NGSQ_ERR_STATE, "shard %u of the file failed", k);
+        }
     bool stable = true;
     uint64_t first = 0;
     for (uint32_t k = 0; k < world; k++) {
-        if (k) stable = stable && rows[W * (k - 1) + 2] == rows[W * k + 1];
-        if (k < rank) first += rows[W * k];
+        if (row(k, R_FAILED)) stable = false;
+        else if (k && !row(k - 1, R_FAILED)) stable = stable && row(k - 1, R_END) == row(k, R_BEGIN);
+        if (k < rank) first += row(k, R_N);
     }
     if (!stable) {
-        // By induction from the header shard 0 is right, hence its end, hence shard 1's begin once corrected, ...: a
-        // shard whose begin differs from its predecessor's end scans again from there (its end may change with it, so
-        // everybody compares again afterwards; at most `world` rounds).
         *again = 1;
         *out = info;
-        if (rank && rows[W * (rank - 1) + 2] != info.begin_voffset) {
+        // (behind a shard that failed nothing is known yet: its successor waits for the next round)
+        if (rank && !row(rank - 1, R_FAILED) && (rc_end != NGSQ_OK || row(rank - 1, R_END) != info.begin_voffset)) {
             out->rescan = 1;
-            const int rc = ngsq_bam_shard_begin(bam, ctx, rank, world, rows[W * (rank - 1) + 2]);
-            // (a failure shows in the next round: the handle has no finished scan, every rank gets the error)
-            if (rc) return comm_fail(comm, rc, "%s", ngsq_bam_last_error());
+            // a failure to re-arm shows in the next round (the handle then holds a failed scan from a confirmed offset:
+            // every rank gets the error); returning it here would leave the others waiting in that round's all-gather
+            (void)ngsq_bam_shard_begin(bam, ctx, rank, world, row(rank - 1, R_END));
         }
         return NGSQ_OK;
     }
@@ -554,10 +565,10 @@ extern "C" int ngsq_bam_shard_verify(ngsq_bam *bam, ngsq_ctx *ctx, ngsq_comm *co
         uint64_t prev_last = 0;
         bool have = false;
         for (uint32_t k = 0; k < world; k++) {
-            if (!rows[W * k]) continue;
-            if (have && rows[W * k + 4] < prev_last)
+            if (!row(k, R_N)) continue;
+            if (have && row(k, R_FIRST_KEY) < prev_last)
                 return comm_fail(comm, NGSQ_ERR_UNSORTED, "sorted_input: shard %u begins in front of the last record of the shard before it", k);
-            prev_last = rows[W * k + 5];
+            prev_last = row(k, R_LAST_KEY);
             have = true;
         }
     }

@@ -5,6 +5,7 @@
 // unseeded RNG, src/generate/command.rs:59-131, and cannot produce these files).
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <map>
@@ -41,36 +42,191 @@ struct RecIdx { // what the index needs to know about one record
     uint32_t uoff;         // offset of the record in its block's data
 };
 
-void append_record(std::vector<uint8_t> &out, const ngsq_synth_config &cfg, uint64_t i, RecIdx *ix) {
+// ---- what an aligner's output carries around the generator's fields (NGSQ_SYNTH_FILE_ALIGNER) ----------------------
+// Shapes and sizes follow bwa-mem + samtools fixmate / markdup output on an Illumina NovaSeq run: every value is a pure
+// function of (seed, record index), like the records themselves.
+void put_z(std::vector<uint8_t> &v, const char tag[2], const char *text) { // XX:Z:<text>
+    v.push_back((uint8_t)tag[0]);
+    v.push_back((uint8_t)tag[1]);
+    v.push_back('Z');
+    v.insert(v.end(), text, text + strlen(text) + 1);
+}
+void put_c(std::vector<uint8_t> &v, const char tag[2], uint32_t x) { // XX:i:<x> in its smallest type, as htslib writes it
+    v.push_back((uint8_t)tag[0]);
+    v.push_back((uint8_t)tag[1]);
+    if (x < 256) {
+        v.push_back('C');
+        v.push_back((uint8_t)x);
+    } else if (x < 65536) {
+        v.push_back('S');
+        put16(v, x);
+    } else {
+        v.push_back('I');
+        put32(v, x);
+    }
+}
+
+// the read name: instrument, run, flowcell, lane, tile, x, y -- the two reads of a pair (records 2k, 2k+1) share it
+int illumina_name(const ngsq_synth_config &cfg, uint64_t i, char *out, size_t cap) {
+    const uint64_t h = ngsq_synth_hash(cfg.seed, i >> 1, NGSQ_KEY_NAME, 0);
+    const uint32_t lane = 1 + (uint32_t)(h & 3), surface = 1 + (uint32_t)((h >> 2) & 1), swath = 1 + (uint32_t)((h >> 3) % 6),
+                   tile = 1 + (uint32_t)((h >> 8) % 78), x = 1000 + (uint32_t)((h >> 16) % 31624), y = 1000 + (uint32_t)((h >> 32) % 36000);
+    return snprintf(out, cap, "A00741:215:HG7WKDSXX:%u:%u%u%02u:%u:%u", lane, surface, swath, tile, x, y) + 1;
+}
+
+void append_aux(std::vector<uint8_t> &out, const ngsq_synth_config &cfg, uint64_t i, const ngsq_synth_record &r, const uint32_t *cig,
+                uint32_t n_cig) {
+    const uint64_t h = ngsq_synth_hash(cfg.seed, i, NGSQ_KEY_AUX, 0), h2 = ngsq_synth_hash(cfg.seed, i, NGSQ_KEY_AUX, 1);
+    const bool mapped = !(r.flag & 0x4u), paired = r.flag & 0x1u, mate_mapped = paired && !(r.flag & 0x8u);
+    char text[256];
+    const uint32_t lane = 1 + (uint32_t)(ngsq_synth_hash(cfg.seed, i >> 1, NGSQ_KEY_NAME, 0) & 3);
+    if (mapped) {
+        // NM: 0 (70 %), 1 (20 %), 2 (6 %), 3..8; MD: the matched runs between the mismatches, ^<bases> for a deletion
+        const uint32_t d = (uint32_t)(h & 0xFFFF);
+        uint32_t nm = d < 45875u ? 0 : d < 58982u ? 1 : d < 62915u ? 2 : 3 + (uint32_t)((h >> 16) % 6);
+        uint32_t m_total = 0, indel = 0;
+        for (uint32_t k = 0; k < n_cig; k++) {
+            const uint32_t op = cig[k] & 15, len = cig[k] >> 4;
+            if (op == 0) m_total += len;
+            if (op == 1 || op == 2) indel += len;
+        }
+        if (nm > m_total) nm = m_total;
+        int at = 0;
+        uint32_t left = nm, hh = (uint32_t)(h >> 24);
+        for (uint32_t k = 0; k < n_cig; k++) {
+            const uint32_t op = cig[k] & 15;
+            uint32_t len = cig[k] >> 4;
+            if (op == 2) {
+                at += snprintf(text + at, sizeof text - (size_t)at, "^");
+                for (uint32_t q = 0; q < len && at < 200; q++) text[at++] = "ACGT"[(hh >> (2 * (q & 7))) & 3];
+                text[at] = 0;
+            }
+            if (op != 0) continue;
+            // the last M run takes the mismatches that are left
+            bool last_m = true;
+            for (uint32_t q = k + 1; q < n_cig; q++) last_m = last_m && (cig[q] & 15) != 0;
+            uint32_t here = last_m ? left : std::min(left, (uint32_t)(hh & 1));
+            left -= here;
+            while (here && len > 1 && at < 200) {
+                const uint32_t run = (hh = hh * 1664525u + 1013904223u, hh >> 8) % (len - 1);
+                at += snprintf(text + at, sizeof text - (size_t)at, "%u%c", run, "ACGT"[hh & 3]);
+                len -= run + 1;
+                here--;
+            }
+            at += snprintf(text + at, sizeof text - (size_t)at, "%u", len);
+        }
+        put_c(out, "NM", nm + indel);
+        put_z(out, "MD", text);
+    }
+    if (paired) { // samtools fixmate -m: the mate's CIGAR and mapping quality
+        const uint32_t l = r.l_seq, a = 1 + (uint32_t)((h2 >> 8) % 40);
+        if (!mate_mapped) snprintf(text, sizeof text, "*");
+        else if ((h2 & 0xFF) < 26) snprintf(text, sizeof text, "%uS%uM", a, l > a ? l - a : 1);
+        else snprintf(text, sizeof text, "%uM", l);
+        put_z(out, "MC", text);
+    }
+    if (mapped) {
+        uint32_t m_total = 0;
+        for (uint32_t k = 0; k < n_cig; k++)
+            if ((cig[k] & 15) == 0) m_total += cig[k] >> 4;
+        const uint32_t pen = 5 * (uint32_t)((h & 0xFFFF) < 45875u ? 0 : 1 + (h >> 16) % 3);
+        put_c(out, "AS", m_total > pen ? m_total - pen : 0);
+        put_c(out, "XS", (h2 >> 16 & 0xFF) < 154 ? 0 : 19 + (uint32_t)((h2 >> 24) % 120));
+    }
+    if (mate_mapped) put_c(out, "MQ", (h2 >> 40 & 0xFF) < 200 ? 60 : (uint32_t)((h2 >> 48) % 60));
+    snprintf(text, sizeof text, "HG7WKDSXX.L00%u.SJNORM0415", lane);
+    put_z(out, "RG", text);
+    const uint64_t h3 = ngsq_synth_hash(cfg.seed, i, NGSQ_KEY_AUX, 2);
+    if (mapped && ((r.flag & 0x800u) || (h3 & 0xFFFF) < 983u)) { // SA: supplementary records and 1.5 % of the others
+        char cg[64];
+        const uint32_t l = r.l_seq, a = 20 + (uint32_t)((h3 >> 16) % (l > 60 ? l - 40 : 1));
+        snprintf(cg, sizeof cg, "%uS%uM", a, l > a ? l - a : 1);
+        snprintf(text, sizeof text, "chr%u,%u,%c,%s,%u,%u;", 1 + (uint32_t)((h3 >> 32) % 22), 10000 + (uint32_t)((h3 >> 24) % 200000000u), (h3 >> 40) & 1 ? '+' : '-', cg,
+                 (uint32_t)((h3 >> 44) % 61), (uint32_t)((h3 >> 52) % 4));
+        put_z(out, "SA", text);
+    }
+    if (mapped && (h3 >> 56 & 0xFF) < 8) { // XA: one to three alternative hits on 3 %
+        int at = 0;
+        uint64_t x = h3;
+        for (uint32_t k = 0, n = 1 + (uint32_t)((h3 >> 20) % 3); k < n; k++) {
+            x = ngsq_mix64(x);
+            at += snprintf(text + at, sizeof text - (size_t)at, "chr%u,%c%u,%uM,%u;", 1 + (uint32_t)(x % 22), (x >> 8) & 1 ? '+' : '-', 10000 + (uint32_t)((x >> 16) % 200000000u), r.l_seq,
+                           (uint32_t)((x >> 48) % 5));
+        }
+        put_z(out, "XA", text);
+    }
+    if (((h3 >> 48) & 0xFF) < 5) { // a B array on 2 %: per-base values of some downstream tool, 8..40 of them
+        const uint32_t n = 8 + (uint32_t)((h3 >> 8) % 33);
+        out.push_back('Z');
+        out.push_back('B');
+        out.push_back('B');
+        out.push_back('S');
+        put32(out, n);
+        uint64_t x = h3;
+        for (uint32_t k = 0; k < n; k++) {
+            if ((k & 3) == 0) x = ngsq_mix64(x);
+            put16(out, (uint32_t)(x >> (16 * (k & 3))) & 0xFFFF);
+        }
+    }
+}
+
+void append_record(std::vector<uint8_t> &out, const ngsq_synth_config &cfg, uint64_t i, RecIdx *ix, std::vector<uint8_t> &aux) {
     ngsq_synth_record r;
     ngsq_synth_record_at(&cfg, i, &r);
     ix->uoff = (uint32_t)out.size();
-    char name[32];
-    const int ln = snprintf(name, sizeof name, "r%llu", (unsigned long long)i) + 1;
+    const bool aligner = cfg.file_style & NGSQ_SYNTH_FILE_ALIGNER;
+    char name[64];
+    const int ln = aligner ? illumina_name(cfg, i, name, sizeof name) : snprintf(name, sizeof name, "r%llu", (unsigned long long)i) + 1;
+    const uint32_t l = r.l_seq;
+    uint32_t cig[NGSQ_SYNTH_MAX_OPS] = {r.cigar[0], r.cigar[1], r.cigar[2]}, n_cig = r.n_cigar;
+    if ((cfg.file_style & NGSQ_SYNTH_FILE_CIGAR_MIX) && cfg.mode == NGSQ_SYNTH_FIXED && n_cig == 1 && l >= 50) {
+        // 15 % of the mapped reads: 9 % soft-clipped at one end (1..60 bases), 3 % an insertion, 3 % a deletion (1..8 bases)
+        const uint64_t hc = ngsq_synth_hash(cfg.seed, i, NGSQ_KEY_CIGAR, 7);
+        const uint32_t kind = (uint32_t)(hc & 0xFFFF), side = (uint32_t)((hc >> 16) & 1), r1 = (uint32_t)((hc >> 24) & 0xFFFF), r2 = (uint32_t)((hc >> 40) & 0xFFFF);
+        if (kind < 5898u) {
+            const uint32_t a = 1 + r1 % std::min(60u, l - 20), b = l - a;
+            n_cig = 2;
+            cig[0] = side ? (a << 4 | 4u) : (b << 4 | 0u);
+            cig[1] = side ? (b << 4 | 0u) : (a << 4 | 4u);
+        } else if (kind < 9830u) {
+            const uint32_t g = 1 + r1 % 8;
+            n_cig = 3;
+            if (kind < 7864u) { // insertion: a + g + b = l
+                const uint32_t a = 1 + r2 % (l - g - 1), b = l - g - a;
+                cig[0] = a << 4 | 0u, cig[1] = g << 4 | 1u, cig[2] = b << 4 | 0u;
+            } else {
+                const uint32_t a = 1 + r2 % (l - 1), b = l - a;
+                cig[0] = a << 4 | 0u, cig[1] = g << 4 | 2u, cig[2] = b << 4 | 0u;
+            }
+        }
+    }
     uint64_t span = 0;
-    for (uint32_t k = 0; k < r.n_cigar; k++)
-        if ((0x18Du >> (r.cigar[k] & 15)) & 1u) span += r.cigar[k] >> 4;
+    for (uint32_t k = 0; k < n_cig; k++)
+        if ((0x18Du >> (cig[k] & 15)) & 1u) span += cig[k] >> 4;
     ix->ref = r.ref_id;
     ix->pos = r.pos;
     ix->end = r.pos + (int32_t)(span ? span : 1);
-    const uint32_t l = r.l_seq;
-    const uint32_t block = 32 + (uint32_t)ln + 4 * r.n_cigar + (l + 1) / 2 + l;
+    aux.clear();
+    if (aligner) append_aux(aux, cfg, i, r, cig, n_cig);
+    const uint32_t block = 32 + (uint32_t)ln + 4 * n_cig + (l + 1) / 2 + l + (uint32_t)aux.size();
     put32(out, block);
     put32(out, (uint32_t)r.ref_id);
     put32(out, (uint32_t)r.pos);
     out.push_back((uint8_t)ln);
     out.push_back(r.mapq);
     put16(out, reg2bin(r.pos, r.pos + (int64_t)(span ? span : 1)));
-    put16(out, r.n_cigar);
+    put16(out, n_cig);
     put16(out, r.flag);
     put32(out, l);
     put32(out, (uint32_t)r.mate_ref_id);
-    put32(out, (uint32_t)-1);
+    // (the mate's position: the files of rounds 1-3 say -1; an aligner's say where the mate starts)
+    put32(out, aligner && (r.flag & 0x1u) ? (uint32_t)std::max<int64_t>(0, (int64_t)r.pos + r.tlen - (r.tlen > 0 ? (int64_t)l : -(int64_t)l)) : (uint32_t)-1);
     put32(out, (uint32_t)r.tlen);
     out.insert(out.end(), name, name + ln);
-    for (uint32_t k = 0; k < r.n_cigar; k++) put32(out, r.cigar[k]);
+    for (uint32_t k = 0; k < n_cig; k++) put32(out, cig[k]);
     for (uint32_t j = 0; j < (l + 1) / 2; j++) out.push_back(ngsq_synth_seq_byte(&cfg, i, l, j));
     for (uint32_t j = 0; j < l; j++) out.push_back(ngsq_synth_qual_byte(&cfg, i, l, j));
+    out.insert(out.end(), aux.begin(), aux.end());
 }
 
 bool bgzf_write(FILE *f, const uint8_t *data, size_t n, int level, std::vector<uint8_t> &scratch) {
@@ -156,48 +312,82 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
     };
     // ---- records: groups of records rendered and deflated in parallel, written in order
     const int nt = n_threads > 0 ? n_threads : ngsq::effective_cores();
-    const uint64_t group = 100; // records per BGZF block (100 x ~270 B < 64 KiB even at 300 bp)
+    // Records per group = per BGZF block.  Plain files: 100 (27 KB of data at 150 bases -- the files of rounds 1-3, kept as they
+    // were).  Aligner-style files fill their blocks as htslib does: as many whole records as fit 0xff00 bytes of data, here
+    // by an estimate of the record size; a group that comes out larger is written as two blocks.
+    constexpr size_t BLOCK_DATA = 0xff00;
+    uint64_t group = 100;
+    if (cfg->file_style & NGSQ_SYNTH_FILE_ALIGNER) {
+        const uint64_t l = cfg->mode == NGSQ_SYNTH_FIXED ? cfg->read_len : (cfg->min_len + cfg->max_len) / 2;
+        group = std::max<uint64_t>(1, BLOCK_DATA * 96 / 100 / (36 + 39 + 12 + 85 + l + (l + 1) / 2));
+    }
     const uint64_t n_groups = (n_records + group - 1) / group;
     const uint64_t wave = (uint64_t)nt * 64;
+    struct Group {
+        std::vector<uint8_t> bytes;       // its BGZF blocks, one after the other
+        std::vector<uint32_t> block_size; // of each
+        std::vector<RecIdx> recs;         // uoff: offset in the data of block `blk`
+        std::vector<uint32_t> blk;
+    };
     for (uint64_t g0 = 0; g0 < n_groups && ok; g0 += wave) {
         const uint64_t g1 = std::min(n_groups, g0 + wave);
-        std::vector<std::vector<uint8_t>> blocks(g1 - g0);
-        std::vector<std::vector<RecIdx>> recs(g1 - g0);
+        std::vector<Group> groups(g1 - g0);
         std::atomic<uint64_t> next{g0};
         std::atomic<int> bad{0};
         auto worker = [&]() {
-            std::vector<uint8_t> raw, sc;
+            std::vector<uint8_t> raw, sc, aux;
+            std::vector<size_t> rec_at;
             for (;;) {
                 const uint64_t g = next.fetch_add(1);
                 if (g >= g1) break;
                 raw.clear();
-                auto &rx = recs[g - g0];
+                rec_at.clear();
+                Group &gr = groups[g - g0];
                 for (uint64_t i = g * group; i < std::min(n_records, (g + 1) * group); i++) {
-                    rx.emplace_back();
-                    append_record(raw, *cfg, i, &rx.back());
+                    gr.recs.emplace_back();
+                    rec_at.push_back(raw.size());
+                    append_record(raw, *cfg, i, &gr.recs.back(), aux);
                 }
-                // deflate into a memory "file"
-                z_stream zs;
-                memset(&zs, 0, sizeof zs);
-                if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; continue; }
-                sc.resize(deflateBound(&zs, (uLong)raw.size()) + 64);
-                zs.next_in = raw.data();
-                zs.avail_in = (uInt)raw.size();
-                zs.next_out = sc.data() + 18;
-                zs.avail_out = (uInt)(sc.size() - 18);
-                const int rc = deflate(&zs, Z_FINISH);
-                const size_t clen = zs.total_out;
-                deflateEnd(&zs);
-                if (rc != Z_STREAM_END || clen + 26 > 65536 || raw.size() > 65536) { bad = 1; continue; }
-                static const uint8_t hd[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
-                memcpy(sc.data(), hd, 16);
-                const size_t bsize = clen + 26;
-                sc[16] = (uint8_t)((bsize - 1) & 0xFF);
-                sc[17] = (uint8_t)((bsize - 1) >> 8);
-                uint8_t *tail = sc.data() + 18 + clen;
-                const uint32_t crc = (uint32_t)crc32(0L, raw.data(), (uInt)raw.size()), isz = (uint32_t)raw.size();
-                for (int k = 0; k < 4; k++) tail[k] = (uint8_t)(crc >> (8 * k)), tail[4 + k] = (uint8_t)(isz >> (8 * k));
-                blocks[g - g0].assign(sc.begin(), sc.begin() + (ptrdiff_t)bsize);
+                rec_at.push_back(raw.size());
+                // cut into blocks of whole records (one, unless the estimate above was too low; a single record larger than a
+                // block's data is cut anywhere, as htslib does)
+                size_t lo = 0, r_lo = 0;
+                while (lo < raw.size()) {
+                    size_t r_hi = r_lo;
+                    while (r_hi + 1 < rec_at.size() && rec_at[r_hi + 1] - lo <= BLOCK_DATA) r_hi++;
+                    const size_t hi = r_hi > r_lo ? rec_at[r_hi] : std::min(raw.size(), lo + BLOCK_DATA);
+                    for (size_t r = r_lo; r < gr.recs.size() && rec_at[r] < hi; r++) {
+                        if (rec_at[r] < lo) continue; // (the record the previous block was cut in)
+                        gr.recs[r].uoff = (uint32_t)(rec_at[r] - lo);
+                        gr.blk.resize(gr.recs.size());
+                        gr.blk[r] = (uint32_t)gr.block_size.size();
+                    }
+                    // deflate into a memory "file"
+                    z_stream zs;
+                    memset(&zs, 0, sizeof zs);
+                    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad = 1; break; }
+                    sc.resize(deflateBound(&zs, (uLong)(hi - lo)) + 64);
+                    zs.next_in = raw.data() + lo;
+                    zs.avail_in = (uInt)(hi - lo);
+                    zs.next_out = sc.data() + 18;
+                    zs.avail_out = (uInt)(sc.size() - 18);
+                    const int rc = deflate(&zs, Z_FINISH);
+                    const size_t clen = zs.total_out;
+                    deflateEnd(&zs);
+                    if (rc != Z_STREAM_END || clen + 26 > 65536 || hi - lo > 65536) { bad = 1; break; }
+                    static const uint8_t hd[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+                    memcpy(sc.data(), hd, 16);
+                    const size_t bsize = clen + 26;
+                    sc[16] = (uint8_t)((bsize - 1) & 0xFF);
+                    sc[17] = (uint8_t)((bsize - 1) >> 8);
+                    uint8_t *tail = sc.data() + 18 + clen;
+                    const uint32_t crc = (uint32_t)crc32(0L, raw.data() + lo, (uInt)(hi - lo)), isz = (uint32_t)(hi - lo);
+                    for (int k = 0; k < 4; k++) tail[k] = (uint8_t)(crc >> (8 * k)), tail[4 + k] = (uint8_t)(isz >> (8 * k));
+                    gr.bytes.insert(gr.bytes.end(), sc.begin(), sc.begin() + (ptrdiff_t)bsize);
+                    gr.block_size.push_back((uint32_t)bsize);
+                    lo = hi;
+                    while (r_lo < gr.recs.size() && rec_at[r_lo] < lo) r_lo++;
+                }
             }
         };
         std::vector<std::thread> pool;
@@ -205,13 +395,14 @@ extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *pa
         worker();
         for (auto &t : pool) t.join();
         if (bad) ok = false;
-        for (size_t k = 0; k < blocks.size() && ok; k++) {
-            const auto &b = blocks[k];
-            if (fwrite(b.data(), 1, b.size(), f) != b.size()) ok = false;
-            const uint64_t next_off = file_off + b.size();
-            const auto &rx = recs[k];
-            for (size_t j = 0; j < rx.size(); j++)
-                index_record(rx[j], (file_off << 16) | rx[j].uoff, j + 1 < rx.size() ? (file_off << 16) | rx[j + 1].uoff : next_off << 16);
+        for (size_t k = 0; k < groups.size() && ok; k++) {
+            const Group &gr = groups[k];
+            if (fwrite(gr.bytes.data(), 1, gr.bytes.size(), f) != gr.bytes.size()) ok = false;
+            std::vector<uint64_t> start(gr.block_size.size() + 1, file_off);
+            for (size_t q = 0; q < gr.block_size.size(); q++) start[q + 1] = start[q] + gr.block_size[q];
+            const uint64_t next_off = start.back();
+            auto voff = [&](size_t j) { return (start[gr.blk[j]] << 16) | gr.recs[j].uoff; };
+            for (size_t j = 0; j < gr.recs.size(); j++) index_record(gr.recs[j], voff(j), j + 1 < gr.recs.size() ? voff(j + 1) : next_off << 16);
             file_off = next_off;
         }
     }

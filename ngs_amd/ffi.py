@@ -51,6 +51,7 @@ PASS_BOTH = 3
 
 SYNTH_FIXED = 0
 SYNTH_MIXED = 1
+SYNTH_FILE_PLAIN, SYNTH_FILE_ALIGNER, SYNTH_FILE_CIGAR_MIX, SYNTH_FILE_REALISTIC = 0, 1, 2, 3  # ngsq_shared.h: what a synthetic BAM FILE carries
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
@@ -196,7 +197,14 @@ class SynthConfig(C.Structure):
         ("max_len", C.c_uint32),
         ("ref_len", C.c_uint32),
         ("n_refs", C.c_uint32),
+        ("file_style", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
+
+
+class IngestStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("chunks", "segments", "walk_one", "batches", "batches_fixed_rows", "batches_one_op",
+                                          "long_cigar_records", "reserved")]
 
 
 ctx_p = C.c_void_p
@@ -315,6 +323,7 @@ PROTOTYPES = {
     "ngsq_bam_next_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(Batch)]),
     "ngsq_bam_records_read": (C.c_uint64, [C.c_void_p]),
     "ngsq_bam_next_batch_device": (C.c_int, [C.c_void_p, ctx_p, C.c_uint64, C.POINTER(Batch)]),
+    "ngsq_bam_device_stats": (C.c_int, [C.c_void_p, C.POINTER(IngestStats)]),
     "ngsq_bam_shard_begin": (C.c_int, [C.c_void_p, ctx_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "ngsq_bam_shard_end": (C.c_int, [C.c_void_p, C.POINTER(ShardInfo)]),
     "ngsq_bgzf_inflate_device": (C.c_int, [ctx_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_int]),

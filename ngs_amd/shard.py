@@ -203,33 +203,37 @@ class Comm:
             if begin_hook is not None:
                 begin_hook(h)          # tests: plant a wrong assumption (ngsq_bam_shard_begin with another offset)
             rounds, mine, scanning = 0, 0, True
+            n, err = 0, None
             while True:
-                n, err = 0, None
-                while True:
-                    b = ffi.Batch()
-                    if self.lib.ngsq_bam_next_batch_device(h, ctx._ctx, batch_records, C.byref(b)) != 0:
-                        err = self.lib.ngsq_bam_last_error().decode()
-                        break
-                    if b.n_records == 0:
-                        break
-                    if on_batch is not None:
-                        on_batch(b)
-                    if self.lib.ngsq_process_batch(ctx._ctx, C.byref(b), pass_mask) != 0:
-                        err = (self.lib.ngsq_last_error(ctx._ctx) or b"").decode()
-                        break
-                    n += int(b.n_records)
+                if scanning:
+                    n, err = 0, None
+                    while True:
+                        b = ffi.Batch()
+                        if self.lib.ngsq_bam_next_batch_device(h, ctx._ctx, batch_records, C.byref(b)) != 0:
+                            err = self.lib.ngsq_bam_last_error().decode()
+                            break
+                        if b.n_records == 0:
+                            break
+                        if on_batch is not None:
+                            on_batch(b)
+                        if self.lib.ngsq_process_batch(ctx._ctx, C.byref(b), pass_mask) != 0:
+                            err = (self.lib.ngsq_last_error(ctx._ctx) or b"").decode()
+                            break
+                        n += int(b.n_records)
                 info, again = ffi.ShardInfo(), C.c_int(0)
-                # (a rank that failed calls it all the same: every rank then gets an error instead of waiting)
+                # (a rank that failed calls it all the same: every rank then gets an error instead of waiting -- unless the
+                # scan ran from an ASSUMED first record: then the assumption may be what failed, and the shard is scanned
+                # again from the offset its neighbour confirms)
                 rc = self.lib.ngsq_bam_shard_verify(h, ctx._ctx, self._h, C.byref(info), C.byref(again))
-                if err is not None:
+                if rc != 0 and err is not None:
                     raise RuntimeError(err)
                 self._check(rc)
-                if scanning:           # (a rank that keeps its state finds its reader at its end: no records this round)
+                if scanning and err is None:
                     mine = n
                 if not again.value:
                     return info, rounds, mine
                 rounds += 1
-                scanning = bool(info.rescan)
+                scanning = bool(info.rescan)    # (a rank that keeps its state does not touch its reader this round)
                 if scanning:
                     ctx.reset()
         finally:

@@ -29,7 +29,7 @@ def reg2bin(beg: int, end: int) -> int:
     return 0
 
 
-def record_bytes(hb, i: int, name: bytes = b"r") -> bytes:
+def record_bytes(hb, i: int, name: bytes = b"r", aux: bytes = b"", full_name: bytes | None = None) -> bytes:
     c = hb.cols
     l = int(c["l_seq"][i])
     if c["seq_off"] is not None:
@@ -44,13 +44,13 @@ def record_bytes(hb, i: int, name: bytes = b"r") -> bytes:
         cig = c["cigar"][int(c["cigar_off"][i]):int(c["cigar_off"][i + 1])]
     else:
         cig = c["cigar"][i * hb.cigar_stride:i * hb.cigar_stride + int(c["n_cigar"][i])]
-    nm = name + b"%d" % i + b"\0"
+    nm = (full_name if full_name is not None else name + b"%d" % i) + b"\0"
     pos = int(c["pos"][i])
     span = sum(int(x) >> 4 for x in cig if (int(x) & 15) in (0, 2, 3, 7, 8))
     bin_ = reg2bin(max(pos, 0), max(pos, 0) + max(span, 1))
     body = struct.pack("<iiBBHHHIiii", int(c["ref_id"][i]), pos, len(nm), int(c["mapq"][i]), bin_, len(cig),
                        int(c["flag"][i]), l, int(c["mate_ref_id"][i]), -1, int(c["tlen"][i]))
-    body += nm + np.asarray(cig, dtype="<u4").tobytes() + seq + q
+    body += nm + np.asarray(cig, dtype="<u4").tobytes() + seq + q + aux
     return struct.pack("<I", len(body)) + body
 
 
@@ -96,9 +96,91 @@ def write_bai(path: str, hb, n_refs: int, rec_voff: Sequence[int], end_voff: int
         f.write(struct.pack("<Q", n_no_coor))
 
 
+def aux_z(tag: bytes, text: bytes) -> bytes:
+    return tag + b"Z" + text + b"\0"
+
+
+def aux_int(tag: bytes, x: int) -> bytes:
+    """An integer tag in its smallest type, as htslib writes it."""
+    if 0 <= x < 256:
+        return tag + b"C" + bytes([x])
+    if 0 <= x < 65536:
+        return tag + b"S" + struct.pack("<H", x)
+    if x >= 0:
+        return tag + b"I" + struct.pack("<I", x)
+    return tag + b"i" + struct.pack("<i", x)
+
+
+def aux_array(tag: bytes, sub: bytes, payload: bytes) -> bytes:
+    w = {b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4}[sub]
+    assert len(payload) % w == 0
+    return tag + b"B" + sub + struct.pack("<I", len(payload) // w) + payload
+
+
+def aligner_name(rng) -> bytes:
+    """An Illumina read name, 37-39 characters (instrument:run:flowcell:lane:tile:x:y)."""
+    return b"A00741:215:HG7WKDSXX:%d:%d%d%02d:%d:%d" % (rng.integers(1, 5), rng.integers(1, 3), rng.integers(1, 7), rng.integers(1, 79),
+                                                        rng.integers(1000, 32624), rng.integers(1000, 37000))
+
+
+def aligner_aux(rng, l_seq: int, mapped: bool = True) -> bytes:
+    """What bwa-mem + samtools fixmate leave on a record: NM MD MC AS XS MQ RG, SA / XA / a B array on a few per cent."""
+    out = b""
+    if mapped:
+        nm = int(rng.choice([0, 0, 0, 1, 1, 2, 5]))
+        md = b"%d" % l_seq if nm == 0 or l_seq < 4 else b"%dA%d" % (l_seq // 3, l_seq - l_seq // 3 - 1)
+        out += aux_int(b"NM", nm) + aux_z(b"MD", md)
+    out += aux_z(b"MC", b"%dM" % max(l_seq, 1))
+    if mapped:
+        out += aux_int(b"AS", max(0, l_seq - 5 * int(rng.integers(0, 3)))) + aux_int(b"XS", int(rng.choice([0, 0, 19, 77, 300])))
+    out += aux_int(b"MQ", int(rng.choice([60, 60, 0, 17]))) + aux_z(b"RG", b"HG7WKDSXX.L00%d.SJNORM0415" % rng.integers(1, 5))
+    r = rng.random()
+    if r < 0.03:
+        out += aux_z(b"SA", b"chr%d,%d,+,%dS%dM,60,1;" % (rng.integers(1, 23), rng.integers(1, 2 * 10 ** 8), l_seq // 2, l_seq - l_seq // 2))
+    elif r < 0.06:
+        out += aux_z(b"XA", b";".join(b"chr%d,-%d,%dM,%d" % (rng.integers(1, 23), rng.integers(1, 2 * 10 ** 8), l_seq, k) for k in range(int(rng.integers(1, 4)))) + b";")
+    elif r < 0.08:
+        out += aux_array(b"ZB", b"S", rng.integers(0, 65536, int(rng.integers(0, 41))).astype("<u2").tobytes())
+    elif r < 0.09:
+        out += aux_int(b"ms", -int(rng.integers(1, 70000))) + b"XTA" + bytes(rng.choice(list(b"URNM"), 1).tolist()) + b"ZfB" + b"f" + struct.pack("<I", 2) + struct.pack("<ff", 0.5, 1e9)
+    return out
+
+
+def fake_record_chain(n_ref: int, rng, k: int, overshoot: int = 0) -> bytes:
+    """ADVERSARIAL aux payload: the bytes of `k` well-formed minimal BAM records back to back (block_size, a reference id inside
+    the header's table, positions >= -1, a one-byte name, no CIGAR, no bases), the last one's block_size claiming `overshoot`
+    bytes more than it has -- so that a parser that starts anywhere inside finds a plausible record CHAIN that runs into
+    whatever follows the payload.  When the payload is a record's last tag that is the next real record: the chain is then
+    indistinguishable from the file's own but for where it starts.  (A guess of a shard's first record must survive this:
+    DESIGN.md section 8 / 9 "Record boundaries".)"""
+    out = b""
+    for j in range(k):
+        extra = int(rng.integers(0, 3))
+        ref = int(rng.integers(-1, n_ref))
+        body = struct.pack("<iiBBHHHIiii", ref, int(rng.integers(-1, 1000)), 1, int(rng.integers(0, 61)), 4680, 0, int(rng.integers(0, 4096)) | 4, 0,
+                           int(rng.integers(-1, n_ref)), int(rng.integers(-1, 1000)), 0) + b"\0" + bytes(extra)
+        out += struct.pack("<I", len(body) + (overshoot if j == k - 1 else 0)) + body
+    return out
+
+
+def adversarial_aux(rng, n_ref: int) -> bytes:
+    """A B:C array (any bytes) or a Z string (no NUL: only the one-hop kind) that reads as record heads."""
+    kind = rng.random()
+    if kind < 0.6:     # a chain of fake records that lands exactly on the next real record (the payload is the last tag)
+        return aux_array(b"ZF", b"C", fake_record_chain(n_ref, rng, int(rng.integers(1, 12))))
+    if kind < 0.8:     # ... that lands 1..40 bytes INTO the next record (a chain that dies there)
+        return aux_array(b"ZF", b"C", fake_record_chain(n_ref, rng, int(rng.integers(1, 6)), overshoot=int(rng.integers(1, 41))))
+    # one fake head whose block_size jumps far ahead (no byte of it is zero, so it also fits a Z string): block_size and
+    # l_seq of tens of MB with the other fields 0x01.. / -1 -- plausible whenever that much data follows in the chunk
+    head = struct.pack("<IiiBBHHHIii", 0x02010101, -1, -1, 1, 1, 0x0101, 0x0101, 0x0505, 0x01010101, -1, -1)
+    return aux_z(b"ZJ", head + b"AAAA") if kind < 0.9 else aux_array(b"ZJ", b"C", head + b"\1\1\1\1")
+
+
 def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], block_payload: int = 60000,
-              with_index: bool = True, sort_order: str = "coordinate", real_index: bool = False) -> np.ndarray:
-    """Returns the records' BAM virtual offsets (block file offset << 16 | offset in the block's data): the ids the
+              with_index: bool = True, sort_order: str = "coordinate", real_index: bool = False, names=None, aux=None) -> np.ndarray:
+    """names / aux: per record, the read name (without its NUL) and the auxiliary bytes behind the qualities (None: "r<i>",
+    nothing -- the tag-less records of rounds 1-3).
+    Returns the records' BAM virtual offsets (block file offset << 16 | offset in the block's data): the ids the
     readers of include/ngsq_bam.h give them (ngsq_batch.record_id)."""
     text = f"@HD\tVN:1.6\tSO:{sort_order}\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(ref_names, ref_len))
     head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(ref_names))
@@ -111,7 +193,7 @@ def write_bam(path: str, hb, ref_names: Sequence[str], ref_len: Sequence[int], b
     cur = bytearray(head)
     rec_at = []  # (block number, offset in the block's data) of every record
     for i in range(hb.n):
-        rec = record_bytes(hb, i)
+        rec = record_bytes(hb, i, aux=aux[i] if aux is not None else b"", full_name=names[i] if names is not None else None)
         if len(cur) >= block_payload:  # a record starts in the block that holds its first byte
             out.append(bgzf_block(bytes(cur)))
             cur = bytearray()

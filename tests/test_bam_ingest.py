@@ -69,11 +69,28 @@ def records_of(hb):
     return out
 
 
-@pytest.mark.parametrize("case", ["ragged", "uniform150", "long"])
+def dressed(rng, hb, n_ref, adversarial):
+    """Read names and auxiliary data for the records of `hb`: what an aligner writes, or (adversarial) payloads that read
+    as BAM records themselves (tests/bamio.py: fake_record_chain)."""
+    names = [bamio.aligner_name(rng) for _ in range(hb.n)]
+    aux = []
+    for i in range(hb.n):
+        a = bamio.aligner_aux(rng, int(hb.cols["l_seq"][i]), mapped=not (int(hb.cols["flag"][i]) & 4))
+        if adversarial and rng.random() < 0.7:
+            a += bamio.adversarial_aux(rng, n_ref)
+        aux.append(a)
+    return names, aux
+
+
+@pytest.mark.parametrize("case", ["ragged", "uniform150", "long", "aligner150", "adversarial"])
 def test_round_trip(lib, tmp_path, case):
     rng = np.random.default_rng(9)
     ref_len = [50_000, 7_000]
-    if case == "ragged":
+    names = aux = None
+    if case in ("aligner150", "adversarial"):     # names of 37-39 characters and tags behind the qualities: skipped unread
+        hb = random_batch(rng, 3000, ref_len, max_len=150, min_len=150 if case == "aligner150" else 20, weird=case == "adversarial")
+        names, aux = dressed(rng, hb, 2, case == "adversarial")
+    elif case == "ragged":
         hb = random_batch(rng, 3000, ref_len, max_len=300, weird=True)
     elif case == "uniform150":
         hb = random_batch(rng, 3000, ref_len, max_len=150, min_len=150, weird=False)
@@ -81,7 +98,7 @@ def test_round_trip(lib, tmp_path, case):
         hb = random_batch(rng, 400, ref_len, max_len=900, min_len=321, weird=False)
     # qualities == 0xFF for a whole read mean "absent" in BAM: keep real scores <= 93 (random_batch does)
     path = str(tmp_path / "t.bam")
-    voff = bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000)
+    voff = bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000, names=names, aux=aux)
     assert lib.ngsq_bam_check_index(path.encode()) == 0
     want = records_of(hb)
     for max_records in (1 << 20, 257):
@@ -152,6 +169,31 @@ def test_synthetic_bam_writer_round_trip(lib, tmp_path):
         assert got == records_of(host.synth_host_batch(cfg, 0, 20_000, lib))
         if mode == ffi.SYNTH_FIXED:
             assert batches[0].qual_stride == 150 and batches[0].cigar_stride == 1
+        # the same records dressed as an aligner's output (names of 37-39 characters, NM MD MC AS XS MQ RG [SA XA B]): the
+        # batches are those of the plain file, the file is a third larger
+        acfg = host.synth_config(20_000, mode=mode, ref_len=3_000_000, file_style=ffi.SYNTH_FILE_ALIGNER)
+        q = str(tmp_path / f"a{mode}.bam")
+        assert lib.ngsq_synth_write_bam(C.byref(acfg), q.encode(), 20_000, 1, 4) == 0
+        assert lib.ngsq_bam_check_index(q.encode()) == 0
+        _, abatches, an = read_all(lib, q, 7000)
+        assert an == 20_000 and [r for b in abatches for r in records_of(b)] == got
+        assert os.path.getsize(q) > 1.15 * os.path.getsize(p)
+    # NGSQ_SYNTH_FILE_CIGAR_MIX: 15 % of the mapped fixed-length reads carry a clip or an indel instead of <l>M
+    rcfg = host.synth_config(20_000, ref_len=3_000_000, file_style=ffi.SYNTH_FILE_REALISTIC)
+    r = str(tmp_path / "r.bam")
+    assert lib.ngsq_synth_write_bam(C.byref(rcfg), r.encode(), 20_000, 6, 4) == 0
+    _, rb, rn = read_all(lib, r, 1 << 20)
+    recs = records_of(rb[0])
+    plain = records_of(host.synth_host_batch(rcfg, 0, 20_000, lib))
+    assert rn == 20_000 and rb[0].qual_stride == 150 and rb[0].cols["cigar_off"] is not None
+    multi = 0
+    for a, b in zip(recs, plain):
+        fa, fb = dict(zip(host.FIXED_COLUMNS, a[0])), dict(zip(host.FIXED_COLUMNS, b[0]))
+        assert a[1:3] == b[1:3] and {k: v for k, v in fa.items() if k != "n_cigar"} == {k: v for k, v in fb.items() if k != "n_cigar"}
+        read_bases = sum(c >> 4 for c in a[3] if (c & 15) in (0, 1, 4, 7, 8))
+        assert read_bases == (150 if a[3] else 0) and len(a[3]) == fa["n_cigar"]
+        multi += len(a[3]) > 1
+    assert 0.12 * rn < multi < 0.18 * rn
 
 
 def test_index_region_query_by_seek(lib, tmp_path):

@@ -238,6 +238,7 @@ def read_all_device(lib, ctx, path, max_records):
                 break
             batches.append(download_batch(lib, ctx, b))
         n = lib.ngsq_bam_records_read(h)
+        read_all_device.last_stats = device_stats(lib, h) if batches else {}
     finally:
         lib.ngsq_bam_close(h)
     return batches, n
@@ -255,11 +256,24 @@ def same_batches(a, b):
                 assert np.array_equal(x.cols[k], y.cols[k]), k
 
 
-@pytest.mark.parametrize("case", ["ragged", "uniform150", "long", "multiop150", "one_base", "three_bases"])
+def device_stats(lib, h) -> dict:
+    st = ffi.IngestStats()
+    assert lib.ngsq_bam_device_stats(h, C.byref(st)) == 0, lib.ngsq_bam_last_error()
+    return {k: int(getattr(st, k)) for k, _ in ffi.IngestStats._fields_}
+
+
+@pytest.mark.parametrize("case", ["ragged", "uniform150", "long", "multiop150", "one_base", "three_bases", "aligner150", "adversarial"])
 def test_device_reader_matches_host_reader(gpu_lib, ctx, tmp_path, monkeypatch, case):
     rng = np.random.default_rng(19)
     ref_len = [50_000, 7_000]
-    if case == "ragged":
+    names = aux = None
+    if case in ("aligner150", "adversarial"):
+        # what an aligner writes around a record (long names, tags), and tag payloads that read as chains of BAM records: the
+        # record index must find the file's own chain whatever the bytes in between look like
+        from tests.test_bam_ingest import dressed
+        hb = random_batch(rng, 6000, ref_len, max_len=150, min_len=150 if case == "aligner150" else 20, weird=case == "adversarial")
+        names, aux = dressed(rng, hb, 2, case == "adversarial")
+    elif case == "ragged":
         hb = random_batch(rng, 6000, ref_len, max_len=300, weird=True)
     elif case == "uniform150":
         hb = random_batch(rng, 6000, ref_len, max_len=150, min_len=150, weird=False)
@@ -272,12 +286,17 @@ def test_device_reader_matches_host_reader(gpu_lib, ctx, tmp_path, monkeypatch, 
     else:
         hb = random_batch(rng, 700, ref_len, max_len=900, min_len=321, weird=False)
     path = str(tmp_path / "t.bam")
-    bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000)
+    bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=5000, names=names, aux=aux)
     for max_records in (1 << 20, 257):
         _, hbatches, n = read_all(gpu_lib, path, max_records)
         dbatches, dn = read_all_device(gpu_lib, ctx, path, max_records)
         assert dn == n == hb.n
         same_batches(dbatches, hbatches)
+    st = read_all_device.last_stats
+    if case == "adversarial":     # the fake chains crowd real record starts out of the candidate table: those segments are walked singly
+        assert st["walk_one"] > st["chunks"], st
+    elif case == "aligner150":    # an aligner's tags do not: only the record cut by a chunk's end takes that path
+        assert st["walk_one"] <= st["chunks"], st
     # many small chunks: the cut record at a chunk's end is carried into the next one
     monkeypatch.setenv("NGSQ_INGEST_RAW_MB", "1")
     dbatches, dn = read_all_device(gpu_lib, ctx, path, 1 << 20)
@@ -426,9 +445,9 @@ def _file_shard_worker(rank, world, port, q, bam, writer, transport=None, wrong_
         from ngs_amd import ffi as F, host as H, shard
         from tests.test_shard_gloo import _make_comm
 
-        comm, done = _make_comm(transport or ("shm" if writer == "synth" else "gloo"), rank, world, port)
+        comm, done = _make_comm(transport or ("shm" if writer in ("synth", "aligner") else "gloo"), rank, world, port)
         lib = F.load_library()
-        ref_len = [3_000_000, 3_000_000] if writer == "synth" else [50_000, 7_000]
+        ref_len = [3_000_000, 3_000_000] if writer in ("synth", "aligner") else [50_000, 7_000]
         names = ["chr1", "chr2"]
         kw = dict(facets=F.FACETS_DEFAULT, bin_size=50_000, max_read_len=1024, gc_seed=5)
 
@@ -468,7 +487,10 @@ def _file_shard_worker(rank, world, port, q, bam, writer, transport=None, wrong_
                 assert lib.ngsq_bam_shard_begin(h, ctx._ctx, 1, world, int(ids[1])) == 0, lib.ngsq_bam_last_error()
         info, rounds, mine = comm.scan_file_shard(ctx, bam, batch_records=7_000, begin_hook=hook)
         assert mine == info.n_records
-        assert rounds == (1 if wrong_guess else 0), rounds
+        if writer == "adversarial":   # the test looks at the sum over the ranks
+            open(f"{bam}.rounds{rank}", "w").write(str(rounds))
+        else:
+            assert rounds == (1 if wrong_guess else 0), rounds
         counts = comm.allgather_ints([mine, int(info.first_record_index)])
         if rank == 0:
             assert sum(c for c, _ in counts) == n_total, (counts, n_total)
@@ -491,18 +513,30 @@ def _file_shard_worker(rank, world, port, q, bam, writer, transport=None, wrong_
 
 
 @pytest.mark.parametrize("writer,transport,wrong", [("synth", None, False), ("straddling", None, False), ("straddling", "rccl-double", False),
-                                                    ("straddling", None, True)])
+                                                    ("straddling", None, True), ("aligner", None, False), ("adversarial", None, False)])
 def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport, wrong):
     """Each rank streams its BGZF block range of the same file through the chunked pipeline; the record boundaries the
     shards assumed are compared afterwards (ngsq_bam_shard_verify); results equal the single-reader run.
     "straddling": a file whose records cross every block boundary, so no shard starts at a record start.
-    wrong: a shard that started from a wrong first record is found out and scanned again."""
+    wrong: a shard that started from a wrong first record is found out and scanned again.
+    "aligner": the synthetic file dressed as an aligner's output (long names, NM MD MC AS XS MQ RG SA XA tags, 15 % multi-op CIGARs).
+    "adversarial": every record carries a B:C array whose bytes are a chain of well-formed BAM records that runs into the next
+    real record, and the blocks are small, so a shard's first block starts inside such a payload: the shard's guess of its
+    first record is a fake one, its neighbour's end says so, and the shard is scanned again -- not planted, found."""
     import multiprocessing as mp
     import socket
     bam = str(tmp_path / "f.bam")
-    if writer == "synth":
-        cfg = host.synth_config(120_000, mode=ffi.SYNTH_MIXED, ref_len=3_000_000)
+    if writer in ("synth", "aligner"):
+        cfg = host.synth_config(120_000, mode=ffi.SYNTH_MIXED if writer == "synth" else ffi.SYNTH_FIXED, ref_len=3_000_000,
+                                file_style=ffi.SYNTH_FILE_REALISTIC if writer == "aligner" else 0)
         assert gpu_lib.ngsq_synth_write_bam(C.byref(cfg), bam.encode(), 120_000, 6, 4) == 0
+    elif writer == "adversarial":
+        rng = np.random.default_rng(31)
+        hb = random_batch(rng, 9000, [50_000, 7_000], max_len=60, min_len=20, weird=False)
+        hb.cols["flag"] &= np.uint16(0xFFFF ^ 0x1)
+        aux = [bamio.aligner_aux(rng, int(l)) + bamio.aux_array(b"ZF", b"C", bamio.fake_record_chain(2, rng, int(rng.integers(6, 12))))
+               for l in hb.cols["l_seq"]]
+        bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=1500, names=[bamio.aligner_name(rng) for _ in range(hb.n)], aux=aux)
     else:
         rng = np.random.default_rng(23)
         hb = random_batch(rng, 9000, [50_000, 7_000], max_len=200, weird=False)
@@ -511,6 +545,9 @@ def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport, wr
         bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=3000)
     from tests.test_shard_gloo import _run_ranks
     _run_ranks(_file_shard_worker, 3, bam, writer, transport, wrong)   # rccl-double: the RCCL transport over tests/rccl_double
+    if writer == "adversarial":
+        rounds = [int(open(f"{bam}.rounds{r}").read()) for r in range(3)]
+        assert max(rounds) >= 1, rounds      # at least one shard's guess was a fake record: found out and scanned again
 
 
 def test_shard_begin_end_api(gpu_lib, ctx, tmp_path, monkeypatch):

@@ -24,10 +24,11 @@ def main():
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--crc", type=int, default=1)
+    ap.add_argument("--style", type=int, default=0, help="ngsq_shared.h NGSQ_SYNTH_FILE_*: 3 = an aligner's names, tags and CIGAR mix")
     args = ap.parse_args()
     build.build(verbose=False)
     lib = ffi.load_library()
-    scfg = host.synth_config(n_total=args.records, read_len=150)
+    scfg = host.synth_config(n_total=args.records, read_len=150, file_style=args.style)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "s.bam")
         rc = lib.ngsq_synth_write_bam(C.byref(scfg), path.encode(), args.records, args.level, 0)

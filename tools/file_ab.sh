@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the in-process file path under environment settings (run on the GPU box):
 #   bash tools/file_ab.sh RECORDS "ENV1=a ENV2=b" "ENV1=c" ...     -- each quoted argument is one variant; "" = defaults
+#   STYLE=3 (environment): the file dressed as an aligner's output (ngsq_shared.h NGSQ_SYNTH_FILE_REALISTIC); KERNELS=1: per-kernel times
 set -u
 N=$1; shift
 R=$GRAFT_REPO_ROOT
@@ -10,7 +11,7 @@ import ctypes as C, time, os, sys
 sys.path.insert(0, "$R")
 from ngs_amd import ffi, host
 lib = ffi.load_library()
-cfg = host.synth_config($N)
+cfg = host.synth_config($N, file_style=int(os.environ.get("STYLE", "0")))
 t = time.time()
 assert lib.ngsq_synth_write_bam(C.byref(cfg), b"/tmp/ab.bam", $N, 6, 0) == 0
 print("bam_write_s", round(time.time() - t, 2), "bytes", os.path.getsize("/tmp/ab.bam"))
@@ -44,6 +45,7 @@ for rep in range(3):
     t1 = time.perf_counter()
     res.append((t1 - t0, (got - first[1]) / (t1 - first[0]) / 1e6))
 kt = ctx.kernel_timing()
+st = ffi.IngestStats()
 print("%-40s" % "$V", " ".join("%.3fs/%.0fM" % r for r in res), " inflate %.2f ms" % (kt["bgzf_inflate"]["total_ms"] / kt["bgzf_inflate"]["launches"]))
 if os.environ.get("KERNELS"):
     print("   ", "  ".join("%s %.3f x%d" % (k, v["total_ms"] / v["launches"], v["launches"]) for k, v in kt.items() if v["launches"]))

@@ -121,7 +121,7 @@ def ingest_sweep(lib, seeds):
     and the column kernels: reads from 1 base to 100 kb (records longer than a 4 KiB piece and than a 64 KiB segment),
     BGZF blocks of 0.7-60 kB, ingest chunks of 1 MiB to 1 GiB (cut records carried over), batches of 257 records to
     everything, the block cache on (buffers of the previous seed recycled)."""
-    from tests.test_bam_ingest import read_all, records_of
+    from tests.test_bam_ingest import dressed, read_all, records_of
     from tests.test_device_ingest_gpu import read_all_device, same_batches
     td = tempfile.mkdtemp(prefix="ngsq_fuzz_ingest_")
     ctx = host.QcContext([100_000, 50_000], [1, 1], lib=lib)
@@ -134,7 +134,11 @@ def ingest_sweep(lib, seeds):
         hb = random_batch(rng, n, ref_len, max_len=max_len, min_len=max_len if uniform else int(rng.integers(0, max_len + 1)),
                           weird=bool(rng.integers(0, 2)))
         p = os.path.join(td, "f.bam")
-        bamio.write_bam(p, hb, ["chr1", "chr2"], ref_len, block_payload=int(rng.choice([700, 4000, 60000])))
+        # two seeds in three: read names and auxiliary data as an aligner writes them; one in three: with payloads that read as
+        # chains of BAM records (tests/bamio.py fake_record_chain, a Z / B value that is a 36-byte record head)
+        style = int(rng.integers(0, 3))
+        names, aux = dressed(rng, hb, 2, style == 2) if style and n <= 8000 else (None, None)
+        bamio.write_bam(p, hb, ["chr1", "chr2"], ref_len, block_payload=int(rng.choice([700, 4000, 60000])), names=names, aux=aux)
         os.environ["NGSQ_INGEST_RAW_MB"] = str(int(rng.choice([1, 4, 1024])))
         max_records = int(rng.choice([257, 2500, 1 << 20]))
         _, hbatches, hn = read_all(lib, p, max_records)
@@ -144,8 +148,10 @@ def ingest_sweep(lib, seeds):
             same_batches(dbatches, hbatches)        # one chunk: the two readers cut the same batches
         else:                                       # a batch also ends where an ingest chunk ends: compare the records
             assert [r for b in dbatches for r in records_of(b)] == [r for b in hbatches for r in records_of(b)] == records_of(hb)
+        st = read_all_device.last_stats
         print(f"ingest seed {seed}: n={n} max_len={max_len} uniform={uniform} chunk={os.environ['NGSQ_INGEST_RAW_MB']} MiB "
-              f"batch={max_records} ok", flush=True)
+              f"batch={max_records} aux={('none', 'aligner', 'adversarial')[style] if names else 'none'} "
+              f"walk_one={st.get('walk_one')}/{st.get('segments')} segments in {st.get('chunks')} chunks ok", flush=True)
     os.environ.pop("NGSQ_INGEST_RAW_MB", None)
     ctx.close()
     print("ingest sweep ok")

@@ -18,10 +18,11 @@ def main():
     ap.add_argument("--records", type=int, default=4_000_000)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--mixed", action="store_true")
+    ap.add_argument("--style", type=int, default=0, help="ngsq_shared.h NGSQ_SYNTH_FILE_*: 3 = an aligner's names, tags and CIGAR mix")
     a = ap.parse_args()
     build.build(verbose=False)
     lib = ffi.load_library()
-    cfg = host.synth_config(a.records, mode=ffi.SYNTH_MIXED if a.mixed else ffi.SYNTH_FIXED)
+    cfg = host.synth_config(a.records, mode=ffi.SYNTH_MIXED if a.mixed else ffi.SYNTH_FIXED, file_style=a.style)
     assert lib.ngsq_synth_write_bam(C.byref(cfg), a.out.encode(), a.records, a.level, 0) == 0
     print(a.out, os.path.getsize(a.out))
 
