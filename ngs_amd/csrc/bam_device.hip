@@ -81,6 +81,23 @@ __device__ bool aux_has_cg_tag(const uint8_t *p, const uint8_t *end) {
     return false;
 }
 
+// The screen of k_rec_candidates, beyond the fields' ranges.  Round 4: in a file whose records carry a real mate position the
+// offset TWO BYTES IN FRONT of every record passes the range tests -- its "block_size" is the last two bytes of the record
+// before and the low half of the real block_size (some tens of MB: plausible wherever that much data follows in the chunk),
+// its reference ids are the zero halves of block_size / refID and of l_seq / next_refID -- and, lying in front of the real
+// start, it took the segment's table slots: one segment in five of an aligner-style file was walked singly (5 M records/s
+// instead of 250 M).  The files of rounds 1-3 said next_pos = -1, whose halves read as a negative position: luck.  So an
+// offset is listed only if, besides, its bin is one of the six bins that can hold an alignment starting at its position
+// (SAM specification 5.3: reg2bin of [pos, end) is the 16 kb window of pos or one of its five ancestors; 4680 for pos -1;
+// the field is 16 bits wide), its read name ends with a NUL where l_read_name says, and its first CIGAR operation has a
+// defined code.  All three are properties of every record a conforming writer produces; a record that lacks one is still
+// found -- its segment is walked by k_walk_one, with the host reader's rule -- only not through the table.
+__device__ __forceinline__ bool bin_fits(int32_t pos, uint32_t bin) {
+    return bin == ((4681u + (uint32_t)(pos >> 14)) & 0xFFFFu) || bin == ((585u + (uint32_t)(pos >> 17)) & 0xFFFFu) ||
+           bin == ((73u + (uint32_t)(pos >> 20)) & 0xFFFFu) || bin == ((9u + (uint32_t)(pos >> 23)) & 0xFFFFu) ||
+           bin == ((1u + (uint32_t)(pos >> 26)) & 0xFFFFu) || bin == 0u;
+}
+
 constexpr uint32_t SUB_NONE = 0xFFFFFFFFu;
 #ifndef NGSQ_PARSE_THREADS
 #define NGSQ_PARSE_THREADS 256
@@ -193,7 +210,9 @@ __global__ __launch_bounds__(64) void k_rec_candidates(const uint8_t *__restrict
                     const uint64_t need = 32ull + l_read_name + 4ull * n_ops + ((uint64_t)l + 1) / 2 + l;
                     const int32_t ref = (int32_t)a.y, p = (int32_t)a.z, mref = (int32_t)b.z, mpos = (int32_t)b.w;
                     pass = o + 4 + (uint64_t)bs <= n_bytes && bs >= 32 && l_read_name != 0 && need <= bs && ref >= -1 && ref < n_ref &&
-                           mref >= -1 && mref < n_ref && p >= -1 && mpos >= -1;
+                           mref >= -1 && mref < n_ref && p >= -1 && mpos >= -1 && bin_fits(p, a.w >> 16);
+                    // the few offsets that get this far: the name ends with its NUL and the first CIGAR operation is one
+                    if (pass) pass = raw[o + 35 + l_read_name] == 0 && (n_ops == 0 || (ld32(raw + o + 36 + l_read_name) & 15u) <= 8u);
                 }
                 const uint64_t m = __ballot(pass);
                 const uint32_t k = (uint32_t)__popcll(m), room = LIST - list_n[g];

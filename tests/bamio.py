@@ -47,7 +47,7 @@ def record_bytes(hb, i: int, name: bytes = b"r", aux: bytes = b"", full_name: by
     nm = (full_name if full_name is not None else name + b"%d" % i) + b"\0"
     pos = int(c["pos"][i])
     span = sum(int(x) >> 4 for x in cig if (int(x) & 15) in (0, 2, 3, 7, 8))
-    bin_ = reg2bin(max(pos, 0), max(pos, 0) + max(span, 1))
+    bin_ = reg2bin(pos, pos + max(span, 1)) if pos >= 0 else 4680   # (reg2bin(-1, 0), SAM specification 4.2.1)
     body = struct.pack("<iiBBHHHIiii", int(c["ref_id"][i]), pos, len(nm), int(c["mapq"][i]), bin_, len(cig),
                        int(c["flag"][i]), l, int(c["mate_ref_id"][i]), -1, int(c["tlen"][i]))
     body += nm + np.asarray(cig, dtype="<u4").tobytes() + seq + q + aux
@@ -156,8 +156,8 @@ def fake_record_chain(n_ref: int, rng, k: int, overshoot: int = 0) -> bytes:
     out = b""
     for j in range(k):
         extra = int(rng.integers(0, 3))
-        ref = int(rng.integers(-1, n_ref))
-        body = struct.pack("<iiBBHHHIiii", ref, int(rng.integers(-1, 1000)), 1, int(rng.integers(0, 61)), 4680, 0, int(rng.integers(0, 4096)) | 4, 0,
+        ref, pos = int(rng.integers(-1, n_ref)), int(rng.integers(-1, 1000))
+        body = struct.pack("<iiBBHHHIiii", ref, pos, 1, int(rng.integers(0, 61)), 4680 if pos < 0 else 4681, 0, int(rng.integers(0, 4096)) | 4, 0,
                            int(rng.integers(-1, n_ref)), int(rng.integers(-1, 1000)), 0) + b"\0" + bytes(extra)
         out += struct.pack("<I", len(body) + (overshoot if j == k - 1 else 0)) + body
     return out
@@ -172,7 +172,7 @@ def adversarial_aux(rng, n_ref: int) -> bytes:
         return aux_array(b"ZF", b"C", fake_record_chain(n_ref, rng, int(rng.integers(1, 6)), overshoot=int(rng.integers(1, 41))))
     # one fake head whose block_size jumps far ahead (no byte of it is zero, so it also fits a Z string): block_size and
     # l_seq of tens of MB with the other fields 0x01.. / -1 -- plausible whenever that much data follows in the chunk
-    head = struct.pack("<IiiBBHHHIii", 0x02010101, -1, -1, 1, 1, 0x0101, 0x0101, 0x0505, 0x01010101, -1, -1)
+    head = struct.pack("<IiiBBHHHIii", 0x02010101, -1, -1, 1, 1, 4680, 0x0101, 0x0505, 0x01010101, -1, -1)
     return aux_z(b"ZJ", head + b"AAAA") if kind < 0.9 else aux_array(b"ZJ", b"C", head + b"\1\1\1\1")
 
 

@@ -40,12 +40,14 @@ for rep in range(3):
         got += int(b.n_records)
         if first is None: first = (time.perf_counter(), got)
         assert lib.ngsq_process_batch(ctx._ctx, C.byref(b), ffi.PASS_BOTH) == 0
+    st = ffi.IngestStats()
+    lib.ngsq_bam_device_stats(h, C.byref(st))
     lib.ngsq_bam_close(h)
     ctx.finalize()
     t1 = time.perf_counter()
     res.append((t1 - t0, (got - first[1]) / (t1 - first[0]) / 1e6))
 kt = ctx.kernel_timing()
-st = ffi.IngestStats()
+print("    ingest:", " ".join("%s=%d" % (k, getattr(st, k)) for k, _ in ffi.IngestStats._fields_[:6]))
 print("%-40s" % "$V", " ".join("%.3fs/%.0fM" % r for r in res), " inflate %.2f ms" % (kt["bgzf_inflate"]["total_ms"] / kt["bgzf_inflate"]["launches"]))
 if os.environ.get("KERNELS"):
     print("   ", "  ".join("%s %.3f x%d" % (k, v["total_ms"] / v["launches"], v["launches"]) for k, v in kt.items() if v["launches"]))
