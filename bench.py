@@ -169,10 +169,12 @@ def main() -> int:
     # (weak scaling: ngs_amd.shard.shard_range(n * world, rank, world) == (rank * n, n))
     emu_rank, emu_world = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
     scfg = host.synth_config(n * emu_world, mode=ffi.SYNTH_MIXED if mixed else ffi.SYNTH_FIXED,
-                             read_len=args.read_len, max_len=args.mixed_max_len, ref_len=CHR1, n_refs=2)
+                             read_len=args.read_len, max_len=args.mixed_max_len, ref_len=CHR1, n_refs=2,
+                             # with Edits in the mask the reads are sampled from the reference they are compared with
+                             seq_model=ffi.SYNTH_SEQ_FROM_REFERENCE if args.facets & ffi.FACET_EDITS else ffi.SYNTH_SEQ_IID)
     if args.coverage == "auto":
         args.coverage = "stream" if emu_world * n / CHR1 <= 0.5 else "array"
-    ref_bases = synthetic_reference(np) if args.facets & ffi.FACET_EDITS else None
+    ref_bases = [host.synth_reference(scfg, r, L, lib) for r, L in enumerate((CHR1, CHR2))] if args.facets & ffi.FACET_EDITS else None
     ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets, device=device,
                          max_read_len=max_len, gc_seed=GC_SEED, timing=not args.no_timing,
                          sorted_input=args.coverage == "stream", ref_bases=ref_bases,
@@ -779,13 +781,6 @@ def leg_file(lib, host, ffi, args):
 # ---------------------------------------------------------------------------------------------
 # Edits and Genomic Features (optional facets of the reference: -r FASTA, -f GFF)
 # ---------------------------------------------------------------------------------------------
-def synthetic_reference(np):
-    """4-bit base codes (A C G T = 1 2 4 8), one per byte, for chr1 and chr2: the reference FASTA resident in HBM."""
-    rng = np.random.default_rng(0x4E4753)
-    codes = np.array([1, 2, 4, 8], dtype=np.uint8)
-    return [codes[rng.integers(0, 4, L, dtype=np.uint8)] for L in (CHR1, CHR2)]
-
-
 def synthetic_gene_model(np):
     """A GENCODE-shaped gene model on chr1/chr2: ~20 k genes per sequence, ~10 exons each, CDS inside exons, UTRs
     at the ends (columns of ngsq_features: sequence index, name id = role, GFF start, GFF end)."""
@@ -812,11 +807,16 @@ def synthetic_gene_model(np):
 
 def leg_extra_facets(lib, host, ffi, np, n=100_000_000):
     """Kernel times of the two optional facets on the first n records of the workload (reference bases of chr1
-    and chr2 and a 400 k-interval gene model resident in HBM)."""
-    scfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2)
-    out = {"records": n}
+    and chr2 and a 400 k-interval gene model resident in HBM).  The reads of this leg are SAMPLED FROM the reference
+    (ngsq_shared.h NGSQ_SYNTH_SEQ_FROM_REFERENCE: the reference's bases under every `M`, one substitution in 200) --
+    what Edits sees on aligner output (edits.rs:276-291: a mismatch is rare); `edits_iid_reads` keeps round 3's input
+    beside it, independent bases that differ from the reference three times in four."""
+    scfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2, seq_model=ffi.SYNTH_SEQ_FROM_REFERENCE)
+    out = {"records": n, "reads": "sampled from the reference, 0.5 % substitutions"}
+    bases = [host.synth_reference(scfg, r, L, lib) for r, L in enumerate((CHR1, CHR2))]
     ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=ffi.FACET_EDITS | ffi.FACET_FEATURES, max_read_len=150, gc_seed=GC_SEED,
-                         timing=True, ref_bases=synthetic_reference(np), lib=lib)
+                         timing=True, ref_bases=bases, lib=lib)
+    del bases
     try:
         ctx.set_features(*synthetic_gene_model(np))
         db = ctx.synth_device_batch(scfg, 0, n)
@@ -834,6 +834,24 @@ def leg_extra_facets(lib, host, ffi, np, n=100_000_000):
         out["features_processed"] = f["processed"]
         r1, r2, vaf = ctx.edits()
         out["edits_reads"] = int(r1.sum() + r2.sum())
+        tot = np.arange(r1.size, dtype=np.float64)
+        out["mean_edits_per_read"] = round(float(((r1 + r2) * tot).sum() / max(1, out["edits_reads"])), 4)
+        out["vaf_positions"] = int(vaf.sum())
+        ctx.free_batch(db)
+        # round 3's input on the same kernel: every compared dword holds a mismatch
+        icfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2)
+        db = ctx.synth_device_batch(icfg, 0, n)
+        for rep in range(2):
+            ctx.reset()
+            ctx.kernel_timing_reset()
+            ctx.process_batch(db)
+            ctx.finalize()
+        ki = kernel_table(ctx.kernel_timing()).get("edits")
+        if ki:
+            ki["hbm_frac"] = round(ki["GBps"] / HBM_PEAK_GBS, 4)
+            r1, r2, _ = ctx.edits()
+            ki["mean_edits_per_read"] = round(float(((r1 + r2) * tot).sum() / max(1, int(r1.sum() + r2.sum()))), 2)
+            out["edits_iid_reads"] = ki
         ctx.free_batch(db)
         return out
     finally:

@@ -59,8 +59,16 @@ typedef struct ngsq_synth_config {
     uint32_t ref_len;   /* length of reference 0 (chr1 = 248 956 422)                  */
     uint32_t n_refs;    /* 1, or 2 (reference 1 only ever appears as a mate reference) */
     uint32_t file_style; /* ngsq_synth_write_bam only: NGSQ_SYNTH_FILE_* bits (0 = round 1-3 files)  */
-    uint32_t reserved;
+    uint32_t seq_model; /* NGSQ_SYNTH_SEQ_IID (0) / NGSQ_SYNTH_SEQ_FROM_REFERENCE                 */
 } ngsq_synth_config;
+
+/* Where a read's bases come from.  IID: independent draws (rounds 1-3) -- compared with any reference three bases in four
+ * differ, which no aligned read does.  FROM_REFERENCE: the bases under an `M` are the synthetic reference's bases at the
+ * positions the CIGAR maps them to (ngsq_synth_ref_code; ngsq_synth_fill_reference writes the same sequence out for
+ * ngsq_config.ref_bases) with one substitution in 200 (0.5 %, always to a different base); inserted and clipped bases
+ * stay independent draws.  What the Edits facet sees on aligner output: a mismatch is rare. */
+#define NGSQ_SYNTH_SEQ_IID 0u
+#define NGSQ_SYNTH_SEQ_FROM_REFERENCE 1u
 
 /* What a record of a synthetic BAM FILE carries besides the generator's fields (ngsq_synth_write_bam; the batches of
  * ngsq_synth_fill_* have no names or tags).  0: the name "r<index>", no auxiliary data (274 B per 150-base record) --
@@ -98,6 +106,8 @@ typedef struct ngsq_synth_record {
 #define NGSQ_KEY_QUAL 8ull
 #define NGSQ_KEY_NAME 9ull
 #define NGSQ_KEY_AUX 10ull
+#define NGSQ_KEY_REF 11ull
+#define NGSQ_KEY_SUB 12ull
 
 NGSQ_HD uint64_t ngsq_synth_hash(uint64_t seed, uint64_t i, uint64_t key, uint64_t word) {
     return ngsq_mix64(ngsq_mix64(seed ^ (key << 56) ^ i) + word);
@@ -239,14 +249,57 @@ NGSQ_HD uint32_t ngsq_synth_base_code(uint32_t r16) {
     return 8u;                    /* T */
 }
 
+/* The synthetic reference: base code (A C G T = 1 2 4 8, uniform) of 0-based position p of reference sequence `ref`. */
+NGSQ_HD uint32_t ngsq_synth_ref_code(const ngsq_synth_config *c, uint32_t ref, uint64_t p) {
+    const uint64_t h = ngsq_synth_hash(c->seed, p >> 5, NGSQ_KEY_REF, (uint64_t)ref); /* 32 bases per hash */
+    return 1u << ((uint32_t)(h >> (2u * (uint32_t)(p & 31ull))) & 3u);
+}
+
+/* NGSQ_SYNTH_SEQ_FROM_REFERENCE: base q of record i (r = its fields): under an M the reference's base at the position the
+ * CIGAR maps q to, substituted by another base with probability 328 / 65536; `iid` everywhere else */
+NGSQ_HD uint32_t ngsq_synth_base_from_reference(const ngsq_synth_config *c, uint64_t i, const ngsq_synth_record *r, uint32_t q,
+                                                uint32_t iid) {
+    uint32_t qp = 0;
+    uint64_t rp = 0;
+    for (uint32_t k = 0; k < r->n_cigar && k < NGSQ_SYNTH_MAX_OPS; k++) {
+        const uint32_t op = r->cigar[k] & 15u, len = r->cigar[k] >> 4;
+        if (op == 0u) {
+            if (q < qp + len) {
+                uint32_t code = ngsq_synth_ref_code(c, (uint32_t)r->ref_id, (uint64_t)r->pos + rp + (q - qp));
+                const uint64_t hs = ngsq_synth_hash(c->seed, i, NGSQ_KEY_SUB, (uint64_t)(q >> 2));
+                const uint32_t d = (uint32_t)(hs >> (16u * (q & 3u))) & 0xFFFFu;
+                if (d < 328u) { /* 0.5 %: one of the three other bases */
+                    const uint32_t idx = (code == 1u ? 0u : code == 2u ? 1u : code == 4u ? 2u : 3u);
+                    code = 1u << ((idx + 1u + d % 3u) & 3u);
+                }
+                return code;
+            }
+            qp += len;
+            rp += len;
+        } else if (op == 1u || op == 4u) { /* I, S: bases without a reference position */
+            if (q < qp + len) return iid;
+            qp += len;
+        } else if (op == 2u || op == 3u) { /* D, N */
+            rp += len;
+        }
+    }
+    return iid; /* no CIGAR (unmapped) */
+}
+
 /* packed sequence byte j (bases 2j, 2j+1; high nibble first) of record i */
 NGSQ_HD uint8_t ngsq_synth_seq_byte(const ngsq_synth_config *c, uint64_t i, uint32_t l_seq,
                                     uint32_t j) {
     /* one hash feeds four 16-bit draws = two bytes */
     const uint64_t h = ngsq_synth_hash(c->seed, i, NGSQ_KEY_SEQ, (uint64_t)(j >> 1));
     const uint32_t sh = (j & 1u) * 32u;
-    const uint32_t hi = ngsq_synth_base_code((uint32_t)((h >> sh) & 0xFFFF));
+    uint32_t hi = ngsq_synth_base_code((uint32_t)((h >> sh) & 0xFFFF));
     uint32_t lo = ngsq_synth_base_code((uint32_t)((h >> (sh + 16u)) & 0xFFFF));
+    if (c->seq_model == NGSQ_SYNTH_SEQ_FROM_REFERENCE) {
+        ngsq_synth_record r;
+        ngsq_synth_record_at(c, i, &r);
+        hi = ngsq_synth_base_from_reference(c, i, &r, 2u * j, hi);
+        lo = ngsq_synth_base_from_reference(c, i, &r, 2u * j + 1u, lo);
+    }
     if (2u * j + 1u >= l_seq) lo = 0u; /* pad nibble of an odd-length read */
     return (uint8_t)((hi << 4) | lo);
 }

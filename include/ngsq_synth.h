@@ -30,6 +30,10 @@ int ngsq_synth_fill_host(const ngsq_synth_config *cfg, uint64_t first, uint64_t 
 int ngsq_synth_fill_device(ngsq_ctx *ctx, const ngsq_synth_config *cfg, uint64_t first, uint64_t n,
                            const ngsq_batch *batch);
 
+/* The synthetic reference sequence `ref` as ngsq_config.ref_bases wants it: codes[p] = ngsq_synth_ref_code(cfg, ref, p), one
+ * 4-bit code per byte, for p in [0, len).  With cfg->seq_model = NGSQ_SYNTH_SEQ_FROM_REFERENCE the reads are sampled from it. */
+int ngsq_synth_fill_reference(const ngsq_synth_config *cfg, uint32_t ref, uint8_t *codes, uint64_t len, int n_threads);
+
 /* Write records [0, n_records) as a BGZF BAM (@SQ chr1 [, chr2]) plus a minimal BAI
  * ("<path>.bai"), rendered and deflated by n_threads workers (0 = all cores). */
 int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *path, uint64_t n_records, int level,

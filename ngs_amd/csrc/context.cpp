@@ -211,7 +211,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
             edits_off[r] = ne;
             ne += round_up(2 * (L + 1), 4);
             bases_off[r] = nbases;
-            nbases += round_up(L, 16);
+            nbases += round_up(L / 2 + 1 + 32, 16); // packed, two bases per byte; slack for the 16-byte loads past a read's last base
         }
     }
     first_chunk[nr] = (uint32_t)(nd / COV_CHUNK);
@@ -296,13 +296,39 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     if (ne) {
         CTX_TRY(hipMalloc((void **)&st.edits, ne * 4));
         CTX_TRY(hipMemsetAsync(st.edits, 0, ne * 4, c->stream));
+        // the reference, packed 4-bit, twice (edits_kernel.hip): [copy from base 0 | copy from base 1]
         uint8_t *bases = nullptr;
-        CTX_TRY(hipMalloc((void **)&bases, nbases + 64)); // k_edits reads reference bytes eight at a time
+        CTX_TRY(hipMalloc((void **)&bases, 2 * nbases + 64));
+        CTX_TRY(hipMemsetAsync(bases, 0, 2 * nbases + 64, c->stream));
         st.ref_bases = bases;
+        st.ref_bases_odd = bases + nbases;
         c->d_ref_bases = bases;
-        for (uint32_t r = 0; r < nr; r++)
-            if (bases_off[r] != NO_DEPTH)
-                CTX_TRY(hipMemcpy(bases + bases_off[r], cfg->ref_bases[r], c->ref_len[r], hipMemcpyHostToDevice));
+        uint8_t *codes = nullptr;
+        unsigned long long *d_bad = nullptr, h_bad = 0;
+        CTX_TRY(hipMalloc((void **)&codes, max_len + 64));
+        CTX_TRY(hipMalloc((void **)&d_bad, 8));
+        CTX_TRY(hipMemsetAsync(d_bad, 0, 8, c->stream));
+        uint64_t n_carry = 0;
+        c->edits_carry_off.assign(nr, 0);
+        for (uint32_t r = 0; r < nr; r++) {
+            if (bases_off[r] == NO_DEPTH) continue;
+            const uint64_t L = c->ref_len[r];
+            CTX_TRY(hipMemcpyAsync(codes, cfg->ref_bases[r], L, hipMemcpyHostToDevice, c->stream));
+            CTX_TRY(launch_pack_reference(c->li, codes, L, bases + bases_off[r], bases + nbases + bases_off[r], L / 2 + 1, d_bad, c->stream));
+            CTX_TRY(hipStreamSynchronize(c->stream)); // `codes` is reused (and the host buffer is the caller's)
+            c->edits_carry_off[r] = n_carry;
+            n_carry += edits_teardown_chunks(L + 1);
+        }
+        CTX_TRY(hipMemcpy(&h_bad, d_bad, 8, hipMemcpyDeviceToHost));
+        (void)hipFree(codes);
+        (void)hipFree(d_bad);
+        if (h_bad) {
+            ngsq_destroy(c);
+            return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "ngsq_config.ref_bases: every byte must be a 4-bit BAM base code (0..15)");
+        }
+        CTX_TRY(hipMalloc((void **)&c->d_edits_carry, (n_carry + 4) * 4));
+        c->edits_conv_lo.assign(nr, 0);
+        c->edits_conv_hi.assign(nr, 0);
     }
     c->h_vaf.assign(NGSQ_VAF_BINS, 0);
     for (int k = 0; k < K_COUNT; k++) c->timing[k] = {KERNEL_NAMES[k], 0, 0.0, 0};
@@ -335,6 +361,7 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->st.depth);
     (void)hipFree(c->st.edits);
     (void)hipFree(c->d_ref_bases);
+    (void)hipFree(c->d_edits_carry);
     (void)hipFree(c->d_ref_len);
     (void)hipFree(c->d_depth_off);
     (void)hipFree(c->d_edits_off);
@@ -754,14 +781,21 @@ int ngsq_teardown(ngsq_ctx *c) {
     if (facets & NGSQ_FACET_EDITS) {
         for (uint32_t r = 0; r < nr; r++) {
             if (c->edits_off[r] == NO_DEPTH) continue;
-            // a sharded run splits the positions of every sequence evenly over the ranks (ngsq_exchange);
-            // the partial histograms are summed with the other teardown results
-            const uint64_t L1 = (uint64_t)c->ref_len[r] + 1;
-            const uint64_t p0 = L1 * c->vaf_part / c->vaf_parts, p1 = L1 * (c->vaf_part + 1) / c->vaf_parts;
-            if (p1 <= p0) continue;
-            const uint32_t *refs = c->st.edits + c->edits_off[r];
-            Bracket br(c, K_EDITS_VAF, (p1 - p0) * 8);
-            HIP_TRY(c, launch_edits_vaf(c->li, refs + p0, refs + L1 + p0, (uint32_t)(p1 - p0 - 1), c->d_vaf, c->stream));
+            // the slot of refs holds the difference array of the `M` cover (edits_kernel.hip): carry of every 4096-entry chunk,
+            // then refs = cover - alts in place and the VAF histogram.  A sharded run splits the chunks of every sequence
+            // evenly over the ranks (ngsq_exchange); the partial histograms are summed with the other teardown results
+            const uint64_t L1 = (uint64_t)c->ref_len[r] + 1, nc = edits_teardown_chunks(L1);
+            const uint64_t c0 = nc * c->vaf_part / c->vaf_parts, c1 = nc * (c->vaf_part + 1) / c->vaf_parts;
+            uint32_t *refs = c->st.edits + c->edits_off[r], *carry = c->d_edits_carry + c->edits_carry_off[r];
+            {
+                Bracket br(c, K_EDITS_VAF, L1 * 4);
+                HIP_TRY(c, launch_edits_chunk_sums(refs, L1, carry, c->stream));
+            }
+            c->edits_conv_lo[r] = c0;
+            c->edits_conv_hi[r] = c1;
+            if (c1 <= c0) continue;
+            Bracket br(c, K_EDITS_VAF, std::min<uint64_t>(L1, (c1 - c0) * 4096) * 12);
+            HIP_TRY(c, launch_edits_refs(refs, refs + L1, L1, carry, c0, c1, c->d_vaf, c->stream));
         }
     }
     c->torn_down = true;
@@ -1029,7 +1063,16 @@ int ngsq_get_edits_positions(ngsq_ctx *c, uint32_t ref, uint32_t *refs, uint32_t
     const size_t L1 = (size_t)c->ref_len[ref] + 1;
     if (n < L1) return NGSQ_ERR_BUFFER_TOO_SMALL;
     HIP_TRY(c, hipSetDevice(c->device));
-    const uint32_t *base = c->st.edits + c->edits_off[ref];
+    uint32_t *base = c->st.edits + c->edits_off[ref];
+    {   // the chunks this context's teardown did not turn into refs (a sharded run: the other ranks' slices), without the tally
+        const uint64_t nc = edits_teardown_chunks(L1);
+        const uint32_t *carry = c->d_edits_carry + c->edits_carry_off[ref];
+        HIP_TRY(c, launch_edits_refs(base, base + L1, L1, carry, 0, c->edits_conv_lo[ref], nullptr, c->stream));
+        HIP_TRY(c, launch_edits_refs(base, base + L1, L1, carry, c->edits_conv_hi[ref], nc, nullptr, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->edits_conv_lo[ref] = 0;
+        c->edits_conv_hi[ref] = nc;
+    }
     HIP_TRY(c, hipMemcpy(refs, base, L1 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(alts, base + L1, L1 * 4, hipMemcpyDeviceToHost));
     return NGSQ_OK;

@@ -56,7 +56,11 @@ struct ngsq_ctx {
     std::vector<uint64_t> depth_off, edits_off, bin_off;
     uint32_t *d_ref_len = nullptr;
     uint64_t *d_depth_off = nullptr, *d_edits_off = nullptr, *d_bases_off = nullptr;
-    uint8_t *d_ref_bases = nullptr;
+    uint8_t *d_ref_bases = nullptr;      // both packed copies of the reference (Edits)
+    // Edits teardown: per sequence the carry of every 4096-entry chunk of its difference array, and which chunks have been
+    // turned into refs so far ([lo, hi); a sharded run converts a slice per rank, ngsq_get_edits_positions the rest)
+    uint32_t *d_edits_carry = nullptr;
+    std::vector<uint64_t> edits_carry_off, edits_conv_lo, edits_conv_hi;
     uint32_t *d_first_chunk = nullptr;
     uint64_t *d_bin_off = nullptr;
     uint64_t n_diff = 0, n_chunks = 0; // difference-array entries / scan chunks of the depth block

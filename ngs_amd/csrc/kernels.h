@@ -89,10 +89,12 @@ struct DeviceState {
     unsigned long long *touched;   // [2] min / max+1 element of `depth` written (shard exchange)
     const uint64_t *ref_depth_off; // [n_refs] element offset into depth, NO_DEPTH if not primary
     const uint32_t *ref_len;       // [n_refs]
-    uint32_t *edits;               // refs/alts per position, all sequences with bases
-    const uint64_t *ref_edits_off; // [n_refs] element offset of refs[]; alts follow at +L+1
-    const uint8_t *ref_bases;      // concatenated 4-bit codes, one per byte
-    const uint64_t *ref_bases_off; // [n_refs] byte offset, NO_DEPTH if absent
+    uint32_t *edits;               // per sequence with bases: L+1 entries that hold the difference array of the `M` cover until the
+                                   // teardown turns them into refs per position, then L+1 entries of alts (edits_kernel.hip)
+    const uint64_t *ref_edits_off; // [n_refs] element offset of that pair; alts follow at +L+1
+    const uint8_t *ref_bases;      // the reference as packed 4-bit codes in SEQ's nibble order, starting at base 0 of each sequence ...
+    const uint8_t *ref_bases_odd;  // ... and starting at base 1 (a read at an odd 0-based position finds its bytes here)
+    const uint64_t *ref_bases_off; // [n_refs] byte offset of the sequence in either copy, NO_DEPTH if absent
     uint64_t gc_seed;
     // ---- streaming Coverage (sorted_input contexts, cov_stream.hip); all null otherwise
     uint32_t *cov_end;     // [batch records] scratch column: exclusive alignment end clipped to L+1, 0 = covers nothing
@@ -210,9 +212,16 @@ struct CovScanArgs {
 };
 hipError_t launch_cov_scan(const LaunchInfo &li, const CovScanArgs &a, hipStream_t s);
 
-// Edits teardown for one sequence (edits.rs:320-341): VAF histogram from refs/alts
-hipError_t launch_edits_vaf(const LaunchInfo &li, const uint32_t *refs, const uint32_t *alts,
-                            uint32_t ref_len, unsigned long long *vaf_hist, hipStream_t s);
+// Edits, edits_kernel.hip.  The reference bases (one 4-bit code per byte, device memory) -> the two packed copies the
+// kernel compares with (n_bytes each, codes behind `len` read as 0); *bad counts bytes that are not 4-bit codes.
+hipError_t launch_pack_reference(const LaunchInfo &li, const uint8_t *codes, uint64_t len, uint8_t *even, uint8_t *odd, uint64_t n_bytes,
+                                 unsigned long long *bad, hipStream_t s);
+// Edits teardown for one sequence (edits.rs:305-344): sums[c] = sum of the difference entries in front of 4096-entry chunk c;
+// then, chunk by chunk, refs in place of the difference array and (vaf_hist != null) the VAF histogram
+uint64_t edits_teardown_chunks(uint64_t n_entries);
+hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uint32_t *sums, hipStream_t s);
+hipError_t launch_edits_refs(uint32_t *refs, const uint32_t *alts, uint64_t n_entries, const uint32_t *carry, uint64_t chunk0, uint64_t chunk1,
+                             unsigned long long *vaf_hist, hipStream_t s);
 
 // synthetic records generated in place on the device (include/ngsq_shared.h)
 struct SynthColumns {

@@ -3,9 +3,11 @@
 // that write the SoA columns in place in HBM.
 #include <hip/hip_runtime.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../include/ngsq_synth.h"
+#include "bam_reader.h"
 #include "context.h"
 
 namespace {
@@ -168,6 +170,20 @@ int ngsq_synth_sizes(const ngsq_synth_config *cfg, uint64_t first, uint64_t n, u
     if (seq_bytes) *seq_bytes = sb;
     if (qual_bytes) *qual_bytes = qb;
     if (cigar_ops) *cigar_ops = co;
+    return NGSQ_OK;
+}
+
+int ngsq_synth_fill_reference(const ngsq_synth_config *cfg, uint32_t ref, uint8_t *codes, uint64_t len, int n_threads) {
+    if (!cfg || (!codes && len)) return NGSQ_ERR_INVALID_ARGUMENT;
+    const int nt = n_threads > 0 ? n_threads : ngsq::effective_cores();
+    std::vector<std::thread> pool;
+    const uint64_t per = ((len + (uint64_t)nt - 1) / (uint64_t)nt + 31) & ~31ull;
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([=]() {
+            const uint64_t lo = per * (uint64_t)t, hi = lo + per < len ? lo + per : len;
+            for (uint64_t p = lo; p < hi; p++) codes[p] = (uint8_t)ngsq_synth_ref_code(cfg, ref, p);
+        });
+    for (auto &th : pool) th.join();
     return NGSQ_OK;
 }
 

@@ -51,6 +51,7 @@ PASS_BOTH = 3
 
 SYNTH_FIXED = 0
 SYNTH_MIXED = 1
+SYNTH_SEQ_IID, SYNTH_SEQ_FROM_REFERENCE = 0, 1  # ngsq_shared.h: where a synthetic read's bases come from
 SYNTH_FILE_PLAIN, SYNTH_FILE_ALIGNER, SYNTH_FILE_CIGAR_MIX, SYNTH_FILE_REALISTIC = 0, 1, 2, 3  # ngsq_shared.h: what a synthetic BAM FILE carries
 
 u8p = C.POINTER(C.c_uint8)
@@ -198,7 +199,7 @@ class SynthConfig(C.Structure):
         ("ref_len", C.c_uint32),
         ("n_refs", C.c_uint32),
         ("file_style", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("seq_model", C.c_uint32),
     ]
 
 
@@ -309,6 +310,7 @@ PROTOTYPES = {
     "ngsq_gc_offset": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32]),
     "ngsq_synth_sizes": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, u64p, u64p, u64p]),
     "ngsq_synth_fill_host": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
+    "ngsq_synth_fill_reference": (C.c_int, [C.POINTER(SynthConfig), C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]),
     "ngsq_synth_write_bam": (C.c_int, [C.POINTER(SynthConfig), C.c_char_p, C.c_uint64, C.c_int, C.c_int]),
     "ngsq_bam_last_error": (C.c_char_p, []),
     "ngsq_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),

@@ -96,12 +96,20 @@ def features_struct(ref_id, name, start, stop, role_name=(0, 1, 2, 3, 4)):
 
 def synth_config(n_total: int, mode: int = ffi.SYNTH_FIXED, read_len: int = 150, min_len: int = 50,
                  max_len: int = 300, ref_len: int = 248_956_422, n_refs: int = 2,
-                 seed: int = 0x4E4753, file_style: int = 0) -> ffi.SynthConfig:
+                 seed: int = 0x4E4753, file_style: int = 0, seq_model: int = 0) -> ffi.SynthConfig:
     s = ffi.SynthConfig()
-    s.file_style = file_style
+    s.file_style, s.seq_model = file_style, seq_model
     s.seed, s.n_total, s.mode, s.read_len = seed, n_total, mode, read_len
     s.min_len, s.max_len, s.ref_len, s.n_refs = min_len, max_len, ref_len, n_refs
     return s
+
+
+def synth_reference(cfg: ffi.SynthConfig, ref: int, length: int, lib=None) -> np.ndarray:
+    """The synthetic reference sequence `ref` (one 4-bit code per byte): what reads of seq_model FROM_REFERENCE are sampled from."""
+    lib = lib or ffi.load_library()
+    out = np.empty(length, dtype=np.uint8)
+    _check(lib.ngsq_synth_fill_reference(C.byref(cfg), ref, out.ctypes.data, length, 0), None, lib)
+    return out
 
 
 def synth_host_batch(cfg: ffi.SynthConfig, first: int, n: int, lib=None) -> HostBatch:
@@ -388,6 +396,13 @@ class QcContext:
                                        ffi.EDITS_BINS, vaf.ctypes.data_as(ffi.u64p), ffi.VAF_BINS),
                self._ctx, self.lib)
         return r1, r2, vaf
+
+    def edits_positions(self, ref: int):
+        """refs_per_position / alts_per_position of one sequence (edits.rs:322-324), ref_len + 1 entries each."""
+        n = int(self._ref_len[ref]) + 1
+        refs, alts = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        _check(self.lib.ngsq_get_edits_positions(self._ctx, ref, refs.ctypes.data, alts.ctypes.data, n), self._ctx, self.lib)
+        return refs, alts
 
     def results_json(self, ref_names: Sequence[str]) -> str:
         names = (C.c_char_p * max(1, len(ref_names)))(*[n.encode() for n in ref_names])

@@ -336,6 +336,83 @@ def test_edits_facet(gpu_lib, oracle_mod, seed):
     run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=ffi.FACET_EDITS, ref_bases=[bases[0], None])
 
 
+def brute_force_refs_alts(hb, ref_len, bases):
+    """refs_per_position / alts_per_position (edits.rs:276-291) by a literal walk in Python: independent of the oracle."""
+    refs = [np.zeros(L + 1, dtype=np.uint32) for L in ref_len]
+    alts = [np.zeros(L + 1, dtype=np.uint32) for L in ref_len]
+    c = hb.cols
+    for i in range(hb.n):
+        f, r, pos, l = int(c["flag"][i]), int(c["ref_id"][i]), int(c["pos"][i]), int(c["l_seq"][i])
+        if r < 0 or pos < 0 or (f & 0x404) or bases[r] is None:
+            continue
+        cig = [int(x) for x in (c["cigar"][int(c["cigar_off"][i]):int(c["cigar_off"][i + 1])] if c["cigar_off"] is not None
+                                 else c["cigar"][i * hb.cigar_stride:i * hb.cigar_stride + int(c["n_cigar"][i])])]
+        span = sum(x >> 4 for x in cig if (x & 15) in (0, 2, 3, 7, 8))
+        s = pos + 1
+        if s + span - 1 == 0 or s > ref_len[r] or s + span - 1 > ref_len[r]:
+            continue
+        sq = (c["seq"][int(c["seq_off"][i]):int(c["seq_off"][i + 1])] if c["seq_off"] is not None
+              else c["seq"][i * hb.seq_stride:i * hb.seq_stride + (l + 1) // 2])
+        read = np.empty(2 * len(sq), dtype=np.uint8)
+        read[0::2], read[1::2] = sq >> 4, sq & 15
+        qp = rp = 0
+        for x in cig:
+            op, ln = x & 15, x >> 4
+            if op == 0:
+                m = min(ln, l - qp)
+                same = read[qp:qp + m] == bases[r][pos + rp:pos + rp + m]
+                np.add.at(refs[r], s + rp + np.nonzero(same)[0], 1)
+                np.add.at(alts[r], s + rp + np.nonzero(~same)[0], 1)
+                if m < ln:
+                    break
+                qp, rp = qp + ln, rp + ln
+            else:
+                if op in (1, 4, 7, 8):
+                    if qp + ln > l:
+                        break
+                    qp += ln
+                if op in (2, 3, 7, 8):
+                    rp += ln
+    return refs, alts
+
+
+@pytest.mark.parametrize("mode", ["fixed", "mixed", "iid", "random"])
+def test_edits_positions_against_a_literal_walk(gpu_lib, oracle_mod, mode):
+    """Round 4's Edits kernel keeps the `M` cover as a difference array and only the mismatches per position; refs = cover -
+    alts appears at the teardown.  ngsq_get_edits_positions against a literal Python walk of every record, and the histograms
+    against the oracle, on reads SAMPLED FROM the reference (0.5 % substitutions: the sparse case the kernel is built for,
+    fixed 150 bases and the 50-300 base CIGAR mix), on independent bases (three in four mismatch: every dword is revisited)
+    and on random records (every CIGAR shape, unsorted, reads that run out of bases)."""
+    rng = np.random.default_rng(77)
+    if mode == "random":
+        ref_len = [6000, 2500]
+        bases = random_ref_bases(rng, ref_len)
+        hb = make_edit_friendly(random_batch(rng, 6000, ref_len, weird=False, min_len=1), rng, bases, ref_len)
+    else:
+        ref_len = [150_000, 20_000]
+        cfg = host.synth_config(30_000, mode=ffi.SYNTH_MIXED if mode == "mixed" else ffi.SYNTH_FIXED, ref_len=ref_len[0], n_refs=2,
+                                seq_model=ffi.SYNTH_SEQ_IID if mode == "iid" else ffi.SYNTH_SEQ_FROM_REFERENCE)
+        bases = [host.synth_reference(cfg, r, L, gpu_lib) for r, L in enumerate(ref_len)]
+        hb = host.synth_host_batch(cfg, 0, 30_000, gpu_lib)
+    gpu, orc = run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=ffi.FACET_EDITS, ref_bases=bases)
+    want_refs, want_alts = brute_force_refs_alts(hb, ref_len, bases)
+    for r in range(len(ref_len)):
+        refs, alts = gpu.edits_positions(r)
+        assert np.array_equal(alts, want_alts[r]) and np.array_equal(refs, want_refs[r]), (mode, r)
+    r1, r2, vaf = gpu.edits()
+    if mode in ("fixed", "mixed"):      # ~0.75 substitutions per 150 bases: most reads have none or one
+        assert r1[0] + r2[0] > 0.2 * hb.n and (r1[:4].sum() + r2[:4].sum()) > 0.9 * (r1.sum() + r2.sum())
+    if mode == "iid":
+        assert r1[:50].sum() + r2[:50].sum() == 0
+
+
+def test_reference_bases_must_be_4_bit_codes(gpu_lib):
+    bad = np.full(100, 1, dtype=np.uint8)
+    bad[57] = 65   # an ASCII letter instead of a code
+    with pytest.raises(Exception, match="4-bit"):
+        host.QcContext([100], facets=ffi.FACET_EDITS, ref_bases=[bad], lib=gpu_lib)
+
+
 def test_vaf_f32_rounding_exhaustive_small_totals(gpu_lib, oracle_mod):
     """Every (alts, total) with total <= 128 through both VAF paths (f32 divide, multiply, truncate)."""
     T = 128
