@@ -362,6 +362,7 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->st.edits);
     (void)hipFree(c->d_ref_bases);
     (void)hipFree(c->d_edits_carry);
+    (void)hipFree(c->d_edits_defer);
     (void)hipFree(c->d_ref_len);
     (void)hipFree(c->d_depth_off);
     (void)hipFree(c->d_edits_off);
@@ -574,7 +575,16 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
     }
     if (seq_f & NGSQ_FACET_EDITS) {
         Bracket br(c, K_EDITS, n * 16 + cs.cigar_ops * 4 + cs.seq_bytes);
-        HIP_TRY(c, launch_edits(c->li, c->st, db, c->stream));
+        const uint64_t words = (n + 63) / 64 + 16;
+        if (c->edits_defer_cap < words) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // (the previous batch's launches may still read the old block)
+            (void)hipFree(c->d_edits_defer);
+            c->d_edits_defer = nullptr;
+            c->edits_defer_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_edits_defer, (words + words / 4) * 8));
+            c->edits_defer_cap = words + words / 4;
+        }
+        HIP_TRY(c, launch_edits(c->li, c->st, db, c->d_edits_defer, c->stream));
     }
     return NGSQ_OK;
 }

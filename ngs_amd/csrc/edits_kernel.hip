@@ -31,13 +31,17 @@ typedef unsigned long long u64;
 
 namespace {
 
+#ifndef EDITS_EXP
+#define EDITS_EXP 0 // measurement builds only: 1 = no atomics for the mismatches, 2 = no cover (window, flush), 3 = no comparison, 4 = neither 1 nor 2
+#endif
 constexpr uint32_t ED_THREADS = 256;
 constexpr uint32_t ED_PASSES = 4;                      // records per thread and tile: lane + 64 * pass of the wave's 256 consecutive records
 constexpr uint32_t ED_WAVE_TILE = 64 * ED_PASSES;
 constexpr uint32_t ED_TILE = ED_THREADS * ED_PASSES;   // records per block and tile
-constexpr uint32_t ED_WINDOW = 2048;                   // entries of the difference array in one wave's LDS window
+constexpr uint32_t ED_WINDOW = 1536;                   // entries of the difference array in one wave's LDS window
 constexpr uint32_t ED_CHUNKS = 5;                      // 16-byte pieces of packed sequence compared per round (160 bases)
-constexpr uint32_t ED_FAST_MAX = 512;                  // longest read of the one-`M` path (a 64-bit map of its dwords)
+constexpr uint32_t ED_LIST = 4;                        // mismatching dwords a read may have on the fast path
+constexpr uint32_t ED_HIST = 64;                       // per-read edit counts tallied in LDS
 
 __device__ __forceinline__ uint32_t ed_wave_sum(uint32_t v) {
 #pragma unroll
@@ -62,11 +66,6 @@ __device__ __forceinline__ u64 ld64(const uint8_t *p) {
     __builtin_memcpy(&v, p, 8);
     return v;
 }
-__device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
 // the eight nibbles that start at nibble offset `q` of the packed run at `base`, first nibble in bits 31..28
 __device__ __forceinline__ uint32_t nibbles8(const uint8_t *base, uint64_t q) {
     const u64 v = ld64(base + (q >> 1));
@@ -75,34 +74,224 @@ __device__ __forceinline__ uint32_t nibbles8(const uint8_t *base, uint64_t q) {
     return (uint32_t)((be << ((q & 1u) * 4u)) >> 32);
 }
 
+// one record, any shape, straight to the global arrays (utils/alignment.rs:48-107 operation by operation; every `M` is compared
+// eight bases at a time from any nibble offset).  The main loop sends here what its fast path does not take: CIGARs other than
+// [clip] M [clip], reads outside the wave's window or on another sequence, reads with more mismatching dwords than its
+// list holds.  Returns 0, or 1 + the error counter the record belongs to; *out_edits = the read's edit count when 0.
+__device__ __forceinline__ uint32_t ed_walk_record(const DeviceState &st, const DeviceBatch &b, uint64_t i, uint32_t *out_edits) {
+    const uint32_t f = b.flag[i];
+    const int32_t ref = b.ref_id[i], pos = b.pos[i];
+    *out_edits = 0xFFFFFFFFu; // "not an Edits record"
+    if (!(ref >= 0 && (uint32_t)ref < st.n_refs && pos >= 0)) return 0;
+    const uint32_t n_ops = b.n_cigar[i];
+    const uint64_t cbase = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
+    uint64_t span = 0;
+    for (uint32_t k = 0; k < n_ops; k++) {
+        const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu;
+        if (op <= 8u && ((0x18Du >> op) & 1u)) span += cg >> 4;
+    }
+    const uint64_t L = st.ref_len[ref];
+    const uint64_t s = (uint64_t)pos + 1, e = s + span - 1;
+    if (e == 0 || s > L || (f & 0x404u)) return 0; // not yielded by query(); unmapped | duplicate (edits.rs:227-229)
+    const uint64_t boff = st.ref_bases_off[ref];
+    if (boff == NO_DEPTH || e > L) return 1; // edits.rs:245-261: no such sequence in the FASTA / slice out of range
+    uint32_t *const diff = st.edits + st.ref_edits_off[ref]; // entry p - 1 <-> position p (the slot that holds refs after the teardown)
+    uint32_t *const alts = diff + (L + 1);
+    const uint8_t *const sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
+    const uint8_t *const rb = st.ref_bases + boff;
+    const uint32_t l = b.l_seq[i];
+    uint32_t edits = 0, qp = 0; // record_ptr
+    uint64_t rp = 0;            // reference_ptr
+    for (uint32_t k = 0; k < n_ops; k++) {
+        const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu, len = cg >> 4;
+        if (op > 8u) continue;
+        const bool c_ref = (0x18Du >> op) & 1u; // M D N = X
+        const bool c_seq = (0x193u >> op) & 1u; // M I S = X
+        if (op == 0u) { // only Kind::Match compares (edits.rs:277)
+            // (a record that runs out of bases inside an M: alignment.rs:84-87; like the reference, the positions visited
+            // before the error stay counted -- the error aborts the run anyway)
+            const uint32_t m = (uint64_t)qp + len > l ? l - qp : len;
+            const uint64_t p0 = (uint64_t)pos + rp;
+            for (uint32_t j = 0; j < m; j += 8) {
+                uint32_t xx = nibbles8(sq, qp + j) ^ nibbles8(rb, p0 + j);
+                if (m - j < 8u) xx &= 0xFFFFFFFFu << (4u * (8u - (m - j)));
+                uint32_t t = nz_nibbles(xx);
+                edits += (uint32_t)__popc(t);
+                while (t && EDITS_EXP != 1 && EDITS_EXP != 4) {
+                    const uint32_t q = 7u - ((uint32_t)__builtin_ctz(t) >> 2); // the first base of the window is the top nibble
+                    t &= t - 1;
+                    atomicAdd(&alts[p0 + 1 + j + q], 1u);
+                }
+            }
+            if (m && EDITS_EXP != 2 && EDITS_EXP != 4) {
+                atomicAdd(&diff[p0], 1u);
+                atomicAdd(&diff[p0 + m], 0xFFFFFFFFu);
+            }
+            qp += m;
+            rp += m;
+            if (m < len) return 2;
+        } else {
+            if (c_seq) {
+                if ((uint64_t)qp + len > l) return 2;
+                qp += len;
+            }
+            if (c_ref) rp += len;
+        }
+    }
+    if (qp != l) return 3;      // alignment.rs:102-103 (the reference side is consumed by construction)
+    if (edits > 512u) return 4; // edits.rs:296-300 unwrap()
+    *out_edits = edits | (f & 0x40u ? 0x80000000u : 0u);
+    return 0;
+}
+
+// what the main loop knows of a record before it touches its bases
+struct EdCols {
+    uint32_t flag, l, n_ops;
+    int32_t ref, pos;
+    uint64_t cbase;
+};
+struct EdCigar {
+    uint32_t g0, g1, g2;
+};
+
 } // namespace
 
-__global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatch b) {
+__global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatch b, u64 *__restrict__ defer_bits) {
     NGSQ_FOREGROUND_WAVE();
-    __shared__ uint32_t s_h1[NGSQ_EDITS_BINS], s_h2[NGSQ_EDITS_BINS];
+    __shared__ uint32_t s_h1[ED_HIST], s_h2[ED_HIST];           // edit counts below ED_HIST; the rest goes straight to the counters
     __shared__ uint32_t s_win[(ED_THREADS / 64) * ED_WINDOW];
+    __shared__ uint2 s_list[ED_LIST * ED_THREADS];              // per thread: (masked XOR dword, its index) of the dwords that hold a mismatch
     __shared__ u64 s_acc[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    for (uint32_t i = tid; i < NGSQ_EDITS_BINS; i += ED_THREADS) s_h1[i] = s_h2[i] = 0;
+    for (uint32_t i = tid; i < ED_HIST; i += ED_THREADS) s_h1[i] = s_h2[i] = 0;
     for (uint32_t i = tid; i < (ED_THREADS / 64) * ED_WINDOW; i += ED_THREADS) s_win[i] = 0;
     if (tid < 4) s_acc[tid] = 0;
     __syncthreads();
     uint32_t c[4] = {0, 0, 0, 0}; // bad_ref, record_short, not_consumed, too_many
     uint32_t *const win = s_win + (tid >> 6) * ED_WINDOW;
+    uint2 *const list = s_list + (tid >> 6) * (ED_LIST * 64) + lane; // entry k at list[64 * k]
 
     // facts of the sequence the wave's window is anchored on (reloaded only when it changes: scalar registers)
     int32_t meta_ref = -1;
     uint64_t meta_eoff = NO_DEPTH, meta_boff = NO_DEPTH;
     uint32_t meta_L = 0;
 
+    auto tally = [&](uint32_t edits, bool first) { // edits.rs:296-300
+        if (edits < ED_HIST) atomicAdd(first ? &s_h1[edits] : &s_h2[edits], 1u);
+        else atomicAdd(&st.counters[(first ? st.off_edits1 : st.off_edits2) + edits], 1ull);
+    };
+
     const uint64_t n_tiles = (b.n + ED_TILE - 1) / ED_TILE;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t w0 = tile * ED_TILE + (uint64_t)(tid >> 6) * ED_WAVE_TILE; // the wave's first record
-        // ---- the wave's window: entries [win_base, win_base + ED_WINDOW) of the difference array of the sequence of its first record
+        if (w0 >= b.n) continue;
+        // ---- stage 1 of a pass: the fixed-width columns of its 64 records (records behind the end read as unmapped)
+        auto load_cols = [&](uint32_t pass) -> EdCols {
+            const uint64_t i = w0 + (uint64_t)pass * 64 + lane;
+            const bool live = i < b.n;
+            const uint64_t ii = live ? i : b.n - 1;
+            EdCols r;
+            r.flag = live ? (uint32_t)b.flag[ii] : 0x4u;
+            r.ref = b.ref_id[ii];
+            r.pos = b.pos[ii];
+            r.l = b.l_seq[ii];
+            r.n_ops = b.n_cigar[ii];
+            r.cbase = b.cigar_off ? b.cigar_off[ii] : ii * (uint64_t)b.cigar_stride;
+            return r;
+        };
+        // ---- stage 2: the first three CIGAR operations
+        auto load_cigar = [&](const EdCols &r) -> EdCigar {
+            EdCigar g{0, 0, 0};
+            if (r.n_ops > 0) g.g0 = b.cigar[r.cbase];
+            if (r.n_ops > 1) g.g1 = b.cigar[r.cbase + 1];
+            if (r.n_ops > 2) g.g2 = b.cigar[r.cbase + 2];
+            return g;
+        };
         int32_t win_ref = -1;
         uint32_t win_base = 0, top = 0;
-        if (w0 < b.n) {
-            const int32_t fr = __builtin_amdgcn_readfirstlane(b.ref_id[w0]), fp = __builtin_amdgcn_readfirstlane(b.pos[w0]);
+        // ---- stage 3 + the comparison: returns true when the record must take ed_walk_record instead
+        auto compare = [&](const EdCols &r, const EdCigar &g, uint32_t pass) -> bool {
+            if (!(r.ref >= 0 && (uint32_t)r.ref < st.n_refs && r.pos >= 0) || (r.flag & 0x404u)) return false; // never an Edits record
+            // [clip] M [clip]: read base q lies on 0-based reference position P + q, P = pos - (leading clip)
+            uint32_t a = 0, m = 0, z = 0;
+            const uint32_t o0 = g.g0 & 15u, o1 = g.g1 & 15u, o2 = g.g2 & 15u;
+            bool shape = false;
+            if (r.n_ops == 1) shape = o0 == 0u, m = g.g0 >> 4;
+            else if (r.n_ops == 2 && o0 == 4u && o1 == 0u) shape = true, a = g.g0 >> 4, m = g.g1 >> 4;
+            else if (r.n_ops == 2 && o0 == 0u && o1 == 4u) shape = true, m = g.g0 >> 4, z = g.g1 >> 4;
+            else if (r.n_ops == 3 && o0 == 4u && o1 == 0u && o2 == 4u) shape = true, a = g.g0 >> 4, m = g.g1 >> 4, z = g.g2 >> 4;
+            const uint64_t s = (uint64_t)r.pos + 1, e = s + m - 1; // (span = m for these shapes)
+            const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m; // entries of the difference array in the window
+            const bool fast = shape && m && (uint64_t)a + m + z == r.l && r.ref == win_ref && (uint32_t)r.pos >= a && e <= meta_L &&
+                              (uint32_t)r.pos >= win_base && i1 < ED_WINDOW;
+            if (!fast) return true;
+            const uint64_t i = w0 + (uint64_t)pass * 64 + lane;
+            const uint8_t *const sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
+            const uint32_t P = (uint32_t)r.pos - a;
+            const uint8_t *const rb = (P & 1u ? st.ref_bases_odd : st.ref_bases) + meta_boff + (P >> 1);
+            const uint32_t v0 = a, v1 = a + m; // the read bases that are compared
+            uint32_t edits = 0, cnt = 0;
+            for (uint32_t c0 = v0 >> 5; c0 * 32 < v1 && EDITS_EXP != 3; c0 += ED_CHUNKS) {
+                uint4 sv[ED_CHUNKS], rv[ED_CHUNKS];
+#pragma unroll
+                for (uint32_t k = 0; k < ED_CHUNKS; k++) {
+                    sv[k] = rv[k] = make_uint4(0, 0, 0, 0);
+                    if ((c0 + k) * 32 < v1) {
+                        if (EDITS_EXP == 5 || EDITS_EXP == 6) // (timing only, wrong bytes: what the sequence loads would cost if a wave's load covered 1 KiB contiguous)
+                            __builtin_memcpy(&sv[k], b.seq + (w0 + pass * 64) * (uint64_t)b.seq_stride + 16 * (64 * (c0 + k) + lane), 16);
+                        else
+                            __builtin_memcpy(&sv[k], sq + 16 * (c0 + k), 16);
+                        __builtin_memcpy(&rv[k], rb + 16 * (c0 + k), 16);
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < ED_CHUNKS; k++) {
+                    const uint32_t x[4] = {sv[k].x ^ rv[k].x, sv[k].y ^ rv[k].y, sv[k].z ^ rv[k].z, sv[k].w ^ rv[k].w};
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++) {
+                        const uint32_t j = (c0 + k) * 4 + d, b0 = 8 * j; // dword j holds read bases [b0, b0 + 8)
+                        uint32_t xx = x[d];
+                        if (b0 < v0 || b0 + 8 > v1) { // a dword at an end of the M (or outside it)
+                            const uint32_t u = b0 < v0 ? min(v0 - b0, 8u) : 0u, v = b0 + 8 > v1 ? (v1 > b0 ? v1 - b0 : 0u) : 8u;
+                            const uint32_t keep = (v >= 8u ? 0xFFFFFFFFu : v ? lead_bases_mask(v) : 0u) & ~(u >= 8u ? 0xFFFFFFFFu : u ? lead_bases_mask(u) : 0u);
+                            xx &= keep;
+                        }
+                        const uint32_t t = nz_nibbles(xx);
+                        edits += (uint32_t)__popc(t);
+                        if (t && EDITS_EXP != 6) {
+                            if (cnt < ED_LIST) list[64 * cnt] = make_uint2(xx, j);
+                            cnt += 1;
+                        }
+                    }
+                }
+            }
+            if (cnt > ED_LIST) return true; // more mismatching dwords than the list holds: the walk does this record
+            // ---- the mismatches' positions (fewer than one per read on real data)
+            for (uint32_t k = 0; k < cnt && EDITS_EXP != 1 && EDITS_EXP != 4; k++) {
+                const uint2 en = list[64 * k];
+                uint32_t t = nz_nibbles(en.x);
+                uint32_t *const alts = st.edits + meta_eoff + ((uint64_t)meta_L + 1) + (uint64_t)P + 1 + 8 * en.y;
+                while (t) {
+                    const uint32_t q = (uint32_t)__builtin_ctz(t) >> 2; // nibble q: byte q >> 1, its high nibble (q odd) is the earlier base
+                    t &= t - 1;
+                    atomicAdd(&alts[(q & ~1u) + ((q & 1u) ^ 1u)], 1u);
+                }
+            }
+            if (EDITS_EXP != 2 && EDITS_EXP != 4) {
+                atomicAdd(&win[i0], 1u);
+                atomicAdd(&win[i1], 0xFFFFFFFFu);
+                top = max(top, (uint32_t)i1);
+            }
+            if (EDITS_EXP == 6) edits = edits ? 1u : 0u;
+            if (edits > 512u) c[3] += 1;
+            else tally(edits, r.flag & 0x40u);
+            return false;
+        };
+        // ---- the four passes, software-pipelined: the columns of pass p + 2 and the CIGARs of pass p + 1 are in flight while
+        // pass p is compared (nothing in compare() but its own loads touches memory on the usual path)
+        EdCols c0 = load_cols(0), c1 = load_cols(1);
+        {   // the wave's window: entries [win_base, win_base + ED_WINDOW) of the difference array of the sequence of its first record
+            const int32_t fr = __builtin_amdgcn_readfirstlane(c0.ref), fp = __builtin_amdgcn_readfirstlane(c0.pos);
             if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
                 if (fr != meta_ref) {
                     const uint64_t eo = st.ref_edits_off[fr], bo = st.ref_bases_off[fr];
@@ -114,152 +303,25 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatc
                 }
                 if (meta_boff != NO_DEPTH) {
                     win_ref = fr;
-                    win_base = (uint32_t)fp & ~3u; // entry index = position - 1 = 0-based position: <= the first record's
+                    win_base = (uint32_t)fp & ~3u; // entry index = 0-based position: <= the first record's
                 }
             }
         }
-#pragma unroll 1
-        for (uint32_t pass = 0; pass < ED_PASSES; pass++) {
-            const uint64_t i = w0 + (uint64_t)pass * 64 + lane;
-            if (i >= b.n) continue;
-            // ---- the record's placement (query() filter, flags, reference slice): edits.rs:227-261
-            const uint32_t f = b.flag[i];
-            const int32_t ref = b.ref_id[i], pos = b.pos[i];
-            if (!(ref >= 0 && (uint32_t)ref < st.n_refs && pos >= 0)) continue;
-            const uint32_t n_ops = b.n_cigar[i];
-            const uint64_t cbase = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
-            const uint32_t cg0 = n_ops ? b.cigar[cbase] : 0u;
-            uint64_t span = 0;
-            if (n_ops == 1) {
-                if ((cg0 & 0xFu) <= 8u && ((0x18Du >> (cg0 & 0xFu)) & 1u)) span = cg0 >> 4;
-            } else {
-                for (uint32_t k = 0; k < n_ops; k++) {
-                    const uint32_t cg = b.cigar[cbase + k], op = cg & 0xFu;
-                    if (op <= 8u && ((0x18Du >> op) & 1u)) span += cg >> 4;
-                }
-            }
-            const bool on_win = ref == win_ref;
-            const uint64_t L = on_win ? meta_L : st.ref_len[ref];
-            const uint64_t s = (uint64_t)pos + 1, e = s + span - 1;
-            if (e == 0 || s > L || (f & 0x404u)) continue; // not yielded by query(); unmapped | duplicate (edits.rs:227-229)
-            const uint64_t boff = on_win ? meta_boff : st.ref_bases_off[ref];
-            if (boff == NO_DEPTH || e > L) { // edits.rs:245-261: no such sequence in the FASTA / slice out of range
-                c[0] += 1;
-                continue;
-            }
-            const uint64_t eoff = on_win ? meta_eoff : st.ref_edits_off[ref];
-            uint32_t *const diff = st.edits + eoff;  // entry p - 1 <-> position p (the slot that holds refs after the teardown)
-            uint32_t *const alts = diff + (L + 1);   // alts[p]
-            const uint8_t *const sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
-            const uint32_t l = b.l_seq[i];
-            // one `M` run [p0, p0 + len) of 0-based positions joins the difference array
-            auto cover = [&](uint64_t p0, uint64_t len) {
-                if (!len) return;
-                const uint64_t i0 = p0 - win_base, i1 = p0 + len - win_base; // (wraps when p0 < win_base: then i0 is huge)
-                if (on_win && p0 >= win_base && i1 < ED_WINDOW) {
-                    atomicAdd(&win[i0], 1u);
-                    atomicAdd(&win[i1], 0xFFFFFFFFu);
-                    top = max(top, (uint32_t)i1);
-                } else {
-                    atomicAdd(&diff[p0], 1u);
-                    atomicAdd(&diff[p0 + len], 0xFFFFFFFFu);
-                }
-            };
-            uint32_t edits = 0;
-            uint32_t qp = 0; // record_ptr
-            int err = 0;
-            if (n_ops == 1 && cg0 == (l << 4) && l <= ED_FAST_MAX) {
-                // ---- the usual read: one M over all its bases.  Its reference bytes start at a byte of one of the two packed
-                // copies (position parity); 16 bytes of each per step, five steps in flight together.
-                const uint8_t *const rb = (pos & 1 ? st.ref_bases_odd : st.ref_bases) + boff + ((uint32_t)pos >> 1);
-                const uint32_t nd = (l + 7) >> 3; // dwords that hold bases
-                u64 bm = 0;                       // dwords with a mismatch
-                for (uint32_t c0 = 0; c0 * 4 < nd; c0 += ED_CHUNKS) {
-                    uint4 sv[ED_CHUNKS], rv[ED_CHUNKS];
-#pragma unroll
-                    for (uint32_t k = 0; k < ED_CHUNKS; k++) {
-                        sv[k] = rv[k] = make_uint4(0, 0, 0, 0);
-                        if ((c0 + k) * 4 < nd) {
-                            __builtin_memcpy(&sv[k], sq + 16 * (c0 + k), 16);
-                            __builtin_memcpy(&rv[k], rb + 16 * (c0 + k), 16);
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t k = 0; k < ED_CHUNKS; k++) {
-                        const uint32_t x[4] = {sv[k].x ^ rv[k].x, sv[k].y ^ rv[k].y, sv[k].z ^ rv[k].z, sv[k].w ^ rv[k].w};
-#pragma unroll
-                        for (uint32_t d = 0; d < 4; d++) {
-                            const uint32_t j = (c0 + k) * 4 + d;
-                            uint32_t xx = x[d];
-                            if (8 * j + 8 > l) xx = 8 * j < l ? xx & lead_bases_mask(l - 8 * j) : 0u; // the read's last, partial dword; nothing behind it
-                            const uint32_t t = nz_nibbles(xx);
-                            edits += (uint32_t)__popc(t);
-                            bm |= (u64)(t != 0) << (j & 63u);
-                        }
-                    }
-                }
-                // ---- the dwords that hold a mismatch, again, for the positions (fewer than one per read on real data)
-                while (bm) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(bm);
-                    bm &= bm - 1;
-                    uint32_t xx = ld32(sq + 4 * j) ^ ld32(rb + 4 * j);
-                    if (8 * j + 8 > l) xx &= lead_bases_mask(l - 8 * j);
-                    uint32_t t = nz_nibbles(xx);
-                    while (t) {
-                        const uint32_t k = (uint32_t)__builtin_ctz(t) >> 2; // nibble k: byte k >> 1, its high nibble (k odd) is the earlier base
-                        t &= t - 1;
-                        atomicAdd(&alts[s + 8 * j + (k & ~1u) + ((k & 1u) ^ 1u)], 1u);
-                    }
-                }
-                cover((uint64_t)pos, l);
-                qp = l;
-            } else {
-                // ---- any other CIGAR: walk the operations (utils/alignment.rs:48-107); only Kind::Match compares (edits.rs:277)
-                const uint8_t *const rb = st.ref_bases + boff;
-                uint64_t rp = 0; // reference_ptr
-                for (uint32_t k = 0; k < n_ops && !err; k++) {
-                    const uint32_t cg = k ? b.cigar[cbase + k] : cg0, op = cg & 0xFu, len = cg >> 4;
-                    if (op > 8u) continue;
-                    const bool c_ref = (0x18Du >> op) & 1u; // M D N = X
-                    const bool c_seq = (0x193u >> op) & 1u; // M I S = X
-                    if (op == 0u) {
-                        // (a record that runs out of bases inside an M: alignment.rs:84-87; like the reference, the positions
-                        // visited before the error stay counted -- the error aborts the run anyway)
-                        const uint32_t m = (uint64_t)qp + len > l ? l - qp : len;
-                        const uint64_t p0 = (uint64_t)pos + rp;
-                        for (uint32_t j = 0; j < m; j += 8) {
-                            uint32_t xx = nibbles8(sq, qp + j) ^ nibbles8(rb, p0 + j);
-                            if (m - j < 8u) xx &= 0xFFFFFFFFu << (4u * (8u - (m - j)));
-                            uint32_t t = nz_nibbles(xx);
-                            edits += (uint32_t)__popc(t);
-                            while (t) {
-                                const uint32_t q = 7u - ((uint32_t)__builtin_ctz(t) >> 2); // first base of the window is the top nibble
-                                t &= t - 1;
-                                atomicAdd(&alts[p0 + 1 + j + q], 1u);
-                            }
-                        }
-                        cover(p0, m);
-                        qp += m;
-                        rp += m;
-                        if (m < len) err = 2;
-                    } else {
-                        if (c_seq) {
-                            if ((uint64_t)qp + len > l) {
-                                err = 2;
-                                break;
-                            }
-                            qp += len;
-                        }
-                        if (c_ref) rp += len;
-                    }
-                }
-            }
-            if (err == 2) c[1] += 1;
-            else if (qp != l) c[2] += 1;      // alignment.rs:102-103 (the reference side is consumed by construction)
-            else if (edits > 512u) c[3] += 1; // edits.rs:296-300 unwrap()
-            else if (f & 0x40u) atomicAdd(&s_h1[edits], 1u);
-            else atomicAdd(&s_h2[edits], 1u);
-        }
+        const EdCigar g0 = load_cigar(c0);
+        const EdCols c2 = load_cols(2);
+        const EdCigar g1 = load_cigar(c1);
+        // (a record the fast path does not take is marked in the launch's bitmap: k_edits_walk does it afterwards)
+        auto mark = [&](uint32_t pass, bool d) {
+            const u64 dm = __ballot(d);
+            if (lane == 0 && w0 + (uint64_t)pass * 64 < b.n) defer_bits[(w0 >> 6) + pass] = dm;
+        };
+        mark(0, compare(c0, g0, 0));
+        const EdCols c3 = load_cols(3);
+        const EdCigar g2 = load_cigar(c2);
+        mark(1, compare(c1, g1, 1));
+        const EdCigar g3 = load_cigar(c3);
+        mark(2, compare(c2, g2, 2));
+        mark(3, compare(c3, g3, 3));
         // ---- the wave flushes the touched part of its window with coalesced global atomics and leaves it zeroed.
         // No barrier: LDS operations of one wave execute in order.
 #pragma unroll
@@ -289,11 +351,320 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatc
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < NGSQ_EDITS_BINS; i += ED_THREADS) {
+    for (uint32_t i = tid; i < ED_HIST; i += ED_THREADS) {
         uint32_t v = s_h1[i];
         if (v) atomicAdd(&st.counters[st.off_edits1 + i], (u64)v);
         v = s_h2[i];
         if (v) atomicAdd(&st.counters[st.off_edits2 + i], (u64)v);
+    }
+    const uint32_t idx[4] = {C_ERR + E_EDITS_BAD_REF, C_ERR + E_EDITS_SHORT, C_ERR + E_EDITS_NOT_CONSUMED, C_ERR + E_EDITS_TOO_MANY};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t r = ed_wave_sum(c[k]);
+        if (lane == 0 && r) atomicAdd(&s_acc[k], (u64)r);
+    }
+    __syncthreads();
+    if (tid < 4 && s_acc[tid]) atomicAdd(&st.counters[idx[tid]], s_acc[tid]);
+}
+
+// ---------------------------------------------------------------------------
+// Fixed-pitch sequence rows (reads of one length, the layout the readers choose for them): the comparison with a LANE PER
+// 16-BYTE WINDOW of the packed rows instead of a lane per record.  With a lane per record every one of a read's five 16-byte
+// loads sweeps the wave's whole 4.8 KB of rows (64 lanes 75 bytes apart: ~38 cache lines per instruction, each line fetched
+// by five instructions); consecutive lanes on consecutive windows read 1 KiB contiguous per instruction -- every line once
+// (measured with the bytes deliberately wrong: 3.65 -> 2.70 ms per 100 M reads).  Per 64 records a wave runs
+//   1. lane = record: columns, CIGAR shape, the record's descriptor (reference position of its base 0, compared bases
+//      [v0, v1)) into LDS, its `M` into the cover window;
+//   2. lane = window g of the 64 rows (record g / R, window g % R; R windows per row): 16 bytes of sequence XOR 16 bytes of
+//      the packed reference -- consecutive lanes of a record read consecutive reference bytes, neighbouring records nearly the
+//      same ones (L1) --, masked to [v0, v1), mismatches counted into the record's LDS slot and added to alts;
+//   3. lane = record: the per-read edit count into the histogram.
+// Records the fast path does not take (other CIGARs, outside the window, another sequence) go through ed_walk_record.
+// ---------------------------------------------------------------------------
+constexpr uint32_t ED_NW = 5;                    // windows per row the kernel is built for (reads of up to 160 bases)
+constexpr uint32_t EDR_PASSES = 4;               // passes of 64 records per wave and window flush
+constexpr uint32_t EDR_WAVE_TILE = 64 * EDR_PASSES, EDR_TILE = ED_THREADS * EDR_PASSES;
+constexpr uint32_t EDR_WINDOW = 1536;            // entries of the wave's cover window (256 sorted reads: 790 positions at 60x, 1430 at 30x)
+constexpr uint32_t EDR_ALTW = EDR_WINDOW / 2;    // dwords of its alts window: 16-bit counters, two positions per dword
+
+struct EdRowCols {
+    uint32_t flag, l, n_ops, g0, g1, g2;
+    int32_t ref, pos;
+};
+
+// CIG_OFF: the CIGARs are addressed through cigar_off (their loads then wait for the offsets; with a fixed pitch they are
+// prefetched with the columns of the pass)
+template <bool CIG_OFF>
+__global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, DeviceBatch b, uint32_t R, uint32_t recip, u64 *__restrict__ defer_bits) {
+    NGSQ_FOREGROUND_WAVE();
+    __shared__ uint32_t s_h1[ED_HIST], s_h2[ED_HIST];
+    __shared__ uint32_t s_win[(ED_THREADS / 64) * EDR_WINDOW];  // cover: difference entries
+    __shared__ uint32_t s_alt[(ED_THREADS / 64) * EDR_ALTW];    // mismatches per position of the same window
+    __shared__ uint2 s_desc[ED_THREADS];   // per record of the wave's current 64: (P, v0 | v1 << 16); v1 = 0: not on the fast path
+    __shared__ uint32_t s_edits[ED_THREADS];
+    __shared__ uint32_t s_tmask[33];       // [n]: the bits 4 q + d of the first n bases of a window (base 8 d + (q ^ 1))
+    __shared__ u64 s_acc[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint32_t i = tid; i < ED_HIST; i += ED_THREADS) s_h1[i] = s_h2[i] = 0;
+    if (tid < 33) {
+        uint32_t m = 0;
+        for (uint32_t i = 0; i < tid; i++) m |= 1u << (4u * ((i & 7u) ^ 1u) + (i >> 3));
+        s_tmask[tid] = m;
+    }
+    for (uint32_t i = tid; i < (ED_THREADS / 64) * EDR_WINDOW; i += ED_THREADS) s_win[i] = 0;
+    for (uint32_t i = tid; i < (ED_THREADS / 64) * EDR_ALTW; i += ED_THREADS) s_alt[i] = 0;
+    if (tid < 4) s_acc[tid] = 0;
+    __syncthreads();
+    uint32_t c_too_many = 0;
+    uint32_t *const win = s_win + wv * EDR_WINDOW;
+    uint32_t *const altw = s_alt + wv * EDR_ALTW;
+    uint2 *const desc = s_desc + wv * 64;
+    uint32_t *const red = s_edits + wv * 64;
+
+    int32_t meta_ref = -1;
+    uint64_t meta_eoff = NO_DEPTH, meta_boff = NO_DEPTH;
+    uint32_t meta_L = 0;
+
+    const uint32_t stride = b.seq_stride;
+    const uint64_t n = b.n, n_tiles = (n + EDR_TILE - 1) / EDR_TILE;
+    // the columns of a pass (records behind the end read as unmapped) and, with a fixed CIGAR pitch, the first three operations
+    auto load_cols = [&](uint64_t r0) -> EdRowCols {
+        const uint64_t i = r0 + lane;
+        const bool live = i < n;
+        const uint64_t ii = live ? i : n - 1;
+        EdRowCols r;
+        r.flag = live ? (uint32_t)b.flag[ii] : 0x4u;
+        r.ref = b.ref_id[ii];
+        r.pos = b.pos[ii];
+        r.l = b.l_seq[ii];
+        r.n_ops = b.n_cigar[ii];
+        r.g0 = r.g1 = r.g2 = 0;
+        if (!CIG_OFF) {
+            const uint64_t cb = ii * (uint64_t)b.cigar_stride;
+            r.g0 = b.cigar[cb];
+            if (b.cigar_stride > 1) r.g1 = b.cigar[cb + 1];
+            if (b.cigar_stride > 2) r.g2 = b.cigar[cb + 2];
+        }
+        return r;
+    };
+    int32_t win_ref = -1;
+    uint32_t win_base = 0, top = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t w0 = tile * EDR_TILE + (uint64_t)wv * EDR_WAVE_TILE; // the wave's first record
+        if (w0 >= n) continue;
+        EdRowCols cur = load_cols(w0);
+        {   // the wave's window: entries [win_base, win_base + EDR_WINDOW) of the difference array of the sequence of its first record
+            win_ref = -1;
+            const int32_t fr = __builtin_amdgcn_readfirstlane(cur.ref), fp = __builtin_amdgcn_readfirstlane(cur.pos);
+            if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
+                if (fr != meta_ref) {
+                    const uint64_t eo = st.ref_edits_off[fr], bo = st.ref_bases_off[fr];
+                    const uint32_t l = st.ref_len[fr];
+                    meta_ref = fr;
+                    meta_eoff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(eo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)eo);
+                    meta_boff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bo);
+                    meta_L = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+                }
+                if (meta_boff != NO_DEPTH) {
+                    win_ref = fr;
+                    win_base = (uint32_t)fp & ~3u;
+                }
+            }
+        }
+#pragma unroll 1
+        for (uint32_t pass = 0; pass < EDR_PASSES; pass++) {
+            const uint64_t r0 = w0 + (uint64_t)pass * 64;
+            if (r0 >= n) break;
+            // ---- 1. lane = record
+            EdRowCols r = cur;
+            if (CIG_OFF) {
+                const uint64_t i = r0 + lane;
+                const uint64_t cb = b.cigar_off[i < n ? i : n - 1];
+                if (r.n_ops > 0) r.g0 = b.cigar[cb];
+                if (r.n_ops > 1) r.g1 = b.cigar[cb + 1];
+                if (r.n_ops > 2) r.g2 = b.cigar[cb + 2];
+            }
+            bool own = false, deferred = false;
+            uint32_t P = 0, vv = 0;
+            if (r.ref >= 0 && (uint32_t)r.ref < st.n_refs && r.pos >= 0 && !(r.flag & 0x404u)) {
+                // [clip] M [clip]: read base q lies on 0-based reference position P + q, P = pos - (leading clip)
+                uint32_t a = 0, m = 0, z = 0;
+                const uint32_t o0 = r.g0 & 15u, o1 = r.g1 & 15u, o2 = r.g2 & 15u;
+                bool shape = false;
+                if (r.n_ops == 1) shape = o0 == 0u, m = r.g0 >> 4;
+                else if (r.n_ops == 2 && o0 == 4u && o1 == 0u) shape = true, a = r.g0 >> 4, m = r.g1 >> 4;
+                else if (r.n_ops == 2 && o0 == 0u && o1 == 4u) shape = true, m = r.g0 >> 4, z = r.g1 >> 4;
+                else if (r.n_ops == 3 && o0 == 4u && o1 == 0u && o2 == 4u) shape = true, a = r.g0 >> 4, m = r.g1 >> 4, z = r.g2 >> 4;
+                const uint64_t e = (uint64_t)r.pos + m; // 1-based last position (span = m for these shapes)
+                const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m;
+                // (P >= win_base: a mismatch's window entry is counted from P's)
+                own = shape && m && (uint64_t)a + m + z == r.l && r.l <= 2 * stride && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_L &&
+                      i1 < EDR_WINDOW;
+                if (own) {
+                    P = (uint32_t)r.pos - a;
+                    vv = a | (a + m) << 16;
+                    if (EDITS_EXP != 2 && EDITS_EXP != 4) {
+                        atomicAdd(&win[i0], 1u);
+                        atomicAdd(&win[i1], 0xFFFFFFFFu);
+                    }
+                    top = max(top, (uint32_t)i1);
+                } else {
+                    deferred = true;
+                }
+            }
+            {   // (a record the fast path does not take is marked in the launch's bitmap: k_edits_walk does it afterwards)
+                const u64 dm = __ballot(deferred);
+                if (lane == 0) defer_bits[r0 >> 6] = dm;
+            }
+            desc[lane] = make_uint2(P, vv);
+            red[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- 2. lane = window g = 64 k + lane of the pass's rows (record g / R, window g % R): 16 bytes of sequence, 16 of
+            // the reference (a window without compared bases reads the arrays' first bytes: nothing of it is kept)
+            const uint8_t *const rows = b.seq + r0 * stride;
+            const uint64_t last = n - 1 - r0; // rows of the pass that exist
+            struct Win {
+                uint4 sv, rv;
+                uint32_t slot, x0, lohi; // record slot, window entry of base 0 of the window, compared bases lo | hi << 8 (none: 0)
+            };
+            // window g = 64 k + lane is window ww of row rr at byte `off` of the pass's rows: stepped from k to k + 1 without a division
+            uint32_t w_rr = (lane * recip) >> 16, w_ww = lane - w_rr * R, w_off = w_rr * stride + 16 * w_ww;
+            const uint32_t step_rr = 64 / R, step_ww = 64 - step_rr * R, step_off = step_rr * stride + 16 * step_ww;
+            auto load_win = [&]() -> Win { // the window (w_rr, w_ww); then on to the next one
+                const uint2 d = desc[w_rr];
+                const uint32_t v0 = d.y & 0xFFFFu, v1 = d.y >> 16, b0 = 32 * w_ww;
+                const bool on = b0 < v1 && b0 + 32 > v0 && w_rr <= last; // the window holds compared bases
+                const uint8_t *const sp = rows + (on ? w_off : 0u);
+                const uint8_t *const rp = (d.x & 1u ? st.ref_bases_odd : st.ref_bases) + (on ? meta_boff + (d.x >> 1) + 16 * w_ww : 0ull);
+                Win w;
+                __builtin_memcpy(&w.sv, sp, 16);
+                __builtin_memcpy(&w.rv, rp, 16);
+                w.slot = w_rr;
+                w.x0 = d.x + b0 - win_base;
+                const uint32_t lo = v0 > b0 ? v0 - b0 : 0u, hi = v1 < b0 + 32 ? v1 - b0 : 32u; // (on: v1 > b0)
+                w.lohi = on ? lo | hi << 8 : 0u;
+                w_rr += step_rr, w_ww += step_ww, w_off += step_off;
+                if (w_ww >= R) w_ww -= R, w_rr += 1, w_off += stride - 16 * R;
+                return w;
+            };
+            auto compare_win = [&](const Win &w) {
+                // the mismatching nibbles of the four dwords in one word: bit 4 q + d <-> nibble q of dword d = base 8 d + (q ^ 1) of
+                // the window; the window's compared bases are [lo, hi): two table masks in that bit order
+                const uint32_t x0 = w.sv.x ^ w.rv.x, x1 = w.sv.y ^ w.rv.y, x2 = w.sv.z ^ w.rv.z, x3 = w.sv.w ^ w.rv.w;
+                const uint32_t n0 = (((x0 & 0x77777777u) + 0x77777777u) | x0) & 0x88888888u, n1 = (((x1 & 0x77777777u) + 0x77777777u) | x1) & 0x88888888u,
+                               n2 = (((x2 & 0x77777777u) + 0x77777777u) | x2) & 0x88888888u, n3 = (((x3 & 0x77777777u) + 0x77777777u) | x3) & 0x88888888u;
+                uint32_t t = ((n0 >> 3) | (n1 >> 2) | (n2 >> 1) | n3) & s_tmask[w.lohi >> 8] & ~s_tmask[w.lohi & 0xFFu];
+                if (t) {
+                    atomicAdd(&red[w.slot], (uint32_t)__popc(t));
+                    while (t && EDITS_EXP != 1 && EDITS_EXP != 4) {
+                        const uint32_t bit = (uint32_t)__builtin_ctz(t);
+                        t &= t - 1;
+                        const uint32_t x0e = w.x0 + 8 * (bit & 3u) + ((bit >> 2) ^ 1u); // window entry of the 0-based position
+                        atomicAdd(&altw[x0e >> 1], 1u << (16u * (x0e & 1u)));
+                    }
+                }
+            };
+            Win wa = load_win(), wb = wa;
+            if (pass + 1 < EDR_PASSES) cur = load_cols(r0 + 64); // in flight while this pass is compared
+#pragma unroll 1
+            for (uint32_t k = 0; k < R && EDITS_EXP != 3; k += 2) { // the next window's bytes are in flight while one is compared
+                if (k + 1 < R) wb = load_win();
+                compare_win(wa);
+                if (k + 1 >= R) break;
+                if (k + 2 < R) wa = load_win();
+                compare_win(wb);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- 3. lane = record: edits.rs:296-300
+            if (own) {
+                const uint32_t edits = red[lane];
+                if (edits > 512u) c_too_many += 1;
+                else if (edits < ED_HIST) atomicAdd((r.flag & 0x40u) ? &s_h1[edits] : &s_h2[edits], 1u);
+                else atomicAdd(&st.counters[((r.flag & 0x40u) ? st.off_edits1 : st.off_edits2) + edits], 1ull);
+            }
+        }
+        // ---- the wave adds the touched part of its two windows to the global arrays (coalesced atomics) and leaves them zeroed
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) top = max(top, (uint32_t)__shfl_xor(top, o, 64));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (win_ref >= 0 && top) {
+            uint32_t *const dst = st.edits + meta_eoff + win_base;
+            uint32_t *const adst = dst + ((uint64_t)meta_L + 1) + 1; // alts[1 + 0-based position]
+            for (uint32_t ib = 0; ib <= top; ib += 256) {
+                uint32_t v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = ib + 64 * k + lane;
+                    v[k] = i < EDR_WINDOW ? win[i] : 0u;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = ib + 64 * k + lane;
+                    if (v[k]) {
+                        atomicAdd(&dst[i], v[k]);
+                        win[i] = 0;
+                    }
+                }
+            }
+            for (uint32_t ib = 0; 2 * ib < top; ib += 64) { // (a mismatch lies below the end of its read's M: below `top`)
+                const uint32_t i = ib + lane;
+                const uint32_t v = i < EDR_ALTW ? altw[i] : 0u;
+                if (v) {
+                    if (v & 0xFFFFu) atomicAdd(&adst[2 * i], v & 0xFFFFu);
+                    if (v >> 16) atomicAdd(&adst[2 * i + 1], v >> 16);
+                    altw[i] = 0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        top = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ED_HIST; i += ED_THREADS) {
+        uint32_t v = s_h1[i];
+        if (v) atomicAdd(&st.counters[st.off_edits1 + i], (u64)v);
+        v = s_h2[i];
+        if (v) atomicAdd(&st.counters[st.off_edits2 + i], (u64)v);
+    }
+    {
+        const uint32_t r = ed_wave_sum(c_too_many);
+        if (lane == 0 && r) atomicAdd(&s_acc[3], (u64)r);
+    }
+    __syncthreads();
+    if (tid == 3 && s_acc[3]) atomicAdd(&st.counters[C_ERR + E_EDITS_TOO_MANY], s_acc[3]);
+}
+
+// The records the fast paths left: a wave per 64 records (one word of the bitmap: nothing marked, nothing done), a lane per
+// marked record.
+__global__ __launch_bounds__(256) void k_edits_walk(DeviceState st, DeviceBatch b, const u64 *__restrict__ defer_bits) {
+    __shared__ uint32_t s_h1[NGSQ_EDITS_BINS], s_h2[NGSQ_EDITS_BINS];
+    __shared__ u64 s_acc[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t k = tid; k < NGSQ_EDITS_BINS; k += 256) s_h1[k] = s_h2[k] = 0;
+    if (tid < 4) s_acc[tid] = 0;
+    __syncthreads();
+    uint32_t c[4] = {0, 0, 0, 0};
+    const uint64_t n_words = (b.n + 63) / 64, waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + (tid >> 6); w < n_words; w += waves) {
+        const u64 word = defer_bits[w]; // (wave-uniform address: a scalar load)
+        if (!word) continue;
+        const uint64_t i = w * 64 + lane;
+        if (!((word >> lane) & 1ull) || i >= b.n) continue;
+        uint32_t edits = 0;
+        const uint32_t err = ed_walk_record(st, b, i, &edits);
+        if (err) c[err - 1] += 1;
+        else if (edits != 0xFFFFFFFFu) atomicAdd(edits >> 31 ? &s_h1[edits & 0x7FFFFFFFu] : &s_h2[edits & 0x7FFFFFFFu], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < NGSQ_EDITS_BINS; k += 256) {
+        uint32_t v = s_h1[k];
+        if (v) atomicAdd(&st.counters[st.off_edits1 + k], (u64)v);
+        v = s_h2[k];
+        if (v) atomicAdd(&st.counters[st.off_edits2 + k], (u64)v);
     }
     const uint32_t idx[4] = {C_ERR + E_EDITS_BAD_REF, C_ERR + E_EDITS_SHORT, C_ERR + E_EDITS_NOT_CONSUMED, C_ERR + E_EDITS_TOO_MANY};
 #pragma unroll
@@ -441,7 +812,7 @@ __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs,
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
+hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, unsigned long long *defer_bits, hipStream_t s) {
     if (!b.n) return hipSuccess;
     static int per_cu = -1;
     if (per_cu < 0) {
@@ -451,7 +822,18 @@ hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const Devic
     uint64_t g = (b.n + ED_TILE - 1) / ED_TILE;
     const uint64_t cap = (uint64_t)li.n_cu * (uint32_t)per_cu;
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(k_edits, dim3((uint32_t)g), dim3(ED_THREADS), 0, s, st, b);
+    // fixed-pitch rows of reads of up to 160 bases: a lane per 16-byte window (k_edits_rows); longer rows and the offsets
+    // layout: a lane per record
+    static const bool per_record = getenv("NGSQ_EDITS_PER_RECORD") && atoi(getenv("NGSQ_EDITS_PER_RECORD")); // A/B measurements
+    const uint32_t R = (b.seq_stride + 15) / 16;
+    const uint32_t gr = (uint32_t)std::min<uint64_t>((b.n + EDR_TILE - 1) / EDR_TILE, cap);
+    if (!b.seq_off && R >= 1 && R <= ED_NW && !per_record && b.cigar_off)
+        hipLaunchKernelGGL(k_edits_rows<true>, dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, 65536u / R + 1u, defer_bits);
+    else if (!b.seq_off && R >= 1 && R <= ED_NW && !per_record && b.cigar_stride >= 1)
+        hipLaunchKernelGGL(k_edits_rows<false>, dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, 65536u / R + 1u, defer_bits);
+    else
+        hipLaunchKernelGGL(k_edits, dim3((uint32_t)g), dim3(ED_THREADS), 0, s, st, b, defer_bits);
+    hipLaunchKernelGGL(k_edits_walk, dim3((uint32_t)std::min<uint64_t>((b.n + 255) / 256, (uint64_t)li.n_cu * 8)), dim3(256), 0, s, st, b, defer_bits);
     return hipGetLastError();
 }
 

@@ -179,8 +179,8 @@ hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const De
 // Quality Score for the offsets layout with max_read_len <= 320 (qual_kernel.hip)
 bool qual_ragged_supported(const DeviceState &st, const DeviceBatch &b);
 hipError_t launch_qual_ragged(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s);
-// Edits process (edits.rs:217-303)
-hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b,
+// Edits process (edits.rs:217-303), edits_kernel.hip; defer_bits: scratch of at least (b.n + 63) / 64 words (device memory)
+hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, unsigned long long *defer_bits,
                         hipStream_t s);
 
 // Coverage teardown for every sequence in ONE launch (coverage.rs:182-246): prefix-sum the

@@ -1,9 +1,10 @@
-# phase switches of k_edits (measurement builds): bash tools/edits_exp.sh
+# phase switches of k_edits (measurement builds): bash tools/edits_exp.sh "0 1 2 3" [edits_time.py args]
 set -u
 cd $GRAFT_REPO_ROOT
-for e in 0 1 2; do
-  touch ngs_amd/csrc/kernels.hip
+EXPS=${1:-"0 1 2 3"}; shift || true
+for e in $EXPS; do
+  touch ngs_amd/csrc/edits_kernel.hip
   NGSQ_EXTRA_FLAGS="-DEDITS_EXP=$e" python -m ngs_amd.build > /tmp/b.log 2>&1 || tail -3 /tmp/b.log
-  python bench.py --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('EDITS_EXP=$e', d['extra_facets']['kernels']['edits'])"
+  python tools/edits_time.py --tag "EDITS_EXP=$e" "$@"
 done
-touch ngs_amd/csrc/kernels.hip; python -m ngs_amd.build > /dev/null 2>&1
+touch ngs_amd/csrc/edits_kernel.hip; python -m ngs_amd.build > /dev/null 2>&1
