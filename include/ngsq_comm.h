@@ -71,6 +71,10 @@ int ngsq_comm_world(const ngsq_comm *comm);
 const char *ngsq_comm_kind(const ngsq_comm *comm);
 /* ncclGetVersion of the library the rccl transport bound (e.g. 22605), 0 when none could be loaded */
 int ngsq_comm_rccl_version(void);
+/* 1: an ngsq_comm_create_rccl of this process gave up on ncclCommInitRank (NGSQ_RCCL_INIT_TIMEOUT_S, default 60 s) and the
+ * thread it ran on is still inside RCCL.  It cannot be cancelled, and the runtime's exit handlers may wait for it: such a
+ * process leaves with _exit() once its work is done (the launchers of this repository do). */
+int ngsq_comm_rccl_stuck(void);
 
 /* Collectives on HOST buffers over any transport (rccl: staged through device memory): what the host side
  * of a sharded run needs -- agreeing on record boundaries, record counts, timings. */

@@ -332,24 +332,37 @@ __global__ __launch_bounds__(PT) void k_rec_offsets(const uint8_t *__restrict__ 
 }
 
 // ---- 4. fixed-width columns + the numbers the layout decision needs ----------------------------
-// stats: [0] max l_seq, [1] max n_cigar, [2] sum l_seq, [3] / [4] (refID << 32 | pos) of the first / last record, [5] index of the
-// first record with the long-CIGAR placeholder (the caller sets it to ~0).
+// work (device, REC_WORK_WORDS words, kept between launches): [W_BAD] smallest index of an invalid record of the chunk (k_rec_offsets;
+// ~0: none -- a launch that finds one there does nothing but report it), then this launch's tallies: max l_seq, max n_cigar_op,
+// sum l_seq, (refID << 32 | pos) of the first / last record, index of the first record with the long-CIGAR placeholder (~0: none),
+// sum n_cigar_op, and a ticket.  The block that finishes LAST writes the eight numbers into `host` -- pinned host memory the device
+// addresses -- and resets the tallies for the next launch: until round 4 the caller reset them with two memsets and fetched them
+// with a copy kernel of its own (k_copy_words: 6 launches per chunk, 0.14 ms each beside the reader's DMA, three of them on the
+// inflate stream; 13 % of the GPU's time in a file scan).
 // record_id (include/ngsq.h): the record's BAM virtual offset -- the block whose data holds its first byte is found
 // by bisection over the chunk's block table (out_off ascending; blocks without data never hold a byte), the record
 // carried over from the previous chunk (view offset < carry) has the id it was given there.  var_base[i] / seq_src[i] = offset of record i's CIGAR / SEQ
 // in raw (k_rec_var and k_rec_rows start from them).  The fixed part of a record is 32 contiguous bytes at any byte
-// offset: two unaligned 16-byte loads.  The three totals are reduced per block first: one atomic per wave on
-// the same three words was most of this kernel's time (same-address atomics serialise in L2, ~9 ns each).
+// offset: two unaligned 16-byte loads.  cig_len (optional, n + 1 entries): n_cigar_op of every record and a 0 behind them (the
+// offsets of the CIGAR column are its prefix sums).
 __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ rec_off,
                                                    uint64_t n, RecColumns c, uint64_t *__restrict__ var_base,
-                                                   uint64_t *__restrict__ seq_src, unsigned long long *__restrict__ stats,
-                                                   RecOrigin org) {
+                                                   uint64_t *__restrict__ seq_src, unsigned long long *__restrict__ work,
+                                                   unsigned long long *__restrict__ host, RecOrigin org, uint64_t *__restrict__ cig_len) {
     NGSQ_FOREGROUND_WAVE();
     constexpr uint32_t NW = PT / 64;
     __shared__ uint32_t s_ml[NW], s_mo[NW];
-    __shared__ unsigned long long s_sl[NW];
+    __shared__ unsigned long long s_sl[NW], s_so[NW];
+    __shared__ uint32_t s_last;
+    {
+        const unsigned long long bad = __hip_atomic_load(&work[W_BAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bad != ~0ull) { // (uniform over the grid: rec_off holds nothing behind that record)
+            if (blockIdx.x == 0 && threadIdx.x == 0) host[H_BAD] = bad;
+            return;
+        }
+    }
     uint32_t ml = 0, mo = 0;
-    unsigned long long sl = 0;
+    unsigned long long sl = 0, so = 0, order = 0; // order: results of this thread's atomics (waited for in front of the ticket)
     for (uint64_t i = (uint64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PT) {
         const uint64_t o = rec_off[i] + 4;
         uint4 a, b;
@@ -366,6 +379,10 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
         c.tlen[i] = (int32_t)b.w;
         var_base[i] = o + 32 + l_read_name;
         seq_src[i] = o + 32 + l_read_name + 4ull * n_ops;
+        if (cig_len) {
+            cig_len[i] = n_ops;
+            if (i == n - 1) cig_len[n] = 0;
+        }
         if (org.record_id) {
             const uint64_t at = o - 4; // view offset of the record's first byte
             uint64_t id = org.carry_id;
@@ -386,39 +403,62 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
             if (op0 == (l << 4 | 4u) && (op1 & 15u) == 3u) {
                 const uint32_t bs = ld32(raw + o - 4); // block_size: the record ends at o + bs
                 const uint64_t need = 32ull + l_read_name + 8ull + ((uint64_t)l + 1) / 2 + l;
-                if (need <= bs && aux_has_cg_tag(raw + o + need, raw + o + bs)) atomicMin(&stats[5], (unsigned long long)i);
+                if (need <= bs && aux_has_cg_tag(raw + o + need, raw + o + bs)) order += atomicMin(&work[W_LONG], (unsigned long long)i);
             }
         }
-        if (i == 0) stats[3] = (unsigned long long)a.x << 32 | a.y;
-        if (i == n - 1) stats[4] = (unsigned long long)a.x << 32 | a.y;
+        if (i == 0) order += atomicExch(&work[W_FIRST], (unsigned long long)a.x << 32 | a.y);
+        if (i == n - 1) order += atomicExch(&work[W_LAST], (unsigned long long)a.x << 32 | a.y);
         ml = max(ml, l);
         mo = max(mo, n_ops);
         sl += l;
+        so += n_ops;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         ml = max(ml, (uint32_t)__shfl_xor((int)ml, o, 64));
         mo = max(mo, (uint32_t)__shfl_xor((int)mo, o, 64));
         sl += __shfl_xor(sl, o, 64);
+        so += __shfl_xor(so, o, 64);
+        order |= __shfl_xor(order, o, 64);
     }
     const uint32_t w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         s_ml[w] = ml;
         s_mo[w] = mo;
         s_sl[w] = sl;
+        s_so[w] = so;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t a = 0, b = 0;
-        unsigned long long t = 0;
+        unsigned long long t = 0, u = 0;
         for (uint32_t k = 0; k < NW; k++) {
             a = max(a, s_ml[k]);
             b = max(b, s_mo[k]);
             t += s_sl[k];
+            u += s_so[k];
         }
-        atomicMax(&stats[0], (unsigned long long)a);
-        atomicMax(&stats[1], (unsigned long long)b);
-        atomicAdd(&stats[2], t);
+        // the block's tallies, then its ticket: the atomics' RESULTS are waited for (they feed the ticket's operand), which puts
+        // them in front of it without a release fence -- on gfx950 an agent-scope release is a write-back of the XCD's L2
+        order |= atomicMax(&work[W_MAXL], (unsigned long long)a);
+        order |= atomicMax(&work[W_MAXOPS], (unsigned long long)b);
+        order |= atomicAdd(&work[W_SUML], t);
+        order |= atomicAdd(&work[W_SUMOPS], u);
+        unsigned long long one = 1ull + (order >> 63 >> 1); // = 1
+        asm volatile("" : "+v"(one));
+        const unsigned long long ticket = atomicAdd(&work[W_TICKET], one);
+        s_last = ticket == (unsigned long long)gridDim.x - 1ull;
+        if (s_last) {
+            host[H_MAXL] = atomicExch(&work[W_MAXL], 0ull);
+            host[H_MAXOPS] = atomicExch(&work[W_MAXOPS], 0ull);
+            host[H_SUML] = atomicExch(&work[W_SUML], 0ull);
+            host[H_FIRST] = atomicExch(&work[W_FIRST], 0ull);
+            host[H_LAST] = atomicExch(&work[W_LAST], 0ull);
+            host[H_LONG] = atomicExch(&work[W_LONG], ~0ull);
+            host[H_SUMOPS] = atomicExch(&work[W_SUMOPS], 0ull);
+            host[H_BAD] = ~0ull;
+            (void)atomicExch(&work[W_TICKET], 0ull);
+        }
     }
 }
 
@@ -437,7 +477,7 @@ __global__ __launch_bounds__(256) void k_rec_lengths(const uint8_t *__restrict__
     for (uint32_t k = 0; k < l && miss; k++) miss = ql[k] == 0xFF;
     seq_len[i] = (l + 1) / 2;
     qual_len[i] = miss ? 0 : l;
-    cig_len[i] = n_ops;
+    if (cig_len) cig_len[i] = n_ops;
 }
 
 // ---- 6. variable-width columns -----------------------------------------------------------------
@@ -648,7 +688,21 @@ __global__ __launch_bounds__(256) void k_copy_words(uint32_t *__restrict__ dst, 
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// device-to-device bytes at any alignment (the record cut by a chunk's end moves in front of the next chunk: a few hundred
+// bytes -- as a hipMemcpyAsync it went through the DMA queue, BEHIND the reader thread's 180 MB of the next chunk's compressed
+// bytes, and held the context's stream for up to 3.5 ms per chunk: most of what index_records seemed to take, round 4)
+__global__ __launch_bounds__(256) void k_copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n) {
+    NGSQ_FOREGROUND_WAVE();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 // ---- launchers ----------------------------------------------------------------------------------
+hipError_t launch_copy_bytes(void *dst, const void *src, uint64_t n_bytes, hipStream_t s) {
+    if (!n_bytes) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_bytes, dim3((uint32_t)std::min<uint64_t>((n_bytes + 255) / 256, 4096)), dim3(256), 0, s, static_cast<uint8_t *>(dst),
+                       static_cast<const uint8_t *>(src), n_bytes);
+    return hipGetLastError();
+}
 hipError_t launch_copy_words(void *dst, const void *src, uint64_t n_bytes, hipStream_t s) {
     const uint64_t n = (n_bytes + 3) / 4; // (the buffers are allocated in whole words)
     if (!n) return hipSuccess;
@@ -668,10 +722,10 @@ hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start,
     return hipGetLastError();
 }
 hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
-                              const RecPieces *pieces, uint64_t *rec_off, unsigned long long *bad, hipStream_t s) {
+                              const RecPieces *pieces, uint64_t *rec_off, unsigned long long *work, hipStream_t s) {
     if (!n_pieces) return hipSuccess;
     hipLaunchKernelGGL(k_rec_offsets, dim3((n_pieces + PT - 1) / PT), dim3(PT), 0, s, raw, n_bytes, n_pieces, chosen, seg_base, pieces,
-                       rec_off, bad);
+                       rec_off, work + W_BAD);
     return hipGetLastError();
 }
 hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value, unsigned long long *out, hipStream_t s) {
@@ -679,10 +733,10 @@ hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value,
     return hipGetLastError();
 }
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
-                            unsigned long long *stats, const RecOrigin &org, hipStream_t s) {
+                            unsigned long long *work, unsigned long long *host, const RecOrigin &org, uint64_t *cig_len, hipStream_t s) {
     if (!n) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + PT - 1) / PT, 2048 * (256 / PT));
-    hipLaunchKernelGGL(k_rec_fixed, dim3(blocks), dim3(PT), 0, s, raw, rec_off, n, c, var_base, var_base + n, stats, org);
+    hipLaunchKernelGGL(k_rec_fixed, dim3(blocks), dim3(PT), 0, s, raw, rec_off, n, c, var_base, var_base + n, work, host, org, cig_len);
     return hipGetLastError();
 }
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,

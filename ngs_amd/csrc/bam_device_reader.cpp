@@ -188,14 +188,23 @@ struct DeviceIngest {
         std::vector<uint64_t> coff; // file offset of every block of `blocks`
         bool ready = false, last = false; // last: the byte range ends with this chunk
         std::string err;
-    } hc[2];
-    int cur = 0; // chunk the consumer takes next
+        PinBuf tab; // [block table | file offsets], pinned: the reader thread sends them behind the chunk's bytes, on the copy stream
+    } hc[4];
+    // Round 4: a chunk's context -- pinned buffer, device copy of the compressed bytes, block tables, Pending -- is one of NC
+    // = 4 used in turn (chunk j: context j % 4), its inflated bytes go to one of NR = 3 raw buffers (j % 3), and the inflates
+    // alternate between two streams.  Until then there were two of everything, on one inflate stream: a context was refilled
+    // -- read, framed, sent across PCIe: ~5 ms -- only when the inflate of its chunk had finished and had to be there again
+    // one inflate later; and the decoders of chunk j + 1 started when the LAST decoder of chunk j had finished -- a launch
+    // of 9 k blocks on 6 k resident decoders ends with half the device waiting for the blocks still in work (the same
+    // bytes inflate 22 % faster per byte in launches twice the size).  Now the inflates of chunks j + 1 and j + 2 are queued
+    // while chunk j is parsed: j + 1 on the other stream, so that its decoders take the wave slots chunk j's leave.
+    static constexpr int NC = 4, NR = 3;
     // the compressed bytes of a chunk cross PCIe on their own stream as soon as the reader thread has
     // framed them, i.e. while the GPU works on the previous chunk
-    DevBuf<uint8_t> d_comp_slot[2];
+    DevBuf<uint8_t> d_comp_slot[NC];
     hipStream_t copy_stream = nullptr;
-    hipEvent_t h2d_done[2] = {nullptr, nullptr};
-    bool h2d_issued[2] = {false, false};
+    hipEvent_t h2d_done[NC] = {nullptr, nullptr, nullptr, nullptr};
+    bool h2d_issued[NC] = {false, false, false, false};
     std::thread reader;
     std::mutex mu;
     std::condition_variable cv;
@@ -222,25 +231,34 @@ struct DeviceIngest {
         BgzfBlock *pin_blocks = nullptr;
         uint64_t *pin_coff = nullptr;
         size_t status_cap = 0;
+        int rslot = 0; // the raw buffer its bytes are inflated to
         std::string err;
-    } pend[2];
+    } pend[NC];
     PinBuf h_cand, h_seg, h_small; // the candidate table, the segments' verdicts, a few result words: host <-> device without DMA
-    DevBuf<uint64_t> d_coff_s[2], d_record_id;
-    DevBuf<uint8_t> d_raw2;
-    DevBuf<BgzfBlock> d_blocks_s[2];
-    DevBuf<uint32_t> d_status_s[2];
-    hipStream_t inf_stream = nullptr;
-    hipEvent_t inf_done[2] = {nullptr, nullptr}, raw_free[2] = {nullptr, nullptr};
-    bool raw_free_set[2] = {false, false};
+    // The block table and the blocks' file offsets of a chunk are read by its inflate AND, later, by the column kernels of its
+    // batches (the records' ids): they belong to the chunk's context, which goes back to the reader thread when the chunk is
+    // RETIRED -- the next chunk has been taken and everything that reads this one's buffers has been queued on the context's
+    // stream; retired_ev[k] marks that point of the stream, the reader's copies into context k wait for it.
+    DevBuf<uint64_t> d_coff_s[NC], d_record_id;
+    DevBuf<BgzfBlock> d_blocks_s[NC];
+    DevBuf<uint32_t> d_status_s[NC];
+    hipEvent_t retired_ev[NC] = {nullptr, nullptr, nullptr, nullptr}, inf_done[NC] = {nullptr, nullptr, nullptr, nullptr};
+    bool retired_set[NC] = {false, false, false, false}; // (under mu)
+    uint64_t chunks_issued = 0, chunks_loaded = 0; // inflates queued / chunks taken by load_chunk
+    int inflate_ahead = 2, inflate_streams = 2;    // inflates queued beyond the chunk being parsed; streams they alternate between (NGSQ_INFLATE_AHEAD, NGSQ_INFLATE_STREAMS: A/B measurements)
+    DevBuf<uint8_t> d_rawb[NR];
+    hipStream_t inf_stream[2] = {nullptr, nullptr};
+    hipEvent_t raw_free[NR] = {nullptr, nullptr, nullptr};
+    bool raw_free_set[NR] = {false, false, false};
     uint8_t *raw = nullptr; // the inflated bytes being indexed / cut into batches: d_raw (sharded mode) or a view into a raw buffer
     // device
-    DevBuf<uint8_t> d_comp, d_raw, d_seq, d_qual, d_scan_tmp;
+    DevBuf<uint8_t> d_comp, d_seq, d_qual, d_scan_tmp;
     DevBuf<BgzfBlock> d_blocks;
     DevBuf<uint32_t> d_status, d_l_seq, d_cigar;
     DevBuf<RecPieces> d_pieces;
     DevBuf<uint64_t> d_var_base;              // per record of the batch: offset of its CIGAR in raw
     DevBuf<uint64_t> d_seg, d_rec_off, d_len; // d_seg: per segment, index of its first record | chosen candidate (u32); d_len: seq | qual | cigar lengths -> offsets
-    DevBuf<unsigned long long> d_small;       // [0] bad record, [1..3] stats, [4..] walk_one result
+    DevBuf<unsigned long long> d_small;       // REC_WORK_WORDS words shared by k_rec_offsets / k_rec_fixed (ingest_kernels.h RecWork)
     DevBuf<uint16_t> d_flag, d_n_cigar;
     DevBuf<uint8_t> d_mapq;
     DevBuf<int32_t> d_ref_id, d_pos, d_mate, d_tlen;
@@ -268,10 +286,11 @@ struct DeviceIngest {
     uint64_t header_bytes0 = 0;   // the handle's header_bytes when the ingest began (load_chunk consumes it)
     unsigned long long first_key = 0, last_key = 0; // refID << 32 | pos of the first / last record handed out
     double t_start = now_ms();    // (NGSQ_INGEST_TRACE)
-    int cur_slot = 0;             // slot of the chunk being handed out
+    int cur_slot = 0;             // context of the chunk being handed out
     uint64_t carry_len = 0;       // bytes of the view in front of the current chunk's first byte
     bool last_chunk = false;      // the chunk being handed out is the range's last
     ngsq_bam_ingest_stats stats{}; // ngsq_bam_device_stats
+    uint64_t chunk_first_record = 0; // records handed out before the current chunk (for the message of an invalid record)
     ~DeviceIngest() {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -284,15 +303,18 @@ struct DeviceIngest {
             (void)hipStreamSynchronize(copy_stream);
             (void)hipStreamDestroy(copy_stream);
         }
-        if (inf_stream) {
-            (void)hipStreamSynchronize(inf_stream);
-            (void)hipStreamDestroy(inf_stream);
-        }
+        for (auto &q : inf_stream)
+            if (q) {
+                (void)hipStreamSynchronize(q);
+                (void)hipStreamDestroy(q);
+            }
         for (auto &e : h2d_done)
             if (e) (void)hipEventDestroy(e);
         for (auto &e : inf_done)
             if (e) (void)hipEventDestroy(e);
         for (auto &e : raw_free)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : retired_ev)
             if (e) (void)hipEventDestroy(e);
         for (auto &c : hc)
             if (c.h) pool_pinned_free(c.h, c.h_bytes);
@@ -491,7 +513,7 @@ void reader_main(DeviceIngest *d, std::string path) {
         }
     }
     uint64_t chunk_no = 0;
-    for (int k = 0;; k ^= 1, chunk_no++) {
+    for (int k = 0;; k = (k + 1) % DeviceIngest::NC, chunk_no++) {
         DeviceIngest::HostChunk &c = d->hc[k];
         // The pipeline fills gradually: nothing can be parsed before the first chunk has been read, copied and inflated, so
         // the first one is small (32 MiB of records) and each of the next is four times its predecessor until the full size
@@ -520,6 +542,16 @@ void reader_main(DeviceIngest *d, std::string path) {
                 return;
             }
         }
+        if (!c.h && ngsq::pool_pinned_alloc((void **)&c.h, cap, &c.h_bytes) != hipSuccess) { // (the third and fourth: when the file gets that far)
+            {
+                std::lock_guard<std::mutex> g(d->mu);
+                c.err = path + ": hipHostMalloc of the ingest buffers failed";
+                c.last = true;
+                c.ready = true;
+            }
+            d->cv.notify_all();
+            return;
+        }
         const double tr0 = now_ms();
         double t_frame = 0, t_send = 0, t_join = 0, t_spawn = 0;
         int n_steps = 0;
@@ -536,6 +568,14 @@ void reader_main(DeviceIngest *d, std::string path) {
         size_t sent = 0;
         bool h2d_ok = d->copy_stream && hipSetDevice(d->ctx->device) == hipSuccess &&
                       d->d_comp_slot[k].reserve(cap + INFLATE_IN_SLACK) == hipSuccess;
+        {   // the context's device buffers were last read by the chunk four in front: behind its retirement on the context's stream
+            bool wait_ev;
+            {
+                std::lock_guard<std::mutex> g(d->mu);
+                wait_ev = d->retired_set[k];
+            }
+            if (h2d_ok && wait_ev) h2d_ok = hipStreamWaitEvent(d->copy_stream, d->retired_ev[k], 0) == hipSuccess;
+        }
         auto send = [&]() {
             if (h2d_ok && c.err.empty() && c.consumed > sent) {
                 const double ts = now_ms();
@@ -632,8 +672,18 @@ void reader_main(DeviceIngest *d, std::string path) {
         const bool last = c.last;
         d->h2d_issued[k] = false;
         if (c.err.empty() && !c.blocks.empty() && h2d_ok && sent == c.consumed) {
-            const bool ok = hipMemsetAsync(d->d_comp_slot[k].p + c.consumed, 0, INFLATE_IN_SLACK, d->copy_stream) == hipSuccess &&
-                            hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
+            // the block table and the blocks' file offsets follow the bytes on the same stream (until round 4 the consumer sent
+            // them with two copy kernels on the INFLATE stream, reading this memory across PCIe beside the DMA: 0.14 ms each)
+            const size_t nb = c.blocks.size(), tb = nb * sizeof(BgzfBlock), ob = nb * sizeof(uint64_t);
+            bool ok = c.tab.reserve(tb + ob) == hipSuccess && d->d_blocks_s[k].reserve(nb) == hipSuccess && d->d_coff_s[k].reserve(nb) == hipSuccess;
+            if (ok) {
+                memcpy(c.tab.h, c.blocks.data(), tb);
+                memcpy(static_cast<uint8_t *>(c.tab.h) + tb, c.coff.data(), ob);
+                ok = hipMemcpyAsync(d->d_blocks_s[k].p, c.tab.h, tb, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess &&
+                     hipMemcpyAsync(d->d_coff_s[k].p, static_cast<uint8_t *>(c.tab.h) + tb, ob, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess;
+            }
+            ok = ok && hipMemsetAsync(d->d_comp_slot[k].p + c.consumed, 0, INFLATE_IN_SLACK, d->copy_stream) == hipSuccess &&
+                 hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
             d->h2d_issued[k] = ok; // on failure the consumer copies on its own stream (and reports errors)
         }
         if (trace_on())
@@ -672,7 +722,6 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     const uint32_t n_pieces = (uint32_t)((d->raw_len + REC_PIECE - 1) / REC_PIECE);
     BHIP(d->d_pieces.reserve((size_t)n_seg * REC_CANDIDATES));
     BHIP(d->d_seg.reserve((size_t)n_seg * 2)); // seg_base | chosen (32-bit words in the second half)
-    BHIP(d->d_small.reserve(16));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, d->raw_len);
         BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), static_cast<RecCandidate *>(d->h_cand.dev),
@@ -708,6 +757,7 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
         *out_entry = first;
     }
     uint64_t cur = first, total_rec = 0;
+    bool chain_broken = false; // a segment's walk stopped at an invalid record
     for (uint32_t s = 0; s < n_seg; s++) {
         const uint64_t s0 = (uint64_t)s * REC_SEGMENT, s1 = std::min<uint64_t>(s0 + REC_SEGMENT, d->raw_len);
         chosen[s] = REC_NO_CHAIN;
@@ -735,32 +785,39 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
         total_rec += c->count;
         // an invalid record ends the chain: the later segments get no entry (k_rec_offsets then reports
         // the record's index from the piece it lies in)
+        if (!c->valid) chain_broken = true;
         cur = c->valid ? c->landing : d->raw_len;
     }
     d->tail_off = std::min(cur, d->raw_len);
     BHIP(d->d_rec_off.reserve(total_rec + 1));
     BHIP(launch_copy_words(d->d_seg.p, d->h_seg.dev, (size_t)n_seg * 2 * sizeof(uint64_t), st));
-    BHIP(hipMemsetAsync(d->d_small.p, 0xFF, sizeof(unsigned long long), st));
+    BHIP(hipMemsetAsync(d->d_small.p + W_BAD, 0xFF, sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, 0);
         BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, reinterpret_cast<const uint32_t *>(d->d_seg.p + n_seg), d->d_seg.p,
                                 d->d_pieces.p, d->d_rec_off.p, d->d_small.p, st));
     }
-    BHIP(launch_copy_words(h_small_dev, d->d_small.p, sizeof(unsigned long long), st));
-    BHIP(hipStreamSynchronize(st));
-    const unsigned long long bad = h_small[0];
-    if (bad != ~0ull)
-        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
-                             (unsigned long long)(b->n_read + bad));
+    // (an invalid record k_rec_offsets alone notices: its index stays in the device word and the first batch of the chunk
+    // reports it -- k_rec_fixed looks before it touches an offset; no copy and no wait here)
+    d->chunk_first_record = b->n_read;
+    if (chain_broken) { // the host's walk met one: say which
+        BHIP(launch_copy_words(h_small_dev, d->d_small.p + W_BAD, sizeof(unsigned long long), st));
+        BHIP(hipStreamSynchronize(st));
+        if (h_small[0] != ~0ull)
+            return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
+                                 (unsigned long long)(b->n_read + h_small[0]));
+    }
     *out_total = total_rec;
     return NGSQ_OK;
 }
 
 // Queue the inflate (+ CRC check) of the framed chunk in host slot `slot` on the inflate stream, into raw buffer
 // `slot` behind its headroom.  The caller has made sure the reader thread marked the slot ready.
-int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
-    DeviceIngest::HostChunk &c = d->hc[slot];
-    DeviceIngest::Pending &p = d->pend[slot];
+int issue_inflate(ngsq_bam *b, DeviceIngest *d, uint64_t j) {
+    const int k = (int)(j % DeviceIngest::NC), rs = (int)(j % DeviceIngest::NR);
+    DeviceIngest::HostChunk &c = d->hc[k];
+    DeviceIngest::Pending &p = d->pend[k];
+    p.rslot = rs;
     p.issued = true;
     p.err = c.err;
     p.last = c.last;
@@ -770,13 +827,12 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
     p.next_coff = c.file_off + c.consumed;
     p.blocks.clear();
     p.coff.clear();
+    d->chunks_issued = j + 1;
     if (!p.err.empty() || !p.n_blk) return NGSQ_OK;
-    p.blocks = c.blocks; // the table is copied to the device asynchronously: keep it while the host slot is reused
+    p.blocks = c.blocks;
     p.coff = c.coff;
-    hipStream_t sb = d->inf_stream;
-    BHIP(d->d_blocks_s[slot].reserve(p.n_blk));
-    BHIP(d->d_coff_s[slot].reserve(p.n_blk));
-    BHIP(d->d_status_s[slot].reserve(p.n_blk + 1)); // + the decoders' block counter
+    hipStream_t sb = d->inf_stream[d->inflate_streams > 1 ? j & 1 : 0];
+    BHIP(d->d_status_s[k].reserve(p.n_blk + 1)); // + the decoders' block counter
     if (p.status_cap < p.n_blk) {
         const size_t cap = p.n_blk + p.n_blk / 4 + 1024;
         BHIP(p.pin.reserve((cap + 2) * (sizeof(uint32_t) + sizeof(BgzfBlock) + sizeof(uint64_t))));
@@ -786,35 +842,37 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, int slot) {
         p.pin_coff = reinterpret_cast<uint64_t *>(p.pin_blocks + cap);
     }
     auto dev_of = [&](const void *host) { return static_cast<uint8_t *>(p.pin.dev) + (static_cast<const uint8_t *>(host) - static_cast<const uint8_t *>(p.pin.h)); };
-    memcpy(p.pin_blocks, p.blocks.data(), p.n_blk * sizeof(BgzfBlock));
-    memcpy(p.pin_coff, p.coff.data(), p.n_blk * sizeof(uint64_t));
-    if (d->h2d_issued[slot]) { // already on its way: the reader thread issued the copy
+    if (d->h2d_issued[k]) { // the bytes and the tables are on their way: the reader thread issued the copies
         if (trace_on()) {
             const double tw = now_ms();
-            BHIP(hipEventSynchronize(d->h2d_done[slot]));
-            fprintf(stderr, "[ingest] waited %.1f ms for the host-to-device copy of slot %d\n", now_ms() - tw, slot);
+            BHIP(hipEventSynchronize(d->h2d_done[k]));
+            fprintf(stderr, "[ingest] waited %.1f ms for the host-to-device copy of context %d\n", now_ms() - tw, k);
         }
-        BHIP(hipStreamWaitEvent(sb, d->h2d_done[slot], 0));
+        BHIP(hipStreamWaitEvent(sb, d->h2d_done[k], 0));
     } else {
-        BHIP(d->d_comp_slot[slot].reserve(p.consumed + INFLATE_IN_SLACK));
-        BHIP(ngsq::pool_pinned_h2d(d->d_comp_slot[slot].p, c.h, 0, p.consumed, sb));
-        BHIP(hipMemsetAsync(d->d_comp_slot[slot].p + p.consumed, 0, INFLATE_IN_SLACK, sb));
+        if (d->retired_set[k]) BHIP(hipStreamWaitEvent(sb, d->retired_ev[k], 0));
+        BHIP(d->d_blocks_s[k].reserve(p.n_blk));
+        BHIP(d->d_coff_s[k].reserve(p.n_blk));
+        memcpy(p.pin_blocks, p.blocks.data(), p.n_blk * sizeof(BgzfBlock));
+        memcpy(p.pin_coff, p.coff.data(), p.n_blk * sizeof(uint64_t));
+        BHIP(d->d_comp_slot[k].reserve(p.consumed + INFLATE_IN_SLACK));
+        BHIP(ngsq::pool_pinned_h2d(d->d_comp_slot[k].p, c.h, 0, p.consumed, sb));
+        BHIP(hipMemsetAsync(d->d_comp_slot[k].p + p.consumed, 0, INFLATE_IN_SLACK, sb));
+        BHIP(launch_copy_words(d->d_blocks_s[k].p, dev_of(p.pin_blocks), p.n_blk * sizeof(BgzfBlock), sb));
+        BHIP(launch_copy_words(d->d_coff_s[k].p, dev_of(p.pin_coff), p.n_blk * sizeof(uint64_t), sb));
     }
-    if (d->raw_free_set[slot]) BHIP(hipStreamWaitEvent(sb, d->raw_free[slot], 0)); // the chunk before last has left this buffer
-    BHIP(launch_copy_words(d->d_blocks_s[slot].p, dev_of(p.pin_blocks), p.n_blk * sizeof(BgzfBlock), sb));
-    BHIP(launch_copy_words(d->d_coff_s[slot].p, dev_of(p.pin_coff), p.n_blk * sizeof(uint64_t), sb));
-    uint8_t *out = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX;
+    if (d->raw_free_set[rs]) BHIP(hipStreamWaitEvent(sb, d->raw_free[rs], 0)); // the chunk three in front has left this buffer
+    uint8_t *out = d->d_rawb[rs].p + CARRY_MAX;
     {   // algorithmic bytes of the inflate: compressed bytes read + inflated bytes written
         KernelTimer kt(d->ctx, K_INFLATE, p.consumed + p.total, sb);
-        BHIP(launch_bgzf_inflate(d->d_comp_slot[slot].p, d->d_blocks_s[slot].p, (uint32_t)p.n_blk, out, d->d_status_s[slot].p,
-                                 d->d_status_s[slot].p + p.n_blk, false, sb));
+        BHIP(launch_bgzf_inflate(d->d_comp_slot[k].p, d->d_blocks_s[k].p, (uint32_t)p.n_blk, out, d->d_status_s[k].p,
+                                 d->d_status_s[k].p + p.n_blk, false, sb));
     }
-    {
+    {   // (the decoders' verdicts reach the host through this kernel: it writes every block's final status into pinned memory)
         KernelTimer kt(d->ctx, K_INFLATE_CRC, p.total, sb);
-        BHIP(launch_bgzf_crc(d->d_blocks_s[slot].p, (uint32_t)p.n_blk, out, d->d_status_s[slot].p, sb));
+        BHIP(launch_bgzf_crc(d->d_blocks_s[k].p, (uint32_t)p.n_blk, out, d->d_status_s[k].p, reinterpret_cast<uint32_t *>(dev_of(p.status)), sb));
     }
-    BHIP(launch_copy_words(dev_of(p.status), d->d_status_s[slot].p, p.n_blk * sizeof(uint32_t), sb));
-    BHIP(hipEventRecord(d->inf_done[slot], sb));
+    BHIP(hipEventRecord(d->inf_done[k], sb));
     (void)b;
     return NGSQ_OK;
 }
@@ -826,16 +884,17 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     const double t0 = now_ms();
     static thread_local double last_end = 0;
     const double batches_ms = last_end ? t0 - last_end : 0.0; // time the caller spent on the previous chunk's batches
-    const int slot = d->cur;
+    const uint64_t j = d->chunks_loaded; // this chunk
+    const int slot = (int)(j % DeviceIngest::NC), rs = (int)(j % DeviceIngest::NR);
     DeviceIngest::HostChunk &c = d->hc[slot];
     DeviceIngest::Pending &p = d->pend[slot];
-    // ---- 1. this chunk's inflate: queued during the previous call unless the reader thread was late (or this is the first)
+    // ---- 1. this chunk's inflate: queued two calls earlier unless the reader thread was late (or these are the first)
     if (!p.issued) {
         {
             std::unique_lock<std::mutex> g(d->mu);
             d->cv.wait(g, [&] { return c.ready; });
         }
-        const int rc = issue_inflate(b, d, slot);
+        const int rc = issue_inflate(b, d, j);
         if (rc) return rc;
     }
     const double t1 = now_ms();
@@ -845,25 +904,47 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
     if (carry > CARRY_MAX)
         return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: a record larger than the device ingest carry space (%llu MiB)", b->path.c_str(),
                              (unsigned long long)(CARRY_MAX >> 20));
-    uint8_t *const view = (slot ? d->d_raw2.p : d->d_raw.p) + CARRY_MAX - carry;
-    if (carry) BHIP(hipMemcpyAsync(view, d->raw + d->tail_off, carry, hipMemcpyDeviceToDevice, st));
-    // everything that reads the previous chunk's buffer has been queued on the context's stream by now
-    BHIP(hipEventRecord(d->raw_free[slot ^ 1], st));
-    d->raw_free_set[slot ^ 1] = true;
-    // ---- 3. the chunk after this one goes onto the inflate stream BEFORE this thread waits for this chunk's inflate: the
-    // decoders then go from one chunk to the next without waiting for the host (the other buffer is free as soon as the
-    // kernels queued above have run, which the stream waits for by itself)
-    auto issue_next = [&]() -> int {
-        if (p.last || d->pend[slot ^ 1].issued) return NGSQ_OK;
-        bool ready;
+    uint8_t *const view = d->d_rawb[rs].p + CARRY_MAX - carry;
+    if (carry) BHIP(launch_copy_bytes(view, d->raw + d->tail_off, carry, st)); // (a kernel: a hipMemcpyAsync queues behind the reader's DMA)
+    // everything that reads the previous chunk's buffers has been queued on the context's stream by now: the chunk is
+    // retired -- its raw buffer may be inflated into again, its context goes back to the reader thread
+    if (j) {
+        const int kp = (int)((j - 1) % DeviceIngest::NC), rp = (int)((j - 1) % DeviceIngest::NR);
+        BHIP(hipEventRecord(d->raw_free[rp], st));
+        d->raw_free_set[rp] = true;
+        BHIP(hipEventRecord(d->retired_ev[kp], st));
+        d->h2d_issued[kp] = false;
+        d->pend[kp].issued = false;
         {
             std::lock_guard<std::mutex> g(d->mu);
-            ready = d->hc[slot ^ 1].ready;
+            d->retired_set[kp] = true;
+            d->hc[kp].ready = false;
         }
-        return ready ? issue_inflate(b, d, slot ^ 1) : NGSQ_OK;
+        d->cv.notify_all();
+    }
+    d->chunks_loaded = j + 1;
+    // ---- 3. the inflates of the two chunks after this one are queued BEFORE this thread waits for this chunk's: the
+    // decoders go from one chunk to the next without waiting for the host, and those of chunk j + 1 (the other inflate
+    // stream) take the wave slots this chunk's leave when its last blocks are in work
+    auto issue_ahead = [&]() -> int {
+        if (p.last) return NGSQ_OK;
+        while (d->chunks_issued <= j + (uint64_t)d->inflate_ahead) {
+            const uint64_t q = d->chunks_issued;
+            const int kq = (int)(q % DeviceIngest::NC);
+            if (q > j && d->pend[(q - 1) % DeviceIngest::NC].last) break; // (nothing behind the range's last chunk)
+            bool ready;
+            {
+                std::lock_guard<std::mutex> g(d->mu);
+                ready = d->hc[kq].ready && !d->pend[kq].issued;
+            }
+            if (!ready) break;
+            const int rc = issue_inflate(b, d, q);
+            if (rc) return rc;
+        }
+        return NGSQ_OK;
     };
     {
-        const int rc = issue_next();
+        const int rc = issue_ahead();
         if (rc) return rc;
     }
     // ---- 4. this chunk's inflate
@@ -876,18 +957,9 @@ int load_chunk(ngsq_bam *b, DeviceIngest *d) {
                                      (unsigned long long)(d->blocks_done + k), inflate_status_text(p.status[k]));
         d->blocks_done += p.n_blk;
     }
-    // the pinned buffer and the device copy of the compressed bytes go back to the reader thread
-    d->h2d_issued[slot] = false;
-    p.issued = false;
-    {
-        std::lock_guard<std::mutex> g(d->mu);
-        c.ready = false;
-    }
-    d->cv.notify_all();
-    d->cur ^= 1;
     const double t3 = now_ms();
     {   // (the reader thread was late a moment ago: look again)
-        const int rc = issue_next();
+        const int rc = issue_ahead();
         if (rc) return rc;
     }
     d->raw = view;
@@ -1079,16 +1151,23 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
         int lo = 0, hi = 0;
         BHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char *e = getenv("NGSQ_INFLATE_PRIORITY");
-        BHIP(hipStreamCreateWithPriority(&d->inf_stream, hipStreamNonBlocking, e && atoi(e) == 0 ? 0 : lo)); // =0: normal priority (A/B measurements)
+        for (auto &q : d->inf_stream) BHIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, e && atoi(e) == 0 ? 0 : lo)); // =0: normal priority (A/B measurements)
     }
     for (auto &e : d->h2d_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : d->inf_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : d->raw_free) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : d->retired_ev) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (const char *e = getenv("NGSQ_INFLATE_AHEAD")) d->inflate_ahead = std::max(1, std::min(2, atoi(e)));
+    if (const char *e = getenv("NGSQ_INFLATE_STREAMS")) d->inflate_streams = std::max(1, std::min(2, atoi(e)));
     // the reader starts pinning and reading at once; the two raw buffers are allocated meanwhile
     d->reader = std::thread(reader_main, d, b->path);
-    BHIP(d->d_raw.reserve(CARRY_MAX + d->raw_cap + 64)); // headroom for the carried record | one chunk's inflated bytes
-    BHIP(d->d_raw2.reserve(CARRY_MAX + d->raw_cap + 64));
-    BHIP(d->d_small.reserve(16));
+    for (auto &r : d->d_rawb) BHIP(r.reserve(CARRY_MAX + d->raw_cap + 64)); // headroom for the carried record | one chunk's inflated bytes
+    BHIP(d->d_small.reserve(REC_WORK_WORDS));
+    {
+        unsigned long long w[REC_WORK_WORDS];
+        rec_work_init(w);
+        BHIP(hipMemcpy(d->d_small.p, w, sizeof w, hipMemcpyHostToDevice));
+    }
     // the host side of this handle is done: release its buffers
     std::vector<uint8_t>().swap(b->comp);
     std::vector<uint8_t>().swap(b->data);
@@ -1250,8 +1329,10 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     col.mate_ref_id = d->d_mate.p;
     col.tlen = d->d_tlen.p;
     col.l_seq = d->d_l_seq.p;
-    BHIP(hipMemsetAsync(d->d_small.p + 1, 0, 3 * sizeof(unsigned long long), st));
-    BHIP(hipMemsetAsync(d->d_small.p + 6, 0xFF, sizeof(unsigned long long), st));
+    BHIP(d->d_len.reserve(3 * (n + 1)));
+    uint64_t *const sl = d->d_len.p, *const ql = sl + (n + 1), *const cl = ql + (n + 1);
+    BHIP(d->h_small.reserve(64 * sizeof(uint64_t)));
+    unsigned long long *const host_stats = static_cast<unsigned long long *>(d->h_small.h) + 16;
     {
         KernelTimer kt(d->ctx, K_REC_COLUMNS, n * 36);
         // the records' ids: their virtual offsets, by the block table of the chunk they come from
@@ -1263,52 +1344,49 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
         org.n_blocks = (uint32_t)cp.blocks.size();
         org.carry = d->carry_len;
         org.carry_id = d->carry_id;
-        BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_var_base.p, d->d_small.p + 1, org, st));
+        BHIP(launch_rec_fixed(d->raw, rec, n, col, d->d_var_base.p, d->d_small.p, static_cast<unsigned long long *>(d->h_small.dev) + 16, org, cl, st));
     }
-    unsigned long long stats[6] = {0, 0, 0, 0, 0, 0};
-    BHIP(d->h_small.reserve(64 * sizeof(uint64_t)));
-    BHIP(launch_copy_words(static_cast<uint64_t *>(d->h_small.dev) + 16, d->d_small.p + 1, sizeof stats, st));
+    // (the kernel's last block has written what the layout decision needs into pinned memory: no copy, one wait)
     BHIP(hipStreamSynchronize(st));
-    memcpy(stats, static_cast<const uint64_t *>(d->h_small.h) + 16, sizeof stats);
-    if (stats[5] != ~0ull)
+    if (host_stats[H_BAD] != ~0ull)
+        return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
+                             (unsigned long long)(d->chunk_first_record + host_stats[H_BAD]));
+    if (host_stats[H_LONG] != ~0ull)
         return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: record %llu: a CIGAR of more than 65535 operations (CG tag, SAM specification 4.2.2) is not supported",
-                             b->path.c_str(), (unsigned long long)(b->n_read + stats[5]));
-    if (!d->n_own) d->first_key = stats[3];
-    d->last_key = stats[4];
+                             b->path.c_str(), (unsigned long long)(b->n_read + host_stats[H_LONG]));
+    if (!d->n_own) d->first_key = host_stats[H_FIRST];
+    d->last_key = host_stats[H_LAST];
     d->n_own += n;
-    const uint32_t max_l = (uint32_t)stats[0], max_ops = (uint32_t)stats[1];
-    const uint64_t sum_qual = stats[2];
+    const uint32_t max_l = (uint32_t)host_stats[H_MAXL], max_ops = (uint32_t)host_stats[H_MAXOPS];
+    const uint64_t sum_qual = host_stats[H_SUML];
     const uint32_t pitch_q = max_l, pitch_s = (max_l + 1) / 2;
     const bool fixed = max_l >= 1 && max_l <= 320 && (uint64_t)pitch_q * n <= sum_qual + sum_qual / 2 + 4096;
     const bool cig1 = max_ops <= 1;
     uint64_t so = (uint64_t)pitch_s * n, qo = (uint64_t)pitch_q * n, co = n;
     if (!fixed || !cig1) {
-        BHIP(d->d_len.reserve(3 * (n + 1)));
-        uint64_t *sl = d->d_len.p, *ql = sl + (n + 1), *cl = ql + (n + 1);
-        BHIP(hipMemsetAsync(d->d_len.p, 0, 3 * (n + 1) * sizeof(uint64_t), st));
-        BHIP(launch_rec_lengths(d->raw, rec, n, sl, ql, cl, st));
         size_t tmp_bytes = 0;
         BHIP(launch_exclusive_scan_u64(sl, n + 1, nullptr, &tmp_bytes, st));
         BHIP(d->d_scan_tmp.reserve(tmp_bytes + 256));
-        uint64_t totals[3] = {0, 0, 0};
-        for (int k = 0; k < 3; k++) {
-            if (k < 2 ? fixed : cig1) continue;
-            uint64_t *arr = d->d_len.p + (size_t)k * (n + 1);
-            size_t tb = d->d_scan_tmp.cap;
-            BHIP(launch_exclusive_scan_u64(arr, n + 1, d->d_scan_tmp.p, &tb, st));
-            BHIP(launch_copy_words(static_cast<uint64_t *>(d->h_small.dev) + 24 + k, arr + n, sizeof(uint64_t), st));
-        }
-        BHIP(hipStreamSynchronize(st));
-        for (int k = 0; k < 3; k++)
-            if (!(k < 2 ? fixed : cig1)) totals[k] = static_cast<const uint64_t *>(d->h_small.h)[24 + k];
         if (!fixed) {
-            so = totals[0];
-            qo = totals[1];
+            // SEQ and QUAL lengths (absent qualities take no bytes: the kernel looks) -> offsets; their totals come back
+            BHIP(hipMemsetAsync(sl, 0, 2 * (n + 1) * sizeof(uint64_t), st));
+            BHIP(launch_rec_lengths(d->raw, rec, n, sl, ql, nullptr, st));
+            for (int k = 0; k < 2; k++) {
+                uint64_t *arr = d->d_len.p + (size_t)k * (n + 1);
+                size_t tb = d->d_scan_tmp.cap;
+                BHIP(launch_exclusive_scan_u64(arr, n + 1, d->d_scan_tmp.p, &tb, st));
+                BHIP(launch_copy_words(static_cast<uint64_t *>(d->h_small.dev) + 24 + k, arr + n, sizeof(uint64_t), st));
+            }
+            BHIP(hipStreamSynchronize(st));
+            so = static_cast<const uint64_t *>(d->h_small.h)[24];
+            qo = static_cast<const uint64_t *>(d->h_small.h)[25];
             col.seq_off = sl;
             col.qual_off = ql;
         }
-        if (!cig1) {
-            co = totals[2];
+        if (!cig1) { // the operations per record are there (k_rec_fixed), their sum too: the offsets need no wait
+            size_t tb = d->d_scan_tmp.cap;
+            BHIP(launch_exclusive_scan_u64(cl, n + 1, d->d_scan_tmp.p, &tb, st));
+            co = host_stats[H_SUMOPS];
             col.cigar_off = cl;
         }
     }

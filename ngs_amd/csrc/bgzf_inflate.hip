@@ -1013,7 +1013,7 @@ constexpr uint32_t CRC_WAVES = 8; // BGZF blocks per workgroup: the tables are l
 constexpr uint32_t CRC_MAX_SLICE = 1024; // bytes of one of the 64 slices of a block (ISIZE <= 65536)
 __global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__restrict__ out, const BgzfBlock *__restrict__ blocks,
                                                              uint32_t n_blocks, uint32_t *__restrict__ status,
-                                                             const uint32_t *__restrict__ pow_tab) {
+                                                             const uint32_t *__restrict__ pow_tab, uint32_t *__restrict__ status_host) {
     NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_tab[CRC_SLICES * 256];
     for (uint32_t k = threadIdx.x; k < CRC_SLICES * 256; k += 64 * CRC_WAVES) s_tab[k] = c_crc.t[k >> 8][k & 0xFFu];
@@ -1022,7 +1022,13 @@ __global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__re
     const uint32_t bi = blockIdx.x * CRC_WAVES + (threadIdx.x >> 6);
     if (bi >= n_blocks) return;
     const uint32_t isize = uni(blocks[bi].isize);
-    if (uni(status[bi]) != INF_OK) return;
+    {
+        const uint32_t st0 = uni(status[bi]);
+        if (st0 != INF_OK) {
+            if (status_host && lane == 0) status_host[bi] = st0;
+            return;
+        }
+    }
     const uint8_t *p = out + uni64(blocks[bi].out_off);
     const uint32_t S = (isize + 63u) / 64u, pad = 64u * S - isize;
     // real bytes of this lane's slice
@@ -1060,11 +1066,14 @@ __global__ __launch_bounds__(64 * CRC_WAVES) void k_bgzf_crc(const uint8_t *__re
         if ((lane & ((2u << j) - 1u)) == (2u << j) - 1u) c = crc_mul(left, pw[j]) ^ c;
     }
     const uint32_t crc = ~__builtin_amdgcn_readlane(c, 63);
-    if (isize && lane == 0 && crc != blocks[bi].crc) status[bi] = INF_CRC_MISMATCH;
-    if (!isize && lane == 0 && blocks[bi].crc != 0) status[bi] = INF_CRC_MISMATCH;
+    const bool mismatch = isize ? crc != blocks[bi].crc : blocks[bi].crc != 0;
+    if (lane == 0) {
+        if (mismatch) status[bi] = INF_CRC_MISMATCH;
+        if (status_host) status_host[bi] = mismatch ? (uint32_t)INF_CRC_MISMATCH : (uint32_t)INF_OK;
+    }
 }
 
-hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s) {
+hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, uint32_t *status_host, hipStream_t s) {
     if (!n_blocks) return hipSuccess;
     // x^(8 S 2^j) mod P for every slice length S and combination step j: 25 KB, computed once per device and process
     static std::mutex mu;
@@ -1091,7 +1100,7 @@ hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uin
         }
         pow_tab = tab[dev];
     }
-    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + CRC_WAVES - 1) / CRC_WAVES), dim3(64 * CRC_WAVES), 0, s, out, blocks, n_blocks, status, pow_tab);
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_blocks + CRC_WAVES - 1) / CRC_WAVES), dim3(64 * CRC_WAVES), 0, s, out, blocks, n_blocks, status, pow_tab, status_host);
     return hipGetLastError();
 }
 
@@ -1115,7 +1124,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < resident ? n_blocks : resident), dim3(64), 0, s, comp, blocks, n_blocks, out,
                        status, counter);
-    if (check_crc) (void)launch_bgzf_crc(blocks, n_blocks, out, status, s);
+    if (check_crc) (void)launch_bgzf_crc(blocks, n_blocks, out, status, nullptr, s);
 #ifdef NGSQ_INFLATE_PROFILE
     {
         unsigned long long h[16];

@@ -63,6 +63,10 @@ void logf(int level, const char *fmt, ...) {
 
 [[noreturn]] void bail(const std::string &msg) { // anyhow::bail! -> "Error: ..." and exit code 1
     fprintf(stderr, "Error: %s\n", msg.c_str());
+    if (ngsq_comm_rccl_stuck()) { // a thread is still inside ncclCommInitRank: the exit handlers may wait for it
+        fflush(nullptr);
+        _exit(1);
+    }
     exit(1);
 }
 
@@ -518,6 +522,13 @@ int main(int argc, char **argv) {
     }
     const bool worker = a.world > 1;
     if (a.gpus < 1 || a.gpus > NGSQ_COMM_MAX_WORLD) bail("--gpus takes a number between 1 and 64");
+    if (a.gpus > 1 && !worker && a.has_n) {
+        // both truncation rules of -n are sequential and bounded by n (the first n records of the file; one counter over all
+        // sequences): one process applies them, as the reference does -- N - 1 workers would only initialise their devices
+        // and RCCL to bring an empty state to the exchange (and time out if rank 0 needs longer than the collective's limit)
+        logf(1, "-n bounds the scan to its first records: --gpus %d is ignored, one process reads them", a.gpus);
+        a.gpus = 1;
+    }
     if (a.gpus > 1 && !worker) {
         // ---- launch one worker per GPU.  Nothing above has touched HIP, and nothing here does: the workers
         // are fresh processes (posix_spawn of this executable), each initialises its own device.
@@ -525,14 +536,22 @@ int main(int argc, char **argv) {
         ngsq_bam_close(bam);
         char shm[128];
         snprintf(shm, sizeof shm, "/ngsq-cli-%d-%lld", (int)getpid(), (long long)time(nullptr));
-        // A worker says "done" through this pipe when the document is on disk and nothing of it is left to do, then leaves;
-        // the command returns when all of them have said so.  What follows in a worker is the kernel unmapping its GiB of
-        // device and pinned memory (0.1-0.35 s, serialised among the workers of one device), which nobody needs to wait for
-        // (NGSQ_WAIT_WORKERS=1 waits, as does any failure).
+        // The command returns when every worker has EXITED and hands on the worst of their exit statuses (round 4).
+        // NGSQ_RETURN_WHEN_DONE=1 is the opt-in for callers that only want the document: a worker then says "done" through
+        // this pipe when the document is on disk and nothing of it is left to do, and the command returns when all of them
+        // have -- while the kernel is still unmapping their GiB of device and pinned memory (0.1-0.35 s, serialised among
+        // the workers of one device): such a caller inherits that memory still in use, and loses the exit statuses.
         int done_fd[2] = {-1, -1};
-        const char *ww = getenv("NGSQ_WAIT_WORKERS");
-        if (!(ww && atoi(ww)) && pipe(done_fd) == 0) setenv("NGSQ_DONE_FD", std::to_string(done_fd[1]).c_str(), 1);
-        else done_fd[0] = done_fd[1] = -1;
+        const char *early = getenv("NGSQ_RETURN_WHEN_DONE");
+        if (early && atoi(early) && pipe(done_fd) == 0) {
+            setenv("NGSQ_DONE_FD", std::to_string(done_fd[1]).c_str(), 1);
+        } else {
+            done_fd[0] = done_fd[1] = -1;
+            unsetenv("NGSQ_DONE_FD"); // (a stale value must not reach the workers)
+        }
+        // the host driver of these machines supports dmabuf IPC only: without this RCCL's peer-memory set-up fails with
+        // "hipIpcGetMemHandle: invalid argument" (bench.py's launcher sets the same default for its ranks)
+        setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
         std::vector<pid_t> pids;
         for (int r = 0; r < a.gpus; r++) {
             std::vector<char *> av(argv, argv + argc);
@@ -727,7 +746,10 @@ int main(int argc, char **argv) {
     // rank says whether it has one: a rank whose initialisation failed must not leave the others waiting inside RCCL.
     auto comm_ready = [&]() {
         if (!rccl_init.joinable()) return;
-        rccl_init.join();
+        rccl_init.join(); // (bounded: ngsq_comm_create_rccl gives up after NGSQ_RCCL_INIT_TIMEOUT_S)
+        // RCCL was asked for by name and this worker has no communicator: leave NOW -- the launcher stops the others, which
+        // may be inside ncclCommInitRank waiting for this one (a vote first would wait for them: ADVICE r3)
+        if (!rccl_comm && a.transport == "rccl") bail(rccl_error);
         ngsq_comm *boot = comm;
         const uint8_t ok = rccl_comm != nullptr;
         std::vector<uint8_t> oks((size_t)a.world);
@@ -998,8 +1020,10 @@ int main(int argc, char **argv) {
         const char ok = 0;
         if (fd && write(atoi(fd), &ok, 1) != 1) { /* the launcher then waits for the exit status instead */ }
     };
+    // (with RCCL's communicator alive the worker goes through ngsq_comm_destroy first: leaving without ncclCommDestroy has
+    // not been seen on a multi-GPU node yet; a thread stuck in ncclCommInitRank forces the quick way out)
     const char *qe = getenv("NGSQ_QUICK_EXIT");
-    const bool quick_exit = qe ? atoi(qe) != 0 : worker;
+    const bool quick_exit = ngsq_comm_rccl_stuck() || (qe ? atoi(qe) != 0 : worker && std::string(ngsq_comm_kind(comm)) != "rccl");
     if (worker && a.rank != 0) { // every rank holds the whole-file result; rank 0 writes it
         if (vaf_file) fclose(vaf_file);
         ngsq_comm_barrier(comm);

@@ -20,12 +20,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "comm.h"
 
 static thread_local std::string g_comm_err;
+static std::atomic<int> g_rccl_stuck{0}; // a thread of this process never came back from ncclCommInitRank
 
 namespace ngsq {
 int comm_fail(ngsq_comm *c, int code, const char *fmt, ...) {
@@ -437,6 +442,8 @@ int ngsq_comm_unique_id(uint8_t id[NGSQ_COMM_ID_BYTES]) {
     return NGSQ_OK;
 }
 
+int ngsq_comm_rccl_stuck(void) { return g_rccl_stuck.load(); }
+
 int ngsq_comm_create_rccl(int rank, int world, const uint8_t id[NGSQ_COMM_ID_BYTES], int device, ngsq_comm **out) {
     if (!id || !out) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
@@ -444,11 +451,58 @@ int ngsq_comm_create_rccl(int rank, int world, const uint8_t id[NGSQ_COMM_ID_BYT
     if (rc) return rc;
     RcclApi *api = rccl_api();
     if (!api) return comm_fail(nullptr, NGSQ_ERR_UNSUPPORTED, "RCCL is not available (librccl.so.1 could not be loaded: %s)", g_rccl.why.c_str());
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return comm_fail(nullptr, NGSQ_ERR_NO_DEVICE, "no HIP device available");
-    if (device < 0 || device >= ndev) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "device %d out of range", device);
-    HIPC_TRY(nullptr, hipSetDevice(device));
+    // (NGSQ_RCCL_SKIP_DEVICE_CHECK=1: tests/test_shard_gloo.py drives the time limit below on a machine without a GPU,
+    // against tests/rccl_double made to stall; nothing else sets it)
+    const bool no_device_check = getenv("NGSQ_RCCL_SKIP_DEVICE_CHECK") && atoi(getenv("NGSQ_RCCL_SKIP_DEVICE_CHECK"));
+    if (!no_device_check) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return comm_fail(nullptr, NGSQ_ERR_NO_DEVICE, "no HIP device available");
+        if (device < 0 || device >= ndev) return comm_fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "device %d out of range", device);
+        HIPC_TRY(nullptr, hipSetDevice(device));
+    }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    // ncclCommInitRank is a collective over sockets and shared memory with no time limit of its own: a rank that never
+    // arrives (a crashed worker, a firewall between the bootstrap sockets, an IPC mode the driver does not support) leaves
+    // the others inside it for good.  It runs on a thread of its own and this call gives up after
+    // NGSQ_RCCL_INIT_TIMEOUT_S seconds (default 60; 0 = wait for ever): an error code like any other, which the
+    // launchers turn into their agreed fallback (`auto`) or a non-zero exit (`rccl`).  The thread cannot be cancelled:
+    // it stays inside RCCL, ngsq_comm_rccl_stuck() says so, and the process must then leave with _exit() -- the
+    // runtime's exit handlers may wait for it.
+    struct InitJob {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t r = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    auto job = std::make_shared<InitJob>();
+    double limit_s = 60.0;
+    if (const char *t = getenv("NGSQ_RCCL_INIT_TIMEOUT_S")) limit_s = atof(t);
+    std::thread([job, api, world, u, rank, device, no_device_check]() {
+        if (!no_device_check) (void)hipSetDevice(device);
+        ncclComm_t cm = nullptr;
+        const ncclResult_t r = api->CommInitRank(&cm, world, u, rank);
+        std::lock_guard<std::mutex> g(job->mu);
+        job->r = r;
+        job->comm = cm;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> g(job->mu);
+        if (limit_s > 0) job->cv.wait_for(g, std::chrono::duration<double>(limit_s), [&] { return job->done; });
+        else job->cv.wait(g, [&] { return job->done; });
+        if (!job->done) {
+            g_rccl_stuck.store(1);
+            return comm_fail(nullptr, NGSQ_ERR_DEVICE, "ncclCommInitRank(rank %d of %d, device %d) did not return within %g s (NGSQ_RCCL_INIT_TIMEOUT_S)",
+                             rank, world, device, limit_s);
+        }
+    }
+    if (job->r != ncclSuccess)
+        return comm_fail(nullptr, NGSQ_ERR_DEVICE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device,
+                         api->GetErrorString(job->r));
     RcclComm *c = new RcclComm();
     c->rank = rank;
     c->world = world;
@@ -456,15 +510,7 @@ int ngsq_comm_create_rccl(int rank, int world, const uint8_t id[NGSQ_COMM_ID_BYT
     c->device = true;
     c->api = api;
     c->dev = device;
-    ncclUniqueId u;
-    memcpy(&u, id, sizeof u);
-    ncclResult_t r = api->CommInitRank(&c->comm, world, u, rank);
-    if (r != ncclSuccess) {
-        c->comm = nullptr;
-        delete c;
-        return comm_fail(nullptr, NGSQ_ERR_DEVICE, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device,
-                         api->GetErrorString(r));
-    }
+    c->comm = job->comm;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;

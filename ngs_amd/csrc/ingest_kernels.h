@@ -48,7 +48,9 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
 
 // CRC32 of every block's inflated bytes against its gzip trailer (status[k] = INF_CRC_MISMATCH); what
 // launch_bgzf_inflate(check_crc = true) runs second
-hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, hipStream_t s);
+// status_host (optional): pinned host memory the device addresses; receives every block's final status (so that the caller
+// needs no copy behind the kernel)
+hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uint8_t *out, uint32_t *status, uint32_t *status_host, hipStream_t s);
 
 // ---- BAM record parse (csrc/bam_device.hip) -------------------------------------------------------
 #ifndef NGSQ_REC_SEGMENT
@@ -104,19 +106,29 @@ hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start,
                            RecPieces *pieces, hipStream_t s);
 // chosen[s]: which candidate of segment s is on the file's chain (REC_NO_CHAIN: none starts there); seg_base[s]: index of
 // its first record.  One lane per REC_PIECE bytes writes the offsets of the records that start there.
+// work: the REC_WORK_WORDS device words shared with launch_rec_fixed; work[W_BAD] (set to ~0 by the caller) = smallest index of an invalid record
 hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
-                              const RecPieces *pieces, uint64_t *rec_off, unsigned long long *bad, hipStream_t s);
+                              const RecPieces *pieces, uint64_t *rec_off, unsigned long long *work, hipStream_t s);
 // copy n_bytes (rounded up to whole 32-bit words) with a kernel: for small tables between device memory and pinned host
 // memory, which a hipMemcpyAsync would queue behind the large transfers of other streams
 hipError_t launch_copy_words(void *dst, const void *src, uint64_t n_bytes, hipStream_t s);
+// device to device, any alignment, by a kernel (not the DMA queue)
+hipError_t launch_copy_bytes(void *dst, const void *src, uint64_t n_bytes, hipStream_t s);
 // out[0] = number of entries of the ascending array a[0, n) that are < value (one thread)
 hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value, unsigned long long *out, hipStream_t s);
 // also writes var_base[i] = offset of record i's CIGAR in raw and var_base[n + i] = offset of its SEQ (2 n entries:
-// what launch_rec_var starts from)
-// stats[0..2]: max l_seq, max n_cigar, sum l_seq (zeroed by the caller); stats[3], stats[4]: refID << 32 | pos of the first
-// and the last record of the batch; stats[5] (set to ~0 by the caller): index of the first long-CIGAR placeholder
+// what launch_rec_var starts from), and -- cig_len given -- n_cigar_op of every record as n + 1 64-bit entries (the last 0).
+// work: REC_WORK_WORDS device words the kernels keep between launches (initial state: rec_work_init); host: REC_HOST_WORDS words of
+// pinned host memory the device addresses, written by the launch's last block: what the layout decision needs, no copy
+// afterwards.  host[H_BAD] != ~0: the chunk's record chain holds an invalid record (its index), nothing else was done.
+enum RecWork : uint32_t { W_BAD = 0, W_MAXL, W_MAXOPS, W_SUML, W_FIRST, W_LAST, W_LONG, W_SUMOPS, W_TICKET, REC_WORK_WORDS = 16 };
+enum RecHost : uint32_t { H_MAXL = 0, H_MAXOPS, H_SUML, H_FIRST, H_LAST, H_LONG, H_SUMOPS, H_BAD, REC_HOST_WORDS = 8 };
+inline void rec_work_init(unsigned long long *w) {
+    for (uint32_t k = 0; k < REC_WORK_WORDS; k++) w[k] = 0;
+    w[W_BAD] = w[W_LONG] = ~0ull;
+}
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
-                            unsigned long long *stats, const RecOrigin &org, hipStream_t s);
+                            unsigned long long *work, unsigned long long *host, const RecOrigin &org, uint64_t *cig_len, hipStream_t s);
 hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, uint64_t *seq_len,
                               uint64_t *qual_len, uint64_t *cig_len, hipStream_t s);
 // exclusive prefix sums of n+1 entries in place (entry n = total); tmp: scratch of *tmp_bytes

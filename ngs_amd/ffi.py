@@ -340,6 +340,7 @@ PROTOTYPES = {
     "ngsq_comm_world": (C.c_int, [comm_p]),
     "ngsq_comm_kind": (C.c_char_p, [comm_p]),
     "ngsq_comm_rccl_version": (C.c_int, []),
+    "ngsq_comm_rccl_stuck": (C.c_int, []),
     "ngsq_comm_allgather_host": (C.c_int, [comm_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "ngsq_comm_allreduce_host": (C.c_int, [comm_p, C.c_void_p, C.c_uint64, C.c_uint32]),
     "ngsq_comm_sendrecv_host": (C.c_int, [comm_p, C.POINTER(P2P), C.c_uint32, C.POINTER(P2P), C.c_uint32]),

@@ -146,6 +146,8 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
 
 ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int rank) {
     if (!out || nranks < 1 || nranks > MAX_WORLD || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    if (const char *st = getenv("RCCL_DOUBLE_STALL_S")) // a bootstrap that never completes (the library's time limit is what is tested)
+        usleep((useconds_t)(atof(st) * 1e6));
     char name[NCCL_UNIQUE_ID_BYTES + 1];
     memcpy(name, id.internal, NCCL_UNIQUE_ID_BYTES);
     name[NCCL_UNIQUE_ID_BYTES] = 0;

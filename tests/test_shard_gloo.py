@@ -392,3 +392,36 @@ def test_launch_without_rccl_agrees_on_shared_memory():
     if not z:
         pytest.skip("no libz to stand in for a librccl without entry points")
     _run_ranks(_fallback_worker, 2, z)
+
+
+def _stall_worker(rank, world, port, q, lib_path):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_PORT=str(port), NGSQ_RCCL_LIB=lib_path,
+                          RCCL_DOUBLE_STALL_S="120", NGSQ_RCCL_INIT_TIMEOUT_S="1.5", NGSQ_RCCL_SKIP_DEVICE_CHECK="1")
+        import time
+        from ngs_amd import ffi, shard
+        t0 = time.time()
+        comm = shard.comm_from_env(0, "rccl")
+        dt = time.time() - t0
+        assert comm.kind == "shm" and "did not return within" in (comm.fallback_reason or ""), comm.fallback_reason
+        assert 1.0 < dt < 30.0, dt
+        assert ffi.load_library().ngsq_comm_rccl_stuck() == 1
+        got = comm.allreduce(np.full(3, rank + 1, dtype=np.uint64))
+        assert list(got) == [sum(range(1, world + 1))] * 3
+        comm.barrier()
+        comm.destroy()
+        q.put((rank, "ok"))
+        os._exit(0)     # a thread of this process is still inside the stalled ncclCommInitRank
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + traceback.format_exc()))
+        os._exit(1)
+
+
+def test_rccl_init_that_never_returns_is_given_up_on():
+    """VERDICT r3 item 3b: ncclCommInitRank has no time limit of its own.  tests/rccl_double stalls in it for two minutes;
+    ngsq_comm_create_rccl gives up after NGSQ_RCCL_INIT_TIMEOUT_S on every rank, the ranks agree on the shared-memory
+    transport through the segment they met in, the exchange runs, and ngsq_comm_rccl_stuck() tells the process to leave
+    with _exit().  (No GPU: NGSQ_RCCL_SKIP_DEVICE_CHECK, which only this test sets.)"""
+    _run_ranks(_stall_worker, 2, rccl_double_path())

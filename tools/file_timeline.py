@@ -12,7 +12,7 @@ def run(n):
     lib = ffi.load_library()
     path = b"/tmp/tl.bam"
     if not os.path.exists(path):
-        cfg = host.synth_config(n)
+        cfg = host.synth_config(n, file_style=int(os.environ.get("STYLE", "0")))   # STYLE=3: an aligner's names, tags and CIGAR mix
         assert lib.ngsq_synth_write_bam(C.byref(cfg), path, n, 6, 0) == 0
         os.sync()
     ctx = host.QcContext([248956422, 242193529], [1, 1], max_read_len=1024, gc_seed=1, sorted_input=True, timing=False, lib=lib)
