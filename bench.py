@@ -74,9 +74,18 @@ def parse_args():
                     help="records PER GPU of the synthetic BAM of the file_end_to_end leg (0 = skip that leg); at N > 1 one file "
                          "of N x this many records is scanned by `ngs qc --gpus N` (fewer when writing it would take longer "
                          "than --file-write-budget seconds: the writer is zlib on the host cores)")
-    ap.add_argument("--file-write-budget", type=float, default=75.0, help="seconds the N > 1 file leg may spend writing its BAM")
-    ap.add_argument("--file-big-records", type=int, default=200_000_000,
-                    help="N = 1: a second, larger file scanned in process beside the --file-records one (0 = skip)")
+    ap.add_argument("--file-write-budget", type=float, default=450.0,
+                    help="seconds the N > 1 file leg may spend writing its BAM (8 x 60 M records take zlib level 6 on 16 host cores "
+                         "~390 s; the driver allows a run 1800 s)")
+    ap.add_argument("--file-big-records", type=int, default=0,
+                    help="N = 1: a second, larger file scanned in process beside the --file-records one (0 = skip; 200 M records "
+                         "take the zlib writer ~160 s)")
+    ap.add_argument("--file-realistic-records", type=int, default=60_000_000,
+                    help="N = 1: records of the aligner-style file (Illumina names, NM/MD/MC/AS/XS/MQ/RG/SA/XA/B tags, 15 %% multi-"
+                         "operation CIGARs, real mate positions) scanned beside the plain one (0 = skip)")
+    ap.add_argument("--mixed-records", type=int, default=100_000_000,
+                    help="N = 1: records of the 50-300 bp mixed-CIGAR workload timed beside the headline one (0 = skip)")
+    ap.add_argument("--mixed-steps", type=int, default=30)
     ap.add_argument("--file-level", type=int, default=6, help="zlib level of that BAM")
     ap.add_argument("--h2d-batch", type=int, default=4_000_000, help="records per host batch of the h2d_inclusive leg (0 = skip)")
     ap.add_argument("--extra-facet-records", type=int, default=100_000_000, help="records of the Edits / Genomic Features leg")
@@ -310,6 +319,8 @@ def main() -> int:
         if world == 1 and not args.emulate_shard:
             if args.cpu_sample > 0:
                 out["cpu_baseline"] = cpu_baseline(lib, host, ffi, scfg, min(args.cpu_sample, n), max_len)
+            if args.mixed_records > 0 and not mixed:
+                out["mixed"] = guarded(leg_mixed, lib, host, ffi, np, args, device)
             if args.h2d_batch > 0 and not mixed:
                 out["h2d_inclusive"] = guarded(leg_h2d, lib, host, ffi, args)
             if args.file_records > 0 and not mixed:
@@ -765,6 +776,10 @@ def leg_file(lib, host, ffi, args):
                                        "check_total": doc_b["general"]["records"]["total"], "source": "page cache"}
                 except Exception as e:  # noqa: BLE001
                     out["big_file"] = {"failed": f"{type(e).__name__}: {e}"}
+            # ---- what an aligner writes: long names, a dozen tags per record, multi-operation CIGARs, real mate positions --
+            # 370 bytes per record where the plain file has 273, and a screen that has to tell records from their tails
+            if args.file_realistic_records > 0:
+                out["realistic"] = guarded(leg_file_realistic, lib, host, ffi, args, ctx, tmp, ngs, out["bam_write_s"] / max(n, 1))
         finally:
             ctx.close()
         def strip(d):  # the GC window offsets are a function of (seed, record id = virtual offset): identical across the runs
@@ -776,6 +791,90 @@ def leg_file(lib, host, ffi, args):
         for f in os.listdir(tmp):
             os.remove(os.path.join(tmp, f))
         os.rmdir(tmp)
+
+
+def leg_file_realistic(lib, host, ffi, args, ctx, tmp, ngs, write_s_per_record):
+    """An aligner-style file (include/ngsq_shared.h NGSQ_SYNTH_FILE_REALISTIC) through the same entry points: in process three
+    times, and once through `ngs qc --ingest host` (the host reader) for the document it must equal."""
+    import ctypes as C
+    nr = int(min(args.file_realistic_records, max(10_000_000, 110.0 / max(write_s_per_record * 1.4, 1e-9))))   # <= ~110 s of writing
+    path = os.path.join(tmp, "realistic.bam")
+    cfg = host.synth_config(nr, read_len=args.read_len, ref_len=CHR1, n_refs=2, file_style=ffi.SYNTH_FILE_REALISTIC)
+    t0 = time.perf_counter()
+    assert lib.ngsq_synth_write_bam(C.byref(cfg), path.encode(), nr, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+    tw = time.perf_counter() - t0
+    os.sync()
+    size = os.path.getsize(path)
+    times, best, timing, after, doc = scan_file_in_process(lib, host, ffi, ctx, path, nr, 3)
+    h = C.c_void_p()
+    stats = None
+    inf = timing.get("bgzf_inflate")
+    raw = (inf["algo_bytes"] - size) if inf else None
+    out = {"records": nr, "bam_bytes": size, "bam_write_s": round(tw, 1),
+           "style": "Illumina read names, NM MD MC AS XS MQ RG on every mapped record, SA / XA / a B,S array on some, "
+                    "15 % CIGARs of 2-5 operations (clips, insertions, deletions), real mate positions",
+           "compressed_bytes_per_record": round(size / nr, 1), "inflated_bytes_per_record": round(raw / nr, 1) if raw else None,
+           "seconds_each_scan": times, "value": round(nr / best, 1), "unit": "records/s",
+           "compressed_GB_per_s": round(size / best / 1e9, 2), "inflated_GB_per_s": round(raw / best / 1e9, 2) if raw else None,
+           "records_per_s_after_first_batch": round(after[0], 1) if after else None,
+           "kernels": kernel_table(timing), "check_total": doc["general"]["records"]["total"], "source": "page cache"}
+    if inf and inf["launches"]:
+        gbs = inf["algo_bytes"] / inf["total_ms"] / 1e6
+        out["inflate"] = {"achieved_GB_per_s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "avg_launch_ms": round(inf["total_ms"] / inf["launches"], 3)}
+    t0 = time.perf_counter()
+    r = subprocess.run([ngs, "-q", "qc", path, "GRCh38_no_alt_AnalysisSet", "-o", tmp, "--ingest", "host"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"ngs qc --ingest host: {r.stderr[-400:]}")
+    out["cli_host_ingest_s"] = round(time.perf_counter() - t0, 2)
+    with open(os.path.join(tmp, "realistic.bam.results.json")) as f:
+        out["same_document_as_host_reader"] = json.dumps(json.load(f), sort_keys=True) == json.dumps(doc, sort_keys=True)
+    return out
+
+
+def leg_mixed(lib, host, ffi, np, args, device):
+    """The 50-300 bp mixed-CIGAR workload (ragged SEQ / QUAL / CIGAR columns with offsets) on the same facets, beside the
+    headline line: the same loop as main()'s, fewer steps."""
+    import types
+    n = args.mixed_records
+    scfg = host.synth_config(n, mode=ffi.SYNTH_MIXED, read_len=args.read_len, max_len=args.mixed_max_len, ref_len=CHR1, n_refs=2)
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=args.facets & 0x1F, device=device, max_read_len=args.mixed_max_len, gc_seed=GC_SEED,
+                         timing=True, sorted_input=n / CHR1 <= 0.5, lib=lib)
+    db = ctx.synth_device_batch(scfg, 0, n)
+    try:
+        def step():
+            ctx.reset(); ctx.process_batch(db); ctx.finalize()
+        for _ in range(3):
+            step()
+        ctx.synchronize()
+        ctx.kernel_timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.mixed_steps):
+            step()
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        margs = types.SimpleNamespace(facets=args.facets & 0x1F, read_len=args.read_len, workload="mixed", mixed_max_len=args.mixed_max_len)
+        parity = check_invariants(ctx, ffi, n, margs, True, False)
+        timing = ctx.kernel_timing()
+        algo_rec = 25.0 + 4.0 * db.cigar_ops / n + db.seq_bytes / n + db.qual_bytes / n
+        out = {"workload": "%d M synthetic 50-%d bp reads, 1-5 CIGAR operations, ragged columns" % (n // 1_000_000, args.mixed_max_len),
+               "value": round(n * args.mixed_steps / dt, 1), "unit": "records/s", "steps": args.mixed_steps,
+               "ms_per_step": round(dt / args.mixed_steps * 1e3, 3), "algorithmic_bytes_per_record": round(algo_rec, 2),
+               "hbm_frac_whole_pass": round(n * args.mixed_steps / dt * algo_rec / (HBM_PEAK_GBS * 1e9), 4),
+               "parity_check": parity, "kernels": kernel_table(timing)}
+        q = timing.get("qual")
+        if q and q["launches"] and q["total_ms"] > 0:
+            avg_ms = q["total_ms"] / q["launches"]
+            achieved = (q["algo_bytes"] / q["launches"]) / (avg_ms * 1e-3) / 1e9
+            traffic, src = pmc_traffic(n, margs)
+            out["roofline"] = {"bound": "hbm", "kernel": "k_qual_ragged", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                               "traffic_measured_in_this_run": False, "avg_launch_ms": round(avg_ms, 4),
+                               "algo_bytes_per_launch": q["algo_bytes"] // q["launches"]}
+        return out
+    finally:
+        ctx.free_batch(db)
+        ctx.close()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGSQ_ABI_VERSION 4u
+#define NGSQ_ABI_VERSION 5u
 
 /* ---- status codes (reference: anyhow::Result<()> / panic) ---- */
 #define NGSQ_OK 0
@@ -98,7 +98,8 @@ typedef struct ngsq_config {
                                read of the batches (see ngsq_batch.max_l_seq)                              */
     uint64_t gc_seed;       /* seed of the deterministic GC window offset (ngsq_gc_offset) */
     const uint8_t *const *ref_bases; /* Edits only: [n_refs] pointers to ref_len[r] bytes of
-                                        4-bit BAM base codes (one code per byte), host memory;
+                                        4-bit BAM base codes (one code per byte, every byte <= 15:
+                                        anything else is NGSQ_ERR_INVALID_ARGUMENT), host memory;
                                         NULL entries => sequence not in FASTA               */
     void *stream;           /* optional hipStream_t to launch on; NULL -> library creates one */
     uint32_t timing;        /* 1 -> bracket every kernel with HIP events (ngsq_kernel_timing) */
@@ -129,6 +130,11 @@ typedef struct ngsq_config {
  *               quals).  With a fixed stride: each row holds qual_stride bytes and the
  *               byte 0xFF means "no score at this cycle" (row padding beyond l_seq, or a
  *               whole 0xFF row = missing qualities, exactly BAM's own encoding)
+ *   n_cigar     the record's number of CIGAR operations, SATURATED at 65535: the column is 16 bits wide, as the BAM field is.
+ *               A record with more operations (SAM specification 4.2.2: its BAM CIGAR is the placeholder <l_seq>S<span>N
+ *               and the real one sits in a CG:B,I tag, which noodles resolves while decoding -- the readers of ngsq_bam.h
+ *               do the same) says 65535 here and its real count is cigar_off[i+1] - cigar_off[i]: such a batch addresses
+ *               its CIGARs through cigar_off (ABI 5; ABI 4 refused these records)
  *   cigar       BAM encoding len<<4|op, op in 0..8 = MIDNSHP=X
  *   record_id   optional: one 64-bit identity per record, the only input of the GC window offset besides gc_seed and
  *               l_seq (ngsq_gc_offset).  NULL -> first_record_index + i, the record's ordinal in the file.  The
@@ -365,9 +371,15 @@ int ngsq_kernel_timing_reset(ngsq_ctx *ctx);
  * uint64 block (all record-facet tallies and histograms, nonsensical count,
  * per-sequence `seen` flags, error counts).  `depth`: one uint32 block holding,
  * per primary sequence, the coverage difference array (ref_len+2 entries);
- * Edits adds refs/alts.  Any summation (RCCL all-reduce, or a host loop) of
+ * `edits`: per sequence with reference bases 2 (ref_len+1) uint32 -- until the teardown the difference array of the `M`
+ * cover (entry p-1 += 1 / entry q -= 1 for an M over positions p..q) and the mismatches per position (alts); the teardown
+ * turns the first half into refs = cover - alts (ngsq_get_edits_positions).  Any summation (RCCL all-reduce, or a host loop) of
  * these blocks across contexts followed by ngsq_finalize on one of them gives
- * the single-context result. */
+ * the single-context result -- PROVIDED the contexts' quality tables have the same number of rows: the table is the last
+ * part of the counters block and grows with the longest read a context has met (ngsq_max_read_len), so n_u64 and the device
+ * pointer change when a batch brings a longer read (fetch them after the last batch, not before), and shards that met
+ * different longest reads hold blocks of different sizes.  ngsq_exchange (ngsq_comm.h) equalises the rows first; a host
+ * that sums the blocks itself creates its contexts with max_read_len = the longest read of the file. */
 int ngsq_state_counters(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u64);
 int ngsq_state_depth(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u32);
 int ngsq_state_edits(ngsq_ctx *ctx, void **dev_ptr, uint64_t *n_u32);

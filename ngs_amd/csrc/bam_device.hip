@@ -51,8 +51,10 @@ __device__ __forceinline__ bool record_valid(const uint8_t *r /* at block_size *
     return l_read_name != 0 && need <= bs;
 }
 
-// bam_reader.h aux_has_cg_tag, on the device (only the rare lane whose CIGAR is the long-CIGAR placeholder walks its tags)
-__device__ bool aux_has_cg_tag(const uint8_t *p, const uint8_t *end) {
+// bam_reader.h aux_find_cg, on the device (only the rare lane whose CIGAR is the long-CIGAR placeholder walks its tags):
+// offset from p of the CG:B,I tag's operations and their number, or 0
+__device__ uint64_t aux_find_cg(const uint8_t *p0, const uint8_t *end, uint32_t *n_ops) {
+    const uint8_t *p = p0;
     while (end - p >= 4) {
         const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
         p += 3;
@@ -62,23 +64,27 @@ __device__ bool aux_has_cg_tag(const uint8_t *p, const uint8_t *end) {
         else if (ty == 'i' || ty == 'I' || ty == 'f') n = 4;
         else if (ty == 'Z' || ty == 'H') {
             while (p < end && *p) p++;
-            if (p >= end) return false;
+            if (p >= end) return 0;
             n = 1;
         } else if (ty == 'B') {
-            if (end - p < 5) return false;
+            if (end - p < 5) return 0;
             const uint8_t sub = p[0];
             const uint32_t cnt = (uint32_t)p[1] | (uint32_t)p[2] << 8 | (uint32_t)p[3] << 16 | (uint32_t)p[4] << 24;
             const uint32_t w = sub == 'c' || sub == 'C' ? 1 : sub == 's' || sub == 'S' ? 2 : sub == 'i' || sub == 'I' || sub == 'f' ? 4 : 0;
-            if (!w) return false;
-            if (t0 == 'C' && t1 == 'G' && sub == 'I') return true;
+            if (!w) return 0;
             n = 5 + (uint64_t)cnt * w;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') {
+                if ((uint64_t)(end - p) < n) return 0;
+                *n_ops = cnt;
+                return (uint64_t)(p + 5 - p0);
+            }
         } else {
-            return false;
+            return 0;
         }
-        if ((uint64_t)(end - p) < n) return false;
+        if ((uint64_t)(end - p) < n) return 0;
         p += n;
     }
-    return false;
+    return 0;
 }
 
 // The screen of k_rec_candidates, beyond the fields' ranges.  Round 4: in a file whose records carry a real mate position the
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(PT) void k_rec_offsets(const uint8_t *__restrict__ 
 // ---- 4. fixed-width columns + the numbers the layout decision needs ----------------------------
 // work (device, REC_WORK_WORDS words, kept between launches): [W_BAD] smallest index of an invalid record of the chunk (k_rec_offsets;
 // ~0: none -- a launch that finds one there does nothing but report it), then this launch's tallies: max l_seq, max n_cigar_op,
-// sum l_seq, (refID << 32 | pos) of the first / last record, index of the first record with the long-CIGAR placeholder (~0: none),
+// sum l_seq, (refID << 32 | pos) of the first / last record, records whose CIGAR came from a CG:B,I tag (specification 4.2.2),
 // sum n_cigar_op, and a ticket.  The block that finishes LAST writes the eight numbers into `host` -- pinned host memory the device
 // addresses -- and resets the tallies for the next launch: until round 4 the caller reset them with two memsets and fetched them
 // with a copy kernel of its own (k_copy_words: 6 launches per chunk, 0.14 ms each beside the reader's DMA, three of them on the
@@ -372,15 +378,31 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
         c.ref_id[i] = (int32_t)a.x;
         c.pos[i] = (int32_t)a.y;
         c.mapq[i] = (uint8_t)(a.z >> 8);
-        c.n_cigar[i] = (uint16_t)n_ops;
         c.flag[i] = (uint16_t)(a.w >> 16);
         c.l_seq[i] = l;
         c.mate_ref_id[i] = (int32_t)b.y;
         c.tlen[i] = (int32_t)b.w;
-        var_base[i] = o + 32 + l_read_name;
+        uint64_t cig_at = o + 32 + l_read_name;
+        uint32_t real_ops = n_ops;
+        if (n_ops == 2 && l) { // the long-CIGAR placeholder <l_seq>S<span>N (specification 4.2.2): the operations are in the record's CG:B,I tag
+            const uint32_t op0 = ld32(raw + cig_at), op1 = ld32(raw + cig_at + 4);
+            if (op0 == (l << 4 | 4u) && (op1 & 15u) == 3u) {
+                const uint32_t bs = ld32(raw + o - 4); // block_size: the record ends at o + bs
+                const uint64_t need = 32ull + l_read_name + 8ull + ((uint64_t)l + 1) / 2 + l;
+                uint32_t cnt = 0;
+                const uint64_t at = need <= bs ? aux_find_cg(raw + o + need, raw + o + bs, &cnt) : 0;
+                if (at && cnt >= 2) { // (as the host reader: a tag with fewer operations than the placeholder is ignored)
+                    cig_at = o + need + at;
+                    real_ops = cnt;
+                    order += atomicAdd(&work[W_LONG], 1ull);
+                }
+            }
+        }
+        c.n_cigar[i] = (uint16_t)min(real_ops, 0xFFFFu);
+        var_base[i] = cig_at;
         seq_src[i] = o + 32 + l_read_name + 4ull * n_ops;
         if (cig_len) {
-            cig_len[i] = n_ops;
+            cig_len[i] = real_ops;
             if (i == n - 1) cig_len[n] = 0;
         }
         if (org.record_id) {
@@ -398,20 +420,12 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
             }
             org.record_id[i] = id;
         }
-        if (n_ops == 2 && l) { // the long-CIGAR placeholder <l_seq>S<span>N (specification 4.2.2): refused by name, as the host reader does
-            const uint32_t op0 = ld32(raw + o + 32 + l_read_name), op1 = ld32(raw + o + 36 + l_read_name);
-            if (op0 == (l << 4 | 4u) && (op1 & 15u) == 3u) {
-                const uint32_t bs = ld32(raw + o - 4); // block_size: the record ends at o + bs
-                const uint64_t need = 32ull + l_read_name + 8ull + ((uint64_t)l + 1) / 2 + l;
-                if (need <= bs && aux_has_cg_tag(raw + o + need, raw + o + bs)) order += atomicMin(&work[W_LONG], (unsigned long long)i);
-            }
-        }
         if (i == 0) order += atomicExch(&work[W_FIRST], (unsigned long long)a.x << 32 | a.y);
         if (i == n - 1) order += atomicExch(&work[W_LAST], (unsigned long long)a.x << 32 | a.y);
         ml = max(ml, l);
-        mo = max(mo, n_ops);
+        mo = max(mo, real_ops);
         sl += l;
-        so += n_ops;
+        so += real_ops;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
             host[H_SUML] = atomicExch(&work[W_SUML], 0ull);
             host[H_FIRST] = atomicExch(&work[W_FIRST], 0ull);
             host[H_LAST] = atomicExch(&work[W_LAST], 0ull);
-            host[H_LONG] = atomicExch(&work[W_LONG], ~0ull);
+            host[H_LONG] = atomicExch(&work[W_LONG], 0ull);
             host[H_SUMOPS] = atomicExch(&work[W_SUMOPS], 0ull);
             host[H_BAD] = ~0ull;
             (void)atomicExch(&work[W_TICKET], 0ull);
@@ -620,9 +634,12 @@ __global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t t = threadIdx.x & 15u;
     if (i >= n) return;
-    const uint32_t n_ops = c.n_cigar[i], l = c.l_seq[i];
+    const uint32_t l = c.l_seq[i];
+    // (a record whose operations sit in its CG tag: their number is in the offsets, var_base points into the tag, SEQ is where
+    // the record's own fields say)
+    const uint32_t n_ops = c.cigar_off ? (uint32_t)(c.cigar_off[i + 1] - c.cigar_off[i]) : c.n_cigar[i];
     const uint8_t *cg = raw + var_base[i];
-    const uint8_t *sq = cg + 4ull * n_ops;
+    const uint8_t *sq = raw + var_base[n + i];
     const uint8_t *ql = sq + (l + 1) / 2;
     const uint32_t sb = (l + 1) / 2;
     if (parts & 1u) {

@@ -478,7 +478,11 @@ void reader_main(DeviceIngest *d, std::string path) {
     constexpr int NT_MAX = ReadPool::NT_MAX;
     // leave two cores of the quota to the thread that drives the GPU and to this one (it frames while the others read)
     // (the workers of a sharded run share the quota: ngsq_bam_shard_begin sets reader_threads)
-    const int NT = d->reader_threads > 0 ? std::min(NT_MAX, d->reader_threads) : std::max(4, std::min(NT_MAX, effective_cores() - 2));
+    // (NGSQ_READER_THREADS: a measurement aid for whole files -- tools/reader_threads.sh -- and the override for shards)
+    const int env_nt = getenv("NGSQ_READER_THREADS") ? atoi(getenv("NGSQ_READER_THREADS")) : 0;
+    const int NT = d->reader_threads > 0 ? std::min(NT_MAX, d->reader_threads)
+                   : env_nt > 0          ? std::min(NT_MAX, env_nt)
+                                         : std::max(4, std::min(NT_MAX, effective_cores() - 2));
     double ratio = 0.0; // compressed bytes per inflated byte, from the chunks framed so far
     bool cold = false;  // the last request came from storage, not from the page cache
     const int fd = fileno(d->f);
@@ -687,9 +691,9 @@ void reader_main(DeviceIngest *d, std::string path) {
             d->h2d_issued[k] = ok; // on failure the consumer copies on its own stream (and reports errors)
         }
         if (trace_on())
-            fprintf(stderr, "[ingest] reader: slot %d, %.1f MB read and %zu blocks framed in %.1f ms (%d steps: starting the read threads %.1f, framing %.1f, "
+            fprintf(stderr, "[ingest] +%.1f ms reader: slot %d, %.1f MB read and %zu blocks framed in %.1f ms (%d steps: starting the read threads %.1f, framing %.1f, "
                             "queueing the copies %.1f, waiting for the reads %.1f ms), %.1f MB left over\n",
-                    k, c.fill / 1e6, c.blocks.size(), tr1 - tr0, n_steps, t_spawn, t_frame, t_send, t_join, leftover.size() / 1e6);
+                    now_ms() - d->t_start, k, c.fill / 1e6, c.blocks.size(), tr1 - tr0, n_steps, t_spawn, t_frame, t_send, t_join, leftover.size() / 1e6);
         {
             std::lock_guard<std::mutex> g(d->mu);
             c.ready = true;
@@ -1160,8 +1164,10 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
     if (const char *e = getenv("NGSQ_INFLATE_AHEAD")) d->inflate_ahead = std::max(1, std::min(2, atoi(e)));
     if (const char *e = getenv("NGSQ_INFLATE_STREAMS")) d->inflate_streams = std::max(1, std::min(2, atoi(e)));
     // the reader starts pinning and reading at once; the two raw buffers are allocated meanwhile
+    if (trace_on()) fprintf(stderr, "[ingest] +%.1f ms streams and events created\n", now_ms() - d->t_start);
     d->reader = std::thread(reader_main, d, b->path);
     for (auto &r : d->d_rawb) BHIP(r.reserve(CARRY_MAX + d->raw_cap + 64)); // headroom for the carried record | one chunk's inflated bytes
+    if (trace_on()) fprintf(stderr, "[ingest] +%.1f ms raw buffers reserved\n", now_ms() - d->t_start);
     BHIP(d->d_small.reserve(REC_WORK_WORDS));
     {
         unsigned long long w[REC_WORK_WORDS];
@@ -1172,6 +1178,7 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
     std::vector<uint8_t>().swap(b->comp);
     std::vector<uint8_t>().swap(b->data);
     (void)c;
+    if (trace_on()) fprintf(stderr, "[ingest] +%.1f ms ingest started\n", now_ms() - d->t_start);
     return NGSQ_OK;
 }
 
@@ -1351,9 +1358,7 @@ int ngsq_bam_next_batch_device(ngsq_bam *b, ngsq_ctx *c, uint64_t max_records, n
     if (host_stats[H_BAD] != ~0ull)
         return ngsq_bam_fail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
                              (unsigned long long)(d->chunk_first_record + host_stats[H_BAD]));
-    if (host_stats[H_LONG] != ~0ull)
-        return ngsq_bam_fail(NGSQ_ERR_UNSUPPORTED, "%s: record %llu: a CIGAR of more than 65535 operations (CG tag, SAM specification 4.2.2) is not supported",
-                             b->path.c_str(), (unsigned long long)(b->n_read + host_stats[H_LONG]));
+    d->stats.long_cigar_records += host_stats[H_LONG]; // (their operations come from the CG tag: k_rec_fixed)
     if (!d->n_own) d->first_key = host_stats[H_FIRST];
     d->last_key = host_stats[H_LAST];
     d->n_own += n;

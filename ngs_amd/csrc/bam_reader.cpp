@@ -275,6 +275,8 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
     if (max_records == 0) return NGSQ_OK;
     // ---- index the records of this batch inside the decompressed buffer
     std::vector<size_t> recs; // offsets (relative to data_pos) of block_size fields
+    // the records whose CIGAR is in a CG tag: (index in recs, (offset of the tag's operations relative to data_pos, their number))
+    std::vector<std::pair<size_t, std::pair<size_t, uint32_t>>> long_cigar;
     size_t cursor = 0;
     uint32_t max_l = 0, max_ops = 0;
     uint64_t sum_qual = 0;
@@ -299,18 +301,24 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
             return bfail(NGSQ_ERR_INVALID_ARGUMENT, "%s: malformed record %llu", b->path.c_str(),
                          (unsigned long long)(b->n_read + recs.size()));
         // SAM/BAM specification 4.2.2: a CIGAR of more than 65535 operations is stored in a CG:B,I tag and the CIGAR field
-        // holds the placeholder <l_seq>S<reference span>N.  noodles resolves the tag; the batch ABI counts the operations of
-        // a record in 16 bits, so such a record is refused by name instead of being scanned with the placeholder ([N10])
+        // holds the placeholder <l_seq>S<reference span>N.  noodles resolves the tag while it decodes the record, so the
+        // facets see the real operations ([N10] in oracle/oracle.h): so do the batches (ABI 5: n_cigar saturates at
+        // 65535, the real count is in cigar_off).  The placeholder alone -- no tag -- is an odd but real alignment.
+        uint32_t real_ops = n_ops;
         if (n_ops == 2 && l > 0) {
             const uint8_t *cg = r + 32 + l_read_name;
-            if (rd32(cg) == (l << 4 | 4u) && (rd32(cg + 4) & 15u) == 3u &&
-                ngsq::aux_has_cg_tag(r + need, r + block_size)) // (the placeholder alone could be an odd but real alignment)
-                return bfail(NGSQ_ERR_UNSUPPORTED, "%s: record %llu: a CIGAR of more than 65535 operations (CG tag, SAM specification 4.2.2) is not supported",
-                             b->path.c_str(), (unsigned long long)(b->n_read + recs.size()));
+            if (rd32(cg) == (l << 4 | 4u) && (rd32(cg + 4) & 15u) == 3u) {
+                uint32_t cnt = 0;
+                const uint8_t *ops = ngsq::aux_find_cg(r + need, r + block_size, &cnt);
+                if (ops && cnt >= 2) { // (the convention is for more than 65535 operations; a tag with fewer than the placeholder's two is ignored)
+                    long_cigar.emplace_back(recs.size(), std::make_pair((size_t)(ops - (b->data.data() + b->data_pos)), cnt));
+                    real_ops = cnt;
+                }
+            }
         }
         recs.push_back(cursor);
         max_l = std::max(max_l, l);
-        max_ops = std::max(max_ops, n_ops);
+        max_ops = std::max(max_ops, real_ops);
 
         sum_qual += l;
 
@@ -346,6 +354,7 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
             b->qual_off.resize(n + 1);
         }
         if (!cig1) b->cigar_off.resize(n + 1);
+        size_t lc = 0;
         for (uint64_t i = 0; i < n; i++) {
             const uint8_t *r = D + recs[i] + 4;
             const uint32_t n_ops = rd16(r + 12), l = rd32(r + 16);
@@ -358,6 +367,7 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
             if (!cig1) {
                 b->cigar_off[i] = co;
                 co += n_ops;
+                if (lc < long_cigar.size() && long_cigar[lc].first == i) co += long_cigar[lc++].second.second - n_ops; // (the tag's count instead of the placeholder's 2)
             }
         }
     }
@@ -371,7 +381,7 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
             b->ref_id[i] = (int32_t)rd32(r);
             b->pos[i] = (int32_t)rd32(r + 4);
             b->mapq[i] = r[9];
-            b->n_cigar[i] = (uint16_t)n_ops;
+            b->n_cigar[i] = (uint16_t)n_ops; // (a record with a CG tag: below)
             b->flag[i] = rd16(r + 14);
             b->l_seq[i] = l;
             b->mate_ref_id[i] = (int32_t)rd32(r + 20);
@@ -409,6 +419,13 @@ int ngsq_bam_next_batch(ngsq_bam *b, uint64_t max_records, ngsq_batch *out) {
             }
         }
     });
+    for (const auto &lc : long_cigar) { // the real operations of the records whose CIGAR field is the placeholder (cig1 is false: they have two)
+        const uint64_t i = lc.first, c0 = b->cigar_off[i];
+        const uint32_t cnt = lc.second.second;
+        const uint8_t *ops = D + lc.second.first;
+        b->n_cigar[i] = (uint16_t)std::min<uint32_t>(cnt, 0xFFFFu);
+        for (uint32_t k = 0; k < cnt; k++) b->cigar[c0 + k] = rd32(ops + 4 * k);
+    }
     memset(SEQ + (fixed ? (size_t)pitch_s * n : (size_t)so), 0, 64);     // slack read by the device's vector loads
     memset(QUAL + (fixed ? (size_t)pitch_q * n : (size_t)qo), 0xFF, 64);
     b->data_pos += cursor;

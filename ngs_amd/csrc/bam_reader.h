@@ -33,10 +33,10 @@ struct RawBuf {
 
 struct DeviceIngest; // bam_device_reader.cpp
 
-// Does the auxiliary data [p, end) of a BAM record (SAM specification 4.2.4: tag[2] type[1] value) hold a CG:B,I tag -- the real
-// CIGAR of a record whose CIGAR field is the placeholder (4.2.2)?  Malformed data ends the walk (false).
-// (bam_device.hip has the same walk for the device reader.)
-inline bool aux_has_cg_tag(const uint8_t *p, const uint8_t *end) {
+// The CG:B,I tag in the auxiliary data [p, end) of a BAM record (SAM specification 4.2.4: tag[2] type[1] value) -- the real
+// CIGAR of a record whose CIGAR field is the placeholder <l_seq>S<span>N (4.2.2).  Returns a pointer to its 32-bit operations
+// and their number, or nullptr (no such tag; malformed data ends the walk).  (bam_device.hip has the same walk for the device reader.)
+inline const uint8_t *aux_find_cg(const uint8_t *p, const uint8_t *end, uint32_t *n_ops) {
     while (end - p >= 4) {
         const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
         p += 3;
@@ -47,25 +47,29 @@ inline bool aux_has_cg_tag(const uint8_t *p, const uint8_t *end) {
         case 'i': case 'I': case 'f': n = 4; break;
         case 'Z': case 'H':
             while (p < end && *p) p++;
-            if (p >= end) return false;
+            if (p >= end) return nullptr;
             n = 1;
             break;
         case 'B': {
-            if (end - p < 5) return false;
+            if (end - p < 5) return nullptr;
             const uint8_t sub = p[0];
             const uint32_t cnt = (uint32_t)p[1] | (uint32_t)p[2] << 8 | (uint32_t)p[3] << 16 | (uint32_t)p[4] << 24;
             const size_t w = sub == 'c' || sub == 'C' ? 1 : sub == 's' || sub == 'S' ? 2 : sub == 'i' || sub == 'I' || sub == 'f' ? 4 : 0;
-            if (!w) return false;
-            if (t0 == 'C' && t1 == 'G' && sub == 'I') return true;
+            if (!w) return nullptr;
             n = 5 + (size_t)cnt * w;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') {
+                if ((size_t)(end - p) < n) return nullptr;
+                *n_ops = cnt;
+                return p + 5;
+            }
             break;
         }
-        default: return false;
+        default: return nullptr;
         }
-        if ((size_t)(end - p) < n) return false;
+        if ((size_t)(end - p) < n) return nullptr;
         p += n;
     }
-    return false;
+    return nullptr;
 }
 
 // cores this process may really use: the cgroup's CPU quota when there is one (the MI355X boxes of this pool show 256

@@ -627,6 +627,14 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
         const uint32_t T = base + lane, src = T - (oe >> 17) - 1u;
         const bool inchunk = active && !lit && (int32_t)(src - base) >= 0;
         uint32_t val = (oe >> 17) & 255u;
+#ifdef NGSQ_INFLATE_PROFILE
+        {   // (round 4: nine emits in ten of an aligner-style BAM hold bytes whose source has left the ring; 46 % of the output bytes)
+            const uint64_t farm = __ballot(active && !lit && !inchunk && (int32_t)(src - base + RING) < 0);
+            PROF_COUNT(3, farm != 0);
+            PROF_COUNT(4, __popcll(farm));
+            PROF_COUNT(5, __popcll(__ballot(inchunk)) != 0);
+        }
+#endif
         if (active && !lit && !inchunk) {
             if (__builtin_expect((int32_t)(src - base + RING) < 0, 0))
                 val = __hip_atomic_load(gdst + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1137,6 +1145,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         for (int k = 0; k < 8; k++)
             fprintf(stderr, "[inflate-prof] %-24s %6.2f %%\n", names[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
         fprintf(stderr, "[inflate-prof] windows %llu, literals %llu, emits %llu, symbols taken the plain way %llu\n", h[8], h[9], h[10], h[14]);
+        fprintf(stderr, "[inflate-prof] emits with bytes read back from HBM %llu (%llu bytes), emits with a source inside their own 64 bytes %llu\n", h[11], h[12], h[13]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_prof), z, sizeof z);
     }

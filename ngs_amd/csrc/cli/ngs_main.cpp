@@ -41,6 +41,22 @@
 
 namespace {
 
+// cores the command may use: the cgroup's CPU quota when there is one (as the library's readers count them)
+int cgroup_cores() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = atol(quota) / period;
+            if (q >= 1 && q < n) n = (int)q;
+        }
+        fclose(f);
+    }
+    return n;
+}
+
 int g_level = 2; // 0 off (-q), 2 info (default), 3 debug (-v)   src/main.rs:71-83
 
 void logf(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -167,6 +183,11 @@ std::map<std::string, std::vector<uint8_t>> read_fasta(const std::string &path) 
     return out;
 }
 
+// a record's number of CIGAR operations: the 16-bit column saturates at 65535, the offsets then hold the count (include/ngsq.h)
+static inline uint64_t n_ops_of(const ngsq_batch &b, uint64_t i) {
+    return b.cigar_off ? b.cigar_off[i + 1] - b.cigar_off[i] : b.n_cigar[i];
+}
+
 // ---- record subsets for the `-n` rules -----------------------------------------------------
 struct Compact { // offsets-layout batch assembled from picked records
     std::vector<uint16_t> flag, n_cigar;
@@ -198,7 +219,7 @@ struct Compact { // offsets-layout batch assembled from picked records
         }
         qual_off.push_back(qual.size());
         const uint32_t *c = b.cigar + (b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride);
-        cigar.insert(cigar.end(), c, c + b.n_cigar[i]);
+        cigar.insert(cigar.end(), c, c + n_ops_of(b, i));
         cigar_off.push_back(cigar.size());
     }
     ngsq_batch batch() {
@@ -228,7 +249,7 @@ bool query_yields(const ngsq_batch &b, uint64_t i, const std::vector<uint32_t> &
     if (r < 0 || (size_t)r >= ref_len.size() || p < 0) return false;
     uint64_t span = 0;
     const uint32_t *c = b.cigar + (b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride);
-    for (uint32_t k = 0; k < b.n_cigar[i]; k++) {
+    for (uint64_t k = 0, n_ops = n_ops_of(b, i); k < n_ops; k++) {
         const uint32_t op = c[k] & 0xF;
         if (op <= 8 && ((0x18Du >> op) & 1u)) span += c[k] >> 4;
     }
@@ -552,6 +573,9 @@ int main(int argc, char **argv) {
         // the host driver of these machines supports dmabuf IPC only: without this RCCL's peer-memory set-up fails with
         // "hipIpcGetMemHandle: invalid argument" (bench.py's launcher sets the same default for its ranks)
         setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+        // fewer than six cores per worker (four pread threads, the reader, the driver: DESIGN.md section 8): the thread
+        // that waits for the GPU sleeps instead of spinning on a core the reader's copies need
+        if (cgroup_cores() < 6 * a.gpus) setenv("NGSQ_BLOCKING_SYNC", "1", 0);
         std::vector<pid_t> pids;
         for (int r = 0; r < a.gpus; r++) {
             std::vector<char *> av(argv, argv + argc);

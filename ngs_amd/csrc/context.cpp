@@ -160,6 +160,12 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     } while (0)
 
     CTX_TRY(hipSetDevice(c->device));
+    // NGSQ_BLOCKING_SYNC=1: a thread that waits for the device sleeps instead of spinning -- for hosts that give a process
+    // few cores (`ngs qc --gpus N` sets it for its workers when the CPU quota leaves a worker fewer than six: the reader's
+    // pread threads need the core the driving thread would spin on).  Refused once the device is in
+    // use by this process: not an error.
+    if (const char *e = getenv("NGSQ_BLOCKING_SYNC"))
+        if (atoi(e)) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     hipDeviceProp_t prop;
     CTX_TRY(hipGetDeviceProperties(&prop, c->device));
     c->li.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -298,8 +304,9 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         CTX_TRY(hipMemsetAsync(st.edits, 0, ne * 4, c->stream));
         // the reference, packed 4-bit, twice (edits_kernel.hip): [copy from base 0 | copy from base 1]
         uint8_t *bases = nullptr;
-        CTX_TRY(hipMalloc((void **)&bases, 2 * nbases + 64));
-        CTX_TRY(hipMemsetAsync(bases, 0, 2 * nbases + 64, c->stream));
+        // (+ 256: the window lanes of k_edits_rows read 16 bytes at up to 80 + 16 bytes behind a read's last compared base)
+        CTX_TRY(hipMalloc((void **)&bases, 2 * nbases + 256));
+        CTX_TRY(hipMemsetAsync(bases, 0, 2 * nbases + 256, c->stream));
         st.ref_bases = bases;
         st.ref_bases_odd = bases + nbases;
         c->d_ref_bases = bases;
@@ -669,6 +676,7 @@ int ngsq_process_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
     db.seq_stride = b->seq_stride;
     db.qual_stride = b->qual_stride;
     db.cigar_stride = b->cigar_stride;
+    db.qual_bytes = cs.qual_bytes;
 
     if (b->location == NGSQ_MEM_DEVICE) {
         db.flag = b->flag;

@@ -83,7 +83,7 @@ __device__ __forceinline__ uint32_t ed_walk_record(const DeviceState &st, const 
     const int32_t ref = b.ref_id[i], pos = b.pos[i];
     *out_edits = 0xFFFFFFFFu; // "not an Edits record"
     if (!(ref >= 0 && (uint32_t)ref < st.n_refs && pos >= 0)) return 0;
-    const uint32_t n_ops = b.n_cigar[i];
+    const uint32_t n_ops = batch_n_ops(b, i);
     const uint64_t cbase = b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride;
     uint64_t span = 0;
     for (uint32_t k = 0; k < n_ops; k++) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
     __shared__ uint32_t s_h1[ED_HIST], s_h2[ED_HIST];
     __shared__ uint32_t s_win[(ED_THREADS / 64) * EDR_WINDOW];  // cover: difference entries
     __shared__ uint32_t s_alt[(ED_THREADS / 64) * EDR_ALTW];    // mismatches per position of the same window
-    __shared__ uint2 s_desc[ED_THREADS];   // per record of the wave's current 64: (P, v0 | v1 << 16); v1 = 0: not on the fast path
+    __shared__ uint2 s_desc[ED_THREADS];   // per record of the wave's current 64: (byte offset of its base 0 in the packed reference, v0 | v1 << 9 | window entry of base 0 << 18); v1 = 0: not on the fast path
     __shared__ uint32_t s_edits[ED_THREADS];
     __shared__ uint32_t s_tmask[33];       // [n]: the bits 4 q + d of the first n bases of a window (base 8 d + (q ^ 1))
     __shared__ u64 s_acc[4];
@@ -426,6 +426,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
     uint32_t meta_L = 0;
 
     const uint32_t stride = b.seq_stride;
+    const uint32_t odd_delta = (uint32_t)(st.ref_bases_odd - st.ref_bases); // (both copies lie inside 4 GiB: launch_edits)
     const uint64_t n = b.n, n_tiles = (n + EDR_TILE - 1) / EDR_TILE;
     // the columns of a pass (records behind the end read as unmapped) and, with a fixed CIGAR pitch, the first three operations
     auto load_cols = [&](uint64_t r0) -> EdRowCols {
@@ -501,8 +502,11 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
                 own = shape && m && (uint64_t)a + m + z == r.l && r.l <= 2 * stride && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_L &&
                       i1 < EDR_WINDOW;
                 if (own) {
+                    // the record's descriptor for the window lanes: where its base 0 lies in the packed reference (a byte offset
+                    // from ref_bases: the copy that starts at base P & 1), compared bases [v0, v1), window entry of base 0
                     P = (uint32_t)r.pos - a;
-                    vv = a | (a + m) << 16;
+                    vv = a | (a + m) << 9 | (P - win_base) << 18;
+                    P = (uint32_t)(meta_boff + (P >> 1)) + (P & 1u ? odd_delta : 0u);
                     if (EDITS_EXP != 2 && EDITS_EXP != 4) {
                         atomicAdd(&win[i0], 1u);
                         atomicAdd(&win[i1], 0xFFFFFFFFu);
@@ -523,27 +527,28 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
             // ---- 2. lane = window g = 64 k + lane of the pass's rows (record g / R, window g % R): 16 bytes of sequence, 16 of
             // the reference (a window without compared bases reads the arrays' first bytes: nothing of it is kept)
             const uint8_t *const rows = b.seq + r0 * stride;
-            const uint64_t last = n - 1 - r0; // rows of the pass that exist
+            const uint32_t last = (uint32_t)min(n - 1 - r0, (uint64_t)63); // rows of the pass that exist
             struct Win {
                 uint4 sv, rv;
-                uint32_t slot, x0, lohi; // record slot, window entry of base 0 of the window, compared bases lo | hi << 8 (none: 0)
+                uint32_t slot, x0, lohi; // record slot, window entry of base 0 of the window, compared bases lo | hi << 8 (none: lo >= hi)
             };
             // window g = 64 k + lane is window ww of row rr at byte `off` of the pass's rows: stepped from k to k + 1 without a division
             uint32_t w_rr = (lane * recip) >> 16, w_ww = lane - w_rr * R, w_off = w_rr * stride + 16 * w_ww;
             const uint32_t step_rr = 64 / R, step_ww = 64 - step_rr * R, step_off = step_rr * stride + 16 * step_ww;
             auto load_win = [&]() -> Win { // the window (w_rr, w_ww); then on to the next one
+                // (a window without compared bases -- a record that is not on the fast path: descriptor 0; a window behind the
+                // read's end -- reads what lies at its place all the same: inside both buffers, and all of it masked away)
                 const uint2 d = desc[w_rr];
-                const uint32_t v0 = d.y & 0xFFFFu, v1 = d.y >> 16, b0 = 32 * w_ww;
-                const bool on = b0 < v1 && b0 + 32 > v0 && w_rr <= last; // the window holds compared bases
-                const uint8_t *const sp = rows + (on ? w_off : 0u);
-                const uint8_t *const rp = (d.x & 1u ? st.ref_bases_odd : st.ref_bases) + (on ? meta_boff + (d.x >> 1) + 16 * w_ww : 0ull);
+                const uint32_t v0 = d.y & 0x1FFu, v1 = (d.y >> 9) & 0x1FFu, b0 = 32 * w_ww;
+                const uint8_t *const sp = rows + (w_rr <= last ? w_off : 0u);
+                const uint8_t *const rp = st.ref_bases + (d.x + 16 * w_ww);
                 Win w;
                 __builtin_memcpy(&w.sv, sp, 16);
                 __builtin_memcpy(&w.rv, rp, 16);
                 w.slot = w_rr;
-                w.x0 = d.x + b0 - win_base;
-                const uint32_t lo = v0 > b0 ? v0 - b0 : 0u, hi = v1 < b0 + 32 ? v1 - b0 : 32u; // (on: v1 > b0)
-                w.lohi = on ? lo | hi << 8 : 0u;
+                w.x0 = (d.y >> 18) + b0;
+                const uint32_t lo = min(v0 > b0 ? v0 - b0 : 0u, 32u), hi = min(v1 > b0 ? v1 - b0 : 0u, 32u);
+                w.lohi = lo | hi << 8;
                 w_rr += step_rr, w_ww += step_ww, w_off += step_off;
                 if (w_ww >= R) w_ww -= R, w_rr += 1, w_off += stride - 16 * R;
                 return w;
@@ -827,9 +832,11 @@ hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const Devic
     static const bool per_record = getenv("NGSQ_EDITS_PER_RECORD") && atoi(getenv("NGSQ_EDITS_PER_RECORD")); // A/B measurements
     const uint32_t R = (b.seq_stride + 15) / 16;
     const uint32_t gr = (uint32_t)std::min<uint64_t>((b.n + EDR_TILE - 1) / EDR_TILE, cap);
-    if (!b.seq_off && R >= 1 && R <= ED_NW && !per_record && b.cigar_off)
+    // (the window lanes address the packed reference by 32-bit byte offsets: 2 x 4 G bases; beyond that the lane-per-record kernel)
+    const bool rows_ok = !b.seq_off && R >= 1 && R <= ED_NW && !per_record && 2 * (uint64_t)(st.ref_bases_odd - st.ref_bases) + 256 < (1ull << 32);
+    if (rows_ok && b.cigar_off)
         hipLaunchKernelGGL(k_edits_rows<true>, dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, 65536u / R + 1u, defer_bits);
-    else if (!b.seq_off && R >= 1 && R <= ED_NW && !per_record && b.cigar_stride >= 1)
+    else if (rows_ok && b.cigar_stride >= 1)
         hipLaunchKernelGGL(k_edits_rows<false>, dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, 65536u / R + 1u, defer_bits);
     else
         hipLaunchKernelGGL(k_edits, dim3((uint32_t)g), dim3(ED_THREADS), 0, s, st, b, defer_bits);

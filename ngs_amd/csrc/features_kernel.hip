@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                 flag[r] = b.flag[idx[r]];
                 ref[r] = b.ref_id[idx[r]];
                 pos[r] = b.pos[idx[r]];
-                n_ops[r] = b.n_cigar[idx[r]];
+                n_ops[r] = batch_n_ops(b, idx[r]);
                 c0[r] = b.cigar_off ? b.cigar_off[idx[r]] : idx[r] * b.cigar_stride;
             }
 #pragma unroll

@@ -302,11 +302,14 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             }
             if ((a.do_general || a.do_cov) && live) {
                 // ---- CIGAR walk: op tallies (general.rs:103-121) and the alignment span
-                const uint32_t n_ops = ncig[j];
+                uint32_t n_ops = ncig[j];
                 const uint32_t r1 = (f >> 6) & 1u; // first segment -> "read one"
                 uint64_t span = 0;
                 uint64_t cbase = (r0 + j) * (uint64_t)b.cigar_stride;
-                if (CIG_OFF) cbase = b.cigar_off[r0 + j];
+                if (CIG_OFF) {
+                    cbase = b.cigar_off[r0 + j];
+                    if (n_ops == 0xFFFFu) n_ops = (uint32_t)(b.cigar_off[r0 + j + 1] - cbase); // (65535 = "or more": include/ngsq.h)
+                }
                 for (uint32_t k = 0; k < n_ops; k++) {
                     const uint32_t cg = (cigar_vec && k == 0) ? cig1[j] : b.cigar[cbase + k];
                     const uint32_t op = cg & 0xFu, len = cg >> 4;

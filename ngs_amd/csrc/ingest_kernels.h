@@ -125,7 +125,7 @@ enum RecWork : uint32_t { W_BAD = 0, W_MAXL, W_MAXOPS, W_SUML, W_FIRST, W_LAST, 
 enum RecHost : uint32_t { H_MAXL = 0, H_MAXOPS, H_SUML, H_FIRST, H_LAST, H_LONG, H_SUMOPS, H_BAD, REC_HOST_WORDS = 8 };
 inline void rec_work_init(unsigned long long *w) {
     for (uint32_t k = 0; k < REC_WORK_WORDS; k++) w[k] = 0;
-    w[W_BAD] = w[W_LONG] = ~0ull;
+    w[W_BAD] = ~0ull;
 }
 hipError_t launch_rec_fixed(const uint8_t *raw, const uint64_t *rec_off, uint64_t n, const RecColumns &c, uint64_t *var_base,
                             unsigned long long *work, unsigned long long *host, const RecOrigin &org, uint64_t *cig_len, hipStream_t s);

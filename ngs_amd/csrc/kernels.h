@@ -122,7 +122,17 @@ struct DeviceBatch {
     const uint64_t *cigar_off;
     uint32_t seq_stride, qual_stride, cigar_stride;
     const uint64_t *record_id; // null: first_record_index + i
+    uint64_t qual_bytes;       // bytes of the qual column as the batch states them (ngsq_batch.qual_bytes; host batches: qual_off[n])
 };
+
+// a record's number of CIGAR operations: the 16-bit column says 65535 for "that many or more, look at the offsets" (include/ngsq.h)
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t batch_n_ops(const DeviceBatch &b, uint64_t i) {
+    uint32_t n = b.n_cigar[i];
+    if (n == 0xFFFFu && b.cigar_off) n = (uint32_t)(b.cigar_off[i + 1] - b.cigar_off[i]);
+    return n;
+}
+#endif
 
 struct LaunchInfo {
     int n_cu; // compute units of the device

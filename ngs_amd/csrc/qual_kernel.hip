@@ -205,6 +205,7 @@ __device__ __forceinline__ uint32_t qr_wave_inclusive_sum(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31
     return v;
 }
+constexpr uint32_t QR_TRASH = QUAL_BINS; // the score the bytes behind a record's end are given: a row of the table nobody reads
 __device__ __forceinline__ uint32_t qr_from_lane(uint32_t v, uint32_t src_lane) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
@@ -215,16 +216,26 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
     NGSQ_FOREGROUND_WAVE();
     constexpr uint32_t RP = qw_rp(R), CP = qw_cp(R), CP4 = CP * 4, RP4 = RP * 4;
     constexpr uint32_t S4 = 4u * RP4;
-    extern __shared__ uint32_t s_q[]; // QUAL_BINS x CP words: the only LDS object
-    constexpr uint32_t nb = QUAL_BINS * CP;
+    extern __shared__ uint32_t s_q[]; // (QUAL_BINS + 1) x CP words (the last row: QR_TRASH, never flushed): the only LDS object
+    constexpr uint32_t nb = (QUAL_BINS + 1) * CP;
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_q[i] = 0;
-    __syncthreads();
     char *const tab = reinterpret_cast<char *>(s_q);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint8_t *const map = reinterpret_cast<uint8_t *>(s_q + nb) + wave * (64u * R); // window -> record lane, this wave's
+    // keep[n] (n = 0..16): 0xFF in the first n bytes of a 16-byte window -- the bytes of a window that belong to its record
+    uint4 *const keep_tab = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(s_q + nb) + 16u * 64u * R);
+    if (threadIdx.x <= 16u) {
+        uint32_t k[4];
+        for (uint32_t d = 0; d < 4; d++) {
+            const uint32_t nvd = threadIdx.x > 4u * d ? min(threadIdx.x - 4u * d, 4u) : 0u;
+            k[d] = nvd >= 4u ? 0xFFFFFFFFu : (1u << (8u * nvd)) - 1u;
+        }
+        keep_tab[threadIdx.x] = make_uint4(k[0], k[1], k[2], k[3]);
+    }
+    __syncthreads();
     const uint64_t per = (n_rec + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = min(per * blockIdx.x, n_rec), hi = min(lo + per, n_rec);
-    const uint64_t end_bytes = n_rec ? qual_off[n_rec] : 0; // a 16-byte load must not run past this
+    const uint64_t end_bytes = n_rec ? qual_off[n_rec] : 0; // a 16-byte load must not run past this (>= 16: launch_qual_ragged)
     uint32_t bad = 0, too_long = 0;
 
     // offsets of a wave's 64 records, loaded one group ahead (branch-free: past the end the last entry twice)
@@ -248,15 +259,19 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
             len = (uint32_t)min(l64, (uint64_t)st.max_read_len);
             too_long += l64 > st.max_read_len; // quality_scores.rs: the table is sized for max_read_len
         }
-        // pass A: the whole 16-byte windows of the 64 records, 64 consecutive windows per step
-        const uint32_t nwin = len >> 4;
-        const uint32_t P = qr_wave_inclusive_sum(nwin); // whole windows of records 0..lane
+        // Every 16-byte window of the 64 records, the last, partial one of a record included, 64 consecutive windows per
+        // step.  (Until round 4 the partial windows were a second pass over the 64 records: by then the lines that hold them
+        // -- three lines in four of the records' bytes -- had left the L2, a block's waves having 180 KB in flight per CU:
+        // TCC_EA0_RDREQ said 1.39 x the bytes, the kernel ran at HBM's rate on 0.50 of its algorithmic bytes.)
+        const uint32_t nwin = (len + 15u) >> 4;
+        const uint32_t P = qr_wave_inclusive_sum(nwin); // windows of records 0..lane
         const uint32_t T = __builtin_amdgcn_readlane(P, 63);
         // byte offsets relative to the wave's first record (64 records of at most 16 R bytes: 32 bits)
         const uint64_t off0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
         const uint32_t rel = rec < hi ? (uint32_t)(off - off0) : 0u;
         const uint32_t first_win = P - nwin;
+        const uint32_t fw_len = first_win | len << 16; // first window (< 64 R <= 1280) and length (<= 16 R) of the record, fetched together
         for (uint32_t j = 0; __ballot(j < nwin); j++) // nwin <= R
             if (j < nwin) map[first_win + j] = (uint8_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -264,18 +279,29 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
         // the window of the NEXT step is in flight while this one is tallied (every lane loads: an idle lane
         // re-reads the first window of the step, which is inside the buffer)
         struct Sched {
-            uint32_t r, w;
+            uint32_t r, w, nv, sh; // record lane, window of the record, its bytes that count, bytes the load was moved back by
             bool active;
             uint4 v;
         };
+        // Addresses as 32-bit offsets from a wave-uniform base g0 <= every address of the group.  The partial window of the
+        // buffer's last record would end behind the buffer: the 16 bytes that END with the buffer are read instead
+        // (offset `lim`) and shifted when used.
+        const uint64_t g0 = min(off0, end_bytes - 16);
+        const uint32_t delta = (uint32_t)(off0 - g0), lim = (uint32_t)min(end_bytes - 16 - g0, (uint64_t)0xFFFFFFFFu);
+        const uint8_t *const gbase = qual + g0;
         auto fetch = [&](uint32_t t0) -> Sched {
             Sched sc;
             const uint32_t t = t0 + lane;
             sc.active = t < T;
-            sc.r = sc.active ? map[t] : map[t0 < T ? t0 : 0u]; // record of window t
-            sc.w = (sc.active ? t : (t0 < T ? t0 : 0u)) - qr_from_lane(first_win, sc.r);
-            const uint64_t at = off0 + qr_from_lane(rel, sc.r) + 16ull * sc.w;
-            __builtin_memcpy(&sc.v, qual + at, 16); // a whole window of a record: inside the buffer
+            const uint32_t tt = sc.active ? t : (t0 < T ? t0 : 0u);
+            sc.r = map[tt]; // record of window tt
+            const uint32_t fl = qr_from_lane(fw_len, sc.r);
+            sc.w = tt - (fl & 0xFFFFu);
+            const uint32_t l = fl >> 16;
+            sc.nv = sc.w == (l >> 4) ? (l & 15u) : 16u;
+            const uint32_t at = qr_from_lane(rel, sc.r) + 16u * sc.w + delta, at_c = min(at, lim);
+            sc.sh = at - at_c;
+            __builtin_memcpy(&sc.v, gbase + at_c, 16);
             return sc;
         };
         Sched nx{};
@@ -284,14 +310,30 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
             const Sched cu = nx;
             nx = fetch(t0 + 64 < T ? t0 + 64 : t0); // past the end: a re-read
             const bool active = cu.active;
-            const uint32_t r = cu.r, w = cu.w;
+            const uint32_t r = cu.r, w = cu.w, nv = cu.nv;
             if (!active) continue;
-            constexpr uint32_t nvalid = 16u;
-            const uint32_t ww[4] = {cu.v.x, cu.v.y, cu.v.z, cu.v.w};
-            const uint32_t any = (ww[0] | ww[1] | ww[2] | ww[3]) & 0xC0C0C0C0u;
+            uint32_t ww[4] = {cu.v.x, cu.v.y, cu.v.z, cu.v.w};
+            if (__builtin_expect(cu.sh != 0u, 0)) { // (one or two windows per launch)
+                u64 l64 = (u64)ww[1] << 32 | ww[0], h64 = (u64)ww[3] << 32 | ww[2];
+                const uint32_t sb = 8u * cu.sh;
+                if (sb >= 64u) {
+                    l64 = h64 >> (sb - 64u);
+                    h64 = 0;
+                } else {
+                    l64 = l64 >> sb | h64 << (64u - sb);
+                    h64 >>= sb;
+                }
+                ww[0] = (uint32_t)l64, ww[1] = (uint32_t)(l64 >> 32), ww[2] = (uint32_t)h64, ww[3] = (uint32_t)(h64 >> 32);
+            }
+            // bytes behind the record's end (they are the next record's) count in the trash row
+            const uint4 kp = keep_tab[nv];
+            const uint32_t keep[4] = {kp.x, kp.y, kp.z, kp.w};
+            const uint32_t any = ((ww[0] & keep[0]) | (ww[1] & keep[1]) | (ww[2] & keep[2]) | (ww[3] & keep[3])) & 0xC0C0C0C0u;
             if (__builtin_expect(any == 0u, 1)) {
                 const uint32_t wbase = 4u * w, rot = r & 3u;
                 uint32_t x[4], bd[4];
+#pragma unroll
+                for (uint32_t d = 0; d < 4; d++) ww[d] = (ww[d] & keep[d]) | (~keep[d] & (QR_TRASH * 0x01010101u)); // (v_bfi_b32)
                 if (NROT == 1) {
 #pragma unroll
                     for (uint32_t d = 0; d < 4; d++) {
@@ -322,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
                 }
             } else {
                 // every byte is a score in this layout: 94..255 are decode errors
-                for (uint32_t j = 0; j < nvalid; j++) {
+                for (uint32_t j = 0; j < nv; j++) {
                     const uint32_t q = (ww[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                     if (q <= NGSQ_MAX_SCORE)
                         atomicAdd(reinterpret_cast<uint32_t *>(tab + q * CP4 + 4u * w + j * RP4), 1u);
@@ -333,27 +375,6 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the map is rewritten for the next 64 records
         __builtin_amdgcn_wave_barrier();
-        // pass B: the last, partial window of every record (lane = record): all lanes walk their bytes
-        // together instead of a few lanes of every step above
-        const uint32_t tail = len & 15u, wl = len >> 4;
-        if (tail) {
-            const uint64_t at = off + 16ull * wl;
-            uint32_t ww[4] = {0, 0, 0, 0};
-            if (at + 16 <= end_bytes) {
-                uint4 v;
-                __builtin_memcpy(&v, qual + at, 16); // the bytes behind the record are the next record's: ignored
-                ww[0] = v.x, ww[1] = v.y, ww[2] = v.z, ww[3] = v.w;
-            } else {
-                for (uint32_t k = 0; k < tail; k++) ww[k >> 2] |= (uint32_t)qual[at + k] << (8 * (k & 3));
-            }
-            for (uint32_t j = 0; j < tail; j++) {
-                const uint32_t q = (ww[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                if (q <= NGSQ_MAX_SCORE)
-                    atomicAdd(reinterpret_cast<uint32_t *>(tab + q * CP4 + 4u * wl + j * RP4), 1u);
-                else
-                    bad += 1;
-            }
-        }
     }
     __syncthreads();
     // flush the cells of real cycles: cycle c = 16 w + kb < max_read_len
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
 
 template <uint32_t R>
 static hipError_t launch_ragged_r(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
-    const uint32_t lds = qual_window_lds_bytes(R) + 16u * 64u * R; // table + one window->record byte map per wave
+    const uint32_t lds = qual_window_lds_bytes(R) + qw_cp(R) * 4u + 16u * 64u * R + 17u * 16u; // table + trash row + one window->record byte map per wave + the keep masks
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_ragged<R, 4>),
@@ -392,7 +413,8 @@ static hipError_t launch_ragged_r(const LaunchInfo &li, const DeviceState &st, c
 }
 
 bool qual_ragged_supported(const DeviceState &st, const DeviceBatch &b) {
-    return b.qual_off != nullptr && st.max_read_len <= 16 * QUAL_WIN_MAX_R;
+    // (fewer than 16 bytes of qualities in the whole batch: the general kernel -- k_qual_ragged reads 16 bytes at a time)
+    return b.qual_off != nullptr && st.max_read_len <= 16 * QUAL_WIN_MAX_R && b.qual_bytes >= 16;
 }
 
 hipError_t launch_qual_ragged(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {

@@ -744,6 +744,7 @@ static int fetch_record(const ngsq_batch *b, uint64_t i, orc_record *r) {
         r->n_qual = 0;
     }
     r->n_cigar = b->n_cigar ? b->n_cigar[i] : 0;
+    if (b->cigar_off) r->n_cigar = (uint32_t)(b->cigar_off[i + 1] - b->cigar_off[i]); /* [N10]: the 16-bit column saturates, the offsets hold the count */
     r->cigar = b->cigar ? b->cigar + (b->cigar_off ? b->cigar_off[i] : i * (uint64_t)b->cigar_stride)
                         : NULL;
     r->index = b->record_id ? b->record_id[i] : b->first_record_index + i; /* include/ngsq.h: the record's identity */

@@ -54,12 +54,14 @@
  *      [N10] a CIGAR of more than 65535 operations (SAM specification 4.2.2): the BAM record
  *            holds the placeholder <l_seq>S<reference span>N and the real operations in a CG:B,I
  *            tag, which noodles-bam resolves while decoding the record (as far as can be told
- *            without its source: the crate gained this in its 0.1x releases).  The facets would
- *            then see the real CIGAR.  This build's batch ABI counts a record's operations in 16
- *            bits, so its readers REFUSE such a record by name (NGSQ_ERR_UNSUPPORTED) rather than
- *            scan the placeholder as if it were the alignment: a limit, not a result
- *            (tests/golden/hand_longcigar.bam).  Aux tags are otherwise skipped unread: no facet
- *            looks at them.
+ *            without its source: the crate gained this in its 0.1x releases).  The facets then
+ *            see the real CIGAR (general.rs:103-121 tallies its operations, coverage.rs:159-160
+ *            its span, edits.rs walks it), and so does this restatement: the readers of
+ *            ngsq_bam.h hand the tag's operations on (the batch's n_cigar column is 16 bits wide
+ *            and saturates at 65535; the count of such a record is in cigar_off, which is what
+ *            orc_view_record uses whenever a batch has offsets).  The placeholder WITHOUT a tag
+ *            is an alignment like any other.  tests/golden/hand_longcigar.bam: expectations
+ *            worked by hand.  Aux tags are otherwise skipped unread: no facet looks at them.
  *     The hand goldens and the synthetic workloads stay away from the corner cases
  *     of [N4] and [N5] (span 0, start beyond L) except where a test names them.
  */

@@ -47,6 +47,9 @@ def record_bytes(hb, i: int, name: bytes = b"r", aux: bytes = b"", full_name: by
     nm = (full_name if full_name is not None else name + b"%d" % i) + b"\0"
     pos = int(c["pos"][i])
     span = sum(int(x) >> 4 for x in cig if (int(x) & 15) in (0, 2, 3, 7, 8))
+    if len(cig) > 65535:   # SAM specification 4.2.2: the placeholder <l_seq>S<span>N in the CIGAR field, the operations in a CG:B,I tag
+        aux = aux + aux_array(b"CG", b"I", np.asarray(cig, dtype="<u4").tobytes())
+        cig = [(l << 4) | 4, (span << 4) | 3]
     bin_ = reg2bin(pos, pos + max(span, 1)) if pos >= 0 else 4680   # (reg2bin(-1, 0), SAM specification 4.2.1)
     body = struct.pack("<iiBBHHHIiii", int(c["ref_id"][i]), pos, len(nm), int(c["mapq"][i]), bin_, len(cig),
                        int(c["flag"][i]), l, int(c["mate_ref_id"][i]), -1, int(c["tlen"][i]))

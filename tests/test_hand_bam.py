@@ -91,14 +91,113 @@ def test_oracle_on_the_hand_assembled_records(lib, oracle_mod):
     assert doc["coverage"]["mean_coverage_per_bin"]["chr2"][11] == 1.0 and doc["coverage"]["mean_coverage_per_bin"]["chr2"][131] == 0.0
 
 
-def test_long_cigar_placeholder_is_refused_by_name(lib):
-    """[N10] (oracle/oracle.h): the real CIGAR of the record is in its CG tag; scanning the placeholder would be a wrong answer."""
-    h = C.c_void_p()
-    assert lib.ngsq_bam_open(LONG.encode(), 1, C.byref(h)) == 0
-    b = ffi.Batch()
-    assert lib.ngsq_bam_next_batch(h, 10, C.byref(b)) == ffi.ERR_UNSUPPORTED
-    assert b"CIGAR of more than 65535 operations" in lib.ngsq_bam_last_error()
-    lib.ngsq_bam_close(h)
+# hand_longcigar.bam (make_hand_bam.py): ONE record, flag 0, chr1 pos 1000 (0-based), 30 bases "ACGTAC" x 5, CIGAR field
+# "30S35N" = the long-CIGAR placeholder, real operations 10M5D20M in its CG:B,I tag (SAM specification 4.2.2; three operations
+# stand in for "more than 65535").  What the facets must see, worked by hand from the reference's source:
+#   General (general.rs:103-121): not first segment -> read_two_cigar_ops {M: 2, D: 1}  (the placeholder would say {S: 1, N: 1})
+#   Coverage (coverage.rs:159-180): span 10 + 5 + 20 = 35 -> positions 1001..1035 (1-based, as the per-position vectors are indexed) at depth 1, 1000 and 1036 at 0
+#   Edits (edits.rs:276-291) against a reference of all A: read bases 0..9 under the first M, 10..29 under the second;
+#         "ACGTAC" x 5 has A at indices 0, 4 (mod 6): of the 30 compared bases 10 are A -> 20 edits; the five deleted
+#         positions 1011..1015 are compared with nothing (refs + alts = 0 there)
+LONG_EXPECT = {"read_two": {"M": 2, "D": 1}, "depth": {1000: 0, 1001: 1, 1010: 1, 1013: 1, 1035: 1, 1036: 0}, "edits": 20}
+
+
+def _check_long_cigar(doc):
+    assert doc["general"]["cigar"]["read_two_cigar_ops"] == LONG_EXPECT["read_two"] and doc["general"]["cigar"]["read_one_cigar_ops"] == {}
+    depth = doc["coverage"]["mean_coverage_per_bin"]["chr1"]   # (bins of one position)
+    for p, dep in LONG_EXPECT["depth"].items():
+        assert depth[p] == float(dep), p
+    if doc.get("edits"):
+        assert doc["edits"]["read_two_edits"]["values"][LONG_EXPECT["edits"]] == 1 and sum(doc["edits"]["read_two_edits"]["values"]) == 1
+        assert sum(doc["edits"]["vaf_histogram"]["values"]) == 30     # thirty compared positions, none of the deleted ones
+
+
+def _long_cigar_context(lib_or_oracle, make):
+    ref_len = [100_000, 5_000]
+    bases = [np.full(L, 1, dtype=np.uint8) for L in ref_len]   # all A
+    return make(ref_len, facets=ffi.FACETS_DEFAULT | ffi.FACET_EDITS, bin_size=1, max_read_len=64, ref_bases=bases), ref_len
+
+
+def test_long_cigar_is_resolved_from_the_cg_tag(lib, oracle_mod):
+    """[N10] (oracle/oracle.h): noodles hands the facets the operations of the CG tag, not the placeholder.  Host reader ->
+    oracle against numbers worked by hand (above)."""
+    _, batches, n = read_all(lib, LONG, 10)
+    assert n == 1
+    hb = batches[0]
+    assert int(hb.cols["n_cigar"][0]) == 3 and hb.cols["cigar_off"] is not None
+    assert [int(x) for x in hb.cols["cigar"][:3]] == [10 << 4 | 0, 5 << 4 | 2, 20 << 4 | 0]
+    orc, _ = _long_cigar_context(None, lambda rl, **kw: oracle_mod.Oracle(rl, **kw))
+    orc.process_batch(hb)
+    orc.finalize()
+    _check_long_cigar(orc.results(["chr1", "chr2"]))
+
+
+@pytest.mark.gpu
+def test_long_cigar_on_the_device(gpu_lib, oracle_mod, tmp_path):
+    """The device reader finds the tag too (k_rec_fixed), the kernels take the count from the offsets, and the facets arrive at
+    the hand-worked numbers."""
+    from tests.test_device_ingest_gpu import read_all_device, same_batches
+    with host.QcContext([100_000, 5_000], lib=gpu_lib) as ctx:
+        got, n = read_all_device(gpu_lib, ctx, LONG, 10)
+        _, want, _ = read_all(gpu_lib, LONG, 10)
+        assert n == 1 and read_all_device.last_stats["long_cigar_records"] == 1
+        same_batches(got, want)
+    _, batches, _ = read_all(gpu_lib, LONG, 10)
+    gpu, _ = _long_cigar_context(None, lambda rl, **kw: host.QcContext(rl, lib=gpu_lib, **kw))
+    gpu.process_batch(batches[0])
+    gpu.finalize()
+    _check_long_cigar(gpu.results(["chr1", "chr2"]))
+    gpu.close()
+
+
+def _seventy_thousand_ops(lib, tmp_path):
+    """More operations than the 16-bit field counts, for real: 35 000 x (1M 1I) between ordinary records.  The test writer
+    stores it as the specification says (placeholder + CG tag)."""
+    from tests import bamio
+    from tests.util import batch_from_records
+    big = "1M1I" * 35_000
+    recs = [dict(flag=0x41 if k % 2 else 0, mapq=30, ref_id=0, pos=500 + 7 * k, mate_ref_id=0, tlen=0, cigar=big if k == 3 else "40M",
+                 seq=("ACGT" * 17_500) if k == 3 else "ACGT" * 10, qual=[20] * (70_000 if k == 3 else 40)) for k in range(8)]
+    p = str(tmp_path / "big.bam")
+    bamio.write_bam(p, batch_from_records(recs), ["chr1"], [200_000])
+    _, hbatches, n = read_all(lib, p, 100)
+    assert n == 8 and int(hbatches[0].cols["n_cigar"][3]) == 65535                  # saturated (include/ngsq.h, ABI 5)
+    off = hbatches[0].cols["cigar_off"]
+    assert int(off[4] - off[3]) == 70_000 and int(off[3] - off[2]) == 1            # the offsets say how many
+    assert np.array_equal(hbatches[0].cols["cigar"][int(off[3]):int(off[4])], np.tile(np.array([16, 17], dtype=np.uint32), 35_000))
+    return p, hbatches
+
+
+def test_a_cigar_of_seventy_thousand_operations_host_reader(lib, oracle_mod, tmp_path):
+    _, hbatches = _seventy_thousand_ops(lib, tmp_path)
+    o = oracle_mod.Oracle([200_000], facets=ffi.FACETS_DEFAULT, bin_size=1000, max_read_len=128)
+    o.process_batch(hbatches[0])
+    o.finalize(allow_malformed=True)
+    g = o.general()
+    assert g["read_one_cigar_ops"][0] + g["read_two_cigar_ops"][0] == 35_000 + 7 and g["read_one_cigar_ops"][1] + g["read_two_cigar_ops"][1] == 35_000
+
+
+@pytest.mark.gpu
+def test_a_cigar_of_seventy_thousand_operations(gpu_lib, oracle_mod, tmp_path):
+    """Both readers resolve it; n_cigar says 65535 and the offsets 70 000; every facet kernel agrees with the oracle."""
+    from tests.test_device_ingest_gpu import read_all_device, same_batches
+    from tests.util import compare_contexts, json_equal
+    p, hbatches = _seventy_thousand_ops(gpu_lib, tmp_path)
+    with host.QcContext([200_000], lib=gpu_lib) as ctx:
+        dbatches, dn = read_all_device(gpu_lib, ctx, p, 100)
+        assert dn == 8 and read_all_device.last_stats["long_cigar_records"] == 1
+        same_batches(dbatches, hbatches)
+    ref_len = [200_000]
+    bases = [np.tile(np.array([1, 2, 4, 8], dtype=np.uint8), 50_000)]
+    kw = dict(facets=ffi.FACETS_DEFAULT | ffi.FACET_EDITS, bin_size=1000, max_read_len=128, ref_bases=bases, gc_seed=3)
+    orc = oracle_mod.Oracle(ref_len, **kw)
+    gpu = host.QcContext(ref_len, lib=gpu_lib, **kw)
+    for c in (orc, gpu):
+        c.process_batch(hbatches[0])
+    assert orc.finalize(allow_malformed=True) == gpu.finalize(allow_malformed=True)
+    compare_contexts(gpu, orc, 1, kw["facets"], kw["bin_size"], ref_len)
+    json_equal(gpu.results(["chr1"]), orc.results(["chr1"]))
+    gpu.close()
 
 
 @pytest.mark.gpu
@@ -113,8 +212,10 @@ def test_device_reader_on_hand_assembled_bytes(gpu_lib, monkeypatch, raw_mb):
             got, n2 = read_all_device(gpu_lib, ctx, BAM, max_records)
             assert n2 == n
             same_batches(got, want)
-        with pytest.raises(RuntimeError, match="CIGAR of more than 65535 operations"):
-            read_all_device(gpu_lib, ctx, LONG, 10)
+        _, want, _ = read_all(gpu_lib, LONG, 10)      # the long-CIGAR convention, resolved by both (ABI 5)
+        got, n2 = read_all_device(gpu_lib, ctx, LONG, 10)
+        assert n2 == 1
+        same_batches(got, want)
 
 
 @pytest.mark.gpu

@@ -412,10 +412,14 @@ def _stall_worker(rank, world, port, q, lib_path):
         comm.barrier()
         comm.destroy()
         q.put((rank, "ok"))
-        os._exit(0)     # a thread of this process is still inside the stalled ncclCommInitRank
+        q.close()
+        q.join_thread()     # (the message is on its way before ...)
+        os._exit(0)         # ... a thread of this process is still inside the stalled ncclCommInitRank
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, "FAIL " + traceback.format_exc()))
+        q.close()
+        q.join_thread()
         os._exit(1)
 
 

@@ -50,7 +50,7 @@ def batch_from_records(records: Sequence[dict], first_record_index: int = 0) -> 
     }
     cig = [parse_cigar(r.get("cigar", "*")) if isinstance(r.get("cigar", "*"), str) else list(r["cigar"])
            for r in records]
-    cols["n_cigar"] = np.array([len(c) for c in cig], dtype=np.uint16)
+    cols["n_cigar"] = np.array([min(len(c), 65535) for c in cig], dtype=np.uint16)  # saturates (include/ngsq.h); the offsets say the rest
     seqs = [pack_seq(r.get("seq", "")) for r in records]
     quals = [np.array(r["qual"], dtype=np.uint8) if r.get("qual") is not None else np.zeros(0, np.uint8)
              for r in records]

@@ -4,16 +4,16 @@
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md, rocprofv3 PMC slots)
 # and summarise them into gpurun_out/<prefix>_*  (copy what is to be judged into profiles/).   usage: bash tools/profile_round.sh r02
 set -u
-P=${1:-r03}
+P=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$P
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-LEGS="--cpu-sample 0 --h2d-batch 0 --file-records 0 --extra-facet-legs 0"
+LEGS="--cpu-sample 0 --h2d-batch 0 --file-records 0 --extra-facet-legs 0 --mixed-records 0"
 rocprofv3 --kernel-trace --stats -d $O/stats -o out --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 $LEGS > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/mixed -o out --output-format csv -- python3 $R/bench.py --workload mixed --steps 20 --warmup 3 --cpu-sample 0 > $O/mixed.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/extra -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 > $O/extra.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/file -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --extra-facet-legs 0 --file-records 24000000 > $O/file.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/extra -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 --mixed-records 0 > $O/extra.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/file -o out --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --extra-facet-legs 0 --mixed-records 0 --file-records 24000000 --file-realistic-records 24000000 > $O/file.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o out --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-timing $LEGS > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o out --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-timing $LEGS > $O/write.log 2>&1
 # the same two PMC passes for the offsets-layout quality kernel (--workload mixed) and for the device inflate (tools/bench_inflate.py:
