@@ -248,6 +248,7 @@ struct DeviceIngest {
     int inflate_ahead = 2, inflate_streams = 2;    // inflates queued beyond the chunk being parsed; streams they alternate between (NGSQ_INFLATE_AHEAD, NGSQ_INFLATE_STREAMS: A/B measurements)
     DevBuf<uint8_t> d_rawb[NR];
     hipStream_t inf_stream[2] = {nullptr, nullptr};
+    bool inf_low_priority = true;
     hipEvent_t raw_free[NR] = {nullptr, nullptr, nullptr};
     bool raw_free_set[NR] = {false, false, false};
     uint8_t *raw = nullptr; // the inflated bytes being indexed / cut into batches: d_raw (sharded mode) or a view into a raw buffer
@@ -299,23 +300,20 @@ struct DeviceIngest {
         cv.notify_all();
         if (reader.joinable()) reader.join();
         if (f) fclose(f);
+        if (ctx) (void)hipSetDevice(ctx->device); // (the cache is per device)
         if (copy_stream) {
             (void)hipStreamSynchronize(copy_stream);
-            (void)hipStreamDestroy(copy_stream);
+            pool_stream_put(false, copy_stream);
         }
         for (auto &q : inf_stream)
             if (q) {
                 (void)hipStreamSynchronize(q);
-                (void)hipStreamDestroy(q);
+                pool_stream_put(inf_low_priority, q);
             }
-        for (auto &e : h2d_done)
-            if (e) (void)hipEventDestroy(e);
-        for (auto &e : inf_done)
-            if (e) (void)hipEventDestroy(e);
-        for (auto &e : raw_free)
-            if (e) (void)hipEventDestroy(e);
-        for (auto &e : retired_ev)
-            if (e) (void)hipEventDestroy(e);
+        for (auto &e : h2d_done) pool_event_put(e);
+        for (auto &e : inf_done) pool_event_put(e);
+        for (auto &e : raw_free) pool_event_put(e);
+        for (auto &e : retired_ev) pool_event_put(e);
         for (auto &c : hc)
             if (c.h) pool_pinned_free(c.h, c.h_bytes);
 
@@ -1148,19 +1146,19 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
     d->raw_cap = env_mb("NGSQ_INGEST_RAW_MB", dflt_mb);
     d->comp_chunk = std::max<size_t>(d->raw_cap / 4, (size_t)1 << 17);
     // (the two pinned buffers are allocated by the reader thread, on the device's NUMA node)
-    BHIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    // (streams and events come from the process's cache when an earlier ingest left them there: mem_pool.h)
+    BHIP(ngsq::pool_stream_get(false, &d->copy_stream));
     {   // the inflate of the NEXT chunk runs beside the parse and the scan of this one, and it takes every
         // wave slot its LDS allows: give it the lowest priority so that the short kernels of the context's stream get
         // the slots its decoders free, instead of queueing behind all of them
-        int lo = 0, hi = 0;
-        BHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char *e = getenv("NGSQ_INFLATE_PRIORITY");
-        for (auto &q : d->inf_stream) BHIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, e && atoi(e) == 0 ? 0 : lo)); // =0: normal priority (A/B measurements)
+        d->inf_low_priority = !(e && atoi(e) == 0); // =0: normal priority (A/B measurements)
+        for (auto &q : d->inf_stream) BHIP(ngsq::pool_stream_get(d->inf_low_priority, &q));
     }
-    for (auto &e : d->h2d_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : d->inf_done) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : d->raw_free) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : d->retired_ev) BHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : d->h2d_done) BHIP(ngsq::pool_event_get(&e));
+    for (auto &e : d->inf_done) BHIP(ngsq::pool_event_get(&e));
+    for (auto &e : d->raw_free) BHIP(ngsq::pool_event_get(&e));
+    for (auto &e : d->retired_ev) BHIP(ngsq::pool_event_get(&e));
     if (const char *e = getenv("NGSQ_INFLATE_AHEAD")) d->inflate_ahead = std::max(1, std::min(2, atoi(e)));
     if (const char *e = getenv("NGSQ_INFLATE_STREAMS")) d->inflate_streams = std::max(1, std::min(2, atoi(e)));
     // the reader starts pinning and reading at once; the two raw buffers are allocated meanwhile

@@ -476,6 +476,43 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
         for (uint32_t pass = 0; pass < EDR_PASSES; pass++) {
             const uint64_t r0 = w0 + (uint64_t)pass * 64;
             if (r0 >= n) break;
+            // ---- 2a. (ahead of 1: it does not depend on it) lane = window g = 64 k + lane of the pass's rows (record g / R, window
+            // g % R): the 16 bytes of sequence of the first two windows are requested before the records' descriptors are worked out
+            const uint8_t *const rows = b.seq + r0 * stride;
+            const uint32_t last = (uint32_t)min(n - 1 - r0, (uint64_t)63); // rows of the pass that exist
+            struct Win {
+                uint4 sv, rv;
+                uint32_t slot, ww, x0, lohi; // record slot, window of the row, window entry of base 0 of the window, compared bases lo | hi << 8 (none: lo >= hi)
+            };
+            // window g = 64 k + lane is window ww of row rr at byte `off` of the pass's rows: stepped from k to k + 1 without a division
+            uint32_t w_rr = (lane * recip) >> 16, w_ww = lane - w_rr * R, w_off = w_rr * stride + 16 * w_ww;
+            const uint32_t step_rr = 64 / R, step_ww = 64 - step_rr * R, step_off = step_rr * stride + 16 * step_ww;
+            auto begin_win = [&]() -> Win { // the sequence bytes of window (w_rr, w_ww); then on to the next one
+                Win w;
+                __builtin_memcpy(&w.sv, rows + (w_rr <= last ? w_off : 0u), 16);
+                w.slot = w_rr, w.ww = w_ww;
+                w_rr += step_rr, w_ww += step_ww, w_off += step_off;
+                if (w_ww >= R) w_ww -= R, w_rr += 1, w_off += stride - 16 * R;
+                return w;
+            };
+            // the reference bytes under it, once its record's descriptor is in LDS
+            // (a window without compared bases -- a record that is not on the fast path: descriptor 0; a window behind the read's
+            // end -- reads what lies at its place all the same: inside both buffers, and all of it masked away)
+            auto finish_win = [&](Win &w) {
+                const uint2 d = desc[w.slot];
+                const uint32_t v0 = d.y & 0x1FFu, v1 = (d.y >> 9) & 0x1FFu, b0 = 32 * w.ww;
+                __builtin_memcpy(&w.rv, st.ref_bases + (d.x + 16 * w.ww), 16);
+                w.x0 = (d.y >> 18) + b0;
+                const uint32_t lo = min(v0 > b0 ? v0 - b0 : 0u, 32u), hi = min(v1 > b0 ? v1 - b0 : 0u, 32u);
+                w.lohi = lo | hi << 8;
+            };
+            auto load_win = [&]() -> Win {
+                Win w = begin_win();
+                finish_win(w);
+                return w;
+            };
+            Win wa = begin_win(), wb = wa, wc = wa;
+            if (R > 1) wb = begin_win();
             // ---- 1. lane = record
             EdRowCols r = cur;
             if (CIG_OFF) {
@@ -524,35 +561,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
             red[lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // ---- 2. lane = window g = 64 k + lane of the pass's rows (record g / R, window g % R): 16 bytes of sequence, 16 of
-            // the reference (a window without compared bases reads the arrays' first bytes: nothing of it is kept)
-            const uint8_t *const rows = b.seq + r0 * stride;
-            const uint32_t last = (uint32_t)min(n - 1 - r0, (uint64_t)63); // rows of the pass that exist
-            struct Win {
-                uint4 sv, rv;
-                uint32_t slot, x0, lohi; // record slot, window entry of base 0 of the window, compared bases lo | hi << 8 (none: lo >= hi)
-            };
-            // window g = 64 k + lane is window ww of row rr at byte `off` of the pass's rows: stepped from k to k + 1 without a division
-            uint32_t w_rr = (lane * recip) >> 16, w_ww = lane - w_rr * R, w_off = w_rr * stride + 16 * w_ww;
-            const uint32_t step_rr = 64 / R, step_ww = 64 - step_rr * R, step_off = step_rr * stride + 16 * step_ww;
-            auto load_win = [&]() -> Win { // the window (w_rr, w_ww); then on to the next one
-                // (a window without compared bases -- a record that is not on the fast path: descriptor 0; a window behind the
-                // read's end -- reads what lies at its place all the same: inside both buffers, and all of it masked away)
-                const uint2 d = desc[w_rr];
-                const uint32_t v0 = d.y & 0x1FFu, v1 = (d.y >> 9) & 0x1FFu, b0 = 32 * w_ww;
-                const uint8_t *const sp = rows + (w_rr <= last ? w_off : 0u);
-                const uint8_t *const rp = st.ref_bases + (d.x + 16 * w_ww);
-                Win w;
-                __builtin_memcpy(&w.sv, sp, 16);
-                __builtin_memcpy(&w.rv, rp, 16);
-                w.slot = w_rr;
-                w.x0 = (d.y >> 18) + b0;
-                const uint32_t lo = min(v0 > b0 ? v0 - b0 : 0u, 32u), hi = min(v1 > b0 ? v1 - b0 : 0u, 32u);
-                w.lohi = lo | hi << 8;
-                w_rr += step_rr, w_ww += step_ww, w_off += step_off;
-                if (w_ww >= R) w_ww -= R, w_rr += 1, w_off += stride - 16 * R;
-                return w;
-            };
+            // ---- 2b. lane = window: 16 bytes of sequence XOR 16 of the reference
             auto compare_win = [&](const Win &w) {
                 // the mismatching nibbles of the four dwords in one word: bit 4 q + d <-> nibble q of dword d = base 8 d + (q ^ 1) of
                 // the window; the window's compared bases are [lo, hi): two table masks in that bit order
@@ -570,15 +579,21 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
                     }
                 }
             };
-            Win wa = load_win(), wb = wa;
+            // two windows' bytes are in flight while one is compared (three slots used in turn; the kernel's waves are limited
+            // by LDS to four per SIMD, which leaves 128 registers each)
+            finish_win(wa);
+            if (R > 1) finish_win(wb);
             if (pass + 1 < EDR_PASSES) cur = load_cols(r0 + 64); // in flight while this pass is compared
 #pragma unroll 1
-            for (uint32_t k = 0; k < R && EDITS_EXP != 3; k += 2) { // the next window's bytes are in flight while one is compared
-                if (k + 1 < R) wb = load_win();
+            for (uint32_t k = 0; k < R && EDITS_EXP != 3; k += 3) {
+                if (k + 2 < R) wc = load_win();
                 compare_win(wa);
                 if (k + 1 >= R) break;
-                if (k + 2 < R) wa = load_win();
+                if (k + 3 < R) wa = load_win();
                 compare_win(wb);
+                if (k + 2 >= R) break;
+                if (k + 4 < R) wb = load_win();
+                compare_win(wc);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

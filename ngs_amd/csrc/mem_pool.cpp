@@ -30,6 +30,8 @@ struct Pool {
     std::map<const void *, Block> pinned_live; // pinned blocks handed out, by base address
     size_t cached[2] = {0, 0}; // device | pinned
     size_t limit[2]; // device | pinned
+    std::map<int, std::vector<hipStream_t>> streams[2]; // by device: normal | lowest priority
+    std::map<int, std::vector<hipEvent_t>> events;
     Pool() {
         // what one ingest pipeline at its largest chunk size (1 GiB) gives back: two raw buffers + two device buffers for the
         // compressed bytes + a batch's columns and the record index ~ 4.5 GiB of device memory, two pinned buffers = 1 GiB
@@ -172,13 +174,81 @@ hipError_t pool_pinned_h2d(void *dst, const void *block, size_t off, size_t len,
     return hipSuccess;
 }
 
+hipError_t pool_stream_get(bool low_priority, hipStream_t *s) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto &v = pool().streams[low_priority][dev];
+        if (!v.empty()) {
+            *s = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    if (!low_priority) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, lo);
+}
+
+void pool_stream_put(bool low_priority, hipStream_t s) {
+    if (!s) return;
+    int dev = 0;
+    if (pool().limit[0] == 0 || hipGetDevice(&dev) != hipSuccess) {
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    std::lock_guard<std::mutex> g(pool().mu);
+    pool().streams[low_priority][dev].push_back(s);
+}
+
+hipError_t pool_event_get(hipEvent_t *ev) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto &v = pool().events[dev];
+        if (!v.empty()) {
+            *ev = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipEventCreateWithFlags(ev, hipEventDisableTiming);
+}
+
+void pool_event_put(hipEvent_t ev) {
+    if (!ev) return;
+    int dev = 0;
+    if (pool().limit[0] == 0 || hipGetDevice(&dev) != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        return;
+    }
+    std::lock_guard<std::mutex> g(pool().mu);
+    pool().events[dev].push_back(ev);
+}
+
 size_t pool_trim() {
     std::vector<Block> take;
+    std::vector<hipStream_t> ts;
+    std::vector<hipEvent_t> te;
     {
         std::lock_guard<std::mutex> g(pool().mu);
         take.swap(pool().blocks);
         pool().cached[0] = pool().cached[1] = 0;
+        for (auto &m : pool().streams) {
+            for (auto &kv : m) ts.insert(ts.end(), kv.second.begin(), kv.second.end());
+            m.clear();
+        }
+        for (auto &kv : pool().events) te.insert(te.end(), kv.second.begin(), kv.second.end());
+        pool().events.clear();
     }
+    for (hipStream_t q : ts) (void)hipStreamDestroy(q);
+    for (hipEvent_t q : te) (void)hipEventDestroy(q);
     size_t n = 0;
     for (Block &b : take) {
         n += b.bytes;
