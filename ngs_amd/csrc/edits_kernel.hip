@@ -32,7 +32,8 @@ typedef unsigned long long u64;
 namespace {
 
 #ifndef EDITS_EXP
-#define EDITS_EXP 0 // measurement builds only: 1 = no atomics for the mismatches, 2 = no cover (window, flush), 3 = no comparison, 4 = neither 1 nor 2
+#define EDITS_EXP 0 // measurement builds only: 1 = no atomics for the mismatches, 2 = no cover (window, flush), 3 = no comparison, 4 = neither 1 nor 2;
+                    // k_edits_rows: 5 = the cover window is not flushed to global memory, 6 = the alts window is not, 7 = neither
 #endif
 constexpr uint32_t ED_THREADS = 256;
 constexpr uint32_t ED_PASSES = 4;                      // records per thread and tile: lane + 64 * pass of the wave's 256 consecutive records
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t i = ib + 64 * k + lane;
                     if (v[k]) {
-                        atomicAdd(&dst[i], v[k]);
+                        if (EDITS_EXP != 5 && EDITS_EXP != 7) atomicAdd(&dst[i], v[k]);
                         win[i] = 0;
                     }
                 }
@@ -633,8 +634,10 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
                 const uint32_t i = ib + lane;
                 const uint32_t v = i < EDR_ALTW ? altw[i] : 0u;
                 if (v) {
-                    if (v & 0xFFFFu) atomicAdd(&adst[2 * i], v & 0xFFFFu);
-                    if (v >> 16) atomicAdd(&adst[2 * i + 1], v >> 16);
+                    if (EDITS_EXP != 6 && EDITS_EXP != 7) {
+                        if (v & 0xFFFFu) atomicAdd(&adst[2 * i], v & 0xFFFFu);
+                        if (v >> 16) atomicAdd(&adst[2 * i + 1], v >> 16);
+                    }
                     altw[i] = 0;
                 }
             }

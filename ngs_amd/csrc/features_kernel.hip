@@ -88,41 +88,37 @@ __device__ __forceinline__ void tally(uint32_t &counter, bool pred) { counter +=
 
 } // namespace
 
-// A TILE is F_RPT x 256 consecutive records, F_RPT per thread (record r * 256 + thread of the tile: coalesced columns): the
-// barriers, the tile's bounds and the twenty bracket searches -- a few microseconds of latency that most of the block sits
-// out -- are paid once per 1024 records instead of once per 256.
+// A TILE is F_RPT x 64 consecutive records of ONE WAVE, F_RPT per lane (record r * 64 + lane of the tile: coalesced columns).
+// Round 4: until then a tile was a block's (F_RPT x 256 records, three barriers, the tile's bounds through LDS atomics, the
+// twenty bracket searches by twenty threads while 236 waited at a barrier).  A wave does all of it by itself now -- the bounds
+// by cross-lane reductions, the searches by its lanes 0..19, which keep their own previous result in a register as the next
+// tile's hint, the brackets handed to the records' searches as SCALARS (v_readlane: the names are uniform) -- so no wave ever
+// waits for another one's L2 probes, and the kernel has no LDS traffic and no barrier inside its loop.
 #ifndef NGSQ_FEATURES_RPT
 #define NGSQ_FEATURES_RPT 4
 #endif
 constexpr uint32_t F_RPT = NGSQ_FEATURES_RPT;
 __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b, FeatureTables ft) {
     NGSQ_FOREGROUND_WAVE();
-    __shared__ unsigned long long s_key; // (sequence << 32 | smallest query start) of the tile's processed records
-    __shared__ uint32_t s_mm[3];         // largest query start, smallest / largest query end on that sequence
-    __shared__ uint32_t s_br[5][4];      // per name id: brackets of the searches (see the head of this file)
     __shared__ uint32_t s_cnt[11];
-    __shared__ uint32_t s_lo[5];         // per name id: begin of its list on the tile's sequence
-    __shared__ int32_t s_prev_ref;       // the sequence s_br belongs to (-1: none): the next tile's searches start from them
     if (threadIdx.x < 11) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_prev_ref = -1;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // a block takes CONSECUTIVE tiles (of a sorted file: consecutive positions), so that a tile's searches can start from
-    // the previous tile's; whole blocks take part in the barriers and ballots
-    constexpr uint64_t TILE = 256ull * F_RPT;
-    const uint64_t per = ((b.n + gridDim.x - 1) / gridDim.x + TILE - 1) / TILE * TILE;
-    const uint64_t lo_i = (uint64_t)blockIdx.x * per, hi_i = lo_i + per < b.n ? lo_i + per : b.n;
+    // a wave takes CONSECUTIVE tiles (of a sorted file: consecutive positions), so that a tile's searches can start from
+    // the previous tile's
+    constexpr uint64_t TILE = 64ull * F_RPT;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6), wave_id = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t per = ((b.n + n_waves - 1) / n_waves + TILE - 1) / TILE * TILE;
+    const uint64_t lo_i = min(wave_id * per, b.n), hi_i = lo_i + per < b.n ? lo_i + per : b.n;
+    int32_t prev_ref = -1; // the sequence `my_br` belongs to (-1: none)
+    uint32_t my_br = 0;    // lanes 0..19: bracket `lane & 3` of name id `lane >> 2` of the previous tile, relative to the list's begin
+    uint32_t my_lo = 0;    // ... and the begin of that list
     for (uint64_t t0 = lo_i; t0 < hi_i; t0 += TILE) {
-        if (threadIdx.x == 0) {
-            s_key = ~0ull;
-            s_mm[0] = 0;
-            s_mm[1] = 0xFFFFFFFFu;
-            s_mm[2] = 0;
-        }
-        __syncthreads();
         uint32_t qs[F_RPT], qe[F_RPT], what[F_RPT]; // what: 0 nothing (past the end), 1 ignored flags, 2 error: reference, 3 ignored: not primary, 4 error: position, 5 looked up
         int32_t ref[F_RPT];
         {
-            // every column of the tile's records first, unconditionally (a record past the end reads the block's first), then
+            // every column of the tile's records first, unconditionally (a record past the end reads the wave's first), then
             // what depends on them: the loads of a stage are in flight together -- one record after the other, each behind its
             // own branches, the tile waited out a dozen memory latencies here
             uint32_t flag[F_RPT], n_ops[F_RPT], op0[F_RPT];
@@ -131,7 +127,7 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
             uint8_t prim[F_RPT];
 #pragma unroll
             for (uint32_t r = 0; r < F_RPT; r++) {
-                const uint64_t i = t0 + r * 256 + threadIdx.x;
+                const uint64_t i = t0 + r * 64 + lane;
                 idx[r] = i < hi_i ? i : lo_i;
                 flag[r] = b.flag[idx[r]];
                 ref[r] = b.ref_id[idx[r]];
@@ -146,7 +142,7 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
             }
 #pragma unroll
             for (uint32_t r = 0; r < F_RPT; r++) {
-                const uint64_t i = t0 + r * 256 + threadIdx.x;
+                const uint64_t i = t0 + r * 64 + lane;
                 qs[r] = qe[r] = what[r] = 0;
                 if (i >= hi_i) {
                     ref[r] = -1;
@@ -172,60 +168,48 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                 }
             }
         }
-        {   // the tile's first (sequence, start): one LDS atomic per wave -- 256 lanes on one word serialise
-            unsigned long long k = ~0ull;
+        // the tile's first (sequence, start) among the records that are looked up
+        unsigned long long key = ~0ull;
 #pragma unroll
-            for (uint32_t r = 0; r < F_RPT; r++) {
-                const unsigned long long kr = what[r] == 5 ? (unsigned long long)(uint32_t)ref[r] << 32 | qs[r] : ~0ull;
-                k = kr < k ? kr : k;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(k, o, 64);
-                k = other < k ? other : k;
-            }
-            if ((threadIdx.x & 63) == 0 && k != ~0ull) atomicMin(&s_key, k);
+        for (uint32_t r = 0; r < F_RPT; r++) {
+            const unsigned long long kr = what[r] == 5 ? (unsigned long long)(uint32_t)ref[r] << 32 | qs[r] : ~0ull;
+            key = kr < key ? kr : key;
         }
-        __syncthreads();
-        const unsigned long long key = s_key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o, 64);
+            key = other < key ? other : key;
+        }
         const int32_t r0 = key == ~0ull ? -1 : (int32_t)(key >> 32);
-        {
-            uint32_t m0 = 0u, m1 = 0xFFFFFFFFu, m2 = 0u;
+        // on that sequence: largest query start, smallest / largest query end
+        uint32_t m0 = 0u, m1 = 0xFFFFFFFFu, m2 = 0u;
 #pragma unroll
-            for (uint32_t r = 0; r < F_RPT; r++)
-                if (what[r] == 5 && ref[r] == r0) {
-                    m0 = max(m0, qs[r]);
-                    m1 = min(m1, qe[r]);
-                    m2 = max(m2, qe[r]);
-                }
+        for (uint32_t r = 0; r < F_RPT; r++)
+            if (what[r] == 5 && ref[r] == r0) {
+                m0 = max(m0, qs[r]);
+                m1 = min(m1, qe[r]);
+                m2 = max(m2, qe[r]);
+            }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o, 64));
-                m1 = min(m1, (uint32_t)__shfl_xor((int)m1, o, 64));
-                m2 = max(m2, (uint32_t)__shfl_xor((int)m2, o, 64));
-            }
-            if ((threadIdx.x & 63) == 0) {
-                atomicMax(&s_mm[0], m0);
-                atomicMin(&s_mm[1], m1);
-                atomicMax(&s_mm[2], m2);
-            }
+        for (int o = 32; o > 0; o >>= 1) {
+            m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o, 64));
+            m1 = min(m1, (uint32_t)__shfl_xor((int)m1, o, 64));
+            m2 = max(m2, (uint32_t)__shfl_xor((int)m2, o, 64));
         }
-        __syncthreads();
-        if (r0 >= 0 && threadIdx.x < 20) {
-            const uint32_t k = threadIdx.x >> 2, which = threadIdx.x & 3;
+        if (r0 >= 0 && lane < 20) {
+            const uint32_t k = lane >> 2, which = lane & 3;
             const uint32_t lo = ft.idx[k * ft.n_refs + r0], hi = ft.idx[k * ft.n_refs + r0 + 1];
-            const uint32_t from = s_prev_ref == r0 ? lo + s_br[k][which] : lo; // (this thread's own word of the previous tile)
+            const uint32_t from = prev_ref == r0 ? lo + my_br : lo; // (this lane's own result for the previous tile)
             uint32_t v;
-            if (which == 0) v = bound_from<false>(ft.starts, lo, hi, from, s_mm[1]) - lo;                         // fewest starts below a query end
-            else if (which == 1) v = bound_from<false>(ft.starts, lo, hi, from, s_mm[2]) - lo;                    // most
+            if (which == 0) v = bound_from<false>(ft.starts, lo, hi, from, m1) - lo;                         // fewest starts below a query end
+            else if (which == 1) v = bound_from<false>(ft.starts, lo, hi, from, m2) - lo;                    // most
             else if (which == 2) v = bound_from<true>(ft.stops, lo, hi, from, (uint32_t)(key & 0xFFFFFFFFu)) - lo; // fewest stops at or below a query start
-            else v = bound_from<true>(ft.stops, lo, hi, from, s_mm[0]) - lo;                                      // most
+            else v = bound_from<true>(ft.stops, lo, hi, from, m0) - lo;                                      // most
             // kept relative to the list's begin, so that counts come out directly; the searches add the begin back
-            s_br[k][which] = v;
-            if (which == 0) s_lo[k] = lo;
+            my_br = v;
+            my_lo = lo;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_prev_ref = r0; // (read again by the twenty only behind the next tile's barriers)
+        prev_ref = r0;
 #pragma unroll
         for (uint32_t r = 0; r < F_RPT; r++) {
             bool utr5 = false, utr3 = false, cds = false, intergenic = false, exonic = false, intronic = false;
@@ -236,8 +220,11 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                     if (!narrow) return count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], nullptr);
                     // (brackets that have closed -- no interval of this name begins or ends inside the tile's span, the usual
                     // case -- give the count without touching the lists: lower_bound / upper_bound of an empty range)
-                    const uint32_t lo = s_lo[name];
-                    const uint32_t br[4] = {lo + s_br[name][0], lo + s_br[name][1], lo + s_br[name][2], lo + s_br[name][3]};
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)(4u * name));
+                    const uint32_t br[4] = {lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name)),
+                                            lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 1u)),
+                                            lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 2u)),
+                                            lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 3u))};
                     return count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], br);
                 };
                 // :186-214  UTR / CDS store: the if / else-if chain over the overlapping intervals only
@@ -329,7 +316,7 @@ hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const De
         const char *e = getenv("NGSQ_FEATURES_BLOCKS_PER_CU");
         per_cu = e && atoi(e) > 0 ? atoi(e) : 12;
     }
-    uint64_t g = (b.n + 256 * F_RPT - 1) / (256 * F_RPT);
+    uint64_t g = (b.n + 256 * F_RPT - 1) / (256 * F_RPT); // four waves per block, a tile of 64 x F_RPT records each
     if (g > (uint64_t)li.n_cu * (uint64_t)per_cu) g = (uint64_t)li.n_cu * (uint64_t)per_cu;
     hipLaunchKernelGGL(k_features, dim3((uint32_t)g), dim3(256), 0, s, st, b, ft);
     return hipGetLastError();
