@@ -309,7 +309,7 @@ __global__ void k_walk_one(const uint8_t *__restrict__ raw, uint64_t n_bytes, ui
 // starts in s), seg_base[s] = index of its first record; the piece's own entry comes from the candidate's piece table.
 // bad[0] = smallest index of an invalid record (or ~0).
 __global__ __launch_bounds__(PT) void k_rec_offsets(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint32_t n_pieces,
-                                                     const uint32_t *__restrict__ chosen, const uint64_t *__restrict__ seg_base,
+                                                     const uint32_t *__restrict__ chosen, const uint32_t *__restrict__ seg_base,
                                                      const RecPieces *__restrict__ pieces, uint64_t *__restrict__ rec_off,
                                                      unsigned long long *__restrict__ bad) {
     NGSQ_FOREGROUND_WAVE();
@@ -700,9 +700,18 @@ __global__ void k_count_below_u64(const uint64_t *__restrict__ a, uint64_t n, ui
 // reader thread's 64 MiB host-to-device copies of the next chunk's compressed bytes (in-order DMA: up to 1.2 ms each,
 // tools/stream_order_probe.hip); a dozen such copies per chunk sat on the pipeline's critical path and were what kept
 // the parse of one chunk from running beside the inflate of the next.
+// (16 bytes per lane where both sides are 16-byte aligned: the segment verdicts of a chunk -- 512 KB read out of pinned host
+// memory over PCIe -- took 130 us a dword per lane, a fifth of the parse kernels' time beside the inflate)
 __global__ __launch_bounds__(256) void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
     NGSQ_FOREGROUND_WAVE();
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+    uint64_t n4 = 0;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0) {
+        n4 = n / 4;
+        const uint4 *const s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *const d4 = reinterpret_cast<uint4 *>(dst);
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) d4[i] = s4[i];
+    }
+    for (uint64_t i = 4 * n4 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // device-to-device bytes at any alignment (the record cut by a chunk's end moves in front of the next chunk: a few hundred
@@ -723,7 +732,7 @@ hipError_t launch_copy_bytes(void *dst, const void *src, uint64_t n_bytes, hipSt
 hipError_t launch_copy_words(void *dst, const void *src, uint64_t n_bytes, hipStream_t s) {
     const uint64_t n = (n_bytes + 3) / 4; // (the buffers are allocated in whole words)
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_copy_words, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 1024)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_copy_words, dim3((uint32_t)std::min<uint64_t>((n / 4 + 255) / 256 + 1, 1024)), dim3(256), 0, s,
                        static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), n);
     return hipGetLastError();
 }
@@ -738,7 +747,7 @@ hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start,
     hipLaunchKernelGGL(k_walk_one, dim3(1), dim3(64), 0, s, raw, n_bytes, start, seg_start, end, out, pieces);
     return hipGetLastError();
 }
-hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
+hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint32_t *seg_base,
                               const RecPieces *pieces, uint64_t *rec_off, unsigned long long *work, hipStream_t s) {
     if (!n_pieces) return hipSuccess;
     hipLaunchKernelGGL(k_rec_offsets, dim3((n_pieces + PT - 1) / PT), dim3(PT), 0, s, raw, n_bytes, n_pieces, chosen, seg_base, pieces,

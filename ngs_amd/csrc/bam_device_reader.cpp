@@ -731,9 +731,11 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     }
     BHIP(hipStreamSynchronize(st));
     const RecCandidate *const cand = static_cast<const RecCandidate *>(d->h_cand.h);
-    uint64_t *const seg = static_cast<uint64_t *>(d->h_seg.h); // [n_seg] index of each segment's first record | [n_seg] (32-bit words) its chain
-    memset(seg, 0, (size_t)n_seg * 2 * sizeof(uint64_t));
-    uint32_t *chosen = reinterpret_cast<uint32_t *>(seg + n_seg);
+    // [n_seg] index of each segment's first record | [n_seg] its chain: 32-bit words (a chunk holds fewer than 2^32 records; 8 bytes
+    // per segment cross PCIe to the device, read by a copy kernel)
+    uint32_t *const seg = static_cast<uint32_t *>(d->h_seg.h);
+    memset(seg, 0, (size_t)n_seg * 2 * sizeof(uint32_t));
+    uint32_t *chosen = seg + n_seg;
     uint64_t *const h_small = static_cast<uint64_t *>(d->h_small.h);
     uint64_t *const h_small_dev = static_cast<uint64_t *>(d->h_small.dev);
     if (find) { // the first plausible chain of the view: an assumption (ngsq_bam_shard_verify confirms or corrects it)
@@ -763,7 +765,7 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     for (uint32_t s = 0; s < n_seg; s++) {
         const uint64_t s0 = (uint64_t)s * REC_SEGMENT, s1 = std::min<uint64_t>(s0 + REC_SEGMENT, d->raw_len);
         chosen[s] = REC_NO_CHAIN;
-        seg[s] = total_rec;
+        seg[s] = (uint32_t)total_rec;
         if (cur >= s1) continue;
         const RecCandidate *c = nullptr;
         for (uint32_t k = 0; k < REC_CANDIDATES; k++) {
@@ -792,11 +794,12 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     }
     d->tail_off = std::min(cur, d->raw_len);
     BHIP(d->d_rec_off.reserve(total_rec + 1));
-    BHIP(launch_copy_words(d->d_seg.p, d->h_seg.dev, (size_t)n_seg * 2 * sizeof(uint64_t), st));
+    if (total_rec >> 32) return ngsq_bam_fail(NGSQ_ERR_LIMIT, "%s: more than 2^32 records in one chunk of the ingest", b->path.c_str());
+    BHIP(launch_copy_words(d->d_seg.p, d->h_seg.dev, (size_t)n_seg * 2 * sizeof(uint32_t), st));
     BHIP(hipMemsetAsync(d->d_small.p + W_BAD, 0xFF, sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, 0);
-        BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, reinterpret_cast<const uint32_t *>(d->d_seg.p + n_seg), d->d_seg.p,
+        BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, reinterpret_cast<const uint32_t *>(d->d_seg.p) + n_seg, reinterpret_cast<const uint32_t *>(d->d_seg.p),
                                 d->d_pieces.p, d->d_rec_off.p, d->d_small.p, st));
     }
     // (an invalid record k_rec_offsets alone notices: its index stays in the device word and the first batch of the chunk

@@ -562,6 +562,7 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
             HIP_TRY(c, launch_fields(c->li, c->st, db, rec_f, cov ? (c->stream_cov ? 2 : 1) : 0, c->stream));
         }
         if (cov && c->stream_cov) {
+            // (on a stream of its own beside k_gc / k_qual it hides its 0.7 ms and costs k_qual_perm 1.2: DESIGN appendix A.8)
             Bracket br(c, K_COV_STREAM, n * 8); // pos + cov_end of every record
             HIP_TRY(c, launch_cov_stream(c->li, c->st, db, c->csa, c->stream));
         }

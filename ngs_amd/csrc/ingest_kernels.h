@@ -107,7 +107,7 @@ hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start,
 // chosen[s]: which candidate of segment s is on the file's chain (REC_NO_CHAIN: none starts there); seg_base[s]: index of
 // its first record.  One lane per REC_PIECE bytes writes the offsets of the records that start there.
 // work: the REC_WORK_WORDS device words shared with launch_rec_fixed; work[W_BAD] (set to ~0 by the caller) = smallest index of an invalid record
-hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint64_t *seg_base,
+hipError_t launch_rec_offsets(const uint8_t *raw, uint64_t n_bytes, uint32_t n_pieces, const uint32_t *chosen, const uint32_t *seg_base,
                               const RecPieces *pieces, uint64_t *rec_off, unsigned long long *work, hipStream_t s);
 // copy n_bytes (rounded up to whole 32-bit words) with a kernel: for small tables between device memory and pinned host
 // memory, which a hipMemcpyAsync would queue behind the large transfers of other streams
