@@ -258,7 +258,7 @@ struct DeviceIngest {
     DevBuf<uint32_t> d_status, d_l_seq, d_cigar;
     DevBuf<RecPieces> d_pieces;
     DevBuf<uint64_t> d_var_base;              // per record of the batch: offset of its CIGAR in raw
-    DevBuf<uint64_t> d_seg, d_rec_off, d_len; // d_seg: per segment, index of its first record | chosen candidate (u32); d_len: seq | qual | cigar lengths -> offsets
+    DevBuf<uint64_t> d_rec_off, d_len; // d_len: seq | qual | cigar lengths -> offsets
     DevBuf<unsigned long long> d_small;       // REC_WORK_WORDS words shared by k_rec_offsets / k_rec_fixed (ingest_kernels.h RecWork)
     DevBuf<uint16_t> d_flag, d_n_cigar;
     DevBuf<uint8_t> d_mapq;
@@ -723,7 +723,6 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     BHIP(d->h_small.reserve(64 * sizeof(uint64_t)));
     const uint32_t n_pieces = (uint32_t)((d->raw_len + REC_PIECE - 1) / REC_PIECE);
     BHIP(d->d_pieces.reserve((size_t)n_seg * REC_CANDIDATES));
-    BHIP(d->d_seg.reserve((size_t)n_seg * 2)); // seg_base | chosen (32-bit words in the second half)
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, d->raw_len);
         BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), static_cast<RecCandidate *>(d->h_cand.dev),
@@ -795,11 +794,14 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     d->tail_off = std::min(cur, d->raw_len);
     BHIP(d->d_rec_off.reserve(total_rec + 1));
     if (total_rec >> 32) return ngsq_bam_fail(NGSQ_ERR_LIMIT, "%s: more than 2^32 records in one chunk of the ingest", b->path.c_str());
-    BHIP(launch_copy_words(d->d_seg.p, d->h_seg.dev, (size_t)n_seg * 2 * sizeof(uint32_t), st));
+    // (k_rec_offsets reads the verdicts where they are, in pinned host memory: 8 bytes per segment, 64 contiguous bytes per
+    // wave and array.  Until late in round 4 a copy kernel brought them over first -- one launch per chunk that waited 90 us on
+    // average, up to 1.3 ms, for a wave slot beside the decoders: 20 ms per 24 M-record scan for 256 KB)
+    const uint32_t *const seg_dev = static_cast<const uint32_t *>(d->h_seg.dev);
     BHIP(hipMemsetAsync(d->d_small.p + W_BAD, 0xFF, sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, 0);
-        BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, reinterpret_cast<const uint32_t *>(d->d_seg.p) + n_seg, reinterpret_cast<const uint32_t *>(d->d_seg.p),
+        BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, seg_dev + n_seg, seg_dev,
                                 d->d_pieces.p, d->d_rec_off.p, d->d_small.p, st));
     }
     // (an invalid record k_rec_offsets alone notices: its index stays in the device word and the first batch of the chunk

@@ -205,7 +205,17 @@ __device__ __forceinline__ uint32_t qr_wave_inclusive_sum(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31
     return v;
 }
-constexpr uint32_t QR_TRASH = QUAL_BINS; // the score the bytes behind a record's end are given: a row of the table nobody reads
+// The table of k_qual_ragged (round 4): 16-BIT counters, two to a word -- the cells of cycle bytes kb = 2 p and 2 p + 1 of a
+// window share the word (q, p, w), so that one ds_add instruction (all its lanes on the same byte k of their dword) never has
+// two lanes on the two halves of a word -- for the scores 0..63 and a trash row: 65 x 8 x RP words = 41 KB for reads of up to
+// 320 bases instead of 122 KB, TWO blocks of sixteen waves per CU instead of one.  A record adds at most one to a cell, so
+// the table is flushed to the global counters every 63 x 1024 records of the block at the latest; scores 64..93 (rare) go to
+// the global counters directly.
+constexpr uint32_t QR_ROWS = 64;         // scores the LDS table holds
+constexpr uint32_t QR_TRASH = QR_ROWS;   // the score the bytes behind a record's end are given: a row of the table nobody reads
+constexpr uint32_t QR_FLUSH_EVERY = 63;  // iterations of 1024 records between two flushes (63 x 1024 < 65536)
+__host__ __device__ constexpr uint32_t qr_cp(uint32_t R) { return (8 * qw_rp(R) + 31) / 32 * 32; } // words per score
+__host__ __device__ constexpr uint32_t qr_table_bytes(uint32_t R) { return (QR_ROWS + 1) * qr_cp(R) * 4; }
 __device__ __forceinline__ uint32_t qr_from_lane(uint32_t v, uint32_t src_lane) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
@@ -214,10 +224,10 @@ template <uint32_t R, uint32_t NROT>
 __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint8_t *__restrict__ qual,
                                                       const uint64_t *__restrict__ qual_off, uint64_t n_rec) {
     NGSQ_FOREGROUND_WAVE();
-    constexpr uint32_t RP = qw_rp(R), CP = qw_cp(R), CP4 = CP * 4, RP4 = RP * 4;
-    constexpr uint32_t S4 = 4u * RP4;
-    extern __shared__ uint32_t s_q[]; // (QUAL_BINS + 1) x CP words (the last row: QR_TRASH, never flushed): the only LDS object
-    constexpr uint32_t nb = (QUAL_BINS + 1) * CP;
+    constexpr uint32_t RP = qw_rp(R), CP = qr_cp(R), CP4 = CP * 4, RP4 = RP * 4;
+    constexpr uint32_t S4 = 2u * RP4; // a dword of a window = two pair rows
+    extern __shared__ uint32_t s_q[]; // (QR_ROWS + 1) x CP words (the last row: QR_TRASH, never flushed): the only LDS object
+    constexpr uint32_t nb = (QR_ROWS + 1) * CP;
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) s_q[i] = 0;
     char *const tab = reinterpret_cast<char *>(s_q);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -237,6 +247,20 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
     const uint64_t lo = min(per * blockIdx.x, n_rec), hi = min(lo + per, n_rec);
     const uint64_t end_bytes = n_rec ? qual_off[n_rec] : 0; // a 16-byte load must not run past this (>= 16: launch_qual_ragged)
     uint32_t bad = 0, too_long = 0;
+    u64 *const gq = st.counters + st.off_qual;
+    const uint32_t n_cyc = min(st.max_read_len, 16u * R);
+    // the table's cells of real cycles (cycle c = 16 w + kb < max_read_len) to the global counters; the whole block
+    auto flush = [&]() {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_cyc * QR_ROWS; i += blockDim.x) {
+            const uint32_t c = i / QR_ROWS, q = i - c * QR_ROWS, kb = c & 15u;
+            const uint32_t v = (s_q[q * CP + (kb >> 1) * RP + (c >> 4)] >> (16u * (kb & 1u))) & 0xFFFFu;
+            if (v) atomicAdd(&gq[(uint64_t)c * QUAL_BINS + q], (u64)v);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < QR_ROWS * CP; i += blockDim.x) s_q[i] = 0;
+        __syncthreads();
+    };
 
     // offsets of a wave's 64 records, loaded one group ahead (branch-free: past the end the last entry twice)
     auto load_offs = [&](uint64_t i0, uint64_t &o0, uint64_t &o1) {
@@ -246,7 +270,11 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
     };
     uint64_t nx_o0 = 0, nx_o1 = 0;
     if (lo + 64ull * wave < hi) load_offs(lo + 64ull * wave, nx_o0, nx_o1);
-    for (uint64_t i0 = lo + 64ull * wave; i0 < hi; i0 += 64ull * 16) {
+    const uint64_t n_iter = (hi - lo + 1023) / 1024; // the same for every wave of the block (the flush is a block's)
+    for (uint64_t it = 0; it < n_iter; it++) {
+        if (it && it % QR_FLUSH_EVERY == 0) flush();
+        const uint64_t i0 = lo + it * 1024 + 64ull * wave;
+        if (i0 >= hi) continue;
         // this wave's 64 records: offset, length (clamped to the table), windows
         const uint64_t rec = i0 + lane;
         const uint64_t cur_o0 = nx_o0, cur_o1 = nx_o1;
@@ -262,7 +290,7 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
         // Every 16-byte window of the 64 records, the last, partial one of a record included, 64 consecutive windows per
         // step.  (Until round 4 the partial windows were a second pass over the 64 records: by then the lines that hold them
         // -- three lines in four of the records' bytes -- had left the L2, a block's waves having 180 KB in flight per CU:
-        // TCC_EA0_RDREQ said 1.39 x the bytes, the kernel ran at HBM's rate on 0.50 of its algorithmic bytes.)
+        // TCC_EA0_RDREQ said 1.39 x the bytes.)
         const uint32_t nwin = (len + 15u) >> 4;
         const uint32_t P = qr_wave_inclusive_sum(nwin); // windows of records 0..lane
         const uint32_t T = __builtin_amdgcn_readlane(P, 63);
@@ -359,15 +387,17 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
                         const uint32_t q = (x[d] >> (8 * k)) & 0xFFu;
-                        atomicAdd(reinterpret_cast<uint32_t *>(tab + (__umul24(q, CP4) + bd[d]) + k * RP4), 1u);
+                        atomicAdd(reinterpret_cast<uint32_t *>(tab + (__umul24(q, CP4) + bd[d]) + (k >> 1) * RP4), 1u << (16u * (k & 1u)));
                     }
                 }
             } else {
                 // every byte is a score in this layout: 94..255 are decode errors
                 for (uint32_t j = 0; j < nv; j++) {
                     const uint32_t q = (ww[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                    if (q <= NGSQ_MAX_SCORE)
-                        atomicAdd(reinterpret_cast<uint32_t *>(tab + q * CP4 + 4u * w + j * RP4), 1u);
+                    if (q < QR_ROWS)
+                        atomicAdd(reinterpret_cast<uint32_t *>(tab + q * CP4 + 4u * w + (j >> 1) * RP4), 1u << (16u * (j & 1u)));
+                    else if (q <= NGSQ_MAX_SCORE)
+                        atomicAdd(&gq[(uint64_t)(16u * w + j) * QUAL_BINS + q], (u64)1);
                     else
                         bad += 1;
                 }
@@ -376,14 +406,7 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the map is rewritten for the next 64 records
         __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    // flush the cells of real cycles: cycle c = 16 w + kb < max_read_len
-    const uint32_t n_out = min(st.max_read_len, 16u * R) * QUAL_BINS;
-    for (uint32_t i = threadIdx.x; i < n_out; i += blockDim.x) {
-        const uint32_t c = i / QUAL_BINS, q = i - c * QUAL_BINS;
-        const uint32_t v = s_q[q * CP + (c & 15u) * RP + (c >> 4)];
-        if (v) atomicAdd(&st.counters[st.off_qual + i], (u64)v);
-    }
+    flush();
     uint32_t r0 = bad, r1 = too_long;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
 
 template <uint32_t R>
 static hipError_t launch_ragged_r(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
-    const uint32_t lds = qual_window_lds_bytes(R) + qw_cp(R) * 4u + 16u * 64u * R + 17u * 16u; // table + trash row + one window->record byte map per wave + the keep masks
+    const uint32_t lds = qr_table_bytes(R) + 16u * 64u * R + 17u * 16u; // table + one window->record byte map per wave + the keep masks
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_ragged<R, 4>),
