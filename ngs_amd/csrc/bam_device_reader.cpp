@@ -175,6 +175,7 @@ namespace ngsq {
 struct DeviceIngest {
     FILE *f = nullptr;
     ngsq_ctx *ctx = nullptr;
+    int device = -1; // ctx->device, kept for the destructor (the context may be gone by then)
     size_t raw_cap = 0, comp_chunk = 0;
     // Compressed chunks come from a reader thread: while the GPU inflates and parses chunk k the
     // thread reads and frames chunk k+1 into the other pinned buffer.
@@ -300,7 +301,7 @@ struct DeviceIngest {
         cv.notify_all();
         if (reader.joinable()) reader.join();
         if (f) fclose(f);
-        if (ctx) (void)hipSetDevice(ctx->device); // (the cache is per device)
+        if (device >= 0) (void)hipSetDevice(device); // (the cache is per device)
         if (copy_stream) {
             (void)hipStreamSynchronize(copy_stream);
             pool_stream_put(false, copy_stream);
@@ -1188,6 +1189,7 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
 int open_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest **out) {
     DeviceIngest *d = new DeviceIngest();
     d->ctx = c;
+    d->device = c->device;
     d->f = fopen(b->path.c_str(), "rb");
     if (!d->f) {
         delete d;

@@ -300,8 +300,10 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         CTX_TRY(hipMemsetAsync(c->d_chunk_flags, 0, c->n_chunks ? c->n_chunks : 1, c->stream));
     }
     if (ne) {
-        CTX_TRY(hipMalloc((void **)&st.edits, ne * 4));
-        CTX_TRY(hipMemsetAsync(st.edits, 0, ne * 4, c->stream));
+        // (+ 64 bytes: the alts flush of k_edits_rows adds pairs of entries with 64-bit atomics; the pair that holds a sequence's
+        // last entry may reach one entry further -- adding zero there)
+        CTX_TRY(hipMalloc((void **)&st.edits, ne * 4 + 64));
+        CTX_TRY(hipMemsetAsync(st.edits, 0, ne * 4 + 64, c->stream));
         // the reference, packed 4-bit, twice (edits_kernel.hip): [copy from base 0 | copy from base 1]
         uint8_t *bases = nullptr;
         // (+ 256: the window lanes of k_edits_rows read 16 bytes at up to 80 + 16 bytes behind a read's last compared base)

@@ -630,17 +630,31 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, Devic
                     }
                 }
             }
-            for (uint32_t ib = 0; 2 * ib < top; ib += 64) { // (a mismatch lies below the end of its read's M: below `top`)
+            // The alts window: two 16-bit counters per LDS word = two neighbouring 32-bit entries of the global array, added with ONE
+            // 64-bit atomic (counts stay far below 2^32, so nothing carries from the low entry into the high one).  The flush is paid
+            // per atomic instruction and line, not per lane (EDITS_EXP 6: the alts' flush cost as much as the cover's although only one
+            // position in four holds a mismatch), so this halves it.  Whether a window word's two entries share an aligned 8 bytes
+            // depends on the sequence's place in the block: if not, a lane adds the high half of the word before its own and the
+            // low half of its own.  (A mismatch lies below the end of its read's M: below `top`.)
+            const uint32_t n_dw = (top >> 1) + 1u;
+            const bool straddle = ((meta_eoff + (uint64_t)meta_L) & 1ull) != 0; // &adst[0] = edits + meta_eoff + win_base + L + 2 entries, win_base % 4 == 0
+            for (uint32_t ib = 0; ib < n_dw + (straddle ? 1u : 0u); ib += 64) {
                 const uint32_t i = ib + lane;
-                const uint32_t v = i < EDR_ALTW ? altw[i] : 0u;
-                if (v) {
-                    if (EDITS_EXP != 6 && EDITS_EXP != 7) {
-                        if (v & 0xFFFFu) atomicAdd(&adst[2 * i], v & 0xFFFFu);
-                        if (v >> 16) atomicAdd(&adst[2 * i + 1], v >> 16);
-                    }
-                    altw[i] = 0;
+                const uint32_t own = i < n_dw && i < EDR_ALTW ? altw[i] : 0u;
+                u64 v;
+                uint32_t *at;
+                if (!straddle) {
+                    v = (u64)(own & 0xFFFFu) | (u64)(own >> 16) << 32;
+                    at = adst + 2 * i;
+                } else {
+                    const uint32_t before = i >= 1 && i - 1 < n_dw && i - 1 < EDR_ALTW ? altw[i - 1] : 0u;
+                    v = (u64)(before >> 16) | (u64)(own & 0xFFFFu) << 32;
+                    at = adst + 2 * i - 1;
                 }
+                if (v && EDITS_EXP != 6 && EDITS_EXP != 7) atomicAdd(reinterpret_cast<u64 *>(at), v);
             }
+            for (uint32_t ib = 0; ib < n_dw; ib += 64) // (behind the adds: a lane reads its neighbour's word above)
+                if (ib + lane < n_dw && ib + lane < EDR_ALTW) altw[ib + lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }

@@ -659,3 +659,25 @@ def test_genomic_features_errors_and_state(gpu_lib, oracle_mod):
     with pytest.raises(Exception, match="ngsq_set_features"):
         q.process_batch(batch_from_records(recs[:1]))
     q.close()
+
+
+def test_quality_counters_of_the_offsets_layout_do_not_wrap(gpu_lib):
+    """k_qual_ragged keeps 16-bit counters in LDS and flushes them every 63 x 1024 records of a block (qual_kernel.hip): 40 M
+    records that all add to the SAME cells -- 78 k per block of the grid's 512 -- come out exact only if the flushes happen."""
+    n, l = 40_000_000, 16
+    cols = {"flag": np.zeros(n, np.uint16), "mapq": np.full(n, 30, np.uint8), "ref_id": np.zeros(n, np.int32),
+            "pos": np.zeros(n, np.int32), "mate_ref_id": np.full(n, -1, np.int32), "tlen": np.zeros(n, np.int32),
+            "l_seq": np.full(n, l, np.uint32), "n_cigar": np.ones(n, np.uint16),
+            "seq": np.full(n * (l // 2), 0x12, np.uint8), "seq_off": None,
+            "qual": np.full(n * l, 30, np.uint8), "qual_off": np.arange(n + 1, dtype=np.uint64) * l,
+            "cigar": np.full(n, l << 4, np.uint32), "cigar_off": None, "record_id": None}
+    cols["qual"][7::16] = 70     # a score beyond the LDS table's 64 rows: straight to the global counters
+    hb = host.HostBatch(n, cols, l // 2, 0, 1, 0)
+    with host.QcContext([1000], facets=ffi.FACET_QUALITY_SCORE, max_read_len=64, lib=gpu_lib) as gpu:
+        gpu.process_batch(hb)
+        gpu.finalize()
+        q = gpu.quality_scores()
+        for c in range(l):
+            want = 70 if c == 7 else 30
+            assert int(q[c][want]) == n and int(q[c].sum()) == n, c
+        assert int(q[l:].sum()) == 0
