@@ -385,7 +385,15 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatc
 constexpr uint32_t ED_NW = 5;                    // windows per row the kernel is built for (reads of up to 160 bases)
 constexpr uint32_t EDR_PASSES = 4;               // passes of 64 records per wave and window flush
 constexpr uint32_t EDR_WAVE_TILE = 64 * EDR_PASSES, EDR_TILE = ED_THREADS * EDR_PASSES;
-constexpr uint32_t EDR_WINDOW = 1536;            // entries of the wave's cover window (256 sorted reads: 790 positions at 60x, 1430 at 30x)
+#ifndef NGSQ_EDR_WINDOW
+#define NGSQ_EDR_WINDOW 1536
+#endif
+#ifdef NGSQ_EDR_WAVES // (measurement builds: waves per SIMD the register allocation is made for)
+#define EDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NGSQ_EDR_WAVES, NGSQ_EDR_WAVES)))
+#else
+#define EDR_WAVES_ATTR
+#endif
+constexpr uint32_t EDR_WINDOW = NGSQ_EDR_WINDOW;            // entries of the wave's cover window (256 sorted reads: 790 positions at 60x, 1430 at 30x)
 constexpr uint32_t EDR_ALTW = EDR_WINDOW / 2;    // dwords of its alts window: 16-bit counters, two positions per dword
 
 struct EdRowCols {
@@ -396,7 +404,7 @@ struct EdRowCols {
 // CIG_OFF: the CIGARs are addressed through cigar_off (their loads then wait for the offsets; with a fixed pitch they are
 // prefetched with the columns of the pass)
 template <bool CIG_OFF>
-__global__ __launch_bounds__(ED_THREADS) void k_edits_rows(DeviceState st, DeviceBatch b, uint32_t R, uint32_t recip, u64 *__restrict__ defer_bits) {
+__global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(DeviceState st, DeviceBatch b, uint32_t R, uint32_t recip, u64 *__restrict__ defer_bits) {
     NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_h1[ED_HIST], s_h2[ED_HIST];
     __shared__ uint32_t s_win[(ED_THREADS / 64) * EDR_WINDOW];  // cover: difference entries
