@@ -259,6 +259,20 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
             }
         }
 
+        // CIG_OFF: the four records' offsets into the CIGAR column and their first operations are requested here, together, and
+        // arrive while the flag tallies below are made.  (Until round 4 each record's offset was loaded when its walk began and
+        // its first operation behind that: eight dependent latencies per thread and tile; `k_fields<true, *>` took twice the
+        // time of the fixed-pitch variants on the 50-300 bp workload.)
+        uint64_t coff[FT_PER_THREAD + 1] = {0, 0, 0, 0, 0};
+        uint32_t cigf[FT_PER_THREAD] = {0, 0, 0, 0};
+        if (CIG_OFF && (a.do_general || a.do_cov)) {
+#pragma unroll
+            for (uint32_t j = 0; j <= FT_PER_THREAD; j++)
+                if (j <= nrec && nrec) coff[j] = b.cigar_off[r0 + j];
+#pragma unroll
+            for (uint32_t j = 0; j < FT_PER_THREAD; j++)
+                if (j < nrec && coff[j + 1] > coff[j]) cigf[j] = b.cigar[coff[j]];
+        }
 #pragma unroll
         for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
             const bool live = j < nrec;
@@ -307,11 +321,11 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 uint64_t span = 0;
                 uint64_t cbase = (r0 + j) * (uint64_t)b.cigar_stride;
                 if (CIG_OFF) {
-                    cbase = b.cigar_off[r0 + j];
-                    if (n_ops == 0xFFFFu) n_ops = (uint32_t)(b.cigar_off[r0 + j + 1] - cbase); // (65535 = "or more": include/ngsq.h)
+                    cbase = coff[j];
+                    if (n_ops == 0xFFFFu) n_ops = (uint32_t)(coff[j + 1] - cbase); // (65535 = "or more": include/ngsq.h)
                 }
                 for (uint32_t k = 0; k < n_ops; k++) {
-                    const uint32_t cg = (cigar_vec && k == 0) ? cig1[j] : b.cigar[cbase + k];
+                    const uint32_t cg = (cigar_vec && k == 0) ? cig1[j] : (CIG_OFF && k == 0) ? cigf[j] : b.cigar[cbase + k];
                     const uint32_t op = cg & 0xFu, len = cg >> 4;
                     if (op > 8u) {
                         bad_op += 1;

@@ -453,12 +453,13 @@ def test_sharded_state_sums_to_single_context(gpu_lib, oracle_mod):
     json_equal(total.results(["a", "b"]), orc.results(["a", "b"]))
 
 
-def test_full_size_properties(gpu_lib):
-    """At a size the oracle cannot reach quickly: size-independent invariants on
-    4 M generated-in-HBM records over a chr1-sized sequence."""
-    n, L = 4_000_000, 248_956_422
+@pytest.mark.parametrize("n,sorted_input", [(4_000_000, False), (100_000_000, True), (100_000_000, False)])
+def test_full_size_properties(gpu_lib, n, sorted_input):
+    """At sizes the oracle cannot reach quickly: size-independent invariants on records generated in HBM over a chr1-sized
+    sequence -- 4 M, and BASELINE configs[2]'s full 100 M (26 GB of columns) with Coverage streamed and on the difference arrays."""
+    L = 248_956_422
     cfg = host.synth_config(n, ref_len=L, n_refs=2)
-    with host.QcContext([L, 242_193_529], max_read_len=150, timing=True, lib=gpu_lib) as gpu:
+    with host.QcContext([L, 242_193_529], max_read_len=150, timing=True, sorted_input=sorted_input, lib=gpu_lib) as gpu:
         db = gpu.synth_device_batch(cfg, 0, n)
         gpu.process_batch(db)
         gpu.finalize()
