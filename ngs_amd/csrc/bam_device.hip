@@ -666,6 +666,22 @@ __global__ __launch_bounds__(256) void k_rec_var(const uint8_t *__restrict__ raw
     }
 }
 
+// The CIGAR column alone in the offsets layout (fixed-pitch SEQ / QUAL rows beside it: an aligner's file, where one read in
+// seven has clips or indels): FOUR lanes per record -- a record has 1.3 operations on average, and with k_rec_var's sixteen
+// lanes fifteen of them only ran the kernel's prologue (0.3 ms per 1.4 M records beside the decoders).
+__global__ __launch_bounds__(256) void k_rec_cigar_var(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base, uint64_t n,
+                                                       const uint64_t *__restrict__ cigar_off, uint32_t *__restrict__ cigar) {
+    NGSQ_FOREGROUND_WAVE();
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const uint32_t t = threadIdx.x & 3u;
+    if (i >= n) return;
+    const uint64_t c0 = cigar_off[i];
+    const uint32_t n_ops = (uint32_t)(cigar_off[i + 1] - c0);
+    if (t >= n_ops) return;
+    const uint8_t *cg = raw + var_base[i];
+    for (uint32_t k = t; k < n_ops; k += 4) cigar[c0 + k] = ld32(cg + 4 * k);
+}
+
 // one CIGAR operation per record (or none): the first one, or 0
 __global__ __launch_bounds__(PT) void k_rec_cigar1(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ var_base,
                                                     const uint16_t *__restrict__ n_cigar, uint64_t n, uint32_t *__restrict__ cigar) {
@@ -796,7 +812,9 @@ hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t
         if (!c.cigar_off)
             hipLaunchKernelGGL(k_rec_cigar1, dim3((uint32_t)std::min<uint64_t>((n + PT - 1) / PT, 2048 * (256 / PT))), dim3(PT), 0, s, raw, var_base,
                                c.n_cigar, n, c.cigar);
-        if (parts)
+        if (parts == 1u)
+            hipLaunchKernelGGL(k_rec_cigar_var, dim3((uint32_t)((n * 4 + 255) / 256)), dim3(256), 0, s, raw, var_base, n, c.cigar_off, c.cigar);
+        else if (parts)
             hipLaunchKernelGGL(k_rec_var, dim3((uint32_t)((n * 16 + 255) / 256)), dim3(256), 0, s, raw, var_base, n, c, parts);
     }
     hipLaunchKernelGGL(k_fill_slack, dim3(1), dim3(64), 0, s, c.seq + seq_bytes, c.qual + qual_bytes);
