@@ -58,7 +58,8 @@ typedef struct ngsq_synth_config {
     uint32_t max_len;   /* MIXED: 300                                                  */
     uint32_t ref_len;   /* length of reference 0 (chr1 = 248 956 422)                  */
     uint32_t n_refs;    /* 1, or 2 (reference 1 only ever appears as a mate reference) */
-    uint32_t file_style; /* ngsq_synth_write_bam only: NGSQ_SYNTH_FILE_* bits (0 = round 1-3 files)  */
+    uint32_t file_style; /* NGSQ_SYNTH_FILE_* bits (0 = round 1-3 records): ALIGNER dresses the records of ngsq_synth_write_bam,
+                            CIGAR_MIX changes the records themselves (every generator) */
     uint32_t seq_model; /* NGSQ_SYNTH_SEQ_IID (0) / NGSQ_SYNTH_SEQ_FROM_REFERENCE                 */
 } ngsq_synth_config;
 
@@ -197,6 +198,30 @@ NGSQ_HD void ngsq_synth_record_at(const ngsq_synth_config *c, uint64_t i, ngsq_s
     } else if (c->mode == NGSQ_SYNTH_FIXED) {
         r->n_cigar = 1;
         r->cigar[0] = (l << 4) | 0u;
+        if ((c->file_style & NGSQ_SYNTH_FILE_CIGAR_MIX) && l >= 50u) {
+            /* an aligner's mix: 15 % of the mapped reads -- 9 % soft-clipped at one end (1..60 bases), 3 % an insertion,
+               3 % a deletion (1..8 bases) */
+            const uint64_t hc = ngsq_synth_hash(c->seed, i, NGSQ_KEY_CIGAR, 7);
+            const uint32_t kind = (uint32_t)(hc & 0xFFFF), side = (uint32_t)((hc >> 16) & 1ull);
+            const uint32_t r1 = (uint32_t)((hc >> 24) & 0xFFFF), r2 = (uint32_t)((hc >> 40) & 0xFFFF);
+            if (kind < 5898u) {
+                const uint32_t lim = l - 20u < 60u ? l - 20u : 60u;
+                const uint32_t a = 1u + r1 % lim, b = l - a;
+                r->n_cigar = 2;
+                r->cigar[0] = side ? ((a << 4) | 4u) : ((b << 4) | 0u);
+                r->cigar[1] = side ? ((b << 4) | 0u) : ((a << 4) | 4u);
+            } else if (kind < 9830u) {
+                const uint32_t g = 1u + r1 % 8u;
+                r->n_cigar = 3;
+                if (kind < 7864u) { /* insertion: a + g + b = l */
+                    const uint32_t a = 1u + r2 % (l - g - 1u), b = l - g - a;
+                    r->cigar[0] = (a << 4) | 0u, r->cigar[1] = (g << 4) | 1u, r->cigar[2] = (b << 4) | 0u;
+                } else {
+                    const uint32_t a = 1u + r2 % (l - 1u), b = l - a;
+                    r->cigar[0] = (a << 4) | 0u, r->cigar[1] = (g << 4) | 2u, r->cigar[2] = (b << 4) | 0u;
+                }
+            }
+        }
     } else {
         const uint64_t hc = ngsq_synth_hash(c->seed, i, NGSQ_KEY_CIGAR, 0);
         const uint32_t kind = (uint32_t)(hc & 0xFFFF);

@@ -179,27 +179,7 @@ void append_record(std::vector<uint8_t> &out, const ngsq_synth_config &cfg, uint
     const int ln = aligner ? illumina_name(cfg, i, name, sizeof name) : snprintf(name, sizeof name, "r%llu", (unsigned long long)i) + 1;
     const uint32_t l = r.l_seq;
     uint32_t cig[NGSQ_SYNTH_MAX_OPS] = {r.cigar[0], r.cigar[1], r.cigar[2]}, n_cig = r.n_cigar;
-    if ((cfg.file_style & NGSQ_SYNTH_FILE_CIGAR_MIX) && cfg.mode == NGSQ_SYNTH_FIXED && n_cig == 1 && l >= 50) {
-        // 15 % of the mapped reads: 9 % soft-clipped at one end (1..60 bases), 3 % an insertion, 3 % a deletion (1..8 bases)
-        const uint64_t hc = ngsq_synth_hash(cfg.seed, i, NGSQ_KEY_CIGAR, 7);
-        const uint32_t kind = (uint32_t)(hc & 0xFFFF), side = (uint32_t)((hc >> 16) & 1), r1 = (uint32_t)((hc >> 24) & 0xFFFF), r2 = (uint32_t)((hc >> 40) & 0xFFFF);
-        if (kind < 5898u) {
-            const uint32_t a = 1 + r1 % std::min(60u, l - 20), b = l - a;
-            n_cig = 2;
-            cig[0] = side ? (a << 4 | 4u) : (b << 4 | 0u);
-            cig[1] = side ? (b << 4 | 0u) : (a << 4 | 4u);
-        } else if (kind < 9830u) {
-            const uint32_t g = 1 + r1 % 8;
-            n_cig = 3;
-            if (kind < 7864u) { // insertion: a + g + b = l
-                const uint32_t a = 1 + r2 % (l - g - 1), b = l - g - a;
-                cig[0] = a << 4 | 0u, cig[1] = g << 4 | 1u, cig[2] = b << 4 | 0u;
-            } else {
-                const uint32_t a = 1 + r2 % (l - 1), b = l - a;
-                cig[0] = a << 4 | 0u, cig[1] = g << 4 | 2u, cig[2] = b << 4 | 0u;
-            }
-        }
-    }
+    // (NGSQ_SYNTH_FILE_CIGAR_MIX: the records carry an aligner's CIGAR mix already -- ngsq_synth_record_at, shared with the device generator)
     uint64_t span = 0;
     for (uint32_t k = 0; k < n_cig; k++)
         if ((0x18Du >> (cig[k] & 15)) & 1u) span += cig[k] >> 4;

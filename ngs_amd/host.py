@@ -121,9 +121,10 @@ def synth_host_batch(cfg: ffi.SynthConfig, first: int, n: int, lib=None) -> Host
     cols["seq"] = np.zeros(sb.value, dtype=np.uint8)
     cols["qual"] = np.zeros(qb.value, dtype=np.uint8)
     if cfg.mode == ffi.SYNTH_FIXED:
-        cols["cigar"] = np.zeros(n, dtype=np.uint32)
+        cs = 3 if cfg.file_style & ffi.SYNTH_FILE_CIGAR_MIX else 1
+        cols["cigar"] = np.zeros(n * cs, dtype=np.uint32)
         cols["seq_off"] = cols["qual_off"] = cols["cigar_off"] = None
-        hb = HostBatch(n, cols, (cfg.read_len + 1) // 2, cfg.read_len, 1, first)
+        hb = HostBatch(n, cols, (cfg.read_len + 1) // 2, cfg.read_len, cs, first)
     else:
         cols["cigar"] = np.zeros(co.value, dtype=np.uint32)
         for k in ("seq_off", "qual_off", "cigar_off"):
@@ -297,8 +298,9 @@ class QcContext:
         sizes = {"flag": 2 * n, "mapq": n, "ref_id": 4 * n, "pos": 4 * n, "mate_ref_id": 4 * n, "tlen": 4 * n,
                  "l_seq": 4 * n, "n_cigar": 2 * n, "seq": sb.value, "qual": qb.value}
         if cfg.mode == ffi.SYNTH_FIXED:
-            sizes["cigar"] = 4 * n
-            strides = ((cfg.read_len + 1) // 2, cfg.read_len, 1)
+            cs = 3 if cfg.file_style & ffi.SYNTH_FILE_CIGAR_MIX else 1    # (an aligner's CIGAR mix: up to three operations, fixed pitch)
+            sizes["cigar"] = 4 * n * cs
+            strides = ((cfg.read_len + 1) // 2, cfg.read_len, cs)
         else:
             sizes["cigar"] = 4 * co.value
             for k in ("seq_off", "qual_off", "cigar_off"):
@@ -306,7 +308,7 @@ class QcContext:
             strides = (0, 0, 0)
         ptrs = {k: self.device_malloc(v + 64) for k, v in sizes.items()}
         db = DeviceBatch(n, ptrs, strides[0], strides[1], strides[2], first, sb.value, qb.value,
-                         co.value if cfg.mode != ffi.SYNTH_FIXED else n, sum(sizes.values()))
+                         co.value if cfg.mode != ffi.SYNTH_FIXED else n * strides[2], sum(sizes.values()))
         st = db.struct()
         _check(self.lib.ngsq_synth_fill_device(self._ctx, C.byref(cfg), first, n, C.byref(st)), self._ctx,
                self.lib)
