@@ -425,6 +425,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
     __shared__ uint2 s_desc[ED_THREADS];   // per record of the wave's current 64: (byte offset of its base 0 in the packed reference, v0 | v1 << 9 | window entry of base 0 << 18); v1 = 0: not on the fast path
     __shared__ uint32_t s_edits[ED_THREADS];
     __shared__ uint32_t s_tmask[33];       // [n]: the bits 4 q + d of the first n bases of a window (base 8 d + (q ^ 1))
+    __shared__ uint8_t s_ilist[ED_THREADS]; // per wave: the lanes of the pass's records of the shape M (I|D) M, in order
     __shared__ u64 s_acc[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (uint32_t i = tid; i < ED_HIST; i += ED_THREADS) s_h1[i] = s_h2[i] = 0;
@@ -441,7 +442,8 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
     uint32_t *const win = s_win + wv * EDR_WINDOW;
     uint32_t *const altw = s_alt + wv * EDR_ALTW;
     uint2 *const desc = s_desc + wv * 64;
-    uint32_t *const red = s_edits + wv * 64;
+    uint32_t *const red = s_edits + wv * 64; // bits 0..9: the record's edit count; bits 10..: what its second M needs (below)
+    uint8_t *const ilist = s_ilist + wv * 64;
 
     int32_t meta_ref = -1;
     uint64_t meta_eoff = NO_DEPTH, meta_boff = NO_DEPTH;
@@ -545,18 +547,26 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 if (r.n_ops > 2) r.g2 = b.cigar[cb + 2];
             }
             bool own = false, deferred = false;
-            uint32_t P = 0, vv = 0;
+            uint32_t P = 0, vv = 0, info = 0;
             if (r.ref >= 0 && (uint32_t)r.ref < st.n_refs && r.pos >= 0 && !(r.flag & 0x404u)) {
                 // [clip] M [clip]: read base q lies on 0-based reference position P + q, P = pos - (leading clip)
-                uint32_t a = 0, m = 0, z = 0;
+                uint32_t a = 0, m = 0, z = 0, m2 = 0, ins = 0, del = 0;
                 const uint32_t o0 = r.g0 & 15u, o1 = r.g1 & 15u, o2 = r.g2 & 15u;
                 bool shape = false;
                 if (r.n_ops == 1) shape = o0 == 0u, m = r.g0 >> 4;
                 else if (r.n_ops == 2 && o0 == 4u && o1 == 0u) shape = true, a = r.g0 >> 4, m = r.g1 >> 4;
                 else if (r.n_ops == 2 && o0 == 0u && o1 == 4u) shape = true, m = r.g0 >> 4, z = r.g1 >> 4;
                 else if (r.n_ops == 3 && o0 == 4u && o1 == 0u && o2 == 4u) shape = true, a = r.g0 >> 4, m = r.g1 >> 4, z = r.g2 >> 4;
-                const uint64_t e = (uint64_t)r.pos + m; // 1-based last position (span = m for these shapes)
-                const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m;
+                // M (I|D) M, an insertion or a deletion of up to 15 bases (what an aligner gives one read in sixteen): the first M
+                // is this record's entry of the window loop, as if the rest were clipped; the second M is compared in a step of its
+                // own behind that loop (2c), with the reference shifted by del - ins
+                else if (r.n_ops == 3 && o0 == 0u && (o1 == 1u || o1 == 2u) && o2 == 0u && (r.g1 >> 4) <= 15u && (r.g0 >> 4) < 512u && r.pos >= 16) {
+                    shape = true, m = r.g0 >> 4, m2 = r.g2 >> 4;
+                    ins = o1 == 1u ? r.g1 >> 4 : 0u, del = o1 == 2u ? r.g1 >> 4 : 0u;
+                    z = ins + m2; // (read bases behind the first M)
+                }
+                const uint64_t e = (uint64_t)r.pos + m + del + m2; // 1-based last position
+                const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m + del + m2;
                 // (P >= win_base: a mismatch's window entry is counted from P's)
                 own = shape && m && (uint64_t)a + m + z == r.l && r.l <= 2 * stride && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_L &&
                       i1 < EDR_WINDOW;
@@ -568,19 +578,27 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                     P = (uint32_t)(meta_boff + (P >> 1)) + (P & 1u ? odd_delta : 0u);
                     if (EDITS_EXP != 2 && EDITS_EXP != 4) {
                         atomicAdd(&win[i0], 1u);
-                        atomicAdd(&win[i1], 0xFFFFFFFFu);
+                        atomicAdd(&win[i0 + m], 0xFFFFFFFFu);
+                        if (m2) {
+                            atomicAdd(&win[i0 + m + del], 1u);
+                            atomicAdd(&win[i1], 0xFFFFFFFFu);
+                        }
                     }
                     top = max(top, (uint32_t)i1);
+                    // what step 2c needs of the record: first M's length, insertion, deletion, parity of P
+                    if (m2) info = m | ins << 9 | del << 13 | ((uint32_t)r.pos & 1u) << 17; // (m >= 1: never 0; 18 bits, kept above the 10 bits of the edit count)
                 } else {
                     deferred = true;
                 }
             }
+            const u64 imask = __ballot(info != 0u); // the pass's records with a second M
+            if (info) ilist[__builtin_amdgcn_mbcnt_hi((uint32_t)(imask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)imask, 0u))] = (uint8_t)lane;
             {   // (a record the fast path does not take is marked in the launch's bitmap: k_edits_walk does it afterwards)
                 const u64 dm = __ballot(deferred);
                 if (lane == 0) defer_bits[r0 >> 6] = dm;
             }
             desc[lane] = make_uint2(P, vv);
-            red[lane] = 0;
+            red[lane] = info << 10;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- 2b. lane = window: 16 bytes of sequence XOR 16 of the reference
@@ -617,11 +635,34 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 if (k + 4 < R) wb = load_win();
                 compare_win(wc);
             }
+            // ---- 2c. the second M of the records that have one: lane = window ww of the e-th such record (its row once more, the
+            // reference del - ins bases further on -- the other packed copy when that is odd)
+            if (imask && EDITS_EXP != 3) {
+                const uint32_t n_ind = (uint32_t)__popcll(imask);
+                for (uint32_t g = lane; g < n_ind * R; g += 64) {
+                    const uint32_t ei = (g * recip) >> 16, ww = g - ei * R, rr = ilist[ei];
+                    const uint2 d = desc[rr];
+                    const uint32_t inf = red[rr] >> 10;
+                    const uint32_t m1 = inf & 0x1FFu, ins = (inf >> 9) & 15u, del = (inf >> 13) & 15u, ppar = (inf >> 17) & 1u;
+                    const uint32_t l_rd = min(b.l_seq[r0 + rr], 2u * stride);
+                    const int32_t shift = (int32_t)del - (int32_t)ins, t = (int32_t)ppar + shift; // P2 = P + shift
+                    const uint32_t off2 = (uint32_t)((int32_t)(d.x - (ppar ? odd_delta : 0u)) + (t >> 1)) + ((t & 1) ? odd_delta : 0u);
+                    const uint32_t b0 = 32u * ww, v0 = m1 + ins, v1 = l_rd;
+                    Win w;
+                    __builtin_memcpy(&w.sv, rows + rr * stride + 16u * ww, 16);
+                    __builtin_memcpy(&w.rv, st.ref_bases + (off2 + 16u * ww), 16);
+                    w.slot = rr, w.ww = ww;
+                    w.x0 = (uint32_t)((int32_t)(d.y >> 18) + shift + (int32_t)b0);
+                    const uint32_t lo = min(v0 > b0 ? v0 - b0 : 0u, 32u), hi = min(v1 > b0 ? v1 - b0 : 0u, 32u);
+                    w.lohi = lo | hi << 8;
+                    compare_win(w);
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- 3. lane = record: edits.rs:296-300
             if (own) {
-                const uint32_t edits = red[lane];
+                const uint32_t edits = red[lane] & 0x3FFu;
                 if (edits > 512u) c_too_many += 1;
                 else if (edits < ED_HIST) atomicAdd((r.flag & 0x40u) ? &s_h1[edits] : &s_h2[edits], 1u);
                 else atomicAdd(&st.counters[((r.flag & 0x40u) ? st.off_edits1 : st.off_edits2) + edits], 1ull);

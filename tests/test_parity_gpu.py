@@ -376,12 +376,13 @@ def brute_force_refs_alts(hb, ref_len, bases):
     return refs, alts
 
 
-@pytest.mark.parametrize("mode", ["fixed", "mixed", "iid", "random"])
+@pytest.mark.parametrize("mode", ["fixed", "aligner", "mixed", "iid", "random"])
 def test_edits_positions_against_a_literal_walk(gpu_lib, oracle_mod, mode):
     """Round 4's Edits kernel keeps the `M` cover as a difference array and only the mismatches per position; refs = cover -
     alts appears at the teardown.  ngsq_get_edits_positions against a literal Python walk of every record, and the histograms
     against the oracle, on reads SAMPLED FROM the reference (0.5 % substitutions: the sparse case the kernel is built for,
-    fixed 150 bases and the 50-300 base CIGAR mix), on independent bases (three in four mismatch: every dword is revisited)
+    fixed 150 bases, the same with an aligner's CIGARs -- 9 % soft-clipped, 3 % an insertion, 3 % a deletion: fixed-pitch rows
+    whose marked records the walk kernel lists and takes 64 at a time -- and the 50-300 base CIGAR mix), on independent bases (three in four mismatch: every dword is revisited)
     and on random records (every CIGAR shape, unsorted, reads that run out of bases)."""
     rng = np.random.default_rng(77)
     if mode == "random":
@@ -391,7 +392,8 @@ def test_edits_positions_against_a_literal_walk(gpu_lib, oracle_mod, mode):
     else:
         ref_len = [150_000, 20_000]
         cfg = host.synth_config(30_000, mode=ffi.SYNTH_MIXED if mode == "mixed" else ffi.SYNTH_FIXED, ref_len=ref_len[0], n_refs=2,
-                                seq_model=ffi.SYNTH_SEQ_IID if mode == "iid" else ffi.SYNTH_SEQ_FROM_REFERENCE)
+                                seq_model=ffi.SYNTH_SEQ_IID if mode == "iid" else ffi.SYNTH_SEQ_FROM_REFERENCE,
+                                file_style=ffi.SYNTH_FILE_CIGAR_MIX if mode == "aligner" else 0)
         bases = [host.synth_reference(cfg, r, L, gpu_lib) for r, L in enumerate(ref_len)]
         hb = host.synth_host_batch(cfg, 0, 30_000, gpu_lib)
     gpu, orc = run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=ffi.FACET_EDITS, ref_bases=bases)
@@ -400,7 +402,9 @@ def test_edits_positions_against_a_literal_walk(gpu_lib, oracle_mod, mode):
         refs, alts = gpu.edits_positions(r)
         assert np.array_equal(alts, want_alts[r]) and np.array_equal(refs, want_refs[r]), (mode, r)
     r1, r2, vaf = gpu.edits()
-    if mode in ("fixed", "mixed"):      # ~0.75 substitutions per 150 bases: most reads have none or one
+    if mode == "aligner":
+        assert (hb.cols["n_cigar"] == 3).mean() > 0.04 and hb.cigar_stride == 3
+    if mode in ("fixed", "aligner", "mixed"):      # ~0.75 substitutions per 150 bases: most reads have none or one
         assert r1[0] + r2[0] > 0.2 * hb.n and (r1[:4].sum() + r2[:4].sum()) > 0.9 * (r1.sum() + r2.sum())
     if mode == "iid":
         assert r1[:50].sum() + r2[:50].sum() == 0
