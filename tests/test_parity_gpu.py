@@ -410,6 +410,54 @@ def test_edits_positions_against_a_literal_walk(gpu_lib, oracle_mod, mode):
         assert r1[:50].sum() + r2[:50].sum() == 0
 
 
+@pytest.mark.parametrize("sorted_rows,cigar_offsets", [(True, False), (True, True), (False, False)])
+def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar_offsets):
+    """k_edits_rows compares the second M of `M (I|D) M` in a step of its own (edits_kernel.hip 2c), against the reference
+    del - ins bases further on.  Every place that arithmetic can go wrong, one record each on 150-base fixed-pitch rows, the
+    literal Python walk and the oracle as judges: the indel at a window boundary (32, 64, 96, 128 bases), one base before and
+    behind it, first M of one base, second M of one base, insertions and deletions of 1, 2, 7, 8 and 15 bases (the shift odd and
+    even: both packed copies of the reference), 16 bases (left to the walk kernel), positions 0, 15 (walk) and 16, odd and even."""
+    from tests.util import to_fixed_stride
+    rng = np.random.default_rng(4242)
+    ref_len = [40_000, 3_000]
+    bases = random_ref_bases(rng, ref_len)
+    L, recs, pos = 150, [], 16
+    for a in (1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 140, 148):
+        for g, op in ((1, "I"), (2, "I"), (7, "I"), (8, "I"), (15, "I"), (16, "I"), (1, "D"), (2, "D"), (7, "D"), (8, "D"), (15, "D"), (16, "D")):
+            m2 = L - a - (g if op == "I" else 0)
+            if m2 < 1:
+                continue
+            for p in (pos, pos + 1):
+                # the read: the reference under both M segments, random bases in the insertion, a substitution in each segment
+                ref0 = p
+                seg1 = bases[0][ref0:ref0 + a].copy()
+                seg2 = bases[0][ref0 + a + (g if op == "D" else 0):ref0 + a + (g if op == "D" else 0) + m2].copy()
+                seg1[a // 2] = 1 if seg1[a // 2] != 1 else 2
+                seg2[m2 // 2] = 4 if seg2[m2 // 2] != 4 else 8
+                codes = np.concatenate([seg1, rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), g if op == "I" else 0), seg2])
+                recs.append(dict(flag=0x40 if len(recs) % 2 else 0, mapq=60, ref_id=0, pos=p, mate_ref_id=-1, tlen=0,
+                                 cigar=f"{a}M{g}{op}{m2}M", seq="".join("=ACMGRSVTWYHKDBN"[c] for c in codes), qual=[30] * L))
+            pos += 5
+    for p in (0, 15):   # too close to the sequence's start for the shifted reference: the walk kernel's
+        recs.append(dict(flag=0, mapq=60, ref_id=0, pos=p, mate_ref_id=-1, tlen=0, cigar="70M3I77M",
+                         seq="".join("=ACMGRSVTWYHKDBN"[c] for c in np.concatenate([bases[0][p:p + 70], [1, 1, 1], bases[0][p + 70:p + 147]])), qual=[30] * L))
+    if sorted_rows:
+        recs.sort(key=lambda r: r["pos"])
+    hv = batch_from_records(recs)
+    hb = to_fixed_stride(hv)
+    assert hb.seq_stride == 75 and hb.cigar_stride == 3
+    if cigar_offsets:   # fixed-pitch SEQ / QUAL rows with the CIGARs through offsets: what the device reader makes of an aligner's file
+        cols = dict(hb.cols)
+        cols["cigar"], cols["cigar_off"] = hv.cols["cigar"], hv.cols["cigar_off"]
+        hb = host.HostBatch(hb.n, cols, hb.seq_stride, hb.qual_stride, 0, 0)
+    gpu, orc = run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=ffi.FACET_EDITS, ref_bases=bases)
+    want_refs, want_alts = brute_force_refs_alts(hb, ref_len, bases)
+    refs, alts = gpu.edits_positions(0)
+    assert np.array_equal(alts, want_alts[0]) and np.array_equal(refs, want_refs[0])
+    r1, r2, _ = gpu.edits()
+    assert int(r1.sum() + r2.sum()) == len(recs) and int(r1[2] + r2[2]) >= len(recs) - 2   # two substitutions per read
+
+
 def test_reference_bases_must_be_4_bit_codes(gpu_lib):
     bad = np.full(100, 1, dtype=np.uint8)
     bad[57] = 65   # an ASCII letter instead of a code
