@@ -417,12 +417,15 @@ __global__ __launch_bounds__(1024) void k_qual_ragged(DeviceState st, const uint
     if (lane == 0 && r1) atomicAdd(&st.counters[C_ERR + E_READ_TOO_LONG], (u64)r1);
 }
 
+#ifndef NGSQ_QR_NROT
+#define NGSQ_QR_NROT 4 // dword orders the records of a wave rotate through (1, 2 or 4: measurement builds)
+#endif
 template <uint32_t R>
 static hipError_t launch_ragged_r(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s) {
     const uint32_t lds = qr_table_bytes(R) + 16u * 64u * R + 17u * 16u; // table + one window->record byte map per wave + the keep masks
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_ragged<R, 4>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_qual_ragged<R, NGSQ_QR_NROT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr = true;
@@ -431,7 +434,7 @@ static hipError_t launch_ragged_r(const LaunchInfo &li, const DeviceState &st, c
     uint64_t g = (b.n + 1023) / 1024;
     if (g > (uint64_t)li.n_cu * per_cu) g = (uint64_t)li.n_cu * per_cu;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL((k_qual_ragged<R, 4>), dim3((uint32_t)g), dim3(1024), lds, s, st, b.qual, b.qual_off, b.n);
+    hipLaunchKernelGGL((k_qual_ragged<R, NGSQ_QR_NROT>), dim3((uint32_t)g), dim3(1024), lds, s, st, b.qual, b.qual_off, b.n);
     return hipGetLastError();
 }
 
