@@ -89,6 +89,11 @@ def parse_args():
     ap.add_argument("--file-level", type=int, default=6, help="zlib level of that BAM")
     ap.add_argument("--h2d-batch", type=int, default=4_000_000, help="records per host batch of the h2d_inclusive leg (0 = skip)")
     ap.add_argument("--extra-facet-records", type=int, default=100_000_000, help="records of the Edits / Genomic Features leg")
+    ap.add_argument("--live-traffic", type=int, default=1,
+                    help="1 (N = 1, default workload): two short passes of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE -- "
+                         "separate passes, child processes started before this one touches HIP) give roofline.traffic of THIS run; "
+                         "0, or any failure: the committed profiles/*_traffic.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--extra-facet-legs", type=int, default=1,
                     help="1: also time the Edits and Genomic Features kernels on a 10 M-record slice (N = 1 only)")
     return ap.parse_args()
@@ -152,6 +157,13 @@ def main() -> int:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    live = (None, None)
+    if (world == 1 and args.live_traffic and not args.pmc_child and args.workload == "fixed" and not args.emulate_shard and not args.force_dist
+            and (args.facets & 0x08)):
+        live = live_pmc_traffic(args)   # (child processes; nothing in this process has touched HIP yet)
+        if args.mixed_records > 0 and args.facets == 0x1F:
+            args.live_mixed = live_pmc_traffic(args, mixed=True)
 
     import numpy as np
     from ngs_amd import ffi, host, shard
@@ -228,7 +240,7 @@ def main() -> int:
     # N = 1: the OTHER Coverage path on the same resident records, so that the 1 -> 2 step of the scaling curve (which
     # switches from streaming to the difference arrays: DESIGN.md section 5.4) can be read as communication only
     coverage_paths = None
-    if world == 1 and not args.emulate_shard and (args.facets & ffi.FACET_COVERAGE) and not args.force_dist:
+    if world == 1 and not args.emulate_shard and (args.facets & ffi.FACET_COVERAGE) and not args.force_dist and not args.pmc_child:
         other = "array" if args.coverage == "stream" else "stream"
         coverage_paths = {args.coverage: round(elapsed / args.steps * 1e3, 3)}
         try:
@@ -266,8 +278,14 @@ def main() -> int:
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_ms": round(avg_ms, 4),
                         "algo_bytes_per_launch": q["algo_bytes"] // q["launches"]}
-            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(n, args)
-            roofline["traffic_measured_in_this_run"] = False  # PMC passes are separate rocprofv3 runs (tools/profile_round.sh)
+            if live[0] is not None and not mixed:
+                roofline["traffic"], roofline["traffic_source"] = live
+                roofline["traffic_measured_in_this_run"] = True   # by this command: separate rocprofv3 --pmc passes of the same workload
+            else:
+                roofline["traffic"], roofline["traffic_source"] = pmc_traffic(n, args)
+                roofline["traffic_measured_in_this_run"] = False  # the committed PMC summary (tools/profile_round.sh)
+                if live[1]:
+                    roofline["live_traffic_unavailable"] = live[1]
         kernels = kernel_table(timing)
         out = {
             "metric": "BAM records/sec (whole node), all qc facets, 150 bp reads",
@@ -316,7 +334,7 @@ def main() -> int:
         comm.destroy()
     if rank == 0:
         # ---- the legs beside the headline number: rank 0 at N = 1 only, each bounded to seconds
-        if world == 1 and not args.emulate_shard:
+        if world == 1 and not args.emulate_shard and not args.pmc_child:
             if args.cpu_sample > 0:
                 out["cpu_baseline"] = cpu_baseline(lib, host, ffi, scfg, min(args.cpu_sample, n), max_len)
             if args.mixed_records > 0 and not mixed:
@@ -441,6 +459,49 @@ def inflate_traffic(algo_bytes_per_launch: int):
                 "traffic_measured_in_this_run": False}
     except Exception as e:  # noqa: BLE001
         return {"traffic": None, "traffic_source": f"unavailable: {e}"}
+
+
+def live_pmc_traffic(args, mixed=False):
+    """HBM bytes per launch of the dominant kernel from two rocprofv3 --pmc passes of this same workload (3 steps each), run as
+    child processes BEFORE this process initialises HIP.  MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in separate passes;
+    on gfx950 the read side is doubled (checked on kernels with known byte counts: profiles/r04_fetch_calib.txt).  Returns
+    (bytes or None, source text)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="ngsq_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out_dir, "-o", "out", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "1", "--no-timing",
+                   "--records", str(args.mixed_records if mixed else args.records), "--read-len", str(args.read_len),
+                   "--facets", hex(args.facets & 0x1F if mixed else args.facets), "--coverage", "auto" if mixed else args.coverage]
+            if mixed:
+                cmd += ["--workload", "mixed", "--mixed-max-len", str(args.mixed_max_len)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=tmp)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"
+            tot, cnt = 0.0, 0
+            with open(files[0], newline="") as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in (("k_qual_ragged",) if mixed else ("k_qual_perm", "k_qual_win"))):
+                        tot += float(row["Counter_Value"])
+                        cnt += 1
+            if not cnt:
+                return None, f"no {counter} rows for the quality kernel"
+            vals[counter] = tot / cnt * 1024.0
+        return int(round(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"])), ("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this workload, 3 steps "
+                                                                            "each, run by this command before its own timed steps; read side doubled (gfx950)")
+    except Exception as e:  # noqa: BLE001 -- never required
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_traffic(n: int, args):
@@ -867,9 +928,13 @@ def leg_mixed(lib, host, ffi, np, args, device):
             avg_ms = q["total_ms"] / q["launches"]
             achieved = (q["algo_bytes"] / q["launches"]) / (avg_ms * 1e-3) / 1e9
             traffic, src = pmc_traffic(n, margs)
+            lm = getattr(args, "live_mixed", (None, None))
+            measured = lm[0] is not None
+            if measured:
+                traffic, src = lm
             out["roofline"] = {"bound": "hbm", "kernel": "k_qual_ragged", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-                               "traffic_measured_in_this_run": False, "avg_launch_ms": round(avg_ms, 4),
+                               "traffic_measured_in_this_run": measured, "avg_launch_ms": round(avg_ms, 4),
                                "algo_bytes_per_launch": q["algo_bytes"] // q["launches"]}
         return out
     finally:
