@@ -162,7 +162,7 @@ def main() -> int:
     if (world == 1 and args.live_traffic and not args.pmc_child and args.workload == "fixed" and not args.emulate_shard and not args.force_dist
             and (args.facets & 0x08)):
         live = live_pmc_traffic(args)   # (child processes; nothing in this process has touched HIP yet)
-        if args.mixed_records > 0 and args.facets == 0x1F:
+        if args.mixed_records > 0 and args.facets == 0x1F and live[0] is not None:   # (not after a failure: at most one time limit is spent)
             args.live_mixed = live_pmc_traffic(args, mixed=True)
 
     import numpy as np
@@ -483,7 +483,7 @@ def live_pmc_traffic(args, mixed=False):
                    "--facets", hex(args.facets & 0x1F if mixed else args.facets), "--coverage", "auto" if mixed else args.coverage]
             if mixed:
                 cmd += ["--workload", "mixed", "--mixed-max-len", str(args.mixed_max_len)]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=tmp)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=90, cwd=tmp)   # (a pass takes ~5 s)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"
