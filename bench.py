@@ -472,6 +472,12 @@ def live_pmc_traffic(args, mixed=False):
     import tempfile
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not on PATH"
+    # Not under a profiler: a tool library preloaded into THIS process has initialised the GPU already, and starting another
+    # program from such a process is what the GPU boxes of this pool refuse (and a profiler inside a profiler measures nothing).
+    for k, v in os.environ.items():
+        if k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD") or k.startswith("ROCPROF") or \
+                (k == "LD_PRELOAD" and "rocprof" in v.lower()):
+            return None, f"running under a profiler ({k} is set)"
     tmp = tempfile.mkdtemp(prefix="ngsq_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     vals = {}
     try:

@@ -9,8 +9,8 @@ for set in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC
   k=$((k+1))
   rm -rf /tmp/cal_a$k /tmp/cal_b$k /tmp/cal_c$k
   rocprofv3 --pmc $set --kernel-trace -d /tmp/cal_a$k -o out --output-format csv -- /tmp/fetch_calib 4096 10 15 > /tmp/cal_a$k.log 2>&1
-  rocprofv3 --pmc $set --kernel-trace -d /tmp/cal_b$k -o out --output-format csv -- python3 $R/bench.py --workload mixed --steps 2 --warmup 1 --cpu-sample 0 > /tmp/cal_b$k.log 2>&1
-  rocprofv3 --pmc $set --kernel-trace -d /tmp/cal_c$k -o out --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --file-records 0 --h2d-batch 0 --extra-facet-legs 0 --mixed-records 0 > /tmp/cal_c$k.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d /tmp/cal_b$k -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 2 --warmup 1 --cpu-sample 0 > /tmp/cal_b$k.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d /tmp/cal_c$k -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 2 --warmup 1 --cpu-sample 0 --file-records 0 --h2d-batch 0 --extra-facet-legs 0 --mixed-records 0 > /tmp/cal_c$k.log 2>&1
 done
 { cat /tmp/calib_plain.txt
 python3 - <<'PY'

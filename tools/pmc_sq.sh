@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 k=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS_ATOMIC SQ_LDS_ADDR_CONFLICT"; do
   k=$((k+1))
-  rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmc_set$k -o out --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-timing "$@" > $R/gpurun_out/pmc_set$k.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmc_set$k -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 2 --warmup 1 --cpu-sample 0 --no-timing "$@" > $R/gpurun_out/pmc_set$k.log 2>&1
 done
 cd $R && python3 - <<'PY' | tee gpurun_out/sq_summary.txt
 import csv,glob,collections
