@@ -26,7 +26,8 @@ def test_launcher_without_gpu(n):
 def _run_bench(*flags):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--records", "2000000",
-                           "--cpu-sample", "100000", "--extra-facet-records", "1000000", "--file-big-records", "0", *flags],
+                           "--cpu-sample", "100000", "--extra-facet-records", "1000000", "--file-big-records", "0",
+                           "--file-realistic-records", "400000", "--mixed-records", "2000000", "--mixed-steps", "3", *flags],
                           capture_output=True, text=True, env=env, timeout=1500)
 
 
@@ -51,6 +52,12 @@ def test_bench_line_contract(flags):
     if d["n_gpus"] == 1:
         assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
         assert fe["json_equal_device_host_inprocess"] is True and fe["check_total"] == 300000
+        # round 4: the aligner-style file, the mixed-CIGAR workload, Edits on an aligner's CIGARs
+        assert fe["realistic"]["same_document_as_host_reader"] is True and fe["realistic"]["check_total"] == fe["realistic"]["records"]
+        assert fe["realistic"]["inflated_bytes_per_record"] > 330
+        assert d["mixed"]["parity_check"].startswith("ok") and d["mixed"]["roofline"]["kernel"] == "k_qual_ragged"
+        assert d["extra_facets"]["edits_aligner_cigars"]["avg_ms"] > 0
+        assert isinstance(d["roofline"]["traffic_measured_in_this_run"], bool)
     else:
         assert fe["json_equal_sharded_one_gpu"] is True and fe["in_process"]["json_equal_one_gpu"] is True
         assert fe["check_total"] == fe["records"] == fe["in_process"]["check_total"]
