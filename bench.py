@@ -158,6 +158,7 @@ def main() -> int:
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    build_once()   # (touches no HIP; before the profiled child passes, so that they only ever LOAD a built library: ADVICE r4)
     live = (None, None)
     if (world == 1 and args.live_traffic and not args.pmc_child and args.workload == "fixed" and not args.emulate_shard and not args.force_dist
             and (args.facets & 0x08)):
@@ -168,7 +169,6 @@ def main() -> int:
     import numpy as np
     from ngs_amd import ffi, host, shard
 
-    build_once()
     lib = ffi.load_library()
     if lib.ngsq_device_count() < 1:
         print("bench.py: no HIP device visible; the hot path has no CPU fallback", file=sys.stderr)

@@ -75,6 +75,12 @@ extern "C" {
 /* where a batch's column pointers live */
 #define NGSQ_MEM_HOST 0u
 #define NGSQ_MEM_DEVICE 1u
+/* NGSQ_MEM_DEVICE batches: the kernels read the seq and qual columns (and cigar) with 16-byte vector loads, so the last
+ * row is read up to 15 bytes past its end.  Every column of a device batch must be READABLE for this many bytes behind its
+ * last element (the bytes' values do not matter).  ngsq_device_malloc adds the slack to every allocation by itself, the
+ * readers of ngsq_bam.h and ngsq_synth.h allocate with it, host batches are staged with it; only a caller that hands
+ * over memory from its own hipMalloc has to size it `bytes + NGSQ_DEVICE_COLUMN_SLACK`. */
+#define NGSQ_DEVICE_COLUMN_SLACK 64u
 
 typedef struct ngsq_ctx ngsq_ctx;
 
@@ -409,7 +415,8 @@ int ngsq_state_download(ngsq_ctx *ctx, int which /*0 counters,1 depth,2 edits,3 
                         uint64_t n_bytes);
 int ngsq_state_upload(ngsq_ctx *ctx, int which, const void *src, uint64_t n_bytes);
 
-/* ---- device memory helpers so a host without a HIP binding can stage batches ---- */
+/* ---- device memory helpers so a host without a HIP binding can stage batches ----
+ * ngsq_device_malloc allocates n_bytes + NGSQ_DEVICE_COLUMN_SLACK (see there). */
 int ngsq_device_malloc(ngsq_ctx *ctx, uint64_t n_bytes, void **dev_ptr);
 int ngsq_device_free(ngsq_ctx *ctx, void *dev_ptr);
 int ngsq_memcpy_h2d(ngsq_ctx *ctx, void *dev_dst, const void *host_src, uint64_t n_bytes);

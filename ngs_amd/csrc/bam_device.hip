@@ -368,7 +368,7 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
         }
     }
     uint32_t ml = 0, mo = 0;
-    unsigned long long sl = 0, so = 0, order = 0; // order: results of this thread's atomics (waited for in front of the ticket)
+    unsigned long long sl = 0, so = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * PT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PT) {
         const uint64_t o = rec_off[i] + 4;
         uint4 a, b;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
                 if (at && cnt >= 2) { // (as the host reader: a tag with fewer operations than the placeholder is ignored)
                     cig_at = o + need + at;
                     real_ops = cnt;
-                    order += atomicAdd(&work[W_LONG], 1ull);
+                    (void)atomicAdd(&work[W_LONG], 1ull);
                 }
             }
         }
@@ -420,8 +420,8 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
             }
             org.record_id[i] = id;
         }
-        if (i == 0) order += atomicExch(&work[W_FIRST], (unsigned long long)a.x << 32 | a.y);
-        if (i == n - 1) order += atomicExch(&work[W_LAST], (unsigned long long)a.x << 32 | a.y);
+        if (i == 0) (void)atomicExch(&work[W_FIRST], (unsigned long long)a.x << 32 | a.y);
+        if (i == n - 1) (void)atomicExch(&work[W_LAST], (unsigned long long)a.x << 32 | a.y);
         ml = max(ml, l);
         mo = max(mo, real_ops);
         sl += l;
@@ -433,8 +433,10 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
         mo = max(mo, (uint32_t)__shfl_xor((int)mo, o, 64));
         sl += __shfl_xor(sl, o, 64);
         so += __shfl_xor(so, o, 64);
-        order |= __shfl_xor(order, o, 64);
     }
+    // this thread's tallies (W_LONG / W_FIRST / W_LAST) have reached the L2 before the block's barrier is passed (the
+    // barrier itself only waits for LDS, and the atomics return nothing a later instruction would wait for)
+    NGSQ_WAIT_VMEM();
     const uint32_t w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         s_ml[w] = ml;
@@ -452,15 +454,18 @@ __global__ __launch_bounds__(PT) void k_rec_fixed(const uint8_t *__restrict__ ra
             t += s_sl[k];
             u += s_so[k];
         }
-        // the block's tallies, then its ticket: the atomics' RESULTS are waited for (they feed the ticket's operand), which puts
-        // them in front of it without a release fence -- on gfx950 an agent-scope release is a write-back of the XCD's L2
-        order |= atomicMax(&work[W_MAXL], (unsigned long long)a);
-        order |= atomicMax(&work[W_MAXOPS], (unsigned long long)b);
-        order |= atomicAdd(&work[W_SUML], t);
-        order |= atomicAdd(&work[W_SUMOPS], u);
-        unsigned long long one = 1ull + (order >> 63 >> 1); // = 1
-        asm volatile("" : "+v"(one));
-        const unsigned long long ticket = atomicAdd(&work[W_TICKET], one);
+        // the block's tallies, then its ticket.  What puts them in front of it is an explicit `s_waitcnt vmcnt(0)`: the tallies
+        // are device-scope atomics executed at the L2, acknowledged in order, and the ticket is not issued before the last of
+        // them has been -- no release fence (on gfx950 an agent-scope release is a write-back of the XCD's L2), and nothing the
+        // optimiser can fold away (until round 4 the ticket's operand was meant to depend on the atomics' results: it was
+        // constant-folded and the atomics became no-return instructions nobody waited for -- ADVICE r4;
+        // tests/test_abi.py::test_rec_fixed_ticket_is_ordered_behind_the_tallies reads the ISA)
+        (void)atomicMax(&work[W_MAXL], (unsigned long long)a);
+        (void)atomicMax(&work[W_MAXOPS], (unsigned long long)b);
+        (void)atomicAdd(&work[W_SUML], t);
+        (void)atomicAdd(&work[W_SUMOPS], u);
+        NGSQ_WAIT_VMEM();
+        const unsigned long long ticket = atomicAdd(&work[W_TICKET], 1ull);
         s_last = ticket == (unsigned long long)gridDim.x - 1ull;
         if (s_last) {
             host[H_MAXL] = atomicExch(&work[W_MAXL], 0ull);

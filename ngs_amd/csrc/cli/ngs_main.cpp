@@ -856,8 +856,11 @@ int main(int argc, char **argv) {
             int again = 0;
             comm_ready();
             const int vrc = ngsq_bam_shard_verify(bam, ctx, comm, &info, &again);
-            // (a scan that failed while it ran from an ASSUMED first record is forgiven once: the verdict is `again`)
-            if (vrc != NGSQ_OK && !scan_error.empty()) bail(scan_error);
+            // (a scan that failed while it ran from an ASSUMED first record is forgiven once: the verdict is `again`.  Only the
+            // round that scanned reports its own failure: a worker that keeps its state while its predecessor is still being
+            // re-armed must not answer a LATER round's failure -- another shard's, the transport's -- with the error it was
+            // forgiven for: ADVICE r4)
+            if (vrc != NGSQ_OK && scanning && !scan_error.empty()) bail(scan_error);
             if (vrc == NGSQ_ERR_UNSORTED) { // neighbouring shards out of coordinate order: same verdict on every worker
                 shard_unsorted = true;
                 break;
@@ -868,10 +871,12 @@ int main(int argc, char **argv) {
                      (unsigned long long)info.first_record_index);
                 break;
             }
+            const std::string forgiven = scan_error;
+            scan_error.clear();
             scanning = info.rescan != 0;
             if (scanning) {
                 logf(1, "worker %d: the assumed first record of its shard was not one%s; scanning the shard again from the confirmed offset", a.rank,
-                     scan_error.empty() ? "" : (" (" + scan_error + ")").c_str());
+                     forgiven.empty() ? "" : (" (" + forgiven + ")").c_str());
                 CHECK(ctx, ngsq_reset(ctx));
             }
         }

@@ -1184,7 +1184,7 @@ int ngsq_state_upload(ngsq_ctx *c, int which, const void *src, uint64_t n_bytes)
 int ngsq_device_malloc(ngsq_ctx *c, uint64_t n, void **p) {
     if (!c || !p) return NGSQ_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMalloc(p, n ? n : 1));
+    HIP_TRY(c, hipMalloc(p, n + NGSQ_DEVICE_COLUMN_SLACK)); // the kernels' 16-byte loads read past a column's last row (ngsq.h)
     return NGSQ_OK;
 }
 int ngsq_device_free(ngsq_ctx *c, void *p) {

@@ -12,6 +12,12 @@
 #define NGSQ_FOREGROUND_WAVE() __builtin_amdgcn_s_setprio(3)
 #endif
 
+// Every vector-memory operation this wave has issued (loads, stores, atomics without a result) has been acknowledged by the L2
+// when this returns: orders device-scope atomics in front of a later one without a release fence (k_rec_fixed's ticket).
+#ifndef NGSQ_WAIT_VMEM
+#define NGSQ_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 namespace ngsq {
 
 // one BGZF block (SAM/BAM specification 4.1): the raw DEFLATE payload of one gzip member

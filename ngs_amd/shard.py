@@ -225,11 +225,12 @@ class Comm:
                 # scan ran from an ASSUMED first record: then the assumption may be what failed, and the shard is scanned
                 # again from the offset its neighbour confirms)
                 rc = self.lib.ngsq_bam_shard_verify(h, ctx._ctx, self._h, C.byref(info), C.byref(again))
-                if rc != 0 and err is not None:
+                if rc != 0 and scanning and err is not None:   # (only the round that scanned reports its own failure: ADVICE r4)
                     raise RuntimeError(err)
                 self._check(rc)
                 if scanning and err is None:
                     mine = n
+                err = None                                      # forgiven by this round's verdict
                 if not again.value:
                     return info, rounds, mine
                 rounds += 1

@@ -172,3 +172,34 @@ def test_oracle_defaults_are_the_reference_s(oracle_mod):
     assert doc["gc_content"]["histogram"]["range_stop"] == 100
     assert doc["coverage"]["coverage_distribution"]["range_stop"] == want["coverage_histogram_capacity"]
     assert sorted(doc["coverage"]["genome_covered_by"]) == sorted(f"{c}x" for c in want["genome_covered_by"])
+
+
+def test_rec_fixed_ticket_is_ordered_behind_the_tallies(tmp_path):
+    """k_rec_fixed's last block publishes the batch's layout statistics (longest read, most CIGAR operations,
+    sums) that size the CIGAR column -- every block's tallies must have reached the L2 before its ticket is drawn.  The
+    ordering is an explicit `s_waitcnt vmcnt(0)`; this reads the gfx950 ISA the product's flags produce and requires (a) one
+    such wait between the last tally atomic and the ticket (the returning add), (b) one in front of the block's barrier."""
+    from ngs_amd import build
+    src = os.path.join(build.CSRC, "bam_device.hip")
+    out = tmp_path / "bam_device.s"
+    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    subprocess.run([build.hipcc()] + flags + ["--cuda-device-only", "-S", src, "-o", str(out)], check=True, cwd=build.CSRC,
+                   stderr=subprocess.DEVNULL)
+    body, on = [], False
+    for line in open(out):
+        if re.match(r"^_ZN4ngsq11k_rec_fixed\w*:", line):
+            on = True
+        if on:
+            body.append(line.strip())
+            if line.strip().startswith("s_endpgm"):
+                break
+    assert body, "k_rec_fixed not found in the ISA"
+    ops = [l for l in body if re.match(r"(global_atomic|s_waitcnt vmcnt\(0\)|s_barrier)", l)]
+    barrier = ops.index("s_barrier")
+    assert "s_waitcnt vmcnt(0)" in ops[:barrier], "no vmcnt(0) in front of the block's barrier"
+    after = ops[barrier + 1:]
+    # the four tallies (two max, two add, none returning), a wait, then the returning ticket add
+    ticket = next(k for k, l in enumerate(after) if l.startswith("global_atomic_add_x2") and "sc0" in l)
+    tallies = [l for l in after[:ticket] if l.startswith("global_atomic")]
+    assert len(tallies) == 4 and sum(l.startswith("global_atomic_umax_x2") for l in tallies) == 2, tallies
+    assert after[ticket - 1] == "s_waitcnt vmcnt(0)", after[:ticket + 1]
