@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
 SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "cov_stream.hip", "synth.hip", "bgzf_inflate.hip",
-           "bam_device.hip", "features_kernel.hip", "edits_kernel.hip", "exchange_kernels.hip", "comm.cpp", "exchange.cpp", "mem_pool.cpp", "context.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
+           "bam_device.hip", "features_kernel.hip", "edits_kernel.hip", "exchange_kernels.hip", "comm.cpp", "exchange.cpp", "mem_pool.cpp", "context.cpp", "stager.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
 HEADERS = ["kernels.h", "context.h", "comm.h", "mem_pool.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h", "../../include/ngsq_comm.h",
-           "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h"]
+           "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h", "../../include/ngsq_stage.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-gpu-rdc"]
 FLAGS += os.environ.get("NGSQ_EXTRA_FLAGS", "").split()  # measurement builds, e.g. -DNGSQ_INFLATE_PROFILE (use --force)
 OBJ_DIR = os.path.join(HERE, "_obj")  # per-source objects (git-ignored): only changed sources recompile

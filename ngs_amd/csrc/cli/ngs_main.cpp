@@ -37,6 +37,7 @@
 
 #include "../../../include/ngsq.h"
 #include "../../../include/ngsq_bam.h"
+#include "../../../include/ngsq_stage.h"
 #include "../../../include/ngsq_comm.h"
 
 namespace {
@@ -189,57 +190,31 @@ static inline uint64_t n_ops_of(const ngsq_batch &b, uint64_t i) {
 }
 
 // ---- record subsets for the `-n` rules -----------------------------------------------------
-struct Compact { // offsets-layout batch assembled from picked records
-    std::vector<uint16_t> flag, n_cigar;
-    std::vector<uint8_t> mapq, seq, qual;
-    std::vector<int32_t> ref_id, pos, mate_ref_id, tlen;
-    std::vector<uint32_t> l_seq, cigar;
-    std::vector<uint64_t> seq_off{0}, qual_off{0}, cigar_off{0}, record_id;
+// Records picked one by one (the two -n rules: command.rs:305-316 with display.rs:58-63, command.rs:354,384-388) go through the
+// per-record side of the boundary, include/ngsq_stage.h -- the calls a host that keeps the reference's loops would make:
+// push per record, flush when full and at the end of the pass.
+struct Picker {
+    ngsq_stager *s = nullptr;
+    ngsq_ctx *ctx;
+    uint32_t pass;
+    uint64_t expect;
+    Picker(ngsq_ctx *c, uint32_t pass_mask, uint64_t expect_) : ctx(c), pass(pass_mask), expect(expect_) {}
+    ~Picker() { ngsq_stager_destroy(s); }
     void push(const ngsq_batch &b, uint64_t i) {
-        record_id.push_back(b.record_id ? b.record_id[i] : b.first_record_index + i); // the record keeps its identity (GC window)
-        flag.push_back(b.flag[i]);
-        mapq.push_back(b.mapq[i]);
-        ref_id.push_back(b.ref_id[i]);
-        pos.push_back(b.pos[i]);
-        mate_ref_id.push_back(b.mate_ref_id[i]);
-        tlen.push_back(b.tlen[i]);
-        l_seq.push_back(b.l_seq[i]);
-        n_cigar.push_back(b.n_cigar[i]);
+        if (!s && ngsq_stager_create(std::min<uint64_t>(std::max<uint64_t>(expect, 1), 1u << 20), NGSQ_STAGE_PINNED, &s) != NGSQ_OK)
+            bail(ngsq_stager_last_error(nullptr)); // (created with the first record: -n 1000 pins a few hundred KB)
         const uint32_t l = b.l_seq[i];
-        const uint8_t *s = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
-        seq.insert(seq.end(), s, s + (l + 1) / 2);
-        seq_off.push_back(seq.size());
-        if (b.qual_off) {
-            qual.insert(qual.end(), b.qual + b.qual_off[i], b.qual + b.qual_off[i + 1]);
-        } else {
-            const uint8_t *q = b.qual + i * (uint64_t)b.qual_stride;
-            bool missing = l > 0;
-            for (uint32_t k = 0; k < l && missing; k++) missing = q[k] == 0xFF;
-            if (!missing) qual.insert(qual.end(), q, q + l);
-        }
-        qual_off.push_back(qual.size());
+        const uint8_t *sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
+        const uint8_t *ql = b.qual_off ? (b.qual_off[i + 1] > b.qual_off[i] ? b.qual + b.qual_off[i] : nullptr) : b.qual + i * (uint64_t)b.qual_stride;
         const uint32_t *c = b.cigar + (b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride);
-        cigar.insert(cigar.end(), c, c + n_ops_of(b, i));
-        cigar_off.push_back(cigar.size());
+        // the record keeps its identity (GC window): its virtual offset from the reader, else its ordinal in the file
+        const uint64_t id = b.record_id ? b.record_id[i] : b.first_record_index + i;
+        if (ngsq_stager_push_packed(s, b.flag[i], b.mapq[i], b.ref_id[i], b.pos[i], b.mate_ref_id[i], b.tlen[i], l, sq, ql, c, (uint32_t)n_ops_of(b, i), id) != NGSQ_OK)
+            bail(ngsq_stager_last_error(s));
+        if (ngsq_stager_len(s) == ngsq_stager_capacity(s)) flush();
     }
-    ngsq_batch batch() {
-        ngsq_batch o;
-        memset(&o, 0, sizeof o);
-        o.struct_size = sizeof o;
-        o.location = NGSQ_MEM_HOST;
-        o.n_records = flag.size();
-        seq.resize(seq.size() + 64); // slack for the device's vector loads
-        qual.resize(qual.size() + 64);
-        cigar.resize(cigar.size() + 16);
-        mapq.resize(mapq.size() + 16);
-        o.flag = flag.data(); o.mapq = mapq.data(); o.ref_id = ref_id.data(); o.pos = pos.data();
-        o.mate_ref_id = mate_ref_id.data(); o.tlen = tlen.data(); o.l_seq = l_seq.data(); o.n_cigar = n_cigar.data();
-        o.seq = seq.data(); o.seq_off = seq_off.data(); o.qual = qual.data(); o.qual_off = qual_off.data();
-        o.cigar = cigar.data(); o.cigar_off = cigar_off.data();
-        o.record_id = record_id.data();
-        for (uint32_t l : l_seq) o.max_l_seq = std::max(o.max_l_seq, l);
-        o.seq_bytes = seq_off.back(); o.qual_bytes = qual_off.back(); o.cigar_ops = cigar_off.back();
-        return o;
+    void flush() {
+        if (s && ngsq_stager_flush(s, ctx, pass) != NGSQ_OK) bail(ngsq_stager_last_error(s));
     }
 };
 
@@ -913,6 +888,7 @@ int main(int argc, char **argv) {
         if (seq_facets && ngsq_bam_index_ref_starts(a.src.c_str(), n_refs, ref_start.data(), &index_bins) != NGSQ_OK)
             bail(ngsq_bam_last_error());
         const bool by_index = seq_facets && index_bins > 0;
+        Picker pass1(ctx, NGSQ_PASS_RECORD, keep), pass2(ctx, NGSQ_PASS_SEQUENCE, keep + n_refs);
         for (;;) {
             ngsq_batch b;
             // (when only the first `keep` records are wanted from this loop, do not decode a whole batch)
@@ -922,11 +898,7 @@ int main(int argc, char **argv) {
             if (!b.n_records) break;
             if (rec_facets && (n_pass1 < keep)) {
                 const unsigned long long take = std::min<unsigned long long>(b.n_records, keep - n_pass1);
-                Compact c;
-                for (unsigned long long i = 0; i < take; i++) c.push(b, i);
-                ngsq_batch cb = c.batch();
-                cb.first_record_index = b.first_record_index;
-                CHECK(ctx, ngsq_process_batch(ctx, &cb, NGSQ_PASS_RECORD));
+                for (unsigned long long i = 0; i < take; i++) pass1.push(b, i);
                 n_pass1 += take;
             }
             if (seq_facets && !by_index)
@@ -938,8 +910,9 @@ int main(int argc, char **argv) {
             if ((!seq_facets || by_index) && n_pass1 >= keep) break;
             if (!rec_facets && by_index) break;
         }
+        pass1.flush(); // `summarize`: the end of pass 1 (command.rs:328-330)
         if (by_index) {
-            Compact c;
+            Picker &c = pass2;
             unsigned long long counter = 0, queries = 0;
             for (uint32_t r = 0; r < n_refs; r++) {
                 if (!ref_start[r]) continue; // the index holds nothing for this sequence
@@ -964,11 +937,7 @@ int main(int argc, char **argv) {
                 }
             }
             logf(3, "  [*] %llu region queries through the index.", queries);
-            if (!c.flag.empty()) {
-                ngsq_batch cb = c.batch();
-                cb.first_record_index = 0; // sequence facets do not use the record index
-                CHECK(ctx, ngsq_process_batch(ctx, &cb, NGSQ_PASS_SEQUENCE));
-            }
+            c.flush(); // (sequence facets do not use the record's identity)
         } else if (seq_facets) {
             std::set<unsigned long long> picks;
             unsigned long long counter = 0;
@@ -980,27 +949,15 @@ int main(int argc, char **argv) {
                 }
             ngsq_bam_close(bam);
             if (ngsq_bam_open(a.src.c_str(), a.threads, &bam) != NGSQ_OK) bail(ngsq_bam_last_error());
-            Compact c;
-            unsigned long long first_idx = 0;
-            bool have_first = false;
+            Picker &c = pass2;
             for (;;) {
                 ngsq_batch b;
                 if (ngsq_bam_next_batch(bam, a.batch_records, &b) != NGSQ_OK) bail(ngsq_bam_last_error());
                 if (!b.n_records) break;
                 auto lo = picks.lower_bound(b.first_record_index);
-                for (; lo != picks.end() && *lo < b.first_record_index + b.n_records; ++lo) {
-                    if (!have_first) {
-                        first_idx = *lo;
-                        have_first = true;
-                    }
-                    c.push(b, *lo - b.first_record_index);
-                }
+                for (; lo != picks.end() && *lo < b.first_record_index + b.n_records; ++lo) c.push(b, *lo - b.first_record_index);
             }
-            if (!c.flag.empty()) {
-                ngsq_batch cb = c.batch();
-                cb.first_record_index = first_idx; // sequence facets do not use the record index
-                CHECK(ctx, ngsq_process_batch(ctx, &cb, NGSQ_PASS_SEQUENCE));
-            }
+            c.flush();
         }
     }
     if (rec_facets) {

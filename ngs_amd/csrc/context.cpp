@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -109,6 +110,13 @@ const char *ngsq_last_error(const ngsq_ctx *c) { return c ? c->err.c_str() : g_e
 uint32_t ngsq_gc_offset(uint64_t seed, uint64_t idx, uint32_t l) { return ngsq_gc_offset_fn(seed, idx, l); }
 
 static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+// NGSQ_STEP_LEGACY=1 (measurement aid): ngsq_reset and ngsq_finalize as they were until round 4 -- one hipMemsetAsync per small
+// block, one device-to-host copy per result block -- for an A/B of the time a step spends outside its kernels
+static bool step_legacy() {
+    static const bool v = [] { const char *e = getenv("NGSQ_STEP_LEGACY"); return e && atoi(e) != 0; }();
+    return v;
+}
 
 int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     if (!cfg || !out) return fail(nullptr, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
@@ -276,7 +284,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         const uint64_t nr4 = round_up(nr ? nr : 1, 4);
         CTX_TRY(hipMalloc((void **)&c->d_stream_u32, (7 * nr4 + 4) * 4));
         CTX_TRY(hipMalloc((void **)&c->d_last_key, 8));
-        CTX_TRY(hipMalloc((void **)&c->d_chunk_flags, c->n_chunks ? c->n_chunks : 1));
+        CTX_TRY(hipMalloc((void **)&c->d_chunk_flags, round_up(c->n_chunks ? c->n_chunks : 1, 16)));
         st.end_acc = c->d_stream_u32;
         st.batch_span = c->d_stream_u32 + 7 * nr4;
         CovStreamArgs &sa = c->csa;
@@ -384,6 +392,7 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_stream_u32);
     (void)hipFree(c->d_last_key);
     (void)hipFree(c->d_chunk_flags);
+    if (c->pin_results) (void)hipHostFree(c->pin_results);
     if (c->xchg_scratch) ngsq::free_exchange_scratch(c->xchg_scratch);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -557,7 +566,12 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
                 c->cov_end_cap = need;
                 c->st.cov_end = c->d_cov_end;
             }
-            HIP_TRY(c, hipMemsetAsync(c->st.batch_span, 0, 4, c->stream));
+            // the batch's largest-span word: two words used in turn, each zeroed by the OTHER batch's k_cov_plan_refs (both by
+            // ngsq_reset) -- until round 4 a 4-byte memset per batch
+            uint32_t *const spans = c->d_stream_u32 + 7 * round_up(c->st.n_refs ? c->st.n_refs : 1, 4);
+            c->st.batch_span = spans + (c->span_turn & 1);
+            c->csa.span_next = spans + ((c->span_turn & 1) ^ 1);
+            c->span_turn += 1;
         }
         {
             Bracket br(c, K_FIELDS, n * 25 + (walk ? cs.cigar_ops * 4 : 0));
@@ -833,18 +847,46 @@ int ngsq_finalize(ngsq_ctx *c) {
         int rc = ngsq_teardown(c);
         if (rc != NGSQ_OK) return rc;
     }
-    if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) {
-        HIP_TRY(c, hipMemcpyAsync(c->h_cov_hist.data(), c->d_cov_hist, c->n_cov_hist * 8, hipMemcpyDeviceToHost,
-                                  c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_bin_totals.data(), c->d_bin_totals, c->bin_off[nr] * 8 + 8,
-                                  hipMemcpyDeviceToHost, c->stream));
+    // the integer results in ONE launch, written by the kernel into pinned host memory the device addresses (until round 4: five
+    // device-to-host copies into pageable vectors, each a host round trip of its own)
+    const bool cov = (facets & NGSQ_FACET_COVERAGE) && c->n_chunks;
+    const uint64_t n_bins = cov ? c->bin_off[nr] + 1 : 0, n_hist = cov ? c->n_cov_hist : 0, n_vaf = (facets & NGSQ_FACET_EDITS) ? NGSQ_VAF_BINS : 0;
+    const uint64_t need = c->n_counters + n_hist + n_bins + n_vaf + 2;
+    if (step_legacy()) {
+        if (cov) {
+            HIP_TRY(c, hipMemcpyAsync(c->h_cov_hist.data(), c->d_cov_hist, c->n_cov_hist * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->h_bin_totals.data(), c->d_bin_totals, c->bin_off[nr] * 8 + 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (n_vaf) HIP_TRY(c, hipMemcpyAsync(c->h_vaf.data(), c->d_vaf, NGSQ_VAF_BINS * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_touched, c->d_touched, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_counters.data(), c->st.counters, c->n_counters * 8, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        if (c->pin_words < need) {
+            if (c->pin_results) (void)hipHostFree(c->pin_results);
+            c->pin_results = nullptr;
+            c->pin_words = 0;
+            HIP_TRY(c, hipHostMalloc((void **)&c->pin_results, (need + need / 4) * 8, hipHostMallocMapped));
+            HIP_TRY(c, hipHostGetDevicePointer((void **)&c->pin_results_dev, c->pin_results, 0));
+            c->pin_words = need + need / 4;
+        }
+        unsigned long long *d = c->pin_results_dev;
+        StateSpans sp;
+        sp.copy(d, c->st.counters, c->n_counters * 2);
+        sp.copy(d + c->n_counters, c->d_cov_hist, n_hist * 2);
+        sp.copy(d + c->n_counters + n_hist, c->d_bin_totals, n_bins * 2);
+        sp.copy(d + c->n_counters + n_hist + n_bins, c->d_vaf, n_vaf * 2);
+        sp.copy(d + c->n_counters + n_hist + n_bins + n_vaf, c->d_touched, 4);
+        HIP_TRY(c, launch_state_spans(sp, c->stream));
     }
-    if (facets & NGSQ_FACET_EDITS)
-        HIP_TRY(c, hipMemcpyAsync(c->h_vaf.data(), c->d_vaf, NGSQ_VAF_BINS * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_touched, c->d_touched, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters.data(), c->st.counters, c->n_counters * 8, hipMemcpyDeviceToHost,
-                              c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!step_legacy()) {
+        const unsigned long long *h = c->pin_results;
+        memcpy(c->h_counters.data(), h, c->n_counters * 8);
+        if (n_hist) memcpy(c->h_cov_hist.data(), h + c->n_counters, n_hist * 8);
+        if (n_bins) memcpy(c->h_bin_totals.data(), h + c->n_counters + n_hist, n_bins * 8);
+        if (n_vaf) memcpy(c->h_vaf.data(), h + c->n_counters + n_hist + n_bins, n_vaf * 8);
+        memcpy(c->h_touched, h + c->n_counters + n_hist + n_bins + n_vaf, 16);
+    }
     resolve_timing(c);
     c->finalized = true;
     if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) { // algorithmic bytes of the scan: 8 B per torn-down position
@@ -931,33 +973,49 @@ int ngsq_state_chunk_flags(ngsq_ctx *c, void **p, uint64_t *n) {
 int ngsq_reset(ngsq_ctx *c) {
     if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->st.counters, 0, c->n_counters * 8, c->stream));
+    const uint64_t nr4 = round_up(c->st.n_refs ? c->st.n_refs : 1, 4);
+    if (step_legacy()) {
+        HIP_TRY(c, hipMemsetAsync(c->st.counters, 0, c->n_counters * 8, c->stream));
+        if (c->n_depth && c->finalized) HIP_TRY(c, hipMemsetAsync(c->st.chunk_sums, 0, (c->n_depth - c->n_diff) * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_td, 0, c->n_td * 8, c->stream));
+        if (c->stream_cov) {
+            HIP_TRY(c, hipMemsetAsync(c->d_stream_u32, 0, (7 * nr4 + 4) * 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->csa.plan_a, 0xFF, nr4 * 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_last_key, 0, 8, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_chunk_flags, 0, c->n_chunks ? c->n_chunks : 1, c->stream));
+        }
+    } else {
+        // every small block in one launch (kernels.hip k_state_spans); the two large ones below stay memsets
+        StateSpans sp;
+        sp.fill(c->st.counters, c->n_counters * 2, 0);
+        if (c->n_depth && c->finalized) sp.fill(c->st.chunk_sums, c->n_depth - c->n_diff, 0);
+        sp.fill(c->d_td, c->n_td * 2, 0);
+        if (c->stream_cov) {
+            sp.fill(c->d_stream_u32, 2 * nr4, 0);            // end_acc | prev_end
+            sp.fill(c->csa.plan_a, nr4, 0xFFFFFFFFu);        // CS_NONE
+            sp.fill(c->csa.plan_z, 4 * nr4 + 4, 0);          // plan_z | plan_h | plan_t | guard_until | the two largest-span words
+            sp.fill(c->d_last_key, 2, 0);
+            sp.fill(c->d_chunk_flags, (c->n_chunks + 3) / 4, 0);
+        }
+        sp.fill(c->d_touched, 2, 0xFFFFFFFFu);               // {~0, 0}
+        sp.fill(c->d_touched + 1, 2, 0);
+        HIP_TRY(c, launch_state_spans(sp, c->stream));
+    }
     if (c->n_depth) {
         if (!c->finalized) {
             HIP_TRY(c, hipMemsetAsync(c->st.depth, 0, c->n_depth * 4, c->stream));
-        } else {
-            // the scan zeroed the difference arrays behind itself; what is left are the chunk /
-            // super-chunk sums and, after a partial teardown, this shard's own entries outside
-            // the chunk range it tore down (h_touched was read back by ngsq_finalize)
-            HIP_TRY(c, hipMemsetAsync(c->st.chunk_sums, 0, (c->n_depth - c->n_diff) * 4, c->stream));
-            if (c->scan_partial && c->h_touched[0] != ~0ull && c->h_touched[1] > c->h_touched[0]) {
-                const uint64_t lo = c->h_touched[0], hi = c->h_touched[1] < c->n_diff ? c->h_touched[1] : c->n_diff;
-                if (hi > lo) HIP_TRY(c, hipMemsetAsync(c->st.depth + lo, 0, (hi - lo) * 4, c->stream));
-            }
+        } else if (c->scan_partial && c->h_touched[0] != ~0ull && c->h_touched[1] > c->h_touched[0]) {
+            // the scan zeroed the difference arrays behind itself; what is left are the chunk / super-chunk sums (above) and, after
+            // a partial teardown, this shard's own entries outside the chunk range it tore down (h_touched: read back by ngsq_finalize)
+            const uint64_t lo = c->h_touched[0], hi = c->h_touched[1] < c->n_diff ? c->h_touched[1] : c->n_diff;
+            if (hi > lo) HIP_TRY(c, hipMemsetAsync(c->st.depth + lo, 0, (hi - lo) * 4, c->stream));
         }
-    }
-    HIP_TRY(c, hipMemsetAsync(c->d_td, 0, c->n_td * 8, c->stream));
-    if (c->stream_cov) {
-        const uint64_t nr4 = round_up(c->st.n_refs ? c->st.n_refs : 1, 4);
-        HIP_TRY(c, hipMemsetAsync(c->d_stream_u32, 0, (7 * nr4 + 4) * 4, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->csa.plan_a, 0xFF, nr4 * 4, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_last_key, 0, 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_chunk_flags, 0, c->n_chunks ? c->n_chunks : 1, c->stream));
     }
     if (c->n_edits) HIP_TRY(c, hipMemsetAsync(c->st.edits, 0, c->n_edits * 4, c->stream));
     c->h_touched[0] = ~0ull;
     c->h_touched[1] = 0;
-    HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
+    if (step_legacy()) HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
+    c->span_turn = 0;
     c->finalized = false;
     c->torn_down = false;
     c->scan_lo = 0;

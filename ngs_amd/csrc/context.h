@@ -82,12 +82,16 @@ struct ngsq_ctx {
     unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
     std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;
     bool finalized = false;
+    // ngsq_finalize's results land here (pinned host memory the device addresses, written by one kernel), then in the vectors above
+    unsigned long long *pin_results = nullptr, *pin_results_dev = nullptr;
+    uint64_t pin_words = 0;
     // streaming Coverage (cfg.sorted_input): per-batch scratch column, per-sequence plan, chunk flags
     bool stream_cov = false;
     uint32_t *d_cov_end = nullptr;
     uint64_t cov_end_cap = 0;
     uint32_t *d_stream_u32 = nullptr; // end_acc | prev_end | plan_a | plan_z | plan_h | plan_t | guard_until (n_refs each) | batch_span
     unsigned long long *d_last_key = nullptr;
+    uint32_t span_turn = 0;           // which of the two largest-span words the next batch uses (launch_all)
     uint8_t *d_chunk_flags = nullptr;
     ngsq::CovStreamArgs csa{};
     // Genomic Features gene model (ngsq_set_features)

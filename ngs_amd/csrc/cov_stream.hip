@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256) void k_cov_plan_tiles(DeviceState st, DeviceBa
 __global__ __launch_bounds__(256) void k_cov_plan_refs(DeviceState st, CovStreamArgs a) {
     NGSQ_FOREGROUND_WAVE();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    // the NEXT batch's largest-span word (the batches use two words in turn): last read by the previous batch's k_cov_stream,
+    // next written by the next batch's k_fields -- no memset per batch
+    if (r == 0 && a.span_next) *a.span_next = 0;
     if (r >= st.n_refs) return;
     const uint32_t pa = a.plan_a[r], pz = a.plan_z[r], prev = a.prev_end[r];
     const uint32_t acc = st.end_acc[r];

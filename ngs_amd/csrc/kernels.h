@@ -99,7 +99,7 @@ struct DeviceState {
     // ---- streaming Coverage (sorted_input contexts, cov_stream.hip); all null otherwise
     uint32_t *cov_end;     // [batch records] scratch column: exclusive alignment end clipped to L+1, 0 = covers nothing
     uint32_t *end_acc;     // [n_refs] largest cov_end of any record so far
-    uint32_t *batch_span;  // [1] largest (cov_end - alignment_start) of the current batch
+    uint32_t *batch_span;  // [1] largest (cov_end - alignment_start) of the current batch (one of two words used in turn)
 };
 
 // device view of one batch (all pointers device memory)
@@ -158,6 +158,7 @@ struct CovStreamArgs {
     unsigned long long *bin_totals;
     const uint64_t *bin_off;
     uint32_t bin_size, cov_cap, head_guard;
+    uint32_t *span_next;             // the word the NEXT batch collects its largest span in (zeroed by k_cov_plan_refs)
 };
 hipError_t launch_cov_stream(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const CovStreamArgs &a,
                              hipStream_t s);
@@ -232,6 +233,26 @@ uint64_t edits_teardown_chunks(uint64_t n_entries);
 hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uint32_t *sums, hipStream_t s);
 hipError_t launch_edits_refs(uint32_t *refs, const uint32_t *alts, uint64_t n_entries, const uint32_t *carry, uint64_t chunk0, uint64_t chunk1,
                              unsigned long long *vaf_hist, hipStream_t s);
+
+// Up to STATE_SPANS_MAX small blocks of 32-bit words filled with a value (src == null) or copied (src -> dst; dst may be pinned
+// host memory the device addresses) by ONE launch: the resets of ngsq_reset, the result download of ngsq_finalize.  kernels.hip
+constexpr uint32_t STATE_SPANS_MAX = 12;
+struct StateSpans {
+    struct Span {
+        uint32_t *dst;
+        const uint32_t *src;
+        uint64_t n_words;
+        uint32_t value;
+    } span[STATE_SPANS_MAX];
+    uint32_t n = 0;
+    void fill(void *dst, uint64_t n_words, uint32_t value) {
+        if (n_words && n < STATE_SPANS_MAX) span[n++] = Span{static_cast<uint32_t *>(dst), nullptr, n_words, value};
+    }
+    void copy(void *dst, const void *src, uint64_t n_words) {
+        if (n_words && n < STATE_SPANS_MAX) span[n++] = Span{static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), n_words, 0};
+    }
+};
+hipError_t launch_state_spans(const StateSpans &a, hipStream_t s);
 
 // synthetic records generated in place on the device (include/ngsq_shared.h)
 struct SynthColumns {

@@ -251,4 +251,45 @@ hipError_t launch_qual(const LaunchInfo &li, const DeviceState &st, const Device
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Small state blocks in ONE launch (kernels.h StateSpans): ngsq_reset used to be nine hipMemsetAsync + one 16-byte
+// host-to-device copy, ngsq_finalize five device-to-host copies into pageable memory -- two dozen operations of a few
+// microseconds each, every one a gap on the stream (and a host round trip for every pageable copy): 0.24-0.41 ms of a
+// 5.6 ms step that no kernel accounted for.  A thread takes four words of the concatenated spans.
+__global__ __launch_bounds__(256) void k_state_spans(StateSpans a) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // quad index over the concatenation
+    uint32_t k = 0;
+    uint64_t base = 0;
+#pragma unroll 1
+    for (; k < a.n; k++) {
+        const uint64_t quads = (a.span[k].n_words + 3) / 4;
+        if (q < base + quads) break;
+        base += quads;
+    }
+    if (k >= a.n) return;
+    const StateSpans::Span sp = a.span[k];
+    const uint64_t w0 = (q - base) * 4;
+    if (sp.src) { // copy (the destination may be pinned host memory the device addresses)
+        if (w0 + 4 <= sp.n_words && (((uintptr_t)sp.src | (uintptr_t)sp.dst) & 15) == 0) {
+            *reinterpret_cast<uint4 *>(sp.dst + w0) = *reinterpret_cast<const uint4 *>(sp.src + w0);
+        } else {
+            for (uint64_t w = w0; w < sp.n_words && w < w0 + 4; w++) sp.dst[w] = sp.src[w];
+        }
+    } else {
+        if (w0 + 4 <= sp.n_words && ((uintptr_t)sp.dst & 15) == 0) {
+            *reinterpret_cast<uint4 *>(sp.dst + w0) = make_uint4(sp.value, sp.value, sp.value, sp.value);
+        } else {
+            for (uint64_t w = w0; w < sp.n_words && w < w0 + 4; w++) sp.dst[w] = sp.value;
+        }
+    }
+}
+
+hipError_t launch_state_spans(const StateSpans &a, hipStream_t s) {
+    uint64_t quads = 0;
+    for (uint32_t k = 0; k < a.n; k++) quads += (a.span[k].n_words + 3) / 4;
+    if (!quads) return hipSuccess;
+    hipLaunchKernelGGL(k_state_spans, dim3((uint32_t)((quads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 } // namespace ngsq

@@ -352,7 +352,23 @@ PROTOTYPES = {
     "ngsq_bam_shard_verify": (C.c_int, [C.c_void_p, ctx_p, comm_p, C.POINTER(ShardInfo), C.POINTER(C.c_int)]),
     "ngsq_synth_fill_device": (
         C.c_int, [ctx_p, C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
+    # include/ngsq_stage.h
+    "ngsq_stager_create": (C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ngsq_stager_destroy": (None, [C.c_void_p]),
+    "ngsq_stager_last_error": (C.c_char_p, [C.c_void_p]),
+    "ngsq_stager_len": (C.c_uint64, [C.c_void_p]),
+    "ngsq_stager_capacity": (C.c_uint64, [C.c_void_p]),
+    "ngsq_stager_pushed": (C.c_uint64, [C.c_void_p]),
+    "ngsq_stager_push": (C.c_int, [C.c_void_p, C.c_uint16, C.c_uint8, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
+                                   C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64]),
+    "ngsq_stager_push_packed": (C.c_int, [C.c_void_p, C.c_uint16, C.c_uint8, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
+    "ngsq_stager_view": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
+    "ngsq_stager_flush": (C.c_int, [C.c_void_p, ctx_p, C.c_uint32]),
+    "ngsq_stager_rewind": (C.c_int, [C.c_void_p, C.c_uint64]),
 }
+STAGE_PINNED, STAGE_PAGEABLE, STAGE_OFFSETS_ONLY = 0, 1, 2
+STAGE_NO_ID = (1 << 64) - 1
 
 
 class LibraryNotBuilt(RuntimeError):
