@@ -91,6 +91,10 @@ def parse_args():
     ap.add_argument("--file-level", type=int, default=6, help="zlib level of that BAM")
     ap.add_argument("--h2d-batch", type=int, default=4_000_000, help="records per host batch of the h2d_inclusive leg (0 = skip)")
     ap.add_argument("--extra-facet-records", type=int, default=100_000_000, help="records of the Edits / Genomic Features leg")
+    ap.add_argument("--all-facets-records", type=int, default=100_000_000,
+                    help="N = 1: records of the all-seven-facets pass (Edits with the reference in HBM, Genomic Features with a gene model) "
+                         "timed beside the headline one (0 = skip)")
+    ap.add_argument("--all-facets-steps", type=int, default=15)
     ap.add_argument("--live-traffic", type=int, default=1,
                     help="1 (N = 1, default workload): two short passes of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE -- "
                          "separate passes, child processes started before this one touches HIP) give roofline.traffic of THIS run; "
@@ -199,10 +203,14 @@ class ClockSampler:
     """Samples the card's clocks, power and temperature every 50 ms on a thread of its own while the timed loops run (the loops
     spend their time inside ctypes calls, which release the interpreter lock)."""
 
-    def __init__(self, index):
+    def __init__(self, index, pci=""):
         import threading
         cards = _sysfs_cards()
-        self.card = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        # the card whose PCI address is the HIP device's (a host shows every card of the node, a container's HIP only its own)
+        mine = [c for c in cards if pci and os.path.realpath(c).lower().endswith(pci.lower())]
+        self.how = "matched by PCI address " + pci if mine else "NOT matched to the HIP device (no PCI address match): card by ordinal"
+        self.card = mine[0] if mine else (cards[index] if index < len(cards) else (cards[0] if cards else None))
+        self.levels = {k: (_read(os.path.join(self.card, k)) or "").split("\n") for k in ("pp_dpm_sclk", "pp_dpm_mclk")} if self.card else {}
         self.samples, self._stop = [], threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True) if self.card else None
 
@@ -224,7 +232,8 @@ class ClockSampler:
     def summary(self):
         if not self.card:
             return {"source": "unavailable: no /sys/class/drm/card*/device/pp_dpm_sclk on this machine"}
-        out = {"source": self.card + " (amdgpu sysfs, sampled every 50 ms during the timed loops)", "samples": len(self.samples)}
+        out = {"source": self.card + " (amdgpu sysfs, sampled every 50 ms during the timed loops; " + self.how + ")", "samples": len(self.samples),
+               "dpm_levels_before_the_loops": {k: [x.strip() for x in v if x.strip()] for k, v in self.levels.items()}}
         for key in ("sclk_mhz", "mclk_mhz", "power_w", "power_cap_w", "temp_edge_c", "temp_junction_c", "temp_mem_c", "busy_pct"):
             vals = sorted(v[key] for v in self.samples if v.get(key) is not None)
             if vals:
@@ -338,7 +347,10 @@ def main() -> int:
     # the timed region: `repeats` loops of EXACTLY --steps steps, each bracketed by barrier + synchronize; `value` is the median
     # loop (all of them are in the line, with the clocks the card ran at), so that a slow box shows as one
     loops = []
-    with ClockSampler(device) as clocks:
+    pci_buf = __import__("ctypes").create_string_buffer(64)
+    pci = pci_buf.value.decode() if lib.ngsq_device_pci_bus_id(device, pci_buf, 64) > 0 else ""
+    pci = pci_buf.value.decode()
+    with ClockSampler(device, pci) as clocks:
         for _ in range(max(1, args.repeats)):
             sync()
             t0 = time.perf_counter()
@@ -467,6 +479,8 @@ def main() -> int:
                 out["file_end_to_end"] = fe
             if args.extra_facet_legs and not mixed and args.facets == 0x1F:
                 out["extra_facets"] = guarded(leg_extra_facets, lib, host, ffi, np, args.extra_facet_records)
+            if args.all_facets_records > 0 and not mixed and args.facets == 0x1F:
+                out["all_facets"] = guarded(leg_all_facets, lib, host, ffi, np, args, device)
         elif world > 1 and args.file_records > 0 and not mixed and not args.emulate_shard:
             # the number the metric is named after, on N GPUs: ONE BAM file scanned by `ngs qc --gpus N` (the other ranks
             # of this launch have released their devices and are on their way out)
@@ -1181,23 +1195,96 @@ def leg_extra_facets(lib, host, ffi, np, n=100_000_000):
             ka["cigars"] = "85 % 150M, 9 % soft-clipped at one end, 3 % an insertion, 3 % a deletion (1-8 bases)"
             out["edits_aligner_cigars"] = ka
         ctx.free_batch(db)
-        # round 3's input on the same kernel: every compared dword holds a mismatch
-        icfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2)
-        db = ctx.synth_device_batch(icfg, 0, n)
-        for rep in range(2):
-            ctx.reset()
-            ctx.kernel_timing_reset()
-            ctx.process_batch(db)
-            ctx.finalize()
-        ki = kernel_table(ctx.kernel_timing()).get("edits")
-        if ki:
-            ki["hbm_frac"] = round(ki["GBps"] / HBM_PEAK_GBS, 4)
-            r1, r2, _ = ctx.edits()
-            ki["mean_edits_per_read"] = round(float(((r1 + r2) * tot).sum() / max(1, int(r1.sum() + r2.sum()))), 2)
-            out["edits_iid_reads"] = ki
-        ctx.free_batch(db)
+        # reads that DIFFER from the reference (edits.rs:276-291 costs the same per base whatever the bases are): 5 % and 25 % of the
+        # compared bases substituted -- bisulfite-converted, cross-species, noisy reads -- and round 3's input, independent random
+        # bases (three in four differ)
+        for key, model, what in (("edits_subst_5pct", ffi.synth_seq_subst(0.05), "sampled from the reference, 5 % substitutions"),
+                                 ("edits_subst_25pct", ffi.synth_seq_subst(0.25), "sampled from the reference, 25 % substitutions"),
+                                 ("edits_iid_reads", ffi.SYNTH_SEQ_IID, "independent random bases")):
+            icfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2, seq_model=model)
+            db = ctx.synth_device_batch(icfg, 0, n)
+            for rep in range(2):
+                ctx.reset()
+                ctx.kernel_timing_reset()
+                ctx.process_batch(db)
+                ctx.finalize()
+            ki = kernel_table(ctx.kernel_timing()).get("edits")
+            if ki:
+                ki["hbm_frac"] = round(ki["GBps"] / HBM_PEAK_GBS, 4)
+                r1, r2, _ = ctx.edits()
+                ki["mean_edits_per_read"] = round(float(((r1 + r2) * tot).sum() / max(1, int(r1.sum() + r2.sum()))), 2)
+                ki["reads"] = what
+                out[key] = ki
+            ctx.free_batch(db)
         return out
     finally:
+        ctx.close()
+
+
+def leg_all_facets(lib, host, ffi, np, args, device):
+    """ALL seven facets as ONE scan (get_qc_facets with -r and -f: qc.rs:44-126 builds General, Template Length, GC Content, Quality
+    Score, Genomic Features, Coverage and Edits for one pass pair): reads sampled from the synthetic reference (0.5 % substitutions),
+    the reference's bases and the 400 k-interval gene model resident in HBM, Coverage streamed.  ms per step, the fraction of the
+    HBM roofline on the pass's algorithmic bytes, the kernels, and the full-size invariants of every facet."""
+    import types
+    n = args.all_facets_records
+    scfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2, seq_model=ffi.SYNTH_SEQ_FROM_REFERENCE)
+    bases = [host.synth_reference(scfg, r, L, lib) for r, L in enumerate((CHR1, CHR2))]
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=0x7F, device=device, max_read_len=args.read_len, gc_seed=GC_SEED, timing=True,
+                         sorted_input=n / CHR1 <= 0.5, ref_bases=bases, lib=lib)
+    del bases
+    db = None
+    try:
+        ctx.set_features(*synthetic_gene_model(np))
+        db = ctx.synth_device_batch(scfg, 0, n)
+
+        def step():
+            ctx.reset(); ctx.process_batch(db); ctx.finalize()
+        for _ in range(3):
+            step()
+        ctx.synchronize()
+        ctx.kernel_timing_reset()
+        loops = []
+        for _ in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.all_facets_steps):
+                step()
+            ctx.synchronize()
+            loops.append((time.perf_counter() - t0) / args.all_facets_steps * 1e3)
+        ms = median(loops)
+        fargs = types.SimpleNamespace(facets=0x1F, read_len=args.read_len, workload="fixed", mixed_max_len=args.mixed_max_len)
+        parity = check_invariants(ctx, ffi, n, fargs, False, False)
+        bad = []
+        g, f = ctx.general(), ctx.features()
+        r1, r2, vaf = ctx.edits()
+        reads = int(r1.sum() + r2.sum())
+        if not (n - g["unmapped"] - g["duplicate"] <= reads <= n - max(g["unmapped"], g["duplicate"])):
+            bad.append("Edits counts the mapped, non-duplicate reads")
+        if not (0 < int(vaf.sum()) <= CHR1 + CHR2):
+            bad.append("VAF histogram counts covered positions")
+        if f["processed"] + f["ignored_flags"] + f["ignored_nonprimary_chromosome"] != n:
+            bad.append("Genomic Features conserves records")
+        if bad:
+            parity = ("FAILED: " if parity.startswith("ok") else parity + "; ") + "; ".join(bad)
+        elif parity.startswith("ok"):
+            parity = "ok: %d full-size invariants" % (int(parity.split()[1]) + 3)
+        timing = ctx.kernel_timing()
+        # algorithmic bytes of the pass: the record's own 254 bytes (every column once) + the teardown scans; the packed reference
+        # bytes Edits compares with (75 per read, mostly served by the L2: neighbouring reads overlap) are NOT counted
+        algo_rec = 25.0 + 4.0 * db.cigar_ops / n + db.seq_bytes / n + db.qual_bytes / n
+        kt = kernel_table(timing)
+        return {"workload": "%d M synthetic %d bp reads sampled from the reference, facets 0x7F (all seven), chr1 + chr2 bases and a 400 k-interval "
+                            "gene model resident in HBM" % (n // 1_000_000, args.read_len),
+                "ms_per_step": round(ms, 3), "ms_per_step_each_loop": [round(x, 3) for x in loops], "steps": args.all_facets_steps,
+                "value": round(n / ms * 1e3, 1), "unit": "records/s", "algorithmic_bytes_per_record": round(algo_rec, 2),
+                "hbm_frac_whole_pass": round(n / ms * 1e3 * algo_rec / (HBM_PEAK_GBS * 1e9), 4),
+                "seq_column_reads": "twice (k_gc and k_edits_rows)" if "gc" in kt else "once (the GC window is tallied by k_edits_rows)",
+                "ms_per_step_outside_kernels": round(ms - sum(v["avg_ms"] * timing[k]["launches"] / max(1, timing["qual"]["launches"]) for k, v in kt.items()), 3),
+                "parity_check": parity, "kernels": kt}
+    finally:
+        if db is not None:
+            ctx.free_batch(db)
         ctx.close()
 
 

@@ -295,6 +295,9 @@ typedef struct ngsq_kernel_time {
 uint32_t ngsq_abi_version(void);
 /* number of HIP devices visible (0 when none); never fails */
 int ngsq_device_count(void);
+/* PCI address of a HIP device ("0000:c1:00.0", what /sys/bus/pci/devices and the device links under /sys/class/drm name it by), for hosts that
+ * want to read the card's clocks or NUMA node; returns the length, 0 when there is no such device */
+int ngsq_device_pci_bus_id(int device, char *buf, size_t cap);
 /* facet display name for one NGSQ_FACET_* bit ("General", "Template Length", ...) or NULL */
 const char *ngsq_facet_name(uint32_t facet_bit);
 /* thread-local message of the last failing call that had no context */
@@ -379,7 +382,7 @@ int ngsq_kernel_timing_reset(ngsq_ctx *ctx);
  * per primary sequence, the coverage difference array (ref_len+2 entries);
  * `edits`: per sequence with reference bases 2 (ref_len+1) uint32 -- until the teardown the difference array of the `M`
  * cover (entry p-1 += 1 / entry q -= 1 for an M over positions p..q) and the mismatches per position (alts); the teardown
- * turns the first half into refs = cover - alts (ngsq_get_edits_positions).  Any summation (RCCL all-reduce, or a host loop) of
+ * leaves both as they are (it only takes the VAF histogram); ngsq_get_edits_positions turns the first half into refs = cover - alts.  Any summation (RCCL all-reduce, or a host loop) of
  * these blocks across contexts followed by ngsq_finalize on one of them gives
  * the single-context result -- PROVIDED the contexts' quality tables have the same number of rows: the table is the last
  * part of the counters block and grows with the longest read a context has met (ngsq_max_read_len), so n_u64 and the device

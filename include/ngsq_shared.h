@@ -70,6 +70,10 @@ typedef struct ngsq_synth_config {
  * stay independent draws.  What the Edits facet sees on aligner output: a mismatch is rare. */
 #define NGSQ_SYNTH_SEQ_IID 0u
 #define NGSQ_SYNTH_SEQ_FROM_REFERENCE 1u
+/* FROM_REFERENCE with another substitution rate: seq_model = NGSQ_SYNTH_SEQ_SUBST(per_65536) -- the rate in the model's upper
+ * 16 bits (0 there = the default 328 / 65536 = 0.5 %); 3277 = 5 %, 16384 = 25 %: bisulfite-converted, cross-species, noisy reads */
+#define NGSQ_SYNTH_SEQ_SUBST(per_65536) (NGSQ_SYNTH_SEQ_FROM_REFERENCE | ((uint32_t)(per_65536) << 16))
+#define NGSQ_SYNTH_SEQ_KIND(model) ((model) & 0xFFFFu)
 
 /* What a record of a synthetic BAM FILE carries besides the generator's fields (ngsq_synth_write_bam; the batches of
  * ngsq_synth_fill_* have no names or tags).  0: the name "r<index>", no auxiliary data (274 B per 150-base record) --
@@ -293,7 +297,8 @@ NGSQ_HD uint32_t ngsq_synth_base_from_reference(const ngsq_synth_config *c, uint
                 uint32_t code = ngsq_synth_ref_code(c, (uint32_t)r->ref_id, (uint64_t)r->pos + rp + (q - qp));
                 const uint64_t hs = ngsq_synth_hash(c->seed, i, NGSQ_KEY_SUB, (uint64_t)(q >> 2));
                 const uint32_t d = (uint32_t)(hs >> (16u * (q & 3u))) & 0xFFFFu;
-                if (d < 328u) { /* 0.5 %: one of the three other bases */
+                const uint32_t rate = c->seq_model >> 16 ? c->seq_model >> 16 : 328u;
+                if (d < rate) { /* 0.5 % unless the model says otherwise: one of the three other bases */
                     const uint32_t idx = (code == 1u ? 0u : code == 2u ? 1u : code == 4u ? 2u : 3u);
                     code = 1u << ((idx + 1u + d % 3u) & 3u);
                 }
@@ -319,7 +324,7 @@ NGSQ_HD uint8_t ngsq_synth_seq_byte(const ngsq_synth_config *c, uint64_t i, uint
     const uint32_t sh = (j & 1u) * 32u;
     uint32_t hi = ngsq_synth_base_code((uint32_t)((h >> sh) & 0xFFFF));
     uint32_t lo = ngsq_synth_base_code((uint32_t)((h >> (sh + 16u)) & 0xFFFF));
-    if (c->seq_model == NGSQ_SYNTH_SEQ_FROM_REFERENCE) {
+    if (NGSQ_SYNTH_SEQ_KIND(c->seq_model) == NGSQ_SYNTH_SEQ_FROM_REFERENCE) {
         ngsq_synth_record r;
         ngsq_synth_record_at(c, i, &r);
         hi = ngsq_synth_base_from_reference(c, i, &r, 2u * j, hi);

@@ -91,6 +91,18 @@ int ngsq_device_count(void) {
     return n;
 }
 
+int ngsq_device_pci_bus_id(int device, char *buf, size_t cap) {
+    char tmp[64] = {0};
+    if (!buf || !cap || hipDeviceGetPCIBusId(tmp, (int)sizeof tmp, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    for (char *p = tmp; *p; p++)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a'); // sysfs spells the address in lower case
+    snprintf(buf, cap, "%s", tmp);
+    return (int)strlen(buf);
+}
+
 const char *ngsq_facet_name(uint32_t bit) {
     switch (bit) {
     case NGSQ_FACET_GENERAL: return "General";
@@ -113,6 +125,10 @@ static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
 // NGSQ_STEP_LEGACY=1 (measurement aid): ngsq_reset and ngsq_finalize as they were until round 4 -- one hipMemsetAsync per small
 // block, one device-to-host copy per result block -- for an A/B of the time a step spends outside its kernels
+#ifndef NGSQ_FEATURES_SIDE_DEFAULT
+#define NGSQ_FEATURES_SIDE_DEFAULT false
+#endif
+
 static bool step_legacy() {
     static const bool v = [] { const char *e = getenv("NGSQ_STEP_LEGACY"); return e && atoi(e) != 0; }();
     return v;
@@ -199,7 +215,8 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     st.off_edits1 = (uint32_t)round_up(st.off_tlen + st.tlen_cap + 1, 8);
     st.off_edits2 = st.off_edits1 + (uint32_t)round_up(NGSQ_EDITS_BINS, 8);
     st.off_seen = st.off_edits2 + (uint32_t)round_up(NGSQ_EDITS_BINS, 8);
-    st.off_qual = (uint32_t)round_up((uint64_t)st.off_seen + nr, 8);
+    st.off_eseen = st.off_seen + nr;
+    st.off_qual = (uint32_t)round_up((uint64_t)st.off_eseen + nr, 8);
     c->n_counters = round_up((uint64_t)st.off_qual + (uint64_t)st.max_read_len * QUAL_BINS, 8);
     CTX_TRY(hipMalloc((void **)&st.counters, c->n_counters * 8));
     CTX_TRY(hipMemsetAsync(st.counters, 0, c->n_counters * 8, c->stream));
@@ -393,6 +410,12 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_last_key);
     (void)hipFree(c->d_chunk_flags);
     if (c->pin_results) (void)hipHostFree(c->pin_results);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+        (void)hipEventDestroy(c->side_fork);
+        (void)hipEventDestroy(c->side_done);
+    }
     if (c->xchg_scratch) ngsq::free_exchange_scratch(c->xchg_scratch);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -547,11 +570,34 @@ static int column_sizes(ngsq_ctx *c, const ngsq_batch *b, ColumnSizes *cs) {
     return NGSQ_OK;
 }
 
+// NGSQ_FEATURES_SIDE=0/1: Genomic Features beside the other facets' kernels on a stream of its own (it reads 16 bytes per record, uses no
+// LDS and waits for its own three dependent stages: what it leaves of a CU the bandwidth-bound kernels can use)
+static bool features_on_side_stream() {
+    static const bool v = [] { const char *e = getenv("NGSQ_FEATURES_SIDE"); return e ? atoi(e) != 0 : NGSQ_FEATURES_SIDE_DEFAULT; }();
+    return v;
+}
+
 static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs, uint32_t pass_mask) {
     const uint32_t facets = c->cfg.facets;
     const uint64_t n = db.n;
     const uint32_t rec_f = (pass_mask & NGSQ_PASS_RECORD) ? (facets & NGSQ_FACETS_RECORD_BASED) : 0;
     const uint32_t seq_f = (pass_mask & NGSQ_PASS_SEQUENCE) ? (facets & NGSQ_FACETS_SEQUENCE_BASED) : 0;
+    bool side_join = false;
+    if ((rec_f & NGSQ_FACET_FEATURES) && c->have_features && features_on_side_stream() && (rec_f | seq_f) != NGSQ_FACET_FEATURES) {
+        if (!c->side_stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipEventRecord(c->side_fork, c->stream)); // (behind the batch's host-to-device copies, and behind ngsq_reset)
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
+        {
+            Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4, c->side_stream);
+            HIP_TRY(c, launch_features(c->li, c->st, db, c->ft, c->side_stream));
+        }
+        HIP_TRY(c, hipEventRecord(c->side_done, c->side_stream));
+        side_join = true;
+    }
     if ((rec_f & (NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH)) || (seq_f & NGSQ_FACET_COVERAGE)) {
         const bool walk = (rec_f & NGSQ_FACET_GENERAL) || (seq_f & NGSQ_FACET_COVERAGE);
         const bool cov = (seq_f & NGSQ_FACET_COVERAGE) != 0;
@@ -583,7 +629,10 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
             HIP_TRY(c, launch_cov_stream(c->li, c->st, db, c->csa, c->stream));
         }
     }
-    if (rec_f & NGSQ_FACET_GC_CONTENT) {
+    // GC Content and Edits in one pass of the batch: k_edits_rows tallies the GC window from the sequence bytes it compares (the
+    // column -- 75 of a record's 254 bytes -- is read once instead of twice; get_qc_facets builds both facets for one scan: qc.rs:44-126)
+    const bool gc_in_edits = (rec_f & NGSQ_FACET_GC_CONTENT) && (seq_f & NGSQ_FACET_EDITS) && edits_can_take_gc(c->st, db);
+    if ((rec_f & NGSQ_FACET_GC_CONTENT) && !gc_in_edits) {
         Bracket br(c, K_GC, n * 6 + cs.seq_bytes);
         HIP_TRY(c, launch_gc(c->li, c->st, db, cs.seq_bytes, c->stream));
     }
@@ -591,7 +640,7 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
         Bracket br(c, K_QUAL, cs.qual_bytes);
         HIP_TRY(c, launch_qual(c->li, c->st, db, c->stream));
     }
-    if (rec_f & NGSQ_FACET_FEATURES) {
+    if ((rec_f & NGSQ_FACET_FEATURES) && !side_join) {
         if (!c->have_features)
             return fail(c, NGSQ_ERR_STATE, "NGSQ_FACET_FEATURES is enabled but ngsq_set_features was not called");
         Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4);
@@ -608,8 +657,9 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
             HIP_TRY(c, hipMalloc((void **)&c->d_edits_defer, (words + words / 4) * 8));
             c->edits_defer_cap = words + words / 4;
         }
-        HIP_TRY(c, launch_edits(c->li, c->st, db, c->d_edits_defer, c->stream));
+        HIP_TRY(c, launch_edits(c->li, c->st, db, c->d_edits_defer, gc_in_edits, c->stream));
     }
+    if (side_join) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_done, 0));
     return NGSQ_OK;
 }
 
@@ -822,15 +872,19 @@ int ngsq_teardown(ngsq_ctx *c) {
             const uint64_t L1 = (uint64_t)c->ref_len[r] + 1, nc = edits_teardown_chunks(L1);
             const uint64_t c0 = nc * c->vaf_part / c->vaf_parts, c1 = nc * (c->vaf_part + 1) / c->vaf_parts;
             uint32_t *refs = c->st.edits + c->edits_off[r], *carry = c->d_edits_carry + c->edits_carry_off[r];
+            // (a sequence Edits wrote nothing for -- its word at off_eseen is zero -- costs two empty launches; round 5: until then
+            // every sequence of the FASTA was summed, converted and, in ngsq_reset, zeroed again whether a read lay on it or not)
+            const unsigned long long *touched = c->st.counters + c->st.off_eseen + r;
             {
                 Bracket br(c, K_EDITS_VAF, L1 * 4);
-                HIP_TRY(c, launch_edits_chunk_sums(refs, L1, carry, c->stream));
+                HIP_TRY(c, launch_edits_chunk_sums(refs, L1, carry, touched, c->stream));
             }
-            c->edits_conv_lo[r] = c0;
-            c->edits_conv_hi[r] = c1;
+            // the VAF histogram only: the slot keeps the cover's difference array until somebody asks for the positions
+            // (ngsq_get_edits_positions converts then) -- 4 bytes per position less to write in every run that does not
+            c->edits_conv_lo[r] = c->edits_conv_hi[r] = c0;
             if (c1 <= c0) continue;
-            Bracket br(c, K_EDITS_VAF, std::min<uint64_t>(L1, (c1 - c0) * 4096) * 12);
-            HIP_TRY(c, launch_edits_refs(refs, refs + L1, L1, carry, c0, c1, c->d_vaf, c->stream));
+            Bracket br(c, K_EDITS_VAF, std::min<uint64_t>(L1, (c1 - c0) * 4096) * 8);
+            HIP_TRY(c, launch_edits_refs(refs, refs + L1, L1, carry, c0, c1, c->d_vaf, touched, false, c->stream));
         }
     }
     c->torn_down = true;
@@ -863,6 +917,12 @@ int ngsq_finalize(ngsq_ctx *c) {
     } else {
         if (c->pin_words < need) {
             if (c->pin_results) (void)hipHostFree(c->pin_results);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+        (void)hipEventDestroy(c->side_fork);
+        (void)hipEventDestroy(c->side_done);
+    }
             c->pin_results = nullptr;
             c->pin_words = 0;
             HIP_TRY(c, hipHostMalloc((void **)&c->pin_results, (need + need / 4) * 8, hipHostMallocMapped));
@@ -1011,7 +1071,15 @@ int ngsq_reset(ngsq_ctx *c) {
             if (hi > lo) HIP_TRY(c, hipMemsetAsync(c->st.depth + lo, 0, (hi - lo) * 4, c->stream));
         }
     }
-    if (c->n_edits) HIP_TRY(c, hipMemsetAsync(c->st.edits, 0, c->n_edits * 4, c->stream));
+    if (c->n_edits) {
+        if (!c->finalized) {
+            HIP_TRY(c, hipMemsetAsync(c->st.edits, 0, c->n_edits * 4, c->stream));
+        } else { // only the sequences Edits wrote something for (h_counters: read back by ngsq_finalize)
+            for (uint32_t r = 0; r < c->st.n_refs; r++)
+                if (c->edits_off[r] != NO_DEPTH && c->h_counters[c->st.off_eseen + r])
+                    HIP_TRY(c, hipMemsetAsync(c->st.edits + c->edits_off[r], 0, round_up(2 * ((uint64_t)c->ref_len[r] + 1), 4) * 4, c->stream));
+        }
+    }
     c->h_touched[0] = ~0ull;
     c->h_touched[1] = 0;
     if (step_legacy()) HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
@@ -1142,12 +1210,17 @@ int ngsq_get_edits_positions(ngsq_ctx *c, uint32_t ref, uint32_t *refs, uint32_t
     const size_t L1 = (size_t)c->ref_len[ref] + 1;
     if (n < L1) return NGSQ_ERR_BUFFER_TOO_SMALL;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->h_counters[c->st.off_eseen + ref]) { // Edits wrote nothing for the sequence (its teardown was skipped: no chunk sums either)
+        memset(refs, 0, L1 * 4);
+        memset(alts, 0, L1 * 4);
+        return NGSQ_OK;
+    }
     uint32_t *base = c->st.edits + c->edits_off[ref];
     {   // the chunks this context's teardown did not turn into refs (a sharded run: the other ranks' slices), without the tally
         const uint64_t nc = edits_teardown_chunks(L1);
         const uint32_t *carry = c->d_edits_carry + c->edits_carry_off[ref];
-        HIP_TRY(c, launch_edits_refs(base, base + L1, L1, carry, 0, c->edits_conv_lo[ref], nullptr, c->stream));
-        HIP_TRY(c, launch_edits_refs(base, base + L1, L1, carry, c->edits_conv_hi[ref], nc, nullptr, c->stream));
+        HIP_TRY(c, launch_edits_refs(base, base + L1, L1, carry, 0, c->edits_conv_lo[ref], nullptr, nullptr, true, c->stream));
+        HIP_TRY(c, launch_edits_refs(base, base + L1, L1, carry, c->edits_conv_hi[ref], nc, nullptr, nullptr, true, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->edits_conv_lo[ref] = 0;
         c->edits_conv_hi[ref] = nc;

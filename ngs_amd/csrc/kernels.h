@@ -18,6 +18,7 @@
 //   [off_qual .. +max_read_len*94)   per-cycle quality table, row = 0-based cycle
 //   [off_edits1 .. +513) [off_edits2 .. +513)   per-read edit-count histograms
 //   [off_seen .. +n_refs)   records Coverage processed per sequence (entry exists iff > 0)
+//   [off_eseen .. +n_refs)  non-zero iff Edits wrote anything for the sequence (its teardown and its reset are skipped otherwise)
 #pragma once
 
 #include <hip/hip_runtime_api.h>
@@ -81,7 +82,7 @@ constexpr uint64_t NO_DEPTH = ~0ull;
 // device view of the context shared by all kernels
 struct DeviceState {
     unsigned long long *counters; // packed block above
-    uint32_t off_tlen, off_qual, off_edits1, off_edits2, off_seen;
+    uint32_t off_tlen, off_qual, off_edits1, off_edits2, off_seen, off_eseen;
     uint32_t tlen_cap, max_read_len, n_refs, cov_cap;
     uint32_t *depth;               // coverage difference arrays, all primary sequences
     uint32_t *chunk_sums;          // per COV_CHUNK positions: sum of the difference entries
@@ -191,7 +192,10 @@ hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const De
 bool qual_ragged_supported(const DeviceState &st, const DeviceBatch &b);
 hipError_t launch_qual_ragged(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, hipStream_t s);
 // Edits process (edits.rs:217-303), edits_kernel.hip; defer_bits: scratch of at least (b.n + 63) / 64 words (device memory)
-hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, unsigned long long *defer_bits,
+// with_gc: the launch also tallies the GC Content facet of the same records (the SEQ column is then read once; only when
+// edits_can_take_gc says so: fixed-pitch rows of up to 160 bases) -- launch_gc is then not called for the batch
+bool edits_can_take_gc(const DeviceState &st, const DeviceBatch &b);
+hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, unsigned long long *defer_bits, bool with_gc,
                         hipStream_t s);
 
 // Coverage teardown for every sequence in ONE launch (coverage.rs:182-246): prefix-sum the
@@ -230,9 +234,11 @@ hipError_t launch_pack_reference(const LaunchInfo &li, const uint8_t *codes, uin
 // Edits teardown for one sequence (edits.rs:305-344): sums[c] = sum of the difference entries in front of 4096-entry chunk c;
 // then, chunk by chunk, refs in place of the difference array and (vaf_hist != null) the VAF histogram
 uint64_t edits_teardown_chunks(uint64_t n_entries);
-hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uint32_t *sums, hipStream_t s);
+// touched (optional, device memory): the sequence's word of the counters block at off_eseen -- zero: nothing to do, the kernels return
+// write_refs: refs = cover - alts in place (ngsq_get_edits_positions); false: the VAF histogram only, the arrays stay as they are
+hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uint32_t *sums, const unsigned long long *touched, hipStream_t s);
 hipError_t launch_edits_refs(uint32_t *refs, const uint32_t *alts, uint64_t n_entries, const uint32_t *carry, uint64_t chunk0, uint64_t chunk1,
-                             unsigned long long *vaf_hist, hipStream_t s);
+                             unsigned long long *vaf_hist, const unsigned long long *touched, bool write_refs, hipStream_t s);
 
 // Up to STATE_SPANS_MAX small blocks of 32-bit words filled with a value (src == null) or copied (src -> dst; dst may be pinned
 // host memory the device addresses) by ONE launch: the resets of ngsq_reset, the result download of ngsq_finalize.  kernels.hip

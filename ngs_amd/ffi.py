@@ -52,6 +52,12 @@ PASS_BOTH = 3
 SYNTH_FIXED = 0
 SYNTH_MIXED = 1
 SYNTH_SEQ_IID, SYNTH_SEQ_FROM_REFERENCE = 0, 1  # ngsq_shared.h: where a synthetic read's bases come from
+
+
+def synth_seq_subst(fraction: float) -> int:
+    """NGSQ_SYNTH_SEQ_SUBST: reads sampled from the reference with this fraction of their compared bases substituted."""
+    return SYNTH_SEQ_FROM_REFERENCE | (max(1, min(65535, int(round(fraction * 65536)))) << 16)
+
 SYNTH_FILE_PLAIN, SYNTH_FILE_ALIGNER, SYNTH_FILE_CIGAR_MIX, SYNTH_FILE_REALISTIC = 0, 1, 2, 3  # ngsq_shared.h: what a synthetic BAM FILE carries
 
 u8p = C.POINTER(C.c_uint8)
@@ -260,6 +266,7 @@ PROTOTYPES = {
     "ngsq_abi_version": (C.c_uint32, []),
     "ngsq_device_count": (C.c_int, []),
     "ngsq_facet_name": (C.c_char_p, [C.c_uint32]),
+    "ngsq_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "ngsq_last_global_error": (C.c_char_p, []),
     "ngsq_create": (C.c_int, [C.POINTER(Config), C.POINTER(ctx_p)]),
     "ngsq_destroy": (None, [ctx_p]),

@@ -410,6 +410,44 @@ def test_edits_positions_against_a_literal_walk(gpu_lib, oracle_mod, mode):
         assert r1[:50].sum() + r2[:50].sum() == 0
 
 
+@pytest.mark.parametrize("mode", ["fixed", "aligner", "subst25", "ragged_rows", "ids"])
+def test_gc_content_tallied_by_the_edits_kernel(gpu_lib, oracle_mod, mode):
+    """With GC Content and Edits both enabled, fixed-pitch rows of up to 160 bases are scanned ONCE: k_edits_rows tallies the GC
+    window from the sequence bytes it compares and k_gc is not launched (round 5).  Every GC counter and the histogram against
+    the oracle -- 150-base reads (plain, an aligner's CIGARs, a quarter of the bases substituted), rows of 60-160 bases padded to
+    one pitch (reads below the 100-base window, windows at every offset and parity, duplicates / secondaries), records with
+    identities of their own (the offset is drawn from them) -- and the launch counts that say which kernel did it."""
+    from tests.util import to_fixed_stride
+    rng = np.random.default_rng(91)
+    facets = ffi.FACETS_DEFAULT | ffi.FACET_EDITS
+    if mode in ("ragged_rows", "ids"):
+        ref_len = [9000, 2500]
+        bases = random_ref_bases(rng, ref_len)
+        hb = to_fixed_stride(make_edit_friendly(random_batch(rng, 9000, ref_len, weird=False, min_len=60, max_len=160), rng, bases, ref_len))
+        assert hb.seq_stride == 80 and hb.cols["seq_off"] is None
+        if mode == "ids":
+            hb.cols["record_id"] = rng.integers(0, 1 << 62, hb.n).astype(np.uint64)
+    else:
+        ref_len = [150_000, 20_000]
+        cfg = host.synth_config(30_000, ref_len=ref_len[0], n_refs=2, file_style=ffi.SYNTH_FILE_CIGAR_MIX if mode == "aligner" else 0,
+                                seq_model=ffi.synth_seq_subst(0.25) if mode == "subst25" else ffi.SYNTH_SEQ_FROM_REFERENCE)
+        bases = [host.synth_reference(cfg, r, L, gpu_lib) for r, L in enumerate(ref_len)]
+        hb = host.synth_host_batch(cfg, 0, 30_000, gpu_lib)
+    for on_device in (False, True):
+        gpu, orc = run_both(oracle_mod, gpu_lib, [hb.slice(0, hb.n // 3), hb.slice(hb.n // 3, hb.n)], ref_len, facets=facets, ref_bases=bases,
+                            on_device=on_device)
+        t = gpu.kernel_timing()
+        assert t["gc"]["launches"] == 0 and t["edits"]["launches"] == 2, t     # the GC window was tallied by the Edits launch
+        g = gpu.gc_content()
+        assert g["processed"] > 0.5 * hb.n and (mode != "ragged_rows" or g["ignored_too_short"] > 100)
+    # the same records through the offsets layout keep k_gc (and give the same document: run_both compares with the oracle)
+    if mode == "fixed":
+        ragged = host.synth_host_batch(host.synth_config(30_000, mode=ffi.SYNTH_MIXED, ref_len=ref_len[0], n_refs=2, seq_model=ffi.SYNTH_SEQ_FROM_REFERENCE),
+                                       0, 30_000, gpu_lib)
+        gpu, _ = run_both(oracle_mod, gpu_lib, [ragged], ref_len, facets=facets, ref_bases=bases)
+        assert gpu.kernel_timing()["gc"]["launches"] == 1
+
+
 @pytest.mark.parametrize("sorted_rows,cigar_offsets", [(True, False), (True, True), (False, False)])
 def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar_offsets):
     """k_edits_rows compares the second M of `M (I|D) M` in a step of its own (edits_kernel.hip 2c), against the reference
@@ -536,6 +574,51 @@ def test_full_size_properties(gpu_lib, n, sorted_input):
         gpu.process_batch(db)
         gpu.finalize()
         json_equal(gpu.results(["chr1", "chr2"]), first)  # deterministic
+
+
+def test_full_size_properties_mixed(gpu_lib):
+    """BASELINE configs[4]'s shape on one GPU at its full 100 M records (50-300 bp reads, clips / insertions / deletions / skips,
+    ragged columns with offsets): the quality table against the read lengths themselves (row c = the reads longer than c -- the
+    16-bit LDS counters of k_qual_ragged and their flushes), the CIGAR tallies against the operations column (the offsets-layout
+    k_fields), the depth total against the reference-consuming operations, the depth histogram over L + 1 positions, determinism."""
+    n, L = 100_000_000, 248_956_422
+    cfg = host.synth_config(n, mode=ffi.SYNTH_MIXED, max_len=300, ref_len=L, n_refs=2)
+    with host.QcContext([L, 242_193_529], max_read_len=300, sorted_input=True, lib=gpu_lib) as gpu:
+        db = gpu.synth_device_batch(cfg, 0, n)
+        gpu.process_batch(db)
+        gpu.finalize()
+        g = gpu.general()
+        assert g["total"] == n and g["primary"] + g["secondary"] + g["supplementary"] == n
+        l_seq = gpu.download_column(db, "l_seq", n)
+        assert int(l_seq.min()) >= 50 and int(l_seq.max()) == 300
+        longer = n - np.cumsum(np.bincount(l_seq, minlength=301))   # longer[c] = reads with more than c bases
+        q = gpu.quality_scores()
+        rows = q.sum(axis=1)
+        assert rows.shape[0] >= 300 and (rows[:300] == longer[:300]).all() and not rows[300:].any()
+        assert int(rows.sum()) == db.qual_bytes == int(l_seq.sum(dtype=np.int64))
+        del l_seq
+        cigar = gpu.download_column(db, "cigar", db.cigar_ops)
+        ops, lens = cigar & 15, (cigar >> 4).astype(np.int64)
+        per_kind = np.bincount(ops, minlength=9)
+        one, two = np.asarray(g["read_one_cigar_ops"]), np.asarray(g["read_two_cigar_ops"])
+        assert ((one + two) == per_kind[:9]).all() and int((one + two).sum()) == db.cigar_ops
+        consumed = int(lens[(ops == 0) | (ops == 2) | (ops == 3) | (ops == 7) | (ops == 8)].sum())
+        del cigar, ops, lens
+        h, processed, ignored = gpu.template_length()
+        assert processed + ignored == n and h.sum() == processed
+        gc = gpu.gc_content()
+        assert gc["processed"] + gc["ignored_flags"] + gc["ignored_too_short"] == n and gc["ignored_too_short"] > 0
+        assert gc["histogram"].sum() == gc["processed"]
+        assert gc["total_gc_count"] + gc["total_at_count"] + gc["total_other_count"] == 100 * gc["processed"]
+        seen, hist, ign, bins = gpu.coverage_sequence(0)
+        assert seen and hist.sum() + ign == L + 1
+        assert int(bins.sum()) == consumed      # every M / D / N / = / X base of a placed read is one unit of depth (coverage.rs:159-176)
+        assert gpu.coverage_nonsensical() == 0 and not gpu.coverage_sequence(1)[0]
+        first = gpu.results(["chr1", "chr2"])
+        gpu.reset()
+        gpu.process_batch(db)
+        gpu.finalize()
+        json_equal(gpu.results(["chr1", "chr2"]), first)
 
 
 # ---------------------------------------------------------------------------------------------
