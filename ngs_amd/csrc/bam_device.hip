@@ -178,8 +178,11 @@ __device__ __forceinline__ bool walk(const uint8_t *raw, uint64_t n_bytes, uint6
 // instead of holding a quarter as many resident waves' worth of latency.
 __global__ __launch_bounds__(64) void k_rec_candidates(const uint8_t *__restrict__ raw, uint64_t n_bytes, uint64_t first,
                                                        uint32_t n_seg, int32_t n_ref, RecCandidate *__restrict__ cand,
-                                                       RecPieces *__restrict__ pieces) {
+                                                       RecPieces *__restrict__ pieces, unsigned long long *__restrict__ work) {
     NGSQ_FOREGROUND_WAVE();
+    // the chunk's "smallest index of an invalid record" starts at "none" (k_rec_offsets, the next kernel of the chunk on this stream,
+    // lowers it; until round 5 a memset per chunk)
+    if (work && blockIdx.x == 0 && threadIdx.x == 0) work[W_BAD] = ~0ull;
     constexpr uint32_t G = REC_GROUP, LIST = REC_CANDIDATES;
     static_assert(G * LIST <= 64, "a lane per chain");
     __shared__ uint64_t s_list[G * LIST];
@@ -758,9 +761,9 @@ hipError_t launch_copy_words(void *dst, const void *src, uint64_t n_bytes, hipSt
     return hipGetLastError();
 }
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
-                                 RecCandidate *cand, RecPieces *pieces, hipStream_t s) {
+                                 RecCandidate *cand, RecPieces *pieces, unsigned long long *work, hipStream_t s) {
     if (!n_seg) return hipSuccess;
-    hipLaunchKernelGGL(k_rec_candidates, dim3((n_seg + REC_GROUP - 1) / REC_GROUP), dim3(64), 0, s, raw, n_bytes, first, n_seg, n_ref, cand, pieces);
+    hipLaunchKernelGGL(k_rec_candidates, dim3((n_seg + REC_GROUP - 1) / REC_GROUP), dim3(64), 0, s, raw, n_bytes, first, n_seg, n_ref, cand, pieces, work);
     return hipGetLastError();
 }
 hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t seg_start, uint64_t end, RecCandidate *out,

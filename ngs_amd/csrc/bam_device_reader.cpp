@@ -261,6 +261,8 @@ struct DeviceIngest {
     DevBuf<uint64_t> d_var_base;              // per record of the batch: offset of its CIGAR in raw
     DevBuf<uint64_t> d_rec_off, d_len; // d_len: seq | qual | cigar lengths -> offsets
     DevBuf<unsigned long long> d_small;       // REC_WORK_WORDS words shared by k_rec_offsets / k_rec_fixed (ingest_kernels.h RecWork)
+    bool inf_masked = false;                  // NGSQ_INFLATE_CU_EXCLUDE: the inflate streams carry a CU mask (not from the cache)
+    uint32_t inf_ctr_base[2] = {0, 0};        // what the decoders' counters (d_small[W_INF0 / W_INF1]) hold before the next launch
     DevBuf<uint16_t> d_flag, d_n_cigar;
     DevBuf<uint8_t> d_mapq;
     DevBuf<int32_t> d_ref_id, d_pos, d_mate, d_tlen;
@@ -309,7 +311,8 @@ struct DeviceIngest {
         for (auto &q : inf_stream)
             if (q) {
                 (void)hipStreamSynchronize(q);
-                pool_stream_put(inf_low_priority, q);
+                if (inf_masked) (void)hipStreamDestroy(q);
+                else pool_stream_put(inf_low_priority, q);
             }
         for (auto &e : h2d_done) pool_event_put(e);
         for (auto &e : inf_done) pool_event_put(e);
@@ -685,8 +688,9 @@ void reader_main(DeviceIngest *d, std::string path) {
                 ok = hipMemcpyAsync(d->d_blocks_s[k].p, c.tab.h, tb, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess &&
                      hipMemcpyAsync(d->d_coff_s[k].p, static_cast<uint8_t *>(c.tab.h) + tb, ob, hipMemcpyHostToDevice, d->copy_stream) == hipSuccess;
             }
-            ok = ok && hipMemsetAsync(d->d_comp_slot[k].p + c.consumed, 0, INFLATE_IN_SLACK, d->copy_stream) == hipSuccess &&
-                 hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
+            // (the INFLATE_IN_SLACK bytes behind the chunk's last payload must be READABLE -- the decoders' input windows reach past a
+            // block's end, into the next block's bytes everywhere but here -- not zero: no memset per chunk)
+            ok = ok && hipEventRecord(d->h2d_done[k], d->copy_stream) == hipSuccess;
             d->h2d_issued[k] = ok; // on failure the consumer copies on its own stream (and reports errors)
         }
         if (trace_on())
@@ -727,7 +731,7 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, d->raw_len);
         BHIP(launch_rec_candidates(d->raw, d->raw_len, first, n_seg, (int32_t)b->ref_names.size(), static_cast<RecCandidate *>(d->h_cand.dev),
-                                   d->d_pieces.p, st));
+                                   d->d_pieces.p, d->d_small.p, st));
     }
     BHIP(hipStreamSynchronize(st));
     const RecCandidate *const cand = static_cast<const RecCandidate *>(d->h_cand.h);
@@ -799,7 +803,6 @@ int index_records(ngsq_bam *b, DeviceIngest *d, uint64_t first, uint64_t *out_to
     // wave and array.  Until late in round 4 a copy kernel brought them over first -- one launch per chunk that waited 90 us on
     // average, up to 1.3 ms, for a wave slot beside the decoders: 20 ms per 24 M-record scan for 256 KB)
     const uint32_t *const seg_dev = static_cast<const uint32_t *>(d->h_seg.dev);
-    BHIP(hipMemsetAsync(d->d_small.p + W_BAD, 0xFF, sizeof(unsigned long long), st));
     {
         KernelTimer kt(d->ctx, K_REC_INDEX, 0);
         BHIP(launch_rec_offsets(d->raw, d->raw_len, n_pieces, seg_dev + n_seg, seg_dev,
@@ -839,8 +842,9 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, uint64_t j) {
     if (!p.err.empty() || !p.n_blk) return NGSQ_OK;
     p.blocks = c.blocks;
     p.coff = c.coff;
-    hipStream_t sb = d->inf_stream[d->inflate_streams > 1 ? j & 1 : 0];
-    BHIP(d->d_status_s[k].reserve(p.n_blk + 1)); // + the decoders' block counter
+    const int si = d->inflate_streams > 1 ? (int)(j & 1) : 0;
+    hipStream_t sb = d->inf_stream[si];
+    BHIP(d->d_status_s[k].reserve(p.n_blk + 1));
     if (p.status_cap < p.n_blk) {
         const size_t cap = p.n_blk + p.n_blk / 4 + 1024;
         BHIP(p.pin.reserve((cap + 2) * (sizeof(uint32_t) + sizeof(BgzfBlock) + sizeof(uint64_t))));
@@ -865,7 +869,6 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, uint64_t j) {
         memcpy(p.pin_coff, p.coff.data(), p.n_blk * sizeof(uint64_t));
         BHIP(d->d_comp_slot[k].reserve(p.consumed + INFLATE_IN_SLACK));
         BHIP(ngsq::pool_pinned_h2d(d->d_comp_slot[k].p, c.h, 0, p.consumed, sb));
-        BHIP(hipMemsetAsync(d->d_comp_slot[k].p + p.consumed, 0, INFLATE_IN_SLACK, sb));
         BHIP(launch_copy_words(d->d_blocks_s[k].p, dev_of(p.pin_blocks), p.n_blk * sizeof(BgzfBlock), sb));
         BHIP(launch_copy_words(d->d_coff_s[k].p, dev_of(p.pin_coff), p.n_blk * sizeof(uint64_t), sb));
     }
@@ -873,8 +876,9 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, uint64_t j) {
     uint8_t *out = d->d_rawb[rs].p + CARRY_MAX;
     {   // algorithmic bytes of the inflate: compressed bytes read + inflated bytes written
         KernelTimer kt(d->ctx, K_INFLATE, p.consumed + p.total, sb);
+        // (the decoders' block counter: a word per inflate stream that is never reset -- no memset per launch)
         BHIP(launch_bgzf_inflate(d->d_comp_slot[k].p, d->d_blocks_s[k].p, (uint32_t)p.n_blk, out, d->d_status_s[k].p,
-                                 d->d_status_s[k].p + p.n_blk, false, sb));
+                                 reinterpret_cast<uint32_t *>(d->d_small.p + (si ? W_INF1 : W_INF0)), false, sb, &d->inf_ctr_base[si]));
     }
     {   // (the decoders' verdicts reach the host through this kernel: it writes every block's final status into pinned memory)
         KernelTimer kt(d->ctx, K_INFLATE_CRC, p.total, sb);
@@ -1159,7 +1163,21 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
         // the slots its decoders free, instead of queueing behind all of them
         const char *e = getenv("NGSQ_INFLATE_PRIORITY");
         d->inf_low_priority = !(e && atoi(e) == 0); // =0: normal priority (A/B measurements)
-        for (auto &q : d->inf_stream) BHIP(ngsq::pool_stream_get(d->inf_low_priority, &q));
+        // NGSQ_INFLATE_CU_EXCLUDE=N (measurement aid): the decoders stay off N compute units, which the CRC and
+        // the parse kernels then find free whatever the decoders do (hipExtStreamCreateWithCUMask; launch_bgzf_inflate sizes its
+        // resident grid by the same variable).  Such streams are not cached.
+        const int excl = getenv("NGSQ_INFLATE_CU_EXCLUDE") ? atoi(getenv("NGSQ_INFLATE_CU_EXCLUDE")) : 0;
+        int n_cu = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (excl > 0 && excl < n_cu) {
+            std::vector<uint32_t> m((size_t)(n_cu + 31) / 32, 0u);
+            for (int k = excl; k < n_cu; k++) m[(size_t)k / 32] |= 1u << (k % 32);
+            for (auto &q : d->inf_stream) BHIP(hipExtStreamCreateWithCUMask(&q, (uint32_t)m.size(), m.data()));
+            d->inf_masked = true;
+        } else {
+            for (auto &q : d->inf_stream) BHIP(ngsq::pool_stream_get(d->inf_low_priority, &q));
+        }
     }
     for (auto &e : d->h2d_done) BHIP(ngsq::pool_event_get(&e));
     for (auto &e : d->inf_done) BHIP(ngsq::pool_event_get(&e));
@@ -1177,6 +1195,7 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
         unsigned long long w[REC_WORK_WORDS];
         rec_work_init(w);
         BHIP(hipMemcpy(d->d_small.p, w, sizeof w, hipMemcpyHostToDevice));
+        d->inf_ctr_base[0] = d->inf_ctr_base[1] = 0; // (the decoders' counters are among those words)
     }
     // the host side of this handle is done: release its buffers
     std::vector<uint8_t>().swap(b->comp);

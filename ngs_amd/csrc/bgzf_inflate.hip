@@ -998,12 +998,12 @@ __device__ __forceinline__ void inflate_block(Lds &L, const uint8_t *__restrict_
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NGSQ_INFLATE_WAVES, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ comp,
                                                      const BgzfBlock *__restrict__ blocks, uint32_t n_blocks,
                                                      uint8_t *__restrict__ out, uint32_t *__restrict__ status,
-                                                     uint32_t *__restrict__ next_block) {
+                                                     uint32_t *__restrict__ next_block, uint32_t base) {
     __shared__ Lds L; // (static: with a dynamic allocation every LDS address is computed with an add of the base, zero)
     const uint32_t lane = threadIdx.x;
     for (;;) {
         uint32_t bi = 0;
-        if (lane == 0) bi = atomicAdd(next_block, 1u);
+        if (lane == 0) bi = atomicAdd(next_block, 1u) - base; // (the counter is never reset: `base` is what the launch found in it)
         bi = uni(bi);
         if (bi >= n_blocks) return;
         inflate_block(L, comp, blocks, bi, out, status, lane);
@@ -1113,7 +1113,7 @@ hipError_t launch_bgzf_crc(const BgzfBlock *blocks, uint32_t n_blocks, const uin
 }
 
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
-                               uint32_t *status, uint32_t *counter, bool check_crc, hipStream_t s) {
+                               uint32_t *status, uint32_t *counter, bool check_crc, hipStream_t s, uint32_t *counter_base) {
     if (!n_blocks) return hipSuccess;
     static bool attr = false;
     static uint32_t resident = 0;
@@ -1125,13 +1125,21 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         // registers and a wave slot for the other stream's kernels (NGSQ_INFLATE_PER_CU: measurement aid)
         uint32_t per_cu = 24;
         if (const char *v = getenv("NGSQ_INFLATE_PER_CU")) per_cu = (uint32_t)atoi(v); // 0: a workgroup per block, as before
+        if (const char *v = getenv("NGSQ_INFLATE_CU_EXCLUDE")) // (the inflate streams are confined to the other CUs: bam_device_reader.cpp)
+            if (atoi(v) > 0 && atoi(v) < n_cu) n_cu -= atoi(v);
         resident = per_cu ? (uint32_t)n_cu * per_cu : 0xFFFFFFFFu;
         attr = true;
     }
-    hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_blocks < resident ? n_blocks : resident), dim3(64), 0, s, comp, blocks, n_blocks, out,
-                       status, counter);
+    const uint32_t grid = n_blocks < resident ? n_blocks : resident;
+    uint32_t base = 0;
+    if (counter_base) { // every decoder draws one ticket past the blocks when it leaves
+        base = *counter_base;
+        *counter_base = base + n_blocks + grid;
+    } else {
+        hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(grid), dim3(64), 0, s, comp, blocks, n_blocks, out, status, counter, base);
     if (check_crc) (void)launch_bgzf_crc(blocks, n_blocks, out, status, nullptr, s);
 #ifdef NGSQ_INFLATE_PROFILE
     {

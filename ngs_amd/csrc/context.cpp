@@ -125,10 +125,6 @@ static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
 // NGSQ_STEP_LEGACY=1 (measurement aid): ngsq_reset and ngsq_finalize as they were until round 4 -- one hipMemsetAsync per small
 // block, one device-to-host copy per result block -- for an A/B of the time a step spends outside its kernels
-#ifndef NGSQ_FEATURES_SIDE_DEFAULT
-#define NGSQ_FEATURES_SIDE_DEFAULT false
-#endif
-
 static bool step_legacy() {
     static const bool v = [] { const char *e = getenv("NGSQ_STEP_LEGACY"); return e && atoi(e) != 0; }();
     return v;
@@ -410,12 +406,6 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_last_key);
     (void)hipFree(c->d_chunk_flags);
     if (c->pin_results) (void)hipHostFree(c->pin_results);
-    if (c->side_stream) {
-        (void)hipStreamSynchronize(c->side_stream);
-        (void)hipStreamDestroy(c->side_stream);
-        (void)hipEventDestroy(c->side_fork);
-        (void)hipEventDestroy(c->side_done);
-    }
     if (c->xchg_scratch) ngsq::free_exchange_scratch(c->xchg_scratch);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -570,34 +560,11 @@ static int column_sizes(ngsq_ctx *c, const ngsq_batch *b, ColumnSizes *cs) {
     return NGSQ_OK;
 }
 
-// NGSQ_FEATURES_SIDE=0/1: Genomic Features beside the other facets' kernels on a stream of its own (it reads 16 bytes per record, uses no
-// LDS and waits for its own three dependent stages: what it leaves of a CU the bandwidth-bound kernels can use)
-static bool features_on_side_stream() {
-    static const bool v = [] { const char *e = getenv("NGSQ_FEATURES_SIDE"); return e ? atoi(e) != 0 : NGSQ_FEATURES_SIDE_DEFAULT; }();
-    return v;
-}
-
 static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs, uint32_t pass_mask) {
     const uint32_t facets = c->cfg.facets;
     const uint64_t n = db.n;
     const uint32_t rec_f = (pass_mask & NGSQ_PASS_RECORD) ? (facets & NGSQ_FACETS_RECORD_BASED) : 0;
     const uint32_t seq_f = (pass_mask & NGSQ_PASS_SEQUENCE) ? (facets & NGSQ_FACETS_SEQUENCE_BASED) : 0;
-    bool side_join = false;
-    if ((rec_f & NGSQ_FACET_FEATURES) && c->have_features && features_on_side_stream() && (rec_f | seq_f) != NGSQ_FACET_FEATURES) {
-        if (!c->side_stream) {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
-        }
-        HIP_TRY(c, hipEventRecord(c->side_fork, c->stream)); // (behind the batch's host-to-device copies, and behind ngsq_reset)
-        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
-        {
-            Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4, c->side_stream);
-            HIP_TRY(c, launch_features(c->li, c->st, db, c->ft, c->side_stream));
-        }
-        HIP_TRY(c, hipEventRecord(c->side_done, c->side_stream));
-        side_join = true;
-    }
     if ((rec_f & (NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH)) || (seq_f & NGSQ_FACET_COVERAGE)) {
         const bool walk = (rec_f & NGSQ_FACET_GENERAL) || (seq_f & NGSQ_FACET_COVERAGE);
         const bool cov = (seq_f & NGSQ_FACET_COVERAGE) != 0;
@@ -624,7 +591,8 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
             HIP_TRY(c, launch_fields(c->li, c->st, db, rec_f, cov ? (c->stream_cov ? 2 : 1) : 0, c->stream));
         }
         if (cov && c->stream_cov) {
-            // (on a stream of its own beside k_gc / k_qual it hides its 0.7 ms and costs k_qual_perm 1.2: DESIGN appendix A.8)
+            // (on a stream of its own beside k_gc / k_qual it hides its 0.7 ms and costs k_qual_perm 1.2: DESIGN appendix A.8; confined to
+            // 16-96 compute units by a CU mask, with or without the other kernels kept off them, 5.74-16.7 ms per step against 5.55: A.9)
             Bracket br(c, K_COV_STREAM, n * 8); // pos + cov_end of every record
             HIP_TRY(c, launch_cov_stream(c->li, c->st, db, c->csa, c->stream));
         }
@@ -640,7 +608,8 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
         Bracket br(c, K_QUAL, cs.qual_bytes);
         HIP_TRY(c, launch_qual(c->li, c->st, db, c->stream));
     }
-    if ((rec_f & NGSQ_FACET_FEATURES) && !side_join) {
+    if (rec_f & NGSQ_FACET_FEATURES) {
+        // (on a stream of its own beside the other facets' kernels it hides nothing: 10.9 ms per all-facets pass either way, round 5)
         if (!c->have_features)
             return fail(c, NGSQ_ERR_STATE, "NGSQ_FACET_FEATURES is enabled but ngsq_set_features was not called");
         Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4);
@@ -659,7 +628,6 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
         }
         HIP_TRY(c, launch_edits(c->li, c->st, db, c->d_edits_defer, gc_in_edits, c->stream));
     }
-    if (side_join) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->side_done, 0));
     return NGSQ_OK;
 }
 
@@ -917,12 +885,6 @@ int ngsq_finalize(ngsq_ctx *c) {
     } else {
         if (c->pin_words < need) {
             if (c->pin_results) (void)hipHostFree(c->pin_results);
-    if (c->side_stream) {
-        (void)hipStreamSynchronize(c->side_stream);
-        (void)hipStreamDestroy(c->side_stream);
-        (void)hipEventDestroy(c->side_fork);
-        (void)hipEventDestroy(c->side_done);
-    }
             c->pin_results = nullptr;
             c->pin_words = 0;
             HIP_TRY(c, hipHostMalloc((void **)&c->pin_results, (need + need / 4) * 8, hipHostMallocMapped));

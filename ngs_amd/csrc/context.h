@@ -99,8 +99,6 @@ struct ngsq_ctx {
     uint32_t *d_ft_idx = nullptr, *d_ft_starts = nullptr, *d_ft_stops = nullptr;
     uint8_t *d_ft_primary = nullptr;
     bool have_features = false;
-    hipStream_t side_stream = nullptr; // Genomic Features beside the other facets' kernels (context.cpp launch_all)
-    hipEvent_t side_fork = nullptr, side_done = nullptr;
     ngsq::Staging stage[2];
     int stage_next = 0;
     ngsq_kernel_time timing[ngsq::K_COUNT]{};

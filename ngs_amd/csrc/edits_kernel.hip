@@ -411,11 +411,13 @@ constexpr uint32_t EDR_WAVE_TILE = 64 * EDR_PASSES, EDR_TILE = ED_THREADS * EDR_
 #ifndef NGSQ_EDR_WINDOW
 #define NGSQ_EDR_WINDOW 1408 // (1536 until the histograms and the GC tally took 2.8 KB more: the block's LDS stays at 32 granules of 1280 bytes, four blocks per CU)
 #endif
-#ifdef NGSQ_EDR_WAVES // (measurement builds: waves per SIMD the register allocation is made for)
-#define EDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NGSQ_EDR_WAVES, NGSQ_EDR_WAVES)))
-#else
-#define EDR_WAVES_ATTR
+// waves per SIMD the register allocation is made for: four, what the block's LDS allows (the variant that also tallies GC Content
+// takes 143-148 registers when left alone -- three waves per SIMD: 3.9 ms per 100 M reads against 3.56 at four; the plain variant
+// fits by itself).  NGSQ_EDR_WAVES: measurement builds.
+#ifndef NGSQ_EDR_WAVES
+#define NGSQ_EDR_WAVES 4
 #endif
+#define EDR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NGSQ_EDR_WAVES, NGSQ_EDR_WAVES)))
 constexpr uint32_t EDR_WINDOW = NGSQ_EDR_WINDOW;            // entries of the wave's cover window (256 sorted reads: 790 positions at 60x, 1430 at 30x: there the last few reads of a tile go to the walk)
 constexpr uint32_t GC_NONE = 0x3FFu;             // "no GC window": an offset whose window lies behind every 16-byte window of a row
 constexpr uint32_t GC_HW = (NGSQ_GC_BINS + 1) / 2; // words of a 101-bin histogram of 16-bit pairs
@@ -424,7 +426,6 @@ constexpr uint32_t EDR_ALTW = EDR_WINDOW / 2;    // dwords of its alts window: 1
 struct EdRowCols {
     uint32_t flag, l, n_ops, g0, g1, g2;
     int32_t ref, pos;
-    uint64_t rid; // GC: the record's identity (the GC window offset is drawn from it)
 };
 
 // CIG_OFF: the CIGARs are addressed through cigar_off (their loads then wait for the offsets; with a fixed pitch they are
@@ -495,8 +496,6 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
         r.pos = b.pos[ii];
         r.l = b.l_seq[ii];
         r.n_ops = b.n_cigar[ii];
-        r.rid = 0;
-        if (GC) r.rid = b.record_id ? b.record_id[ii] : b.first_record_index + ii;
         r.g0 = r.g1 = r.g2 = 0;
         if (!CIG_OFF) {
             const uint64_t cb = ii * (uint64_t)b.cigar_stride;
@@ -627,6 +626,8 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             if (R > 1) wb = begin_win();
             // ---- 1. lane = record
             EdRowCols r = cur;
+            uint64_t rid = 0; // GC: the record's identity, what its window's offset is drawn from (requested here, used at the end of the step)
+            if (GC) rid = b.record_id ? b.record_id[r0 + lane < n ? r0 + lane : n - 1] : b.first_record_index + r0 + lane;
             if (CIG_OFF) {
                 const uint64_t i = r0 + lane;
                 const uint64_t cb = b.cigar_off[i < n ? i : n - 1];
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 const bool live = r0 + lane < n;
                 const bool ign_f = live && (r.flag & 0x500u), ign_s = live && !ign_f && r.l < NGSQ_GC_WINDOW;
                 gc_take = live && !ign_f && !ign_s;
-                goff[lane] = (uint16_t)(gc_take && r.l <= 2 * stride ? ngsq_gc_offset_fn(st.gc_seed, r.rid, r.l) : GC_NONE);
+                goff[lane] = (uint16_t)(gc_take && r.l <= 2 * stride ? ngsq_gc_offset_fn(st.gc_seed, rid, r.l) : GC_NONE);
                 if (!(lane & 1u)) gacc[lane >> 1] = 0; // (read by step 3 of the previous pass: LDS operations of a wave execute in order)
                 const u64 mf = __ballot(ign_f), ms = __ballot(ign_s);
                 if (lane == 0 && (mf | ms)) {
@@ -993,15 +994,20 @@ __global__ __launch_bounds__(1024) void k_edits_chunk_scan(uint32_t *__restrict_
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs, const uint32_t *__restrict__ alts, uint64_t n_entries,
-                                                     const uint32_t *__restrict__ carry, uint32_t chunk0, u64 *vaf_hist, const u64 *touched) {
+                                                     const uint32_t *__restrict__ carry, uint32_t chunk0, uint32_t chunk1, u64 *vaf_hist, const u64 *touched) {
     __shared__ uint32_t s_h[NGSQ_VAF_BINS];
     __shared__ uint32_t s_w[4];
     if (touched && !*touched) return;
     if (threadIdx.x < NGSQ_VAF_BINS) s_h[threadIdx.x] = 0;
-    const uint32_t chunk = chunk0 + blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t zero_bin = 0;       // covered positions of this thread with alts == 0 (VAF 0.0 -> bin 0)
+    __syncthreads();
+    // a block takes every gridDim.x-th chunk and adds its histogram to the global one ONCE (a block per chunk meant sixty thousand
+    // blocks per chromosome adding to the same bin: same-address atomics at the L2, ~9 ns each)
+#pragma unroll 1
+    for (uint32_t chunk = chunk0 + blockIdx.x; chunk < chunk1; chunk += gridDim.x) {
     const uint64_t base = (uint64_t)chunk * EDC;
     uint32_t run = carry[chunk]; // sum of every entry in front of the chunk
-    __syncthreads();
 #pragma unroll 1
     for (uint32_t k = 0; k < EDC / 1024; k++) {
         const uint64_t i = base + (uint64_t)k * 1024 + threadIdx.x * 4;
@@ -1035,8 +1041,14 @@ __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs,
         for (uint32_t q = 0; q < 4; q++) {
             out[q] = cov - a[q];
             if (i + q < n_entries && cov && vaf_hist) {
-                const float vaf = __fdiv_rn((float)a[q], (float)cov); // total = refs + alts = cover
-                atomicAdd(&s_h[(uint32_t)__fmul_rn(vaf, 100.0f)], 1u);
+                // (a covered position without a mismatch -- 99 in 100 -- is bin 0: counted in a register; 64 lanes adding to that
+                // one LDS word serialise, and that, not the 8 bytes per position, was most of the teardown's time until round 5)
+                if (a[q] == 0u) {
+                    zero_bin += 1;
+                } else {
+                    const float vaf = __fdiv_rn((float)a[q], (float)cov); // total = refs + alts = cover
+                    atomicAdd(&s_h[(uint32_t)__fmul_rn(vaf, 100.0f)], 1u);
+                }
             }
             cov += d[q];
         }
@@ -1050,9 +1062,15 @@ __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs,
         run += step_total;
         __syncthreads();
     }
-    if (vaf_hist && threadIdx.x < NGSQ_VAF_BINS) {
-        const uint32_t v = s_h[threadIdx.x];
-        if (v) atomicAdd(&vaf_hist[threadIdx.x], (u64)v);
+    }
+    if (vaf_hist) {
+        zero_bin = ed_wave_sum(zero_bin);
+        if (lane == 0 && zero_bin) atomicAdd(&s_h[0], zero_bin);
+        __syncthreads();
+        if (threadIdx.x < NGSQ_VAF_BINS) {
+            const uint32_t v = s_h[threadIdx.x];
+            if (v) atomicAdd(&vaf_hist[threadIdx.x], (u64)v);
+        }
     }
 }
 
@@ -1122,10 +1140,11 @@ hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uin
 hipError_t launch_edits_refs(uint32_t *refs, const uint32_t *alts, uint64_t n_entries, const uint32_t *carry, uint64_t chunk0, uint64_t chunk1,
                              unsigned long long *vaf_hist, const unsigned long long *touched, bool write_refs, hipStream_t s) {
     if (chunk1 <= chunk0) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(chunk1 - chunk0, 4096);
     if (write_refs)
-        hipLaunchKernelGGL(k_edits_refs<true>, dim3((uint32_t)(chunk1 - chunk0)), dim3(256), 0, s, refs, alts, n_entries, carry, (uint32_t)chunk0, vaf_hist, touched);
+        hipLaunchKernelGGL(k_edits_refs<true>, dim3(grid), dim3(256), 0, s, refs, alts, n_entries, carry, (uint32_t)chunk0, (uint32_t)chunk1, vaf_hist, touched);
     else
-        hipLaunchKernelGGL(k_edits_refs<false>, dim3((uint32_t)(chunk1 - chunk0)), dim3(256), 0, s, refs, alts, n_entries, carry, (uint32_t)chunk0, vaf_hist, touched);
+        hipLaunchKernelGGL(k_edits_refs<false>, dim3(grid), dim3(256), 0, s, refs, alts, n_entries, carry, (uint32_t)chunk0, (uint32_t)chunk1, vaf_hist, touched);
     return hipGetLastError();
 }
 

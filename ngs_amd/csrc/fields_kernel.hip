@@ -263,15 +263,31 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         // arrive while the flag tallies below are made.  (Until round 4 each record's offset was loaded when its walk began and
         // its first operation behind that: eight dependent latencies per thread and tile; `k_fields<true, *>` took twice the
         // time of the fixed-pitch variants on the 50-300 bp workload.)
+        // Round 5: the SECOND and THIRD operations come with the first (a record of an aligner's file has one to three; the walk below
+        // then loads nothing for them -- it used to fetch every operation behind the first when it got there, one dependent latency
+        // per operation and record, with the other lanes of the wave waiting), and a full tile's five offsets are two 16-byte loads
+        // and one 8-byte load instead of five.
         uint64_t coff[FT_PER_THREAD + 1] = {0, 0, 0, 0, 0};
-        uint32_t cigf[FT_PER_THREAD] = {0, 0, 0, 0};
+        uint32_t cigf[FT_PER_THREAD] = {0, 0, 0, 0}, cig2[FT_PER_THREAD] = {0, 0, 0, 0}, cig3[FT_PER_THREAD] = {0, 0, 0, 0};
         if (CIG_OFF && (a.do_general || a.do_cov)) {
+            if (full_tile) {
+                ulonglong2 c01, c23;
+                __builtin_memcpy(&c01, b.cigar_off + r0, 16);
+                __builtin_memcpy(&c23, b.cigar_off + r0 + 2, 16);
+                coff[0] = c01.x, coff[1] = c01.y, coff[2] = c23.x, coff[3] = c23.y;
+                coff[4] = b.cigar_off[r0 + 4];
+            } else {
 #pragma unroll
-            for (uint32_t j = 0; j <= FT_PER_THREAD; j++)
-                if (j <= nrec && nrec) coff[j] = b.cigar_off[r0 + j];
+                for (uint32_t j = 0; j <= FT_PER_THREAD; j++)
+                    if (j <= nrec && nrec) coff[j] = b.cigar_off[r0 + j];
+            }
 #pragma unroll
-            for (uint32_t j = 0; j < FT_PER_THREAD; j++)
-                if (j < nrec && coff[j + 1] > coff[j]) cigf[j] = b.cigar[coff[j]];
+            for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
+                const uint64_t nj = j < nrec ? coff[j + 1] - coff[j] : 0;
+                if (nj > 0) cigf[j] = b.cigar[coff[j]];
+                if (nj > 1) cig2[j] = b.cigar[coff[j] + 1];
+                if (nj > 2) cig3[j] = b.cigar[coff[j] + 2];
+            }
         }
 #pragma unroll
         for (uint32_t j = 0; j < FT_PER_THREAD; j++) {
@@ -325,7 +341,9 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                     if (n_ops == 0xFFFFu) n_ops = (uint32_t)(coff[j + 1] - cbase); // (65535 = "or more": include/ngsq.h)
                 }
                 for (uint32_t k = 0; k < n_ops; k++) {
-                    const uint32_t cg = (cigar_vec && k == 0) ? cig1[j] : (CIG_OFF && k == 0) ? cigf[j] : b.cigar[cbase + k];
+                    const uint32_t cg = (cigar_vec && k == 0) ? cig1[j]
+                                        : (CIG_OFF && k < 3) ? (k == 0 ? cigf[j] : k == 1 ? cig2[j] : cig3[j])
+                                                             : b.cigar[cbase + k];
                     const uint32_t op = cg & 0xFu, len = cg >> 4;
                     if (op > 8u) {
                         bad_op += 1;

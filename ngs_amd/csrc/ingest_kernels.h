@@ -49,8 +49,11 @@ constexpr uint32_t INFLATE_IN_SLACK = 1024;
 
 // Inflate blocks [0, n_blocks): one wavefront per block at a time, a resident grid of decoders taking block after block
 // from *counter (device memory, 4 bytes, zeroed by the launcher on the stream).  status[k] = InflateStatus of block k.
+// counter_base (optional, host): the value *counter holds when this launch begins -- a caller that keeps one counter word for all
+// its launches on a stream passes it and gets the value behind this launch back (every decoder leaves the counter one past the
+// blocks: n_blocks + the grid); no memset per launch then.  NULL: *counter is zeroed on the stream first.
 hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uint32_t n_blocks, uint8_t *out,
-                               uint32_t *status, uint32_t *counter, bool check_crc, hipStream_t s);
+                               uint32_t *status, uint32_t *counter, bool check_crc, hipStream_t s, uint32_t *counter_base = nullptr);
 
 // CRC32 of every block's inflated bytes against its gzip trailer (status[k] = INF_CRC_MISMATCH); what
 // launch_bgzf_inflate(check_crc = true) runs second
@@ -105,8 +108,9 @@ struct RecOrigin {
 };
 
 // cand / pieces: REC_CANDIDATES entries per segment
+// work (optional): the REC_WORK_WORDS device words; work[W_BAD] is set to ~0 for the chunk (launch_rec_offsets lowers it)
 hipError_t launch_rec_candidates(const uint8_t *raw, uint64_t n_bytes, uint64_t first, uint32_t n_seg, int32_t n_ref,
-                                 RecCandidate *cand, RecPieces *pieces, hipStream_t s);
+                                 RecCandidate *cand, RecPieces *pieces, unsigned long long *work, hipStream_t s);
 // the chain from `start` inside the segment [seg_start, end), walked by one thread with the host reader's rules
 hipError_t launch_walk_one(const uint8_t *raw, uint64_t n_bytes, uint64_t start, uint64_t seg_start, uint64_t end, RecCandidate *out,
                            RecPieces *pieces, hipStream_t s);
@@ -127,7 +131,8 @@ hipError_t launch_count_below_u64(const uint64_t *a, uint64_t n, uint64_t value,
 // work: REC_WORK_WORDS device words the kernels keep between launches (initial state: rec_work_init); host: REC_HOST_WORDS words of
 // pinned host memory the device addresses, written by the launch's last block: what the layout decision needs, no copy
 // afterwards.  host[H_BAD] != ~0: the chunk's record chain holds an invalid record (its index), nothing else was done.
-enum RecWork : uint32_t { W_BAD = 0, W_MAXL, W_MAXOPS, W_SUML, W_FIRST, W_LAST, W_LONG, W_SUMOPS, W_TICKET, REC_WORK_WORDS = 16 };
+// (W_INF0 / W_INF1: not the parse kernels' -- the block counters of the decoders on the two inflate streams, never reset: launch_bgzf_inflate's counter_base)
+enum RecWork : uint32_t { W_BAD = 0, W_MAXL, W_MAXOPS, W_SUML, W_FIRST, W_LAST, W_LONG, W_SUMOPS, W_TICKET, W_INF0 = 12, W_INF1 = 13, REC_WORK_WORDS = 16 };
 enum RecHost : uint32_t { H_MAXL = 0, H_MAXOPS, H_SUML, H_FIRST, H_LAST, H_LONG, H_SUMOPS, H_BAD, REC_HOST_WORDS = 8 };
 inline void rec_work_init(unsigned long long *w) {
     for (uint32_t k = 0; k < REC_WORK_WORDS; k++) w[k] = 0;

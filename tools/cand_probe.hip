@@ -145,7 +145,7 @@ int main() {
         for (int r = 0; r < 5; r++) { hipEventRecord(e0, 0); fn(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
         printf("%-44s %.3f ms\n", name, best);
     };
-    time("k_rec_candidates", [&] { launch_rec_candidates(raw, n_bytes, 0, n_seg, 2, cand, pieces, 0); });
+    time("k_rec_candidates", [&] { launch_rec_candidates(raw, n_bytes, 0, n_seg, 2, cand, pieces, nullptr, 0); });
     time("screen only", [&] { hipLaunchKernelGGL(k_var<0>, dim3(n_seg), dim3(64), 0, 0, raw, n_bytes, 0, n_seg, 2, out); });
     time("screen + one lane walks", [&] { hipLaunchKernelGGL(k_var<1>, dim3(n_seg), dim3(64), 0, 0, raw, n_bytes, 0, n_seg, 2, out); });
     time("screen + all listed lanes walk", [&] { hipLaunchKernelGGL(k_var<2>, dim3(n_seg), dim3(64), 0, 0, raw, n_bytes, 0, n_seg, 2, out); });
@@ -155,7 +155,7 @@ int main() {
     time("chase, 1 wave per block, 1 load per hop", [&] { hipLaunchKernelGGL(k_chase, dim3(n_seg), dim3(64), 0, 0, raw, n_bytes, n_seg, rec, out, 1); });
     time("chase, 1 wave per block, 2 loads per hop", [&] { hipLaunchKernelGGL(k_chase, dim3(n_seg), dim3(64), 0, 0, raw, n_bytes, n_seg, rec, out, 2); });
     time("chase, 4 waves per block, 2 loads per hop", [&] { hipLaunchKernelGGL(k_chase, dim3((n_seg + 3) / 4), dim3(256), 0, 0, raw, n_bytes, n_seg, rec, out, 2); });
-    time("k_rec_candidates (again)", [&] { launch_rec_candidates(raw, n_bytes, 0, n_seg, 2, cand, pieces, 0); });
+    time("k_rec_candidates (again)", [&] { launch_rec_candidates(raw, n_bytes, 0, n_seg, 2, cand, pieces, nullptr, 0); });
     std::vector<RecCandidate> hc((size_t)n_seg * REC_CANDIDATES);
     CK(hipMemcpy(hc.data(), cand, hc.size() * sizeof(RecCandidate), hipMemcpyDeviceToHost));
     uint64_t cur = 0, total = 0; int miss = 0;
