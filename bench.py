@@ -100,6 +100,7 @@ def parse_args():
                          "separate passes, child processes started before this one touches HIP) give roofline.traffic of THIS run; "
                          "0, or any failure: the committed profiles/*_traffic.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-inflate-child", default="", help=argparse.SUPPRESS)   # path of the BAM this child scans once under rocprofv3 --pmc
     ap.add_argument("--extra-facet-legs", type=int, default=1,
                     help="1: also time the Edits and Genomic Features kernels on a 10 M-record slice (N = 1 only)")
     return ap.parse_args()
@@ -277,7 +278,12 @@ def main() -> int:
     os.dup2(2, 1)
 
     build_once()   # (touches no HIP; before the profiled child passes, so that they only ever LOAD a built library: ADVICE r4)
+    if args.pmc_inflate_child:
+        return pmc_inflate_child(args, json_fd)
     live = (None, None)
+    args.live_inflate = None
+    if world == 1 and args.live_traffic and not args.pmc_child and args.workload == "fixed" and not args.emulate_shard and args.file_records > 0:
+        args.live_inflate = live_inflate_traffic(args)   # (child processes; nothing in this process has touched HIP yet)
     if (world == 1 and args.live_traffic and not args.pmc_child and args.workload == "fixed" and not args.emulate_shard and not args.force_dist
             and (args.facets & 0x08)):
         live = live_pmc_traffic(args)   # (child processes; nothing in this process has touched HIP yet)
@@ -576,6 +582,20 @@ def check_invariants(ctx, ffi, total: int, args, mixed: bool, emulated: bool) ->
     return ("ok: %d full-size invariants" % checked) if not bad else "FAILED: " + "; ".join(bad)
 
 
+def ingest_traffic(args, algo_bytes_per_launch: int):
+    """ingest_roofline.traffic: measured by this run (live_inflate_traffic) when it could be, else the committed summary."""
+    li = getattr(args, "live_inflate", None)
+    if li and "per_algo_byte_raw" in li:
+        return {"traffic": round(li["per_algo_byte_raw"] * algo_bytes_per_launch),
+                "traffic_read_side_doubled": round(li["per_algo_byte_read_side_doubled"] * algo_bytes_per_launch),
+                "traffic_per_algorithmic_byte": [round(li["per_algo_byte_raw"], 3), round(li["per_algo_byte_read_side_doubled"], 3)],
+                "traffic_source": li["traffic_source"], "traffic_measured_in_this_run": True}
+    out = inflate_traffic(algo_bytes_per_launch)
+    if li:
+        out["live_traffic_unavailable"] = li.get("traffic_source")
+    return out
+
+
 def inflate_traffic(algo_bytes_per_launch: int):
     """HBM bytes per launch of k_bgzf_inflate, scaled from the committed PMC summary of tools/bench_inflate.py (one launch over
     1.5 GB of algorithmic bytes) to this run's launch size.  Raw and with the read side doubled: the doubling is the guide's
@@ -640,6 +660,86 @@ def live_pmc_traffic(args, mixed=False):
                                                                             "each, run by this command before its own timed steps; read side doubled (gfx950)")
     except Exception as e:  # noqa: BLE001 -- never required
         return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_inflate_child(args, json_fd) -> int:
+    """Under rocprofv3 --pmc: one in-process scan of the BAM the parent wrote; prints the algorithmic bytes of its inflate launches."""
+    import ctypes as C
+    from ngs_amd import ffi, host
+    lib = ffi.load_library()
+    path = args.pmc_inflate_child
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=1024, gc_seed=GC_SEED, sorted_input=True, timing=False, lib=lib)
+    h = C.c_void_p()
+    if lib.ngsq_bam_open(path.encode(), 0, C.byref(h)) != 0:
+        return 4
+    n = 0
+    while True:
+        b = ffi.Batch()
+        if lib.ngsq_bam_next_batch_device(h, ctx._ctx, 1 << 22, C.byref(b)) != 0 or b.n_records == 0:
+            break
+        n += int(b.n_records)
+        lib.ngsq_process_batch(ctx._ctx, C.byref(b), ffi.PASS_BOTH)
+    lib.ngsq_bam_close(h)
+    ctx.finalize()
+    t = ctx.kernel_timing()["bgzf_inflate"]
+    ctx.close()
+    os.write(json_fd, (json.dumps({"records": n, "inflate_algo_bytes": t["algo_bytes"], "launches": t["launches"]}) + "\n").encode())
+    return 0
+
+
+def live_inflate_traffic(args):
+    """HBM bytes per ALGORITHMIC byte of k_bgzf_inflate, measured by this command: a small file of the bench's plain style written here
+    (host code, no HIP), scanned once by a child under `rocprofv3 --pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE` (separate
+    passes, MI355X_MICROARCH.md).  Returns a dict for ingest_roofline, or {"traffic_source": why not}."""
+    import csv
+    import ctypes as C
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return {"traffic_source": "unavailable: rocprofv3 not on PATH"}
+    for k, v in os.environ.items():
+        if k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD") or k.startswith("ROCPROF") or \
+                (k == "LD_PRELOAD" and "rocprof" in v.lower()):
+            return {"traffic_source": f"unavailable: running under a profiler ({k} is set)"}
+    tmp = tempfile.mkdtemp(prefix="ngsq_pmci_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        from ngs_amd import ffi, host
+        lib = ffi.load_library()           # (loading the library and writing a file with it touch no HIP)
+        n = 4_000_000
+        bam = os.path.join(tmp, "small.bam")
+        cfg = host.synth_config(n, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+        if lib.ngsq_synth_write_bam(C.byref(cfg), bam.encode(), n, args.file_level, 0) != 0:
+            return {"traffic_source": "unavailable: could not write the small file"}
+        vals, algo = {}, None
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", out_dir, "-o", "out", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-inflate-child", bam]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=tmp)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"traffic_source": f"unavailable: rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"}
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{") and "inflate_algo_bytes" in ln), None)
+            if line is None:
+                return {"traffic_source": "unavailable: the profiled child printed no line"}
+            algo = json.loads(line)["inflate_algo_bytes"]
+            tot = 0.0
+            with open(files[0], newline="") as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == counter and "k_bgzf_inflate" in row["Kernel_Name"]:
+                        tot += float(row["Counter_Value"])
+            if not tot:
+                return {"traffic_source": f"unavailable: no {counter} rows for k_bgzf_inflate"}
+            vals[counter] = tot * 1024.0
+        return {"per_algo_byte_raw": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) / algo,
+                "per_algo_byte_read_side_doubled": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) / algo,
+                "traffic_source": "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one scan of a 4 M-record file of the same style, run by "
+                                  "this command before its own timed steps; scaled by this run's algorithmic bytes per launch"}
+    except Exception as e:  # noqa: BLE001 -- never required
+        return {"traffic_source": f"unavailable: {type(e).__name__}: {e}"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -960,7 +1060,7 @@ def leg_file(lib, host, ffi, args):
                 gbs = inf["algo_bytes"] / inf["total_ms"] / 1e6
                 out["ingest_roofline"] = {"bound": "hbm", "kernel": "k_bgzf_inflate", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                           "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                          **inflate_traffic(inf["algo_bytes"] // inf["launches"]),
+                                          **ingest_traffic(args, inf["algo_bytes"] // inf["launches"]),
                                           "avg_launch_ms": round(inf["total_ms"] / inf["launches"], 3),
                                           "algo_bytes_per_launch": inf["algo_bytes"] // inf["launches"],
                                           "note": "algorithmic bytes = compressed bytes read + inflated bytes written; the kernel is "

@@ -261,7 +261,6 @@ struct DeviceIngest {
     DevBuf<uint64_t> d_var_base;              // per record of the batch: offset of its CIGAR in raw
     DevBuf<uint64_t> d_rec_off, d_len; // d_len: seq | qual | cigar lengths -> offsets
     DevBuf<unsigned long long> d_small;       // REC_WORK_WORDS words shared by k_rec_offsets / k_rec_fixed (ingest_kernels.h RecWork)
-    bool inf_masked = false;                  // NGSQ_INFLATE_CU_EXCLUDE: the inflate streams carry a CU mask (not from the cache)
     uint32_t inf_ctr_base[2] = {0, 0};        // what the decoders' counters (d_small[W_INF0 / W_INF1]) hold before the next launch
     DevBuf<uint16_t> d_flag, d_n_cigar;
     DevBuf<uint8_t> d_mapq;
@@ -311,8 +310,7 @@ struct DeviceIngest {
         for (auto &q : inf_stream)
             if (q) {
                 (void)hipStreamSynchronize(q);
-                if (inf_masked) (void)hipStreamDestroy(q);
-                else pool_stream_put(inf_low_priority, q);
+                pool_stream_put(inf_low_priority, q);
             }
         for (auto &e : h2d_done) pool_event_put(e);
         for (auto &e : inf_done) pool_event_put(e);
@@ -1163,21 +1161,10 @@ int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
         // the slots its decoders free, instead of queueing behind all of them
         const char *e = getenv("NGSQ_INFLATE_PRIORITY");
         d->inf_low_priority = !(e && atoi(e) == 0); // =0: normal priority (A/B measurements)
-        // NGSQ_INFLATE_CU_EXCLUDE=N (measurement aid): the decoders stay off N compute units, which the CRC and
-        // the parse kernels then find free whatever the decoders do (hipExtStreamCreateWithCUMask; launch_bgzf_inflate sizes its
-        // resident grid by the same variable).  Such streams are not cached.
-        const int excl = getenv("NGSQ_INFLATE_CU_EXCLUDE") ? atoi(getenv("NGSQ_INFLATE_CU_EXCLUDE")) : 0;
-        int n_cu = 0, dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (excl > 0 && excl < n_cu) {
-            std::vector<uint32_t> m((size_t)(n_cu + 31) / 32, 0u);
-            for (int k = excl; k < n_cu; k++) m[(size_t)k / 32] |= 1u << (k % 32);
-            for (auto &q : d->inf_stream) BHIP(hipExtStreamCreateWithCUMask(&q, (uint32_t)m.size(), m.data()));
-            d->inf_masked = true;
-        } else {
-            for (auto &q : d->inf_stream) BHIP(ngsq::pool_stream_get(d->inf_low_priority, &q));
-        }
+        // (keeping the decoders off 8 / 16 / 32 compute units with a CU mask, so that the CRC and the parse kernels always find free
+        // ones, was measured in round 5: 269 -> 210 / 210 / 204 M records/s on the plain file, 250 -> 194 / 198 / 200 M on the
+        // aligner-style one -- masked streams cannot carry the low priority, and the decoders lose more than the others gain)
+        for (auto &q : d->inf_stream) BHIP(ngsq::pool_stream_get(d->inf_low_priority, &q));
     }
     for (auto &e : d->h2d_done) BHIP(ngsq::pool_event_get(&e));
     for (auto &e : d->inf_done) BHIP(ngsq::pool_event_get(&e));

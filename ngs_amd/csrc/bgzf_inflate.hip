@@ -1125,8 +1125,6 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
         // registers and a wave slot for the other stream's kernels (NGSQ_INFLATE_PER_CU: measurement aid)
         uint32_t per_cu = 24;
         if (const char *v = getenv("NGSQ_INFLATE_PER_CU")) per_cu = (uint32_t)atoi(v); // 0: a workgroup per block, as before
-        if (const char *v = getenv("NGSQ_INFLATE_CU_EXCLUDE")) // (the inflate streams are confined to the other CUs: bam_device_reader.cpp)
-            if (atoi(v) > 0 && atoi(v) < n_cu) n_cu -= atoi(v);
         resident = per_cu ? (uint32_t)n_cu * per_cu : 0xFFFFFFFFu;
         attr = true;
     }

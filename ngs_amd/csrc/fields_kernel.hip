@@ -32,6 +32,9 @@ namespace ngsq {
 
 typedef unsigned long long u64;
 
+#ifndef NGSQ_FT_PREFETCH_OFFS
+#define NGSQ_FT_PREFETCH_OFFS 1 // (0: the offsets are loaded when the tile is processed -- A/B builds)
+#endif
 constexpr uint32_t FT_THREADS = 256;
 constexpr uint32_t FT_PER_THREAD = 4;
 constexpr uint32_t FT_TILE = FT_THREADS * FT_PER_THREAD; // records per tile
@@ -68,6 +71,8 @@ struct FtRaw {
     int4 ref, mate, tlen, pos;
     uint4 cig;
     int32_t prev_ref, prev_pos; // STREAM: the record in front of this thread's first one
+    uint32_t co[FT_PER_THREAD + 1]; // CIG_OFF: cigar_off of the thread's records and of the one behind them, less the tile's first (co_base)
+    uint64_t co_base;
 };
 
 // number of lanes of the wave for which `c` holds: a wave-uniform value (SALU)
@@ -151,6 +156,20 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         }
         if (a.do_tlen) r.tlen = *reinterpret_cast<const int4 *>(b.tlen + r0);
         if (a.do_cov) r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
+#pragma unroll
+        for (uint32_t j = 0; j <= FT_PER_THREAD; j++) r.co[j] = 0;
+        r.co_base = 0;
+        if (CIG_OFF && NGSQ_FT_PREFETCH_OFFS && (a.do_general || a.do_cov)) {
+            // Round 5: the offsets come WITH the tile (a tile ahead), as 32-bit distances from the tile's first (a scalar load): the
+            // operations are then requested at the top of process() instead of behind a load of their own
+            r.co_base = b.cigar_off[tile * FT_TILE];
+            ulonglong2 c01, c23;
+            __builtin_memcpy(&c01, b.cigar_off + r0, 16);
+            __builtin_memcpy(&c23, b.cigar_off + r0 + 2, 16);
+            const uint64_t c4 = b.cigar_off[r0 + 4];
+            r.co[0] = (uint32_t)(c01.x - r.co_base), r.co[1] = (uint32_t)(c01.y - r.co_base), r.co[2] = (uint32_t)(c23.x - r.co_base);
+            r.co[3] = (uint32_t)(c23.y - r.co_base), r.co[4] = (uint32_t)(c4 - r.co_base);
+        }
         r.prev_ref = r.prev_pos = 0;
         if (STREAM) { // the record in front of the WAVE's first one: a wave-uniform address, i.e. a scalar load;
                       // the other lanes take their predecessor from the neighbouring lane (process())
@@ -192,6 +211,9 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         r.tlen = make_int4(tlen[0], tlen[1], tlen[2], tlen[3]);
         r.pos = make_int4(pos[0], pos[1], pos[2], pos[3]);
         r.cig = make_uint4(cig[0], cig[1], cig[2], cig[3]);
+#pragma unroll
+        for (uint32_t j = 0; j <= FT_PER_THREAD; j++) r.co[j] = 0;
+        r.co_base = 0;
         r.prev_ref = r.prev_pos = 0;
         if (STREAM && nrec) {
             const uint64_t pi = r0 ? r0 - 1 : 0;
@@ -265,12 +287,15 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         // time of the fixed-pitch variants on the 50-300 bp workload.)
         // Round 5: the SECOND and THIRD operations come with the first (a record of an aligner's file has one to three; the walk below
         // then loads nothing for them -- it used to fetch every operation behind the first when it got there, one dependent latency
-        // per operation and record, with the other lanes of the wave waiting), and a full tile's five offsets are two 16-byte loads
-        // and one 8-byte load instead of five.
+        // per operation and record, with the other lanes of the wave waiting), and a full tile's offsets have come with the tile
+        // (load_tile).
         uint64_t coff[FT_PER_THREAD + 1] = {0, 0, 0, 0, 0};
         uint32_t cigf[FT_PER_THREAD] = {0, 0, 0, 0}, cig2[FT_PER_THREAD] = {0, 0, 0, 0}, cig3[FT_PER_THREAD] = {0, 0, 0, 0};
         if (CIG_OFF && (a.do_general || a.do_cov)) {
-            if (full_tile) {
+            if (full_tile && NGSQ_FT_PREFETCH_OFFS) {
+#pragma unroll
+                for (uint32_t j = 0; j <= FT_PER_THREAD; j++) coff[j] = raw.co_base + raw.co[j];
+            } else if (full_tile) {
                 ulonglong2 c01, c23;
                 __builtin_memcpy(&c01, b.cigar_off + r0, 16);
                 __builtin_memcpy(&c23, b.cigar_off + r0 + 2, 16);

@@ -27,7 +27,8 @@ def _run_bench(*flags):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--records", "2000000",
                            "--cpu-sample", "100000", "--extra-facet-records", "1000000", "--file-big-records", "0",
-                           "--file-realistic-records", "400000", "--mixed-records", "2000000", "--mixed-steps", "3", *flags],
+                           "--file-realistic-records", "400000", "--mixed-records", "2000000", "--mixed-steps", "3",
+                           "--all-facets-records", "2000000", "--all-facets-steps", "2", *flags],
                           capture_output=True, text=True, env=env, timeout=1500)
 
 
@@ -58,6 +59,16 @@ def test_bench_line_contract(flags):
         assert d["mixed"]["parity_check"].startswith("ok") and d["mixed"]["roofline"]["kernel"] == "k_qual_ragged"
         assert d["extra_facets"]["edits_aligner_cigars"]["avg_ms"] > 0
         assert isinstance(d["roofline"]["traffic_measured_in_this_run"], bool)
+        # round 5: three timed loops and the card's state, every scan of every file leg and the median, reads that differ from the
+        # reference, all seven facets as one scan with the SEQ column read once
+        assert len(d["ms_per_step_each_loop"]) == 3 and "source" in d["gpu_state"] and d["ms_per_step_outside_kernels"] < d["ms_per_step"]
+        assert len(fe["in_process_device_ingest"]["seconds_each_scan"]) == 6 and "median" in fe["value_is"]
+        assert len(fe["realistic"]["seconds_each_scan"]) == 5 and "median" in fe["realistic"]["value_is"]
+        assert "phases_ms" in fe["cli_device_ingest"] and len(fe["cli_device_ingest"]["seconds_each_run"]) == 3
+        for leg in ("edits_subst_5pct", "edits_subst_25pct", "edits_iid_reads"):
+            assert d["extra_facets"][leg]["avg_ms"] > 0
+        assert d["all_facets"]["parity_check"].startswith("ok") and d["all_facets"]["seq_column_reads"].startswith("once")
+        assert "gc" not in d["all_facets"]["kernels"] and d["all_facets"]["kernels"]["edits"]["avg_ms"] > 0
     else:
         assert fe["json_equal_sharded_one_gpu"] is True and fe["in_process"]["json_equal_one_gpu"] is True
         assert fe["check_total"] == fe["records"] == fe["in_process"]["check_total"]
