@@ -1144,13 +1144,14 @@ int find_block_start(FILE *f, uint64_t from, uint64_t file_size, uint64_t *out, 
 
 // Streams, events, the reader thread and the two raw buffers of an ingest over d's byte range.
 int start_ingest(ngsq_bam *b, ngsq_ctx *c, DeviceIngest *d) {
-    // Chunk size: every buffer of the pipeline (two raw buffers, two pinned and two device buffers for the compressed
+    // Chunk size: every buffer of the pipeline (three raw buffers, four pinned and four device buffers for the compressed
     // bytes) is proportional to it and costs ~175 ms of allocation and pinning per GiB of chunk before the first record
-    // is seen, while the inflate launch runs ~13 % better with 1 GiB of blocks than with 256 MiB (fewer partial waves of
-    // decoders).  Measured on a 6 GB file (60 M records): 0.55 / 0.58 / 0.61 s with 256 / 512 / 1024 MiB; the big
-    // chunks win from roughly 50 GiB of inflated data on.  NGSQ_INGEST_RAW_MB overrides.
+    // is seen (the first file of a process; later ones take the blocks from the cache).  Measured in round 5 on a 100 M-record
+    // aligner-style file (12.5 GB; median of five scans, profiles/r05_chunk_size.txt): 256 MiB 238 M records/s, 512 MiB 273-275 M,
+    // 1 GiB 252 M -- the 1 GiB chunks round 2 chose for files beyond 16 GiB (their inflate launch runs fuller BY ITSELF) cost the
+    // 150 M-record file of the bench 9 %.  NGSQ_INGEST_RAW_MB overrides.
     const uint64_t sz = d->pos_end > d->pos_lo ? d->pos_end - d->pos_lo : 0;
-    const size_t dflt_mb = sz > ((uint64_t)16 << 30) ? 1024 : sz > ((uint64_t)4 << 30) ? 512 : 256;
+    const size_t dflt_mb = sz > ((uint64_t)4 << 30) ? 512 : 256;
     d->raw_cap = env_mb("NGSQ_INGEST_RAW_MB", dflt_mb);
     d->comp_chunk = std::max<size_t>(d->raw_cap / 4, (size_t)1 << 17);
     // (the two pinned buffers are allocated by the reader thread, on the device's NUMA node)

@@ -33,7 +33,8 @@ namespace ngsq {
 typedef unsigned long long u64;
 
 #ifndef NGSQ_FT_PREFETCH_OFFS
-#define NGSQ_FT_PREFETCH_OFFS 1 // (0: the offsets are loaded when the tile is processed -- A/B builds)
+#define NGSQ_FT_PREFETCH_OFFS 0 // 1: the tile's CIGAR offsets come with the tile, a tile ahead (measured in round 5: 1.26 ms against 1.04 on the
+                                // mixed workload -- ten more registers held across the tile loop, six spilled; A/B builds)
 #endif
 constexpr uint32_t FT_THREADS = 256;
 constexpr uint32_t FT_PER_THREAD = 4;
