@@ -16,8 +16,6 @@
 //                        with the host reader's rules.
 #include <hip/hip_runtime.h>
 
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 
 #include "ingest_kernels.h"
@@ -796,9 +794,96 @@ hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint6
                        qual_len, cig_len);
     return hipGetLastError();
 }
+// ---- exclusive prefix sums of 64-bit entries in place (the offsets of the variable-width columns) ----------------
+// Three small launches: the sum of every 4096-entry piece, an exclusive scan of those sums by one block, every piece scanned with
+// its carry.  (Until round 5 this was hipcub::DeviceScan::ExclusiveSum, the one library call on the path.)
+constexpr uint32_t SCAN_PIECE = 4096, SCAN_T = 256, SCAN_PER = SCAN_PIECE / SCAN_T;
+__device__ __forceinline__ uint64_t scan_wave_inclusive(uint64_t v, uint32_t lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t up = __shfl_up(v, o, 64);
+        if ((int)lane >= o) v += up;
+    }
+    return v;
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(const uint64_t *__restrict__ data, uint64_t n, uint64_t *__restrict__ sums) {
+    NGSQ_FOREGROUND_WAVE();
+    __shared__ uint64_t s_w[SCAN_T / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_PIECE + (uint64_t)threadIdx.x * SCAN_PER;
+    uint64_t t = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER; k++)
+        if (base + k < n) t += data[base + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_of_sums(uint64_t *__restrict__ sums, uint64_t n) {
+    NGSQ_FOREGROUND_WAVE();
+    __shared__ uint64_t s_part[1024];
+    const uint64_t per = (n + 1023) / 1024, lo = (uint64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint64_t t = 0;
+    for (uint64_t i = lo; i < hi; i++) t += sums[i];
+    s_part[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x < 64) { // the 1024 partial sums: sixteen per lane of the first wave
+        uint64_t loc[16], run = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            loc[k] = run;
+            run += s_part[threadIdx.x * 16 + k];
+        }
+        const uint64_t before = scan_wave_inclusive(run, threadIdx.x) - run;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) s_part[threadIdx.x * 16 + k] = before + loc[k];
+    }
+    __syncthreads();
+    uint64_t run = s_part[threadIdx.x];
+    for (uint64_t i = lo; i < hi; i++) {
+        const uint64_t v = sums[i];
+        sums[i] = run;
+        run += v;
+    }
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_apply(uint64_t *__restrict__ data, uint64_t n, const uint64_t *__restrict__ sums) {
+    NGSQ_FOREGROUND_WAVE();
+    __shared__ uint64_t s_w[SCAN_T / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_PIECE + (uint64_t)threadIdx.x * SCAN_PER;
+    uint64_t v[SCAN_PER], t = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER; k++) {
+        v[k] = base + k < n ? data[base + k] : 0;
+        t += v[k];
+    }
+    const uint64_t inc = scan_wave_inclusive(t, lane);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint64_t run = sums[blockIdx.x] + inc - t;
+    for (uint32_t w = 0; w < wave; w++) run += s_w[w];
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER; k++) {
+        if (base + k < n) data[base + k] = run;
+        run += v[k];
+    }
+}
+// tmp == nullptr: *tmp_bytes = the scratch the scan of n_plus_1 entries needs
 hipError_t launch_exclusive_scan_u64(uint64_t *data, uint64_t n_plus_1, void *tmp, size_t *tmp_bytes, hipStream_t s) {
-    if (n_plus_1 > 0x7FFFFFFFull) return hipErrorInvalidValue; // hipCUB counts in int: the caller cuts its batches below that
-    return hipcub::DeviceScan::ExclusiveSum(tmp, *tmp_bytes, data, data, (int)n_plus_1, s);
+    const uint64_t pieces = (n_plus_1 + SCAN_PIECE - 1) / SCAN_PIECE;
+    if (pieces > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (!tmp) {
+        *tmp_bytes = (size_t)(pieces + 1) * sizeof(uint64_t);
+        return hipSuccess;
+    }
+    if (!n_plus_1) return hipSuccess;
+    if (*tmp_bytes < (size_t)(pieces + 1) * sizeof(uint64_t)) return hipErrorInvalidValue;
+    uint64_t *const sums = static_cast<uint64_t *>(tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3((uint32_t)pieces), dim3(SCAN_T), 0, s, data, n_plus_1, sums);
+    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, s, sums, pieces);
+    hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)pieces), dim3(SCAN_T), 0, s, data, n_plus_1, sums);
+    return hipGetLastError();
 }
 hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t n, const RecColumns &c, uint64_t seq_bytes,
                           uint64_t qual_bytes, hipStream_t s) {

@@ -179,7 +179,8 @@ struct EdCigar {
 
 } // namespace
 
-__global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatch b, u64 *__restrict__ defer_bits) {
+// (four waves per SIMD, what the block's 33 KB of LDS allow: left alone the two-segment comparison takes 136 registers)
+__global__ __launch_bounds__(ED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_edits(DeviceState st, DeviceBatch b, u64 *__restrict__ defer_bits) {
     NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_h1[ED_HIST], s_h2[ED_HIST];           // edit counts below ED_HIST; the rest goes straight to the counters
     __shared__ uint32_t s_win[(ED_THREADS / 64) * ED_WINDOW];
@@ -235,55 +236,66 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatc
         // ---- stage 3 + the comparison: returns true when the record must take ed_walk_record instead
         auto compare = [&](const EdCols &r, const EdCigar &g, uint32_t pass) -> bool {
             if (!(r.ref >= 0 && (uint32_t)r.ref < st.n_refs && r.pos >= 0) || (r.flag & 0x404u)) return false; // never an Edits record
-            // [clip] M [clip]: read base q lies on 0-based reference position P + q, P = pos - (leading clip)
-            uint32_t a = 0, m = 0, z = 0;
+            // [clip] M [clip]: read base q lies on 0-based reference position P + q, P = pos - (leading clip).
+            // M (I|D|N) M (round 5): two such segments -- the first as if the rest were clipped, the second with the reference
+            // gap - ins bases further on; an aligner gives one read in sixteen an insertion or a deletion, the 50-300 bp workload one
+            // in seven an insertion, a deletion or a skip, and until round 5 all of those went to the walk kernel (5.2 of this shape's 11.3 ms)
+            uint32_t a = 0, m = 0, z = 0, m2 = 0, ins = 0, gap = 0;
             const uint32_t o0 = g.g0 & 15u, o1 = g.g1 & 15u, o2 = g.g2 & 15u;
             bool shape = false;
             if (r.n_ops == 1) shape = o0 == 0u, m = g.g0 >> 4;
             else if (r.n_ops == 2 && o0 == 4u && o1 == 0u) shape = true, a = g.g0 >> 4, m = g.g1 >> 4;
             else if (r.n_ops == 2 && o0 == 0u && o1 == 4u) shape = true, m = g.g0 >> 4, z = g.g1 >> 4;
             else if (r.n_ops == 3 && o0 == 4u && o1 == 0u && o2 == 4u) shape = true, a = g.g0 >> 4, m = g.g1 >> 4, z = g.g2 >> 4;
-            const uint64_t s = (uint64_t)r.pos + 1, e = s + m - 1; // (span = m for these shapes)
-            const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m; // entries of the difference array in the window
-            const bool fast = shape && m && (uint64_t)a + m + z == r.l && r.ref == win_ref && (uint32_t)r.pos >= a && e <= meta_L &&
-                              (uint32_t)r.pos >= win_base && i1 < ED_WINDOW;
+            else if (r.n_ops == 3 && o0 == 0u && o1 >= 1u && o1 <= 3u && o2 == 0u && (g.g2 >> 4)) {
+                shape = true, m = g.g0 >> 4, m2 = g.g2 >> 4;
+                if (o1 == 1u) ins = g.g1 >> 4;
+                else gap = g.g1 >> 4;
+                z = ins + m2; // (read bases behind the first M)
+            }
+            const uint64_t s = (uint64_t)r.pos + 1, e = s + m + gap + m2 - 1; // 1-based first and last position
+            const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m; // the first M's entries of the difference array in the window
+            const bool fast = shape && m && (uint64_t)a + m + z == r.l && r.ref == win_ref && (uint32_t)r.pos >= a + ins && e <= meta_L &&
+                              (uint32_t)r.pos >= win_base && i1 < ED_WINDOW && r.l < (1u << 16);
             if (!fast) return true;
             const uint64_t i = w0 + (uint64_t)pass * 64 + lane;
             const uint8_t *const sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
-            const uint32_t P = (uint32_t)r.pos - a;
-            const uint8_t *const rb = (P & 1u ? st.ref_bases_odd : st.ref_bases) + meta_boff + (P >> 1);
-            const uint32_t v0 = a, v1 = a + m; // the read bases that are compared
             uint32_t edits = 0, cnt = 0;
-            for (uint32_t c0 = v0 >> 5; c0 * 32 < v1 && EDITS_EXP != 3; c0 += ED_CHUNKS) {
-                uint4 sv[ED_CHUNKS], rv[ED_CHUNKS];
+            // one M at a time: read bases [v0, v1) against the reference, base q on 0-based position P + q (a loop, not two copies of
+            // the body: inlined twice it took 138 registers -- three waves per SIMD instead of four)
+            const uint32_t P1 = (uint32_t)r.pos - a, P2 = (uint32_t)r.pos + gap - ins;
+#pragma unroll 1
+            for (uint32_t seg = 0; seg < (m2 ? 2u : 1u); seg++) {
+                const uint32_t v0 = seg ? m + ins : a, v1 = seg ? r.l : a + m, P = seg ? P2 : P1;
+                const uint8_t *const rb = (P & 1u ? st.ref_bases_odd : st.ref_bases) + meta_boff + (P >> 1);
+                for (uint32_t c0 = v0 >> 5; c0 * 32 < v1 && EDITS_EXP != 3; c0 += ED_CHUNKS) {
+                    uint4 sv[ED_CHUNKS], rv[ED_CHUNKS];
 #pragma unroll
-                for (uint32_t k = 0; k < ED_CHUNKS; k++) {
-                    sv[k] = rv[k] = make_uint4(0, 0, 0, 0);
-                    if ((c0 + k) * 32 < v1) {
-                        if (EDITS_EXP == 5 || EDITS_EXP == 6) // (timing only, wrong bytes: what the sequence loads would cost if a wave's load covered 1 KiB contiguous)
-                            __builtin_memcpy(&sv[k], b.seq + (w0 + pass * 64) * (uint64_t)b.seq_stride + 16 * (64 * (c0 + k) + lane), 16);
-                        else
+                    for (uint32_t k = 0; k < ED_CHUNKS; k++) {
+                        sv[k] = rv[k] = make_uint4(0, 0, 0, 0);
+                        if ((c0 + k) * 32 < v1) {
                             __builtin_memcpy(&sv[k], sq + 16 * (c0 + k), 16);
-                        __builtin_memcpy(&rv[k], rb + 16 * (c0 + k), 16);
-                    }
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < ED_CHUNKS; k++) {
-                    const uint32_t x[4] = {sv[k].x ^ rv[k].x, sv[k].y ^ rv[k].y, sv[k].z ^ rv[k].z, sv[k].w ^ rv[k].w};
-#pragma unroll
-                    for (uint32_t d = 0; d < 4; d++) {
-                        const uint32_t j = (c0 + k) * 4 + d, b0 = 8 * j; // dword j holds read bases [b0, b0 + 8)
-                        uint32_t xx = x[d];
-                        if (b0 < v0 || b0 + 8 > v1) { // a dword at an end of the M (or outside it)
-                            const uint32_t u = b0 < v0 ? min(v0 - b0, 8u) : 0u, v = b0 + 8 > v1 ? (v1 > b0 ? v1 - b0 : 0u) : 8u;
-                            const uint32_t keep = (v >= 8u ? 0xFFFFFFFFu : v ? lead_bases_mask(v) : 0u) & ~(u >= 8u ? 0xFFFFFFFFu : u ? lead_bases_mask(u) : 0u);
-                            xx &= keep;
+                            __builtin_memcpy(&rv[k], rb + 16 * (c0 + k), 16);
                         }
-                        const uint32_t t = nz_nibbles(xx);
-                        edits += (uint32_t)__popc(t);
-                        if (t && EDITS_EXP != 6) {
-                            if (cnt < ED_LIST) list[64 * cnt] = make_uint2(xx, j);
-                            cnt += 1;
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < ED_CHUNKS; k++) {
+                        const uint32_t x[4] = {sv[k].x ^ rv[k].x, sv[k].y ^ rv[k].y, sv[k].z ^ rv[k].z, sv[k].w ^ rv[k].w};
+#pragma unroll
+                        for (uint32_t d = 0; d < 4; d++) {
+                            const uint32_t j = (c0 + k) * 4 + d, b0 = 8 * j; // dword j holds read bases [b0, b0 + 8)
+                            uint32_t xx = x[d];
+                            if (b0 < v0 || b0 + 8 > v1) { // a dword at an end of the M (or outside it)
+                                const uint32_t u = b0 < v0 ? min(v0 - b0, 8u) : 0u, v = b0 + 8 > v1 ? (v1 > b0 ? v1 - b0 : 0u) : 8u;
+                                const uint32_t keep = (v >= 8u ? 0xFFFFFFFFu : v ? lead_bases_mask(v) : 0u) & ~(u >= 8u ? 0xFFFFFFFFu : u ? lead_bases_mask(u) : 0u);
+                                xx &= keep;
+                            }
+                            const uint32_t t = nz_nibbles(xx);
+                            edits += (uint32_t)__popc(t);
+                            if (t) {
+                                if (cnt < ED_LIST) list[64 * cnt] = make_uint2(xx, j | seg << 16);
+                                cnt += 1;
+                            }
                         }
                     }
                 }
@@ -293,7 +305,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatc
             for (uint32_t k = 0; k < cnt && EDITS_EXP != 1 && EDITS_EXP != 4; k++) {
                 const uint2 en = list[64 * k];
                 uint32_t t = nz_nibbles(en.x);
-                uint32_t *const alts = st.edits + meta_eoff + ((uint64_t)meta_L + 1) + (uint64_t)P + 1 + 8 * en.y;
+                uint32_t *const alts = st.edits + meta_eoff + ((uint64_t)meta_L + 1) + (uint64_t)(en.y >> 16 ? P2 : P1) + 1 + 8 * (en.y & 0xFFFFu);
                 while (t) {
                     const uint32_t q = (uint32_t)__builtin_ctz(t) >> 2; // nibble q: byte q >> 1, its high nibble (q odd) is the earlier base
                     t &= t - 1;
@@ -304,8 +316,20 @@ __global__ __launch_bounds__(ED_THREADS) void k_edits(DeviceState st, DeviceBatc
                 atomicAdd(&win[i0], 1u);
                 atomicAdd(&win[i1], 0xFFFFFFFFu);
                 top = max(top, (uint32_t)i1);
+                if (m2) { // the second M's cover: in the window when it reaches that far, else straight to the array (a skip of kilobases)
+                    const uint64_t q0 = i1 + gap, q1 = q0 + m2;
+                    if (q1 < ED_WINDOW) {
+                        atomicAdd(&win[q0], 1u);
+                        atomicAdd(&win[q1], 0xFFFFFFFFu);
+                        top = max(top, (uint32_t)q1);
+                    } else {
+                        uint32_t *const diff = st.edits + meta_eoff + win_base;
+                        atomicAdd(&diff[q0], 1u);
+                        atomicAdd(&diff[q1], 0xFFFFFFFFu);
+                        st.counters[st.off_eseen + win_ref] = 1ull;
+                    }
+                }
             }
-            if (EDITS_EXP == 6) edits = edits ? 1u : 0u;
             if (edits > 512u) c[3] += 1;
             else tally(edits, r.flag & 0x40u);
             return false;

@@ -448,7 +448,7 @@ def test_gc_content_tallied_by_the_edits_kernel(gpu_lib, oracle_mod, mode):
         assert gpu.kernel_timing()["gc"]["launches"] == 1
 
 
-@pytest.mark.parametrize("sorted_rows,cigar_offsets", [(True, False), (True, True), (False, False)])
+@pytest.mark.parametrize("sorted_rows,cigar_offsets", [(True, False), (True, True), (False, False), (True, "offsets layout")])
 def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar_offsets):
     """k_edits_rows compares the second M of `M (I|D) M` in a step of its own (edits_kernel.hip 2c), against the reference
     del - ins bases further on.  Every place that arithmetic can go wrong, one record each on 150-base fixed-pitch rows, the
@@ -476,6 +476,17 @@ def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar
                 recs.append(dict(flag=0x40 if len(recs) % 2 else 0, mapq=60, ref_id=0, pos=p, mate_ref_id=-1, tlen=0,
                                  cigar=f"{a}M{g}{op}{m2}M", seq="".join("=ACMGRSVTWYHKDBN"[c] for c in codes), qual=[30] * L))
             pos += 5
+    # a skip (N) between two M: the lane-per-record kernel of the offsets layout compares the second M kilobases further on (its cover
+    # goes straight to the array when it lies beyond the wave's window); the rows kernel leaves these to the walk
+    for skip in (100, 1300, 5000):
+        for p in (pos, pos + 1):
+            a1 = 70
+            seg1, seg2 = bases[0][p:p + a1].copy(), bases[0][p + a1 + skip:p + a1 + skip + L - a1].copy()
+            seg1[3] = 1 if seg1[3] != 1 else 2
+            seg2[-1] = 4 if seg2[-1] != 4 else 8
+            recs.append(dict(flag=0x40, mapq=60, ref_id=0, pos=p, mate_ref_id=-1, tlen=0, cigar=f"{a1}M{skip}N{L - a1}M",
+                             seq="".join("=ACMGRSVTWYHKDBN"[c] for c in np.concatenate([seg1, seg2])), qual=[30] * L))
+        pos += 7
     for p in (0, 15):   # too close to the sequence's start for the shifted reference: the walk kernel's
         recs.append(dict(flag=0, mapq=60, ref_id=0, pos=p, mate_ref_id=-1, tlen=0, cigar="70M3I77M",
                          seq="".join("=ACMGRSVTWYHKDBN"[c] for c in np.concatenate([bases[0][p:p + 70], [1, 1, 1], bases[0][p + 70:p + 147]])), qual=[30] * L))
@@ -484,7 +495,9 @@ def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar
     hv = batch_from_records(recs)
     hb = to_fixed_stride(hv)
     assert hb.seq_stride == 75 and hb.cigar_stride == 3
-    if cigar_offsets:   # fixed-pitch SEQ / QUAL rows with the CIGARs through offsets: what the device reader makes of an aligner's file
+    if cigar_offsets == "offsets layout":   # everything through offsets: k_edits, a lane per record, with its own second-segment step (round 5)
+        hb = hv
+    elif cigar_offsets:   # fixed-pitch SEQ / QUAL rows with the CIGARs through offsets: what the device reader makes of an aligner's file
         cols = dict(hb.cols)
         cols["cigar"], cols["cigar_off"] = hv.cols["cigar"], hv.cols["cigar_off"]
         hb = host.HostBatch(hb.n, cols, hb.seq_stride, hb.qual_stride, 0, 0)
