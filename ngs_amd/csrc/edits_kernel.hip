@@ -264,6 +264,24 @@ __global__ __launch_bounds__(ED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             // one M at a time: read bases [v0, v1) against the reference, base q on 0-based position P + q (a loop, not two copies of
             // the body: inlined twice it took 138 registers -- three waves per SIMD instead of four)
             const uint32_t P1 = (uint32_t)r.pos - a, P2 = (uint32_t)r.pos + gap - ins;
+            // the listed dwords' mismatches -> alts (fewer than one per read on real data: after the comparison).  A read with more
+            // mismatching dwords than the list holds is left to the walk kernel: this layout has no LDS window for alts, so reads
+            // that differ much from the reference cost a global atomic per mismatch either way (50-300 bp reads with 5 % of their
+            // bases substituted: 38.8 ms per 100 M; emptying the list as it fills, inside the comparison: 32 ms, and 4 % slower on
+            // the reads the kernel is built for -- measured in round 5, not kept)
+            auto drain = [&]() {
+                for (uint32_t k = 0; k < cnt && EDITS_EXP != 1 && EDITS_EXP != 4; k++) {
+                    const uint2 en = list[64 * k];
+                    uint32_t t = nz_nibbles(en.x);
+                    uint32_t *const alts = st.edits + meta_eoff + ((uint64_t)meta_L + 1) + (uint64_t)(en.y >> 16 ? P2 : P1) + 1 + 8 * (en.y & 0xFFFFu);
+                    while (t) {
+                        const uint32_t q = (uint32_t)__builtin_ctz(t) >> 2; // nibble q: byte q >> 1, its high nibble (q odd) is the earlier base
+                        t &= t - 1;
+                        atomicAdd(&alts[(q & ~1u) + ((q & 1u) ^ 1u)], 1u);
+                    }
+                }
+                cnt = 0;
+            };
 #pragma unroll 1
             for (uint32_t seg = 0; seg < (m2 ? 2u : 1u); seg++) {
                 const uint32_t v0 = seg ? m + ins : a, v1 = seg ? r.l : a + m, P = seg ? P2 : P1;
@@ -301,17 +319,7 @@ __global__ __launch_bounds__(ED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
             }
             if (cnt > ED_LIST) return true; // more mismatching dwords than the list holds: the walk does this record
-            // ---- the mismatches' positions (fewer than one per read on real data)
-            for (uint32_t k = 0; k < cnt && EDITS_EXP != 1 && EDITS_EXP != 4; k++) {
-                const uint2 en = list[64 * k];
-                uint32_t t = nz_nibbles(en.x);
-                uint32_t *const alts = st.edits + meta_eoff + ((uint64_t)meta_L + 1) + (uint64_t)(en.y >> 16 ? P2 : P1) + 1 + 8 * (en.y & 0xFFFFu);
-                while (t) {
-                    const uint32_t q = (uint32_t)__builtin_ctz(t) >> 2; // nibble q: byte q >> 1, its high nibble (q odd) is the earlier base
-                    t &= t - 1;
-                    atomicAdd(&alts[(q & ~1u) + ((q & 1u) ^ 1u)], 1u);
-                }
-            }
+            drain();
             if (EDITS_EXP != 2 && EDITS_EXP != 4) {
                 atomicAdd(&win[i0], 1u);
                 atomicAdd(&win[i1], 0xFFFFFFFFu);
@@ -430,8 +438,7 @@ __global__ __launch_bounds__(ED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // Records the fast path does not take (other CIGARs, outside the window, another sequence) go through ed_walk_record.
 // ---------------------------------------------------------------------------
 constexpr uint32_t ED_NW = 5;                    // windows per row the kernel is built for (reads of up to 160 bases)
-constexpr uint32_t EDR_PASSES = 4;               // passes of 64 records per wave and window flush
-constexpr uint32_t EDR_WAVE_TILE = 64 * EDR_PASSES, EDR_TILE = ED_THREADS * EDR_PASSES;
+constexpr uint32_t EDR_TILE = ED_THREADS * 4;    // records a block is launched for (the grid; the waves cut their runs of passes themselves)
 #ifndef NGSQ_EDR_WINDOW
 #define NGSQ_EDR_WINDOW 1408 // (1536 until the histograms and the GC tally took 2.8 KB more: the block's LDS stays at 32 granules of 1280 bytes, four blocks per CU)
 #endif
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
 
     const uint32_t stride = b.seq_stride;
     const uint32_t odd_delta = (uint32_t)(st.ref_bases_odd - st.ref_bases); // (both copies lie inside 4 GiB: launch_edits)
-    const uint64_t n = b.n, n_tiles = (n + EDR_TILE - 1) / EDR_TILE;
+    const uint64_t n = b.n;
     // the columns of a pass (records behind the end read as unmapped) and, with a fixed CIGAR pitch, the first three operations
     auto load_cols = [&](uint64_t r0) -> EdRowCols {
         const uint64_t i = r0 + lane;
@@ -574,38 +581,110 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
         }
         __syncthreads();
     };
-    uint32_t tiles_done = 0;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (tiles_done == ED_HW_FLUSH_TILES) { // (uniform over the block: every wave makes the same number of rounds)
-            flush_hist();
-            tiles_done = 0;
-        }
-        tiles_done += 1;
-        const uint64_t w0 = tile * EDR_TILE + (uint64_t)wv * EDR_WAVE_TILE; // the wave's first record
-        if (w0 >= n) continue;
-        EdRowCols cur = load_cols(w0);
-        {   // the wave's window: entries [win_base, win_base + EDR_WINDOW) of the difference array of the sequence of its first record
-            win_ref = -1;
-            const int32_t fr = __builtin_amdgcn_readfirstlane(cur.ref), fp = __builtin_amdgcn_readfirstlane(cur.pos);
-            if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
-                if (fr != meta_ref) {
-                    const uint64_t eo = st.ref_edits_off[fr], bo = st.ref_bases_off[fr];
-                    const uint32_t l = st.ref_len[fr];
-                    meta_ref = fr;
-                    meta_eoff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(eo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)eo);
-                    meta_boff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bo);
-                    meta_L = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+    // ---- the wave adds the touched part of its two windows to the global arrays (coalesced atomics) and leaves them zeroed
+    auto flush_windows = [&]() {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) top = max(top, (uint32_t)__shfl_xor(top, o, 64));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (win_ref >= 0 && top) {
+            uint32_t *const dst = st.edits + meta_eoff + win_base;
+            uint32_t *const adst = dst + ((uint64_t)meta_L + 1) + 1; // alts[1 + 0-based position]
+            if (lane == 0) st.counters[st.off_eseen + win_ref] = 1ull; // the sequence has Edits state (plain store)
+            for (uint32_t ib = 0; ib <= top; ib += 256) {
+                uint32_t v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = ib + 64 * k + lane;
+                    v[k] = i < EDR_WINDOW ? win[i] : 0u;
                 }
-                if (meta_boff != NO_DEPTH) {
-                    win_ref = fr;
-                    win_base = (uint32_t)fp & ~3u;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t i = ib + 64 * k + lane;
+                    if (v[k]) {
+                        if (EDITS_EXP != 5 && EDITS_EXP != 7) atomicAdd(&dst[i], v[k]);
+                        win[i] = 0;
+                    }
                 }
             }
+            // The alts window: two 16-bit counters per LDS word = two neighbouring 32-bit entries of the global array, added with ONE
+            // 64-bit atomic (counts stay far below 2^32, so nothing carries from the low entry into the high one).  The flush is paid
+            // per atomic instruction and line, not per lane (EDITS_EXP 6: the alts' flush cost as much as the cover's although only one
+            // position in four holds a mismatch), so this halves it.  Whether a window word's two entries share an aligned 8 bytes
+            // depends on the sequence's place in the block: if not, a lane adds the high half of the word before its own and the
+            // low half of its own.  (A mismatch lies below the end of its read's M: below `top`.)
+            const uint32_t n_dw = (top >> 1) + 1u;
+            const bool straddle = ((meta_eoff + (uint64_t)meta_L) & 1ull) != 0; // &adst[0] = edits + meta_eoff + win_base + L + 2 entries, win_base % 4 == 0
+            for (uint32_t ib = 0; ib < n_dw + (straddle ? 1u : 0u); ib += 64) {
+                const uint32_t i = ib + lane;
+                const uint32_t own = i < n_dw && i < EDR_ALTW ? altw[i] : 0u;
+                u64 v;
+                uint32_t *at;
+                if (!straddle) {
+                    v = (u64)(own & 0xFFFFu) | (u64)(own >> 16) << 32;
+                    at = adst + 2 * i;
+                } else {
+                    const uint32_t before = i >= 1 && i - 1 < n_dw && i - 1 < EDR_ALTW ? altw[i - 1] : 0u;
+                    v = (u64)(before >> 16) | (u64)(own & 0xFFFFu) << 32;
+                    at = adst + 2 * i - 1;
+                }
+                if (v && EDITS_EXP != 6 && EDITS_EXP != 7) atomicAdd(reinterpret_cast<u64 *>(at), v);
+            }
+            for (uint32_t ib = 0; ib < n_dw; ib += 64) // (behind the adds: a lane reads its neighbour's word above)
+                if (ib + lane < n_dw && ib + lane < EDR_ALTW) altw[ib + lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
+        top = 0;
+    };
+    // Round 5: a wave walks a CONTIGUOUS run of passes (64 records each) and flushes its windows when the next pass would not fit them
+    // -- not every four passes: at 60x a window of 1408 entries holds seven passes of sorted 150-base reads, at 120x fourteen -- and
+    // re-anchors at that pass's first record.  Fewer flushes: fewer entries flushed twice where neighbouring tiles overlap, and fewer
+    // rounds of global atomics for the pass behind them to wait out (vmcnt is in order on gfx9: a wave that wants a load's result waits
+    // for every atomic it issued before the load as well).
+    const uint64_t n_pass = (n + 63) / 64, waves_total = (uint64_t)gridDim.x * (ED_THREADS / 64);
+    const uint64_t ppw = (n_pass + waves_total - 1) / waves_total;              // passes per wave: the same for all (flush_hist is a block's)
+    const uint64_t p0 = ((uint64_t)blockIdx.x * (ED_THREADS / 64) + wv) * ppw;  // this wave's first pass
+    EdRowCols cur = load_cols(p0 * 64 < n ? p0 * 64 : 0);
+    uint32_t rounds = 0;
 #pragma unroll 1
-        for (uint32_t pass = 0; pass < EDR_PASSES; pass++) {
-            const uint64_t r0 = w0 + (uint64_t)pass * 64;
-            if (r0 >= n) break;
+    for (uint64_t it = 0; it < ppw; it++) {
+        if (rounds == 4 * ED_HW_FLUSH_TILES) { // (uniform over the block; a block tallies at most 256 records per round)
+            flush_hist();
+            rounds = 0;
+        }
+        rounds += 1;
+        {
+            const uint64_t r0 = (p0 + it) * 64;
+            if (r0 >= n) continue;
+            {   // does the pass fit the window?  (its records reach at most l + 16 entries behind their position)
+                const int32_t fr = __builtin_amdgcn_readfirstlane(cur.ref), fp = __builtin_amdgcn_readfirstlane(cur.pos);
+                // (judged by the pass's LAST record: in a sorted file the one that reaches furthest -- three scalar instructions; a wave-wide
+                // maximum cost the kernel 3 %.  A record that reaches beyond the window all the same is left to the walk kernel, as ever)
+                const uint32_t lastl = (uint32_t)min(n - 1 - r0, (uint64_t)63);
+                const int32_t lr = __builtin_amdgcn_readlane(cur.ref, lastl), lp = __builtin_amdgcn_readlane(cur.pos, lastl);
+                const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane((int)cur.l, lastl);
+                const uint32_t need = (lr == win_ref && lp >= 0 && (uint32_t)lp >= win_base) ? (uint32_t)lp - win_base + ll + 16u : 0u;
+                if (win_ref < 0 || fr != win_ref || need >= EDR_WINDOW || fp < 0 || (uint32_t)fp < win_base) {
+                    flush_windows();
+                    // the wave's window: entries [win_base, win_base + EDR_WINDOW) of the difference array of the sequence of this pass's first record
+                    win_ref = -1;
+                    if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
+                        if (fr != meta_ref) {
+                            const uint64_t eo = st.ref_edits_off[fr], bo = st.ref_bases_off[fr];
+                            const uint32_t l = st.ref_len[fr];
+                            meta_ref = fr;
+                            meta_eoff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(eo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)eo);
+                            meta_boff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bo);
+                            meta_L = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+                        }
+                        if (meta_boff != NO_DEPTH) {
+                            win_ref = fr;
+                            win_base = (uint32_t)fp & ~3u;
+                        }
+                    }
+                }
+            }
             // ---- 2a. (ahead of 1: it does not depend on it) lane = window g = 64 k + lane of the pass's rows (record g / R, window
             // g % R): the 16 bytes of sequence of the first two windows are requested before the records' descriptors are worked out
             const uint8_t *const rows = b.seq + r0 * stride;
@@ -766,7 +845,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             // by LDS to four per SIMD, which leaves 128 registers each)
             finish_win(wa);
             if (R > 1) finish_win(wb);
-            if (pass + 1 < EDR_PASSES) cur = load_cols(r0 + 64); // in flight while this pass is compared
+            if (it + 1 < ppw) cur = load_cols(r0 + 64); // in flight while this pass is compared (behind the end: the last record again)
 #pragma unroll 1
             for (uint32_t k = 0; k < R && EDITS_EXP != 3; k += 3) {
                 if (k + 2 < R) wc = load_win();
@@ -815,61 +894,8 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 else atomicAdd(((r.flag & 0x40u) ? s_h1 : s_h2) + (edits >> 1), 1u << (16u * (edits & 1u)));
             }
         }
-        // ---- the wave adds the touched part of its two windows to the global arrays (coalesced atomics) and leaves them zeroed
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) top = max(top, (uint32_t)__shfl_xor(top, o, 64));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (win_ref >= 0 && top) {
-            uint32_t *const dst = st.edits + meta_eoff + win_base;
-            uint32_t *const adst = dst + ((uint64_t)meta_L + 1) + 1; // alts[1 + 0-based position]
-            if (lane == 0) st.counters[st.off_eseen + win_ref] = 1ull; // the sequence has Edits state (plain store)
-            for (uint32_t ib = 0; ib <= top; ib += 256) {
-                uint32_t v[4];
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t i = ib + 64 * k + lane;
-                    v[k] = i < EDR_WINDOW ? win[i] : 0u;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t i = ib + 64 * k + lane;
-                    if (v[k]) {
-                        if (EDITS_EXP != 5 && EDITS_EXP != 7) atomicAdd(&dst[i], v[k]);
-                        win[i] = 0;
-                    }
-                }
-            }
-            // The alts window: two 16-bit counters per LDS word = two neighbouring 32-bit entries of the global array, added with ONE
-            // 64-bit atomic (counts stay far below 2^32, so nothing carries from the low entry into the high one).  The flush is paid
-            // per atomic instruction and line, not per lane (EDITS_EXP 6: the alts' flush cost as much as the cover's although only one
-            // position in four holds a mismatch), so this halves it.  Whether a window word's two entries share an aligned 8 bytes
-            // depends on the sequence's place in the block: if not, a lane adds the high half of the word before its own and the
-            // low half of its own.  (A mismatch lies below the end of its read's M: below `top`.)
-            const uint32_t n_dw = (top >> 1) + 1u;
-            const bool straddle = ((meta_eoff + (uint64_t)meta_L) & 1ull) != 0; // &adst[0] = edits + meta_eoff + win_base + L + 2 entries, win_base % 4 == 0
-            for (uint32_t ib = 0; ib < n_dw + (straddle ? 1u : 0u); ib += 64) {
-                const uint32_t i = ib + lane;
-                const uint32_t own = i < n_dw && i < EDR_ALTW ? altw[i] : 0u;
-                u64 v;
-                uint32_t *at;
-                if (!straddle) {
-                    v = (u64)(own & 0xFFFFu) | (u64)(own >> 16) << 32;
-                    at = adst + 2 * i;
-                } else {
-                    const uint32_t before = i >= 1 && i - 1 < n_dw && i - 1 < EDR_ALTW ? altw[i - 1] : 0u;
-                    v = (u64)(before >> 16) | (u64)(own & 0xFFFFu) << 32;
-                    at = adst + 2 * i - 1;
-                }
-                if (v && EDITS_EXP != 6 && EDITS_EXP != 7) atomicAdd(reinterpret_cast<u64 *>(at), v);
-            }
-            for (uint32_t ib = 0; ib < n_dw; ib += 64) // (behind the adds: a lane reads its neighbour's word above)
-                if (ib + lane < n_dw && ib + lane < EDR_ALTW) altw[ib + lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        top = 0;
     }
+    flush_windows();
     flush_hist();
     {
         const uint32_t r = ed_wave_sum(c_too_many);

@@ -33,8 +33,7 @@ namespace ngsq {
 typedef unsigned long long u64;
 
 #ifndef NGSQ_FT_PREFETCH_OFFS
-#define NGSQ_FT_PREFETCH_OFFS 0 // 1: the tile's CIGAR offsets come with the tile, a tile ahead (measured in round 5: 1.26 ms against 1.04 on the
-                                // mixed workload -- ten more registers held across the tile loop, six spilled; A/B builds)
+#define NGSQ_FT_PREFETCH_OFFS 1 // 0: the offsets are loaded when the tile is processed (A/B builds)
 #endif
 constexpr uint32_t FT_THREADS = 256;
 constexpr uint32_t FT_PER_THREAD = 4;
@@ -72,7 +71,7 @@ struct FtRaw {
     int4 ref, mate, tlen, pos;
     uint4 cig;
     int32_t prev_ref, prev_pos; // STREAM: the record in front of this thread's first one
-    uint32_t co[FT_PER_THREAD + 1]; // CIG_OFF: cigar_off of the thread's records and of the one behind them, less the tile's first (co_base)
+    uint32_t co0;      // CIG_OFF: cigar_off of the thread's first record, less the tile's first (co_base); the others follow from n_cigar
     uint64_t co_base;
 };
 
@@ -157,19 +156,15 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         }
         if (a.do_tlen) r.tlen = *reinterpret_cast<const int4 *>(b.tlen + r0);
         if (a.do_cov) r.pos = *reinterpret_cast<const int4 *>(b.pos + r0);
-#pragma unroll
-        for (uint32_t j = 0; j <= FT_PER_THREAD; j++) r.co[j] = 0;
+        r.co0 = 0;
         r.co_base = 0;
         if (CIG_OFF && NGSQ_FT_PREFETCH_OFFS && (a.do_general || a.do_cov)) {
-            // Round 5: the offsets come WITH the tile (a tile ahead), as 32-bit distances from the tile's first (a scalar load): the
-            // operations are then requested at the top of process() instead of behind a load of their own
+            // Round 5: the thread's FIRST offset comes with the tile (a tile ahead), as a 32-bit distance from the tile's first (a scalar
+            // load); the other three follow from the n_cigar column, which is here anyway -- so the operations are requested at the
+            // top of process() instead of behind a load of their own.  (All five offsets prefetched cost ten registers held across
+            // the tile loop, six of them spilled: 1.26 ms against 1.04.)
             r.co_base = b.cigar_off[tile * FT_TILE];
-            ulonglong2 c01, c23;
-            __builtin_memcpy(&c01, b.cigar_off + r0, 16);
-            __builtin_memcpy(&c23, b.cigar_off + r0 + 2, 16);
-            const uint64_t c4 = b.cigar_off[r0 + 4];
-            r.co[0] = (uint32_t)(c01.x - r.co_base), r.co[1] = (uint32_t)(c01.y - r.co_base), r.co[2] = (uint32_t)(c23.x - r.co_base);
-            r.co[3] = (uint32_t)(c23.y - r.co_base), r.co[4] = (uint32_t)(c4 - r.co_base);
+            r.co0 = (uint32_t)(b.cigar_off[r0] - r.co_base);
         }
         r.prev_ref = r.prev_pos = 0;
         if (STREAM) { // the record in front of the WAVE's first one: a wave-uniform address, i.e. a scalar load;
@@ -212,8 +207,7 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         r.tlen = make_int4(tlen[0], tlen[1], tlen[2], tlen[3]);
         r.pos = make_int4(pos[0], pos[1], pos[2], pos[3]);
         r.cig = make_uint4(cig[0], cig[1], cig[2], cig[3]);
-#pragma unroll
-        for (uint32_t j = 0; j <= FT_PER_THREAD; j++) r.co[j] = 0;
+        r.co0 = 0;
         r.co_base = 0;
         r.prev_ref = r.prev_pos = 0;
         if (STREAM && nrec) {
@@ -293,9 +287,11 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
         uint64_t coff[FT_PER_THREAD + 1] = {0, 0, 0, 0, 0};
         uint32_t cigf[FT_PER_THREAD] = {0, 0, 0, 0}, cig2[FT_PER_THREAD] = {0, 0, 0, 0}, cig3[FT_PER_THREAD] = {0, 0, 0, 0};
         if (CIG_OFF && (a.do_general || a.do_cov)) {
-            if (full_tile && NGSQ_FT_PREFETCH_OFFS) {
+            const bool saturated = ncig[0] == 0xFFFFu || ncig[1] == 0xFFFFu || ncig[2] == 0xFFFFu || ncig[3] == 0xFFFFu; // (the count is in the offsets then)
+            if (full_tile && NGSQ_FT_PREFETCH_OFFS && !saturated) {
+                coff[0] = raw.co_base + raw.co0;
 #pragma unroll
-                for (uint32_t j = 0; j <= FT_PER_THREAD; j++) coff[j] = raw.co_base + raw.co[j];
+                for (uint32_t j = 0; j < FT_PER_THREAD; j++) coff[j + 1] = coff[j] + ncig[j];
             } else if (full_tile) {
                 ulonglong2 c01, c23;
                 __builtin_memcpy(&c01, b.cigar_off + r0, 16);

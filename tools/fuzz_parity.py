@@ -87,13 +87,18 @@ def extra_sweep(lib, seeds):
         hb = random_batch(rng, n, ref_len, max_len=max_len, min_len=int(rng.integers(0, max_len + 1)), weird=bool(rng.integers(0, 2)))
         if rng.random() < 0.7:
             hb = coordinate_sorted(hb)
+        # round 5: half of the short-read seeds as fixed-pitch rows (k_edits_rows, which then also tallies GC Content: the facet is on
+        # below), the others through offsets (k_edits with its own second-segment step)
+        rows = max_len <= 160 and rng.random() < 0.5
+        if rows:
+            hb = to_fixed_stride(hb)
         m = int(rng.integers(0, 3000))
         fr = rng.integers(0, n_refs, m).astype(np.uint32)
         fs = np.array([rng.integers(1, ref_len[r] + 1) for r in fr], dtype=np.uint32)
         fe = fs + np.where(rng.random(m) < 0.1, 0, rng.integers(0, 5000, m)).astype(np.uint32)
         fn = rng.choice(5, m).astype(np.uint32)
         roles = tuple(int(x) for x in rng.choice([0, 1, 2, 3, 4], 5)) if rng.random() < 0.3 else (0, 1, 2, 3, 4)
-        kw = dict(facets=ffi.FACET_EDITS | ffi.FACET_FEATURES | ffi.FACET_GENERAL, max_read_len=320, gc_seed=seed, ref_bases=bases)
+        kw = dict(facets=ffi.FACET_EDITS | ffi.FACET_FEATURES | ffi.FACET_GENERAL | ffi.FACET_GC_CONTENT, max_read_len=320, gc_seed=seed, ref_bases=bases)
         orc = oracle_py.Oracle(ref_len, primary, **kw)
         gpu = host.QcContext(ref_len, primary, lib=lib, **kw)
         orc.set_features(fr, fn, fs, fe, roles)
@@ -108,11 +113,13 @@ def extra_sweep(lib, seeds):
         for a, b in zip(orc.edits(), gpu.edits()):
             assert (a == b).all()
         assert orc.features() == gpu.features() and orc.error_counts() == gpu.error_counts()
+        go, gg = orc.gc_content(), gpu.gc_content()
+        assert all((go[k] == gg[k]).all() if k == "histogram" else go[k] == gg[k] for k in go), (go, gg)
         names = [f"s{i}" for i in range(n_refs)]
         if not any(orc.error_counts().values()):
             json_equal(gpu.results(names), orc.results(names))
         gpu.close()
-        print(f"extra seed {seed}: n={n} refs={n_refs} intervals={m} roles={roles} ok", flush=True)
+        print(f"extra seed {seed}: n={n} refs={n_refs} intervals={m} roles={roles} {'rows' if rows else 'offsets'} ok", flush=True)
     print("extra sweep ok")
 
 
