@@ -9,17 +9,17 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$P
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-LEGS="--cpu-sample 0 --h2d-batch 0 --file-records 0 --extra-facet-legs 0 --mixed-records 0"
+LEGS="--cpu-sample 0 --h2d-batch 0 --file-records 0 --extra-facet-legs 0 --mixed-records 0 --all-facets-records 0 --repeats 1"
 rocprofv3 --kernel-trace --stats -d $O/stats -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 20 --warmup 3 $LEGS > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/mixed -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 20 --warmup 3 --cpu-sample 0 > $O/mixed.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/extra -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 --mixed-records 0 > $O/extra.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/file -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --extra-facet-legs 0 --mixed-records 0 --file-records 24000000 --file-realistic-records 24000000 > $O/file.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/mixed -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 20 --warmup 3 --cpu-sample 0 --repeats 1 > $O/mixed.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/extra -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --repeats 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 --mixed-records 0 --all-facets-steps 3 > $O/extra.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/file -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --extra-facet-legs 0 --mixed-records 0 --all-facets-records 0 --repeats 1 --file-records 24000000 --file-realistic-records 24000000 > $O/file.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 2 --warmup 1 --no-timing $LEGS > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 2 --warmup 1 --no-timing $LEGS > $O/write.log 2>&1
 # the same two PMC passes for the offsets-layout quality kernel (--workload mixed) and for the device inflate (tools/bench_inflate.py:
 # one launch over 4 M records = 1.09 GB of inflated bytes)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/mfetch -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 2 --warmup 1 --no-timing --cpu-sample 0 > $O/mfetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/mwrite -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 2 --warmup 1 --no-timing --cpu-sample 0 > $O/mwrite.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/mfetch -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 2 --warmup 1 --repeats 1 --no-timing --cpu-sample 0 > $O/mfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/mwrite -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 2 --warmup 1 --repeats 1 --no-timing --cpu-sample 0 > $O/mwrite.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/ifetch -o out --output-format csv -- python3 $R/tools/bench_inflate.py --records 4000000 --reps 2 > $O/ifetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/iwrite -o out --output-format csv -- python3 $R/tools/bench_inflate.py --records 4000000 --reps 2 > $O/iwrite.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/istats -o out --output-format csv -- python3 $R/tools/bench_inflate.py --records 4000000 --reps 2 > $O/istats.log 2>&1
