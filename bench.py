@@ -479,6 +479,7 @@ def main() -> int:
                 out["mixed"] = guarded(leg_mixed, lib, host, ffi, np, args, device)
             if args.h2d_batch > 0 and not mixed:
                 out["h2d_inclusive"] = guarded(leg_h2d, lib, host, ffi, args)
+                out["stager"] = guarded(leg_stager, lib, host, ffi, args)
             if args.file_records > 0 and not mixed:
                 fe = guarded(leg_file, lib, host, ffi, args)
                 out["ingest_roofline"] = fe.pop("ingest_roofline", None) if isinstance(fe, dict) else None
@@ -879,6 +880,51 @@ def leg_h2d(lib, host, ffi, args):
         ctx.close()
         for p in keep:
             lib.ngsq_host_free_pinned(p)
+
+
+def leg_stager(lib, host, ffi, args):
+    """The per-record adapter (include/ngsq_stage.h) on one host core: every record of a host batch through
+    ngsq_stager_push_packed (in C: ngsq_stager_push_records), a flush per full stager -- what a host that keeps the reference's
+    `process(&Record)` loop gets."""
+    import ctypes as C
+    scfg = host.synth_config(100_000_000, read_len=args.read_len, ref_len=CHR1, n_refs=2)
+    n = min(args.h2d_batch, 4_000_000)
+    hb = host.synth_host_batch(scfg, 0, n, lib)
+    src = hb.struct()
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], max_read_len=args.read_len, gc_seed=GC_SEED, lib=lib)
+    st = C.c_void_p()
+    try:
+        if lib.ngsq_stager_create(1 << 20, ffi.STAGE_PINNED, C.byref(st)) != 0:
+            raise RuntimeError(lib.ngsq_stager_last_error(None).decode())
+        took = C.c_uint64(0)
+
+        def one_pass():
+            push_s, first = 0.0, 0
+            while first < n:
+                t = time.perf_counter()
+                if lib.ngsq_stager_push_records(st, C.byref(src), first, n - first, C.byref(took)) != 0:
+                    raise RuntimeError(lib.ngsq_stager_last_error(st).decode())
+                push_s += time.perf_counter() - t
+                first += took.value
+                if lib.ngsq_stager_flush(st, ctx._ctx, ffi.PASS_BOTH) != 0:
+                    raise RuntimeError((lib.ngsq_last_error(ctx._ctx) or b"ngsq_stager_flush failed").decode())
+            return push_s
+        one_pass()
+        ctx.synchronize()
+        ctx.reset()
+        reps = 3
+        t0 = time.perf_counter()
+        push_s = sum(one_pass() for _ in range(reps))
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        ctx.finalize()
+        return {"value": round(reps * n / dt, 1), "unit": "records/s", "push_only_records_per_s": round(reps * n / push_s, 1), "cores": 1,
+                "records": reps * n, "stager_capacity": 1 << 20,
+                "note": "one thread pushes record by record and flushes; the flush's copies are synchronous, so push and copy do not overlap"}
+    finally:
+        if st:
+            lib.ngsq_stager_destroy(st)
+        ctx.close()
 
 
 def fs_type_of(path: str) -> str:

@@ -82,6 +82,11 @@ int ngsq_stager_push_packed(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t
                             int32_t tlen, uint32_t l_seq, const uint8_t *seq_packed, const uint8_t *quals, const uint32_t *cigar,
                             uint32_t n_cigar, uint64_t record_id);
 
+/* Records [first, first + count) of a HOST batch (any layout of ngsq.h), one ngsq_stager_push_packed each -- for a host that picks
+ * records out of batches it already has (this repo's `ngs qc` applies the two `-n` rules that way), and the per-record path's rate
+ * without a foreign-function call per record (bench.py `stager`).  Stops when the stager is full; *pushed = records taken. */
+int ngsq_stager_push_records(ngsq_stager *s, const ngsq_batch *host_batch, uint64_t first, uint64_t count, uint64_t *pushed);
+
 /* The staged records as the batch a flush would hand over (host pointers into the stager; valid until the next push, flush
  * or destroy).  For hosts that want to look, and for tests. */
 int ngsq_stager_view(ngsq_stager *s, ngsq_batch *out);

@@ -203,14 +203,9 @@ struct Picker {
     void push(const ngsq_batch &b, uint64_t i) {
         if (!s && ngsq_stager_create(std::min<uint64_t>(std::max<uint64_t>(expect, 1), 1u << 20), NGSQ_STAGE_PINNED, &s) != NGSQ_OK)
             bail(ngsq_stager_last_error(nullptr)); // (created with the first record: -n 1000 pins a few hundred KB)
-        const uint32_t l = b.l_seq[i];
-        const uint8_t *sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
-        const uint8_t *ql = b.qual_off ? (b.qual_off[i + 1] > b.qual_off[i] ? b.qual + b.qual_off[i] : nullptr) : b.qual + i * (uint64_t)b.qual_stride;
-        const uint32_t *c = b.cigar + (b.cigar_off ? b.cigar_off[i] : i * (uint64_t)b.cigar_stride);
-        // the record keeps its identity (GC window): its virtual offset from the reader, else its ordinal in the file
-        const uint64_t id = b.record_id ? b.record_id[i] : b.first_record_index + i;
-        if (ngsq_stager_push_packed(s, b.flag[i], b.mapq[i], b.ref_id[i], b.pos[i], b.mate_ref_id[i], b.tlen[i], l, sq, ql, c, (uint32_t)n_ops_of(b, i), id) != NGSQ_OK)
-            bail(ngsq_stager_last_error(s));
+        // (the record keeps its identity -- its virtual offset from the reader, else its ordinal in the file: the GC window)
+        uint64_t took = 0;
+        if (ngsq_stager_push_records(s, &b, i, 1, &took) != NGSQ_OK || took != 1) bail(ngsq_stager_last_error(s));
         if (ngsq_stager_len(s) == ngsq_stager_capacity(s)) flush();
     }
     void flush() {

@@ -220,6 +220,32 @@ int ngsq_stager_push_packed(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t
     return NGSQ_OK;
 }
 
+int ngsq_stager_push_records(ngsq_stager *s, const ngsq_batch *b, uint64_t first, uint64_t count, uint64_t *pushed) {
+    if (pushed) *pushed = 0;
+    if (!s || !b) return NGSQ_ERR_INVALID_ARGUMENT;
+    if (b->struct_size != sizeof(ngsq_batch) || b->location != NGSQ_MEM_HOST) return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "a host batch is wanted");
+    if (first > b->n_records || count > b->n_records - first) return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "records [%llu, +%llu) of a batch of %llu",
+                                                                          (unsigned long long)first, (unsigned long long)count, (unsigned long long)b->n_records);
+    if (!b->flag || !b->l_seq) return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "flag / l_seq column is null");
+    uint64_t done = 0;
+    for (; done < count && s->n < s->capacity; done++) {
+        const uint64_t i = first + done;
+        const uint32_t l = b->l_seq[i];
+        const uint8_t *sq = b->seq ? b->seq + (b->seq_off ? b->seq_off[i] : i * (uint64_t)b->seq_stride) : nullptr;
+        const uint8_t *ql = nullptr;
+        if (b->qual) ql = b->qual_off ? (b->qual_off[i + 1] > b->qual_off[i] ? b->qual + b->qual_off[i] : nullptr) : b->qual + i * (uint64_t)b->qual_stride;
+        uint32_t n_ops = b->n_cigar ? b->n_cigar[i] : 0;
+        if (n_ops == 0xFFFFu && b->cigar_off) n_ops = (uint32_t)(b->cigar_off[i + 1] - b->cigar_off[i]); // (saturated: ngsq.h)
+        const uint32_t *cg = b->cigar ? b->cigar + (b->cigar_off ? b->cigar_off[i] : i * (uint64_t)b->cigar_stride) : nullptr;
+        const int rc = ngsq_stager_push_packed(s, b->flag[i], b->mapq ? b->mapq[i] : 255, b->ref_id ? b->ref_id[i] : -1, b->pos ? b->pos[i] : -1,
+                                               b->mate_ref_id ? b->mate_ref_id[i] : -1, b->tlen ? b->tlen[i] : 0, l, l ? sq : nullptr, ql, cg, cg ? n_ops : 0,
+                                               b->record_id ? b->record_id[i] : b->first_record_index + i);
+        if (rc != NGSQ_OK) return rc;
+    }
+    if (pushed) *pushed = done;
+    return NGSQ_OK;
+}
+
 int ngsq_stager_view(ngsq_stager *s, ngsq_batch *o) {
     if (!s || !o) return NGSQ_ERR_INVALID_ARGUMENT;
     memset(o, 0, sizeof *o);

@@ -370,6 +370,7 @@ PROTOTYPES = {
                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint64]),
     "ngsq_stager_push_packed": (C.c_int, [C.c_void_p, C.c_uint16, C.c_uint8, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
+    "ngsq_stager_push_records": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint64, C.c_uint64, u64p]),
     "ngsq_stager_view": (C.c_int, [C.c_void_p, C.POINTER(Batch)]),
     "ngsq_stager_flush": (C.c_int, [C.c_void_p, ctx_p, C.c_uint32]),
     "ngsq_stager_rewind": (C.c_int, [C.c_void_p, C.c_uint64]),

@@ -111,6 +111,44 @@ def test_pushed_records_are_the_batch_they_came_from(lib, oracle_mod, packed):
     lib.ngsq_stager_destroy(st)
 
 
+@pytest.mark.parametrize("rows", [False, True])
+def test_push_records_is_push_packed_per_record(lib, rows):
+    """ngsq_stager_push_records over a host batch (offsets layout; fixed-pitch rows) stages what one ngsq_stager_push_packed
+    per record stages, stops at a full stager, and refuses a range outside the batch."""
+    rng = np.random.default_rng(23)
+    if rows:
+        cfg = host.synth_config(300, ffi.SYNTH_FIXED, read_len=150, seed=4)
+        hb = host.synth_host_batch(cfg, 0, 300, lib)
+    else:
+        hb = random_batch(rng, 300, LENS, max_len=200)
+    st = new_stager(lib, 256)
+    took = C.c_uint64(0)
+    src = hb.struct()
+    assert lib.ngsq_stager_push_records(st, C.byref(src), 10, 500, C.byref(took)) == ffi.ERR_INVALID_ARGUMENT
+    assert lib.ngsq_stager_push_records(st, C.byref(src), 10, 290, C.byref(took)) == 0, lib.ngsq_stager_last_error(st)
+    assert took.value == 256 == lib.ngsq_stager_len(st)                      # full: the caller flushes and goes on from first + took
+    got, b = view(lib, st)
+    want = hb.slice(10, 266)
+    assert bool(b.seq_off) == (not rows) and (int(b.seq_stride) == 75) == rows
+    for k in host.FIXED_COLUMNS:
+        assert np.array_equal(got.cols[k], want.cols[k]), k
+    if rows:
+        for k in ("seq", "qual"):
+            assert np.array_equal(got.cols[k][:len(want.cols[k])], want.cols[k]), k
+        # (an unmapped record of the generator has no operation: its slot of the fixed-pitch column is not staged)
+        assert np.array_equal(got.cols["cigar"], want.cols["cigar"][want.cols["n_cigar"] == 1])
+    else:
+        for k in ("seq_off", "qual_off", "cigar_off", "qual", "cigar"):
+            assert np.array_equal(got.cols[k], want.cols[k]), k
+        seq = want.cols["seq"].copy()
+        odd = np.nonzero(want.cols["l_seq"] & 1)[0]
+        seq[want.cols["seq_off"][odd + 1].astype(np.int64) - 1] &= 0xF0
+        assert np.array_equal(got.cols["seq"], seq)
+    # the records keep their ordinal in the source batch as their identity
+    assert np.array_equal(got.cols["record_id"], np.arange(10, 266, dtype=np.uint64) + np.uint64(hb.first_record_index))
+    lib.ngsq_stager_destroy(st)
+
+
 def test_layout_follows_the_records(lib):
     """Reads of one length with qualities and one operation each are handed over as fixed-pitch rows (the fast kernels); the
     first record that differs turns the same columns into the offsets layout -- nothing is moved."""
