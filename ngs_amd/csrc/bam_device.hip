@@ -795,8 +795,14 @@ hipError_t launch_rec_lengths(const uint8_t *raw, const uint64_t *rec_off, uint6
     return hipGetLastError();
 }
 // ---- exclusive prefix sums of 64-bit entries in place (the offsets of the variable-width columns) ----------------
-// Three small launches: the sum of every 4096-entry piece, an exclusive scan of those sums by one block, every piece scanned with
-// its carry.  (Until round 5 this was hipcub::DeviceScan::ExclusiveSum, the one library call on the path.)
+// Two small launches: the sum of every 4096-entry piece; every piece scanned behind its carry, which the piece's block adds up
+// itself from the sums in front of it (a chunk of a file is a few hundred pieces).  Beyond SCAN_OWN_CARRY pieces a launch
+// between the two scans the sums instead.  (Until round 5 this was hipcub::DeviceScan::ExclusiveSum, the one library call on the
+// path.  The first version of this had the middle launch always, ONE block of 1024 threads: it needs a whole compute unit's
+// register file at once, and beside the persistent inflate decoders of the next chunk, which hold 24 waves on every compute unit
+// until their launch ends, it waited for exactly that -- 1.27 ms per chunk of an aligner's file for a scan of 355 numbers,
+// profiles/r05_ingest_kernel_stats.csv; the library's look-back scan had taken 15 us there.)
+constexpr uint64_t SCAN_OWN_CARRY = 8192;
 constexpr uint32_t SCAN_PIECE = 4096, SCAN_T = 256, SCAN_PER = SCAN_PIECE / SCAN_T;
 __device__ __forceinline__ uint64_t scan_wave_inclusive(uint64_t v, uint32_t lane) {
 #pragma unroll
@@ -820,24 +826,24 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_sums(const uint64_t *__restrict
     __syncthreads();
     if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-__global__ __launch_bounds__(1024) void k_scan_of_sums(uint64_t *__restrict__ sums, uint64_t n) {
+__global__ __launch_bounds__(256) void k_scan_of_sums(uint64_t *__restrict__ sums, uint64_t n) {
     NGSQ_FOREGROUND_WAVE();
-    __shared__ uint64_t s_part[1024];
-    const uint64_t per = (n + 1023) / 1024, lo = (uint64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    __shared__ uint64_t s_part[256];
+    const uint64_t per = (n + 255) / 256, lo = (uint64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
     uint64_t t = 0;
     for (uint64_t i = lo; i < hi; i++) t += sums[i];
     s_part[threadIdx.x] = t;
     __syncthreads();
-    if (threadIdx.x < 64) { // the 1024 partial sums: sixteen per lane of the first wave
-        uint64_t loc[16], run = 0;
+    if (threadIdx.x < 64) { // the 256 partial sums: four per lane of the first wave
+        uint64_t loc[4], run = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) {
+        for (uint32_t k = 0; k < 4; k++) {
             loc[k] = run;
-            run += s_part[threadIdx.x * 16 + k];
+            run += s_part[threadIdx.x * 4 + k];
         }
         const uint64_t before = scan_wave_inclusive(run, threadIdx.x) - run;
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) s_part[threadIdx.x * 16 + k] = before + loc[k];
+        for (uint32_t k = 0; k < 4; k++) s_part[threadIdx.x * 4 + k] = before + loc[k];
     }
     __syncthreads();
     uint64_t run = s_part[threadIdx.x];
@@ -847,10 +853,19 @@ __global__ __launch_bounds__(1024) void k_scan_of_sums(uint64_t *__restrict__ su
         run += v;
     }
 }
+// OWN_CARRY: sums[] holds the pieces' sums and the block adds up those in front of its piece; else sums[] holds their exclusive scan
+template <bool OWN_CARRY>
 __global__ __launch_bounds__(SCAN_T) void k_scan_apply(uint64_t *__restrict__ data, uint64_t n, const uint64_t *__restrict__ sums) {
     NGSQ_FOREGROUND_WAVE();
-    __shared__ uint64_t s_w[SCAN_T / 64];
+    __shared__ uint64_t s_w[SCAN_T / 64], s_c[SCAN_T / 64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t carry = 0;
+    if (OWN_CARRY) {
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += SCAN_T) carry += sums[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) carry += __shfl_down(carry, o, 64);
+        if (lane == 0) s_c[wave] = carry;
+    }
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_PIECE + (uint64_t)threadIdx.x * SCAN_PER;
     uint64_t v[SCAN_PER], t = 0;
 #pragma unroll
@@ -861,7 +876,8 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(uint64_t *__restrict__ da
     const uint64_t inc = scan_wave_inclusive(t, lane);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    uint64_t run = sums[blockIdx.x] + inc - t;
+    uint64_t run = (OWN_CARRY ? s_c[0] + s_c[1] + s_c[2] + s_c[3] : sums[blockIdx.x]) + inc - t;
+    static_assert(SCAN_T == 256, "four waves");
     for (uint32_t w = 0; w < wave; w++) run += s_w[w];
 #pragma unroll
     for (uint32_t k = 0; k < SCAN_PER; k++) {
@@ -881,8 +897,13 @@ hipError_t launch_exclusive_scan_u64(uint64_t *data, uint64_t n_plus_1, void *tm
     if (*tmp_bytes < (size_t)(pieces + 1) * sizeof(uint64_t)) return hipErrorInvalidValue;
     uint64_t *const sums = static_cast<uint64_t *>(tmp);
     hipLaunchKernelGGL(k_scan_sums, dim3((uint32_t)pieces), dim3(SCAN_T), 0, s, data, n_plus_1, sums);
-    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, s, sums, pieces);
-    hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)pieces), dim3(SCAN_T), 0, s, data, n_plus_1, sums);
+    const char *const e = getenv("NGSQ_SCAN_OWN_CARRY"); // tests: the pieces up to which a block adds up its own carry (0: the three-launch path)
+    if (pieces <= (e ? strtoull(e, nullptr, 10) : SCAN_OWN_CARRY)) {
+        hipLaunchKernelGGL(k_scan_apply<true>, dim3((uint32_t)pieces), dim3(SCAN_T), 0, s, data, n_plus_1, sums);
+    } else {
+        hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, s, sums, pieces);
+        hipLaunchKernelGGL(k_scan_apply<false>, dim3((uint32_t)pieces), dim3(SCAN_T), 0, s, data, n_plus_1, sums);
+    }
     return hipGetLastError();
 }
 hipError_t launch_rec_var(const uint8_t *raw, const uint64_t *var_base, uint64_t n, const RecColumns &c, uint64_t seq_bytes,

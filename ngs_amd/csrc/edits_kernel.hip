@@ -452,12 +452,16 @@ constexpr uint32_t EDR_TILE = ED_THREADS * 4;    // records a block is launched 
 constexpr uint32_t EDR_WINDOW = NGSQ_EDR_WINDOW;            // entries of the wave's cover window (256 sorted reads: 790 positions at 60x, 1430 at 30x: there the last few reads of a tile go to the walk)
 constexpr uint32_t GC_NONE = 0x3FFu;             // "no GC window": an offset whose window lies behind every 16-byte window of a row
 constexpr uint32_t GC_HW = (NGSQ_GC_BINS + 1) / 2; // words of a 101-bin histogram of 16-bit pairs
-constexpr uint32_t EDR_ALTW = EDR_WINDOW / 2;    // dwords of its alts window: 16-bit counters, two positions per dword
 
 struct EdRowCols {
     uint32_t flag, l, n_ops, g0, g1, g2;
     int32_t ref, pos;
+    uint64_t so;  // RAGGED: where the record's packed bases begin in the column,
+    uint32_t sb;  //         and how many bytes it has there (saturated)
+    uint64_t cb;  // CIG_OFF: its first operation's index (loaded with the columns, a pass ahead: the operations' loads then wait for nothing)
 };
+constexpr uint32_t EDG_MAXW = 16;     // RAGGED: 16-byte windows a record may have on the fast path: 255 bytes, reads of up to 510 bases
+constexpr uint32_t EDG_WINDOW = 1152; // RAGGED: entries of the wave's cover window (256 fewer than EDR_WINDOW pay for the window -> record map)
 
 // CIG_OFF: the CIGARs are addressed through cigar_off (their loads then wait for the offsets; with a fixed pitch they are
 // prefetched with the columns of the pass)
@@ -468,16 +472,29 @@ struct EdRowCols {
 // window's offset (flag filter, length filter, ngsq_gc_offset_fn) into LDS; lane = window adds its (gc, at) counts to the
 // record's 16-bit pair; lane = record tallies the two 101-bin histograms (gc and at per read, 16-bit pairs) from which the
 // flush derives every counter of the facet (total_gc = sum g * hist[g], ...).  k_gc is then not launched at all.
-template <bool CIG_OFF, bool GC>
+// RAGGED (round 5): the offsets layout (reads of different lengths: SEQ at seq_off[i]) through the same window lanes.  A record has
+// ceil(bytes / 16) windows that start at ITS first byte (the last one reads on into the next record's bytes and is masked, as a
+// row's last window is); the records of a pass lie back to back in the column, so consecutive lanes still read consecutive
+// 16-byte pieces but for one overlap per record.  Which record a window belongs to comes from a byte map in LDS that the record
+// lanes fill behind a prefix sum of their window counts (k_qual_ragged's scheme): one byte store per window, and per window one
+// byte read + one 8-byte read (the record's first window and byte offset).  Records that are not on the fast path have no windows.
+// Until then this layout went through k_edits, a lane per RECORD: 64 lanes 25..150 bytes apart per load instruction, 11.1 ms per
+// 100 M reads of 50-300 bases, and 32 ms with 5 % of their bases substituted (no alts window in LDS there).
+template <bool CIG_OFF, bool GC, bool RAGGED>
 __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(DeviceState st, DeviceBatch b, uint32_t R, uint32_t recip, u64 *__restrict__ defer_bits) {
     NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_h1[ED_HW], s_h2[ED_HW];               // per-read edit counts, 16-bit pairs
-    __shared__ uint32_t s_win[(ED_THREADS / 64) * EDR_WINDOW];  // cover: difference entries
-    __shared__ uint32_t s_alt[(ED_THREADS / 64) * EDR_ALTW];    // mismatches per position of the same window
+    static_assert(!(GC && RAGGED), "the GC tally is fused into the fixed-pitch variants only");
+    constexpr uint32_t WIN = RAGGED ? EDG_WINDOW : GC ? EDR_WINDOW - 64 : EDR_WINDOW, ALTW = WIN / 2; // (GC: its 1.4 KB come out of the window -- the block stays at 32 granules)
+    __shared__ uint32_t s_win[(ED_THREADS / 64) * WIN];  // cover: difference entries
+    __shared__ uint32_t s_alt[(ED_THREADS / 64) * ALTW]; // mismatches per position of the same window
+    __shared__ uint8_t s_wmap[RAGGED ? ED_THREADS * EDG_MAXW : 4]; // RAGGED: per wave, the record slot of each of the pass's windows
+    __shared__ uint2 s_rg[RAGGED ? ED_THREADS : 1];                // RAGGED: per record slot (byte offset of its bases from the pass's first byte, first window | windows << 16)
     __shared__ uint2 s_desc[ED_THREADS];   // per record of the wave's current 64: (byte offset of its base 0 in the packed reference, v0 | v1 << 9 | window entry of base 0 << 18); v1 = 0: not on the fast path
     __shared__ uint32_t s_edits[ED_THREADS];
     __shared__ uint32_t s_tmask[33];       // [n]: the bits 4 q + d of the first n bases of a window (base 8 d + (q ^ 1))
-    __shared__ uint8_t s_ilist[ED_THREADS]; // per wave: the lanes of the pass's records of the shape M (I|D) M, in order
+    __shared__ uint8_t s_ilist[ED_THREADS]; // per wave: the lanes of the pass's records of the shape M (I|D|N) M, in order
+    __shared__ uint32_t s_gap[ED_THREADS];  // per record slot of that shape: the reference bases between its two M (a deletion's, a skip's)
     __shared__ u64 s_acc[4];
     // GC: per record of the wave's current 64 its window offset (GC_NONE: not processed) and its (gc | at << 7) sum, two records per
     // word; the block's two histograms; records ignored for their flags / their length
@@ -496,16 +513,19 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
         for (uint32_t i = 0; i < tid; i++) m |= 1u << (4u * ((i & 7u) ^ 1u) + (i >> 3));
         s_tmask[tid] = m;
     }
-    for (uint32_t i = tid; i < (ED_THREADS / 64) * EDR_WINDOW; i += ED_THREADS) s_win[i] = 0;
-    for (uint32_t i = tid; i < (ED_THREADS / 64) * EDR_ALTW; i += ED_THREADS) s_alt[i] = 0;
+    for (uint32_t i = tid; i < (ED_THREADS / 64) * WIN; i += ED_THREADS) s_win[i] = 0;
+    for (uint32_t i = tid; i < (ED_THREADS / 64) * ALTW; i += ED_THREADS) s_alt[i] = 0;
     if (tid < 4) s_acc[tid] = 0;
     __syncthreads();
     uint32_t c_too_many = 0;
-    uint32_t *const win = s_win + wv * EDR_WINDOW;
-    uint32_t *const altw = s_alt + wv * EDR_ALTW;
+    uint32_t *const win = s_win + wv * WIN;
+    uint32_t *const altw = s_alt + wv * ALTW;
+    uint8_t *const wmap = s_wmap + (RAGGED ? wv * (64 * EDG_MAXW) : 0);
+    uint2 *const rg = s_rg + (RAGGED ? wv * 64 : 0);
     uint2 *const desc = s_desc + wv * 64;
     uint32_t *const red = s_edits + wv * 64; // bits 0..9: the record's edit count; bits 10..: what its second M needs (below)
     uint8_t *const ilist = s_ilist + wv * 64;
+    uint32_t *const gapl = s_gap + wv * 64;
     uint16_t *const goff = s_goff + (GC ? wv * 64 : 0);
     uint32_t *const gacc = s_gacc + (GC ? wv * 32 : 0);
 
@@ -528,6 +548,13 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
         r.l = b.l_seq[ii];
         r.n_ops = b.n_cigar[ii];
         r.g0 = r.g1 = r.g2 = 0;
+        r.so = 0, r.sb = 0, r.cb = 0;
+        if (CIG_OFF) r.cb = b.cigar_off[ii];
+        if (RAGGED) {
+            r.so = b.seq_off[ii];
+            const uint64_t nb = b.seq_off[ii + 1] - r.so;
+            r.sb = nb < 0xFFFFFFFFull ? (uint32_t)nb : 0xFFFFFFFFu;
+        }
         if (!CIG_OFF) {
             const uint64_t cb = ii * (uint64_t)b.cigar_stride;
             r.g0 = b.cigar[cb];
@@ -596,7 +623,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t i = ib + 64 * k + lane;
-                    v[k] = i < EDR_WINDOW ? win[i] : 0u;
+                    v[k] = i < WIN ? win[i] : 0u;
                 }
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
@@ -617,21 +644,21 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             const bool straddle = ((meta_eoff + (uint64_t)meta_L) & 1ull) != 0; // &adst[0] = edits + meta_eoff + win_base + L + 2 entries, win_base % 4 == 0
             for (uint32_t ib = 0; ib < n_dw + (straddle ? 1u : 0u); ib += 64) {
                 const uint32_t i = ib + lane;
-                const uint32_t own = i < n_dw && i < EDR_ALTW ? altw[i] : 0u;
+                const uint32_t own = i < n_dw && i < ALTW ? altw[i] : 0u;
                 u64 v;
                 uint32_t *at;
                 if (!straddle) {
                     v = (u64)(own & 0xFFFFu) | (u64)(own >> 16) << 32;
                     at = adst + 2 * i;
                 } else {
-                    const uint32_t before = i >= 1 && i - 1 < n_dw && i - 1 < EDR_ALTW ? altw[i - 1] : 0u;
+                    const uint32_t before = i >= 1 && i - 1 < n_dw && i - 1 < ALTW ? altw[i - 1] : 0u;
                     v = (u64)(before >> 16) | (u64)(own & 0xFFFFu) << 32;
                     at = adst + 2 * i - 1;
                 }
                 if (v && EDITS_EXP != 6 && EDITS_EXP != 7) atomicAdd(reinterpret_cast<u64 *>(at), v);
             }
             for (uint32_t ib = 0; ib < n_dw; ib += 64) // (behind the adds: a lane reads its neighbour's word above)
-                if (ib + lane < n_dw && ib + lane < EDR_ALTW) altw[ib + lane] = 0;
+                if (ib + lane < n_dw && ib + lane < ALTW) altw[ib + lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -664,8 +691,14 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 const uint32_t lastl = (uint32_t)min(n - 1 - r0, (uint64_t)63);
                 const int32_t lr = __builtin_amdgcn_readlane(cur.ref, lastl), lp = __builtin_amdgcn_readlane(cur.pos, lastl);
                 const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane((int)cur.l, lastl);
-                const uint32_t need = (lr == win_ref && lp >= 0 && (uint32_t)lp >= win_base) ? (uint32_t)lp - win_base + ll + 16u : 0u;
-                if (win_ref < 0 || fr != win_ref || need >= EDR_WINDOW || fp < 0 || (uint32_t)fp < win_base) {
+                uint32_t need = (lr == win_ref && lp >= 0 && (uint32_t)lp >= win_base) ? (uint32_t)lp - win_base + ll + 16u : 0u;
+                if (RAGGED) { // reads of different lengths: the last record is not the one that reaches furthest
+                    uint32_t reach = (cur.ref == win_ref && cur.pos >= 0 && (uint32_t)cur.pos >= win_base) ? (uint32_t)cur.pos - win_base + min(cur.l, 511u) + 16u : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) reach = max(reach, (uint32_t)__shfl_xor(reach, o, 64));
+                    need = reach;
+                }
+                if (win_ref < 0 || fr != win_ref || need >= WIN || fp < 0 || (uint32_t)fp < win_base) {
                     flush_windows();
                     // the wave's window: entries [win_base, win_base + EDR_WINDOW) of the difference array of the sequence of this pass's first record
                     win_ref = -1;
@@ -687,8 +720,11 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             }
             // ---- 2a. (ahead of 1: it does not depend on it) lane = window g = 64 k + lane of the pass's rows (record g / R, window
             // g % R): the 16 bytes of sequence of the first two windows are requested before the records' descriptors are worked out
-            const uint8_t *const rows = b.seq + r0 * stride;
+            // (RAGGED: the pass's first byte -- lane 0's record exists)
+            const uint64_t so0 = RAGGED ? ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cur.so >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cur.so) : 0ull;
+            const uint8_t *const rows = RAGGED ? b.seq + so0 : b.seq + r0 * stride;
             const uint32_t last = (uint32_t)min(n - 1 - r0, (uint64_t)63); // rows of the pass that exist
+            uint32_t n_win = 0, w_g = lane; // RAGGED: windows of the pass (known behind step 1); the next window of this lane
             struct Win {
                 uint4 sv, rv;
                 uint32_t slot, ww, x0, lohi; // record slot, window of the row, window entry of base 0 of the window, compared bases lo | hi << 8 (none: lo >= hi)
@@ -698,6 +734,15 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             const uint32_t step_rr = 64 / R, step_ww = 64 - step_rr * R, step_off = step_rr * stride + 16 * step_ww;
             auto begin_win = [&]() -> Win { // the sequence bytes of window (w_rr, w_ww); then on to the next one
                 Win w;
+                if (RAGGED) { // window w_g of the pass: its record from the map; a lane behind the last window compares nothing (ww = 255)
+                    const bool live = w_g < n_win;
+                    const uint32_t rr = live ? wmap[w_g] : 0u;
+                    const uint2 q = rg[rr];
+                    w.slot = rr, w.ww = live ? w_g - (q.y & 0xFFFFu) : 255u;
+                    __builtin_memcpy(&w.sv, rows + (live ? q.x + 16u * w.ww : 0u), 16);
+                    w_g += 64;
+                    return w;
+                }
                 __builtin_memcpy(&w.sv, rows + (w_rr <= last ? w_off : 0u), 16);
                 w.slot = w_rr, w.ww = w_ww;
                 w_rr += step_rr, w_ww += step_ww, w_off += step_off;
@@ -708,7 +753,8 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             // (a window without compared bases -- a record that is not on the fast path: descriptor 0; a window behind the read's
             // end -- reads what lies at its place all the same: inside both buffers, and all of it masked away)
             auto finish_win = [&](Win &w) {
-                const uint2 d = desc[w.slot];
+                uint2 d = desc[w.slot];
+                if (RAGGED && w.ww == 255u) d = make_uint2(0u, 0u), w.ww = 0u; // (nothing compared: v0 = v1 = 0)
                 const uint32_t v0 = d.y & 0x1FFu, v1 = (d.y >> 9) & 0x1FFu, b0 = 32 * w.ww;
                 __builtin_memcpy(&w.rv, st.ref_bases + (d.x + 16 * w.ww), 16);
                 w.x0 = (d.y >> 18) + b0;
@@ -725,15 +771,21 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 finish_win(w);
                 return w;
             };
-            Win wa = begin_win(), wb = wa, wc = wa;
-            if (R > 1) wb = begin_win();
+            Win wa, wb, wc;
+            if (!RAGGED) {
+                wa = begin_win(), wb = wa, wc = wa;
+                if (R > 1) wb = begin_win();
+            }
             // ---- 1. lane = record
             EdRowCols r = cur;
             uint64_t rid = 0; // GC: the record's identity, what its window's offset is drawn from (requested here, used at the end of the step)
             if (GC) rid = b.record_id ? b.record_id[r0 + lane < n ? r0 + lane : n - 1] : b.first_record_index + r0 + lane;
             if (CIG_OFF) {
-                const uint64_t i = r0 + lane;
-                const uint64_t cb = b.cigar_off[i < n ? i : n - 1];
+#ifdef NGSQ_EDR_CB_LATE // A/B: the offset loaded here, in front of the operations, as until round 5
+                const uint64_t cb = b.cigar_off[r0 + lane < n ? r0 + lane : n - 1];
+#else
+                const uint64_t cb = r.cb;
+#endif
                 if (r.n_ops > 0) r.g0 = b.cigar[cb];
                 if (r.n_ops > 1) r.g1 = b.cigar[cb + 1];
                 if (r.n_ops > 2) r.g2 = b.cigar[cb + 2];
@@ -749,19 +801,24 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 else if (r.n_ops == 2 && o0 == 4u && o1 == 0u) shape = true, a = r.g0 >> 4, m = r.g1 >> 4;
                 else if (r.n_ops == 2 && o0 == 0u && o1 == 4u) shape = true, m = r.g0 >> 4, z = r.g1 >> 4;
                 else if (r.n_ops == 3 && o0 == 4u && o1 == 0u && o2 == 4u) shape = true, a = r.g0 >> 4, m = r.g1 >> 4, z = r.g2 >> 4;
-                // M (I|D) M, an insertion or a deletion of up to 15 bases (what an aligner gives one read in sixteen): the first M
-                // is this record's entry of the window loop, as if the rest were clipped; the second M is compared in a step of its
-                // own behind that loop (2c), with the reference shifted by del - ins
-                else if (r.n_ops == 3 && o0 == 0u && (o1 == 1u || o1 == 2u) && o2 == 0u && (r.g1 >> 4) <= 15u && (r.g0 >> 4) < 512u && r.pos >= 16) {
+                // M (I|D|N) M -- an insertion of up to 15 bases, a deletion or a skip of any length (an aligner gives one read in sixteen an
+                // insertion or a deletion; a spliced aligner many reads a skip of kilobases): the first M is this record's entry of the
+                // window loop, as if the rest were clipped; the second M is compared in a step of its own behind that loop (2c), with the
+                // reference shifted by gap - ins.  Where the second M lies beyond the wave's window (a skip), its cover and its mismatches
+                // go straight to the arrays.  (Until late in round 5 a deletion of more than 15 bases and every skip were the walk kernel's.)
+                else if (r.n_ops == 3 && o0 == 0u && o1 >= 1u && o1 <= 3u && o2 == 0u && (o1 != 1u || (r.g1 >> 4) <= 15u) && (r.g0 >> 4) < 512u && (r.g2 >> 4) &&
+                         r.pos >= 16) {
                     shape = true, m = r.g0 >> 4, m2 = r.g2 >> 4;
-                    ins = o1 == 1u ? r.g1 >> 4 : 0u, del = o1 == 2u ? r.g1 >> 4 : 0u;
+                    ins = o1 == 1u ? r.g1 >> 4 : 0u, del = o1 != 1u ? r.g1 >> 4 : 0u;
                     z = ins + m2; // (read bases behind the first M)
                 }
                 const uint64_t e = (uint64_t)r.pos + m + del + m2; // 1-based last position
                 const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m + del + m2;
+                const bool far2 = m2 && i1 >= WIN; // the second M reaches beyond the window
                 // (P >= win_base: a mismatch's window entry is counted from P's)
-                own = shape && m && (uint64_t)a + m + z == r.l && r.l <= 2 * stride && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_L &&
-                      i1 < EDR_WINDOW;
+                // (RAGGED: the record's bytes hold its bases, at most EDG_MAXW windows of them, within 4 GiB of the pass's first byte)
+                const bool holds = RAGGED ? ((r.l + 1u) >> 1) <= r.sb && r.sb <= 16u * EDG_MAXW - 1u && r.so - so0 < 0xFFFF0000ull : r.l <= 2 * stride;
+                own = shape && m && (uint64_t)a + m + z == r.l && holds && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_L && i0 + m < WIN;
                 if (own) {
                     // the record's descriptor for the window lanes: where its base 0 lies in the packed reference (a byte offset
                     // from ref_bases: the copy that starts at base P & 1), compared bases [v0, v1), window entry of base 0
@@ -771,14 +828,21 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                     if (EDITS_EXP != 2 && EDITS_EXP != 4) {
                         atomicAdd(&win[i0], 1u);
                         atomicAdd(&win[i0 + m], 0xFFFFFFFFu);
-                        if (m2) {
+                        if (m2 && !far2) {
                             atomicAdd(&win[i0 + m + del], 1u);
                             atomicAdd(&win[i1], 0xFFFFFFFFu);
+                        } else if (m2) {
+                            uint32_t *const diff = st.edits + meta_eoff + win_base;
+                            atomicAdd(&diff[i0 + m + del], 1u);
+                            atomicAdd(&diff[i1], 0xFFFFFFFFu);
                         }
                     }
-                    top = max(top, (uint32_t)i1);
-                    // what step 2c needs of the record: first M's length, insertion, deletion, parity of P
-                    if (m2) info = m | ins << 9 | del << 13 | ((uint32_t)r.pos & 1u) << 17; // (m >= 1: never 0; 18 bits, kept above the 10 bits of the edit count)
+                    top = max(top, (uint32_t)(far2 ? WIN - 1 : i1)); // (far2: the second M's mismatches below the window's end are tallied in it)
+                    // what step 2c needs of the record: first M's length, insertion, parity of P; the gap in an array of its own
+                    if (m2) {
+                        info = m | ins << 9 | ((uint32_t)r.pos & 1u) << 13; // (m >= 1: never 0; 14 bits, kept above the 10 bits of the edit count)
+                        gapl[lane] = del;
+                    }
                 } else {
                     deferred = true;
                 }
@@ -804,10 +868,28 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             }
             desc[lane] = make_uint2(P, vv);
             red[lane] = info << 10;
+            if (RAGGED) { // the pass's windows: a prefix sum of the records' counts, each record's run of the map
+                const uint32_t wi = own ? (r.sb + 15u) >> 4 : 0u;
+                uint32_t incl = wi;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up(incl, o, 64);
+                    if (lane >= (uint32_t)o) incl += up;
+                }
+                const uint32_t first = incl - wi;
+                n_win = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                rg[lane] = make_uint2((uint32_t)(r.so - so0), first | wi << 16);
+                for (uint32_t k = 0; k < wi; k++) wmap[first + k] = (uint8_t)lane;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            const uint32_t n_steps = RAGGED ? (n_win + 63u) >> 6 : R; // steps of 64 windows
+            if (RAGGED) {
+                wa = begin_win(), wb = wa, wc = wa;
+                if (n_steps > 1) wb = begin_win();
+            }
             // ---- 2b. lane = window: 16 bytes of sequence XOR 16 of the reference
-            auto compare_win = [&](const Win &w) {
+            auto compare_win = [&](const Win &w, const bool far = false) { // far (2c only): the window may lie beyond the wave's LDS window
                 if (GC) { // the window's share of its record's GC window
                     const uint32_t glo = (w.lohi >> 16) & 0xFFu, ghi = w.lohi >> 24;
                     if (ghi > glo) {
@@ -837,47 +919,49 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                         const uint32_t bit = (uint32_t)__builtin_ctz(t);
                         t &= t - 1;
                         const uint32_t x0e = w.x0 + 8 * (bit & 3u) + ((bit >> 2) ^ 1u); // window entry of the 0-based position
-                        atomicAdd(&altw[x0e >> 1], 1u << (16u * (x0e & 1u)));
+                        if (far && x0e >= WIN) atomicAdd(st.edits + meta_eoff + win_base + ((uint64_t)meta_L + 1) + 1 + x0e, 1u); // alts[1 + position]
+                        else atomicAdd(&altw[x0e >> 1], 1u << (16u * (x0e & 1u)));
                     }
                 }
             };
             // two windows' bytes are in flight while one is compared (three slots used in turn; the kernel's waves are limited
             // by LDS to four per SIMD, which leaves 128 registers each)
             finish_win(wa);
-            if (R > 1) finish_win(wb);
+            if (n_steps > 1) finish_win(wb);
             if (it + 1 < ppw) cur = load_cols(r0 + 64); // in flight while this pass is compared (behind the end: the last record again)
 #pragma unroll 1
-            for (uint32_t k = 0; k < R && EDITS_EXP != 3; k += 3) {
-                if (k + 2 < R) wc = load_win();
+            for (uint32_t k = 0; k < n_steps && EDITS_EXP != 3; k += 3) {
+                if (k + 2 < n_steps) wc = load_win();
                 compare_win(wa);
-                if (k + 1 >= R) break;
-                if (k + 3 < R) wa = load_win();
+                if (k + 1 >= n_steps) break;
+                if (k + 3 < n_steps) wa = load_win();
                 compare_win(wb);
-                if (k + 2 >= R) break;
-                if (k + 4 < R) wb = load_win();
+                if (k + 2 >= n_steps) break;
+                if (k + 4 < n_steps) wb = load_win();
                 compare_win(wc);
             }
             // ---- 2c. the second M of the records that have one: lane = window ww of the e-th such record (its row once more, the
             // reference del - ins bases further on -- the other packed copy when that is odd)
             if (imask && EDITS_EXP != 3) {
                 const uint32_t n_ind = (uint32_t)__popcll(imask);
-                for (uint32_t g = lane; g < n_ind * R; g += 64) {
-                    const uint32_t ei = (g * recip) >> 16, ww = g - ei * R, rr = ilist[ei];
+                for (uint32_t g = lane; g < n_ind * (RAGGED ? EDG_MAXW : R); g += 64) {
+                    const uint32_t ei = RAGGED ? g / EDG_MAXW : (g * recip) >> 16, ww = RAGGED ? g % EDG_MAXW : g - ei * R, rr = ilist[ei];
+                    if (RAGGED && ww >= rg[rr].y >> 16) continue; // (a window behind the record's last)
                     const uint2 d = desc[rr];
                     const uint32_t inf = red[rr] >> 10;
-                    const uint32_t m1 = inf & 0x1FFu, ins = (inf >> 9) & 15u, del = (inf >> 13) & 15u, ppar = (inf >> 17) & 1u;
-                    const uint32_t l_rd = min(b.l_seq[r0 + rr], 2u * stride);
+                    const uint32_t m1 = inf & 0x1FFu, ins = (inf >> 9) & 15u, del = gapl[rr], ppar = (inf >> 13) & 1u;
+                    const uint32_t l_rd = RAGGED ? b.l_seq[r0 + rr] : min(b.l_seq[r0 + rr], 2u * stride);
                     const int32_t shift = (int32_t)del - (int32_t)ins, t = (int32_t)ppar + shift; // P2 = P + shift
                     const uint32_t off2 = (uint32_t)((int32_t)(d.x - (ppar ? odd_delta : 0u)) + (t >> 1)) + ((t & 1) ? odd_delta : 0u);
                     const uint32_t b0 = 32u * ww, v0 = m1 + ins, v1 = l_rd;
                     Win w;
-                    __builtin_memcpy(&w.sv, rows + rr * stride + 16u * ww, 16);
+                    __builtin_memcpy(&w.sv, rows + (RAGGED ? rg[rr].x : rr * stride) + 16u * ww, 16);
                     __builtin_memcpy(&w.rv, st.ref_bases + (off2 + 16u * ww), 16);
                     w.slot = rr, w.ww = ww;
                     w.x0 = (uint32_t)((int32_t)(d.y >> 18) + shift + (int32_t)b0);
                     const uint32_t lo = min(v0 > b0 ? v0 - b0 : 0u, 32u), hi = min(v1 > b0 ? v1 - b0 : 0u, 32u);
                     w.lohi = lo | hi << 8;
-                    compare_win(w);
+                    compare_win(w, true);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1129,12 +1213,15 @@ __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs,
 // ---------------------------------------------------------------------------
 // fixed-pitch rows of reads of up to 160 bases: a lane per 16-byte window (k_edits_rows); longer rows and the offsets layout: a lane
 // per record (the window lanes address the packed reference by 32-bit byte offsets: 2 x 4 G bases; beyond that the lane-per-record kernel)
-static bool edits_rows_ok(const DeviceState &st, const DeviceBatch &b) {
+static bool edits_windows_ok(const DeviceState &st, const DeviceBatch &b) { // (what both window-lane variants need)
     static const bool per_record = getenv("NGSQ_EDITS_PER_RECORD") && atoi(getenv("NGSQ_EDITS_PER_RECORD")); // A/B measurements
-    const uint32_t R = (b.seq_stride + 15) / 16;
-    return !b.seq_off && R >= 1 && R <= ED_NW && !per_record && 2 * (uint64_t)(st.ref_bases_odd - st.ref_bases) + 256 < (1ull << 32) &&
-           (b.cigar_off || b.cigar_stride >= 1);
+    return !per_record && 2 * (uint64_t)(st.ref_bases_odd - st.ref_bases) + 256 < (1ull << 32) && (b.cigar_off || b.cigar_stride >= 1);
 }
+static bool edits_rows_ok(const DeviceState &st, const DeviceBatch &b) {
+    const uint32_t R = (b.seq_stride + 15) / 16;
+    return !b.seq_off && R >= 1 && R <= ED_NW && edits_windows_ok(st, b);
+}
+static bool edits_ragged_ok(const DeviceState &st, const DeviceBatch &b) { return b.seq_off && edits_windows_ok(st, b); }
 
 bool edits_can_take_gc(const DeviceState &st, const DeviceBatch &b) {
     static const bool off = getenv("NGSQ_EDITS_NO_GC") && atoi(getenv("NGSQ_EDITS_NO_GC")); // A/B measurements: k_gc as a kernel of its own
@@ -1157,11 +1244,14 @@ hipError_t launch_edits(const LaunchInfo &li, const DeviceState &st, const Devic
     if (with_gc && !rows_ok) return hipErrorInvalidValue; // (the caller asked edits_can_take_gc)
     const uint32_t recip = R ? 65536u / R + 1u : 0u;
     if (rows_ok && b.cigar_off) {
-        if (with_gc) hipLaunchKernelGGL((k_edits_rows<true, true>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
-        else hipLaunchKernelGGL((k_edits_rows<true, false>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
+        if (with_gc) hipLaunchKernelGGL((k_edits_rows<true, true, false>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
+        else hipLaunchKernelGGL((k_edits_rows<true, false, false>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
     } else if (rows_ok) {
-        if (with_gc) hipLaunchKernelGGL((k_edits_rows<false, true>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
-        else hipLaunchKernelGGL((k_edits_rows<false, false>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
+        if (with_gc) hipLaunchKernelGGL((k_edits_rows<false, true, false>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
+        else hipLaunchKernelGGL((k_edits_rows<false, false, false>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, R, recip, defer_bits);
+    } else if (edits_ragged_ok(st, b)) { // (R, recip: unused)
+        if (b.cigar_off) hipLaunchKernelGGL((k_edits_rows<true, false, true>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, 1u, 65536u, defer_bits);
+        else hipLaunchKernelGGL((k_edits_rows<false, false, true>), dim3(gr), dim3(ED_THREADS), 0, s, st, b, 1u, 65536u, defer_bits);
     } else {
         hipLaunchKernelGGL(k_edits, dim3((uint32_t)g), dim3(ED_THREADS), 0, s, st, b, defer_bits);
     }

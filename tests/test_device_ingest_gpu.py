@@ -378,6 +378,26 @@ def test_device_reader_header_larger_than_segments_and_chunks(gpu_lib, tmp_path,
             assert [r for b in dbatches for r in records_of(b)] == records_of(hb)
 
 
+def test_device_reader_offsets_scan_both_ways(gpu_lib, tmp_path, monkeypatch):
+    """The offsets of the variable-width columns are an exclusive scan of the records' lengths (bam_device.hip
+    launch_exclusive_scan_u64): pieces of 4096 entries, each block adding up the sums in front of its own piece -- or, beyond
+    8192 pieces (33 M records in one chunk), a launch that scans the sums between the two.  Both on 30 000 ragged records (eight
+    pieces), and with chunks of 1 MiB (pieces that end inside a chunk)."""
+    rng = np.random.default_rng(43)
+    ref_len = [50_000, 9000]
+    hb = random_batch(rng, 30_000, ref_len, max_len=140, weird=False)
+    path = str(tmp_path / "s.bam")
+    bamio.write_bam(path, hb, ["chr1", "chr2"], ref_len, block_payload=40_000)
+    want = records_of(hb)
+    with host.QcContext(ref_len, facets=ffi.FACET_GENERAL, lib=gpu_lib) as ctx:
+        for own_carry in ("8192", "3", "0"):
+            for raw_mb in ("256", "1"):
+                monkeypatch.setenv("NGSQ_SCAN_OWN_CARRY", own_carry)
+                monkeypatch.setenv("NGSQ_INGEST_RAW_MB", raw_mb)
+                dbatches, dn = read_all_device(gpu_lib, ctx, path, 1 << 20)
+                assert dn == hb.n and [r for b in dbatches for r in records_of(b)] == want, (own_carry, raw_mb)
+
+
 def test_device_reader_errors(gpu_lib, ctx, tmp_path):
     rng = np.random.default_rng(1)
     hb = random_batch(rng, 2000, [9000], max_len=80)

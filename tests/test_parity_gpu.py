@@ -454,7 +454,8 @@ def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar
     del - ins bases further on.  Every place that arithmetic can go wrong, one record each on 150-base fixed-pitch rows, the
     literal Python walk and the oracle as judges: the indel at a window boundary (32, 64, 96, 128 bases), one base before and
     behind it, first M of one base, second M of one base, insertions and deletions of 1, 2, 7, 8 and 15 bases (the shift odd and
-    even: both packed copies of the reference), 16 bases (left to the walk kernel), positions 0, 15 (walk) and 16, odd and even."""
+    even: both packed copies of the reference), 16 bases (the walk kernel's until the gap got a word of its own), positions 0, 15 (walk) and 16,
+    odd and even; skips that end inside the wave's window and kilobases beyond it."""
     from tests.util import to_fixed_stride
     rng = np.random.default_rng(4242)
     ref_len = [40_000, 3_000]
@@ -476,8 +477,8 @@ def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar
                 recs.append(dict(flag=0x40 if len(recs) % 2 else 0, mapq=60, ref_id=0, pos=p, mate_ref_id=-1, tlen=0,
                                  cigar=f"{a}M{g}{op}{m2}M", seq="".join("=ACMGRSVTWYHKDBN"[c] for c in codes), qual=[30] * L))
             pos += 5
-    # a skip (N) between two M: the lane-per-record kernel of the offsets layout compares the second M kilobases further on (its cover
-    # goes straight to the array when it lies beyond the wave's window); the rows kernel leaves these to the walk
+    # a skip (N) between two M: the second M is compared kilobases further on (its cover and its mismatches go straight to the arrays
+    # when it lies beyond the wave's window)
     for skip in (100, 1300, 5000):
         for p in (pos, pos + 1):
             a1 = 70
@@ -495,7 +496,7 @@ def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar
     hv = batch_from_records(recs)
     hb = to_fixed_stride(hv)
     assert hb.seq_stride == 75 and hb.cigar_stride == 3
-    if cigar_offsets == "offsets layout":   # everything through offsets: k_edits, a lane per record, with its own second-segment step (round 5)
+    if cigar_offsets == "offsets layout":   # everything through offsets: the RAGGED variant of the window lanes
         hb = hv
     elif cigar_offsets:   # fixed-pitch SEQ / QUAL rows with the CIGARs through offsets: what the device reader makes of an aligner's file
         cols = dict(hb.cols)
@@ -507,6 +508,102 @@ def test_edits_second_segment_edge_cases(gpu_lib, oracle_mod, sorted_rows, cigar
     assert np.array_equal(alts, want_alts[0]) and np.array_equal(refs, want_refs[0])
     r1, r2, _ = gpu.edits()
     assert int(r1.sum() + r2.sum()) == len(recs) and int(r1[2] + r2[2]) >= len(recs) - 2   # two substitutions per read
+
+
+@pytest.mark.parametrize("order", ["sorted", "unsorted", "one position"])
+@pytest.mark.parametrize("subst", [0.0, 0.05, 0.6])
+def test_edits_ragged_window_edge_cases(gpu_lib, oracle_mod, order, subst):
+    """The offsets layout through the window lanes (k_edits_rows<.., RAGGED>, round 5): a record has ceil(bytes / 16) windows of its
+    own and a byte map in LDS says which record a window of the pass belongs to.  Reads of every length around the window size
+    (1..49 bases), around 100, 150, 256 and 300, around the variant's limit (255 bytes: 509..512 bases, the longer ones are the walk
+    kernel's) and far beyond it, with no bases at all, soft clips on either end, an insertion or a deletion, the first and the last
+    base substituted -- sorted (the windows a pass needs fit the LDS window), unsorted (most records are left to the walk) and all
+    on one position (a pass's cover on two entries); the literal Python walk and the oracle as judges."""
+    rng = np.random.default_rng(991)
+    ref_len = [60_000, 4_000]
+    bases = random_ref_bases(rng, ref_len)
+    lens = list(range(1, 50)) + [63, 64, 65, 95, 96, 97, 100, 127, 128, 129, 149, 150, 151, 255, 256, 257, 299, 300, 301,
+                                 479, 480, 481, 508, 509, 510, 511, 512, 513, 600, 1000, 2200]
+    recs, pos = [], 20
+    code = "=ACMGRSVTWYHKDBN"
+
+    def sample(r, p, m):
+        x = bases[r][p:p + m].copy()
+        if m:
+            x[0] = 1 if x[0] != 1 else 2          # the first and the last compared base
+            x[-1] = 4 if x[-1] != 4 else 8
+        if subst:
+            hit = rng.random(m) < subst
+            x[hit] = rng.choice(np.array([1, 2, 4, 8, 15], dtype=np.uint8), int(hit.sum()))
+        return x
+    for rep in range(3):
+        for l in lens:
+            for shape in ("M", "SM", "MS", "SMS", "MIM", "MDM", "MNM"):
+                r = 1 if (l < 300 and rep == 2 and shape == "M") else 0
+                p = pos if order != "one position" else 500
+                if p + l + 40 > ref_len[r]:
+                    p = int(rng.integers(16, ref_len[r] - l - 40))
+                a = z = 0
+                if "S" in shape and l >= 3:
+                    a = int(rng.integers(1, max(2, l // 3))) if shape[0] == "S" else 0
+                    z = int(rng.integers(1, max(2, l // 3))) if shape[-1] == "S" else 0
+                m = l - a - z
+                if shape in ("MIM", "MDM", "MNM") and l >= 8:
+                    # (a deletion of up to 40 bases, a skip that ends inside the wave's window of ~1100 positions, at its end, or far beyond it)
+                    g = int(rng.integers(1, 6)) if shape == "MIM" else int(rng.integers(1, 41)) if shape == "MDM" else int(rng.choice([1, 90, 700, 1100, 1160, 9000]))
+                    g = min(g, l - 3) if shape == "MIM" else g
+                    m1 = int(rng.integers(1, l - (g if shape == "MIM" else 0) - 1))
+                    if p + l + g + 40 > ref_len[r]:
+                        p = int(rng.integers(16, ref_len[r] - l - g - 40))
+                    if shape == "MIM":
+                        m2 = l - m1 - g
+                        x = np.concatenate([sample(r, p, m1), rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), g), sample(r, p + m1, m2)])
+                        cigar = f"{m1}M{g}I{m2}M"
+                    else:
+                        m2 = l - m1
+                        x = np.concatenate([sample(r, p, m1), sample(r, p + m1 + g, m2)])
+                        cigar = f"{m1}M{g}{'D' if shape == 'MDM' else 'N'}{m2}M"
+                else:
+                    x = np.concatenate([rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), a), sample(r, p, m),
+                                        rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), z)])
+                    cigar = (f"{a}S" if a else "") + f"{m}M" + (f"{z}S" if z else "")
+                recs.append(dict(flag=(0x40 if len(recs) % 3 else 0x80) | (0x10 if len(recs) % 5 == 0 else 0), mapq=60, ref_id=r, pos=p,
+                                 mate_ref_id=-1, tlen=0, cigar=cigar, seq="".join(code[c] for c in x), qual=[30] * l))
+                pos += int(rng.integers(0, 4))
+    # records with nothing for the window lanes: no bases (the reference aborts on them: counted), unmapped, no CIGAR
+    recs.append(dict(flag=0, mapq=60, ref_id=0, pos=700, mate_ref_id=-1, tlen=0, cigar="10M", seq="", qual=[]))
+    recs.append(dict(flag=4, mapq=0, ref_id=-1, pos=-1, mate_ref_id=-1, tlen=0, cigar="*", seq="ACGT" * 30, qual=[30] * 120))
+    recs.append(dict(flag=0, mapq=60, ref_id=0, pos=800, mate_ref_id=-1, tlen=0, cigar="*", seq="ACGT" * 30, qual=[30] * 120))
+    if order == "sorted":
+        recs.sort(key=lambda q: (q["ref_id"] if q["ref_id"] >= 0 else 99, q["pos"]))
+    elif order == "unsorted":
+        rng.shuffle(recs)
+    hb = batch_from_records(recs)
+    assert hb.cols["seq_off"] is not None
+    gpu, orc = run_both(oracle_mod, gpu_lib, [hb], ref_len, facets=ffi.FACET_EDITS, ref_bases=bases)
+    want_refs, want_alts = brute_force_refs_alts(hb, ref_len, bases)
+    for r in range(2):
+        refs, alts = gpu.edits_positions(r)
+        assert np.array_equal(alts, want_alts[r]) and np.array_equal(refs, want_refs[r]), r
+    r1, r2, _ = gpu.edits()
+    assert int(r1.sum() + r2.sum()) >= 0.9 * len(recs)     # (the longest reads at 60 % have more than 512 edits: counted as such)
+
+
+def test_lane_per_record_edits_kernel_still_agrees(gpu_lib):
+    """`k_edits` (a lane per record) is what the offsets layout ran on until round 5 and what is left for references beyond
+    4 Gbases (the window lanes address the two packed copies with 32-bit offsets): NGSQ_EDITS_PER_RECORD=1 sends every batch through
+    it.  The Edits tests of this file once more in a child process with that set."""
+    import subprocess
+    import sys
+    if os.environ.get("NGSQ_EDITS_PER_RECORD"):
+        pytest.skip("already the child")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_edits_facet or test_edits_positions_against_a_literal_walk or test_edits_second_segment_edge_cases "
+                              "or (test_edits_ragged_window_edge_cases and sorted)"],
+                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, NGSQ_EDITS_PER_RECORD="1"),
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 def test_reference_bases_must_be_4_bit_codes(gpu_lib):
