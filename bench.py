@@ -1344,10 +1344,14 @@ def leg_extra_facets(lib, host, ffi, np, n=100_000_000):
         # reads that DIFFER from the reference (edits.rs:276-291 costs the same per base whatever the bases are): 5 % and 25 % of the
         # compared bases substituted -- bisulfite-converted, cross-species, noisy reads -- and round 3's input, independent random
         # bases (three in four differ)
-        for key, model, what in (("edits_subst_5pct", ffi.synth_seq_subst(0.05), "sampled from the reference, 5 % substitutions"),
-                                 ("edits_subst_25pct", ffi.synth_seq_subst(0.25), "sampled from the reference, 25 % substitutions"),
-                                 ("edits_iid_reads", ffi.SYNTH_SEQ_IID, "independent random bases")):
-            icfg = host.synth_config(100_000_000, ref_len=CHR1, n_refs=2, seq_model=model)
+        # ... and the 50-300 base reads of `mixed` (the offsets layout: since round 5 through the same window lanes, a byte map in LDS
+        # saying which record a window belongs to; 10 % M (I|D) M, 5 % M (N of 100-5000) M)
+        for key, model, what, mode in (("edits_subst_5pct", ffi.synth_seq_subst(0.05), "sampled from the reference, 5 % substitutions", ffi.SYNTH_FIXED),
+                                       ("edits_subst_25pct", ffi.synth_seq_subst(0.25), "sampled from the reference, 25 % substitutions", ffi.SYNTH_FIXED),
+                                       ("edits_iid_reads", ffi.SYNTH_SEQ_IID, "independent random bases", ffi.SYNTH_FIXED),
+                                       ("edits_mixed_reads", ffi.SYNTH_SEQ_FROM_REFERENCE, "50-300 bases, 1-3 CIGAR operations, offsets layout; sampled from the reference, 0.5 % substitutions", ffi.SYNTH_MIXED),
+                                       ("edits_mixed_subst_5pct", ffi.synth_seq_subst(0.05), "50-300 bases, 1-3 CIGAR operations, offsets layout; 5 % substitutions", ffi.SYNTH_MIXED)):
+            icfg = host.synth_config(100_000_000, mode=mode, ref_len=CHR1, n_refs=2, seq_model=model)
             db = ctx.synth_device_batch(icfg, 0, n)
             for rep in range(2):
                 ctx.reset()

@@ -458,7 +458,6 @@ struct EdRowCols {
     int32_t ref, pos;
     uint64_t so;  // RAGGED: where the record's packed bases begin in the column,
     uint32_t sb;  //         and how many bytes it has there (saturated)
-    uint64_t cb;  // CIG_OFF: its first operation's index (loaded with the columns, a pass ahead: the operations' loads then wait for nothing)
 };
 constexpr uint32_t EDG_MAXW = 16;     // RAGGED: 16-byte windows a record may have on the fast path: 255 bytes, reads of up to 510 bases
 constexpr uint32_t EDG_WINDOW = 1152; // RAGGED: entries of the wave's cover window (256 fewer than EDR_WINDOW pay for the window -> record map)
@@ -548,8 +547,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
         r.l = b.l_seq[ii];
         r.n_ops = b.n_cigar[ii];
         r.g0 = r.g1 = r.g2 = 0;
-        r.so = 0, r.sb = 0, r.cb = 0;
-        if (CIG_OFF) r.cb = b.cigar_off[ii];
+        r.so = 0, r.sb = 0;
         if (RAGGED) {
             r.so = b.seq_off[ii];
             const uint64_t nb = b.seq_off[ii + 1] - r.so;
@@ -781,11 +779,8 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
             uint64_t rid = 0; // GC: the record's identity, what its window's offset is drawn from (requested here, used at the end of the step)
             if (GC) rid = b.record_id ? b.record_id[r0 + lane < n ? r0 + lane : n - 1] : b.first_record_index + r0 + lane;
             if (CIG_OFF) {
-#ifdef NGSQ_EDR_CB_LATE // A/B: the offset loaded here, in front of the operations, as until round 5
+                // (the offset loaded a pass ahead with the columns: measured in round 5, the same time)
                 const uint64_t cb = b.cigar_off[r0 + lane < n ? r0 + lane : n - 1];
-#else
-                const uint64_t cb = r.cb;
-#endif
                 if (r.n_ops > 0) r.g0 = b.cigar[cb];
                 if (r.n_ops > 1) r.g1 = b.cigar[cb + 1];
                 if (r.n_ops > 2) r.g2 = b.cigar[cb + 2];
