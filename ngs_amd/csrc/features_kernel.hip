@@ -55,7 +55,11 @@ __device__ __forceinline__ uint32_t bound_from(const uint32_t *a, uint32_t lo, u
     auto below = [&](uint32_t x) { return UPPER ? x <= v : x < v; }; // the entries in front of the answer
     if (from > hi) from = hi;
     if (from < lo) from = lo;
-    if (from > lo && !below(a[from - 1])) return UPPER ? upper_bound(a, lo, from, v) : lower_bound(a, lo, from, v);
+    // the usual answer is `from` itself (the entry in front of it below the bound, the one at it not): both are requested at once
+    // (a value that decides nothing where there is no such entry)
+    const uint32_t before = from > lo ? a[from - 1] : 0u, here = from < hi ? a[from] : 0u;
+    if (from > lo && !below(before)) return UPPER ? upper_bound(a, lo, from, v) : lower_bound(a, lo, from, v);
+    if (from >= hi || !below(here)) return from;
     uint32_t at = from, step = 1;
     while (at < hi && below(a[at])) { // gallop: from, from + 1, from + 3, from + 7, ...
         at += step;
@@ -86,6 +90,21 @@ __device__ __forceinline__ uint32_t count_overlaps(const FeatureTables &ft, uint
 // and was what this kernel's time consisted of
 __device__ __forceinline__ void tally(uint32_t &counter, bool pred) { counter += (uint32_t)__popcll(__ballot(pred)); }
 
+// wave-wide minimum / maximum without the LDS pipe: prefix steps inside the rows of sixteen lanes (row_shr), then across them
+// (row_bcast); lane 63 holds the result.  (Five of them per tile: as __shfl_xor butterflies they were thirty ds_bpermute.)
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_extreme(uint32_t v) {
+    constexpr int ID = MAX ? 0 : -1; // what a lane without a source contributes
+    auto pick = [](uint32_t a, uint32_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+    v = pick(v, (uint32_t)__builtin_amdgcn_update_dpp(ID, (int)v, 0x111, 0xF, 0xF, false)); // row_shr:1
+    v = pick(v, (uint32_t)__builtin_amdgcn_update_dpp(ID, (int)v, 0x112, 0xF, 0xF, false)); // row_shr:2
+    v = pick(v, (uint32_t)__builtin_amdgcn_update_dpp(ID, (int)v, 0x114, 0xF, 0xF, false)); // row_shr:4
+    v = pick(v, (uint32_t)__builtin_amdgcn_update_dpp(ID, (int)v, 0x118, 0xF, 0xF, false)); // row_shr:8
+    v = pick(v, (uint32_t)__builtin_amdgcn_update_dpp(ID, (int)v, 0x142, 0xA, 0xF, false)); // row_bcast:15
+    v = pick(v, (uint32_t)__builtin_amdgcn_update_dpp(ID, (int)v, 0x143, 0xC, 0xF, false)); // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 } // namespace
 
 // A TILE is F_RPT x 64 consecutive records of ONE WAVE, F_RPT per lane (record r * 64 + lane of the tile: coalesced columns).
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
     const uint64_t lo_i = min(wave_id * per, b.n), hi_i = lo_i + per < b.n ? lo_i + per : b.n;
     int32_t prev_ref = -1; // the sequence `my_br` belongs to (-1: none)
     uint32_t my_br = 0;    // lanes 0..19: bracket `lane & 3` of name id `lane >> 2` of the previous tile, relative to the list's begin
-    uint32_t my_lo = 0;    // ... and the begin of that list
+    uint32_t my_lo = 0, my_hi = 0; // ... and the begin and the end of that list
     for (uint64_t t0 = lo_i; t0 < hi_i; t0 += TILE) {
         uint32_t qs[F_RPT], qe[F_RPT], what[F_RPT]; // what: 0 nothing (past the end), 1 ignored flags, 2 error: reference, 3 ignored: not primary, 4 error: position, 5 looked up
         int32_t ref[F_RPT];
@@ -138,8 +157,14 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
 #pragma unroll
             for (uint32_t r = 0; r < F_RPT; r++) {
                 op0[r] = b.cigar[c0[r]]; // (the column has slack behind its last operation)
-                prim[r] = ref[r] >= 0 && (uint32_t)ref[r] < ft.n_refs ? ft.primary[ref[r]] : (uint8_t)0;
             }
+            // `primary` of the records' sequences: one (uniform) load for the sequence of the wave's first record, a load of its own
+            // only for a record on another one
+            const int32_t g = __builtin_amdgcn_readfirstlane(ref[0]);
+            const uint8_t prim_g = g >= 0 && (uint32_t)g < ft.n_refs ? ft.primary[g] : (uint8_t)0;
+#pragma unroll
+            for (uint32_t r = 0; r < F_RPT; r++)
+                prim[r] = ref[r] == g ? prim_g : ref[r] >= 0 && (uint32_t)ref[r] < ft.n_refs ? ft.primary[ref[r]] : (uint8_t)0;
 #pragma unroll
             for (uint32_t r = 0; r < F_RPT; r++) {
                 const uint64_t i = t0 + r * 64 + lane;
@@ -168,98 +193,115 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
                 }
             }
         }
-        // the tile's first (sequence, start) among the records that are looked up
-        unsigned long long key = ~0ull;
+        // the tile's first (sequence, start) among the records that are looked up: the smallest sequence, then the smallest start on it
+        uint32_t fr = 0xFFFFFFFFu;
 #pragma unroll
-        for (uint32_t r = 0; r < F_RPT; r++) {
-            const unsigned long long kr = what[r] == 5 ? (unsigned long long)(uint32_t)ref[r] << 32 | qs[r] : ~0ull;
-            key = kr < key ? kr : key;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(key, o, 64);
-            key = other < key ? other : key;
-        }
-        const int32_t r0 = key == ~0ull ? -1 : (int32_t)(key >> 32);
-        // on that sequence: largest query start, smallest / largest query end
-        uint32_t m0 = 0u, m1 = 0xFFFFFFFFu, m2 = 0u;
+        for (uint32_t r = 0; r < F_RPT; r++)
+            if (what[r] == 5) fr = min(fr, (uint32_t)ref[r]);
+        fr = wave_extreme<false>(fr);
+        const int32_t r0 = fr == 0xFFFFFFFFu ? -1 : (int32_t)fr;
+        // on that sequence: smallest / largest query start, smallest / largest query end
+        uint32_t q0 = 0xFFFFFFFFu, m0 = 0u, m1 = 0xFFFFFFFFu, m2 = 0u;
 #pragma unroll
         for (uint32_t r = 0; r < F_RPT; r++)
             if (what[r] == 5 && ref[r] == r0) {
+                q0 = min(q0, qs[r]);
                 m0 = max(m0, qs[r]);
                 m1 = min(m1, qe[r]);
                 m2 = max(m2, qe[r]);
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o, 64));
-            m1 = min(m1, (uint32_t)__shfl_xor((int)m1, o, 64));
-            m2 = max(m2, (uint32_t)__shfl_xor((int)m2, o, 64));
+        if (r0 >= 0) { // (uniform)
+            q0 = wave_extreme<false>(q0);
+            m0 = wave_extreme<true>(m0);
+            m1 = wave_extreme<false>(m1);
+            m2 = wave_extreme<true>(m2);
         }
         if (r0 >= 0 && lane < 20) {
             const uint32_t k = lane >> 2, which = lane & 3;
-            const uint32_t lo = ft.idx[k * ft.n_refs + r0], hi = ft.idx[k * ft.n_refs + r0 + 1];
+            // (the list's ends: kept from the previous tile while the sequence stays the same -- a dependent load less per tile)
+            if (prev_ref != r0) {
+                my_lo = ft.idx[k * ft.n_refs + r0];
+                my_hi = ft.idx[k * ft.n_refs + r0 + 1];
+            }
+            const uint32_t lo = my_lo, hi = my_hi;
             const uint32_t from = prev_ref == r0 ? lo + my_br : lo; // (this lane's own result for the previous tile)
             uint32_t v;
             if (which == 0) v = bound_from<false>(ft.starts, lo, hi, from, m1) - lo;                         // fewest starts below a query end
             else if (which == 1) v = bound_from<false>(ft.starts, lo, hi, from, m2) - lo;                    // most
-            else if (which == 2) v = bound_from<true>(ft.stops, lo, hi, from, (uint32_t)(key & 0xFFFFFFFFu)) - lo; // fewest stops at or below a query start
+            else if (which == 2) v = bound_from<true>(ft.stops, lo, hi, from, q0) - lo;                      // fewest stops at or below a query start
             else v = bound_from<true>(ft.stops, lo, hi, from, m0) - lo;                                      // most
             // kept relative to the list's begin, so that counts come out directly; the searches add the begin back
             my_br = v;
-            my_lo = lo;
         }
         prev_ref = r0;
+        // ---- the five role names' overlap counts of every record, two bits each (0..3: the chains below never ask for more).
+        // Round 5: a role at a time for all F_RPT records of the lane, its brackets taken out of the bracket lanes ONCE (they are
+        // uniform: scalar registers), and where a bracket holds at most two list entries -- nearly always: a tile spans a few hundred
+        // positions, a list has an entry every few thousand -- those entries are loaded once per tile (uniform addresses) and a
+        // record's count is two compares against each: no search, no loop, no load per record.  (Until then every record ran its ten
+        // searches inside the brackets, each with its own loop set-up: 300 vector instructions per record and lane.)
+        uint32_t acc[F_RPT];
+#pragma unroll
+        for (uint32_t r = 0; r < F_RPT; r++) acc[r] = 0;
+#pragma unroll 1
+        for (uint32_t role = 0; role < 5; role++) {
+            const uint32_t name = ft.role_name[role];
+            uint32_t lo = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (r0 >= 0) {
+                lo = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)(4u * name));
+                b0 = (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name));
+                b1 = (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 1u));
+                b2 = (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 2u));
+                b3 = (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 3u));
+            }
+            const bool few = b1 - b0 <= 2u && b3 - b2 <= 2u; // (uniform)
+            // the bracket's entries, or a value no query bound is above
+            uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, e0 = 0xFFFFFFFFu, e1 = 0xFFFFFFFFu;
+            if (few) {
+                if (b1 - b0 >= 1u) s0 = ft.starts[lo + b0];
+                if (b1 - b0 >= 2u) s1 = ft.starts[lo + b0 + 1u];
+                if (b3 - b2 >= 1u) e0 = ft.stops[lo + b2];
+                if (b3 - b2 >= 2u) e1 = ft.stops[lo + b2 + 1u];
+                s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0), s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s1);
+                e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e0), e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e1);
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < F_RPT; r++) {
+                if (what[r] != 5) continue;
+                uint32_t c;
+                if (ref[r] != r0) { // another sequence than the tile's first: the whole lists
+                    c = count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], nullptr);
+                } else if (few) {
+                    // #{s < qe} - #{e <= qs}, the entries in front of the brackets counted by the brackets themselves
+                    c = (b0 + (s0 < qe[r] ? 1u : 0u) + (s1 < qe[r] ? 1u : 0u)) - (b2 + (e0 <= qs[r] ? 1u : 0u) + (e1 <= qs[r] ? 1u : 0u));
+                } else {
+                    const uint32_t br[4] = {lo + b0, lo + b1, lo + b2, lo + b3};
+                    c = count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], br);
+                }
+                acc[r] |= min(c, 3u) << (2u * role);
+            }
+        }
+        // features.rs:186-214  UTR / CDS store: the if / else-if chain over the overlapping intervals sets, per distinct NAME, one flag
+        // per overlapping interval in the order 5' UTR, 3' UTR, CDS among the roles that carry the name -- role X is set iff its name's
+        // count exceeds the number of roles in front of X with the same name (roles may share a name).
+        // :216-238  gene / exon store: a name that is also a UTR/CDS name never reaches this store (:322-333), and `name == gene` is
+        // tested before `name == exon`.
+        const uint32_t n5 = ft.role_name[NGSQ_ROLE_FIVE_PRIME_UTR], n3 = ft.role_name[NGSQ_ROLE_THREE_PRIME_UTR],
+                       nc = ft.role_name[NGSQ_ROLE_CODING_SEQUENCE], ne = ft.role_name[NGSQ_ROLE_EXON], ng = ft.role_name[NGSQ_ROLE_GENE];
+        const uint32_t rank3 = n3 == n5 ? 1u : 0u, rankc = (nc == n5 ? 1u : 0u) + (nc == n3 ? 1u : 0u);
+        const bool gene_in_store = ng != n5 && ng != n3 && ng != nc;
+        const bool exon_in_store = ne != n5 && ne != n3 && ne != nc && ne != ng;
+        static_assert(NGSQ_ROLE_FIVE_PRIME_UTR == 0 && NGSQ_ROLE_THREE_PRIME_UTR == 1 && NGSQ_ROLE_CODING_SEQUENCE == 2, "the UTR/CDS chain's order");
 #pragma unroll
         for (uint32_t r = 0; r < F_RPT; r++) {
-            bool utr5 = false, utr3 = false, cds = false, intergenic = false, exonic = false, intronic = false;
             const bool look = what[r] == 5;
-            if (look) {
-                const bool narrow = ref[r] == r0;
-                auto count = [&](uint32_t name) -> uint32_t {
-                    if (!narrow) return count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], nullptr);
-                    // (brackets that have closed -- no interval of this name begins or ends inside the tile's span, the usual
-                    // case -- give the count without touching the lists: lower_bound / upper_bound of an empty range)
-                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)(4u * name));
-                    const uint32_t br[4] = {lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name)),
-                                            lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 1u)),
-                                            lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 2u)),
-                                            lo + (uint32_t)__builtin_amdgcn_readlane((int)my_br, (int)(4u * name + 3u))};
-                    return count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], br);
-                };
-                // :186-214  UTR / CDS store: the if / else-if chain over the overlapping intervals only
-                // depends on how many there are of each name (roles may share a name)
-                bool c5 = false, c3 = false, cc = false;
-                const uint32_t n5 = ft.role_name[NGSQ_ROLE_FIVE_PRIME_UTR], n3 = ft.role_name[NGSQ_ROLE_THREE_PRIME_UTR],
-                               nc = ft.role_name[NGSQ_ROLE_CODING_SEQUENCE];
-#pragma unroll
-                for (uint32_t role = 0; role < 3; role++) {
-                    const uint32_t name = ft.role_name[role];
-                    bool seen = false; // count each distinct name once
-                    for (uint32_t q = 0; q < role; q++) seen |= ft.role_name[q] == name;
-                    if (seen) continue;
-                    uint32_t c = min(count(name), 3u);
-                    for (; c; c--) {
-                        if (!c5 && name == n5) c5 = true;
-                        else if (!c3 && name == n3) c3 = true;
-                        else if (!cc && name == nc) cc = true;
-                    }
-                }
-                utr5 = c5, utr3 = c3, cds = cc;
-                // :216-238  gene / exon store.  A name that is also a UTR/CDS name never reaches this
-                // store (:322-333), and `name == gene` is tested before `name == exon`.
-                const uint32_t ne = ft.role_name[NGSQ_ROLE_EXON], ng = ft.role_name[NGSQ_ROLE_GENE];
-                const bool gene_in_store = ng != n5 && ng != n3 && ng != nc;
-                const bool exon_in_store = ne != n5 && ne != n3 && ne != nc && ne != ng;
-                const bool has_gene = gene_in_store && count(ng) > 0;
-                const bool has_exon = exon_in_store && count(ne) > 0;
-                if (has_gene) {
-                    if (has_exon) exonic = true;
-                    else intronic = true;
-                } else {
-                    intergenic = true;
-                }
-            }
+            auto cnt_of = [&](uint32_t role) { return (acc[r] >> (2u * role)) & 3u; };
+            const bool utr5 = look && cnt_of(NGSQ_ROLE_FIVE_PRIME_UTR) > 0u;
+            const bool utr3 = look && cnt_of(NGSQ_ROLE_THREE_PRIME_UTR) > rank3;
+            const bool cds = look && cnt_of(NGSQ_ROLE_CODING_SEQUENCE) > rankc;
+            const bool has_gene = gene_in_store && cnt_of(NGSQ_ROLE_GENE) > 0u;
+            const bool has_exon = exon_in_store && cnt_of(NGSQ_ROLE_EXON) > 0u;
+            const bool exonic = look && has_gene && has_exon, intronic = look && has_gene && !has_exon, intergenic = look && !has_gene;
             tally(cnt[F_UTR5], utr5);
             tally(cnt[F_UTR3], utr3);
             tally(cnt[F_CDS], cds);
@@ -267,10 +309,12 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
             tally(cnt[F_EXONIC], exonic);
             tally(cnt[F_INTRONIC], intronic);
             tally(cnt[F_PROCESSED], look); // :240
-            tally(cnt[F_IGN_FLAGS], what[r] == 1);
-            tally(cnt[F_IGN_NONPRIMARY], what[r] == 3);
-            tally(cnt[9], what[r] == 2);
-            tally(cnt[10], what[r] == 4);
+            if (__ballot(what[r] != 5 && what[r] != 0)) { // (a record that is not looked up: one in a hundred)
+                tally(cnt[F_IGN_FLAGS], what[r] == 1);
+                tally(cnt[F_IGN_NONPRIMARY], what[r] == 3);
+                tally(cnt[9], what[r] == 2);
+                tally(cnt[10], what[r] == 4);
+            }
         }
     }
     __syncthreads();
