@@ -1104,13 +1104,22 @@ __global__ __launch_bounds__(1024) void k_edits_chunk_scan(uint32_t *__restrict_
     for (uint32_t i = lo; i < hi; i++) t += sums[i];
     s_part[threadIdx.x] = t;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < 1024; k++) {
-            const uint32_t v = s_part[k];
-            s_part[k] = run;
-            run += v;
+    if (threadIdx.x < 64) { // the 1024 partial sums: sixteen per lane of the first wave (one thread walking all of them took 50 us)
+        uint32_t loc[16], run = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            loc[k] = run;
+            run += s_part[threadIdx.x * 16 + k];
         }
+        uint32_t inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64);
+            if ((int)threadIdx.x >= o) inc += up;
+        }
+        const uint32_t before = inc - run;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) s_part[threadIdx.x * 16 + k] = before + loc[k];
     }
     __syncthreads();
     uint32_t run = s_part[threadIdx.x];
