@@ -347,7 +347,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
             CTX_TRY(launch_pack_reference(c->li, codes, L, bases + bases_off[r], bases + nbases + bases_off[r], L / 2 + 1, d_bad, c->stream));
             CTX_TRY(hipStreamSynchronize(c->stream)); // `codes` is reused (and the host buffer is the caller's)
             c->edits_carry_off[r] = n_carry;
-            n_carry += edits_teardown_chunks(L + 1);
+            n_carry += edits_teardown_carry_words(L + 1);
         }
         CTX_TRY(hipMemcpy(&h_bad, d_bad, 8, hipMemcpyDeviceToHost));
         (void)hipFree(codes);

@@ -1096,48 +1096,30 @@ __global__ __launch_bounds__(256) void k_edits_chunk_sums(const uint32_t *__rest
     if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-__global__ __launch_bounds__(1024) void k_edits_chunk_scan(uint32_t *__restrict__ sums, uint32_t n, const u64 *touched) {
-    __shared__ uint32_t s_part[1024];
+// The carry of a chunk (the sum of every entry in front of it) is never written down: behind the chunks' sums lie the sums of every
+// EDS consecutive chunks, and a block of k_edits_refs adds up the (at most a few hundred) super sums in front of its chunk's group and
+// the (at most EDS - 1) chunk sums in front of it inside the group.  (Until round 5 one block scanned the sixty thousand chunk sums of
+// a chromosome in place, sixty sequential loads per thread: 0.09 ms of a 0.45 ms teardown.)
+constexpr uint32_t EDS = 256; // chunks per super sum
+__global__ __launch_bounds__(256) void k_edits_super_sums(const uint32_t *__restrict__ sums, uint32_t n, uint32_t *__restrict__ supers, const u64 *touched) {
+    __shared__ uint32_t s_w[4];
     if (touched && !*touched) return;
-    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = min(n, lo + per);
-    uint32_t t = 0;
-    for (uint32_t i = lo; i < hi; i++) t += sums[i];
-    s_part[threadIdx.x] = t;
+    const uint32_t i = blockIdx.x * EDS + threadIdx.x;
+    uint32_t t = ed_wave_sum(i < n ? sums[i] : 0u);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x < 64) { // the 1024 partial sums: sixteen per lane of the first wave (one thread walking all of them took 50 us)
-        uint32_t loc[16], run = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) {
-            loc[k] = run;
-            run += s_part[threadIdx.x * 16 + k];
-        }
-        uint32_t inc = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)inc, o, 64);
-            if ((int)threadIdx.x >= o) inc += up;
-        }
-        const uint32_t before = inc - run;
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) s_part[threadIdx.x * 16 + k] = before + loc[k];
-    }
-    __syncthreads();
-    uint32_t run = s_part[threadIdx.x];
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t v = sums[i];
-        sums[i] = run;
-        run += v;
-    }
+    if (threadIdx.x == 0) supers[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs, const uint32_t *__restrict__ alts, uint64_t n_entries,
                                                      const uint32_t *__restrict__ carry, uint32_t chunk0, uint32_t chunk1, u64 *vaf_hist, const u64 *touched) {
     __shared__ uint32_t s_h[NGSQ_VAF_BINS];
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[4], s_c[4];
     if (touched && !*touched) return;
     if (threadIdx.x < NGSQ_VAF_BINS) s_h[threadIdx.x] = 0;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t *const supers = carry + (uint32_t)((n_entries + EDC - 1) / EDC); // (`carry`: the chunks' sums, the super sums behind them)
     uint32_t zero_bin = 0;       // covered positions of this thread with alts == 0 (VAF 0.0 -> bin 0)
     __syncthreads();
     // a block takes every gridDim.x-th chunk and adds its histogram to the global one ONCE (a block per chunk meant sixty thousand
@@ -1145,7 +1127,16 @@ __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs,
 #pragma unroll 1
     for (uint32_t chunk = chunk0 + blockIdx.x; chunk < chunk1; chunk += gridDim.x) {
     const uint64_t base = (uint64_t)chunk * EDC;
-    uint32_t run = carry[chunk]; // sum of every entry in front of the chunk
+    uint32_t run; // sum of every entry in front of the chunk
+    {
+        const uint32_t grp = chunk / EDS, in_grp = chunk - grp * EDS;
+        uint32_t t = threadIdx.x < in_grp ? carry[grp * EDS + threadIdx.x] : 0u;
+        for (uint32_t i = threadIdx.x; i < grp; i += 256) t += supers[i];
+        t = ed_wave_sum(t);
+        if (lane == 0) s_c[wave] = t;
+        __syncthreads(); // (s_c is rewritten for the next chunk behind the barriers of this chunk's steps)
+        run = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    }
 #pragma unroll 1
     for (uint32_t k = 0; k < EDC / 1024; k++) {
         const uint64_t i = base + (uint64_t)k * 1024 + threadIdx.x * 4;
@@ -1272,12 +1263,16 @@ hipError_t launch_pack_reference(const LaunchInfo &li, const uint8_t *codes, uin
 }
 
 uint64_t edits_teardown_chunks(uint64_t n_entries) { return (n_entries + EDC - 1) / EDC; }
+uint64_t edits_teardown_carry_words(uint64_t n_entries) { // the chunks' sums + the super sums behind them
+    const uint64_t n = edits_teardown_chunks(n_entries);
+    return n + (n + EDS - 1) / EDS;
+}
 
 hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uint32_t *sums, const unsigned long long *touched, hipStream_t s) {
     const uint64_t n = edits_teardown_chunks(n_entries);
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_edits_chunk_sums, dim3((uint32_t)n), dim3(256), 0, s, diff, n_entries, sums, touched);
-    hipLaunchKernelGGL(k_edits_chunk_scan, dim3(1), dim3(1024), 0, s, sums, (uint32_t)n, touched);
+    hipLaunchKernelGGL(k_edits_super_sums, dim3((uint32_t)((n + EDS - 1) / EDS)), dim3(256), 0, s, sums, (uint32_t)n, sums + n, touched);
     return hipGetLastError();
 }
 

@@ -165,32 +165,25 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
 #pragma unroll
             for (uint32_t r = 0; r < F_RPT; r++)
                 prim[r] = ref[r] == g ? prim_g : ref[r] >= 0 && (uint32_t)ref[r] < ft.n_refs ? ft.primary[ref[r]] : (uint8_t)0;
+            // (selects, not branches: every divergent `if` costs the scalar unit -- the busier one here -- half a dozen instructions)
 #pragma unroll
             for (uint32_t r = 0; r < F_RPT; r++) {
                 const uint64_t i = t0 + r * 64 + lane;
-                qs[r] = qe[r] = what[r] = 0;
-                if (i >= hi_i) {
-                    ref[r] = -1;
-                } else if (flag[r] & 0x4u) { // features.rs:127-130
-                    what[r] = 1;
-                } else if (ref[r] < 0 || (uint32_t)ref[r] >= ft.n_refs) { // :132-155
-                    what[r] = 2;
-                } else if (!prim[r]) { // :157-165
-                    what[r] = 3;
-                } else if (pos[r] < 0) { // :171-174
-                    what[r] = 4;
-                } else {
-                    // :176-178  start = alignment_start (1-based), end = start + cigar.alignment_span()
-                    uint32_t span = 0;
-                    for (uint32_t k = 0; k < n_ops[r]; k++) {
-                        const uint32_t op = k ? b.cigar[c0[r] + k] : op0[r], code = op & 15u;
-                        // M, D, N, =, X consume the reference
-                        if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) span += op >> 4;
-                    }
-                    qs[r] = (uint32_t)pos[r] + 1u;
-                    qe[r] = qs[r] + span + 1u; // find(start, end + 1)
-                    what[r] = 5;
+                const bool live = i < hi_i, valid_ref = ref[r] >= 0 && (uint32_t)ref[r] < ft.n_refs;
+                // features.rs:127-130 unmapped, :132-155 no such sequence, :157-165 not a primary one, :171-174 no position
+                what[r] = !live ? 0u : (flag[r] & 0x4u) ? 1u : !valid_ref ? 2u : !prim[r] ? 3u : pos[r] < 0 ? 4u : 5u;
+                if (!live) ref[r] = -1;
+                // :176-178  start = alignment_start (1-based), end = start + cigar.alignment_span(): M, D, N, =, X consume the reference
+                uint32_t span = n_ops[r] && ((0x18Du >> (op0[r] & 15u)) & 1u) ? op0[r] >> 4 : 0u;
+                if (__ballot(what[r] == 5 && n_ops[r] > 1)) { // (uniform: a batch of one-operation CIGARs never gets here)
+                    if (what[r] == 5)
+                        for (uint32_t k = 1; k < n_ops[r]; k++) {
+                            const uint32_t op = b.cigar[c0[r] + k];
+                            if ((0x18Du >> (op & 15u)) & 1u) span += op >> 4;
+                        }
                 }
+                qs[r] = (uint32_t)pos[r] + 1u;
+                qe[r] = qs[r] + span + 1u; // find(start, end + 1)  (both only looked at where what == 5)
             }
         }
         // the tile's first (sequence, start) among the records that are looked up: the smallest sequence, then the smallest start on it
@@ -267,18 +260,20 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
             }
 #pragma unroll
             for (uint32_t r = 0; r < F_RPT; r++) {
-                if (what[r] != 5) continue;
-                uint32_t c;
-                if (ref[r] != r0) { // another sequence than the tile's first: the whole lists
-                    c = count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], nullptr);
-                } else if (few) {
-                    // #{s < qe} - #{e <= qs}, the entries in front of the brackets counted by the brackets themselves
-                    c = (b0 + (s0 < qe[r] ? 1u : 0u) + (s1 < qe[r] ? 1u : 0u)) - (b2 + (e0 <= qs[r] ? 1u : 0u) + (e1 <= qs[r] ? 1u : 0u));
-                } else {
-                    const uint32_t br[4] = {lo + b0, lo + b1, lo + b2, lo + b3};
-                    c = count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], br);
+                // #{s < qe} - #{e <= qs}, the entries in front of the brackets counted by the brackets themselves -- computed by every
+                // lane, looked up or not (no branch); the two rare cases behind UNIFORM tests
+                uint32_t c = (b0 + (s0 < qe[r] ? 1u : 0u) + (s1 < qe[r] ? 1u : 0u)) - (b2 + (e0 <= qs[r] ? 1u : 0u) + (e1 <= qs[r] ? 1u : 0u));
+                const bool look = what[r] == 5;
+                if (!few) { // a bracket with more than two entries: the searches inside it
+                    if (look && ref[r] == r0) {
+                        const uint32_t br[4] = {lo + b0, lo + b1, lo + b2, lo + b3};
+                        c = count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], br);
+                    }
                 }
-                acc[r] |= min(c, 3u) << (2u * role);
+                if (__ballot(look && ref[r] != r0)) { // a record on another sequence than the tile's first: the whole lists
+                    if (look && ref[r] != r0) c = count_overlaps(ft, name, (uint32_t)ref[r], qs[r], qe[r], nullptr);
+                }
+                acc[r] |= min(c, 3u) << (2u * role); // (of a record that is not looked up: never read)
             }
         }
         // features.rs:186-214  UTR / CDS store: the if / else-if chain over the overlapping intervals sets, per distinct NAME, one flag

@@ -234,6 +234,7 @@ hipError_t launch_pack_reference(const LaunchInfo &li, const uint8_t *codes, uin
 // Edits teardown for one sequence (edits.rs:305-344): sums[c] = sum of the difference entries in front of 4096-entry chunk c;
 // then, chunk by chunk, refs in place of the difference array and (vaf_hist != null) the VAF histogram
 uint64_t edits_teardown_chunks(uint64_t n_entries);
+uint64_t edits_teardown_carry_words(uint64_t n_entries); // words of the teardown's scratch for a sequence of n_entries - 1 bases
 // touched (optional, device memory): the sequence's word of the counters block at off_eseen -- zero: nothing to do, the kernels return
 // write_refs: refs = cover - alts in place (ngsq_get_edits_positions); false: the VAF histogram only, the arrays stay as they are
 hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uint32_t *sums, const unsigned long long *touched, hipStream_t s);
