@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restric
 // ---------------------------------------------------------------------------
 // Edits teardown (edits.rs:305-344).  The slot of refs holds the difference array of the `M` cover until here:
 //   k_edits_chunk_sums   sum of the entries of every 4096-entry chunk
-//   k_edits_chunk_scan   exclusive prefix over a sequence's chunk sums (one block; a sequence has at most 2^20 chunks)
+//   k_edits_super_sums   sum of every 256 consecutive chunk sums (a chunk's carry = the super sums and the chunk sums in front of it)
 //   k_edits_refs         chunks [c0, c1): cover[p] = sum of the entries [0, p), refs[p] = cover[p] - alts[p] in place, and the
 //                        VAF histogram of the positions with refs + alts > 0 -- f32 arithmetic exactly as edits.rs:331-335:
 //                        alts as f32 / total as f32, * 100.0, truncated
