@@ -32,7 +32,13 @@
 extern "C" {
 #endif
 
-#define NGSQ_ABI_VERSION 5u
+/* ABI 6 (round 6): the STATE layout changed under ABI 5's name in round 5 and is now versioned -- the counters block holds
+ * n_refs "Edits wrote here" words (one per sequence) in front of the quality table, so n_counters and every later offset
+ * moved for ngsq_state_download / _upload and the ngsq_shard_state all-reduce; the edits block holds the difference array
+ * of the `M` cover, not refs; device batches must be readable NGSQ_DEVICE_COLUMN_SLACK bytes behind every column.
+ * ngsq_exchange compares the ABI version and the block sizes of all ranks before the first sum (a rank built against
+ * another layout is refused, not summed).  New in 6: ngsq_config.ref_bases_len, ngsq_reference.h. */
+#define NGSQ_ABI_VERSION 6u
 
 /* ---- status codes (reference: anyhow::Result<()> / panic) ---- */
 #define NGSQ_OK 0

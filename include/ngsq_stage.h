@@ -64,7 +64,9 @@ uint64_t ngsq_stager_pushed(const ngsq_stager *s);   /* records pushed since cre
  *                an entry above 15 is NGSQ_ERR_INVALID_ARGUMENT
  *   quals        record.quality_scores(): n_quals entries (Phred, <= 93: a larger score is counted on the device as the
  *                decode error it is in noodles).  n_quals is l_seq, or 0 for a record without qualities; anything else is
- *                NGSQ_ERR_INVALID_ARGUMENT (noodles refuses such a record while decoding)
+ *                NGSQ_ERR_INVALID_ARGUMENT (noodles refuses such a record while decoding).  l_seq scores that are ALL 0xFF
+ *                are BAM's own encoding of "no qualities" and are staged as n_quals = 0 (as ngsq_stager_push_packed reads
+ *                them), whatever the layout of the flush; l_seq ends at 2^31 - 1 (BAM's field)
  *   cigar        record.cigar(): n_cigar operations, len << 4 | op with op in 0..8 = MIDNSHP=X (any number of operations:
  *                the 16-bit n_cigar column saturates, ngsq.h)
  *   record_id    the record's identity for the GC window offset (ngsq.h): reader.virtual_position() before the record was

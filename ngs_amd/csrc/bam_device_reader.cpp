@@ -570,8 +570,13 @@ void reader_main(DeviceIngest *d, std::string path) {
         // the framed bytes cross PCIe step by step, on the copy stream, while the next step is read: the device
         // buffer of this slot is free (the consumer released the slot only after the kernels that read it had finished)
         size_t sent = 0;
+        const uint8_t *slot_was = d->d_comp_slot[k].p;
         bool h2d_ok = d->copy_stream && hipSetDevice(d->ctx->device) == hipSuccess &&
                       d->d_comp_slot[k].reserve(cap + INFLATE_IN_SLACK) == hipSuccess;
+        // (a new allocation is zeroed once: the decoders' input windows read up to INFLATE_IN_SLACK bytes behind the chunk's
+        // last payload -- never used, but not left to whatever the memory held before)
+        if (h2d_ok && d->d_comp_slot[k].p != slot_was)
+            h2d_ok = hipMemsetAsync(d->d_comp_slot[k].p, 0, d->d_comp_slot[k].bytes, d->copy_stream) == hipSuccess;
         {   // the context's device buffers were last read by the chunk four in front: behind its retirement on the context's stream
             bool wait_ev;
             {
@@ -865,7 +870,11 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, uint64_t j) {
         BHIP(d->d_coff_s[k].reserve(p.n_blk));
         memcpy(p.pin_blocks, p.blocks.data(), p.n_blk * sizeof(BgzfBlock));
         memcpy(p.pin_coff, p.coff.data(), p.n_blk * sizeof(uint64_t));
-        BHIP(d->d_comp_slot[k].reserve(p.consumed + INFLATE_IN_SLACK));
+        {
+            const uint8_t *slot_was = d->d_comp_slot[k].p;
+            BHIP(d->d_comp_slot[k].reserve(p.consumed + INFLATE_IN_SLACK));
+            if (d->d_comp_slot[k].p != slot_was) BHIP(hipMemsetAsync(d->d_comp_slot[k].p, 0, d->d_comp_slot[k].bytes, sb));
+        }
         BHIP(ngsq::pool_pinned_h2d(d->d_comp_slot[k].p, c.h, 0, p.consumed, sb));
         BHIP(launch_copy_words(d->d_blocks_s[k].p, dev_of(p.pin_blocks), p.n_blk * sizeof(BgzfBlock), sb));
         BHIP(launch_copy_words(d->d_coff_s[k].p, dev_of(p.pin_coff), p.n_blk * sizeof(uint64_t), sb));

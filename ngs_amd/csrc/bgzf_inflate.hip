@@ -1137,12 +1137,17 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfBlock *blocks, uin
     uint32_t base = 0;
     if (counter_base) { // every decoder draws one ticket past the blocks when it leaves
         base = *counter_base;
-        *counter_base = base + n_blocks + grid;
     } else {
         hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(grid), dim3(64), 0, s, comp, blocks, n_blocks, out, status, counter, base);
+    {   // the host's copy of the never-reset counter moves only with a launch that was accepted: a refused launch leaves the
+        // device word where it was, and every later launch on this stream still computes its block indices from the right base
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (counter_base) *counter_base = base + n_blocks + grid;
+    }
     if (check_crc) (void)launch_bgzf_crc(blocks, n_blocks, out, status, nullptr, s);
 #ifdef NGSQ_INFLATE_PROFILE
     {

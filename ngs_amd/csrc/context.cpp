@@ -799,12 +799,30 @@ int ngsq_synchronize(ngsq_ctx *c) {
 
 void *ngsq_stream(ngsq_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+// every sequence that has Edits slots counts as written (the words at off_eseen of the counters block; kept non-zero ones)
+static int mark_edits_written(ngsq_ctx *c) {
+    const uint32_t nr = c->st.n_refs;
+    if (!c->n_edits || !nr) return NGSQ_OK;
+    std::vector<unsigned long long> eseen(nr);
+    HIP_TRY(c, hipMemcpyAsync(eseen.data(), c->st.counters + c->st.off_eseen, nr * 8ull, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t r = 0; r < nr; r++)
+        if (c->edits_off[r] != NO_DEPTH && !eseen[r]) eseen[r] = 1;
+    HIP_TRY(c, hipMemcpyAsync(c->st.counters + c->st.off_eseen, eseen.data(), nr * 8ull, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return NGSQ_OK;
+}
+
 int ngsq_teardown(ngsq_ctx *c) {
     if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
     if (c->finalized || c->torn_down) return fail(c, NGSQ_ERR_STATE, "already torn down");
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t facets = c->cfg.facets;
     const uint32_t nr = c->st.n_refs;
+    if (c->edits_uploaded) { // see ngsq_state_upload: every sequence with Edits slots counts as written
+        const int rc = mark_edits_written(c);
+        if (rc) return rc;
+    }
     if ((facets & NGSQ_FACET_COVERAGE) && c->n_chunks) {
         // one launch tears down every sequence that has an entry (coverage.rs:187-193 skips the rest)
         CovScanArgs a{};
@@ -1034,7 +1052,7 @@ int ngsq_reset(ngsq_ctx *c) {
         }
     }
     if (c->n_edits) {
-        if (!c->finalized) {
+        if (!c->finalized || c->edits_uploaded) { // (after an upload the host's words say nothing certain about the slots)
             HIP_TRY(c, hipMemsetAsync(c->st.edits, 0, c->n_edits * 4, c->stream));
         } else { // only the sequences Edits wrote something for (h_counters: read back by ngsq_finalize)
             for (uint32_t r = 0; r < c->st.n_refs; r++)
@@ -1047,6 +1065,7 @@ int ngsq_reset(ngsq_ctx *c) {
     if (step_legacy()) HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
     c->span_turn = 0;
     c->finalized = false;
+    c->edits_uploaded = false;
     c->torn_down = false;
     c->scan_lo = 0;
     c->scan_hi = c->n_chunks;
@@ -1268,7 +1287,15 @@ int ngsq_state_upload(ngsq_ctx *c, int which, const void *src, uint64_t n_bytes)
         c->h_touched[1] = c->n_diff;
         HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
     }
+    // uploaded cover / alts may sit on any sequence: the teardown, ngsq_get_edits_positions and the reset behind a finalize act
+    // on the sequences whose "Edits wrote here" word (counters block, off_eseen) is set.  ngsq_teardown sets them all when an
+    // edits block came in from outside (whatever the order of the uploads), the next ngsq_reset clears every slot (a
+    // host that restored or merged only this block got an empty VAF histogram, and the next run inherited the data)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (which == 2 && c->n_edits) {
+        c->edits_uploaded = true;
+        return mark_edits_written(c); // (now, for an exchange that sums the words before the teardown; again there, for a counters block uploaded later)
+    }
     return NGSQ_OK;
 }
 

@@ -82,6 +82,7 @@ struct ngsq_ctx {
     unsigned long long *d_cov_hist = nullptr, *d_bin_totals = nullptr, *d_vaf = nullptr;
     std::vector<unsigned long long> h_counters, h_cov_hist, h_bin_totals, h_vaf;
     bool finalized = false;
+    bool edits_uploaded = false; // ngsq_state_upload(which = 2) since the last reset: any sequence's slots may hold data
     // ngsq_finalize's results land here (pinned host memory the device addresses, written by one kernel), then in the vectors above
     unsigned long long *pin_results = nullptr, *pin_results_dev = nullptr;
     uint64_t pin_words = 0;

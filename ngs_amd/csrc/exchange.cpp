@@ -214,6 +214,23 @@ struct Xchg {
         if (!S.counters || !S.synchronize || !S.teardown_range)
             return fail(NGSQ_ERR_INVALID_ARGUMENT, "ngsq_shard_state: counters / synchronize / teardown_range missing");
 
+        // ---- step 0: every rank must hold the SAME state layout -- the blocks are summed element by element, and a rank built
+        // against another ABI (or configured with other sequences / facets / quality rows) would be summed misaligned, silently
+        {
+            const uint64_t mine[6] = {NGSQ_ABI_VERSION, S.n_counters, S.n_depth, S.n_edits, S.n_teardown, S.n_chunks};
+            std::vector<uint64_t> all(6 * (size_t)world);
+            int rc0 = ngsq_comm_allgather_host(&T, mine, all.data(), sizeof mine);
+            if (rc0) return rc0;
+            for (uint32_t r = 0; r < world; r++)
+                if (memcmp(&all[6 * (size_t)r], mine, sizeof mine) != 0) {
+                    static const char *const what[6] = {"ABI version", "counters", "depth", "edits", "teardown", "chunks"};
+                    int f = 0;
+                    while (f < 5 && all[6 * (size_t)r + f] == mine[f]) f++;
+                    // (the same verdict on every rank: each compares with all the others)
+                    return comm_fail(&T, NGSQ_ERR_STATE, "shard state layouts differ: %s is %llu on rank %u and %llu on rank %u", what[f],
+                                     (unsigned long long)all[6 * (size_t)r + f], r, (unsigned long long)mine[f], rank);
+                }
+        }
         // ---- step 1: the record-facet state (and the Edits refs/alts) of all shards
         int rc = allreduce(S.counters, S.n_counters, 8);
         if (rc) return rc;

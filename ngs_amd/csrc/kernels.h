@@ -243,7 +243,7 @@ hipError_t launch_edits_refs(uint32_t *refs, const uint32_t *alts, uint64_t n_en
 
 // Up to STATE_SPANS_MAX small blocks of 32-bit words filled with a value (src == null) or copied (src -> dst; dst may be pinned
 // host memory the device addresses) by ONE launch: the resets of ngsq_reset, the result download of ngsq_finalize.  kernels.hip
-constexpr uint32_t STATE_SPANS_MAX = 12;
+constexpr uint32_t STATE_SPANS_MAX = 16;
 struct StateSpans {
     struct Span {
         uint32_t *dst;
@@ -252,11 +252,16 @@ struct StateSpans {
         uint32_t value;
     } span[STATE_SPANS_MAX];
     uint32_t n = 0;
+    bool overflow = false; // a span that did not fit: launch_state_spans then fails (hipErrorInvalidValue) instead of leaving a block untouched
     void fill(void *dst, uint64_t n_words, uint32_t value) {
-        if (n_words && n < STATE_SPANS_MAX) span[n++] = Span{static_cast<uint32_t *>(dst), nullptr, n_words, value};
+        if (!n_words) return;
+        if (n < STATE_SPANS_MAX) span[n++] = Span{static_cast<uint32_t *>(dst), nullptr, n_words, value};
+        else overflow = true;
     }
     void copy(void *dst, const void *src, uint64_t n_words) {
-        if (n_words && n < STATE_SPANS_MAX) span[n++] = Span{static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), n_words, 0};
+        if (!n_words) return;
+        if (n < STATE_SPANS_MAX) span[n++] = Span{static_cast<uint32_t *>(dst), static_cast<const uint32_t *>(src), n_words, 0};
+        else overflow = true;
     }
 };
 hipError_t launch_state_spans(const StateSpans &a, hipStream_t s);

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void k_state_spans(StateSpans a) {
 }
 
 hipError_t launch_state_spans(const StateSpans &a, hipStream_t s) {
+    if (a.overflow) return hipErrorInvalidValue; // more blocks queued than STATE_SPANS_MAX: a block would be left un-reset / un-copied
     uint64_t quads = 0;
     for (uint32_t k = 0; k < a.n; k++) quads += (a.span[k].n_words + 3) / 4;
     if (!quads) return hipSuccess;

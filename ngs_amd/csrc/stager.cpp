@@ -140,12 +140,14 @@ static int push_common(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t ref_
                        uint32_t n_quals, const uint32_t *cigar, uint32_t n_cigar, uint64_t record_id) {
     if (s->n >= s->capacity) return sfail(s, NGSQ_ERR_STATE, "the stager is full (%llu records): flush first", (unsigned long long)s->capacity);
     if (n_cigar && !cigar) return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "cigar is null");
+    // (BAM's l_seq is a signed 32-bit field; (l + 1) / 2 below must not wrap)
+    if (l > 0x7FFFFFFFu) return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "a record of %u bases: BAM's l_seq ends at 2^31 - 1", l);
     if (n_quals != 0 && n_quals != l)
         return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "a record of %u bases with %u quality scores (noodles refuses it while decoding)", l, n_quals);
     const bool has_id = record_id != NGSQ_STAGE_NO_ID;
     if (s->n && (s->n_with_id != 0) != has_id)
         return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "records with and without a record_id in one flush");
-    if (!s->seq.reserve(s->so + (l + 1) / 2 + SLACK) || !s->qual.reserve(s->qo + n_quals + SLACK) || !s->cigar.reserve((s->co + n_cigar) * 4 + SLACK))
+    if (!s->seq.reserve(s->so + ((uint64_t)l + 1) / 2 + SLACK) || !s->qual.reserve(s->qo + n_quals + SLACK) || !s->cigar.reserve((s->co + n_cigar) * 4 + SLACK))
         return sfail(s, NGSQ_ERR_DEVICE, "could not grow the staging columns");
     const uint64_t i = s->n;
     reinterpret_cast<uint16_t *>(s->flag.p)[i] = flag;
@@ -188,6 +190,15 @@ int ngsq_stager_push(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t ref_id
     uint8_t over = 0;
     for (uint32_t k = 0; k < l_seq; k++) over |= bases[k];
     if (over > 15) return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "bases: every entry is a 4-bit BAM base code (0..15)");
+    // l_seq scores of 0xFF are BAM's encoding of "no qualities" (SAM/BAM specification 4.2.3; noodles yields none): the same
+    // record must not count differently by the layout of the flush it lands in -- fixed-pitch rows read an all-0xFF row as
+    // absent, the offsets layout would count l_seq scores of 255 as decode errors -- so it is staged as a record
+    // without qualities here too, exactly as ngsq_stager_push_packed does
+    if (n_quals && n_quals == l_seq) {
+        bool missing = true;
+        for (uint32_t k = 0; k < n_quals && missing; k++) missing = quals[k] == 0xFF;
+        if (missing) n_quals = 0;
+    }
     int rc = push_common(s, flag, mapq, ref_id, pos, mate_ref_id, tlen, l_seq, n_quals, cigar, n_cigar, record_id);
     if (rc != NGSQ_OK) return rc;
     uint8_t *dst = s->seq.p + s->so; // BAM's packing: two bases per byte, high nibble first, a trailing low nibble of zero

@@ -13,7 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libngsq.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1

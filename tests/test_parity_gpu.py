@@ -653,6 +653,47 @@ def test_sharded_state_sums_to_single_context(gpu_lib, oracle_mod):
     json_equal(total.results(["a", "b"]), orc.results(["a", "b"]))
 
 
+def test_edits_block_uploaded_alone_is_torn_down_and_reset(gpu_lib, oracle_mod):
+    """A host that restores or merges ONLY the edits block (ngsq_state_upload which = 2): the teardown, the per-position
+    getter and the reset behind the finalize act on the sequences whose `Edits wrote here` word is set -- an upload sets them
+    (it did not; the VAF histogram came back empty and the next run inherited the uploaded data)."""
+    rng = np.random.default_rng(77)
+    ref_len = [5000, 1800, 900]
+    bases = random_ref_bases(rng, ref_len)
+    hb = make_edit_friendly(random_batch(rng, 5000, ref_len, weird=False, min_len=1), rng, bases, ref_len)
+    kw = dict(facets=ffi.FACET_EDITS, ref_bases=bases)
+    with host.QcContext(ref_len, lib=gpu_lib, **kw) as src:
+        src.process_batch(hb)
+        src.synchronize()
+        block = src.state_download(2)
+        src.finalize(allow_malformed=True)
+        want_vaf = src.edits()[2].copy()
+        want_pos = [src.edits_positions(r) for r in range(3)]
+    assert want_vaf.sum() > 500
+    with host.QcContext(ref_len, lib=gpu_lib, **kw) as dst:
+        dst.state_upload(2, block)          # nothing else: no counters, no records
+        dst.finalize(allow_malformed=True)
+        np.testing.assert_array_equal(dst.edits()[2], want_vaf)
+        for r in range(3):
+            for a, b in zip(dst.edits_positions(r), want_pos[r]):
+                np.testing.assert_array_equal(a, b)
+        # ... and the next run starts from zero
+        dst.reset()
+        hb2 = make_edit_friendly(random_batch(rng, 700, ref_len, weird=False, min_len=1), rng, bases, ref_len)
+        dst.process_batch(hb2)
+        dst.finalize(allow_malformed=True)
+        orc = oracle_mod.Oracle(ref_len, **kw)
+        orc.process_batch(hb2)
+        orc.finalize(allow_malformed=True)
+        compare_contexts(dst, orc, 3, ffi.FACET_EDITS, 50_000, ref_len)
+        # the upload before the counters block (whose words are zero) still counts
+        dst.reset()
+        dst.state_upload(2, block)
+        dst.state_upload(0, np.zeros_like(dst.state_download(0)))
+        dst.finalize(allow_malformed=True)
+        np.testing.assert_array_equal(dst.edits()[2], want_vaf)
+
+
 @pytest.mark.parametrize("n,sorted_input", [(4_000_000, False), (100_000_000, True), (100_000_000, False)])
 def test_full_size_properties(gpu_lib, n, sorted_input):
     """At sizes the oracle cannot reach quickly: size-independent invariants on records generated in HBM over a chr1-sized

@@ -309,6 +309,21 @@ def _owner_worker(rank, world, port, q, layout, transport):
                 done()
                 q.put((rank, "ok"))
                 return
+        if layout == "layout_mismatch":
+            # a rank whose state blocks have another shape (built against another ABI, other sequences, other quality rows)
+            # must be refused by every rank before anything is summed, not summed misaligned
+            if rank == 1:
+                mine.counters = np.zeros(mine.counters.size + 3, dtype=np.uint64)
+            before = mine.counters.copy()
+            try:
+                comm.exchange_state(mine.shard_state())
+                raise AssertionError("state blocks of different sizes were summed")
+            except shard.CommError as e:
+                assert e.code == ffi.ERR_STATE and "layouts differ" in str(e) and "counters" in str(e), e
+            assert (mine.counters == before).all()
+            done()
+            q.put((rank, "ok"))
+            return
         rep = comm.exchange_state(mine.shard_state()) if not layout.startswith("flags") else rep
         assert rep["mode"] == ("allreduce" if layout == "unsorted" else "owner"), rep
         assert (mine.td == whole.td).all(), "teardown results differ from the single-context scan"
@@ -326,7 +341,8 @@ def _owner_worker(rank, world, port, q, layout, transport):
 @pytest.mark.parametrize("world,layout,transport", [(2, "sorted", "gloo"), (3, "sorted", "gloo"), (3, "sorted", "shm"),
                                                     (3, "empty_rank", "gloo"), (2, "unsorted", "gloo"), (3, "unsorted", "shm"),
                                                     (3, "flags_ok", "gloo"), (3, "flags_overlap", "gloo"),
-                                                    (3, "flags_overlap", "shm"), (3, "flags_sender", "shm"), (2, "flags_sender", "gloo")])
+                                                    (3, "flags_overlap", "shm"), (3, "flags_sender", "shm"), (2, "flags_sender", "gloo"),
+                                                    (3, "layout_mismatch", "shm"), (2, "layout_mismatch", "gloo")])
 def test_owner_teardown_world_2_3(world, layout, transport):
     _run_ranks(_owner_worker, world, layout, transport)
 

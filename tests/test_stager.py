@@ -184,6 +184,35 @@ def test_layout_follows_the_records(lib):
     lib.ngsq_stager_destroy(st)
 
 
+def test_all_0xff_scores_are_no_qualities_in_either_layout(lib, oracle_mod):
+    """ngsq_stager_push with l_seq scores of 0xFF is BAM's encoding of "no qualities": staged as n_quals = 0 whatever else the
+    flush holds (fixed-pitch rows read such a row as absent, the offsets layout counted l_seq decode errors)."""
+    bases = np.array([1, 2, 4, 8] * 5, dtype=np.uint8)
+    ff = np.full(20, 0xFF, dtype=np.uint8)
+    q = np.full(20, 30, dtype=np.uint8)
+    one, two = np.array([20 << 4], dtype=np.uint32), np.array([10 << 4, 10 << 4 | 4], dtype=np.uint32)
+    docs = []
+    for ragged in (False, True):
+        st = new_stager(lib, 8)
+        assert lib.ngsq_stager_push(st, 0, 60, 0, 10, -1, 0, 20, bases.ctypes.data, q.ctypes.data, 20, one.ctypes.data, 1, ffi.STAGE_NO_ID) == 0
+        assert lib.ngsq_stager_push(st, 0, 60, 0, 11, -1, 0, 20, bases.ctypes.data, ff.ctypes.data, 20, one.ctypes.data, 1, ffi.STAGE_NO_ID) == 0
+        if ragged:  # a record of another shape turns the flush into the offsets layout
+            assert lib.ngsq_stager_push(st, 0, 60, 0, 12, -1, 0, 20, bases.ctypes.data, q.ctypes.data, 20, two.ctypes.data, 2, ffi.STAGE_NO_ID) == 0
+        got, b = view(lib, st)
+        assert int(got.cols["qual_off"][2] - got.cols["qual_off"][1]) == 0     # the 0xFF record holds no score bytes
+        orc = oracle_mod.Oracle(LENS, PRIMARY, facets=ffi.FACET_QUALITY_SCORE, max_read_len=32)
+        orc.process_batch(got.slice(0, 2))
+        assert orc.finalize(allow_malformed=True) == 0                          # no bad_quality_score
+        docs.append(orc.results(NAMES))
+        lib.ngsq_stager_destroy(st)
+    json_equal(docs[0], docs[1])
+    # a read longer than BAM's l_seq field is refused before anything is sized from it
+    st = new_stager(lib, 2)
+    assert lib.ngsq_stager_push_packed(st, 0, 0, -1, -1, -1, 0, 0xFFFFFFFF, bases.ctypes.data, None, None, 0, ffi.STAGE_NO_ID) == ffi.ERR_INVALID_ARGUMENT
+    assert b"l_seq" in lib.ngsq_stager_last_error(st)
+    lib.ngsq_stager_destroy(st)
+
+
 def test_errors_and_lifecycle(lib):
     st = C.c_void_p()
     assert lib.ngsq_stager_create(0, ffi.STAGE_PAGEABLE, C.byref(st)) == ffi.ERR_INVALID_ARGUMENT
