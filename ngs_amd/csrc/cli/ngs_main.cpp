@@ -155,7 +155,8 @@ bool load_genome(const std::string &want, Genome *g, std::string *supported) {
 // ---- FASTA (Edits facet, edits.rs:185-205): name -> 4-bit BAM base codes, one per byte
 int base_code(char c) {
     static const char tab[] = "=ACMGRSVTWYHKDBN";
-    const char *p = (const char *)memchr(tab, c, 16); // upper case only, as noodles' Base::try_from(char)
+    if (c >= 'a' && c <= 'z') c = (char)(c - 32); // [N9]: Base::try_from folds case (oracle/oracle.h): soft-masked FASTA is the norm
+    const char *p = (const char *)memchr(tab, c, 16);
     return p ? (int)(p - tab) : -1;
 }
 
