@@ -112,7 +112,9 @@ typedef struct ngsq_config {
     const uint8_t *const *ref_bases; /* Edits only: [n_refs] pointers to ref_len[r] bytes of
                                         4-bit BAM base codes (one code per byte, every byte <= 15:
                                         anything else is NGSQ_ERR_INVALID_ARGUMENT), host memory;
-                                        NULL entries => sequence not in FASTA               */
+                                        NULL entries => sequence not in FASTA.  A host that has the
+                                        FASTA as a FILE leaves this NULL, sets ref_bases_deferred and
+                                        calls ngsq_reference_load (ngsq_reference.h)          */
     void *stream;           /* optional hipStream_t to launch on; NULL -> library creates one */
     uint32_t timing;        /* 1 -> bracket every kernel with HIP events (ngsq_kernel_timing) */
     uint32_t sorted_input;  /* 1 -> the caller promises coordinate-sorted records over all batches of this
@@ -123,7 +125,13 @@ typedef struct ngsq_config {
     uint32_t cov_head_guard; /* sorted_input shards other than the first of a file: number of positions
                                after this context's first record on a sequence that records of the shard
                                in front may still cover (kept on the exchanged depth array); 0 = none      */
-    uint32_t reserved;
+    uint32_t ref_bases_deferred; /* 1 -> Edits state and room for the bases of EVERY sequence; the bases come from
+                               ngsq_reference_load (ngsq_reference.h), which ngsq_process_batch waits for        */
+    const uint32_t *ref_bases_len; /* optional, with ref_bases: [n_refs] bases the FASTA holds of each sequence when that
+                               differs from ref_len (the reference slices the FASTA's sequence, edits.rs:257-261: a read
+                               that runs past ITS end fails, counted as edits_bad_reference; bases beyond ref_len are never
+                               looked at).  ref_bases[r] then points to min(ref_bases_len[r], ref_len[r]) bytes.  NULL =
+                               every sequence has ref_len bases                                                   */
 } ngsq_config;
 
 /*

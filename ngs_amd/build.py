@@ -13,8 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libngsq.so")
 SOURCES = ["kernels.hip", "qual_kernel.hip", "fields_kernel.hip", "cov_scan.hip", "cov_stream.hip", "synth.hip", "bgzf_inflate.hip",
-           "bam_device.hip", "features_kernel.hip", "edits_kernel.hip", "exchange_kernels.hip", "comm.cpp", "exchange.cpp", "mem_pool.cpp", "context.cpp", "stager.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp"]
-HEADERS = ["kernels.h", "context.h", "comm.h", "mem_pool.h", "ingest_kernels.h", "bgzf.h", "../../include/ngsq.h", "../../include/ngsq_comm.h",
+           "bam_device.hip", "features_kernel.hip", "edits_kernel.hip", "exchange_kernels.hip", "comm.cpp", "exchange.cpp", "mem_pool.cpp", "context.cpp", "stager.cpp", "results.cpp", "bam_reader.cpp", "bam_device_reader.cpp", "synth_bam.cpp",
+           "reference.cpp", "reference_kernels.hip"]
+HEADERS = ["kernels.h", "context.h", "comm.h", "mem_pool.h", "ingest_kernels.h", "bgzf.h", "reference_kernels.h", "../../include/ngsq.h",
+           "../../include/ngsq_reference.h", "../../include/ngsq_comm.h",
            "../../include/ngsq_shared.h", "../../include/ngsq_synth.h", "../../include/ngsq_bam.h", "../../include/ngsq_stage.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-gpu-rdc"]
 FLAGS += os.environ.get("NGSQ_EXTRA_FLAGS", "").split()  # measurement builds, e.g. -DNGSQ_INFLATE_PROFILE (use --force)
@@ -42,11 +44,12 @@ CLI_OUT = os.path.join(HERE, "ngs")
 
 def build_cli(force: bool = False, verbose: bool = True) -> str:
     """The `ngs qc` command line (host C++ only), linked against libngsq.so next to it."""
-    deps = [CLI_SRC, OUT, os.path.join(HERE, "..", "include", "ngsq.h"), os.path.join(HERE, "..", "include", "ngsq_bam.h")]
+    deps = [CLI_SRC, OUT, os.path.join(HERE, "..", "include", "ngsq.h"), os.path.join(HERE, "..", "include", "ngsq_bam.h"),
+            os.path.join(HERE, "..", "include", "ngsq_reference.h"), os.path.join(CSRC, "cli", "gff_loader.h")]
     if not force and os.path.exists(CLI_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(CLI_OUT) for d in deps):
         return CLI_OUT
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", CLI_SRC, "-L" + HERE, "-lngsq", "-Wl,-rpath,$ORIGIN",
-           "-Wl,-rpath-link," + "/opt/rocm/lib", "-lz", "-o", CLI_OUT + ".tmp"]
+           "-Wl,-rpath-link," + "/opt/rocm/lib", "-lz", "-lpthread", "-o", CLI_OUT + ".tmp"]
     if verbose:
         print("[ngs_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -39,6 +39,8 @@
 #include "../../../include/ngsq_bam.h"
 #include "../../../include/ngsq_stage.h"
 #include "../../../include/ngsq_comm.h"
+#include "../../../include/ngsq_reference.h"
+#include "gff_loader.h"
 
 namespace {
 
@@ -152,39 +154,6 @@ bool load_genome(const std::string &want, Genome *g, std::string *supported) {
     return false;
 }
 
-// ---- FASTA (Edits facet, edits.rs:185-205): name -> 4-bit BAM base codes, one per byte
-int base_code(char c) {
-    static const char tab[] = "=ACMGRSVTWYHKDBN";
-    if (c >= 'a' && c <= 'z') c = (char)(c - 32); // [N9]: Base::try_from folds case (oracle/oracle.h): soft-masked FASTA is the norm
-    const char *p = (const char *)memchr(tab, c, 16);
-    return p ? (int)(p - tab) : -1;
-}
-
-std::map<std::string, std::vector<uint8_t>> read_fasta(const std::string &path) {
-    std::ifstream f(path);
-    if (!f) bail("opening reference FASTA file: " + path);
-    std::map<std::string, std::vector<uint8_t>> out;
-    std::string line, name;
-    std::vector<uint8_t> *cur = nullptr;
-    while (std::getline(f, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
-        if (line[0] == '>') {
-            const size_t sp = line.find_first_of(" \t");
-            name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-            cur = &out[name];
-            continue;
-        }
-        if (!cur) bail("invalid FASTA: sequence data before the first definition line");
-        for (char c : line) {
-            const int code = base_code(c);
-            if (code < 0) bail(std::string("invalid base in reference FASTA sequence ") + name + ": '" + c + "'");
-            cur->push_back((uint8_t)code);
-        }
-    }
-    return out;
-}
-
 // a record's number of CIGAR operations: the 16-bit column saturates at 65535, the offsets then hold the count (include/ngsq.h)
 static inline uint64_t n_ops_of(const ngsq_batch &b, uint64_t i) {
     return b.cigar_off ? b.cigar_off[i + 1] - b.cigar_off[i] : b.n_cigar[i];
@@ -228,14 +197,7 @@ bool query_yields(const ngsq_batch &b, uint64_t i, const std::vector<uint32_t> &
     return e != 0 && s <= ref_len[r];
 }
 
-// ---- Genomic Features gene model: GenomicFeaturesFacet::try_from (features.rs:270-355) ----------
-struct GeneModel {
-    std::vector<uint32_t> ref, name, start, stop;
-    uint32_t role_name[5] = {0, 1, 2, 3, 4};
-};
-
-// formats/gff.rs:19-47 (open by extension) + noodles-gff records(): nine tab-separated columns,
-// '#' lines are comments/directives, "##FASTA" ends the records.
+// (the gene model of the Genomic Features facet: gff_loader.h)
 // utils/formats.rs:117-186  BioinformaticsFileFormat::try_detect, with the names its Display prints (:79-101).
 // "" = no format (the callers then report the extension).  `.gz` / `.bgz` look at the whole name, case-sensitively,
 // the other extensions are matched case-insensitively -- as the reference does.
@@ -268,86 +230,6 @@ std::string detect_format(const std::string &path) {
     for (const auto &t : table)
         if (ext == t.ext) return t.name;
     return "";
-}
-
-GeneModel load_gff(const std::string &path, const std::string (&feature_name)[5], const std::set<std::string> &primary,
-                   const std::map<std::string, uint32_t> &ref_index) {
-    const size_t dot = path.rfind('.');
-    const std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
-    const std::string format = detect_format(path); // utils/formats/gff.rs:19-47
-    if (format.empty()) bail("opening GFF file: " + path + ": Not able to determine filetype for extension: " + ext);
-    if (format != "GFF" && format != "Gzipped GFF")
-        bail("opening GFF file: " + path + ": incompatible formats: required GFF, found " + format);
-    gzFile f = gzopen(path.c_str(), "rb"); // reads plain text as well
-    if (!f) bail("opening GFF file: " + path + ": No such file or directory (os error 2)");
-    GeneModel m;
-    // roles that are configured with the same name are one name (the reference compares strings)
-    for (int k = 0; k < 5; k++)
-        for (int q = 0; q <= k; q++)
-            if (feature_name[q] == feature_name[k]) {
-                m.role_name[k] = (uint32_t)q;
-                break;
-            }
-    logf(3, "Reading all records in GFF.");
-    std::string line;
-    char buf[1 << 16];
-    unsigned long long line_no = 0;
-    bool more = true;
-    while (more) {
-        line.clear();
-        for (;;) { // one line of any length
-            if (!gzgets(f, buf, sizeof buf)) {
-                more = false;
-                break;
-            }
-            line += buf;
-            if (!line.empty() && line.back() == '\n') break;
-        }
-        if (line.empty()) break;
-        line_no++;
-        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-        if (line.empty()) continue;
-        if (line[0] == '#') {
-            if (line.compare(0, 7, "##FASTA") == 0) break;
-            continue;
-        }
-        std::vector<std::string> col;
-        size_t p = 0;
-        for (;;) {
-            const size_t t = line.find('\t', p);
-            col.push_back(line.substr(p, t == std::string::npos ? std::string::npos : t - p));
-            if (t == std::string::npos) break;
-            p = t + 1;
-        }
-        char *e1 = nullptr, *e2 = nullptr;
-        const unsigned long long start = col.size() >= 5 ? strtoull(col[3].c_str(), &e1, 10) : 0;
-        const unsigned long long stop = col.size() >= 5 ? strtoull(col[4].c_str(), &e2, 10) : 0;
-        if (col.size() != 9 || col[3].empty() || col[4].empty() || *e1 || *e2 || start == 0 || stop < start ||
-            stop > 0xFFFFFFFFull) {
-            gzclose(f);
-            bail("invalid GFF record on line " + std::to_string(line_no) + " of " + path); // result.unwrap(): features.rs:291
-        }
-        if (!primary.count(col[0])) continue; // :300-304 only primary-assembly sequences get interval stores
-        // :310-312: the strand of EVERY record on a primary sequence is parsed, '+' or '-' only
-        if (col[6] != "+" && col[6] != "-") {
-            gzclose(f);
-            bail("attempted to parse strand from value: " + col[6]);
-        }
-        int name = -1;
-        for (int k = 0; k < 5 && name < 0; k++)
-            if (col[2] == feature_name[k]) name = (int)m.role_name[k];
-        if (name < 0) continue;
-        const auto it = ref_index.find(col[0]);
-        if (it == ref_index.end()) continue; // a primary sequence this BAM does not have: never looked up
-        m.ref.push_back(it->second);
-        m.name.push_back((uint32_t)name);
-        m.start.push_back((uint32_t)start);
-        m.stop.push_back((uint32_t)stop);
-    }
-    gzclose(f);
-    logf(3, "Tabulating GFF features.");
-    logf(3, "Finalizing GFF features lookup.");
-    return m;
 }
 
 struct Args {
@@ -608,13 +490,63 @@ int main(int argc, char **argv) {
     uint32_t facets = NGSQ_FACET_GENERAL | NGSQ_FACET_TEMPLATE_LENGTH | NGSQ_FACET_GC_CONTENT | NGSQ_FACET_QUALITY_SCORE |
                       NGSQ_FACET_COVERAGE;
     if (!a.fasta.empty()) facets |= NGSQ_FACET_EDITS;
-    // Genomic Features: the gene model is read while the facets are built (qc.rs:68-79), before --only
+    // Genomic Features: the gene model is read while the facets are built (qc.rs:68-79), before --only.  Here it is read by
+    // threads of its own (gff_loader.h) WHILE the device is initialised below; its errors are reported where the reference
+    // reports them -- before anything of the scan happens.
     GeneModel model;
+    std::thread gff_thread;
     if (!a.gff.empty()) {
-        std::map<std::string, uint32_t> ref_index;
-        for (uint32_t r = 0; r < n_refs; r++) ref_index[names[r]] = r;
-        model = load_gff(a.gff, a.feature_name, genome.primary, ref_index);
+        const size_t dot = a.gff.rfind('.');
+        const std::string ext = dot == std::string::npos ? "" : a.gff.substr(dot + 1);
+        const std::string format = detect_format(a.gff); // utils/formats/gff.rs:19-47
+        if (format.empty()) bail("opening GFF file: " + a.gff + ": Not able to determine filetype for extension: " + ext);
+        if (format != "GFF" && format != "Gzipped GFF") bail("opening GFF file: " + a.gff + ": incompatible formats: required GFF, found " + format);
+        {
+            struct stat st;
+            if (stat(a.gff.c_str(), &st) != 0) bail("opening GFF file: " + a.gff + ": No such file or directory (os error 2)");
+        }
+        logf(3, "Reading all records in GFF.");
+        const bool gz = format == "Gzipped GFF";
+        const int nt = std::max(1, std::min(8, cgroup_cores() - 2));
+        gff_thread = std::thread([&model, &a, &genome, &names, n_refs, gz, nt] {
+            std::map<std::string, uint32_t> ref_index;
+            for (uint32_t r = 0; r < n_refs; r++) ref_index[names[r]] = r;
+            model = load_gff_parallel(a.gff, gz, a.feature_name, genome.primary, ref_index, nt);
+        });
         facets |= NGSQ_FACET_FEATURES;
+    }
+    auto gff_ready = [&]() { // (at most once)
+        if (!gff_thread.joinable()) return;
+        gff_thread.join();
+        if (!model.error.empty()) bail(model.error);
+        logf(3, "Tabulating GFF features.");
+        logf(3, "Finalizing GFF features lookup.");
+        if (getenv("NGSQ_INGEST_TRACE") && atoi(getenv("NGSQ_INGEST_TRACE")))
+            fprintf(stderr, "[ngs] gene model: %.1f MB of GFF, %llu lines, %zu intervals kept, %.1f ms on its threads\n", model.text_bytes / 1e6,
+                    (unsigned long long)model.lines, model.ref.size(), model.seconds * 1e3);
+    };
+    // EditsFacet::try_from (edits.rs:120-151): the FASTA is opened once "to make sure that all is well" -- formats::fasta::open
+    // (utils/formats/fasta.rs:15-41) decides by the extension -- and the VAF file is created, both before --only filters the
+    // facets.  Opening it HERE also starts the index of its definition lines on threads of the library (include/ngsq_reference.h),
+    // beside the gene model and the device's initialisation.
+    ngsq_fasta *fasta = nullptr;
+    if (!a.fasta.empty()) {
+        const size_t dot = a.fasta.rfind('.');
+        const std::string ext = dot == std::string::npos ? "" : a.fasta.substr(dot + 1);
+        const std::string format = detect_format(a.fasta);
+        const std::string ctxt = "opening reference FASTA file: " + a.fasta + ": ";
+        if (format == "Gzipped FASTA") bail(ctxt + "This command does not yet support gzipped FASTA files. Please unzip your FASTA file and try again.");
+        if (format.empty()) bail(ctxt + "Not able to determine filetype for extension: " + ext);
+        if (format != "FASTA") bail(ctxt + "incompatible formats: required FASTA, found " + format);
+        // (a sharded run's workers share the cores: a FASTA thread or two each)
+        if (ngsq_fasta_open(a.fasta.c_str(), worker ? std::max(1, std::min(4, cgroup_cores() / std::max(1, a.world) - 1)) : 0, &fasta) != NGSQ_OK)
+            bail(ctxt + ngsq_fasta_last_error());
+    }
+    const bool want_vaf = !a.fasta.empty() && !a.vaf.empty() && (a.world <= 1 || a.rank == 0); // one writer in a --gpus run
+    if (want_vaf) {
+        struct stat st;
+        if (stat(a.vaf.c_str(), &st) == 0)
+            bail("refusing to overwrite existing VAF file: " + a.vaf + ". Please delete and rerun if you'd like to replace it.");
     }
     if (a.has_only) {
         uint32_t sel = 0;
@@ -624,31 +556,41 @@ int main(int argc, char **argv) {
                 sel |= bit;
                 matched++;
             }
-        if (matched == 0) bail("No facets matched the specified `--only` flag: " + a.only);
+        if (matched == 0) {
+            gff_ready(); // (the reference has read the GFF by now: its errors come first)
+            bail("No facets matched the specified `--only` flag: " + a.only);
+        }
         facets = sel;
     }
-    std::map<std::string, std::vector<uint8_t>> fasta;
-    std::vector<const uint8_t *> bases(n_refs, nullptr);
-    if (facets & NGSQ_FACET_EDITS) {
-        fasta = read_fasta(a.fasta);
-        for (uint32_t r = 0; r < n_refs; r++) { // EditsFacet::setup runs for every sequence (edits.rs:173-209)
-            auto it = fasta.find(names[r]);
-            if (it == fasta.end()) bail("sequence " + names[r] + " not found in reference FASTA.");
-            if (it->second.size() != ref_len[r])
-                bail("sequence " + names[r] + " has a different length in the reference FASTA");
-            bases[r] = it->second.data();
-        }
-    }
-    // EditsFacet::try_from (edits.rs:134-151) creates the VAF file while the facets are built -- before
-    // --only filters them -- and refuses to overwrite one
     FILE *vaf_file = nullptr;
-    if (!a.fasta.empty() && !a.vaf.empty() && (a.world <= 1 || a.rank == 0)) { // one writer in a --gpus run
+    // which sequences' bases this process needs: all of them -- or, for a worker of a --gpus run, the sequences whose records
+    // its byte range of the (sorted, indexed) file can hold; the others are never uploaded (N workers do not read the FASTA N times)
+    std::vector<uint8_t> ref_wanted;
+    if ((facets & NGSQ_FACET_EDITS) && worker && !a.has_n) {
+        std::vector<uint64_t> ref_start(n_refs, 0);
+        uint64_t index_bins = 0;
         struct stat st;
-        if (stat(a.vaf.c_str(), &st) == 0)
-            bail("refusing to overwrite existing VAF file: " + a.vaf + ". Please delete and rerun if you'd like to replace it.");
-        vaf_file = fopen(a.vaf.c_str(), "wb");
-        if (!vaf_file) bail("creating VAF file");
-        fputs("Sequence\tPosition\tVAF\n", vaf_file);
+        if (ngsq_bam_index_ref_starts(a.src.c_str(), n_refs, ref_start.data(), &index_bins) == NGSQ_OK && index_bins > 0 && stat(a.src.c_str(), &st) == 0) {
+            const uint64_t size = (uint64_t)st.st_size, margin = (uint64_t)20 << 20; // (the reader goes on 17 MiB behind its range for its last record)
+            const uint64_t lo = size / (uint64_t)a.world * (uint64_t)a.rank, hi = a.rank + 1 == a.world ? size : size / (uint64_t)a.world * (uint64_t)(a.rank + 1) + margin;
+            ref_wanted.assign(n_refs, 0);
+            int64_t prev = -1; // the last sequence in front with records
+            for (uint32_t r = 0; r < n_refs; r++) {
+                if (!ref_start[r]) continue;
+                const uint64_t begin = ref_start[r] >> 16;
+                uint64_t end = size;
+                for (uint32_t q = r + 1; q < n_refs; q++)
+                    if (ref_start[q]) {
+                        end = (ref_start[q] >> 16) + 65536; // (the block the next sequence starts in may still hold this one's records)
+                        break;
+                    }
+                if (begin < hi && end > lo) {
+                    ref_wanted[r] = 1;
+                    if (prev >= 0) ref_wanted[(size_t)prev] = 1; // (and its neighbour in front, for good measure)
+                }
+                prev = r;
+            }
+        }
     }
 
     ngsq_config cfg;
@@ -664,7 +606,8 @@ int main(int argc, char **argv) {
     cfg.cov_cap = 2048;    // coverage.rs:76
     cfg.max_read_len = 256; // where the quality table starts: it grows with the longest read of the file
     cfg.gc_seed = a.gc_seed;
-    cfg.ref_bases = (facets & NGSQ_FACET_EDITS) ? bases.data() : nullptr;
+    cfg.ref_bases = nullptr;
+    cfg.ref_bases_deferred = (facets & NGSQ_FACET_EDITS) ? 1 : 0; // the bases come from the file: ngsq_reference_load below
     // Coverage while the records stream by (ngsq_config.sorted_input) needs coordinate order.  `ngs qc` only
     // accepts indexed, i.e. sorted, files (formats/bam.rs:86-96); "auto" takes the header's word for it and
     // falls back to the depth arrays when a record turns out to break the order.
@@ -771,6 +714,22 @@ int main(int argc, char **argv) {
     milestone("checks done");
     if (ngsq_create(&cfg, &ctx) != NGSQ_OK) bail(ngsq_last_global_error());
     milestone("context created (HIP initialised)");
+    if (facets & NGSQ_FACET_EDITS) {
+        // EditsFacet::setup for every sequence of the header (edits.rs:177-215), as one pass over the file: the text goes to the
+        // device as it is, on the library's threads, while this thread goes on to the first batches (ngsq_process_batch waits
+        // for it in front of the first Edits kernel only)
+        std::vector<const char *> name_ptrs(n_refs ? n_refs : 1, "");
+        for (uint32_t r = 0; r < n_refs; r++) name_ptrs[r] = names[r].c_str();
+        CHECK(ctx, ngsq_reference_load(ctx, fasta, name_ptrs.data(), ref_wanted.empty() ? nullptr : ref_wanted.data()));
+        milestone("reference load started");
+    }
+    gff_ready();
+    milestone("gene model ready");
+    if (want_vaf && !vaf_file) {
+        vaf_file = fopen(a.vaf.c_str(), "wb");
+        if (!vaf_file) bail("creating VAF file");
+        fputs("Sequence\tPosition\tVAF\n", vaf_file);
+    }
     if (facets & NGSQ_FACET_FEATURES) {
         ngsq_features f;
         memset(&f, 0, sizeof f);
@@ -977,6 +936,15 @@ int main(int argc, char **argv) {
             why = ngsq_comm_last_error(comm);
         } else if (worker && (rc = ngsq_exchange(ctx, comm, nullptr)) != NGSQ_OK) why = ngsq_comm_last_error(comm);
         milestone("records scanned");
+        // (a file without records never asked for the reference: its sequences are looked up all the same, edits.rs:207-209)
+        if (rc == NGSQ_OK && (facets & NGSQ_FACET_EDITS) && (rc = ngsq_reference_wait(ctx)) != NGSQ_OK) why = ngsq_last_error(ctx);
+        if (rc == NGSQ_OK && (facets & NGSQ_FACET_EDITS) && getenv("NGSQ_INGEST_TRACE") && atoi(getenv("NGSQ_INGEST_TRACE"))) {
+            ngsq_reference_stats rs;
+            if (ngsq_reference_get_stats(ctx, &rs) == NGSQ_OK)
+                fprintf(stderr, "[ngs] reference: %.1f MB of FASTA text, %u sequences, %llu bases; index %s %.1f ms (waited %.1f), read + copy %.1f ms, kernels %.1f ms, load %.1f ms\n",
+                        rs.text_bytes / 1e6, rs.sequences, (unsigned long long)rs.bases, ngsq_fasta_index_from_fai(fasta) ? "(.fai)" : "(scan)",
+                        ngsq_fasta_index_seconds(fasta) * 1e3, rs.index_wait_s * 1e3, rs.read_s * 1e3, rs.device_s * 1e3, rs.total_s * 1e3);
+        }
         if (rc == NGSQ_OK && (rc = ngsq_finalize(ctx)) != NGSQ_OK) why = ngsq_last_error(ctx);
         milestone("finalized");
         if (rc == NGSQ_ERR_UNSORTED && a.coverage == 0 && !force_array) {
@@ -1065,6 +1033,7 @@ int main(int argc, char **argv) {
     }
     ngsq_destroy(ctx);
     ngsq_bam_close(bam);
+    ngsq_fasta_close(fasta);
     milestone("context and reader released");
     if (comm) ngsq_comm_destroy(comm);
     return 0;

@@ -219,6 +219,9 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     c->h_counters.assign(c->n_counters, 0);
 
     // ---- per-sequence tables
+    // (ref_bases_deferred: the bases come later, from a file -- ngsq_reference_load; every sequence gets Edits state and room)
+    const bool deferred = (c->cfg.facets & NGSQ_FACET_EDITS) && cfg->ref_bases_deferred && !cfg->ref_bases;
+    c->ref_deferred = deferred;
     std::vector<uint64_t> depth_off(nr, NO_DEPTH), edits_off(nr, NO_DEPTH), bases_off(nr, NO_DEPTH);
     std::vector<uint32_t> first_chunk(nr + 1, 0);
     uint64_t nd = 0, ne = 0, nbases = 0;
@@ -234,7 +237,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         }
         const uint64_t nb = 1 + L / c->cfg.bin_size + (L % c->cfg.bin_size != 0);
         c->bin_off[r + 1] = c->bin_off[r] + ((c->cfg.facets & NGSQ_FACET_COVERAGE) && c->primary[r] ? nb : 0);
-        if ((c->cfg.facets & NGSQ_FACET_EDITS) && cfg->ref_bases && cfg->ref_bases[r]) {
+        if ((c->cfg.facets & NGSQ_FACET_EDITS) && (deferred || (cfg->ref_bases && cfg->ref_bases[r]))) {
             edits_off[r] = ne;
             ne += round_up(2 * (L + 1), 4);
             bases_off[r] = nbases;
@@ -244,6 +247,8 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
     first_chunk[nr] = (uint32_t)(nd / COV_CHUNK);
     c->depth_off = depth_off;
     c->edits_off = edits_off;
+    c->bases_off = bases_off;
+    c->nbases = nbases;
     // depth block = difference arrays | one sum per chunk | one sum per COV_SUPER chunks
     c->n_diff = nd;
     c->n_chunks = nd / COV_CHUNK;
@@ -335,19 +340,33 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
         c->d_ref_bases = bases;
         uint8_t *codes = nullptr;
         unsigned long long *d_bad = nullptr, h_bad = 0;
-        CTX_TRY(hipMalloc((void **)&codes, max_len + 64));
+        CTX_TRY(hipMalloc((void **)&codes, (deferred ? 0 : max_len) + 64));
         CTX_TRY(hipMalloc((void **)&d_bad, 8));
         CTX_TRY(hipMemsetAsync(d_bad, 0, 8, c->stream));
         uint64_t n_carry = 0;
         c->edits_carry_off.assign(nr, 0);
+        std::vector<uint32_t> have(2 * (size_t)nr, 0); // bases of each sequence: what a read may reach | the fast paths' bound
+        bool lens_differ = false;
         for (uint32_t r = 0; r < nr; r++) {
             if (bases_off[r] == NO_DEPTH) continue;
             const uint64_t L = c->ref_len[r];
-            CTX_TRY(hipMemcpyAsync(codes, cfg->ref_bases[r], L, hipMemcpyHostToDevice, c->stream));
-            CTX_TRY(launch_pack_reference(c->li, codes, L, bases + bases_off[r], bases + nbases + bases_off[r], L / 2 + 1, d_bad, c->stream));
-            CTX_TRY(hipStreamSynchronize(c->stream)); // `codes` is reused (and the host buffer is the caller's)
+            // (ref_bases_len: the FASTA's sequence may be shorter or longer than @SQ LN says -- edits.rs:257-261 slices the FASTA's)
+            const uint64_t have_r = cfg->ref_bases_len && !deferred ? std::min<uint64_t>(cfg->ref_bases_len[r], L) : L;
+            have[r] = have[nr + r] = (uint32_t)have_r;
+            lens_differ = lens_differ || have_r != L;
+            if (!deferred && have_r) {
+                CTX_TRY(hipMemcpyAsync(codes, cfg->ref_bases[r], have_r, hipMemcpyHostToDevice, c->stream));
+                CTX_TRY(launch_pack_reference(c->li, codes, have_r, bases + bases_off[r], bases + nbases + bases_off[r], L / 2 + 1, d_bad, c->stream));
+                CTX_TRY(hipStreamSynchronize(c->stream)); // `codes` is reused (and the host buffer is the caller's)
+            }
             c->edits_carry_off[r] = n_carry;
             n_carry += edits_teardown_carry_words(L + 1);
+        }
+        if (lens_differ) {
+            CTX_TRY(hipMalloc((void **)&c->d_edits_len, have.size() * 4));
+            CTX_TRY(hipMemcpy(c->d_edits_len, have.data(), have.size() * 4, hipMemcpyHostToDevice));
+            st.ref_edits_len = c->d_edits_len;
+            st.ref_fast_len = c->d_edits_len + nr;
         }
         CTX_TRY(hipMemcpy(&h_bad, d_bad, 8, hipMemcpyDeviceToHost));
         (void)hipFree(codes);
@@ -371,6 +390,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
 void ngsq_destroy(ngsq_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    ngsq::reference_abandon(c); // (a reference load still on its way writes into this context's buffers)
     (void)ngsq::pool_trim(); // blocks a finished device ingest left for the next file (mem_pool.h)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_ft_idx);
@@ -391,6 +411,9 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->st.depth);
     (void)hipFree(c->st.edits);
     (void)hipFree(c->d_ref_bases);
+    (void)hipFree(c->d_edits_len);
+    (void)hipFree(c->d_bad_off);
+    (void)hipFree(c->d_bad_pos);
     (void)hipFree(c->d_edits_carry);
     (void)hipFree(c->d_edits_defer);
     (void)hipFree(c->d_ref_len);
@@ -616,6 +639,13 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
         HIP_TRY(c, launch_features(c->li, c->st, db, c->ft, c->stream));
     }
     if (seq_f & NGSQ_FACET_EDITS) {
+        if (c->ref_deferred && !c->ref_ready) {
+            // the reference comes from a file (ngsq_reference_load): everything above has been queued meanwhile; the first Edits
+            // kernel waits for the loader's last kernel (the loader thread synchronises its stream before it reports)
+            if (!c->ref_loader) return fail(c, NGSQ_ERR_STATE, "ngsq_config.ref_bases_deferred is set but ngsq_reference_load was not called");
+            const int rc = reference_join(c);
+            if (rc != NGSQ_OK) return rc;
+        }
         Bracket br(c, K_EDITS, n * 16 + cs.cigar_ops * 4 + cs.seq_bytes);
         const uint64_t words = (n + 63) / 64 + 16;
         if (c->edits_defer_cap < words) {

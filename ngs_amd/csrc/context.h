@@ -39,6 +39,8 @@ struct Staging {
 };
 
 int grow_quality_table(ngsq_ctx *c, uint64_t rows); // context.cpp: at least `rows` cycles in the quality table
+int reference_join(ngsq_ctx *c);                    // reference.cpp: wait for ngsq_reference_load's thread; its verdict
+void reference_abandon(ngsq_ctx *c);                // reference.cpp: ngsq_destroy
 
 } // namespace ngsq
 
@@ -57,6 +59,12 @@ struct ngsq_ctx {
     uint32_t *d_ref_len = nullptr;
     uint64_t *d_depth_off = nullptr, *d_edits_off = nullptr, *d_bases_off = nullptr;
     uint8_t *d_ref_bases = nullptr;      // both packed copies of the reference (Edits)
+    std::vector<uint64_t> bases_off;     // byte offset of each sequence in either copy (NO_DEPTH: none)
+    uint64_t nbases = 0;                 // bytes of one copy
+    uint32_t *d_edits_len = nullptr;     // [2 n_refs] st.ref_edits_len | st.ref_fast_len (null: ref_len everywhere)
+    uint32_t *d_bad_off = nullptr, *d_bad_pos = nullptr; // st.ref_bad_off / _pos
+    void *ref_loader = nullptr;          // reference.cpp: the thread of ngsq_reference_load and what it reports
+    bool ref_deferred = false, ref_ready = false;
     // Edits teardown: per sequence the carry of every 4096-entry chunk of its difference array, and which chunks have been
     // turned into refs so far ([lo, hi); a sharded run converts a slice per rank, ngsq_get_edits_positions the rest)
     uint32_t *d_edits_carry = nullptr;

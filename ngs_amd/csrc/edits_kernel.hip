@@ -103,7 +103,20 @@ __device__ __forceinline__ uint32_t ed_walk_record(const DeviceState &st, const 
     const uint64_t s = (uint64_t)pos + 1, e = s + span - 1;
     if (e == 0 || s > L || (f & 0x404u)) return 0; // not yielded by query(); unmapped | duplicate (edits.rs:227-229)
     const uint64_t boff = st.ref_bases_off[ref];
-    if (boff == NO_DEPTH || e > L) return 1; // edits.rs:245-261: no such sequence in the FASTA / slice out of range
+    // edits.rs:245-261: no such sequence in the FASTA / the slice start..start+span runs past the FASTA's sequence (its own
+    // length, which need not be @SQ LN: ref_edits_len) or past LN (the per-position histograms end there) ...
+    if (boff == NO_DEPTH || e > (st.ref_edits_len ? (uint64_t)st.ref_edits_len[ref] : L)) return 1;
+    if (st.ref_bad_off) { // ... or holds a byte Base::try_from refuses (edits.rs:257-261 `?` on the collected Result)
+        uint32_t lo = st.ref_bad_off[ref];
+        const uint32_t hi0 = st.ref_bad_off[ref + 1];
+        uint32_t hi = hi0;
+        while (lo < hi) { // first listed position >= s
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)st.ref_bad_pos[mid] < s) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < hi0 && (uint64_t)st.ref_bad_pos[lo] <= e) return 1;
+    }
     uint32_t *const diff = st.edits + st.ref_edits_off[ref]; // entry p - 1 <-> position p (the slot that holds refs after the teardown)
     uint32_t *const alts = diff + (L + 1);
     const uint8_t *const sq = b.seq + (b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride);
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(ED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // facts of the sequence the wave's window is anchored on (reloaded only when it changes: scalar registers)
     int32_t meta_ref = -1;
     uint64_t meta_eoff = NO_DEPTH, meta_boff = NO_DEPTH;
-    uint32_t meta_L = 0;
+    uint32_t meta_L = 0, meta_E = 0; // @SQ LN; what the fast path may reach (the FASTA's bases of the sequence: st.ref_fast_len)
 
     auto tally = [&](uint32_t edits, bool first) { // edits.rs:296-300
         if (edits < ED_HIST) atomicAdd(first ? &s_h1[edits] : &s_h2[edits], 1u);
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(ED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             }
             const uint64_t s = (uint64_t)r.pos + 1, e = s + m + gap + m2 - 1; // 1-based first and last position
             const uint64_t i0 = (uint64_t)(uint32_t)r.pos - win_base, i1 = i0 + m; // the first M's entries of the difference array in the window
-            const bool fast = shape && m && (uint64_t)a + m + z == r.l && r.ref == win_ref && (uint32_t)r.pos >= a + ins && e <= meta_L &&
+            const bool fast = shape && m && (uint64_t)a + m + z == r.l && r.ref == win_ref && (uint32_t)r.pos >= a + ins && e <= meta_E &&
                               (uint32_t)r.pos >= win_base && i1 < ED_WINDOW && r.l < (1u << 16);
             if (!fast) return true;
             const uint64_t i = w0 + (uint64_t)pass * 64 + lane;
@@ -350,11 +363,12 @@ __global__ __launch_bounds__(ED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
                 if (fr != meta_ref) {
                     const uint64_t eo = st.ref_edits_off[fr], bo = st.ref_bases_off[fr];
-                    const uint32_t l = st.ref_len[fr];
+                    const uint32_t l = st.ref_len[fr], fl = st.ref_fast_len ? st.ref_fast_len[fr] : l;
                     meta_ref = fr;
                     meta_eoff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(eo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)eo);
                     meta_boff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bo);
                     meta_L = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+                    meta_E = (uint32_t)__builtin_amdgcn_readfirstlane((int)fl);
                 }
                 if (meta_boff != NO_DEPTH) {
                     win_ref = fr;
@@ -530,7 +544,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
 
     int32_t meta_ref = -1;
     uint64_t meta_eoff = NO_DEPTH, meta_boff = NO_DEPTH;
-    uint32_t meta_L = 0;
+    uint32_t meta_L = 0, meta_E = 0; // @SQ LN; what the fast path may reach (the FASTA's bases of the sequence: st.ref_fast_len)
 
     const uint32_t stride = b.seq_stride;
     const uint32_t odd_delta = (uint32_t)(st.ref_bases_odd - st.ref_bases); // (both copies lie inside 4 GiB: launch_edits)
@@ -703,11 +717,12 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                     if (fr >= 0 && (uint32_t)fr < st.n_refs && fp >= 0) {
                         if (fr != meta_ref) {
                             const uint64_t eo = st.ref_edits_off[fr], bo = st.ref_bases_off[fr];
-                            const uint32_t l = st.ref_len[fr];
+                            const uint32_t l = st.ref_len[fr], fl = st.ref_fast_len ? st.ref_fast_len[fr] : l;
                             meta_ref = fr;
                             meta_eoff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(eo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)eo);
                             meta_boff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bo);
                             meta_L = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+                            meta_E = (uint32_t)__builtin_amdgcn_readfirstlane((int)fl);
                         }
                         if (meta_boff != NO_DEPTH) {
                             win_ref = fr;
@@ -813,7 +828,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 // (P >= win_base: a mismatch's window entry is counted from P's)
                 // (RAGGED: the record's bytes hold its bases, at most EDG_MAXW windows of them, within 4 GiB of the pass's first byte)
                 const bool holds = RAGGED ? ((r.l + 1u) >> 1) <= r.sb && r.sb <= 16u * EDG_MAXW - 1u && r.so - so0 < 0xFFFF0000ull : r.l <= 2 * stride;
-                own = shape && m && (uint64_t)a + m + z == r.l && holds && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_L && i0 + m < WIN;
+                own = shape && m && (uint64_t)a + m + z == r.l && holds && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_E && i0 + m < WIN;
                 if (own) {
                     // the record's descriptor for the window lanes: where its base 0 lies in the packed reference (a byte offset
                     // from ref_bases: the copy that starts at base P & 1), compared bases [v0, v1), window entry of base 0

@@ -85,7 +85,8 @@ class Config(C.Structure):
         ("timing", C.c_uint32),
         ("sorted_input", C.c_uint32),
         ("cov_head_guard", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("ref_bases_deferred", C.c_uint32),
+        ("ref_bases_len", u32p),
     ]
 
 
@@ -261,6 +262,14 @@ class ShardState(C.Structure):
 
 comm_p = C.c_void_p
 
+
+class ReferenceStats(C.Structure):
+    """ngsq_reference_stats (include/ngsq_reference.h)"""
+    _fields_ = [("text_bytes", C.c_uint64), ("bases", C.c_uint64), ("invalid_bytes", C.c_uint64), ("sequences", C.c_uint32),
+                ("shorter", C.c_uint32), ("longer", C.c_uint32), ("reserved", C.c_uint32), ("index_wait_s", C.c_double),
+                ("read_s", C.c_double), ("device_s", C.c_double), ("total_s", C.c_double)]
+
+
 # name -> (restype, argtypes): every symbol include/ngsq.h and include/ngsq_synth.h declare
 PROTOTYPES = {
     "ngsq_abi_version": (C.c_uint32, []),
@@ -315,6 +324,19 @@ PROTOTYPES = {
     "ngsq_host_malloc_pinned": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
     "ngsq_host_free_pinned": (C.c_int, [C.c_void_p]),
     "ngsq_gc_offset": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint32]),
+    # include/ngsq_reference.h
+    "ngsq_fasta_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "ngsq_fasta_close": (None, [C.c_void_p]),
+    "ngsq_fasta_last_error": (C.c_char_p, []),
+    "ngsq_fasta_n_records": (C.c_int64, [C.c_void_p]),
+    "ngsq_fasta_record_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "ngsq_fasta_record_text_bytes": (C.c_uint64, [C.c_void_p, C.c_uint32]),
+    "ngsq_fasta_index_seconds": (C.c_double, [C.c_void_p]),
+    "ngsq_fasta_index_from_fai": (C.c_int, [C.c_void_p]),
+    "ngsq_fasta_base_code": (C.c_int, [C.c_uint8]),
+    "ngsq_reference_load": (C.c_int, [ctx_p, C.c_void_p, C.POINTER(C.c_char_p), u8p]),
+    "ngsq_reference_wait": (C.c_int, [ctx_p]),
+    "ngsq_reference_get_stats": (C.c_int, [ctx_p, C.POINTER(ReferenceStats)]),
     "ngsq_synth_sizes": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, u64p, u64p, u64p]),
     "ngsq_synth_fill_host": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
     "ngsq_synth_fill_reference": (C.c_int, [C.POINTER(SynthConfig), C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]),

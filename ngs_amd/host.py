@@ -180,7 +180,10 @@ class QcContext:
                  facets: int = ffi.FACETS_DEFAULT, device: int = 0, bin_size: int = 0, tlen_cap: int = 0,
                  cov_cap: int = 0, max_read_len: int = 0, gc_seed: int = 0,
                  ref_bases: Optional[Sequence[Optional[np.ndarray]]] = None, stream: int = 0,
-                 timing: bool = False, sorted_input: bool = False, cov_head_guard: int = 0, lib=None):
+                 timing: bool = False, sorted_input: bool = False, cov_head_guard: int = 0, lib=None,
+                 ref_bases_len: Optional[Sequence[int]] = None, ref_fasta: Optional[str] = None,
+                 ref_names: Optional[Sequence[str]] = None, ref_wanted: Optional[Sequence[int]] = None, fasta_threads: int = 0):
+        """ref_fasta (+ ref_names): the Edits reference from a FASTA FILE (include/ngsq_reference.h) instead of ref_bases."""
         self.lib = lib or ffi.load_library()
         self._ref_len = np.asarray(ref_len, dtype=np.uint32)
         self._primary = np.asarray(ref_is_primary if ref_is_primary is not None else [1] * len(ref_len),
@@ -206,6 +209,16 @@ class QcContext:
                     arr[r] = a.ctypes.data_as(ffi.u8p)
             self._bases_keep = (arr, keep)
             cfg.ref_bases = arr
+            if ref_bases_len is not None:
+                self._bases_len = np.asarray(ref_bases_len, dtype=np.uint32)
+                cfg.ref_bases_len = self._bases_len.ctypes.data_as(ffi.u32p)
+        self._fasta = None
+        if ref_fasta is not None:
+            assert ref_bases is None and ref_names is not None and len(ref_names) == len(self._ref_len)
+            cfg.ref_bases_deferred = 1
+            self._fasta = C.c_void_p()
+            if self.lib.ngsq_fasta_open(ref_fasta.encode(), fasta_threads, C.byref(self._fasta)) != 0:
+                raise NgsqError(ffi.ERR_INVALID_ARGUMENT, (self.lib.ngsq_fasta_last_error() or b"").decode())
         cfg.stream = stream or None
         cfg.timing = 1 if timing else 0
         cfg.sorted_input = 1 if sorted_input else 0
@@ -215,6 +228,18 @@ class QcContext:
         self._ctx = ffi.ctx_p()
         _check(self.lib.ngsq_create(C.byref(cfg), C.byref(self._ctx)), None, self.lib)
         self._allocs: List[int] = []
+        if self._fasta is not None:
+            names = (C.c_char_p * len(ref_names))(*[n.encode() for n in ref_names])
+            wanted = np.asarray(ref_wanted, dtype=np.uint8) if ref_wanted is not None else None
+            _check(self.lib.ngsq_reference_load(self._ctx, self._fasta, names, wanted.ctypes.data_as(ffi.u8p) if wanted is not None else None),
+                   self._ctx, self.lib)
+
+    def reference_wait(self) -> Dict[str, float]:
+        """Wait for the FASTA load (ngsq_process_batch does so by itself); what it did."""
+        _check(self.lib.ngsq_reference_wait(self._ctx), self._ctx, self.lib)
+        st = ffi.ReferenceStats()
+        _check(self.lib.ngsq_reference_get_stats(self._ctx, C.byref(st)), self._ctx, self.lib)
+        return {k: getattr(st, k) for k, _ in ffi.ReferenceStats._fields_ if k != "reserved"}
 
     # -- lifecycle
     def close(self):
@@ -222,8 +247,11 @@ class QcContext:
             for p in self._allocs:
                 self.lib.ngsq_device_free(self._ctx, p)
             self._allocs = []
-            self.lib.ngsq_destroy(self._ctx)
+            self.lib.ngsq_destroy(self._ctx)   # (waits for a reference load that is still on its way)
             self._ctx = ffi.ctx_p()
+            if getattr(self, "_fasta", None) is not None:
+                self.lib.ngsq_fasta_close(self._fasta)
+                self._fasta = None
 
     def __enter__(self):
         return self

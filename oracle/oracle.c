@@ -56,6 +56,7 @@ struct orc_ctx {
     uint32_t *ref_len;
     uint8_t *ref_is_primary;
     const uint8_t **ref_bases;
+    uint32_t *ref_bases_len; /* NULL: ref_len bases of every sequence */
     /* general/metrics.rs */
     ngsq_general_metrics general;
     double duplication_pct, mapped_pct, mismatch_pct, mismatch_hq_pct;
@@ -119,6 +120,10 @@ orc_ctx *orc_create(const ngsq_config *cfg) {
         c->ref_len[r] = cfg->ref_len[r];
         c->ref_is_primary[r] = cfg->ref_is_primary ? cfg->ref_is_primary[r] : 1;
         c->ref_bases[r] = cfg->ref_bases ? cfg->ref_bases[r] : NULL;
+    }
+    if (cfg->ref_bases && cfg->ref_bases_len) {
+        c->ref_bases_len = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+        for (uint32_t r = 0; r < n; r++) c->ref_bases_len[r] = cfg->ref_bases_len[r];
     }
     orc_hist_init(&c->tlen_hist, c->cfg.tlen_cap); /* template_length.rs:58-67 */
     orc_hist_init(&c->gc_hist, 100);               /* gc_content.rs:129-138 */
@@ -210,6 +215,7 @@ void orc_destroy(orc_ctx *c) {
     free(c->ref_len);
     free(c->ref_is_primary);
     free(c->ref_bases);
+    free(c->ref_bases_len);
     free(c);
 }
 
@@ -596,6 +602,19 @@ static void edits_visit(void *user, uint32_t kind, int has_ref, uint32_t ref_bas
     }
 }
 
+/* [N9] noodles-sam 0.25 record::sequence::Base: `impl TryFrom<u8>` goes through `char::from(n)` to `impl TryFrom<char>`,
+ * which matches `c.to_ascii_uppercase()` against the sixteen letters "=ACMGRSVTWYHKDBN" (the crate's own unit test of that
+ * impl converts 'a' as well as 'A').  edits.rs:257-261 applies it to the FASTA's raw bytes -- noodles-fasta keeps them as
+ * they are in the file, case included.  Returns the 4-bit BAM code, or -1 = TryFromCharError. */
+int orc_fasta_base_code(uint8_t byte) {
+    static const char letters[] = "=ACMGRSVTWYHKDBN";
+    uint8_t c = byte;
+    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 'a' + 'A');
+    for (int k = 0; k < 16; k++)
+        if ((uint8_t)letters[k] == c) return k;
+    return -1;
+}
+
 /* edits.rs:217-303 */
 static void edits_process(orc_ctx *c, const orc_record *r, uint64_t start) {
     /* (1) :227-229 */
@@ -607,10 +626,23 @@ static void edits_process(orc_ctx *c, const orc_record *r, uint64_t start) {
     uint64_t reference_end = reference_start + alignment_span(r);
     /* :245-251 + :257-261  current_sequence.get(start..end) -> [start-1, end-1) */
     const uint8_t *bases = c->ref_bases[ref];
-    if (!bases || reference_end - 1 > (uint64_t)c->ref_len[ref]) {
+    /* the slice is taken from the FASTA's sequence, whose length need not be @SQ LN (ngsq_config.ref_bases_len): `get` is None
+     * -- unwrap panics -- when the read runs past ITS end; a read past LN panics two steps later, in
+     * refs/alts_per_position.increment (:284-291, histograms of LN + 1 bins).  Either way the run aborts here. */
+    uint64_t have = c->ref_len[ref];
+    if (c->ref_bases_len && c->ref_bases_len[ref] < have) have = c->ref_bases_len[ref];
+    if (!bases || reference_end - 1 > have) {
         c->errors.edits_bad_reference += 1;
         return;
     }
+    /* :257-261 [N9] Base::try_from over every byte of the slice, collected into a Result and `?`: ONE byte it refuses (here:
+     * a code above 15, what orc_fasta_base_code's -1 is stored as) fails the record -- whatever CIGAR operation lies over it,
+     * and only records whose slice holds it */
+    for (uint64_t i = reference_start - 1; i < reference_end - 1; i++)
+        if (bases[i] > 15) {
+            c->errors.edits_bad_reference += 1;
+            return;
+        }
     if (!e->refs_per_position[ref].values) { /* setup :211-213 */
         orc_hist_init(&e->refs_per_position[ref], c->ref_len[ref]);
         orc_hist_init(&e->alts_per_position[ref], c->ref_len[ref]);

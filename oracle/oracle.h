@@ -49,8 +49,18 @@
  *            counts C/G, A/T and "other" on them (gc_content.rs:77-87);
  *       [N8] CIGAR op codes 0..8 = MIDNSHP=X; a code above 8 is a decode error
  *            (counted as bad_cigar_op);
- *       [N9] FASTA bases compare as upper-case A C G T N codes (edits.rs:265:
- *            Base::try_from; the synthetic references are upper case);
+ *       [N9] FASTA bytes become bases through Base::try_from(u8) (edits.rs:257-261) and that conversion FOLDS CASE:
+ *            'a' is Base::A.  DECIDED in round 6 (it was "upper case only, unverified" until then, and the command line
+ *            refused lower case).  Grounds: (i) noodles-sam's `impl TryFrom<char> for Base` matches on
+ *            `c.to_ascii_uppercase()` -- restated from the published crate source, which is not in this container;
+ *            (ii) the reference's own code expects lower-case FASTA bytes to reach it: src/generate/utils.rs:96-106
+ *            complements 'a' 'c' 'g' 't' next to 'A' 'C' 'G' 'T' on sequences read with the same noodles-fasta reader;
+ *            (iii) the genome the command's argument is named after, the GRCh38 no-alt analysis set, is soft-masked --
+ *            about half of its bases are lower case -- so the other reading makes `ngs qc -r` fail on line 2 of chr1 of the
+ *            one FASTA it is documented for.  Any other byte (not one of "=ACMGRSVTWYHKDBN" in either case) is a
+ *            TryFromCharError for the record whose slice start..start+span holds it, and for no other record: the
+ *            conversion runs per record over its slice.  orc_fasta_base_code restates the conversion; a refused byte is
+ *            kept in ref_bases as a code above 15 (tests/golden/hand_softmasked.json: worked by hand);
  *      [N10] a CIGAR of more than 65535 operations (SAM specification 4.2.2): the BAM record
  *            holds the placeholder <l_seq>S<reference span>N and the real operations in a CG:B,I
  *            tag, which noodles-bam resolves while decoding the record (as far as can be told
@@ -132,6 +142,9 @@ int orc_stepthrough_edits(const uint8_t *reference, size_t n_reference, const ui
                           size_t n_record, const uint32_t *cigar, size_t n_cigar,
                           uint64_t *edits);
 const char *orc_stepthrough_error_message(int code);
+
+/* [N9] Base::try_from(u8) on a FASTA byte: the 4-bit BAM code, or -1 (the byte is refused) */
+int orc_fasta_base_code(uint8_t byte);
 
 /* timing helper for bench.py's cpu_baseline leg: seconds of CPU work spent in
  * orc_process_batch + orc_finalize since orc_create */

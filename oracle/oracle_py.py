@@ -47,6 +47,8 @@ def load() -> C.CDLL:
     lib.orc_create.restype = P
     lib.orc_create.argtypes = [C.POINTER(ffi.Config)]
     lib.orc_destroy.argtypes = [P]
+    lib.orc_fasta_base_code.restype = C.c_int
+    lib.orc_fasta_base_code.argtypes = [C.c_uint8]
     lib.orc_last_error.restype = C.c_char_p
     lib.orc_last_error.argtypes = [P]
     lib.orc_process_batch.argtypes = [P, C.POINTER(ffi.Batch), C.c_uint32]
@@ -113,7 +115,7 @@ class Oracle:
 
     def __init__(self, ref_len: Sequence[int], ref_is_primary: Optional[Sequence[int]] = None,
                  facets: int = ffi.FACETS_DEFAULT, bin_size: int = 0, tlen_cap: int = 0, cov_cap: int = 0,
-                 max_read_len: int = 0, gc_seed: int = 0, ref_bases=None):
+                 max_read_len: int = 0, gc_seed: int = 0, ref_bases=None, ref_bases_len=None):
         self.lib = load()
         self._ref_len = np.asarray(ref_len, dtype=np.uint32)
         self._primary = np.asarray(ref_is_primary if ref_is_primary is not None else [1] * len(ref_len),
@@ -137,6 +139,10 @@ class Oracle:
                     arr[r] = a.ctypes.data_as(ffi.u8p)
             self._keep.append(arr)
             cfg.ref_bases = arr
+            if ref_bases_len is not None:
+                lens = np.asarray(ref_bases_len, dtype=np.uint32)
+                self._keep.append(lens)
+                cfg.ref_bases_len = lens.ctypes.data_as(ffi.u32p)
         self.max_read_len = max_read_len or 512
         self.tlen_cap = tlen_cap or 1024
         self.cov_cap = cov_cap or 2048
@@ -264,3 +270,11 @@ class Oracle:
 
     def results(self, ref_names: Sequence[str]) -> dict:
         return json.loads(self.results_json(ref_names))
+
+
+def fasta_codes(text: bytes) -> np.ndarray:
+    """One FASTA sequence's bytes (line terminators already removed) as the oracle wants its ref_bases: [N9]
+    orc_fasta_base_code per byte, a refused byte as 0xFF."""
+    lib = load()
+    table = np.array([lib.orc_fasta_base_code(b) & 0xFF for b in range(256)], dtype=np.uint8)
+    return table[np.frombuffer(text, dtype=np.uint8)]

@@ -164,14 +164,76 @@ def ingest_sweep(lib, seeds):
     print("ingest sweep ok")
 
 
+def genome_sweep(lib, seeds):
+    """All seven facets on headers of up to 200 sequences (no seed had more than four): the 195 @SQ lines of the
+    GRCh38 no-alt analysis set with its chromosomes scaled down by a random factor, or a random header of 5-200 sequences of
+    40 bp to 3 Mbp; records on a random subset of the sequences (empty ones in between), raw or clean, sorted (then also
+    streamed Coverage) or not, batches cut anywhere."""
+    from tests import genome_util as gu
+    from tests.util import make_edit_friendly
+    facets = ffi.FACETS_DEFAULT | ffi.FACET_EDITS | ffi.FACET_FEATURES
+    for seed in range(seeds):
+        rng = np.random.default_rng(12000 + seed)
+        if seed % 2 == 0:
+            names, lens, primary = gu.header(int(rng.choice([64, 256, 1024, 4096])))
+        else:
+            nr = int(rng.integers(5, 201))
+            lens = [int(10 ** rng.uniform(1.6, 6.5)) for _ in range(nr)]
+            primary = [int(rng.random() < 0.9) for _ in range(nr)]
+            names = [f"s{i}" for i in range(nr)]
+        nr = len(lens)
+        bases = [rng.choice(np.array([1, 2, 4, 8, 15], dtype=np.uint8), size=L, p=[.24, .24, .24, .24, .04]) for L in lens]
+        live = np.flatnonzero(rng.random(nr) < float(rng.choice([0.1, 0.6, 1.0])))
+        if live.size == 0:
+            live = np.array([int(rng.integers(0, nr))])
+        n = int(rng.integers(1, 50_000))
+        max_len = int(rng.choice([36, 150, 250]))
+        raw = random_batch(rng, n, [lens[r] for r in live], max_len=max_len, min_len=int(rng.integers(0, max_len + 1)), weird=bool(rng.integers(0, 2)))
+        for col in ("ref_id", "mate_ref_id"):
+            a = raw.cols[col]
+            raw.cols[col] = np.where(a >= 0, live[np.clip(a, 0, live.size - 1)], a).astype(np.int32)
+        hb = make_edit_friendly(raw, rng, bases, lens) if rng.random() < 0.6 else raw
+        is_sorted = rng.random() < 0.7
+        if is_sorted:
+            hb = coordinate_sorted(hb)
+        m = int(rng.integers(0, 4000))
+        fr = rng.integers(0, nr, m).astype(np.uint32)
+        fs = np.array([rng.integers(1, lens[r] + 1) for r in fr], dtype=np.uint32)
+        fe = fs + np.where(rng.random(m) < 0.1, 0, rng.integers(0, 5000, m)).astype(np.uint32)
+        fn = rng.choice(5, m).astype(np.uint32)
+        kw = dict(facets=facets, bin_size=int(rng.choice([1000, 50_000])), max_read_len=320, gc_seed=seed, ref_bases=bases)
+        orc = oracle_py.Oracle(lens, primary, **kw)
+        orc.set_features(fr, fn, fs, fe)
+        orc.process_batch(hb)
+        rc = orc.finalize(allow_malformed=True)
+        for streamed in ([False, True] if is_sorted else [False]):
+            gpu = host.QcContext(lens, primary, lib=lib, sorted_input=streamed, **kw)
+            gpu.set_features(fr, fn, fs, fe)
+            cuts = sorted(set([0, hb.n] + [int(x) for x in rng.integers(0, hb.n + 1, 3)]))
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                part = take_records(hb, np.arange(lo, hi))
+                part.first_record_index = lo
+                gpu.process_batch(gpu.upload(part) if rng.random() < 0.5 else part)
+            assert gpu.finalize(allow_malformed=True) == rc
+            compare_contexts(gpu, orc, nr, facets, kw["bin_size"], lens)
+            json_equal(gpu.results(names), orc.results(names))
+            gpu.close()
+        print(f"genome seed {seed}: refs={nr} ({'GRCh38 names' if seed % 2 == 0 else 'random'}) total={sum(lens)} live={live.size} n={n} "
+              f"sorted={is_sorted} errors={sum(orc.error_counts().values())} ok", flush=True)
+    print("genome sweep ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=int, default=0, help="seeds of the many-sequences sweep (all seven facets, up to 200 @SQ)")
     ap.add_argument("--extra", type=int, default=0, help="seeds of the Edits + Genomic Features sweep")
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--sorted", type=int, default=0, help="seeds of the sorted_input (streaming Coverage) sweep")
     ap.add_argument("--ingest", type=int, default=0, help="seeds of the device-reader-against-host-reader sweep")
     a = ap.parse_args()
     lib = ffi.load_library()
+    if a.genome:
+        genome_sweep(lib, a.genome)
     if a.sorted:
         sorted_sweep(lib, a.sorted)
     if a.extra:
