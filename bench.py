@@ -95,6 +95,9 @@ def parse_args():
                     help="N = 1: records of the all-seven-facets pass (Edits with the reference in HBM, Genomic Features with a gene model) "
                          "timed beside the headline one (0 = skip)")
     ap.add_argument("--all-facets-steps", type=int, default=15)
+    ap.add_argument("--whole-genome-records", type=int, default=100_000_000,
+                    help="N = 1: records of the whole_genome leg -- the 195-sequence GRCh38 header at full length, records on all of it (0 = skip)")
+    ap.add_argument("--whole-genome-steps", type=int, default=7)
     ap.add_argument("--live-traffic", type=int, default=1,
                     help="1 (N = 1, default workload): two short passes of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE -- "
                          "separate passes, child processes started before this one touches HIP) give roofline.traffic of THIS run; "
@@ -488,6 +491,8 @@ def main() -> int:
                 out["extra_facets"] = guarded(leg_extra_facets, lib, host, ffi, np, args.extra_facet_records)
             if args.all_facets_records > 0 and not mixed and args.facets == 0x1F:
                 out["all_facets"] = guarded(leg_all_facets, lib, host, ffi, np, args, device)
+            if args.whole_genome_records > 0 and not mixed and args.facets == 0x1F:
+                out["whole_genome"] = guarded(leg_whole_genome, lib, host, ffi, np, args, device)
         elif world > 1 and args.file_records > 0 and not mixed and not args.emulate_shard:
             # the number the metric is named after, on N GPUs: ONE BAM file scanned by `ngs qc --gpus N` (the other ranks
             # of this launch have released their devices and are on their way out)
@@ -1436,6 +1441,124 @@ def leg_all_facets(lib, host, ffi, np, args, device):
         if db is not None:
             ctx.free_batch(db)
         ctx.close()
+
+
+def leg_whole_genome(lib, host, ffi, np, args, device):
+    """The header `ngs qc` meets in practice -- the 195 @SQ of the GRCh38 no-alt analysis set at their real lengths (3.1 Gbp; the
+    reference loops over every one of them: command.rs:258-272,356) -- with the records spread over all of it (GENOME mode of the
+    synthetic generator).  Until round 6 every leg had chr1 + chr2.  Reported: what 3.1 Gbp of Coverage and Edits state cost to
+    create, reset and tear down, ms per pass of the default facets (streamed Coverage and depth arrays) and of all seven, the
+    launches of one finalize, and full-size invariants in place of the oracle."""
+    from ngs_amd.genome_shape import grch38_no_alt
+    names, lens, primary = grch38_no_alt()
+    n = args.whole_genome_records
+    G = int(sum(lens))
+    scfg = host.synth_config(n, read_len=args.read_len, genome=lens, seq_model=ffi.SYNTH_SEQ_FROM_REFERENCE, lib=lib)
+    out = {"workload": "%d M synthetic %d bp reads over the 195 sequences of the GRCh38 no-alt analysis set (%.2f Gbp; the 169 contigs' "
+                       "lengths are stand-ins in the real range: ngs_amd/genome_shape.py)" % (n // 1_000_000, args.read_len, G / 1e9),
+           "sequences": len(lens), "primary": int(sum(primary)), "depth": round(n * args.read_len / G, 2)}
+    seen_primary = None
+    db = None
+    keep = None   # the context the batch's columns live in
+    try:
+        for label, kw in (("default_streamed", dict(facets=0x1F, sorted_input=True)), ("default_arrays", dict(facets=0x1F, sorted_input=False)),
+                          ("all_seven_streamed", dict(facets=0x7F, sorted_input=True))):
+            row = {}
+            t0 = time.perf_counter()
+            bases = None
+            if kw["facets"] & ffi.FACET_EDITS:
+                bases = [host.synth_reference(scfg, r, L, lib) for r, L in enumerate(lens)]
+                row["reference_generated_s"] = round(time.perf_counter() - t0, 2)
+                t0 = time.perf_counter()
+            ctx = host.QcContext(lens, primary, device=device, max_read_len=args.read_len, gc_seed=GC_SEED, timing=True, ref_bases=bases, lib=lib, **kw)
+            ctx.synchronize()
+            row["create_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            del bases
+            try:
+                if kw["facets"] & ffi.FACET_FEATURES:
+                    rng = np.random.default_rng(7)
+                    m = 3_000_000   # a GENCODE-sized model: ~3 M rows of the five feature types
+                    fr = rng.integers(0, 24, m).astype(np.uint32)
+                    fs = (rng.random(m) * (np.array(lens, dtype=np.float64)[fr] - 5000)).astype(np.uint32) + 1
+                    ctx.set_features(fr, rng.choice(5, m, p=[.05, .05, .3, .5, .1]).astype(np.uint32), fs, fs + rng.integers(0, 4000, m).astype(np.uint32))
+                if db is None:
+                    t0 = time.perf_counter()
+                    db = ctx.synth_device_batch(scfg, 0, n)
+                    keep = ctx
+                    out["generate_s"] = round(time.perf_counter() - t0, 2)
+
+                def timed(fn):
+                    ctx.synchronize()
+                    t = time.perf_counter()
+                    fn()
+                    ctx.synchronize()
+                    return (time.perf_counter() - t) * 1e3
+                for _ in range(2):
+                    ctx.reset(); ctx.process_batch(db); ctx.finalize()
+                ctx.kernel_timing_reset()
+                steps = args.whole_genome_steps
+                parts = {"reset": [], "process": [], "finalize": []}
+                for _ in range(steps):
+                    parts["reset"].append(timed(ctx.reset))
+                    parts["process"].append(timed(lambda: ctx.process_batch(db)))
+                    parts["finalize"].append(timed(ctx.finalize))
+                timing = ctx.kernel_timing()
+                row["ms_per_pass"] = round(sum(median(v) for v in parts.values()), 3)
+                row["of_which_ms"] = {k: round(median(v), 3) for k, v in parts.items()}
+                row["records_per_s"] = round(n / row["ms_per_pass"] * 1e3, 1)
+                row["kernels"] = kernel_table(timing)
+                row["launches_per_pass"] = {k: round(v["launches"] / steps, 1) for k, v in timing.items() if v["launches"]}
+                # ---- invariants
+                bad = []
+                g = ctx.general()
+                if g["total"] != n:
+                    bad.append("general.total == records")
+                cov_seen, pos_sum, depth_sum = [], 0, 0
+                for r in range(len(lens)):
+                    seen, hist, ign, bins = ctx.coverage_sequence(r)
+                    if seen and not primary[r]:
+                        bad.append("a sequence outside the primary assembly has a Coverage entry")
+                    if seen:
+                        cov_seen.append(r)
+                        pos_sum += int(hist.sum()) + ign - (lens[r] + 1)
+                        depth_sum += int(bins.sum())
+                if pos_sum != 0:
+                    bad.append("every covered sequence's depth histogram counts its L+1 positions")
+                if seen_primary is None:
+                    seen_primary = cov_seen
+                elif cov_seen != seen_primary:
+                    bad.append("the same sequences have entries on both Coverage paths")
+                if ctx.coverage_nonsensical() != 0:
+                    bad.append("no read crosses the end of its sequence")
+                row["coverage_entries"] = len(cov_seen)
+                row["depth_total"] = depth_sum
+                if kw["facets"] & ffi.FACET_EDITS:
+                    r1, r2, vaf = ctx.edits()
+                    reads = int(r1.sum() + r2.sum())
+                    if not (n - g["unmapped"] - g["duplicate"] <= reads <= n - max(g["unmapped"], g["duplicate"])):
+                        bad.append("Edits counts the mapped, non-duplicate reads")
+                    if int(r1[:8].sum() + r2[:8].sum()) < 0.99 * reads:
+                        bad.append("reads sampled from the reference have a handful of edits at most (every sequence's bases are the right ones)")
+                    f = ctx.features()
+                    if f["processed"] + f["ignored_flags"] + f["ignored_nonprimary_chromosome"] != n:
+                        bad.append("Genomic Features conserves records")
+                    row["state_GB"] = round((12 * G) / 1e9, 1)   # u32 depth + 2 x u32 Edits arrays per position
+                row["parity_check"] = "ok" if not bad else "FAILED: " + "; ".join(bad)
+            finally:
+                if ctx is not keep:
+                    t0 = time.perf_counter()
+                    ctx.close()
+                    row["destroy_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            out[label] = row
+        d0, d1 = out["default_streamed"].get("depth_total"), out["default_arrays"].get("depth_total")
+        out["streamed_equals_arrays"] = d0 == d1 and d0 is not None
+        out["parity_check"] = "ok" if all(out[k].get("parity_check") == "ok" for k in ("default_streamed", "default_arrays", "all_seven_streamed")) and out["streamed_equals_arrays"] else "FAILED"
+        return out
+    finally:
+        if keep is not None:
+            if db is not None:
+                keep.free_batch(db)
+            keep.close()
 
 
 def write_sharded_bam(lib, host, args, world, tmp, bam):

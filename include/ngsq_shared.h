@@ -61,7 +61,21 @@ typedef struct ngsq_synth_config {
     uint32_t file_style; /* NGSQ_SYNTH_FILE_* bits (0 = round 1-3 records): ALIGNER dresses the records of ngsq_synth_write_bam,
                             CIGAR_MIX changes the records themselves (every generator) */
     uint32_t seq_model; /* NGSQ_SYNTH_SEQ_IID (0) / NGSQ_SYNTH_SEQ_FROM_REFERENCE                 */
+    /* GENOME mode (round 6; all three zero = the one-sequence records of rounds 1-5): the records are spread, in coordinate
+     * order, over genome_n sequences in proportion to their lengths -- the 195 @SQ of a real header, 24 of them long and 171
+     * of a few kb.  genome_len[r] = @SQ LN; genome_room[r] = sum over q < r of the alignment starts sequence q offers
+     * (ngsq_synth_genome_room fills it; genome_n + 1 entries).  Reads never cross the end of their sequence: on a sequence
+     * of at most 5400 bases every mapped read is plain <l>M (the CIGAR mixes' deletions and skips would).  The mate
+     * reference of the 1 % of pairs that map apart is the NEXT sequence.  Host pointers for the host functions; the
+     * device generator copies the tables itself. */
+    const uint32_t *genome_len;
+    const uint64_t *genome_room;
+    uint32_t genome_n;
+    uint32_t reserved;
 } ngsq_synth_config;
+
+/* alignment starts a sequence of L bases offers the generator (GENOME mode); 150-300 base reads, skips of up to 5000 */
+NGSQ_HD uint64_t ngsq_synth_room_of(uint32_t L) { return L > 5400u ? (uint64_t)(L - 5300u) : (L > 640u ? (uint64_t)(L - 320u) : 1ull); }
 
 /* Where a read's bases come from.  IID: independent draws (rounds 1-3) -- compared with any reference three bases in four
  * differ, which no aligned read does.  FROM_REFERENCE: the bases under an `M` are the synthetic reference's bases at the
@@ -162,18 +176,37 @@ NGSQ_HD void ngsq_synth_record_at(const ngsq_synth_config *c, uint64_t i, ngsq_s
         r->mapq = (uint8_t)((hm >> 32) % 60ull);
 
     /* position: coordinate-sorted by construction, never within 5300 of the end */
-    const uint64_t room = (c->ref_len > 5400u) ? (uint64_t)(c->ref_len - 5300u) : 100ull;
     const uint64_t n = c->n_total ? c->n_total : 1ull;
-    const uint64_t step = room / n;
-    uint64_t start = 2ull + (i * room) / n; /* 1-based; >= 2 so placed-unmapped reads stay legal */
-    if (step > 0) start += ngsq_synth_hash(c->seed, i, NGSQ_KEY_POS, 0) % step;
-    r->ref_id = 0;
-    r->pos = (int32_t)(start - 1ull);
+    int small_seq = 0; /* GENOME mode: a sequence too short for the CIGAR mixes' deletions and skips */
+    if (c->genome_n) {
+        const uint64_t room = c->genome_room[c->genome_n];
+        const uint64_t step = room / n;
+        uint64_t g = i * step + (i * (room % n)) / n; /* = floor(i * room / n) without the 128-bit product (n_total < 2^32) */
+        if (step > 0) g += ngsq_synth_hash(c->seed, i, NGSQ_KEY_POS, 0) % step;
+        uint32_t lo = 0, hi = c->genome_n; /* genome_room[lo] <= g < genome_room[hi] */
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (c->genome_room[mid] <= g) lo = mid;
+            else hi = mid;
+        }
+        r->ref_id = (int32_t)lo;
+        r->pos = (int32_t)(1ull + (g - c->genome_room[lo])); /* 1-based start >= 2 */
+        small_seq = c->genome_len[lo] <= 5400u;
+    } else {
+        const uint64_t room = (c->ref_len > 5400u) ? (uint64_t)(c->ref_len - 5300u) : 100ull;
+        const uint64_t step = room / n;
+        uint64_t start = 2ull + (i * room) / n; /* 1-based; >= 2 so placed-unmapped reads stay legal */
+        if (step > 0) start += ngsq_synth_hash(c->seed, i, NGSQ_KEY_POS, 0) % step;
+        r->ref_id = 0;
+        r->pos = (int32_t)(start - 1ull);
+    }
 
-    /* mate reference: same, except 1 % on reference 1 when it exists; none when unpaired */
+    /* mate reference: same, except 1 % on reference 1 (GENOME mode: the next sequence) when it exists; none when unpaired */
     const uint64_t hp = ngsq_synth_hash(c->seed, i, NGSQ_KEY_POS, 1);
     if (!paired)
         r->mate_ref_id = -1;
+    else if (c->genome_n)
+        r->mate_ref_id = (c->genome_n >= 2u && (hp & 0xFFFF) < 655u) ? (int32_t)(((uint32_t)r->ref_id + 1u) % c->genome_n) : r->ref_id;
     else if (c->n_refs >= 2u && (hp & 0xFFFF) < 655u)
         r->mate_ref_id = 1;
     else
@@ -199,10 +232,10 @@ NGSQ_HD void ngsq_synth_record_at(const ngsq_synth_config *c, uint64_t i, ngsq_s
     r->cigar[0] = r->cigar[1] = r->cigar[2] = 0;
     if (unmapped) {
         r->n_cigar = 0;
-    } else if (c->mode == NGSQ_SYNTH_FIXED) {
+    } else if (c->mode == NGSQ_SYNTH_FIXED || small_seq) {
         r->n_cigar = 1;
         r->cigar[0] = (l << 4) | 0u;
-        if ((c->file_style & NGSQ_SYNTH_FILE_CIGAR_MIX) && l >= 50u) {
+        if (c->mode == NGSQ_SYNTH_FIXED && !small_seq && (c->file_style & NGSQ_SYNTH_FILE_CIGAR_MIX) && l >= 50u) {
             /* an aligner's mix: 15 % of the mapped reads -- 9 % soft-clipped at one end (1..60 bases), 3 % an insertion,
                3 % a deletion (1..8 bases) */
             const uint64_t hc = ngsq_synth_hash(c->seed, i, NGSQ_KEY_CIGAR, 7);
@@ -316,22 +349,27 @@ NGSQ_HD uint32_t ngsq_synth_base_from_reference(const ngsq_synth_config *c, uint
     return iid; /* no CIGAR (unmapped) */
 }
 
-/* packed sequence byte j (bases 2j, 2j+1; high nibble first) of record i */
-NGSQ_HD uint8_t ngsq_synth_seq_byte(const ngsq_synth_config *c, uint64_t i, uint32_t l_seq,
-                                    uint32_t j) {
+/* packed sequence byte j (bases 2j, 2j+1; high nibble first) of record i; r = its fields (ngsq_synth_record_at), or NULL */
+NGSQ_HD uint8_t ngsq_synth_seq_byte_of(const ngsq_synth_config *c, uint64_t i, uint32_t l_seq, uint32_t j, const ngsq_synth_record *r) {
     /* one hash feeds four 16-bit draws = two bytes */
     const uint64_t h = ngsq_synth_hash(c->seed, i, NGSQ_KEY_SEQ, (uint64_t)(j >> 1));
     const uint32_t sh = (j & 1u) * 32u;
     uint32_t hi = ngsq_synth_base_code((uint32_t)((h >> sh) & 0xFFFF));
     uint32_t lo = ngsq_synth_base_code((uint32_t)((h >> (sh + 16u)) & 0xFFFF));
     if (NGSQ_SYNTH_SEQ_KIND(c->seq_model) == NGSQ_SYNTH_SEQ_FROM_REFERENCE) {
-        ngsq_synth_record r;
-        ngsq_synth_record_at(c, i, &r);
-        hi = ngsq_synth_base_from_reference(c, i, &r, 2u * j, hi);
-        lo = ngsq_synth_base_from_reference(c, i, &r, 2u * j + 1u, lo);
+        ngsq_synth_record own;
+        if (!r) {
+            ngsq_synth_record_at(c, i, &own);
+            r = &own;
+        }
+        hi = ngsq_synth_base_from_reference(c, i, r, 2u * j, hi);
+        lo = ngsq_synth_base_from_reference(c, i, r, 2u * j + 1u, lo);
     }
     if (2u * j + 1u >= l_seq) lo = 0u; /* pad nibble of an odd-length read */
     return (uint8_t)((hi << 4) | lo);
+}
+NGSQ_HD uint8_t ngsq_synth_seq_byte(const ngsq_synth_config *c, uint64_t i, uint32_t l_seq, uint32_t j) {
+    return ngsq_synth_seq_byte_of(c, i, l_seq, j, (const ngsq_synth_record *)0);
 }
 
 /* Phred score of cycle j (0-based) of record i:

@@ -34,6 +34,13 @@ int ngsq_synth_fill_device(ngsq_ctx *ctx, const ngsq_synth_config *cfg, uint64_t
  * 4-bit code per byte, for p in [0, len).  With cfg->seq_model = NGSQ_SYNTH_SEQ_FROM_REFERENCE the reads are sampled from it. */
 int ngsq_synth_fill_reference(const ngsq_synth_config *cfg, uint32_t ref, uint8_t *codes, uint64_t len, int n_threads);
 
+/* GENOME mode (ngsq_shared.h): room[r] = the alignment starts of the sequences in front of r; n + 1 entries */
+int ngsq_synth_genome_room(const uint32_t *genome_len, uint32_t n, uint64_t *room);
+
+/* ngsq_synth_write_bam for a GENOME-mode configuration: the @SQ lines carry ref_names[r] and cfg->genome_len[r] */
+int ngsq_synth_write_bam_named(const ngsq_synth_config *cfg, const char *const *ref_names, const char *path, uint64_t n_records, int level,
+                               int n_threads);
+
 /* Write records [0, n_records) as a BGZF BAM (@SQ chr1 [, chr2]) plus a minimal BAI
  * ("<path>.bai"), rendered and deflated by n_threads workers (0 = all cores). */
 int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *path, uint64_t n_records, int level,

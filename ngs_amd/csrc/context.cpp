@@ -368,6 +368,7 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
             st.ref_edits_len = c->d_edits_len;
             st.ref_fast_len = c->d_edits_len + nr;
         }
+        CTX_TRY(hipStreamSynchronize(c->stream)); // (d_bad was zeroed on this stream, which the copy below does not wait for by itself)
         CTX_TRY(hipMemcpy(&h_bad, d_bad, 8, hipMemcpyDeviceToHost));
         (void)hipFree(codes);
         (void)hipFree(d_bad);

@@ -240,6 +240,23 @@ int ngsq_synth_fill_device(ngsq_ctx *ctx, const ngsq_synth_config *cfg, uint64_t
             hipMemcpy(const_cast<uint64_t *>(b->cigar_off), co.data(), (n + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
             return NGSQ_ERR_DEVICE;
     }
+    // GENOME mode: the kernels take the configuration by value -- with the tables in device memory
+    ngsq_synth_config dcfg = *cfg;
+    uint32_t *d_glen = nullptr;
+    uint64_t *d_groom = nullptr;
+    if (cfg->genome_n) {
+        if (!cfg->genome_len || !cfg->genome_room) return NGSQ_ERR_INVALID_ARGUMENT;
+        if (hipMalloc((void **)&d_glen, cfg->genome_n * 4ull) != hipSuccess || hipMalloc((void **)&d_groom, (cfg->genome_n + 1ull) * 8) != hipSuccess ||
+            hipMemcpy(d_glen, cfg->genome_len, cfg->genome_n * 4ull, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_groom, cfg->genome_room, (cfg->genome_n + 1ull) * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_glen);
+            (void)hipFree(d_groom);
+            return NGSQ_ERR_DEVICE;
+        }
+        dcfg.genome_len = d_glen;
+        dcfg.genome_room = d_groom;
+    }
+    cfg = &dcfg;
     const uint32_t g = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(k_synth_fields, dim3(g), dim3(256), 0, s, *cfg, c, first, n);
     const uint32_t big = (uint32_t)ctx->li.n_cu * 16;
@@ -251,9 +268,10 @@ int ngsq_synth_fill_device(ngsq_ctx *ctx, const ngsq_synth_config *cfg, uint64_t
     } else {
         hipLaunchKernelGGL(k_synth_seq_qual_var, dim3(big), dim3(256), 0, s, *cfg, c, first, n);
     }
-    if (hipGetLastError() != hipSuccess) return NGSQ_ERR_DEVICE;
-    if (hipStreamSynchronize(s) != hipSuccess) return NGSQ_ERR_DEVICE;
-    return NGSQ_OK;
+    const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(d_glen);
+    (void)hipFree(d_groom);
+    return ok ? NGSQ_OK : NGSQ_ERR_DEVICE;
 }
 
 } // extern "C"

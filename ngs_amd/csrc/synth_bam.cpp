@@ -204,7 +204,7 @@ void append_record(std::vector<uint8_t> &out, const ngsq_synth_config &cfg, uint
     put32(out, (uint32_t)r.tlen);
     out.insert(out.end(), name, name + ln);
     for (uint32_t k = 0; k < n_cig; k++) put32(out, cig[k]);
-    for (uint32_t j = 0; j < (l + 1) / 2; j++) out.push_back(ngsq_synth_seq_byte(&cfg, i, l, j));
+    for (uint32_t j = 0; j < (l + 1) / 2; j++) out.push_back(ngsq_synth_seq_byte_of(&cfg, i, l, j, &r)); // (the record's fields are worked out once)
     for (uint32_t j = 0; j < l; j++) out.push_back(ngsq_synth_qual_byte(&cfg, i, l, j));
     out.insert(out.end(), aux.begin(), aux.end());
 }
@@ -237,12 +237,33 @@ bool bgzf_write(FILE *f, const uint8_t *data, size_t n, int level, std::vector<u
 
 } // namespace
 
-extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *path, uint64_t n_records, int level,
-                                    int n_threads) {
+extern "C" int ngsq_synth_genome_room(const uint32_t *genome_len, uint32_t n, uint64_t *room) {
+    if (!genome_len || !room) return NGSQ_ERR_INVALID_ARGUMENT;
+    room[0] = 0;
+    for (uint32_t r = 0; r < n; r++) room[r + 1] = room[r] + ngsq_synth_room_of(genome_len[r]);
+    return NGSQ_OK;
+}
+
+static int write_bam(const ngsq_synth_config *cfg, const char *const *ref_names, const char *path, uint64_t n_records, int level, int n_threads);
+
+extern "C" int ngsq_synth_write_bam(const ngsq_synth_config *cfg, const char *path, uint64_t n_records, int level, int n_threads) {
+    if (cfg && cfg->genome_n) return NGSQ_ERR_INVALID_ARGUMENT; // (a GENOME-mode file needs its sequences' names: ngsq_synth_write_bam_named)
+    return write_bam(cfg, nullptr, path, n_records, level, n_threads);
+}
+
+extern "C" int ngsq_synth_write_bam_named(const ngsq_synth_config *cfg, const char *const *ref_names, const char *path, uint64_t n_records, int level,
+                                          int n_threads) {
+    if (!cfg || !cfg->genome_n || !cfg->genome_len || !cfg->genome_room || !ref_names) return NGSQ_ERR_INVALID_ARGUMENT;
+    return write_bam(cfg, ref_names, path, n_records, level, n_threads);
+}
+
+static int write_bam(const ngsq_synth_config *cfg, const char *const *ref_names, const char *path, uint64_t n_records, int level, int n_threads) {
     if (!cfg || !path) return NGSQ_ERR_INVALID_ARGUMENT;
-    static const char *names[2] = {"chr1", "chr2"};
-    const uint32_t lens[2] = {cfg->ref_len, 242193529u};
-    const uint32_t n_refs = cfg->n_refs >= 2 ? 2 : 1;
+    static const char *two_names[2] = {"chr1", "chr2"};
+    const uint32_t two_lens[2] = {cfg->ref_len, 242193529u};
+    const char *const *names = ref_names ? ref_names : two_names;
+    const uint32_t *lens = ref_names ? cfg->genome_len : two_lens;
+    const uint32_t n_refs = ref_names ? cfg->genome_n : (cfg->n_refs >= 2 ? 2 : 1);
     FILE *f = fopen(path, "wb");
     if (!f) return NGSQ_ERR_INVALID_ARGUMENT;
     std::vector<uint8_t> scratch;

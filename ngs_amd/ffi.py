@@ -207,6 +207,10 @@ class SynthConfig(C.Structure):
         ("n_refs", C.c_uint32),
         ("file_style", C.c_uint32),
         ("seq_model", C.c_uint32),
+        ("genome_len", u32p),
+        ("genome_room", u64p),
+        ("genome_n", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -341,6 +345,8 @@ PROTOTYPES = {
     "ngsq_synth_fill_host": (C.c_int, [C.POINTER(SynthConfig), C.c_uint64, C.c_uint64, C.POINTER(Batch)]),
     "ngsq_synth_fill_reference": (C.c_int, [C.POINTER(SynthConfig), C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]),
     "ngsq_synth_write_bam": (C.c_int, [C.POINTER(SynthConfig), C.c_char_p, C.c_uint64, C.c_int, C.c_int]),
+    "ngsq_synth_genome_room": (C.c_int, [u32p, C.c_uint32, u64p]),
+    "ngsq_synth_write_bam_named": (C.c_int, [C.POINTER(SynthConfig), C.POINTER(C.c_char_p), C.c_char_p, C.c_uint64, C.c_int, C.c_int]),
     "ngsq_bam_last_error": (C.c_char_p, []),
     "ngsq_bam_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ngsq_bam_close": (None, [C.c_void_p]),

@@ -96,8 +96,16 @@ def features_struct(ref_id, name, start, stop, role_name=(0, 1, 2, 3, 4)):
 
 def synth_config(n_total: int, mode: int = ffi.SYNTH_FIXED, read_len: int = 150, min_len: int = 50,
                  max_len: int = 300, ref_len: int = 248_956_422, n_refs: int = 2,
-                 seed: int = 0x4E4753, file_style: int = 0, seq_model: int = 0) -> ffi.SynthConfig:
+                 seed: int = 0x4E4753, file_style: int = 0, seq_model: int = 0, genome=None, lib=None) -> ffi.SynthConfig:
+    """genome: the lengths of the sequences of a GENOME-mode file (include/ngsq_shared.h): the records are spread over them."""
     s = ffi.SynthConfig()
+    if genome is not None:
+        lib = lib or ffi.load_library()
+        glen = np.ascontiguousarray(genome, dtype=np.uint32)
+        room = np.zeros(len(glen) + 1, dtype=np.uint64)
+        _check(lib.ngsq_synth_genome_room(glen.ctypes.data_as(ffi.u32p), len(glen), room.ctypes.data_as(ffi.u64p)), None, lib)
+        s.genome_len, s.genome_room, s.genome_n = glen.ctypes.data_as(ffi.u32p), room.ctypes.data_as(ffi.u64p), len(glen)
+        s._keep = (glen, room)   # (the structure holds pointers into them)
     s.file_style, s.seq_model = file_style, seq_model
     s.seed, s.n_total, s.mode, s.read_len = seed, n_total, mode, read_len
     s.min_len, s.max_len, s.ref_len, s.n_refs = min_len, max_len, ref_len, n_refs
@@ -204,7 +212,7 @@ class QcContext:
                     arr[r] = None
                 else:
                     a = np.ascontiguousarray(a, dtype=np.uint8)
-                    assert a.size == int(self._ref_len[r])
+                    assert a.size == (int(self._ref_len[r]) if ref_bases_len is None else min(int(ref_bases_len[r]), int(self._ref_len[r])))
                     keep.append(a)
                     arr[r] = a.ctypes.data_as(ffi.u8p)
             self._bases_keep = (arr, keep)
