@@ -1162,6 +1162,8 @@ def leg_file(lib, host, ffi, args):
             # 370 bytes per record where the plain file has 273, and a screen that has to tell records from their tails
             if args.file_realistic_records > 0:
                 out["realistic"] = guarded(leg_file_realistic, lib, host, ffi, args, ctx, tmp, ngs, out["bam_write_s"] / max(n, 1))
+                if isinstance(out["realistic"], dict) and "cli_all_facets" in out["realistic"]:
+                    out["cli_all_facets"] = out["realistic"].pop("cli_all_facets")   # (file_end_to_end.cli_all_facets: on the realistic file)
         finally:
             ctx.close()
         def strip(d):  # the GC window offsets are a function of (seed, record id = virtual offset): identical across the runs
@@ -1175,28 +1177,121 @@ def leg_file(lib, host, ffi, args):
         os.rmdir(tmp)
 
 
+def write_bench_fasta(np, lib, host, scfg, names, lens, path):
+    """The FASTA the reads of `scfg` (seq_model FROM_REFERENCE) were sampled from, as the analysis set comes: 60 bases per line,
+    soft-masked (runs of a few hundred lower-case bases, about half of it), a .fai-less plain file of the genome's size."""
+    lut = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+    rng = np.random.default_rng(3)
+    with open(path, "wb") as f:
+        for r, (name, L) in enumerate(zip(names, lens)):
+            s_ = lut[host.synth_reference(scfg, r, L, lib)]
+            # soft-masking: alternate runs, lengths 50-700, lower-cased with probability one half
+            edges = np.cumsum(rng.integers(50, 700, L // 375 + 2))
+            edges = edges[edges < L]
+            run = np.zeros(L, dtype=np.uint8)
+            run[edges] = 1
+            lower = (np.cumsum(run, dtype=np.uint32) & 1).astype(bool)
+            s_ = np.where(lower, s_ | 0x20, s_).astype(np.uint8)
+            f.write(f">{name}  AC:stand-in  gi:0  LN:{L}  rl:Chromosome  M5:0  AS:GRCh38\n".encode())
+            full = L // 60 * 60
+            if full:
+                lines = np.empty((full // 60, 61), dtype=np.uint8)
+                lines[:, :60] = s_[:full].reshape(-1, 60)
+                lines[:, 60] = 10
+                f.write(lines.tobytes())
+            if L > full:
+                f.write(s_[full:].tobytes() + b"\n")
+    return os.path.getsize(path)
+
+
+def write_bench_gff(np, names, lens, primary, path, n_rows=3_400_000):
+    """A GENCODE-shaped GFF3: ~3.4 M rows (gene / transcript / exon / CDS / UTR / codon rows with their attribute strings, ~330
+    bytes each), on the 24 chromosomes and chrM, both strands.  Returns (bytes, the model the facet keeps of it)."""
+    rng = np.random.default_rng(11)
+    types = ["gene", "transcript", "exon", "CDS", "five_prime_UTR", "three_prime_UTR", "start_codon", "stop_codon"]
+    tp = rng.choice(len(types), n_rows, p=[.02, .08, .48, .27, .06, .05, .02, .02])
+    seq = rng.choice(25, n_rows)
+    seq.sort()
+    L = np.array(lens, dtype=np.int64)[seq]
+    start = (rng.random(n_rows) * (L - 6000)).astype(np.int64) + 1
+    stop = start + np.where(tp == 0, rng.integers(1000, 5000, n_rows), rng.integers(30, 900, n_rows))
+    strand = rng.integers(0, 2, n_rows)
+    role = {"five_prime_UTR": 0, "three_prime_UTR": 1, "CDS": 2, "exon": 3, "gene": 4}
+    keep = np.array([types[t] in role and primary[q] for t, q in zip(tp, seq)], dtype=bool)
+    model = (seq[keep].astype(np.uint32), np.array([role.get(types[t], 0) for t in tp[keep]], dtype=np.uint32), start[keep].astype(np.uint32),
+             stop[keep].astype(np.uint32))
+    attr = ("ID={0}:ENST00000{1:06d}.{2};Parent=ENST00000{1:06d}.{2};gene_id=ENSG00000{3:06d}.{2};transcript_id=ENST00000{1:06d}.{2};"
+            "gene_type=protein_coding;gene_name=GENE{3};transcript_type=protein_coding;transcript_name=GENE{3}-20{2};exon_number={4};"
+            "exon_id=ENSE0000{1:07d}.1;level=2;protein_id=ENSP00000{1:06d}.{2};transcript_support_level=1;tag=basic,Ensembl_canonical,MANE_Select,appris_principal_1,CCDS")
+    with open(path, "w") as f:
+        f.write("##gff-version 3\n#description: stand-in for a GENCODE comprehensive annotation\n#provider: bench.py\n")
+        chunk = []
+        for k in range(n_rows):
+            t = types[tp[k]]
+            chunk.append(f"{names[seq[k]]}\tHAVANA\t{t}\t{start[k]}\t{stop[k]}\t.\t{'+-'[strand[k]]}\t{'.' if t != 'CDS' else k % 3}\t" +
+                         attr.format(t, k % 1000000, 1 + k % 9, k % 60000, 1 + k % 30))
+            if len(chunk) == 200_000:
+                f.write("\n".join(chunk) + "\n")
+                chunk = []
+        if chunk:
+            f.write("\n".join(chunk) + "\n")
+    return os.path.getsize(path), model
+
+
+def run_cli_traced(ngs, argv, tmp):
+    """`ngs qc ...` as a child with its own milestones (NGSQ_INGEST_TRACE=1): wall clock, phases, and what it says of the set-up."""
+    t0 = time.perf_counter()
+    r = subprocess.run([ngs, "-q", "qc", *argv, "-o", tmp], capture_output=True, text=True, env=dict(os.environ, NGSQ_INGEST_TRACE="1"))
+    wall = (time.perf_counter() - t0) * 1e3
+    if r.returncode != 0:
+        raise RuntimeError(f"ngs qc {' '.join(argv[2:])}: {r.stderr[-600:]}")
+    marks, notes = [], {}
+    for ln in r.stderr.splitlines():
+        if ln.startswith("[ngs] gene model:") or ln.startswith("[ngs] reference:"):
+            notes[ln[6:].split(":")[0]] = ln.split(":", 1)[1].strip()
+        elif ln.startswith("[ngs]") and " ms " in ln:
+            ms, what = ln[5:].split(" ms ", 1)
+            marks.append((what.strip(), float(ms)))
+    ph, prev = {}, 0.0
+    for what, ms in marks[1:]:
+        ph["until " + what] = round(ms - prev, 1)
+        prev = ms
+    ph["process start + exit (wall clock of the command - its own last milestone)"] = round(wall - (marks[-1][1] if marks else 0.0), 1)
+    return wall, ph, notes
+
+
 def leg_file_realistic(lib, host, ffi, args, ctx, tmp, ngs, write_s_per_record):
-    """An aligner-style file (include/ngsq_shared.h NGSQ_SYNTH_FILE_REALISTIC) through the same entry points: in process three
-    times, and once through `ngs qc --ingest host` (the host reader) for the document it must equal."""
+    """An aligner-style file (include/ngsq_shared.h NGSQ_SYNTH_FILE_REALISTIC) on the header a user has -- the 195 @SQ of the GRCh38
+    no-alt analysis set at full length, the records over all of it, their bases sampled from the reference (round 6: chr1 + chr2
+    and independent bases until then) -- through the same entry points: in process five times, once through `ngs qc --ingest
+    host` for the document it must equal, and then THE COMMAND A USER RUNS: `ngs qc -r <the 3.1 GB soft-masked FASTA> -f <a 3.4 M-row
+    GFF>` -- all seven facets, wall clock with phases -- beside the same command without -r / -f."""
     import ctypes as C
+    import numpy as np
+    from ngs_amd.genome_shape import grch38_no_alt
+    names, lens, primary = grch38_no_alt()
     # (the writer is zlib level 6 on the host cores, ~1.1 M aligner-style records/s on the 16 these boxes grant: 150 M records -- a
     # file on which the GPU's time, not the pipeline's start, is what is measured -- take it ~140 s; a slower host gets a smaller file)
     nr = int(min(args.file_realistic_records, max(10_000_000, args.file_realistic_budget / max(write_s_per_record * 1.4, 1e-9))))
     path = os.path.join(tmp, "realistic.bam")
-    cfg = host.synth_config(nr, read_len=args.read_len, ref_len=CHR1, n_refs=2, file_style=ffi.SYNTH_FILE_REALISTIC)
+    cfg = host.synth_config(nr, read_len=args.read_len, genome=lens, file_style=ffi.SYNTH_FILE_REALISTIC, seq_model=ffi.SYNTH_SEQ_FROM_REFERENCE, lib=lib)
+    name_arr = (C.c_char_p * len(names))(*[x.encode() for x in names])
     t0 = time.perf_counter()
-    assert lib.ngsq_synth_write_bam(C.byref(cfg), path.encode(), nr, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
+    assert lib.ngsq_synth_write_bam_named(C.byref(cfg), name_arr, path.encode(), nr, args.file_level, 0) == 0, lib.ngsq_bam_last_error()
     tw = time.perf_counter() - t0
     os.sync()
     size = os.path.getsize(path)
     settled = settle_page_cache(path)
-    times, best, timing, after, doc = scan_file_in_process(lib, host, ffi, ctx, path, nr, FILE_SCANS)
+    gctx = host.QcContext(lens, primary, max_read_len=1024, gc_seed=GC_SEED, sorted_input=True, timing=True, lib=lib)
+    try:
+        times, best, timing, after, doc = scan_file_in_process(lib, host, ffi, gctx, path, nr, FILE_SCANS)
+    finally:
+        gctx.close()
     best_scan, best = best, median(times)   # everything below is quoted on the MEDIAN scan
-    h = C.c_void_p()
-    stats = None
     inf = timing.get("bgzf_inflate")
     raw = (inf["algo_bytes"] - size) if inf else None
     out = {"records": nr, "bam_bytes": size, "bam_write_s": round(tw, 1),
+           "header": "195 @SQ: the GRCh38 no-alt analysis set at full length (3.1 Gbp), records on all of it, bases sampled from the reference",
            "style": "Illumina read names, NM MD MC AS XS MQ RG on every mapped record, SA / XA / a B,S array on some, "
                     "15 % CIGARs of 2-5 operations (clips, insertions, deletions), real mate positions",
            "compressed_bytes_per_record": round(size / nr, 1), "inflated_bytes_per_record": round(raw / nr, 1) if raw else None,
@@ -1217,6 +1312,59 @@ def leg_file_realistic(lib, host, ffi, args, ctx, tmp, ngs, write_s_per_record):
     out["cli_host_ingest_s"] = round(time.perf_counter() - t0, 2)
     with open(os.path.join(tmp, "realistic.bam.results.json")) as f:
         out["same_document_as_host_reader"] = json.dumps(json.load(f), sort_keys=True) == json.dumps(doc, sort_keys=True)
+    # ---- the command a user runs: all seven facets from the files they have
+    try:
+        fa, gff = os.path.join(tmp, "GRCh38_stand_in.fa"), os.path.join(tmp, "annotation.gff3")
+        t0 = time.perf_counter()
+        fa_bytes = write_bench_fasta(np, lib, host, cfg, names, lens, fa)
+        gff_bytes, model = write_bench_gff(np, names, lens, primary, gff)
+        os.sync()
+        for f_ in (fa, gff):
+            settle_page_cache(f_)
+        made_s = time.perf_counter() - t0
+        base = [path, "GRCh38_no_alt_AnalysisSet"]
+        runs = {"default": [], "all": []}
+        phases = {}
+        for rep in range(3):
+            for key, extra in (("default", []), ("all", ["-r", fa, "-f", gff])):
+                wall, ph, notes = run_cli_traced(ngs, base + extra, tmp)
+                runs[key].append(round(wall, 1))
+                phases[key] = (ph, notes)
+                if key == "all":
+                    with open(os.path.join(tmp, "realistic.bam.results.json")) as f:
+                        cli_doc = json.load(f)
+        # the same seven facets inside this process (HIP up, FASTA through the same loader): the document the command must give
+        t0 = time.perf_counter()
+        actx = host.QcContext(lens, primary, facets=0x7F, max_read_len=1024, gc_seed=GC_SEED, sorted_input=True, timing=True, lib=lib,
+                              ref_fasta=fa, ref_names=names)
+        try:
+            actx.set_features(*model)
+            t_all, _, timing_all, _, doc_all = scan_file_in_process(lib, host, ffi, actx, path, nr, 1)
+            ref_stats = actx.reference_wait()
+        finally:
+            actx.close()
+        wall_default, wall_all = median(runs["default"]), median(runs["all"])
+        ph_all, notes = phases["all"]
+        scan_ms = ph_all.get("until records scanned", 0.0)
+        out["cli_all_facets"] = {
+            "command": "ngs qc realistic.bam GRCh38_no_alt_AnalysisSet -r <FASTA> -f <GFF>  (General, Template Length, GC Content, Quality Score, "
+                       "Genomic Features, Coverage, Edits)",
+            "fasta_bytes": fa_bytes, "fasta": "195 sequences, 60 bases per line, soft-masked (half of it lower case), no .fai",
+            "gff_bytes": gff_bytes, "gff_rows": 3_400_000, "gff_intervals_kept": int(len(model[0])), "files_written_s": round(made_s, 1),
+            "wall_ms": wall_all, "wall_ms_each_run": runs["all"], "records_per_s": round(nr / wall_all * 1e3, 1),
+            "phases_ms": ph_all, "set_up": notes,
+            "default_facets_same_file": {"wall_ms": wall_default, "wall_ms_each_run": runs["default"], "phases_ms": phases["default"][0],
+                                         "records_per_s": round(nr / wall_default * 1e3, 1)},
+            "extra_wall_for_edits_and_features_ms": round(wall_all - wall_default, 1),
+            "in_process_all_facets": {"seconds": t_all[0], "records_per_s": round(nr / t_all[0], 1), "reference_load": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ref_stats.items()},
+                                      "kernels": kernel_table(timing_all)},
+            "same_document_as_in_process": json.dumps(cli_doc, sort_keys=True) == json.dumps(doc_all, sort_keys=True),
+            "edits_reads": int(sum(cli_doc["edits"]["read_one_edits"]["values"]) + sum(cli_doc["edits"]["read_two_edits"]["values"])),
+            "mean_edits_read_one": cli_doc["edits"]["summary"]["mean_edits_read_one"],
+            "features_processed": cli_doc["features"]["records"]["processed"],
+        }
+    except Exception as e:  # noqa: BLE001 -- reported, never required
+        out["cli_all_facets"] = {"failed": f"{type(e).__name__}: {e}"}
     return out
 
 

@@ -209,6 +209,11 @@ typedef struct ngsq_batch {
 #define NGSQ_PASS_RECORD 0x1u
 #define NGSQ_PASS_SEQUENCE 0x2u
 #define NGSQ_PASS_BOTH 0x3u
+/* OR-ed into pass_mask, host batches only: ngsq_process_batch returns when the copies to the device are QUEUED, not when they
+ * have landed -- the host columns stay untouched until an event the CALLER records on ngsq_stream(ctx) behind the call has
+ * completed (the explicit "batch done" event of SURVEY.md 8b: the next batch is assembled in a second set of columns
+ * meanwhile).  include/ngsq_stage.h does exactly that. */
+#define NGSQ_PASS_NOWAIT 0x100u
 
 /* ---- plain-integer result blocks (all counters are the reference's usize) ---- */
 

@@ -42,7 +42,7 @@ typedef struct ngsq_stager ngsq_stager;
 #define NGSQ_STAGE_NO_ID (~0ull)
 
 /* capacity_records: records a flush holds at most (the byte columns grow by themselves: reads of any length).
- * 1 << 21 records of 150 bases are 0.53 GB of pinned memory. */
+ * 1 << 21 records of 150 bases are 0.53 GB of pinned memory -- twice that: a pinned stager has two sets of columns (ngsq_stager_flush). */
 int ngsq_stager_create(uint64_t capacity_records, uint32_t flags, ngsq_stager **out);
 void ngsq_stager_destroy(ngsq_stager *s);
 /* message of the stager's last failing call (s == NULL: of the calling thread's last failing create) */
@@ -93,8 +93,12 @@ int ngsq_stager_push_records(ngsq_stager *s, const ngsq_batch *host_batch, uint6
  * or destroy).  For hosts that want to look, and for tests. */
 int ngsq_stager_view(ngsq_stager *s, ngsq_batch *out);
 
-/* facet.process for every staged record: ngsq_process_batch(ctx, staged batch, pass_mask), then the stager is empty (the
- * host-to-device copies have landed when this returns; the kernels run on behind it).  pass_mask as in ngsq.h:
+/* facet.process for every staged record: ngsq_process_batch(ctx, staged batch, pass_mask), then the stager is empty.  A
+ * pinned stager holds its columns TWICE: the flush queues the host-to-device copies of the set it hands over (NGSQ_PASS_NOWAIT),
+ * records an event behind them on the context's stream and returns; the next pushes fill the other set, and a set is waited
+ * for only when its turn comes again, one flush later -- the copies of a flush (5 ms per million 150-base records) run beside
+ * the next flush's pushes (30 ms per million on one core), so a host pays for the pushes only.  (NGSQ_STAGE_PAGEABLE: one set,
+ * the copies have landed when the call returns.)  pass_mask as in ngsq.h:
  * NGSQ_PASS_RECORD for the calls of pass 1, NGSQ_PASS_SEQUENCE for those of pass 2, NGSQ_PASS_BOTH for a host that makes one
  * pass.  Nothing staged: NGSQ_OK.  On a failure of ngsq_process_batch the records stay staged and the context has the message. */
 int ngsq_stager_flush(ngsq_stager *s, ngsq_ctx *ctx, uint32_t pass_mask);

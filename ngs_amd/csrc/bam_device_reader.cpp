@@ -3,6 +3,8 @@
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
 #include <sched.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 
 #include <cctype>
@@ -180,8 +182,12 @@ struct DeviceIngest {
     // Compressed chunks come from a reader thread: while the GPU inflates and parses chunk k the
     // thread reads and frames chunk k+1 into the other pinned buffer.
     struct HostChunk {
-        uint8_t *h = nullptr; // pinned, 2 x comp_chunk
-        size_t h_bytes = 0;   // of the block behind h (mem_pool.h)
+        uint8_t *h = nullptr; // the chunk's compressed bytes: h[j] = byte file_off + j of the file -- in `pin` (behind a pad that makes
+                              // the address congruent to the file offset mod 4096: O_DIRECT reads land where they belong), or, for a
+                              // chunk whose bytes are in the page cache, in the MAPPING of the file itself (nothing is copied by the host)
+        uint8_t *pin = nullptr; // pinned block, 2 x comp_chunk + 2 pages (mem_pool.h)
+        size_t h_bytes = 0;     // of the block behind pin
+        bool mapped = false;    // h points into the file's mapping
         size_t fill = 0, consumed = 0;
         uint64_t total = 0; // decompressed bytes of `blocks`
         std::vector<BgzfBlock> blocks;
@@ -317,7 +323,7 @@ struct DeviceIngest {
         for (auto &e : raw_free) pool_event_put(e);
         for (auto &e : retired_ev) pool_event_put(e);
         for (auto &c : hc)
-            if (c.h) pool_pinned_free(c.h, c.h_bytes);
+            if (c.pin) pool_pinned_free(c.pin, c.h_bytes);
 
     }
 };
@@ -357,6 +363,8 @@ struct ReadPool {
     static constexpr size_t PIECE = (size_t)4 << 20, PIECE_COLD = (size_t)16 << 20, MAX_PIECES = 1024; // a request is at most 4 GiB
     size_t piece = PIECE;
     int nt = 0, fd = -1;
+    int fd_direct = -1;  // the same file opened O_DIRECT (-1: not available): requests marked `direct` read through it
+    bool direct = false; // this request: whole 4 KiB sectors straight into the pinned buffer -- no page cache, no kernel copy
     std::thread th[NT_MAX];
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
@@ -386,17 +394,44 @@ struct ReadPool {
                 const size_t lo = i * piece, hi = std::min(want, lo + piece);
                 uint8_t *const to = dst;
                 const uint64_t from = pos;
+                const bool dio = direct && fd_direct >= 0;
                 g.unlock();
                 size_t n = 0;
-                bool err = false;
-                while (lo + n < hi) {
-                    const ssize_t r = pread(fd, to + lo + n, hi - lo - n, (off_t)(from + lo + n));
-                    if (r < 0) {
-                        err = true;
-                        break;
+                bool err = false, buffered = !dio;
+                if (dio) {
+                    // The buffer address of a file byte is congruent to its file offset mod 4096 (reader_main keeps it so), so the
+                    // sectors that hold [from + lo, from + hi) can be read as they lie: up to 4095 bytes in front of the piece and
+                    // behind it are read too -- bytes of the neighbouring pieces (or of the data in front of the request), which
+                    // land on the addresses those same bytes have anyway.
+                    const uint64_t a0 = (from + lo) & ~(uint64_t)4095, a1 = (from + hi + 4095) & ~(uint64_t)4095;
+                    uint8_t *const at = to + lo - ((from + lo) - a0);
+                    uint64_t got_to = a0; // file offset the sectors read so far reach
+                    while (got_to < a1) {
+                        const ssize_t r = pread(fd_direct, at + (got_to - a0), (size_t)(a1 - got_to), (off_t)got_to);
+                        if (r < 0) {
+                            if (got_to == a0 && (errno == EINVAL || errno == ENOTSUP)) { // this filesystem refuses after all: the ordinary way
+                                got_to = 0;
+                                break;
+                            }
+                            err = true;
+                            break;
+                        }
+                        if (r == 0) break; // end of file
+                        got_to += (uint64_t)r;
                     }
-                    if (r == 0) break; // end of file
-                    n += (size_t)r;
+                    if (got_to) n = got_to > from + lo ? (size_t)std::min<uint64_t>(got_to - (from + lo), hi - lo) : 0;
+                    else if (!err) buffered = true;
+                }
+                if (buffered) {
+                    while (lo + n < hi) {
+                        const ssize_t r = pread(fd, to + lo + n, hi - lo - n, (off_t)(from + lo + n));
+                        if (r < 0) {
+                            err = true;
+                            break;
+                        }
+                        if (r == 0) break; // end of file
+                        n += (size_t)r;
+                    }
                 }
                 g.lock();
                 got[i] = (uint32_t)n;
@@ -415,6 +450,7 @@ struct ReadPool {
             dst = to;
             pos = file_pos;
             want = n;
+            direct = cold;
             piece = cold ? PIECE_COLD : PIECE;
             n_pieces = (n + piece - 1) / piece;
             next = finished = 0;
@@ -488,33 +524,57 @@ void reader_main(DeviceIngest *d, std::string path) {
     const int fd = fileno(d->f);
     // this thread, its pread workers and the pinned buffers they fill: all on the device's NUMA node
     pin_to_device_node(d->ctx->device);
-    ReadPool pool;
-    pool.open(NT, fd);
-    // (pinning 2 x 512 MiB costs ~0.2 s: the second buffer is allocated by a helper while this thread fills the first)
-    std::thread alloc1;
-    std::string alloc1_err;
-    {
-        std::string err;
-        const double ta = now_ms();
-        if (hipSetDevice(d->ctx->device) != hipSuccess) err = "hipSetDevice failed in the reader thread";
-        alloc1 = std::thread([&]() {
-            if (hipSetDevice(d->ctx->device) != hipSuccess ||
-                ngsq::pool_pinned_alloc((void **)&d->hc[1].h, cap, &d->hc[1].h_bytes) != hipSuccess)
-                alloc1_err = "hipHostMalloc of the ingest buffers failed";
-        });
-        if (err.empty() && ngsq::pool_pinned_alloc((void **)&d->hc[0].h, cap, &d->hc[0].h_bytes) != hipSuccess) err = "hipHostMalloc of the ingest buffers failed";
-        if (trace_on()) fprintf(stderr, "[ingest] reader: first pinned buffer after %.1f ms\n", now_ms() - ta);
-        if (!err.empty()) {
-            alloc1.join();
-            {
-                std::lock_guard<std::mutex> g(d->mu);
-                d->hc[0].err = path + ": " + err;
-                d->hc[0].last = true;
-                d->hc[0].ready = true;
-            }
-            d->cv.notify_all();
-            return;
+    // ---- three ways for a chunk's bytes to reach the device (round 6; tools/reader_paths_probe.cpp):
+    //   mapped   the bytes are in the page cache: the chunk IS the file's mapping -- framed in place, copied to the device straight
+    //            from it (the runtime pins the pages it reads; no copy by the host: 30-38 GB per core-second against 12-14 through
+    //            pread, one thread instead of four)
+    //   direct   they are not: O_DIRECT reads into the pinned buffer -- no kernel copy, no page cache pollution (35 GB per
+    //            core-second against 3.8 for buffered reads of a cold file, and the storage's full rate)
+    //   pread    buffered reads into the pinned buffer (rounds 1-5): mappings or O_DIRECT not available, NGSQ_READER_PATH=pread
+    const char *path_env = getenv("NGSQ_READER_PATH"); // measurement aid: mapped | direct | pread | auto
+    const std::string path_mode = path_env ? path_env : "auto";
+    const uint8_t *fmap = nullptr;
+    if (path_mode == "auto" || path_mode == "mapped") {
+        void *m = d->file_size ? mmap(nullptr, d->file_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+        if (m != MAP_FAILED) fmap = static_cast<const uint8_t *>(m);
+    }
+    int fd_direct = -1;
+    if (path_mode == "auto" || path_mode == "direct") fd_direct = open(path.c_str(), O_RDONLY | O_DIRECT | O_CLOEXEC);
+    struct Closer {
+        const uint8_t *m;
+        uint64_t n;
+        int fd;
+        ~Closer() {
+            if (m) munmap(const_cast<uint8_t *>(m), n);
+            if (fd >= 0) close(fd);
         }
+    } closer{fmap, d->file_size, fd_direct};
+    // how much of file[lo, hi) the page cache holds: every 16th page of the range is looked at
+    auto resident = [&](uint64_t lo, uint64_t hi) -> double {
+        if (!fmap || hi <= lo) return 0.0;
+        const uint64_t a = lo & ~(uint64_t)4095;
+        const size_t pages = (size_t)((hi - a + 4095) >> 12);
+        std::vector<unsigned char> vec(pages);
+        if (mincore(const_cast<uint8_t *>(fmap) + a, hi - a, vec.data()) != 0) return 0.0;
+        size_t seen = 0, in = 0;
+        for (size_t i = 0; i < pages; i += 16) {
+            seen++;
+            in += vec[i] & 1;
+        }
+        return seen ? (double)in / (double)seen : 0.0;
+    };
+    ReadPool pool;
+    pool.fd_direct = fd_direct;
+    bool pool_open = false; // (a file that is scanned out of the page cache never starts the pread workers)
+    if (hipSetDevice(d->ctx->device) != hipSuccess) {
+        {
+            std::lock_guard<std::mutex> g(d->mu);
+            d->hc[0].err = path + ": hipSetDevice failed in the reader thread";
+            d->hc[0].last = true;
+            d->hc[0].ready = true;
+        }
+        d->cv.notify_all();
+        return;
     }
     uint64_t chunk_no = 0;
     for (int k = 0;; k = (k + 1) % DeviceIngest::NC, chunk_no++) {
@@ -528,38 +588,39 @@ void reader_main(DeviceIngest *d, std::string path) {
         {
             std::unique_lock<std::mutex> g(d->mu);
             d->cv.wait(g, [&] { return d->stop || !c.ready; });
-            if (d->stop) {
-                if (alloc1.joinable()) alloc1.join();
-                return;
-            }
+            if (d->stop) return;
         }
-        if (k == 1 && alloc1.joinable()) {
-            alloc1.join();
-            if (!alloc1_err.empty()) {
+        // ---- where this chunk's bytes are: in the page cache (then the chunk is the mapping), or not (pinned buffer, O_DIRECT)
+        const uint64_t chunk_off = file_pos - leftover.size(); // file offset of the chunk's first byte
+        {
+            const uint64_t look = std::min<uint64_t>(d->pos_end, chunk_off + std::min<uint64_t>(cap, (uint64_t)256 << 20));
+            const double in_cache = (path_mode == "direct" || path_mode == "pread") ? 0.0 : resident(chunk_off, look);
+            c.mapped = fmap && (path_mode == "mapped" || in_cache >= 0.95);
+            cold = !c.mapped && fd_direct >= 0 && (path_mode == "direct" || in_cache < 0.5);
+        }
+        if (!c.mapped) {
+            if (!c.pin && ngsq::pool_pinned_alloc((void **)&c.pin, cap + 8192, &c.h_bytes) != hipSuccess) {
                 {
                     std::lock_guard<std::mutex> g(d->mu);
-                    c.err = path + ": " + alloc1_err;
+                    c.err = path + ": hipHostMalloc of the ingest buffers failed";
                     c.last = true;
                     c.ready = true;
                 }
                 d->cv.notify_all();
                 return;
             }
-        }
-        if (!c.h && ngsq::pool_pinned_alloc((void **)&c.h, cap, &c.h_bytes) != hipSuccess) { // (the third and fourth: when the file gets that far)
-            {
-                std::lock_guard<std::mutex> g(d->mu);
-                c.err = path + ": hipHostMalloc of the ingest buffers failed";
-                c.last = true;
-                c.ready = true;
+            if (!pool_open) {
+                pool.open(NT, fd);
+                pool_open = true;
             }
-            d->cv.notify_all();
-            return;
+            c.h = c.pin + (chunk_off & 4095); // address == file offset (mod 4096): O_DIRECT reads whole sectors in place
+        } else {
+            c.h = const_cast<uint8_t *>(fmap) + chunk_off;
         }
         const double tr0 = now_ms();
         double t_frame = 0, t_send = 0, t_join = 0, t_spawn = 0;
         int n_steps = 0;
-        memcpy(c.h, leftover.data(), leftover.size());
+        if (!c.mapped) memcpy(c.h, leftover.data(), leftover.size()); // (a mapped chunk simply starts that many bytes earlier in the file)
         c.fill = leftover.size();
         c.file_off = file_pos - leftover.size();
         c.err.clear();
@@ -588,7 +649,9 @@ void reader_main(DeviceIngest *d, std::string path) {
         auto send = [&]() {
             if (h2d_ok && c.err.empty() && c.consumed > sent) {
                 const double ts = now_ms();
-                h2d_ok = ngsq::pool_pinned_h2d(d->d_comp_slot[k].p + sent, c.h, sent, c.consumed - sent, d->copy_stream) == hipSuccess;
+                // (from the mapping: the runtime pins the pages and copies from them -- the call returns when the bytes have left)
+                h2d_ok = (c.mapped ? hipMemcpyAsync(d->d_comp_slot[k].p + sent, c.h + sent, c.consumed - sent, hipMemcpyHostToDevice, d->copy_stream)
+                                   : ngsq::pool_pinned_h2d(d->d_comp_slot[k].p + sent, c.pin, (size_t)(c.h - c.pin) + sent, c.consumed - sent, d->copy_stream)) == hipSuccess;
                 sent = c.consumed;
                 t_send += now_ms() - ts;
             }
@@ -634,26 +697,40 @@ void reader_main(DeviceIngest *d, std::string path) {
             want = std::min(want, ReadPool::PIECE * ReadPool::MAX_PIECES);
             const double tsp = now_ms();
             n_steps++;
-            pool.start(c.h + c.fill, file_pos, want, cold);
-            t_spawn += now_ms() - tsp;
-            // what has arrived is framed and sent while the rest is read, STEP bytes at a time
             const size_t fill0 = c.fill;
             size_t avail = 0;
-            bool all = false, short_read = false;
-            while (!all) {
-                const double tj = now_ms();
-                pool.wait_prefix(std::min(want, avail + STEP), &avail, &all, &short_read);
-                t_join += now_ms() - tj;
-                c.fill = fill0 + avail;
-                if (c.err.empty() && !full) {
-                    frame();
-                    send();
+            bool short_read = false;
+            if (c.mapped) {
+                // nothing to read: the bytes are where they are; framed and sent STEP bytes at a time (the copies pin as they go)
+                const size_t have = (size_t)std::min<uint64_t>(want, d->file_size > file_pos ? d->file_size - file_pos : 0);
+                short_read = have < want;
+                while (avail < have) {
+                    avail = std::min(have, avail + STEP);
+                    c.fill = fill0 + avail;
+                    if (c.err.empty() && !full) {
+                        frame();
+                        send();
+                    }
                 }
+            } else {
+                pool.start(c.h + c.fill, file_pos, want, cold);
+                t_spawn += now_ms() - tsp;
+                // what has arrived is framed and sent while the rest is read, STEP bytes at a time
+                bool all = false;
+                while (!all) {
+                    const double tj = now_ms();
+                    pool.wait_prefix(std::min(want, avail + STEP), &avail, &all, &short_read);
+                    t_join += now_ms() - tj;
+                    c.fill = fill0 + avail;
+                    if (c.err.empty() && !full) {
+                        frame();
+                        send();
+                    }
+                }
+                if (pool.bad) c.err = "read error on " + path;
+                // (without O_DIRECT: below 1.2 GB/s per read thread the bytes did not come out of the page cache -- larger pieces then)
+                if (fd_direct < 0 && avail >= ((size_t)32 << 20)) cold = (double)avail / ((now_ms() - tsp) * 1e-3) < 1.2e9 * NT;
             }
-            if (pool.bad) c.err = "read error on " + path;
-            // below 1.2 GB/s per read thread the bytes did not come out of the page cache (which gives each of them twice that
-            // and more; a dozen threads on storage get 0.9 each)
-            if (avail >= ((size_t)32 << 20)) cold = (double)avail / ((now_ms() - tsp) * 1e-3) < 1.2e9 * NT;
             if (avail < want || short_read) eof = true;
             file_pos += avail;
             if (file_pos >= d->pos_end) eof = true;
@@ -705,10 +782,7 @@ void reader_main(DeviceIngest *d, std::string path) {
             c.ready = true;
         }
         d->cv.notify_all();
-        if (last) {
-            if (alloc1.joinable()) alloc1.join();
-            return;
-        }
+        if (last) return;
     }
 }
 
@@ -875,7 +949,8 @@ int issue_inflate(ngsq_bam *b, DeviceIngest *d, uint64_t j) {
             BHIP(d->d_comp_slot[k].reserve(p.consumed + INFLATE_IN_SLACK));
             if (d->d_comp_slot[k].p != slot_was) BHIP(hipMemsetAsync(d->d_comp_slot[k].p, 0, d->d_comp_slot[k].bytes, sb));
         }
-        BHIP(ngsq::pool_pinned_h2d(d->d_comp_slot[k].p, c.h, 0, p.consumed, sb));
+        if (c.mapped) BHIP(hipMemcpyAsync(d->d_comp_slot[k].p, c.h, p.consumed, hipMemcpyHostToDevice, sb));
+        else BHIP(ngsq::pool_pinned_h2d(d->d_comp_slot[k].p, c.pin, (size_t)(c.h - c.pin), p.consumed, sb));
         BHIP(launch_copy_words(d->d_blocks_s[k].p, dev_of(p.pin_blocks), p.n_blk * sizeof(BgzfBlock), sb));
         BHIP(launch_copy_words(d->d_coff_s[k].p, dev_of(p.pin_coff), p.n_blk * sizeof(uint64_t), sb));
     }

@@ -815,8 +815,8 @@ int ngsq_process_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t pass_mask) {
     rc = launch_all(c, db, cs, pass_mask);
     if (rc != NGSQ_OK) return rc;
     HIP_TRY(c, hipEventRecord(sg.done, c->stream));
-    // the caller may reuse its (possibly pinned) buffers once the copies have landed
-    HIP_TRY(c, hipEventSynchronize(c->copy_done));
+    // the caller may reuse its (possibly pinned) buffers once the copies have landed (NGSQ_PASS_NOWAIT: the caller waits itself)
+    if (!(pass_mask & NGSQ_PASS_NOWAIT)) HIP_TRY(c, hipEventSynchronize(c->copy_done));
     return NGSQ_OK;
 }
 

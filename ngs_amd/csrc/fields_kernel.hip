@@ -257,6 +257,39 @@ __global__ __launch_bounds__(FT_THREADS, 4) void k_fields(DeviceState st, Device
                 }
             }
         }
+        // ---- the per-sequence run-length tallies of the lanes (`seen`, STREAM: the largest end) are flushed HERE, once per wave,
+        // when the wave has moved on to another sequence.  A block strides through the file a grid's worth of tiles at a time: on a
+        // real header (195 sequences) nearly every tile of a block lies on another sequence than its last one, and until round 6
+        // every LANE then flushed its run with an atomic of its own on the same few words -- 256 same-address atomics per tile
+        // and block: 42 ms for 20 M records spread over the GRCh38 sequences, against 0.16 ms for the same records on chr1 alone
+        // (bench.py whole_genome; no test or leg had more than four sequences before).
+        if (a.do_cov) {
+            const int32_t fr = __builtin_amdgcn_readfirstlane(ref[0]);
+            const bool stale = seen_cnt != 0 && seen_ref != fr;
+            const u64 sm = __ballot(stale);
+            if (sm) {
+                const int32_t rr = __shfl(seen_ref, __ffsll((long long)sm) - 1, 64);
+                const bool same = stale && seen_ref == rr;
+                const uint32_t sum = ft_wave_sum(same ? seen_cnt : 0u);
+                if (lane == 0 && sum) atomicAdd(&st.counters[st.off_seen + rr], (u64)sum);
+                if (stale && !same) atomicAdd(&st.counters[st.off_seen + seen_ref], (u64)seen_cnt);
+                if (stale) seen_cnt = 0;
+            }
+            if (STREAM) {
+                const bool stale_e = run_end != 0 && run_ref != fr;
+                const u64 em = __ballot(stale_e);
+                if (em) {
+                    const int32_t rr = __shfl(run_ref, __ffsll((long long)em) - 1, 64);
+                    const bool same = stale_e && run_ref == rr;
+                    uint32_t m = same ? run_end : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor(m, o, 64));
+                    if (lane == 0 && m) atomicMax(&st.end_acc[rr], m);
+                    if (stale_e && !same) atomicMax(&st.end_acc[run_ref], run_end);
+                    if (stale_e) run_end = 0;
+                }
+            }
+        }
         uint32_t my_max = 0;
         uint32_t cend[4] = {0, 0, 0, 0}; // STREAM: exclusive alignment end of each record (0: covers nothing)
         if (STREAM) { // coordinate order of adjacent records; unplaced (-1) sorts last, as in a sorted BAM

@@ -54,17 +54,30 @@ constexpr size_t SLACK = NGSQ_DEVICE_COLUMN_SLACK; // the staged copies are read
 
 } // namespace
 
+// one set of staging columns
+struct ColSet {
+    Col flag, mapq, ref_id, pos, mate, tlen, l_seq, n_cigar, rid, seq, qual, cigar, seq_off, qual_off, cigar_off;
+    Col *all[15] = {&flag, &mapq, &ref_id, &pos, &mate, &tlen, &l_seq, &n_cigar, &rid, &seq, &qual, &cigar, &seq_off, &qual_off, &cigar_off};
+    hipEvent_t busy = nullptr; // recorded behind the flush that handed this set over: its copies have landed when it completes
+    bool in_flight = false;
+};
+
+// The columns exist TWICE when they are pinned (round 6): a flush hands one set to ngsq_process_batch without waiting for the
+// copies to land (NGSQ_PASS_NOWAIT), records an event on the context's stream and goes on pushing into the other set; a set is
+// waited for only when it comes round again -- a flush later, when its copies (5 ms per million records) have long landed.  Until
+// then the pushing thread sat out every copy: 27 M records/s per core against 31 M for the pushes alone.
 struct ngsq_stager {
     uint64_t capacity = 0, n = 0, pushed = 0, first_index = 0;
     uint32_t flags = 0;
-    Col flag, mapq, ref_id, pos, mate, tlen, l_seq, n_cigar, rid, seq, qual, cigar, seq_off, qual_off, cigar_off;
+    ColSet set[2];
+    int cur = 0;
+    ColSet &k() { return set[cur]; }
     uint64_t so = 0, qo = 0, co = 0; // bytes / operations staged
     uint64_t n_with_id = 0;
     // what decides the layout of a flush
     uint32_t first_l = 0, max_l = 0;
     bool same_len = true, all_quals = true, one_op = true;
     std::string err;
-    Col *all[15] = {&flag, &mapq, &ref_id, &pos, &mate, &tlen, &l_seq, &n_cigar, &rid, &seq, &qual, &cigar, &seq_off, &qual_off, &cigar_off};
 };
 
 static int sfail(ngsq_stager *s, int code, const char *fmt, ...) {
@@ -104,27 +117,43 @@ int ngsq_stager_create(uint64_t capacity, uint32_t flags, ngsq_stager **out) {
     ngsq_stager *s = new ngsq_stager();
     s->capacity = capacity;
     s->flags = flags;
-    for (Col *c : s->all) c->pinned = pinned;
     const uint64_t n = capacity;
-    bool ok = s->flag.reserve(n * 2 + SLACK) && s->mapq.reserve(n + SLACK) && s->ref_id.reserve(n * 4 + SLACK) && s->pos.reserve(n * 4 + SLACK) &&
-              s->mate.reserve(n * 4 + SLACK) && s->tlen.reserve(n * 4 + SLACK) && s->l_seq.reserve(n * 4 + SLACK) && s->n_cigar.reserve(n * 2 + SLACK) &&
-              s->rid.reserve(n * 8 + SLACK) && s->seq_off.reserve((n + 1) * 8) && s->qual_off.reserve((n + 1) * 8) && s->cigar_off.reserve((n + 1) * 8) &&
-              // the byte columns start sized for short reads and grow with what is pushed
-              s->seq.reserve(n * 80 + SLACK) && s->qual.reserve(n * 160 + SLACK) && s->cigar.reserve(n * 8 + SLACK);
+    bool ok = true;
+    for (int q = 0; q < (pinned ? 2 : 1) && ok; q++) { // (ordinary memory is copied from synchronously anyway: one set)
+        ColSet &k = s->set[q];
+        for (Col *c : k.all) c->pinned = pinned;
+        ok = k.flag.reserve(n * 2 + SLACK) && k.mapq.reserve(n + SLACK) && k.ref_id.reserve(n * 4 + SLACK) && k.pos.reserve(n * 4 + SLACK) &&
+             k.mate.reserve(n * 4 + SLACK) && k.tlen.reserve(n * 4 + SLACK) && k.l_seq.reserve(n * 4 + SLACK) && k.n_cigar.reserve(n * 2 + SLACK) &&
+             k.rid.reserve(n * 8 + SLACK) && k.seq_off.reserve((n + 1) * 8) && k.qual_off.reserve((n + 1) * 8) && k.cigar_off.reserve((n + 1) * 8) &&
+             // the byte columns start sized for short reads and grow with what is pushed
+             k.seq.reserve(n * 80 + SLACK) && k.qual.reserve(n * 160 + SLACK) && k.cigar.reserve(n * 8 + SLACK);
+        if (ok) {
+            reinterpret_cast<uint64_t *>(k.seq_off.p)[0] = 0;
+            reinterpret_cast<uint64_t *>(k.qual_off.p)[0] = 0;
+            reinterpret_cast<uint64_t *>(k.cigar_off.p)[0] = 0;
+        }
+        if (ok && pinned && hipEventCreateWithFlags(&k.busy, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+        }
+    }
     if (!ok) {
         ngsq_stager_destroy(s);
         return sfail(nullptr, NGSQ_ERR_DEVICE, "could not allocate the staging columns for %llu records", (unsigned long long)capacity);
     }
-    reinterpret_cast<uint64_t *>(s->seq_off.p)[0] = 0;
-    reinterpret_cast<uint64_t *>(s->qual_off.p)[0] = 0;
-    reinterpret_cast<uint64_t *>(s->cigar_off.p)[0] = 0;
     *out = s;
     return NGSQ_OK;
 }
 
 void ngsq_stager_destroy(ngsq_stager *s) {
     if (!s) return;
-    for (Col *c : s->all) c->release();
+    for (ColSet &k : s->set) {
+        if (k.busy) {
+            if (k.in_flight) (void)hipEventSynchronize(k.busy); // (the copies read these columns)
+            (void)hipEventDestroy(k.busy);
+        }
+        for (Col *c : k.all) c->release();
+    }
     delete s;
 }
 
@@ -147,21 +176,21 @@ static int push_common(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t ref_
     const bool has_id = record_id != NGSQ_STAGE_NO_ID;
     if (s->n && (s->n_with_id != 0) != has_id)
         return sfail(s, NGSQ_ERR_INVALID_ARGUMENT, "records with and without a record_id in one flush");
-    if (!s->seq.reserve(s->so + ((uint64_t)l + 1) / 2 + SLACK) || !s->qual.reserve(s->qo + n_quals + SLACK) || !s->cigar.reserve((s->co + n_cigar) * 4 + SLACK))
+    if (!s->k().seq.reserve(s->so + ((uint64_t)l + 1) / 2 + SLACK) || !s->k().qual.reserve(s->qo + n_quals + SLACK) || !s->k().cigar.reserve((s->co + n_cigar) * 4 + SLACK))
         return sfail(s, NGSQ_ERR_DEVICE, "could not grow the staging columns");
     const uint64_t i = s->n;
-    reinterpret_cast<uint16_t *>(s->flag.p)[i] = flag;
-    s->mapq.p[i] = mapq;
-    reinterpret_cast<int32_t *>(s->ref_id.p)[i] = ref_id;
-    reinterpret_cast<int32_t *>(s->pos.p)[i] = pos;
-    reinterpret_cast<int32_t *>(s->mate.p)[i] = mate;
-    reinterpret_cast<int32_t *>(s->tlen.p)[i] = tlen;
-    reinterpret_cast<uint32_t *>(s->l_seq.p)[i] = l;
-    reinterpret_cast<uint16_t *>(s->n_cigar.p)[i] = (uint16_t)(n_cigar < 0xFFFFu ? n_cigar : 0xFFFFu); // saturates (ngsq.h, ABI 5)
-    reinterpret_cast<uint64_t *>(s->rid.p)[i] = has_id ? record_id : s->first_index + s->pushed;
-    if (n_cigar) memcpy(s->cigar.p + s->co * 4, cigar, (size_t)n_cigar * 4);
+    reinterpret_cast<uint16_t *>(s->k().flag.p)[i] = flag;
+    s->k().mapq.p[i] = mapq;
+    reinterpret_cast<int32_t *>(s->k().ref_id.p)[i] = ref_id;
+    reinterpret_cast<int32_t *>(s->k().pos.p)[i] = pos;
+    reinterpret_cast<int32_t *>(s->k().mate.p)[i] = mate;
+    reinterpret_cast<int32_t *>(s->k().tlen.p)[i] = tlen;
+    reinterpret_cast<uint32_t *>(s->k().l_seq.p)[i] = l;
+    reinterpret_cast<uint16_t *>(s->k().n_cigar.p)[i] = (uint16_t)(n_cigar < 0xFFFFu ? n_cigar : 0xFFFFu); // saturates (ngsq.h, ABI 5)
+    reinterpret_cast<uint64_t *>(s->k().rid.p)[i] = has_id ? record_id : s->first_index + s->pushed;
+    if (n_cigar) memcpy(s->k().cigar.p + s->co * 4, cigar, (size_t)n_cigar * 4);
     s->co += n_cigar;
-    reinterpret_cast<uint64_t *>(s->cigar_off.p)[i + 1] = s->co;
+    reinterpret_cast<uint64_t *>(s->k().cigar_off.p)[i + 1] = s->co;
     if (i == 0) s->first_l = l;
     s->same_len = s->same_len && l == s->first_l;
     s->all_quals = s->all_quals && (n_quals == l);
@@ -174,8 +203,8 @@ static int push_common(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t ref_
 static void finish_row(ngsq_stager *s, uint32_t l, uint32_t n_quals) {
     s->so += (l + 1) / 2;
     s->qo += n_quals;
-    reinterpret_cast<uint64_t *>(s->seq_off.p)[s->n + 1] = s->so;
-    reinterpret_cast<uint64_t *>(s->qual_off.p)[s->n + 1] = s->qo;
+    reinterpret_cast<uint64_t *>(s->k().seq_off.p)[s->n + 1] = s->so;
+    reinterpret_cast<uint64_t *>(s->k().qual_off.p)[s->n + 1] = s->qo;
     s->n += 1;
     s->pushed += 1;
 }
@@ -201,11 +230,11 @@ int ngsq_stager_push(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t ref_id
     }
     int rc = push_common(s, flag, mapq, ref_id, pos, mate_ref_id, tlen, l_seq, n_quals, cigar, n_cigar, record_id);
     if (rc != NGSQ_OK) return rc;
-    uint8_t *dst = s->seq.p + s->so; // BAM's packing: two bases per byte, high nibble first, a trailing low nibble of zero
+    uint8_t *dst = s->k().seq.p + s->so; // BAM's packing: two bases per byte, high nibble first, a trailing low nibble of zero
     uint32_t k = 0;
     for (; k + 1 < l_seq; k += 2) *dst++ = (uint8_t)(bases[k] << 4 | bases[k + 1]);
     if (k < l_seq) *dst = (uint8_t)(bases[k] << 4);
-    if (n_quals) memcpy(s->qual.p + s->qo, quals, n_quals);
+    if (n_quals) memcpy(s->k().qual.p + s->qo, quals, n_quals);
     finish_row(s, l_seq, n_quals);
     return NGSQ_OK;
 }
@@ -223,10 +252,10 @@ int ngsq_stager_push_packed(ngsq_stager *s, uint16_t flag, uint8_t mapq, int32_t
     int rc = push_common(s, flag, mapq, ref_id, pos, mate_ref_id, tlen, l_seq, n_quals, cigar, n_cigar, record_id);
     if (rc != NGSQ_OK) return rc;
     if (l_seq) {
-        memcpy(s->seq.p + s->so, seq_packed, (l_seq + 1) / 2);
-        if (l_seq & 1) s->seq.p[s->so + l_seq / 2] &= 0xF0; // the unused low nibble reads as '=' (0), as noodles never looks at it
+        memcpy(s->k().seq.p + s->so, seq_packed, (l_seq + 1) / 2);
+        if (l_seq & 1) s->k().seq.p[s->so + l_seq / 2] &= 0xF0; // the unused low nibble reads as '=' (0), as noodles never looks at it
     }
-    if (n_quals) memcpy(s->qual.p + s->qo, quals, n_quals);
+    if (n_quals) memcpy(s->k().qual.p + s->qo, quals, n_quals);
     finish_row(s, l_seq, n_quals);
     return NGSQ_OK;
 }
@@ -264,18 +293,18 @@ int ngsq_stager_view(ngsq_stager *s, ngsq_batch *o) {
     o->location = NGSQ_MEM_HOST;
     o->n_records = s->n;
     o->first_record_index = s->first_index + s->pushed - s->n;
-    o->flag = reinterpret_cast<uint16_t *>(s->flag.p);
-    o->mapq = s->mapq.p;
-    o->ref_id = reinterpret_cast<int32_t *>(s->ref_id.p);
-    o->pos = reinterpret_cast<int32_t *>(s->pos.p);
-    o->mate_ref_id = reinterpret_cast<int32_t *>(s->mate.p);
-    o->tlen = reinterpret_cast<int32_t *>(s->tlen.p);
-    o->l_seq = reinterpret_cast<uint32_t *>(s->l_seq.p);
-    o->n_cigar = reinterpret_cast<uint16_t *>(s->n_cigar.p);
-    o->seq = s->seq.p;
-    o->qual = s->qual.p;
-    o->cigar = reinterpret_cast<uint32_t *>(s->cigar.p);
-    o->record_id = s->n_with_id ? reinterpret_cast<uint64_t *>(s->rid.p) : nullptr;
+    o->flag = reinterpret_cast<uint16_t *>(s->k().flag.p);
+    o->mapq = s->k().mapq.p;
+    o->ref_id = reinterpret_cast<int32_t *>(s->k().ref_id.p);
+    o->pos = reinterpret_cast<int32_t *>(s->k().pos.p);
+    o->mate_ref_id = reinterpret_cast<int32_t *>(s->k().mate.p);
+    o->tlen = reinterpret_cast<int32_t *>(s->k().tlen.p);
+    o->l_seq = reinterpret_cast<uint32_t *>(s->k().l_seq.p);
+    o->n_cigar = reinterpret_cast<uint16_t *>(s->k().n_cigar.p);
+    o->seq = s->k().seq.p;
+    o->qual = s->k().qual.p;
+    o->cigar = reinterpret_cast<uint32_t *>(s->k().cigar.p);
+    o->record_id = s->n_with_id ? reinterpret_cast<uint64_t *>(s->k().rid.p) : nullptr;
     o->max_l_seq = s->max_l;
     o->seq_bytes = s->so;
     o->qual_bytes = s->qo;
@@ -287,15 +316,15 @@ int ngsq_stager_view(ngsq_stager *s, ngsq_batch *o) {
         o->seq_stride = (s->first_l + 1) / 2;
         o->qual_stride = s->first_l;
     } else {
-        o->seq_off = reinterpret_cast<uint64_t *>(s->seq_off.p);
-        o->qual_off = reinterpret_cast<uint64_t *>(s->qual_off.p);
+        o->seq_off = reinterpret_cast<uint64_t *>(s->k().seq_off.p);
+        o->qual_off = reinterpret_cast<uint64_t *>(s->k().qual_off.p);
     }
     if (!(s->flags & NGSQ_STAGE_OFFSETS_ONLY) && s->n && s->one_op) o->cigar_stride = 1;
-    else o->cigar_off = reinterpret_cast<uint64_t *>(s->cigar_off.p);
+    else o->cigar_off = reinterpret_cast<uint64_t *>(s->k().cigar_off.p);
     // what the device's vector loads read behind the last row: "no score" / '=' (values never counted)
-    memset(s->seq.p + s->so, 0, SLACK);
-    memset(s->qual.p + s->qo, 0xFF, SLACK);
-    memset(s->cigar.p + s->co * 4, 0, SLACK);
+    memset(s->k().seq.p + s->so, 0, SLACK);
+    memset(s->k().qual.p + s->qo, 0xFF, SLACK);
+    memset(s->k().cigar.p + s->co * 4, 0, SLACK);
     return NGSQ_OK;
 }
 
@@ -304,8 +333,31 @@ int ngsq_stager_flush(ngsq_stager *s, ngsq_ctx *ctx, uint32_t pass_mask) {
     if (!s->n) return NGSQ_OK;
     ngsq_batch b;
     ngsq_stager_view(s, &b);
-    const int rc = ngsq_process_batch(ctx, &b, pass_mask); // (returns when the copies have landed: the columns are free again)
-    if (rc != NGSQ_OK) return sfail(s, rc, "ngsq_process_batch: %s", ngsq_last_error(ctx));
+    ColSet &k = s->k();
+    if (!k.busy) { // ordinary memory: the copies are synchronous, the columns are free again when the call returns
+        const int rc = ngsq_process_batch(ctx, &b, pass_mask);
+        if (rc != NGSQ_OK) return sfail(s, rc, "ngsq_process_batch: %s", ngsq_last_error(ctx));
+        clear(s);
+        return NGSQ_OK;
+    }
+    // pinned: the copies are queued, an event behind them says when this set may be written again, the pushes go on in the other
+    const int rc = ngsq_process_batch(ctx, &b, pass_mask | NGSQ_PASS_NOWAIT);
+    if (rc != NGSQ_OK) {
+        (void)ngsq_synchronize(ctx); // (whatever was queued of it has read the columns)
+        return sfail(s, rc, "ngsq_process_batch: %s", ngsq_last_error(ctx));
+    }
+    if (hipEventRecord(k.busy, static_cast<hipStream_t>(ngsq_stream(ctx))) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ngsq_synchronize(ctx) != NGSQ_OK) return sfail(s, NGSQ_ERR_DEVICE, "could not wait for the staged batch");
+    } else {
+        k.in_flight = true;
+    }
+    s->cur ^= 1;
+    ColSet &next = s->k();
+    if (next.in_flight) { // handed over one flush ago
+        if (hipEventSynchronize(next.busy) != hipSuccess) return sfail(s, NGSQ_ERR_DEVICE, "hipEventSynchronize failed (staged batch)");
+        next.in_flight = false;
+    }
     clear(s);
     return NGSQ_OK;
 }

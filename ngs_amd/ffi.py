@@ -48,6 +48,7 @@ MEM_DEVICE = 1
 PASS_RECORD = 1
 PASS_SEQUENCE = 2
 PASS_BOTH = 3
+PASS_NOWAIT = 0x100
 
 SYNTH_FIXED = 0
 SYNTH_MIXED = 1

@@ -432,6 +432,25 @@ def test_gpus_flag_workers_share_one_file(ngs, gpu_lib, oracle_mod, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpus_8_workers_on_one_device(ngs, gpu_lib, oracle_mod, tmp_path):
+    """`ngs qc --gpus 8 --same-device`: the launcher, eight workers, the eight-way reader split of the CPU quota
+    (bam_device_reader.cpp: max(2, (quota - 2 n) / n) threads each), seven boundaries, one exchange -- over shared memory and
+    over the RCCL transport bound to tests/rccl_double; the document equals the oracle's."""
+    hb = sorted_batch(17, 64_000, max_len=200, min_len=40)
+    bam = str(tmp_path / "g8.bam")
+    hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS, block_payload=9_000))
+    want = oracle_json(oracle_mod, hb)
+    from tests.test_shard_gloo import rccl_double_path
+    for k, (extra, env) in enumerate(((["--coverage", "auto"], None), (["--coverage", "array"], None),
+                                      (["--transport", "rccl"], dict(os.environ, NGSQ_RCCL_LIB=rccl_double_path())))):
+        out = tmp_path / f"w{k}"
+        r = run(ngs, "qc", bam, GENOME, "-o", str(out), "--gpus", "8", "--same-device", "--batch-records", "3001", *extra, env=env)
+        assert r.returncode == 0, r.stderr
+        assert "Worker 0 of 8 on device 0, exchange over %s." % ("rccl" if env else "shm") in r.stderr
+        json_equal(json.load(open(out / "g8.bam.results.json")), want)
+
+
+@pytest.mark.gpu
 def test_baseline_config_0_general_only(ngs, gpu_lib, oracle_mod, tmp_path):
     """BASELINE.json configs[0] verbatim: `ngs qc` general-metrics-only (--only General) on a 10k-record 150 bp
     single-reference BAM (one @SQ chr1 LN:248956422, the synthetic workload's records written as a real BGZF BAM +

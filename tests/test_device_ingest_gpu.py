@@ -494,17 +494,18 @@ def _file_shard_worker(rank, world, port, q, bam, writer, transport=None, wrong_
         # "wrong-guess": rank 1 starts from a deliberately wrong first record (one record too late): the shards notice
         # when they compare notes, rank 1 is re-armed from rank 0's end and scans again
         hook = None
-        if wrong_guess and rank == 1:
+        wrong_rank = 1 if world <= 3 else 5
+        if wrong_guess and rank == wrong_rank:
             def hook(h):
                 probe = C.c_void_p()
                 assert lib.ngsq_bam_open(bam.encode(), 1, C.byref(probe)) == 0
-                assert lib.ngsq_bam_shard_begin(probe, ctx._ctx, 1, world, 0) == 0, lib.ngsq_bam_last_error()
+                assert lib.ngsq_bam_shard_begin(probe, ctx._ctx, wrong_rank, world, 0) == 0, lib.ngsq_bam_last_error()
                 b = F.Batch()
                 assert lib.ngsq_bam_next_batch_device(probe, ctx._ctx, 2, C.byref(b)) == 0 and b.n_records == 2
                 ids = np.empty(2, dtype=np.uint64)
                 assert lib.ngsq_memcpy_d2h(ctx._ctx, ids.ctypes.data, b.record_id, 16) == 0
                 lib.ngsq_bam_close(probe)
-                assert lib.ngsq_bam_shard_begin(h, ctx._ctx, 1, world, int(ids[1])) == 0, lib.ngsq_bam_last_error()
+                assert lib.ngsq_bam_shard_begin(h, ctx._ctx, wrong_rank, world, int(ids[1])) == 0, lib.ngsq_bam_last_error()
         info, rounds, mine = comm.scan_file_shard(ctx, bam, batch_records=7_000, begin_hook=hook)
         assert mine == info.n_records
         if writer == "adversarial":   # the test looks at the sum over the ranks
@@ -568,6 +569,31 @@ def test_three_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport, wr
     if writer == "adversarial":
         rounds = [int(open(f"{bam}.rounds{r}").read()) for r in range(3)]
         assert max(rounds) >= 1, rounds      # at least one shard's guess was a fake record: found out and scanned again
+
+
+@pytest.mark.parametrize("writer,transport,wrong", [("synth", None, False), ("straddling", "rccl-double", True), ("tail-heavy", None, False)])
+def test_eight_ranks_share_one_bam_file(gpu_lib, tmp_path, writer, transport, wrong):
+    """The same with EIGHT ranks (sharing this box's GPU): seven boundaries found independently and compared in one round, a
+    wrong first record planted on rank 5 (found out, re-armed from rank 4's end, scanned again), and -- "tail-heavy" -- a file
+    whose last eighth holds no record start at all (one record of 300 kb ends the file: rank 7 is an EMPTY shard and passes
+    its predecessor's end on)."""
+    bam = str(tmp_path / "f.bam")
+    if writer == "synth":
+        cfg = host.synth_config(320_000, mode=ffi.SYNTH_MIXED, ref_len=3_000_000)
+        assert gpu_lib.ngsq_synth_write_bam(C.byref(cfg), bam.encode(), 320_000, 6, 4) == 0
+    else:
+        rng = np.random.default_rng(29)
+        hb = random_batch(rng, 24_000, [50_000, 7_000], max_len=200, weird=False)
+        hb.cols["flag"] &= np.uint16(0xFFFF ^ 0x1)
+        if writer == "tail-heavy":
+            from tests.util import batch_from_records
+            from tests.genome_util import concat
+            big = batch_from_records([dict(flag=4, ref_id=-1, pos=-1, cigar="*", seq="".join(rng.choice(list("ACGT"), 300_000)),
+                                           qual=[int(x) for x in rng.integers(0, 41, 300_000)])])
+            hb = concat(hb.slice(0, 1500), big)   # ~200 kB of records, then ONE of 250 kB (compressed): the last ranks' ranges lie inside it
+        bamio.write_bam(bam, hb, ["chr1", "chr2"], [50_000, 7_000], block_payload=3000, sort_order="unsorted" if writer == "tail-heavy" else "coordinate")
+    from tests.test_shard_gloo import _run_ranks
+    _run_ranks(_file_shard_worker, 8, bam, writer, transport, wrong)
 
 
 def test_shard_begin_end_api(gpu_lib, ctx, tmp_path, monkeypatch):

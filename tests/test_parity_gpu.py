@@ -790,7 +790,8 @@ def _rank_worker(rank, world, port, q, mode, transport):
 
         comm, done = _make_comm(transport, rank, world, port)
         lib = F.load_library()
-        n, L = 90_000, 700_000
+        # (eight ranks -- the node this is for: 200 k records and 200 Coverage chunks per rank)
+        n, L = (90_000, 700_000) if world <= 3 else (200_000 * world, 800_000 * world)
         ref_len = [L, 50_000]
         stream = "stream" in mode   # sorted_input contexts: Coverage streamed, only the seams are exchanged
         scfg = H.synth_config(n, mode=F.SYNTH_MIXED if "mixed" in mode else F.SYNTH_FIXED, ref_len=L, n_refs=2)
@@ -854,6 +855,16 @@ def _rank_worker(rank, world, port, q, mode, transport):
 def test_three_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode, transport):
     from tests.test_shard_gloo import _run_ranks
     _run_ranks(_rank_worker, 3, mode, transport)
+
+
+@pytest.mark.parametrize("mode,transport", [("fixed", "shm"), ("mixed-stream", "shm"), ("edits", "rccl-double"), ("fixed-stream", "rccl-double"),
+                                            ("stream-overlap", "rccl-double")])
+def test_eight_ranks_owner_computes_teardown(gpu_lib, oracle_mod, mode, transport):
+    """The world the library is for -- eight ranks, here sharing this box's one GPU (no more than three had ever
+    run together): the exchange plan cut eight ways, halos between seven seams, the VAF teardown split in eight, over the
+    shared-memory transport and over the RCCL transport's own code path (device buffers; librccl replaced by tests/rccl_double)."""
+    from tests.test_shard_gloo import _run_ranks
+    _run_ranks(_rank_worker, 8, mode, transport)
 
 
 def test_rccl_transport_host_collectives_three_ranks(gpu_lib):
