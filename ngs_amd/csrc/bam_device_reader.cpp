@@ -380,14 +380,22 @@ struct ReadPool {
     void open(int n, int file) {
         nt = n;
         fd = file;
-        for (int t = 0; t < nt; t++) th[t] = std::thread([this] { work(); });
+        // O_DIRECT requests go straight to the storage's queue: two readers keep it full on the boxes measured (6 GB cold: 0.39 s
+        // with one, 0.37 with two, 0.44 with fourteen -- and fourteen times the CPU); NGSQ_DIRECT_THREADS for other storage
+        if (const char *e = getenv("NGSQ_DIRECT_THREADS")) direct_nt = std::max(1, atoi(e));
+        for (int t = 0; t < nt; t++) th[t] = std::thread([this, t] { work(t); });
     }
-    void work() {
+    int direct_nt = 2;
+    void work(int idx) {
         uint64_t seen = 0;
         std::unique_lock<std::mutex> g(mu);
         for (;;) {
             cv_go.wait(g, [&] { return quit || (gen != seen && next < n_pieces); });
             if (quit) return;
+            if (direct && fd_direct >= 0 && idx >= direct_nt) { // this request is the first readers' alone
+                seen = gen;
+                continue;
+            }
             const uint64_t my_gen = gen;
             while (gen == my_gen && next < n_pieces) {
                 const size_t i = next++;
@@ -549,17 +557,18 @@ void reader_main(DeviceIngest *d, std::string path) {
             if (fd >= 0) close(fd);
         }
     } closer{fmap, d->file_size, fd_direct};
-    // how much of file[lo, hi) the page cache holds: every 16th page of the range is looked at
+    // how much of file[lo, hi) the page cache holds: 32 pages spread over the range are looked at (mincore over a whole chunk walks
+    // 65 k page-cache entries per call: it cost a warm 6 GB scan 0.09 of its 0.20 s)
     auto resident = [&](uint64_t lo, uint64_t hi) -> double {
         if (!fmap || hi <= lo) return 0.0;
-        const uint64_t a = lo & ~(uint64_t)4095;
-        const size_t pages = (size_t)((hi - a + 4095) >> 12);
-        std::vector<unsigned char> vec(pages);
-        if (mincore(const_cast<uint8_t *>(fmap) + a, hi - a, vec.data()) != 0) return 0.0;
         size_t seen = 0, in = 0;
-        for (size_t i = 0; i < pages; i += 16) {
-            seen++;
-            in += vec[i] & 1;
+        for (int k = 0; k < 32; k++) {
+            const uint64_t a = (lo + (hi - lo) / 32 * (uint64_t)k) & ~(uint64_t)4095;
+            unsigned char v = 0;
+            if (a < d->file_size && mincore(const_cast<uint8_t *>(fmap) + a, 4096, &v) == 0) {
+                seen++;
+                in += v & 1;
+            }
         }
         return seen ? (double)in / (double)seen : 0.0;
     };
@@ -595,7 +604,9 @@ void reader_main(DeviceIngest *d, std::string path) {
         {
             const uint64_t look = std::min<uint64_t>(d->pos_end, chunk_off + std::min<uint64_t>(cap, (uint64_t)256 << 20));
             const double in_cache = (path_mode == "direct" || path_mode == "pread") ? 0.0 : resident(chunk_off, look);
-            c.mapped = fmap && (path_mode == "mapped" || in_cache >= 0.95);
+            // (auto does not take the mapped path: in the pipeline it is cheaper per byte than pread but slower on the wall -- 0.35-0.74 s
+            // against 0.20-0.33 s for the 6 GB file -- see the table in DESIGN.md section 8)
+            c.mapped = fmap && path_mode == "mapped";
             cold = !c.mapped && fd_direct >= 0 && (path_mode == "direct" || in_cache < 0.5);
         }
         if (!c.mapped) {
@@ -649,7 +660,9 @@ void reader_main(DeviceIngest *d, std::string path) {
         auto send = [&]() {
             if (h2d_ok && c.err.empty() && c.consumed > sent) {
                 const double ts = now_ms();
-                // (from the mapping: the runtime pins the pages and copies from them -- the call returns when the bytes have left)
+                // (from the mapping: the runtime pins the pages it copies from and lets them go inside the call -- it returns when
+                // the bytes have left.  Registering the pieces ourselves and copying asynchronously crashed in the runtime when the
+                // consumer thread's calls ran beside it (round 6, not pursued: DESIGN.md section 8))
                 h2d_ok = (c.mapped ? hipMemcpyAsync(d->d_comp_slot[k].p + sent, c.h + sent, c.consumed - sent, hipMemcpyHostToDevice, d->copy_stream)
                                    : ngsq::pool_pinned_h2d(d->d_comp_slot[k].p + sent, c.pin, (size_t)(c.h - c.pin) + sent, c.consumed - sent, d->copy_stream)) == hipSuccess;
                 sent = c.consumed;

@@ -416,6 +416,7 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_bad_off);
     (void)hipFree(c->d_bad_pos);
     (void)hipFree(c->d_edits_carry);
+    (void)hipFree(c->d_edits_td);
     (void)hipFree(c->d_edits_defer);
     (void)hipFree(c->d_ref_len);
     (void)hipFree(c->d_depth_off);
@@ -482,14 +483,17 @@ static void resolve_timing(ngsq_ctx *c) {
 // The per-cycle quality table has one row per cycle of the longest read met so far (the reference: a map entry per
 // position, quality_scores.rs:37-49).  Rows are added by moving the counters block into a larger allocation; nothing but
 // the block's size changes (the table is its last part).
-static int grow_rows(ngsq_ctx *c, uint64_t rows) {
+// exact: to `rows` rows, not beyond (ngsq_exchange: every shard takes the size of the largest table among them -- a size this policy
+// produced on some rank; growing "by half again" from it would leave the ranks with tables of two sizes: found by the eight-rank
+// file test of round 6 on a 300 kb read, refused by the exchange's layout check instead of being summed misaligned)
+static int grow_rows(ngsq_ctx *c, uint64_t rows, bool exact = false) {
     if (rows <= c->st.max_read_len) return NGSQ_OK;
     if (rows > NGSQ_QUALITY_ROWS_LIMIT)
         return fail(c, NGSQ_ERR_LIMIT, "implementation limit: a read of %llu bases (the quality table holds up to %u cycles)",
                     (unsigned long long)rows, (unsigned)NGSQ_QUALITY_ROWS_LIMIT);
     // short reads: to the next multiple of 64 (what the fast kernels are specialised for depends on the rows); long reads: by
     // half again, so that a file of ever longer reads does not move the block for each of them
-    const uint64_t want = std::min<uint64_t>(rows <= 1024 ? round_up(rows, 64) : round_up(rows + rows / 2, 1024), NGSQ_QUALITY_ROWS_LIMIT);
+    const uint64_t want = exact ? rows : std::min<uint64_t>(rows <= 1024 ? round_up(rows, 64) : round_up(rows + rows / 2, 1024), NGSQ_QUALITY_ROWS_LIMIT);
     const uint64_t n_new = round_up((uint64_t)c->st.off_qual + want * QUAL_BINS, 8);
     unsigned long long *bigger = nullptr;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -881,27 +885,57 @@ int ngsq_teardown(ngsq_ctx *c) {
         HIP_TRY(c, launch_cov_scan(c->li, a, c->stream));
     }
     if (facets & NGSQ_FACET_EDITS) {
+        // The slot of refs holds the difference array of the `M` cover (edits_kernel.hip): sums of every 4096-entry chunk and of every
+        // 256 chunks, then -- chunk by chunk, the carry from those sums -- the VAF histogram of the covered positions.  A sharded run
+        // splits the chunks of every sequence evenly over the ranks (ngsq_exchange); the partial histograms are summed with the other
+        // teardown results.  The slots keep the difference array until somebody asks for the positions (ngsq_get_edits_positions
+        // converts then).  All sequences in THREE launches (round 6; sequences Edits wrote nothing for -- their word at off_eseen is
+        // zero -- cost their blocks one load each): a real header has 195, and one launch per sequence and step was 585.
+        std::vector<EditsSeq> seqs;
+        std::vector<uint32_t> first[3];
+        uint64_t nb[3] = {0, 0, 0};
+        uint64_t algo = 0;
         for (uint32_t r = 0; r < nr; r++) {
             if (c->edits_off[r] == NO_DEPTH) continue;
-            // the slot of refs holds the difference array of the `M` cover (edits_kernel.hip): carry of every 4096-entry chunk,
-            // then refs = cover - alts in place and the VAF histogram.  A sharded run splits the chunks of every sequence
-            // evenly over the ranks (ngsq_exchange); the partial histograms are summed with the other teardown results
             const uint64_t L1 = (uint64_t)c->ref_len[r] + 1, nc = edits_teardown_chunks(L1);
             const uint64_t c0 = nc * c->vaf_part / c->vaf_parts, c1 = nc * (c->vaf_part + 1) / c->vaf_parts;
-            uint32_t *refs = c->st.edits + c->edits_off[r], *carry = c->d_edits_carry + c->edits_carry_off[r];
-            // (a sequence Edits wrote nothing for -- its word at off_eseen is zero -- costs two empty launches; round 5: until then
-            // every sequence of the FASTA was summed, converted and, in ngsq_reset, zeroed again whether a read lay on it or not)
-            const unsigned long long *touched = c->st.counters + c->st.off_eseen + r;
-            {
-                Bracket br(c, K_EDITS_VAF, L1 * 4);
-                HIP_TRY(c, launch_edits_chunk_sums(refs, L1, carry, touched, c->stream));
-            }
-            // the VAF histogram only: the slot keeps the cover's difference array until somebody asks for the positions
-            // (ngsq_get_edits_positions converts then) -- 4 bytes per position less to write in every run that does not
             c->edits_conv_lo[r] = c->edits_conv_hi[r] = c0;
-            if (c1 <= c0) continue;
-            Bracket br(c, K_EDITS_VAF, std::min<uint64_t>(L1, (c1 - c0) * 4096) * 8);
-            HIP_TRY(c, launch_edits_refs(refs, refs + L1, L1, carry, c0, c1, c->d_vaf, touched, false, c->stream));
+            EditsSeq e{};
+            e.edits_off = c->edits_off[r];
+            e.n_entries = L1;
+            e.carry_off = c->edits_carry_off[r];
+            e.chunk0 = (uint32_t)c0;
+            e.chunk1 = (uint32_t)c1;
+            e.ref = r;
+            seqs.push_back(e);
+            for (int k = 0; k < 3; k++) first[k].push_back((uint32_t)nb[k]);
+            nb[0] += nc;
+            nb[1] += (nc + 255) / 256; // (EDS = 256 chunks per super sum: edits_kernel.hip)
+            nb[2] += std::min<uint64_t>(c1 - c0, 4096);
+            algo += L1 * 4 + std::min<uint64_t>(L1, (c1 - c0) * 4096) * 8;
+        }
+        if (!seqs.empty()) {
+            for (int k = 0; k < 3; k++) first[k].push_back((uint32_t)nb[k]);
+            const size_t n_seq = seqs.size(), tab = (n_seq + 1) * 4, bytes = n_seq * sizeof(EditsSeq) + 3 * tab;
+            if (c->edits_td_cap < bytes) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                (void)hipFree(c->d_edits_td);
+                c->d_edits_td = nullptr;
+                c->edits_td_cap = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->d_edits_td, bytes));
+                c->edits_td_cap = bytes;
+            }
+            // (the tables travel from a host vector that lives until the copies have been made: a pageable copy returns then)
+            c->h_edits_td.resize(bytes);
+            uint8_t *h = c->h_edits_td.data();
+            memcpy(h, seqs.data(), n_seq * sizeof(EditsSeq));
+            for (int k = 0; k < 3; k++) memcpy(h + n_seq * sizeof(EditsSeq) + (size_t)k * tab, first[k].data(), tab);
+            HIP_TRY(c, hipMemcpyAsync(c->d_edits_td, h, bytes, hipMemcpyHostToDevice, c->stream));
+            const EditsSeq *d_seqs = reinterpret_cast<const EditsSeq *>(c->d_edits_td);
+            const uint32_t *d_first = reinterpret_cast<const uint32_t *>(c->d_edits_td + n_seq * sizeof(EditsSeq));
+            Bracket br(c, K_EDITS_VAF, algo);
+            HIP_TRY(c, launch_edits_teardown_all(d_seqs, (uint32_t)n_seq, d_first, (uint32_t)nb[0], d_first + (n_seq + 1), (uint32_t)nb[1], d_first + 2 * (n_seq + 1),
+                                                 (uint32_t)nb[2], c->st.edits, c->d_edits_carry, c->d_vaf, c->st.counters + c->st.off_eseen, c->stream));
         }
     }
     c->torn_down = true;
@@ -1374,5 +1408,5 @@ int ngsq_host_free_pinned(void *p) {
 } // extern "C"
 
 namespace ngsq {
-int grow_quality_table(ngsq_ctx *c, uint64_t rows) { return grow_rows(c, rows); }
+int grow_quality_table(ngsq_ctx *c, uint64_t rows) { return grow_rows(c, rows, true); }
 } // namespace ngsq

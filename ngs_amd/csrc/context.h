@@ -68,6 +68,9 @@ struct ngsq_ctx {
     // Edits teardown: per sequence the carry of every 4096-entry chunk of its difference array, and which chunks have been
     // turned into refs so far ([lo, hi); a sharded run converts a slice per rank, ngsq_get_edits_positions the rest)
     uint32_t *d_edits_carry = nullptr;
+    uint8_t *d_edits_td = nullptr;       // tables of the all-sequences Edits teardown (kernels.h EditsSeq)
+    size_t edits_td_cap = 0;
+    std::vector<uint8_t> h_edits_td;
     unsigned long long *d_edits_defer = nullptr; // one bit per record of the batch: left to k_edits_walk (edits_kernel.hip)
     uint64_t edits_defer_cap = 0;
     std::vector<uint64_t> edits_carry_off, edits_conv_lo, edits_conv_hi;

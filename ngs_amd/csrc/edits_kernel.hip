@@ -1089,10 +1089,11 @@ __global__ __launch_bounds__(256) void k_pack_reference(const uint8_t *__restric
 // ---------------------------------------------------------------------------
 constexpr uint32_t EDC = 4096; // entries per teardown chunk
 
-__global__ __launch_bounds__(256) void k_edits_chunk_sums(const uint32_t *__restrict__ diff, uint64_t n_entries, uint32_t *__restrict__ sums, const u64 *touched) {
+__device__ __forceinline__ void ed_chunk_sums_body(const uint32_t *__restrict__ diff, uint64_t n_entries, uint32_t *__restrict__ sums, const u64 *touched,
+                                                   uint32_t bidx) {
     __shared__ uint32_t s_w[4];
     if (touched && !*touched) return; // (uniform) nothing was written for this sequence
-    const uint64_t base = (uint64_t)blockIdx.x * EDC;
+    const uint64_t base = (uint64_t)bidx * EDC;
     uint32_t t = 0;
 #pragma unroll
     for (uint32_t k = 0; k < EDC / 1024; k++) {
@@ -1108,7 +1109,10 @@ __global__ __launch_bounds__(256) void k_edits_chunk_sums(const uint32_t *__rest
     t = ed_wave_sum(t);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) sums[bidx] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void k_edits_chunk_sums(const uint32_t *__restrict__ diff, uint64_t n_entries, uint32_t *__restrict__ sums, const u64 *touched) {
+    ed_chunk_sums_body(diff, n_entries, sums, touched, blockIdx.x);
 }
 
 // The carry of a chunk (the sum of every entry in front of it) is never written down: behind the chunks' sums lie the sums of every
@@ -1116,19 +1120,23 @@ __global__ __launch_bounds__(256) void k_edits_chunk_sums(const uint32_t *__rest
 // the (at most EDS - 1) chunk sums in front of it inside the group.  (Until round 5 one block scanned the sixty thousand chunk sums of
 // a chromosome in place, sixty sequential loads per thread: 0.09 ms of a 0.45 ms teardown.)
 constexpr uint32_t EDS = 256; // chunks per super sum
-__global__ __launch_bounds__(256) void k_edits_super_sums(const uint32_t *__restrict__ sums, uint32_t n, uint32_t *__restrict__ supers, const u64 *touched) {
+__device__ __forceinline__ void ed_super_sums_body(const uint32_t *__restrict__ sums, uint32_t n, uint32_t *__restrict__ supers, const u64 *touched, uint32_t bidx) {
     __shared__ uint32_t s_w[4];
     if (touched && !*touched) return;
-    const uint32_t i = blockIdx.x * EDS + threadIdx.x;
+    const uint32_t i = bidx * EDS + threadIdx.x;
     uint32_t t = ed_wave_sum(i < n ? sums[i] : 0u);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) supers[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) supers[bidx] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void k_edits_super_sums(const uint32_t *__restrict__ sums, uint32_t n, uint32_t *__restrict__ supers, const u64 *touched) {
+    ed_super_sums_body(sums, n, supers, touched, blockIdx.x);
 }
 
 template <bool WRITE>
-__global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs, const uint32_t *__restrict__ alts, uint64_t n_entries,
-                                                     const uint32_t *__restrict__ carry, uint32_t chunk0, uint32_t chunk1, u64 *vaf_hist, const u64 *touched) {
+__device__ __forceinline__ void ed_refs_body(uint32_t *__restrict__ refs, const uint32_t *__restrict__ alts, uint64_t n_entries,
+                                             const uint32_t *__restrict__ carry, uint32_t chunk0, uint32_t chunk1, u64 *vaf_hist, const u64 *touched,
+                                             uint32_t bidx, uint32_t gdim) {
     __shared__ uint32_t s_h[NGSQ_VAF_BINS];
     __shared__ uint32_t s_w[4], s_c[4];
     if (touched && !*touched) return;
@@ -1140,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs,
     // a block takes every gridDim.x-th chunk and adds its histogram to the global one ONCE (a block per chunk meant sixty thousand
     // blocks per chromosome adding to the same bin: same-address atomics at the L2, ~9 ns each)
 #pragma unroll 1
-    for (uint32_t chunk = chunk0 + blockIdx.x; chunk < chunk1; chunk += gridDim.x) {
+    for (uint32_t chunk = chunk0 + bidx; chunk < chunk1; chunk += gdim) {
     const uint64_t base = (uint64_t)chunk * EDC;
     uint32_t run; // sum of every entry in front of the chunk
     {
@@ -1217,6 +1225,45 @@ __global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs,
         }
     }
 }
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_edits_refs(uint32_t *__restrict__ refs, const uint32_t *__restrict__ alts, uint64_t n_entries,
+                                                     const uint32_t *__restrict__ carry, uint32_t chunk0, uint32_t chunk1, u64 *vaf_hist, const u64 *touched) {
+    ed_refs_body<WRITE>(refs, alts, n_entries, carry, chunk0, chunk1, vaf_hist, touched, blockIdx.x, gridDim.x);
+}
+
+// ---- the teardown of EVERY sequence in three launches (round 6).  One launch per sequence and step was 585 launches for the 195
+// sequences of a real header -- 9.6 ms of launch latency in a finalize whose work is 4 ms -- and two launches per sequence even for
+// the sequences no read lay on.  A block finds its sequence in a table of first-block numbers.
+__device__ __forceinline__ uint32_t ed_seq_of_block(const uint32_t *__restrict__ first, uint32_t n_seq, uint32_t b) {
+    uint32_t lo = 0, hi = n_seq; // first[lo] <= b < first[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (first[mid] <= b) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_edits_chunk_sums_all(const EditsSeq *__restrict__ seqs, uint32_t n_seq, const uint32_t *__restrict__ first,
+                                                               uint32_t *edits, uint32_t *carry, const u64 *touched) {
+    const uint32_t q = ed_seq_of_block(first, n_seq, blockIdx.x);
+    const EditsSeq e = seqs[q];
+    ed_chunk_sums_body(edits + e.edits_off, e.n_entries, carry + e.carry_off, touched + e.ref, blockIdx.x - first[q]);
+}
+__global__ __launch_bounds__(256) void k_edits_super_sums_all(const EditsSeq *__restrict__ seqs, uint32_t n_seq, const uint32_t *__restrict__ first,
+                                                               uint32_t *carry, const u64 *touched) {
+    const uint32_t q = ed_seq_of_block(first, n_seq, blockIdx.x);
+    const EditsSeq e = seqs[q];
+    const uint32_t nc = (uint32_t)((e.n_entries + EDC - 1) / EDC);
+    ed_super_sums_body(carry + e.carry_off, nc, carry + e.carry_off + nc, touched + e.ref, blockIdx.x - first[q]);
+}
+__global__ __launch_bounds__(256) void k_edits_refs_all(const EditsSeq *__restrict__ seqs, uint32_t n_seq, const uint32_t *__restrict__ first,
+                                                         uint32_t *edits, const uint32_t *carry, u64 *vaf_hist, const u64 *touched) {
+    const uint32_t q = ed_seq_of_block(first, n_seq, blockIdx.x);
+    const EditsSeq e = seqs[q];
+    uint32_t *const refs = edits + e.edits_off;
+    ed_refs_body<false>(refs, refs + e.n_entries, e.n_entries, carry + e.carry_off, e.chunk0, e.chunk1, vaf_hist, touched + e.ref, blockIdx.x - first[q],
+                        first[q + 1] - first[q]);
+}
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -1274,6 +1321,17 @@ hipError_t launch_pack_reference(const LaunchInfo &li, const uint8_t *codes, uin
     if (!n_bytes) return hipSuccess;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n_bytes + 255) / 256, (uint64_t)li.n_cu * 16);
     hipLaunchKernelGGL(k_pack_reference, dim3(grid), dim3(256), 0, s, codes, len, even, odd, n_bytes, bad);
+    return hipGetLastError();
+}
+
+// tables: seqs [n_seq], first_sums / first_supers / first_refs [n_seq + 1] each (device memory, filled by the host: context.cpp)
+hipError_t launch_edits_teardown_all(const EditsSeq *seqs, uint32_t n_seq, const uint32_t *first_sums, uint32_t n_sums, const uint32_t *first_supers,
+                                     uint32_t n_supers, const uint32_t *first_refs, uint32_t n_refs_blocks, uint32_t *edits, uint32_t *carry,
+                                     unsigned long long *vaf_hist, const unsigned long long *touched, hipStream_t s) {
+    if (!n_seq) return hipSuccess;
+    if (n_sums) hipLaunchKernelGGL(k_edits_chunk_sums_all, dim3(n_sums), dim3(256), 0, s, seqs, n_seq, first_sums, edits, carry, touched);
+    if (n_supers) hipLaunchKernelGGL(k_edits_super_sums_all, dim3(n_supers), dim3(256), 0, s, seqs, n_seq, first_supers, carry, touched);
+    if (n_refs_blocks) hipLaunchKernelGGL(k_edits_refs_all, dim3(n_refs_blocks), dim3(256), 0, s, seqs, n_seq, first_refs, edits, carry, vaf_hist, touched);
     return hipGetLastError();
 }
 

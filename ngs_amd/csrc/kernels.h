@@ -243,6 +243,19 @@ uint64_t edits_teardown_carry_words(uint64_t n_entries); // words of the teardow
 // touched (optional, device memory): the sequence's word of the counters block at off_eseen -- zero: nothing to do, the kernels return
 // write_refs: refs = cover - alts in place (ngsq_get_edits_positions); false: the VAF histogram only, the arrays stay as they are
 hipError_t launch_edits_chunk_sums(const uint32_t *diff, uint64_t n_entries, uint32_t *sums, const unsigned long long *touched, hipStream_t s);
+// ... and of EVERY sequence in three launches: one entry per sequence with Edits state; a block finds its sequence in the tables of
+// first-block numbers (n_seq + 1 entries each: chunk sums, super sums, the blocks that take the sequence's chunks [chunk0, chunk1))
+struct EditsSeq {
+    uint64_t edits_off;  // elements into st.edits: the difference array (n_entries), alts behind it
+    uint64_t n_entries;  // ref_len + 1
+    uint64_t carry_off;  // elements into the carry scratch
+    uint32_t chunk0, chunk1; // this context's share of the sequence's chunks (a sharded run splits them over the ranks)
+    uint32_t ref;        // index of the sequence: its word of the counters block at off_eseen
+    uint32_t reserved;
+};
+hipError_t launch_edits_teardown_all(const EditsSeq *seqs, uint32_t n_seq, const uint32_t *first_sums, uint32_t n_sums, const uint32_t *first_supers,
+                                     uint32_t n_supers, const uint32_t *first_refs, uint32_t n_refs_blocks, uint32_t *edits, uint32_t *carry,
+                                     unsigned long long *vaf_hist, const unsigned long long *touched, hipStream_t s);
 hipError_t launch_edits_refs(uint32_t *refs, const uint32_t *alts, uint64_t n_entries, const uint32_t *carry, uint64_t chunk0, uint64_t chunk1,
                              unsigned long long *vaf_hist, const unsigned long long *touched, bool write_refs, hipStream_t s);
 

@@ -443,6 +443,8 @@ class QcContext:
         return refs, alts
 
     def results_json(self, ref_names: Sequence[str]) -> str:
+        if len(ref_names) < len(self._ref_len):   # (the C entry point reads n_refs names: it cannot know how many it was given)
+            raise ValueError(f"{len(ref_names)} names for a context of {len(self._ref_len)} sequences")
         names = (C.c_char_p * max(1, len(ref_names)))(*[n.encode() for n in ref_names])
         need = self.lib.ngsq_results_json(self._ctx, names, None, 0)
         if need < 0:

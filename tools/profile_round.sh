@@ -4,16 +4,17 @@
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md, rocprofv3 PMC slots)
 # and summarise them into gpurun_out/<prefix>_*  (copy what is to be judged into profiles/).   usage: bash tools/profile_round.sh r02
 set -u
-P=${1:-r04}
+P=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$P
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-LEGS="--cpu-sample 0 --h2d-batch 0 --file-records 0 --extra-facet-legs 0 --mixed-records 0 --all-facets-records 0 --repeats 1"
+LEGS="--cpu-sample 0 --h2d-batch 0 --file-records 0 --extra-facet-legs 0 --mixed-records 0 --all-facets-records 0 --whole-genome-records 0 --repeats 1"
 rocprofv3 --kernel-trace --stats -d $O/stats -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 20 --warmup 3 $LEGS > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/mixed -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 20 --warmup 3 --cpu-sample 0 --repeats 1 > $O/mixed.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/extra -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --repeats 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 --mixed-records 0 --all-facets-steps 3 > $O/extra.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/file -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --extra-facet-legs 0 --mixed-records 0 --all-facets-records 0 --repeats 1 --file-records 24000000 --file-realistic-records 24000000 > $O/file.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/mixed -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --workload mixed --steps 20 --warmup 3 --cpu-sample 0 --repeats 1 --whole-genome-records 0 > $O/mixed.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/extra -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --repeats 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 --mixed-records 0 --all-facets-steps 3 --whole-genome-records 0 > $O/extra.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/file -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --cpu-sample 0 --h2d-batch 0 --extra-facet-legs 0 --mixed-records 0 --all-facets-records 0 --repeats 1 --file-records 24000000 --file-realistic-records 24000000 --whole-genome-records 0 > $O/file.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/genome -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 3 --warmup 1 --repeats 1 --cpu-sample 0 --h2d-batch 0 --file-records 0 --mixed-records 0 --all-facets-records 0 --extra-facet-legs 0 > $O/genome.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 2 --warmup 1 --no-timing $LEGS > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o out --output-format csv -- python3 $R/bench.py --live-traffic 0 --steps 2 --warmup 1 --no-timing $LEGS > $O/write.log 2>&1
 # the same two PMC passes for the offsets-layout quality kernel (--workload mixed) and for the device inflate (tools/bench_inflate.py:
@@ -33,5 +34,6 @@ python3 tools/collect_traffic.py "$F" "$W" "$S" gpurun_out/$P
 cp "$(find $O/mixed -name '*kernel_stats.csv' | head -n 1)" gpurun_out/${P}_mixed_kernel_stats.csv
 cp "$(find $O/extra -name '*kernel_stats.csv' | head -n 1)" gpurun_out/${P}_extra_kernel_stats.csv
 cp "$(find $O/file -name '*kernel_stats.csv' | head -n 1)" gpurun_out/${P}_ingest_kernel_stats.csv
-for f in stats mixed extra file; do grep '^{"metric"' $O/$f.log | tail -n 1 > gpurun_out/${P}_bench_$f.json; done
+cp "$(find $O/genome -name '*kernel_stats.csv' | head -n 1)" gpurun_out/${P}_whole_genome_kernel_stats.csv
+for f in stats mixed extra file genome; do grep '^{"metric"' $O/$f.log | tail -n 1 > gpurun_out/${P}_bench_$f.json; done
 head -n 12 "$S" | cut -c1-160
