@@ -20,6 +20,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <chrono>
 #include <cstdarg>
@@ -403,6 +404,37 @@ int main(int argc, char **argv) {
         logf(1, "-n bounds the scan to its first records: --gpus %d is ignored, one process reads them", a.gpus);
         a.gpus = 1;
     }
+    // NGSQ_RETURN_WHEN_DONE=1, one process: the command returns when the document is on disk, not when the driver has finished
+    // taking the process apart (0.13-0.21 s for the 17-40 GB of device memory and the pinned buffers of a whole-genome run: a
+    // quarter of the command).  The scan runs in a child forked HERE -- nothing has touched HIP yet -- which says "done" through a
+    // pipe behind its last file; the parent then leaves with 0 and the child's teardown goes on behind it (a caller that starts
+    // another GPU job at once finds that memory still in use for those 0.2 s, and an exit status of the teardown itself is lost:
+    // hence opt-in, as for --gpus N below).  A child that ends before it has reported hands its status on.
+    int single_done_fd = -1;
+    if (a.gpus == 1 && !worker) {
+        const char *early = getenv("NGSQ_RETURN_WHEN_DONE");
+        int fds[2];
+        if (early && atoi(early) && pipe(fds) == 0) {
+            fflush(nullptr);
+            const pid_t child = fork();
+            if (child > 0) {
+                close(fds[1]);
+                char b;
+                const ssize_t n = read(fds[0], &b, 1); // 1: done; 0: the child has ended without saying so
+                if (n == 1) _exit(0);
+                int status = 0;
+                waitpid(child, &status, 0);
+                _exit(WIFEXITED(status) ? WEXITSTATUS(status) : 1);
+            }
+            if (child == 0) {
+                close(fds[0]);
+                single_done_fd = fds[1];
+            } else { // (no fork: carry on as one process)
+                close(fds[0]);
+                close(fds[1]);
+            }
+        }
+    }
     if (a.gpus > 1 && !worker) {
         // ---- launch one worker per GPU.  Nothing above has touched HIP, and nothing here does: the workers
         // are fresh processes (posix_spawn of this executable), each initialises its own device.
@@ -495,6 +527,7 @@ int main(int argc, char **argv) {
     // reports them -- before anything of the scan happens.
     GeneModel model;
     std::thread gff_thread;
+    std::atomic<bool> gff_done{false};
     if (!a.gff.empty()) {
         const size_t dot = a.gff.rfind('.');
         const std::string ext = dot == std::string::npos ? "" : a.gff.substr(dot + 1);
@@ -508,10 +541,11 @@ int main(int argc, char **argv) {
         logf(3, "Reading all records in GFF.");
         const bool gz = format == "Gzipped GFF";
         const int nt = std::max(1, std::min(8, cgroup_cores() - 2));
-        gff_thread = std::thread([&model, &a, &genome, &names, n_refs, gz, nt] {
+        gff_thread = std::thread([&model, &a, &genome, &names, &gff_done, n_refs, gz, nt] {
             std::map<std::string, uint32_t> ref_index;
             for (uint32_t r = 0; r < n_refs; r++) ref_index[names[r]] = r;
             model = load_gff_parallel(a.gff, gz, a.feature_name, genome.primary, ref_index, nt);
+            gff_done = true;
         });
         facets |= NGSQ_FACET_FEATURES;
     }
@@ -714,7 +748,8 @@ int main(int argc, char **argv) {
     milestone("checks done");
     if (ngsq_create(&cfg, &ctx) != NGSQ_OK) bail(ngsq_last_global_error());
     milestone("context created (HIP initialised)");
-    if (facets & NGSQ_FACET_EDITS) {
+    auto start_reference = [&]() {
+        if (!(facets & NGSQ_FACET_EDITS)) return;
         // EditsFacet::setup for every sequence of the header (edits.rs:177-215), as one pass over the file: the text goes to the
         // device as it is, on the library's threads, while this thread goes on to the first batches (ngsq_process_batch waits
         // for it in front of the first Edits kernel only)
@@ -722,15 +757,11 @@ int main(int argc, char **argv) {
         for (uint32_t r = 0; r < n_refs; r++) name_ptrs[r] = names[r].c_str();
         CHECK(ctx, ngsq_reference_load(ctx, fasta, name_ptrs.data(), ref_wanted.empty() ? nullptr : ref_wanted.data()));
         milestone("reference load started");
-    }
-    gff_ready();
-    milestone("gene model ready");
-    if (want_vaf && !vaf_file) {
-        vaf_file = fopen(a.vaf.c_str(), "wb");
-        if (!vaf_file) bail("creating VAF file");
-        fputs("Sequence\tPosition\tVAF\n", vaf_file);
-    }
-    if (facets & NGSQ_FACET_FEATURES) {
+    };
+    auto install_gene_model = [&]() {
+        gff_ready();
+        milestone("gene model ready");
+        if (!(facets & NGSQ_FACET_FEATURES)) return;
         ngsq_features f;
         memset(&f, 0, sizeof f);
         f.struct_size = sizeof f;
@@ -741,6 +772,22 @@ int main(int argc, char **argv) {
         f.start = model.start.data();
         f.stop = model.stop.data();
         CHECK(ctx, ngsq_set_features(ctx, &f));
+        milestone("gene model on the device");
+    };
+    // The gene model is usually there by now (it was parsed beside the device's initialisation): it goes to the device FIRST -- its
+    // synchronous copies took 0.4 s when they queued behind the reference's 3 GB of text (round 6) -- and the reference starts
+    // behind it; a model that is still being read (a gzip stream inflates on one thread) waits beside the reference instead.
+    if (!gff_thread.joinable() || gff_done) {
+        install_gene_model();
+        start_reference();
+    } else {
+        start_reference();
+        install_gene_model();
+    }
+    if (want_vaf && !vaf_file) {
+        vaf_file = fopen(a.vaf.c_str(), "wb");
+        if (!vaf_file) bail("creating VAF file");
+        fputs("Sequence\tPosition\tVAF\n", vaf_file);
     }
 
     const bool rec_facets = (facets & NGSQ_FACETS_RECORD_BASED) != 0, seq_facets = (facets & NGSQ_FACETS_SEQUENCE_BASED) != 0;
@@ -966,6 +1013,11 @@ int main(int argc, char **argv) {
     // pinned memory to the kernel's process teardown instead of unmapping them block by block and running the HIP
     // runtime's exit handlers (three workers on one device: 0.37 s of the command's 1.07; NGSQ_QUICK_EXIT=0 turns it off)
     auto report_done = [&]() { // (the launcher's pipe: see there)
+        if (single_done_fd >= 0) {
+            const char ok = 0;
+            if (write(single_done_fd, &ok, 1) != 1) { /* the parent then waits for the exit status instead */ }
+            return;
+        }
         const char *fd = worker ? getenv("NGSQ_DONE_FD") : nullptr;
         const char ok = 0;
         if (fd && write(atoi(fd), &ok, 1) != 1) { /* the launcher then waits for the exit status instead */ }

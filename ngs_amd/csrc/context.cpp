@@ -9,11 +9,13 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ngsq.h"
@@ -693,9 +695,24 @@ int ngsq_set_features(ngsq_ctx *c, const ngsq_features *f) {
         starts[slot] = f->start[i];
         stops[slot] = f->stop[i];
     }
-    for (size_t k = 0; k + 1 < idx.size(); k++) {
-        std::sort(starts.begin() + idx[k], starts.begin() + idx[k + 1]);
-        std::sort(stops.begin() + idx[k], stops.begin() + idx[k + 1]);
+    {   // (a GENCODE-sized model -- 2.9 M intervals in 975 buckets -- took one thread 0.25 s of the command's wall clock: round 6)
+        const size_t n_buckets = idx.size() - 1;
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= 2 * n_buckets) return;
+                std::vector<uint32_t> &v = k < n_buckets ? starts : stops;
+                const size_t q = k < n_buckets ? k : k - n_buckets;
+                std::sort(v.begin() + idx[q], v.begin() + idx[q + 1]);
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = f->n < 100000 ? 1 : std::min<size_t>(8, hw ? hw : 1);
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
     }
     HIP_TRY(c, hipSetDevice(c->device));
     (void)hipFree(c->d_ft_idx);

@@ -185,3 +185,79 @@ def test_cli_argument_paths_under_asan_ubsan(tmp_path):
         bad = [l for l in r.stderr.splitlines() if "AddressSanitizer" in l or "runtime error:" in l]
         assert not bad, (args, r.stderr[-3000:])
         assert r.returncode == want, (args, r.returncode, r.stderr[-600:])
+
+
+def test_gff_loader_under_asan_ubsan(tmp_path):
+    """ngs_amd/csrc/cli/gff_loader.h (the parallel parser behind `-f`, round 6) as a stand-alone program under ASan / UBSan:
+    well-formed text cut into pieces at every thread count, lines without a terminator, CRLF, a tenth column, numbers that
+    overflow, an empty file, `##FASTA` first, gzip -- the intervals kept and the FIRST offending line must not depend on how
+    the text was cut."""
+    import gzip
+    src = tmp_path / "drive.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdint>
+#include "gff_loader.h"
+int main(int argc, char **argv) {
+    const std::string names[5] = {"five_prime_UTR", "three_prime_UTR", "CDS", "exon", "gene"};
+    std::set<std::string> primary = {"chr1", "chr2", "chrX"};
+    std::map<std::string, uint32_t> idx = {{"chr1", 0}, {"chr2", 1}, {"chrM", 2}};
+    const std::string path = argv[1];
+    const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    GeneModel m = load_gff_parallel(path, gz, names, primary, idx, atoi(argv[2]));
+    unsigned long long sum = 0;
+    for (size_t i = 0; i < m.ref.size(); i++) sum = sum * 1000003ull + m.ref[i] * 7 + m.name[i] * 3 + m.start[i] + 5ull * m.stop[i];
+    printf("%zu %llu %llu|%s\n", m.ref.size(), sum, (unsigned long long)m.lines, m.error.c_str());
+    return 0;
+}''')
+    exe = str(tmp_path / "drive")
+    subprocess.run(["g++", "-std=c++17", *SAN, "-I", os.path.join(ROOT, "ngs_amd", "csrc", "cli"), str(src), "-lz", "-lpthread", "-o", exe], check=True)
+    import random
+    rnd = random.Random(5)
+    types = ["gene", "exon", "CDS", "five_prime_UTR", "three_prime_UTR", "transcript"]
+    lines = ["##gff-version 3", "#c"]
+    for k in range(30_000):
+        s = rnd.randrange(1, 10 ** 6)
+        lines.append(f"{rnd.choice(['chr1', 'chr2', 'chrX', 'chrM', 'scaffold_9'])}\tsrc\t{rnd.choice(types)}\t{s}\t{s + rnd.randrange(0, 5000)}\t.\t{rnd.choice('+-')}\t.\tID=x{k};note=" + "y" * rnd.randrange(0, 300))
+    good = "\n".join(lines) + "\n"
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+
+    def run(text, threads, name="t.gff"):
+        p = tmp_path / name
+        if name.endswith(".gz"):
+            with gzip.open(p, "wb") as f:
+                f.write(text if isinstance(text, bytes) else text.encode())
+        else:
+            p.write_bytes(text if isinstance(text, bytes) else text.encode())
+        r = subprocess.run([exe, str(p), str(threads)], capture_output=True, text=True, env=env, timeout=120)
+        bad = [l for l in r.stderr.splitlines() if "AddressSanitizer" in l or "runtime error:" in l]
+        assert r.returncode == 0 and not bad, r.stderr[-3000:]
+        return r.stdout.strip()
+
+    want = run(good, 1)
+    n_kept = int(want.split()[0])
+    assert n_kept > 5000 and want.endswith("|")
+    for t in (2, 3, 8, 31):
+        assert run(good, t) == want
+    assert run(good, 4, "t.gff3.gz") == want
+    assert run(good[:-1], 5).split("|")[0].split()[:2] == want.split("|")[0].split()[:2]          # no newline at the end
+    assert run(good.replace("\n", "\r\n"), 3).split()[:2] == want.split()[:2]                      # CRLF
+    assert run(good + "##FASTA\n>x\nACGT\tnot\ta\trecord\n", 4).split()[:2] == want.split()[:2]   # ##FASTA ends the records
+    assert run("##FASTA\n" + good, 2).startswith("0 0 ")
+    assert run("", 3).startswith("0 0 0|")
+    # the first offending line, wherever the pieces are cut
+    bad_at = 20_001
+    broken = lines[:]
+    broken[bad_at] = "chr1\tsrc\tgene\t12\t11\t.\t+\t.\tID=stop_before_start"
+    broken[bad_at + 3000] = "chr1\tsrc\tgene\tx\t11\t.\t+\t.\tID=later"
+    for t in (1, 2, 7):
+        out = run("\n".join(broken) + "\n", t)
+        assert out.endswith(f"|invalid GFF record on line {bad_at + 1} of {tmp_path / 't.gff'}"), out
+    for bad_line, msg in (("chr1\tsrc\tgene\t1\t2\t.\t.\t.\tID=s", "attempted to parse strand from value: ."),
+                          ("chr1\tsrc\tgene\t1\t2\t.\t+\t.\tID=s\ttenth", "invalid GFF record on line 3"),
+                          ("chr1\tsrc\tgene\t1\t99999999999999999999\t.\t+\t.\tID=s", "invalid GFF record on line 3"),
+                          ("chr1\tsrc\tgene\t0\t2\t.\t+\t.\tID=s", "invalid GFF record on line 3"),
+                          ("chr1\tsrc\tgene", "invalid GFF record on line 3"),
+                          ("chrM\tsrc\tgene\t1\t2\t.\t?\t.\tID=not_primary_strand_never_parsed", "")):
+        out = run("##gff-version 3\n#c\n" + bad_line + "\n", 2)
+        assert msg in out.split("|", 1)[1] and (msg or out.endswith("|")), (bad_line, out)
