@@ -68,6 +68,20 @@ def test_error_texts(ngs, tmp_path):
     assert r.returncode == 1
 
 
+def test_return_when_done_hands_on_a_failure(ngs, lib, tmp_path):
+    """NGSQ_RETURN_WHEN_DONE=1 (one process): the scan runs in a forked child and the command returns when the document is on disk;
+    a child that ends BEFORE it has reported hands its exit status on -- here, on a box without a GPU, the missing device."""
+    if lib.ngsq_device_count() > 0:
+        pytest.skip("needs a box without a HIP device (the GPU suite checks the successful return)")
+    hb = sorted_batch(1, 50)
+    bam = str(tmp_path / "a.bam")
+    bamio.write_bam(bam, hb, NAMES, LENS)
+    r = run(ngs, "qc", bam, GENOME, "-o", str(tmp_path), env=dict(os.environ, NGSQ_RETURN_WHEN_DONE="1"))
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    r = run(ngs, "qc", bam, "hg19", env=dict(os.environ, NGSQ_RETURN_WHEN_DONE="1"))     # (fails before the fork)
+    assert r.returncode == 1 and "reference genome is not supported" in r.stderr
+
+
 def test_cli_surface_is_the_reference_s(ngs, tmp_path):
     """tests/golden/qc_cli_surface.json is derived from the reference's clap definition (src/qc/command.rs:36-102):
     every option there -- long name, short letter, value name, default -- is in this build's `ngs qc --help`, and the
@@ -183,6 +197,11 @@ def test_end_to_end(ngs, gpu_lib, oracle_mod, tmp_path, shape):
     got = json.load(open(out / "sample.bam.results.json"))     # default prefix = BAM file name
     json_equal(got, oracle_json(oracle_mod, hb))
     assert "chrM" not in got["coverage"]["mean_coverage"]      # not part of the primary assembly
+    # NGSQ_RETURN_WHEN_DONE=1: the command returns when the document is on disk (the scan in a forked child); same document
+    out2 = tmp_path / "out2"
+    r = run(ngs, "-q", "qc", bam, GENOME, "-o", str(out2), "--batch-records", "1700", env=dict(os.environ, NGSQ_RETURN_WHEN_DONE="1"))
+    assert r.returncode == 0, r.stderr
+    json_equal(json.load(open(out2 / "sample.bam.results.json")), got)
     # --only + -p, written to the current directory
     r = run(ngs, "-q", "qc", bam, GENOME, "--only", "gc content", "-p", "x", cwd=str(tmp_path))
     assert r.returncode == 0 and r.stderr == ""
