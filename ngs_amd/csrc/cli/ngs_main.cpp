@@ -605,7 +605,9 @@ int main(int argc, char **argv) {
         uint64_t index_bins = 0;
         struct stat st;
         if (ngsq_bam_index_ref_starts(a.src.c_str(), n_refs, ref_start.data(), &index_bins) == NGSQ_OK && index_bins > 0 && stat(a.src.c_str(), &st) == 0) {
-            const uint64_t size = (uint64_t)st.st_size, margin = (uint64_t)20 << 20; // (the reader goes on 17 MiB behind its range for its last record)
+            // (a record belongs to the worker its first byte lies in; the margin covers the rounding of a range's end to a block start --
+            // and is generous: a sequence too many costs 0.1 s, one too few fails the run.  NGSQ_REF_MARGIN_BYTES: tests)
+            const uint64_t size = (uint64_t)st.st_size, margin = getenv("NGSQ_REF_MARGIN_BYTES") ? strtoull(getenv("NGSQ_REF_MARGIN_BYTES"), nullptr, 10) : (uint64_t)20 << 20;
             const uint64_t lo = size / (uint64_t)a.world * (uint64_t)a.rank, hi = a.rank + 1 == a.world ? size : size / (uint64_t)a.world * (uint64_t)(a.rank + 1) + margin;
             ref_wanted.assign(n_refs, 0);
             int64_t prev = -1; // the last sequence in front with records
@@ -756,6 +758,11 @@ int main(int argc, char **argv) {
         std::vector<const char *> name_ptrs(n_refs ? n_refs : 1, "");
         for (uint32_t r = 0; r < n_refs; r++) name_ptrs[r] = names[r].c_str();
         CHECK(ctx, ngsq_reference_load(ctx, fasta, name_ptrs.data(), ref_wanted.empty() ? nullptr : ref_wanted.data()));
+        if (!ref_wanted.empty()) {
+            uint32_t n_w = 0;
+            for (uint8_t w : ref_wanted) n_w += w;
+            logf(3, "  [*] Worker %d: the bases of %u of the %u sequences.", a.rank, n_w, n_refs);
+        }
         milestone("reference load started");
     };
     auto install_gene_model = [&]() {

@@ -162,3 +162,22 @@ def test_command_line_array_coverage_and_host_ingest(ngs, gpu_lib, world, files,
         r = run(ngs, "-q", "qc", world.bam, gu.GENOME, "-r", fa, "-f", gff, "-o", str(out), *extra)
         assert r.returncode == 0, r.stderr
         json_equal(json.load(open(out / "g.bam.results.json")), world.doc)
+
+
+def test_workers_load_the_sequences_their_byte_range_reaches(ngs, gpu_lib, world, files, tmp_path):
+    """`ngs qc --gpus 3 -r` on a file with a REAL index: a worker asks the loader only for the sequences whose records its byte
+    range of the file can hold (first virtual offsets from the BAI) -- N workers do not upload the FASTA N times -- and the
+    document is still the oracle's.  A sequence left out by mistake would fail the run (`edits_bad_reference`), never compare
+    with nothing."""
+    fa, gff = files
+    bam = str(tmp_path / "indexed.bam")
+    bamio.write_bam(bam, world.clean, world.names, world.lens, block_payload=30_000, real_index=True)
+    out = tmp_path / "o"
+    r = run(ngs, "-v", "qc", bam, gu.GENOME, "-r", fa, "-f", gff, "-o", str(out), "--gpus", "3", "--same-device",
+            env=dict(os.environ, NGSQ_REF_MARGIN_BYTES="65536"))
+    assert r.returncode == 0, r.stderr
+    got = json.load(open(out / "indexed.bam.results.json"))
+    json_equal(got, world.doc)          # (the same BAM bytes as world.bam -- only the index differs -- so the same record ids)
+    import re
+    loaded = [int(m.group(1)) for m in re.finditer(r"the bases of (\d+) of the 195 sequences", r.stderr)]
+    assert len(loaded) >= 1 and min(loaded) < 195, r.stderr[-2000:]      # (rank 0 narrates; at least it loaded a part only)
