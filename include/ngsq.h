@@ -330,9 +330,11 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out);
 void ngsq_destroy(ngsq_ctx *ctx);
 const char *ngsq_last_error(const ngsq_ctx *ctx);
 
-/* Install the gene model of the Genomic Features facet (required before the first batch when
- * NGSQ_FACET_FEATURES is enabled; the arrays are copied).  Replaces GenomicFeaturesFacet::try_from's
- * interval stores (features.rs:300-343). */
+/* Install the gene model of the Genomic Features facet (the arrays are copied).  Replaces GenomicFeaturesFacet::try_from's
+ * interval stores (features.rs:300-343).  The model may arrive AFTER the first batches (ABI 6: a host still reading its GFF need
+ * not hold the scan back): ngsq_process_batch then keeps what the facet needs of the batch's records on the device (flag,
+ * sequence, position, reference span: 16 bytes per record) and this call looks them up; it must have been called before
+ * ngsq_exchange / ngsq_finalize when any batch was scanned (NGSQ_ERR_STATE otherwise). */
 int ngsq_set_features(ngsq_ctx *ctx, const ngsq_features *features);
 
 /* facet.process for every record of the batch (asynchronous on the context's

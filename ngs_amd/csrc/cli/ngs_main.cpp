@@ -784,13 +784,24 @@ int main(int argc, char **argv) {
     // The gene model is usually there by now (it was parsed beside the device's initialisation): it goes to the device FIRST -- its
     // synchronous copies took 0.4 s when they queued behind the reference's 3 GB of text (round 6) -- and the reference starts
     // behind it; a model that is still being read (a gzip stream inflates on one thread) waits beside the reference instead.
+    bool model_pending = false;
     if (!gff_thread.joinable() || gff_done) {
         install_gene_model();
         start_reference();
     } else {
+        // (the scan does not wait for it: batches that come before the model keep what the facet needs of their records on the
+        // device -- ngsq_process_batch, 16 bytes per record -- and ngsq_set_features looks them up when it arrives: a gzipped GFF
+        // inflates on one thread for seconds, beside a scan of seconds)
         start_reference();
-        install_gene_model();
+        model_pending = (facets & NGSQ_FACET_FEATURES) != 0;
+        if (!model_pending) install_gene_model();
     }
+    auto model_if_ready = [&](bool wait) {
+        if (model_pending && (wait || gff_done)) {
+            install_gene_model();
+            model_pending = false;
+        }
+    };
     if (want_vaf && !vaf_file) {
         vaf_file = fopen(a.vaf.c_str(), "wb");
         if (!vaf_file) bail("creating VAF file");
@@ -833,11 +844,13 @@ int main(int argc, char **argv) {
                         scan_error = ngsq_last_error(ctx);
                         break;
                     }
+                    model_if_ready(false);
                     n_pass1 += b.n_records;
                 }
             }
             ngsq_bam_shard_info info;
             int again = 0;
+            model_if_ready(true);
             comm_ready();
             const int vrc = ngsq_bam_shard_verify(bam, ctx, comm, &info, &again);
             // (a scan that failed while it ran from an ASSUMED first record is forgiven once: the verdict is `again`.  Only the
@@ -873,6 +886,7 @@ int main(int argc, char **argv) {
                 bail(ngsq_bam_last_error());
             if (!b.n_records) break;
             CHECK(ctx, ngsq_process_batch(ctx, &b, NGSQ_PASS_BOTH));
+            model_if_ready(false);
             const unsigned long long before = n_pass1;
             n_pass1 += b.n_records;
             for (unsigned long long m = before / 1000000 + 1; m * 1000000 <= n_pass1; m++)
@@ -984,6 +998,7 @@ int main(int argc, char **argv) {
     {
         int rc = NGSQ_OK;
         std::string why;
+        model_if_ready(true); // (at the latest: the facet's tallies are part of what is exchanged and finalized)
         comm_ready();
         if (shard_unsorted) {
             rc = NGSQ_ERR_UNSORTED;

@@ -400,6 +400,7 @@ void ngsq_destroy(ngsq_ctx *c) {
     (void)hipFree(c->d_ft_starts);
     (void)hipFree(c->d_ft_stops);
     (void)hipFree(c->d_ft_primary);
+    for (const ngsq_ctx::DeferredFeatures &d : c->ft_deferred) (void)hipFree(d.buf);
     for (auto &p : c->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -640,10 +641,21 @@ static int launch_all(ngsq_ctx *c, const DeviceBatch &db, const ColumnSizes &cs,
     }
     if (rec_f & NGSQ_FACET_FEATURES) {
         // (on a stream of its own beside the other facets' kernels it hides nothing: 10.9 ms per all-facets pass either way, round 5)
-        if (!c->have_features)
-            return fail(c, NGSQ_ERR_STATE, "NGSQ_FACET_FEATURES is enabled but ngsq_set_features was not called");
-        Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4);
-        HIP_TRY(c, launch_features(c->li, c->st, db, c->ft, c->stream));
+        if (!c->have_features) {
+            // the gene model is not there yet (the host is still reading the GFF): keep what the facet needs of these records --
+            // 16 bytes each -- and look them up when it arrives (ngsq_set_features); ngsq_finalize fails if it never does
+            ngsq_ctx::DeferredFeatures d{nullptr, 0, n};
+            const uint64_t n16 = round_up(n, 16);
+            HIP_TRY(c, ngsq::pool_device_alloc((void **)&d.buf, n16 * 16 + 256, &d.bytes));
+            c->ft_deferred.push_back(d);
+            Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4);
+            HIP_TRY(c, launch_features_defer(c->li, db, reinterpret_cast<uint16_t *>(d.buf + n16 * 12), reinterpret_cast<int32_t *>(d.buf),
+                                             reinterpret_cast<int32_t *>(d.buf + n16 * 4), reinterpret_cast<uint16_t *>(d.buf + n16 * 14),
+                                             reinterpret_cast<uint32_t *>(d.buf + n16 * 8), c->stream));
+        } else {
+            Bracket br(c, K_FEATURES, n * 12 + cs.cigar_ops * 4);
+            HIP_TRY(c, launch_features(c->li, c->st, db, c->ft, c->stream));
+        }
     }
     if (seq_f & NGSQ_FACET_EDITS) {
         if (c->ref_deferred && !c->ref_ready) {
@@ -738,6 +750,25 @@ int ngsq_set_features(ngsq_ctx *c, const ngsq_features *f) {
     c->ft.n_refs = n_refs;
     for (int r = 0; r < 5; r++) c->ft.role_name[r] = f->role_name[r];
     c->have_features = true;
+    // the batches that came first
+    for (const ngsq_ctx::DeferredFeatures &d : c->ft_deferred) {
+        const uint64_t n16 = round_up(d.n, 16);
+        DeviceBatch db{};
+        db.n = d.n;
+        db.ref_id = reinterpret_cast<const int32_t *>(d.buf);
+        db.pos = reinterpret_cast<const int32_t *>(d.buf + n16 * 4);
+        db.cigar = reinterpret_cast<const uint32_t *>(d.buf + n16 * 8);
+        db.flag = reinterpret_cast<const uint16_t *>(d.buf + n16 * 12);
+        db.n_cigar = reinterpret_cast<const uint16_t *>(d.buf + n16 * 14);
+        db.cigar_stride = 1;
+        Bracket br(c, K_FEATURES, d.n * 16);
+        HIP_TRY(c, launch_features(c->li, c->st, db, c->ft, c->stream));
+    }
+    if (!c->ft_deferred.empty()) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (const ngsq_ctx::DeferredFeatures &d : c->ft_deferred) ngsq::pool_device_free(d.buf, d.bytes);
+        c->ft_deferred.clear();
+    }
     return NGSQ_OK;
 }
 
@@ -868,6 +899,8 @@ static int mark_edits_written(ngsq_ctx *c) {
 int ngsq_teardown(ngsq_ctx *c) {
     if (!c) return NGSQ_ERR_INVALID_ARGUMENT;
     if (c->finalized || c->torn_down) return fail(c, NGSQ_ERR_STATE, "already torn down");
+    if (!c->ft_deferred.empty())
+        return fail(c, NGSQ_ERR_STATE, "NGSQ_FACET_FEATURES: batches were scanned but ngsq_set_features was never called");
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t facets = c->cfg.facets;
     const uint32_t nr = c->st.n_refs;
@@ -1145,6 +1178,8 @@ int ngsq_reset(ngsq_ctx *c) {
     c->h_touched[0] = ~0ull;
     c->h_touched[1] = 0;
     if (step_legacy()) HIP_TRY(c, hipMemcpyAsync(c->d_touched, c->h_touched, 16, hipMemcpyHostToDevice, c->stream));
+    for (const ngsq_ctx::DeferredFeatures &d : c->ft_deferred) ngsq::pool_device_free(d.buf, d.bytes); // (frees behind a device sync)
+    c->ft_deferred.clear();
     c->span_turn = 0;
     c->finalized = false;
     c->edits_uploaded = false;

@@ -111,6 +111,13 @@ struct ngsq_ctx {
     uint32_t *d_ft_idx = nullptr, *d_ft_starts = nullptr, *d_ft_stops = nullptr;
     uint8_t *d_ft_primary = nullptr;
     bool have_features = false;
+    // batches that came before ngsq_set_features: their records' (flag, sequence, position, span) kept on the device
+    struct DeferredFeatures {
+        uint8_t *buf;
+        size_t bytes;
+        uint64_t n;
+    };
+    std::vector<DeferredFeatures> ft_deferred;
     ngsq::Staging stage[2];
     int stage_next = 0;
     ngsq_kernel_time timing[ngsq::K_COUNT]{};

@@ -476,6 +476,8 @@ int ctx_teardown_range(void *u, uint64_t b0, uint64_t b1, const uint32_t *words,
 extern "C" int ngsq_exchange(ngsq_ctx *c, ngsq_comm *comm, ngsq_exchange_report *report) {
     if (!c || !comm) return comm_fail(comm, NGSQ_ERR_INVALID_ARGUMENT, "null argument");
     if (c->finalized || c->torn_down) return comm_fail(comm, NGSQ_ERR_STATE, "ngsq_exchange after the teardown; call ngsq_reset");
+    if (!c->ft_deferred.empty())
+        return comm_fail(comm, NGSQ_ERR_STATE, "NGSQ_FACET_FEATURES: batches were scanned but ngsq_set_features was never called");
     if (hipSetDevice(c->device) != hipSuccess) return comm_fail(comm, NGSQ_ERR_DEVICE, "hipSetDevice(%d) failed", c->device);
     {   // the shards' quality tables have grown to the longest read each of them met: the counter blocks are summed element
         // by element, so they take the size of the largest first

@@ -20,6 +20,8 @@
 
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ngsq {
@@ -340,6 +342,37 @@ __global__ __launch_bounds__(256) void k_features(DeviceState st, DeviceBatch b,
         if (sum) atomicAdd(dst, sum);
     }
     if (threadIdx.x == 0) ft.scratch[FT_SLOTS * 16] = 0;
+}
+
+// What Genomic Features needs of a record -- flag, sequence, position, reference span (features.rs:127-178) -- written out as a
+// batch of its own (16 bytes per record: the span as ONE `M` operation, clamped to 2^28 - 1, beyond every sequence) for batches that
+// arrive BEFORE the gene model does: ngsq_set_features runs k_features over them when the model is there (round 6: a gzipped GFF
+// inflates on one host thread for seconds; the scan no longer waits for it).
+__global__ __launch_bounds__(256) void k_features_defer(DeviceBatch b, uint16_t *__restrict__ flag, int32_t *__restrict__ ref, int32_t *__restrict__ pos,
+                                                        uint16_t *__restrict__ ncig, uint32_t *__restrict__ cig) {
+    NGSQ_FOREGROUND_WAVE();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < b.n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t n_ops = batch_n_ops(b, i);
+        const uint64_t c0 = b.cigar_off ? b.cigar_off[i] : i * b.cigar_stride;
+        uint64_t span = 0;
+        for (uint32_t k = 0; k < n_ops; k++) {
+            const uint32_t op = b.cigar[c0 + k];
+            if ((0x18Du >> (op & 15u)) & 1u) span += op >> 4;
+        }
+        flag[i] = b.flag[i];
+        ref[i] = b.ref_id[i];
+        pos[i] = b.pos[i];
+        ncig[i] = 1;
+        cig[i] = (uint32_t)(span < 0x0FFFFFFFull ? span : 0x0FFFFFFFull) << 4; // <span>M
+    }
+}
+
+hipError_t launch_features_defer(const LaunchInfo &li, const DeviceBatch &b, uint16_t *flag, int32_t *ref, int32_t *pos, uint16_t *ncig, uint32_t *cig,
+                                 hipStream_t s) {
+    if (!b.n) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((b.n + 255) / 256, (uint64_t)li.n_cu * 16);
+    hipLaunchKernelGGL(k_features_defer, dim3(grid), dim3(256), 0, s, b, flag, ref, pos, ncig, cig);
+    return hipGetLastError();
 }
 
 hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const FeatureTables &ft,

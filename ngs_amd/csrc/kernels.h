@@ -191,6 +191,9 @@ struct FeatureTables {
     unsigned long long *scratch; // [FT_SLOTS * 16 + 1] zero between launches: per-slot partial tallies, then the launch's ticket
 };
 constexpr uint32_t FT_SLOTS = 32;
+// a batch that arrives before the gene model: the four facts the facet needs of each record, as columns of a batch of their own
+hipError_t launch_features_defer(const LaunchInfo &li, const DeviceBatch &b, uint16_t *flag, int32_t *ref, int32_t *pos, uint16_t *ncig, uint32_t *cig,
+                                 hipStream_t s);
 hipError_t launch_features(const LaunchInfo &li, const DeviceState &st, const DeviceBatch &b, const FeatureTables &ft,
                            hipStream_t s);
 // Quality Score for the offsets layout with max_read_len <= 320 (qual_kernel.hip)

@@ -952,11 +952,47 @@ def test_genomic_features_errors_and_state(gpu_lib, oracle_mod):
     e = gpu.error_counts()
     assert e["features_missing_reference_id"] == 1 and e["features_missing_position"] == 1
     assert gpu.features()["intronic_count"] == 1
-    # the facet cannot run without a gene model
+    # the facet cannot FINISH without a gene model (batches may come before it: test_gene_model_after_the_first_batches)
     q = host.QcContext(ref_len, facets=ffi.FACET_FEATURES, lib=gpu_lib)
+    q.process_batch(batch_from_records(recs[:1]))
     with pytest.raises(Exception, match="ngsq_set_features"):
-        q.process_batch(batch_from_records(recs[:1]))
+        q.finalize()
+    q.reset()                 # (drops what was kept of the batch)
+    assert q.finalize() == 0 and q.features()["processed"] == 0
     q.close()
+
+
+@pytest.mark.parametrize("layout", ["offsets", "rows"])
+def test_gene_model_after_the_first_batches(gpu_lib, oracle_mod, layout):
+    """Batches that reach the context BEFORE ngsq_set_features (the host is still reading the GFF: a gzip stream inflates on one
+    thread for seconds) keep what Genomic Features needs of their records -- flag, sequence, position, span: 16 bytes each -- and are
+    looked up when the model arrives; batches behind it go the usual way.  Same tallies and errors as the oracle's, every facet
+    beside it untouched; a model that arrives twice (ngsq_set_features again) replaces the tables for what follows."""
+    from tests.util import to_fixed_stride
+    rng = np.random.default_rng(404)
+    ref_len = [60_000, 9_000, 25_000]
+    primary = [1, 0, 1]
+    ref, name, start, stop = random_gene_model(rng, ref_len, 600)
+    hb = random_batch(rng, 30_000, ref_len, weird=True, max_len=120 if layout == "rows" else 300)
+    if layout == "rows":
+        hb = to_fixed_stride(hb)
+    facets = ffi.FACETS_DEFAULT | ffi.FACET_FEATURES
+    kw = dict(facets=facets, bin_size=1000, max_read_len=320, gc_seed=7)
+    orc = oracle_mod.Oracle(ref_len, primary, **kw)
+    orc.set_features(ref, name, start, stop)
+    orc.process_batch(hb)
+    rc = orc.finalize(allow_malformed=True)
+    with host.QcContext(ref_len, primary, lib=gpu_lib, **kw) as gpu:
+        gpu.process_batch(hb.slice(0, 7_001))
+        gpu.process_batch(gpu.upload(hb.slice(7_001, 19_000)))
+        gpu.set_features(ref, name, start, stop)        # the model arrives: the 19 000 records kept so far are looked up
+        gpu.process_batch(hb.slice(19_000, hb.n))
+        assert gpu.finalize(allow_malformed=True) == rc
+        compare_contexts(gpu, orc, 3, facets, 1000, ref_len)
+        json_equal(gpu.results(["a", "b", "c"]), orc.results(["a", "b", "c"]))
+        f = gpu.features()
+        assert f["processed"] + f["ignored_flags"] + f["ignored_nonprimary_chromosome"] + \
+            gpu.error_counts()["features_missing_reference_id"] + gpu.error_counts()["features_missing_position"] == hb.n
 
 
 def test_quality_counters_of_the_offsets_layout_do_not_wrap(gpu_lib):
