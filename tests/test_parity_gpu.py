@@ -106,6 +106,45 @@ def test_device_generator_matches_host_generator(gpu_lib):
                 np.testing.assert_array_equal(got, a, err_msg=f"mode {mode} column {name}")
 
 
+@pytest.mark.parametrize("mode", ["fixed", "mixed"])
+def test_genome_mode_generator_and_parity(gpu_lib, oracle_mod, mode):
+    """GENOME mode of the synthetic generator (include/ngsq_shared.h; bench.py whole_genome and the realistic file): the records are
+    spread over the 195 sequences of the GRCh38 header (chromosomes scaled down here), coordinate-sorted, never across a sequence's
+    end, mates of 1 % of the pairs on the next sequence; the device generator equals the host's byte for byte, and all default
+    facets + Edits on them equal the oracle's (the reads are sampled from the synthetic reference of their OWN sequence)."""
+    from ngs_amd.genome_shape import grch38_no_alt
+    names, lens, primary = grch38_no_alt(256)
+    n = 120_000
+    cfg = host.synth_config(n, mode=ffi.SYNTH_MIXED if mode == "mixed" else ffi.SYNTH_FIXED, genome=lens, lib=gpu_lib,
+                            seq_model=ffi.SYNTH_SEQ_FROM_REFERENCE, file_style=ffi.SYNTH_FILE_CIGAR_MIX if mode == "fixed" else 0)
+    hb = host.synth_host_batch(cfg, 0, n, gpu_lib)
+    c = hb.cols
+    key = (c["ref_id"].astype(np.int64) << 32) | c["pos"]
+    assert (np.diff(key) >= 0).all() and len(np.unique(c["ref_id"])) > 150
+    span = np.zeros(n, dtype=np.int64)
+    co = c["cigar_off"] if c.get("cigar_off") is not None else np.arange(n + 1, dtype=np.uint64) * hb.cigar_stride
+    for i in range(0, n, 37):      # (a sample: a Python loop)
+        ops = c["cigar"][int(co[i]):int(co[i]) + int(c["n_cigar"][i])]
+        span[i] = sum(int(x) >> 4 for x in ops if (int(x) & 15) in (0, 2, 3, 7, 8))
+    assert (c["pos"][::37] + span[::37] <= np.array(lens)[c["ref_id"][::37]]).all()      # no read crosses the end of its sequence
+    bases = [host.synth_reference(cfg, r, L, gpu_lib) for r, L in enumerate(lens)]
+    kw = dict(facets=ffi.FACETS_DEFAULT | ffi.FACET_EDITS, max_read_len=320, gc_seed=3)
+    orc = oracle_mod.Oracle(lens, primary, ref_bases=bases, **kw)
+    orc.process_batch(hb)
+    assert orc.finalize() == 0
+    r1, r2, _ = orc.edits()
+    assert int(r1[:6].sum() + r2[:6].sum()) > 0.98 * int(r1.sum() + r2.sum())          # sampled from the right sequence: few edits
+    with host.QcContext(lens, primary, ref_bases=bases, sorted_input=True, lib=gpu_lib, **kw) as gpu:
+        db = gpu.synth_device_batch(cfg, 0, n)
+        for name_, a in hb.cols.items():
+            if a is not None:
+                np.testing.assert_array_equal(gpu.download_column(db, name_, a.size), a, err_msg=f"{mode} column {name_}")
+        gpu.process_batch(db)
+        assert gpu.finalize() == 0
+        compare_contexts(gpu, orc, len(lens), kw["facets"], 50_000, lens)
+        json_equal(gpu.results(names), orc.results(names))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_edge_cases(gpu_lib, oracle_mod, seed):
     """Ragged, empty, unplaced, out-of-range, every flag bit, every CIGAR op."""
