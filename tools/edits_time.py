@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iid", action="store_true")
     ap.add_argument("--aligner", action="store_true", help="an aligner's CIGAR mix on the fixed-length reads: 9 %% soft clips, 3 %% insertions, 3 %% deletions")
     ap.add_argument("--subst", type=float, default=0.0, help="fraction of the compared bases substituted (default: the model's 0.5 %%)")
+    ap.add_argument("--gc", action="store_true", help="GC Content in the same context: the variant of k_edits_rows that tallies it")
     ap.add_argument("--tag", default="")
     a = ap.parse_args()
     lib = ffi.load_library()
@@ -27,7 +28,7 @@ def main():
                             seq_model=ffi.SYNTH_SEQ_IID if a.iid else (ffi.synth_seq_subst(a.subst) if a.subst else ffi.SYNTH_SEQ_FROM_REFERENCE),
                             file_style=ffi.SYNTH_FILE_CIGAR_MIX if a.aligner else 0)
     bases = [host.synth_reference(cfg, 0, CHR1, lib), None]
-    ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=ffi.FACET_EDITS, max_read_len=300 if a.mixed else 150, timing=True, ref_bases=bases, lib=lib)
+    ctx = host.QcContext([CHR1, CHR2], [1, 1], facets=ffi.FACET_EDITS | (ffi.FACET_GC_CONTENT if a.gc else 0), max_read_len=300 if a.mixed else 150, timing=True, ref_bases=bases, lib=lib)
     db = ctx.synth_device_batch(cfg, 0, a.records)
     for _ in range(3):
         ctx.reset()
