@@ -129,9 +129,10 @@ typedef struct ngsq_config {
                                ngsq_reference_load (ngsq_reference.h), which ngsq_process_batch waits for        */
     const uint32_t *ref_bases_len; /* optional, with ref_bases: [n_refs] bases the FASTA holds of each sequence when that
                                differs from ref_len (the reference slices the FASTA's sequence, edits.rs:257-261: a read
-                               that runs past ITS end fails, counted as edits_bad_reference; bases beyond ref_len are never
-                               looked at).  ref_bases[r] then points to min(ref_bases_len[r], ref_len[r]) bytes.  NULL =
-                               every sequence has ref_len bases                                                   */
+                               that runs past ITS end fails, counted as edits_bad_reference; a read that ends beyond
+                               ref_len inside a longer sequence fails only if an `M` base lies there, edits.rs:283-291 --
+                               the VALUES of bases beyond ref_len are never looked at).  ref_bases[r] then points to at
+                               least min(ref_bases_len[r], ref_len[r]) bytes.  NULL = every sequence has ref_len bases */
 } ngsq_config;
 
 /*

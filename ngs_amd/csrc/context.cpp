@@ -354,8 +354,9 @@ int ngsq_create(const ngsq_config *cfg, ngsq_ctx **out) {
             const uint64_t L = c->ref_len[r];
             // (ref_bases_len: the FASTA's sequence may be shorter or longer than @SQ LN says -- edits.rs:257-261 slices the FASTA's)
             const uint64_t have_r = cfg->ref_bases_len && !deferred ? std::min<uint64_t>(cfg->ref_bases_len[r], L) : L;
-            have[r] = have[nr + r] = (uint32_t)have_r;
-            lens_differ = lens_differ || have_r != L;
+            have[nr + r] = (uint32_t)have_r;
+            have[r] = cfg->ref_bases_len && !deferred ? cfg->ref_bases_len[r] : (uint32_t)L; // (the FASTA's own length: a read may end beyond LN inside it)
+            lens_differ = lens_differ || have[r] != L;
             if (!deferred && have_r) {
                 CTX_TRY(hipMemcpyAsync(codes, cfg->ref_bases[r], have_r, hipMemcpyHostToDevice, c->stream));
                 CTX_TRY(launch_pack_reference(c->li, codes, have_r, bases + bases_off[r], bases + nbases + bases_off[r], L / 2 + 1, d_bad, c->stream));

@@ -104,7 +104,8 @@ __device__ __forceinline__ uint32_t ed_walk_record(const DeviceState &st, const 
     if (e == 0 || s > L || (f & 0x404u)) return 0; // not yielded by query(); unmapped | duplicate (edits.rs:227-229)
     const uint64_t boff = st.ref_bases_off[ref];
     // edits.rs:245-261: no such sequence in the FASTA / the slice start..start+span runs past the FASTA's sequence (its own
-    // length, which need not be @SQ LN: ref_edits_len) or past LN (the per-position histograms end there) ...
+    // length, which need not be @SQ LN: ref_edits_len -- a read may end beyond LN inside a longer FASTA sequence as long as
+    // no `M` base lies there: see the operation loop) ...
     if (boff == NO_DEPTH || e > (st.ref_edits_len ? (uint64_t)st.ref_edits_len[ref] : L)) return 1;
     if (st.ref_bad_off) { // ... or holds a byte Base::try_from refuses (edits.rs:257-261 `?` on the collected Result)
         uint32_t lo = st.ref_bad_off[ref];
@@ -132,8 +133,15 @@ __device__ __forceinline__ uint32_t ed_walk_record(const DeviceState &st, const 
         if (op == 0u) { // only Kind::Match compares (edits.rs:277)
             // (a record that runs out of bases inside an M: alignment.rs:84-87; like the reference, the positions visited
             // before the error stay counted -- the error aborts the run anyway)
-            const uint32_t m = (uint64_t)qp + len > l ? l - qp : len;
+            const uint32_t avail = (uint64_t)qp + len > l ? l - qp : len;
             const uint64_t p0 = (uint64_t)pos + rp;
+            // edits.rs:283-291: refs/alts_per_position have LN + 1 bins and increment(..).unwrap() panics beyond them -- the
+            // first `M` base at a position above LN stops the run (bases under D, N, = and X there do not: nothing is
+            // incremented for them).  It comes before the read runs out iff fewer bases fit than the read still has; the
+            // bases in front of it are counted like those in front of any other stop.
+            const uint64_t fit = p0 < L ? L - p0 : 0ull;
+            const bool beyond = fit < (uint64_t)avail;
+            const uint32_t m = beyond ? (uint32_t)fit : avail;
             // 32 bases per round: the eight loads of four 8-base steps first, then their mismatches (an atomic between two
             // steps' loads kept the compiler from having more than one step's loads in flight: the walk of an aligner's 6 % of
             // reads with an insertion or a deletion took as long as the fast path took for the other 94 %)
@@ -163,6 +171,7 @@ __device__ __forceinline__ uint32_t ed_walk_record(const DeviceState &st, const 
                 atomicAdd(&diff[p0 + m], 0xFFFFFFFFu);
                 st.counters[st.off_eseen + ref] = 1ull; // (a plain store: the sequence has Edits state)
             }
+            if (beyond) return 1;
             qp += m;
             rp += m;
             if (m < len) return 2;

@@ -97,8 +97,8 @@ struct DeviceState {
     const uint8_t *ref_bases_odd;  // ... and starting at base 1 (a read at an odd 0-based position finds its bytes here)
     const uint64_t *ref_bases_off; // [n_refs] byte offset of the sequence in either copy, NO_DEPTH if absent
     // what the FASTA holds of each sequence (ngsq_config.ref_bases_len, ngsq_reference_load); all null = ref_len bases of each
-    const uint32_t *ref_edits_len; // [n_refs] min(bases in the FASTA, ref_len): a read that ends beyond it fails (edits.rs:257-261)
-    const uint32_t *ref_fast_len;  // [n_refs] the same, or 0 = every record of the sequence takes the one-record walk (it has bad positions)
+    const uint32_t *ref_edits_len; // [n_refs] bases of the sequence in the FASTA (more or fewer than ref_len): a read that ends beyond them fails (edits.rs:257-261)
+    const uint32_t *ref_fast_len;  // [n_refs] min(that, ref_len): what the window lanes may reach; 0 = every record of the sequence takes the one-record walk (it has bad positions)
     const uint32_t *ref_bad_off;   // [n_refs + 1] the sequence's entries of ref_bad_pos
     const uint32_t *ref_bad_pos;   // sorted 1-based positions whose FASTA byte is no base letter: a read that covers one fails
     uint64_t gc_seed;

@@ -537,7 +537,7 @@ int load_main(Loader *L) {
             for (unsigned long long v : list) {
                 const size_t k = (size_t)(v >> 40);
                 const uint64_t pos = v & ((1ull << 40) - 1);
-                if (k < nseq && pos <= c->ref_len[want[k].ref]) bad[want[k].ref].push_back((uint32_t)pos);
+                if (k < nseq && pos <= 0xFFFFFFFFull) bad[want[k].ref].push_back((uint32_t)pos); // (beyond LN too: a read may end there, ed_walk_record)
             }
         }
     }
@@ -547,7 +547,7 @@ int load_main(Loader *L) {
         S.bases += have;
         S.shorter += h_back[k] < Lr;
         S.longer += h_back[k] > Lr;
-        lens[r] = (uint32_t)have;
+        lens[r] = (uint32_t)std::min<uint64_t>(h_back[k], 0xFFFFFFFFull); // the FASTA's own count: a read may end beyond LN inside a longer sequence
         std::sort(bad[r].begin(), bad[r].end());
         lens[nr + r] = bad[r].empty() ? (uint32_t)have : 0u; // a sequence with listed positions: every record takes the walk, which looks them up
     }

@@ -212,7 +212,8 @@ class QcContext:
                     arr[r] = None
                 else:
                     a = np.ascontiguousarray(a, dtype=np.uint8)
-                    assert a.size == (int(self._ref_len[r]) if ref_bases_len is None else min(int(ref_bases_len[r]), int(self._ref_len[r])))
+                    # (with ref_bases_len the array may hold the FASTA's whole sequence: only min(its length, LN) bases are read)
+                    assert a.size == int(self._ref_len[r]) if ref_bases_len is None else a.size >= min(int(ref_bases_len[r]), int(self._ref_len[r]))
                     keep.append(a)
                     arr[r] = a.ctypes.data_as(ffi.u8p)
             self._bases_keep = (arr, keep)

@@ -584,6 +584,7 @@ typedef struct {
     uint32_t ref;
     uint64_t reference_start;
     uint64_t edits;
+    int beyond; /* an `M` base at a position the per-position histograms do not have: increment(..).unwrap() panics (:283-291) */
 } edits_visit_state;
 
 static void edits_visit(void *user, uint32_t kind, int has_ref, uint32_t ref_base, size_t rp,
@@ -595,9 +596,9 @@ static void edits_visit(void *user, uint32_t kind, int has_ref, uint32_t ref_bas
         uint64_t reference_position = s->reference_start + rp; /* :278-280 */
         if (ref_base != rec_base) {                             /* :282-287 */
             s->edits += 1;
-            orc_hist_increment(&s->c->edits.alts_per_position[s->ref], reference_position);
+            if (orc_hist_increment(&s->c->edits.alts_per_position[s->ref], reference_position) != ORC_OK) s->beyond = 1;
         } else { /* :288-291 */
-            orc_hist_increment(&s->c->edits.refs_per_position[s->ref], reference_position);
+            if (orc_hist_increment(&s->c->edits.refs_per_position[s->ref], reference_position) != ORC_OK) s->beyond = 1;
         }
     }
 }
@@ -627,10 +628,11 @@ static void edits_process(orc_ctx *c, const orc_record *r, uint64_t start) {
     /* :245-251 + :257-261  current_sequence.get(start..end) -> [start-1, end-1) */
     const uint8_t *bases = c->ref_bases[ref];
     /* the slice is taken from the FASTA's sequence, whose length need not be @SQ LN (ngsq_config.ref_bases_len): `get` is None
-     * -- unwrap panics -- when the read runs past ITS end; a read past LN panics two steps later, in
-     * refs/alts_per_position.increment (:284-291, histograms of LN + 1 bins).  Either way the run aborts here. */
-    uint64_t have = c->ref_len[ref];
-    if (c->ref_bases_len && c->ref_bases_len[ref] < have) have = c->ref_bases_len[ref];
+     * -- unwrap panics -- when the read runs past ITS end.  A read past LN inside a longer FASTA sequence is another matter:
+     * what panics then is refs/alts_per_position.increment (:283-291, histograms of LN + 1 bins), and only an `M` base
+     * increments -- a read whose bases beyond LN lie under D, N, = or X goes through (found in round 6 by the second reading of
+     * the source, tests/literal_model.py: until then every read that ended beyond LN was counted as one the reference stops at). */
+    uint64_t have = c->ref_bases_len ? c->ref_bases_len[ref] : c->ref_len[ref];
     if (!bases || reference_end - 1 > have) {
         c->errors.edits_bad_reference += 1;
         return;
@@ -647,9 +649,13 @@ static void edits_process(orc_ctx *c, const orc_record *r, uint64_t start) {
         orc_hist_init(&e->refs_per_position[ref], c->ref_len[ref]);
         orc_hist_init(&e->alts_per_position[ref], c->ref_len[ref]);
     }
-    edits_visit_state st = {c, ref, reference_start, 0};
+    edits_visit_state st = {c, ref, reference_start, 0, 0};
     int rc = stepthrough(bases + (reference_start - 1), (size_t)(reference_end - reference_start),
                          r->seq, NULL, r->l_seq, r->cigar, r->n_cigar, edits_visit, &st);
+    if (st.beyond) { /* (the walk visits the bases in order and stops at its own first error: this one came before it) */
+        c->errors.edits_bad_reference += 1;
+        return;
+    }
     if (rc == 2) {
         c->errors.edits_record_short += 1;
         return;

@@ -74,6 +74,16 @@
  *            worked by hand.  Aux tags are otherwise skipped unread: no facet looks at them.
  *     The hand goldens and the synthetic workloads stay away from the corner cases
  *     of [N4] and [N5] (span 0, start beyond L) except where a test names them.
+ *   - A SECOND READING (round 6).  tests/literal_model.py restates the same facets once more, from the .rs files
+ *     alone, in the reference's own shape (a record at a time, dicts for its HashMaps, a Histogram class with its
+ *     methods), and tests/test_literal_model.py holds the two restatements against each other: the same Results
+ *     document on random records (all seven facets, FASTA lengths that differ from LN, soft-masked and refused bytes,
+ *     roles that share names), and "the model stops at a record" <=> "this oracle counts an error".  It does not lift
+ *     "parity unpinned" -- both are readings of one source, and [N1]..[N10] are shared assumptions -- but a slip in
+ *     either shows.  Its first 800 random settings found one in THIS file: every read that ended beyond @SQ LN inside a
+ *     longer FASTA sequence was counted as a run the reference aborts, where edits.rs only panics for an `M` base there
+ *     (increment().unwrap(), :283-291); bases beyond LN under D, N, = or X go through.  Oracle, kernels and loader now
+ *     keep the exact rule (tests/test_reference.py::test_reads_beyond_ln_inside_a_longer_fasta_sequence).
  */
 #ifndef ORC_ORACLE_H
 #define ORC_ORACLE_H

@@ -196,6 +196,8 @@ def test_end_to_end(ngs, gpu_lib, oracle_mod, tmp_path, shape):
     assert "Processed 6,000 records in the first pass." in r.stderr
     got = json.load(open(out / "sample.bam.results.json"))     # default prefix = BAM file name
     json_equal(got, oracle_json(oracle_mod, hb))
+    from tests import literal_model as lm                       # (the second reading of the source judges the command too)
+    json_equal(got, lm.run(lm.records_of(hb), NAMES, LENS, PRIMARY, gc_seed=0x4E4753))
     assert "chrM" not in got["coverage"]["mean_coverage"]      # not part of the primary assembly
     # NGSQ_RETURN_WHEN_DONE=1: the command returns when the document is on disk (the scan in a forked child); same document
     out2 = tmp_path / "out2"
@@ -246,6 +248,9 @@ def test_num_records_rules(ngs, gpu_lib, oracle_mod, tmp_path, n, index, gpus):
                 break
     want = oracle_json(oracle_mod, hb, pass1=hb.slice(0, keep1), pass2=[hb.slice(i, i + 1) for i in picks])
     json_equal(got, want)
+    # the second reading of the source (tests/literal_model.py) with its own `-n`: the command's document, directly
+    from tests import literal_model as lm
+    json_equal(got, lm.run(lm.records_of(hb), NAMES, LENS, PRIMARY, gc_seed=0x4E4753, num_records=n))
 
 
 @pytest.mark.gpu

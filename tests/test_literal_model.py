@@ -1,0 +1,212 @@
+"""oracle/oracle.c against a second, independent reading of the reference (tests/literal_model.py).
+
+The oracle is what every GPU result is judged by, and the reference holds no vector for any facet's `process`
+(oracle/oracle.h: "parity unpinned").  Here the two restatements -- the C one and a record-at-a-time Python one in the
+reference's own shape -- process the same random records and must write the same Results document; and a record the
+Python reading says the reference would stop at (a panic, a bail!) must be one the oracle counts as an error.
+CPU only: no GPU, no HIP library.
+"""
+import numpy as np
+import pytest
+
+from ngs_amd import ffi
+from oracle import oracle_py
+from tests import literal_model as lm
+from tests.util import json_equal, make_edit_friendly, random_batch, take_records
+
+LETTERS = np.frombuffer(b"ACGTacgtNnRYKMSWBDHVrykm=", dtype=np.uint8)   # what Base::try_from takes, either case [N9]
+REFUSED = np.frombuffer(b"X-*Ux", dtype=np.uint8)                      # what it refuses
+
+
+def random_fasta(rng, ref_len, refused=0.0005):
+    out = []
+    for L in ref_len:
+        k = int(rng.choice([L, L, L, max(1, L - int(rng.integers(1, 200))), L + int(rng.integers(1, 200))]))   # FASTA length need not be @SQ LN
+        p = np.full(LETTERS.size, 0.04 / (LETTERS.size - 8))
+        p[:8] = 0.96 / 8
+        text = rng.choice(LETTERS, k, p=p)
+        bad = rng.random(k) < refused
+        text[bad] = rng.choice(REFUSED, int(bad.sum()))
+        out.append(text.astype(np.uint8).tobytes())
+    return out
+
+
+def codes_of(text: bytes) -> np.ndarray:
+    """4-bit codes of FASTA bytes, for reads that are copies of the reference (make_edit_friendly); a refused byte: N"""
+    t = np.full(256, 15, dtype=np.uint8)
+    for i, ch in enumerate(lm.BASES):
+        t[ord(ch)] = i
+        t[ord(ch.lower())] = i
+    return t[np.frombuffer(text, dtype=np.uint8)]
+
+
+def setting(seed, edits):
+    rng = np.random.default_rng(77_000 + seed)
+    n_refs = int(rng.integers(1, 5))
+    ref_len = [int(rng.integers(250, 6000)) for _ in range(n_refs)]
+    primary = [int(rng.random() < 0.8) for _ in range(n_refs)]
+    names = [f"s{i}" for i in range(n_refs)]
+    n = int(rng.integers(200, 1500))
+    max_len = int(rng.choice([36, 100, 101, 150, 250]))
+    hb = random_batch(rng, n, ref_len, max_len=max_len, min_len=int(rng.integers(0, max_len + 1)), weird=bool(rng.integers(0, 2)))
+    fasta = random_fasta(rng, ref_len) if edits else None
+    if edits:   # reads that mostly are the reference, under CIGARs that consume them (flags stay random)
+        hb = make_edit_friendly(hb, rng, [np.resize(codes_of(t), L) for t, L in zip(fasta, ref_len)], ref_len)
+    m = int(rng.integers(0, 400))
+    fr = rng.integers(0, n_refs, m).astype(np.uint32)
+    fs = np.array([rng.integers(1, ref_len[r] + 1) for r in fr], dtype=np.uint32)
+    fe = fs + np.where(rng.random(m) < 0.1, 0, rng.integers(0, 900, m)).astype(np.uint32)
+    fn = rng.choice(5, m).astype(np.uint32)
+    roles = tuple(int(x) for x in rng.choice([0, 1, 2, 3, 4], 5)) if rng.random() < 0.4 else (0, 1, 2, 3, 4)
+    bin_size = int(rng.choice([7, 100, 1000, 50_000]))
+    return dict(rng=rng, ref_len=ref_len, primary=primary, names=names, hb=hb, fasta=fasta, feat=(fr, fn, fs, fe, roles),
+                bin_size=bin_size, gc_seed=seed)
+
+
+def model_kwargs(s):
+    fr, fn, fs, fe, roles = s["feat"]
+    kw = dict(bin_size=s["bin_size"], gc_seed=s["gc_seed"],
+              intervals=[(int(r), f"t{int(t)}", int(a), int(b)) for r, t, a, b in zip(fr, fn, fs, fe)],
+              role_names=tuple(f"t{k}" for k in roles))
+    if s["fasta"] is not None:
+        kw["fasta"] = dict(zip(s["names"], s["fasta"]))
+    return kw
+
+
+def stops(records, s):
+    """Indices of the records the reference would stop at, each judged on facets of its own (what a record does to a
+    facet that stops at it is nobody's business: the run is over)."""
+    kw = model_kwargs(s)
+    bad = set()
+    g, c, t, q = lm.General(), lm.GcContent(s["gc_seed"]), lm.TemplateLength(1024), lm.QualityScore()
+    f = lm.Features(s["names"], s["primary"], kw["intervals"], kw["role_names"])
+    cov = lm.Coverage(s["names"], s["primary"], s["bin_size"])
+    eds = {}
+    if s["fasta"] is not None:
+        for name, L in zip(s["names"], s["ref_len"]):
+            eds[name] = lm.Edits(kw["fasta"])
+            eds[name].setup(name, L)
+    for i, rec in enumerate(records):
+        try:
+            for facet in (g, f, c, t, q):
+                facet.process(rec)
+            if 0 <= rec.ref_id < len(s["names"]):
+                name, L = s["names"][rec.ref_id], s["ref_len"][rec.ref_id]
+                if any(True for _ in lm.query([rec], rec.ref_id, L)):
+                    if cov.supports(name):
+                        cov.process(name, L, rec)
+                    if eds:
+                        eds[name].process(name, L, rec)
+        except lm.Abort:
+            bad.add(i)
+    return bad
+
+
+def oracle_of(s, hb):
+    facets = ffi.FACETS_DEFAULT | ffi.FACET_FEATURES | (ffi.FACET_EDITS if s["fasta"] is not None else 0)
+    kw = dict(facets=facets, bin_size=s["bin_size"], gc_seed=s["gc_seed"], max_read_len=320)
+    if s["fasta"] is not None:
+        kw["ref_bases"] = [oracle_py.fasta_codes(t) for t in s["fasta"]]
+        kw["ref_bases_len"] = [len(t) for t in s["fasta"]]
+    orc = oracle_py.Oracle(s["ref_len"], s["primary"], **kw)
+    orc.set_features(*s["feat"])
+    orc.process_batch(hb)
+    return orc
+
+
+@pytest.mark.parametrize("edits", [False, True], ids=["six_facets", "all_seven"])
+@pytest.mark.parametrize("seed", range(20))
+def test_oracle_equals_the_literal_model(seed, edits):
+    s = setting(seed, edits)
+    hb = s["hb"]
+    records = lm.records_of(hb)
+    bad = stops(records, s)
+    # (1) the whole batch: the oracle counts an error iff the reference would have stopped somewhere
+    orc = oracle_of(s, hb)
+    orc.finalize(allow_malformed=True)
+    errors = orc.error_counts()
+    assert bool(bad) == any(errors.values()), (sorted(bad)[:5], errors)
+    orc.close()
+    # (2) without those records: the same document
+    keep = np.array([i for i in range(hb.n) if i not in bad], dtype=np.int64)
+    clean = take_records(hb, keep)
+    clean.first_record_index = 0
+    orc = oracle_of(s, clean)
+    assert orc.finalize() == 0 and not any(orc.error_counts().values())
+    want = lm.run(lm.records_of(clean), s["names"], s["ref_len"], s["primary"], **model_kwargs(s))
+    json_equal(orc.results(s["names"]), want)
+    orc.close()
+    assert keep.size > hb.n // 4, "the sample must not be mostly records the reference stops at"
+
+
+def test_literal_histogram_on_the_reference_vectors():
+    """src/utils/histogram.rs:414-463, 514-523 -- the model's Histogram is the reference's"""
+    h = lm.Histogram(100)
+    for b, v in ((25, 1), (50, 1), (75, 3), (100, 5)):
+        assert h.increment_by(b, v)
+    assert h.mean() == 80.0 and h.percentile(0.25) == 75.0 and h.median() == 87.5 and h.percentile(0.75) == 100.0
+    assert lm.Histogram(5000).median() is None and not lm.Histogram(100).increment(101)
+    h = lm.Histogram(5000)
+    for b, v in ((0, 2500), (10, 2500), (100, 2500), (5000, 5000)):
+        h.increment_by(b, v)
+    assert h.median() == 100.0
+    h.increment_by(200, 2500)
+    assert h.median() == 150.0
+    h.increment(200)
+    assert h.median() == 200.0
+    h = lm.Histogram(3)
+    for b, v in ((0, 5), (1, 3), (2, 6)):
+        h.increment_by(b, v)
+    assert [h.count_from_top_until(b) for b in (3, 2, 1, 0)] == [0, 6, 9, 14]
+
+
+def test_literal_stepthrough_on_the_reference_vectors():
+    """src/utils/alignment.rs:134-202 through the model's Edits.process"""
+    def edits_of(ref, read, cigar):
+        e = lm.Edits({"s": ref.encode()})
+        e.setup("s", len(ref))
+        ops = [(k, int(n)) for n, k in __import__("re").findall(r"(\d+)([MIDNSHP=X])", cigar)]
+        rec = lm.Record(0, 0x40, 60, 0, 0, -1, 0, ops, [lm.BASES.index(ch) for ch in read], [])
+        e.process("s", len(ref), rec)
+        return next(i for i, v in enumerate(e.one.values) if v)
+    assert edits_of("ACTG", "ACTG", "4M") == 0 and edits_of("ACTG", "AATG", "4M") == 1 and edits_of("ACTG", "ACTGACTG", "4M4S") == 0
+    with pytest.raises(lm.Abort, match="consume a record base"):
+        edits_of("ACTG", "ACTGACTG", "4M5S")
+    with pytest.raises(lm.Abort):   # 3M2D over a four-base reference: the slice start..start+5 does not exist (edits.rs:257-260)
+        edits_of("ACTG", "ACT", "3M2D")
+
+
+def _gold(name):
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)) as f:
+        return json.load(f)
+
+
+def test_literal_model_on_the_hand_goldens():
+    """The documents worked out on paper (tests/golden/make_hand_goldens*.py) judge the second reading too."""
+    from tests.util import batch_from_records
+    g = _gold("hand_six_records.json")
+    cfg = g["config"]
+    got = lm.run(lm.records_of(batch_from_records(g["records"])), cfg["ref_names"], cfg["ref_len"], cfg["ref_is_primary"], bin_size=cfg["bin_size"])
+    json_equal(got, g["expected"])
+    g = _gold("hand_edits_multiseq.json")   # facets 49: General, Coverage, Edits
+    cfg = g["config"]
+    got = lm.run(lm.records_of(batch_from_records(g["records"])), cfg["ref_names"], cfg["ref_len"], cfg["ref_is_primary"], bin_size=cfg["bin_size"],
+                 template_length=False, gc_content=False, quality_scores=False,
+                 fasta={n: s.encode() for n, s in zip(cfg["ref_names"], cfg["ref_bases"])})
+    json_equal(got, g["expected"])
+    g = _gold("hand_softmasked.json")       # [N9]: a soft-masked stretch under reads
+    fasta = {"chrA": b"".join(g["fasta"].encode().split(b"\n")[1:])}
+    recs = lm.records_of(batch_from_records(g["records"]))
+    e = lm.Edits(fasta)
+    e.setup("chrA", g["ref_len"][0])
+    for rec in lm.query(recs, 0, g["ref_len"][0]):
+        e.process("chrA", g["ref_len"][0], rec)
+    sparse = lambda h: {str(i): v for i, v in enumerate(h.values) if v}   # noqa: E731
+    want = g["expected"]
+    assert sparse(e.refs) == want["refs_per_position"] and sparse(e.alts) == want["alts_per_position"]
+    e.teardown("chrA", g["ref_len"][0])
+    e.aggregate()
+    assert sparse(e.one) == want["read_one_edits"] and sparse(e.two) == want["read_two_edits"] and sparse(e.vaf) == want["vaf_histogram"]
+    assert e.summary["mean_edits_read_one"] == want["mean_edits_read_one"] and e.summary["mean_edits_read_two"] == want["mean_edits_read_two"]

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from ngs_amd import ffi, host
-from tests.util import batch_from_records, compare_contexts, json_equal, make_edit_friendly, random_batch
+from tests.util import batch_from_records, compare_contexts, json_equal, make_edit_friendly, random_batch, take_records
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hand_softmasked.json")
 LETTERS = "=ACMGRSVTWYHKDBN"
@@ -233,7 +233,8 @@ def orc_positions(orc, hb, lens, bases, r):
 
 @pytest.mark.gpu
 def test_fasta_lengths_and_bytes_that_are_no_bases(gpu_lib, oracle_mod, tmp_path):
-    """A FASTA sequence shorter than @SQ LN fails the reads that run past ITS end, a longer one changes nothing; a byte
+    """A FASTA sequence shorter than @SQ LN fails the reads that run past ITS end, a longer one changes nothing for reads inside
+    LN (beyond it: test_reads_beyond_ln_inside_a_longer_fasta_sequence); a byte
     Base::try_from refuses fails the reads whose slice start..start+span holds it -- under a deletion or a skip too -- and no
     other (edits.rs:257-261).  The device keeps such positions in a list; the oracle sees them as codes above 15."""
     rng = np.random.default_rng(77)
@@ -246,13 +247,13 @@ def test_fasta_lengths_and_bytes_that_are_no_bases(gpu_lib, oracle_mod, tmp_path
     open(p, "wb").write(text)
     parsed = dict(reversed(parse_fasta(text)))
     assert [len(parsed[n]) for n in names] == fasta_len
-    bases = [oracle_mod.fasta_codes(parsed[n])[:min(fl, L)] for n, fl, L in zip(names, fasta_len, lens)]
+    bases = [oracle_mod.fasta_codes(parsed[n]) for n in names]           # (the FASTA's own lengths: ref_bases_len below)
     assert int((bases[0] > 15).sum()) == 4 and int((bases[3] > 15).sum()) == 1
     clean = [np.where(b > 15, 15, b).astype(np.uint8) for b in bases]
-    padded = [np.concatenate([b, np.full(L - len(b), 15, np.uint8)]) for b, L in zip(clean, lens)]
+    padded = [np.concatenate([b, np.full(max(0, L - len(b)), 15, np.uint8)]) for b, L in zip(clean, lens)]
     hb = make_edit_friendly(random_batch(rng, 30_000, lens, weird=False, min_len=1, max_len=200), rng, padded, lens)
     kw = dict(facets=ffi.FACET_EDITS)
-    orc = oracle_mod.Oracle(lens, ref_bases=bases, ref_bases_len=[min(a, b) for a, b in zip(fasta_len, lens)], **kw)
+    orc = oracle_mod.Oracle(lens, ref_bases=bases, ref_bases_len=fasta_len, **kw)
     orc.process_batch(hb)
     rc = orc.finalize(allow_malformed=True)
     errs = orc.error_counts()
@@ -272,6 +273,83 @@ def test_fasta_lengths_and_bytes_that_are_no_bases(gpu_lib, oracle_mod, tmp_path
         assert gpu.finalize(allow_malformed=True) == rc2
         compare_contexts(gpu, orc2, 4, ffi.FACET_EDITS, 50_000, lens)
     assert 0 < orc2.error_counts()["edits_bad_reference"] < errs["edits_bad_reference"]
+
+
+@pytest.mark.gpu
+def test_reads_beyond_ln_inside_a_longer_fasta_sequence(gpu_lib, oracle_mod, tmp_path):
+    """A FASTA sequence LONGER than @SQ LN: edits.rs:257-261 slices the FASTA's own sequence, so a read may end beyond LN inside
+    it; what stops the run then is refs/alts_per_position.increment().unwrap() (:283-291, LN + 1 bins) -- for an `M` base only.
+    Bases beyond LN under D, N, = or X go through; an M there, a slice beyond the FASTA's end, a refused byte under the tail do
+    not.  (Round 6: until tests/literal_model.py read the source a second time every read ending beyond LN was counted as an
+    abort.)  Three judges: the oracle, the literal model, the numbers worked out here."""
+    from tests import literal_model as lm
+    rng = np.random.default_rng(5)
+    lens, names, fasta_len = [5_000, 900], ["c", "d"], [6_000, 900]
+    text, seqs = awkward_fasta(rng, names, lens, fasta_len=fasta_len, poison={0: [(5_499, ord("!"))]})   # position 5500 of c
+    p = str(tmp_path / "r.fa")
+    open(p, "wb").write(text)
+    parsed = dict(reversed(parse_fasta(text)))
+    codes = oracle_mod.fasta_codes(parsed["c"])
+    letters = "=ACMGRSVTWYHKDBN"
+
+    def read_at(pos0, n):   # the reference's own bases (N where the FASTA has the refused byte)
+        return "".join(letters[c] if c <= 15 else "N" for c in codes[pos0:pos0 + n])
+    recs = [
+        dict(flag=0x40, ref_id=0, pos=4899, cigar="101M50D", seq=read_at(4899, 101), qual=[30] * 101),            # M 4900..5000, D 5001..5050: goes through
+        dict(flag=0x40, ref_id=0, pos=4899, cigar="102M", seq=read_at(4899, 102), qual=[30] * 102),               # an M base at 5001: stops
+        dict(flag=0x40, ref_id=0, pos=4899, cigar="101M2000N", seq=read_at(4899, 101), qual=[30] * 101),          # the slice ends at 7000 > 6000: stops
+        dict(flag=0x80, ref_id=0, pos=4949, cigar="51M10N5X", seq=read_at(4949, 51) + "ACGTA", qual=[30] * 56),   # N and X beyond LN: goes through
+        dict(flag=0x80, ref_id=0, pos=4949, cigar="40M20D5M", seq=read_at(4949, 40) + "ACGTA", qual=[30] * 45),   # the second M at 5010..: stops
+        dict(flag=0x80, ref_id=0, pos=4949, cigar="51M600N5=", seq=read_at(4949, 51) + "ACGTA", qual=[30] * 56),  # the slice holds position 5500: stops
+        dict(flag=0x40, ref_id=0, pos=4989, cigar="11M989D", seq="T" * 11, qual=[30] * 11),                       # ends exactly at the FASTA's 6000... over 5500: stops
+        dict(flag=0x40, ref_id=0, pos=5099, cigar="10M", seq="A" * 10, qual=[30] * 10),                           # starts beyond LN: not yielded by query()
+        dict(flag=0x40, ref_id=1, pos=0, cigar="900M", seq=seqs["d"].decode().upper(), qual=[30] * 900),          # d, whole: no edit
+    ]
+    hb = batch_from_records(recs)
+    bases = [oracle_mod.fasta_codes(parsed[n]) for n in names]
+    kw = dict(facets=ffi.FACET_EDITS)
+    orc = oracle_mod.Oracle(lens, ref_bases=bases, ref_bases_len=fasta_len, **kw)
+    orc.process_batch(hb)
+    assert orc.finalize(allow_malformed=True) == ffi.ERR_MALFORMED_RECORD
+    errs = orc.error_counts()
+    assert errs["edits_bad_reference"] == 5 and sum(errs.values()) == 5, errs
+    r1, r2, _vaf = orc.edits()
+    assert int(r1.sum()) == 2 and int(r2.sum()) == 1 and int(r1[0]) == 2      # the 101M50D read and d; 51M10N5X
+    # the literal model: the same five records stop it, and without them it writes the oracle's document
+    model = lm.records_of(hb)
+    stopped = []
+    for i, rec in enumerate(model):
+        e = lm.Edits(dict(zip(names, [parsed[n] for n in names])))
+        e.setup(names[rec.ref_id], lens[rec.ref_id])
+        try:
+            if any(True for _ in lm.query([rec], rec.ref_id, lens[rec.ref_id])):
+                e.process(names[rec.ref_id], lens[rec.ref_id], rec)
+        except lm.Abort:
+            stopped.append(i)
+    assert stopped == [1, 2, 4, 5, 6]
+    with host.QcContext(lens, ref_fasta=p, ref_names=names, lib=gpu_lib, **kw) as gpu:
+        gpu.process_batch(hb)
+        assert gpu.finalize(allow_malformed=True) == ffi.ERR_MALFORMED_RECORD
+        compare_contexts(gpu, orc, 2, ffi.FACET_EDITS, 50_000, lens)
+        st = gpu.reference_wait()
+        assert (st["invalid_bytes"], st["shorter"], st["longer"]) == (1, 0, 1)
+    # the batch API (ngsq_config.ref_bases_len: 4-bit codes, so without the refused byte -- the 600N read then goes through)
+    clean = [np.where(b > 15, 15, b).astype(np.uint8) for b in bases]
+    orc2 = oracle_mod.Oracle(lens, ref_bases=clean, ref_bases_len=fasta_len, **kw)
+    orc2.process_batch(hb)
+    assert orc2.finalize(allow_malformed=True) == ffi.ERR_MALFORMED_RECORD and orc2.error_counts()["edits_bad_reference"] == 3
+    for layout in ("offsets", "uploaded"):
+        with host.QcContext(lens, ref_bases=clean, ref_bases_len=fasta_len, lib=gpu_lib, **kw) as gpu:
+            gpu.process_batch(hb if layout == "offsets" else gpu.upload(hb))
+            assert gpu.finalize(allow_malformed=True) == ffi.ERR_MALFORMED_RECORD
+            compare_contexts(gpu, orc2, 2, ffi.FACET_EDITS, 50_000, lens)
+    keep = take_records(hb, np.array([0, 3, 7, 8]))
+    orc3 = oracle_mod.Oracle(lens, ref_bases=bases, ref_bases_len=fasta_len, **kw)
+    orc3.process_batch(keep)
+    assert orc3.finalize() == 0
+    want = lm.run(lm.records_of(keep), names, lens, [1, 1], general=False, template_length=False, gc_content=False, quality_scores=False,
+                  coverage=False, fasta=dict(zip(names, [parsed[n] for n in names])))
+    json_equal(orc3.results(names)["edits"], want["edits"])
 
 
 @pytest.mark.gpu

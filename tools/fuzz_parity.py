@@ -20,10 +20,10 @@ from tests.util import (batch_from_records, compare_contexts, coordinate_sorted,
                         take_records, to_fixed_stride)
 
 
-def sorted_sweep(lib, seeds):
+def sorted_sweep(lib, seeds, base=0):
     """Streaming Coverage (sorted_input) against the oracle: random densities (sparse to piles deeper than the
     open-ends list and than cov_cap), span mixes with long skips, several sequences, batches cut anywhere."""
-    for seed in range(seeds):
+    for seed in range(base, base + seeds):
         rng = np.random.default_rng(5000 + seed)
         n_refs = int(rng.integers(1, 4))
         # one seed in three on long sequences: sparse reads, a tile of 256 then owns dozens of LDS windows
@@ -72,11 +72,11 @@ def sorted_sweep(lib, seeds):
     print("sorted sweep ok")
 
 
-def extra_sweep(lib, seeds):
+def extra_sweep(lib, seeds, base=0):
     """Edits (LDS window per tile of sorted reads, eight bases per step) and Genomic Features (bracketed searches per
     tile) against the oracle: sorted and unsorted batches, long skips that leave the window, several sequences with
     and without reference bases / intervals, roles that share names."""
-    for seed in range(seeds):
+    for seed in range(base, base + seeds):
         rng = np.random.default_rng(9000 + seed)
         n_refs = int(rng.integers(1, 4))
         ref_len = [int(rng.integers(300, 60_000)) for _ in range(n_refs)]
@@ -123,7 +123,7 @@ def extra_sweep(lib, seeds):
     print("extra sweep ok")
 
 
-def ingest_sweep(lib, seeds):
+def ingest_sweep(lib, seeds, base=0):
     """Device reader against the host reader, batch for batch and byte for byte, on shapes that stress the record index
     and the column kernels: reads from 1 base to 100 kb (records longer than a 4 KiB piece and than a 64 KiB segment),
     BGZF blocks of 0.7-60 kB, ingest chunks of 1 MiB to 1 GiB (cut records carried over), batches of 257 records to
@@ -132,7 +132,7 @@ def ingest_sweep(lib, seeds):
     from tests.test_device_ingest_gpu import read_all_device, same_batches
     td = tempfile.mkdtemp(prefix="ngsq_fuzz_ingest_")
     ctx = host.QcContext([100_000, 50_000], [1, 1], lib=lib)
-    for seed in range(seeds):
+    for seed in range(base, base + seeds):
         rng = np.random.default_rng(9000 + seed)
         max_len = int(rng.choice([1, 3, 36, 150, 151, 300, 1000, 5000, 20_000, 100_000]))
         n = int(rng.integers(1, max(2, min(30_000, 6_000_000 // max(max_len, 40)))))
@@ -164,7 +164,7 @@ def ingest_sweep(lib, seeds):
     print("ingest sweep ok")
 
 
-def genome_sweep(lib, seeds):
+def genome_sweep(lib, seeds, base=0):
     """All seven facets on headers of up to 200 sequences (no seed had more than four): the 195 @SQ lines of the
     GRCh38 no-alt analysis set with its chromosomes scaled down by a random factor, or a random header of 5-200 sequences of
     40 bp to 3 Mbp; records on a random subset of the sequences (empty ones in between), raw or clean, sorted (then also
@@ -172,7 +172,7 @@ def genome_sweep(lib, seeds):
     from tests import genome_util as gu
     from tests.util import make_edit_friendly
     facets = ffi.FACETS_DEFAULT | ffi.FACET_EDITS | ffi.FACET_FEATURES
-    for seed in range(seeds):
+    for seed in range(base, base + seeds):
         rng = np.random.default_rng(12000 + seed)
         if seed % 2 == 0:
             names, lens, primary = gu.header(int(rng.choice([64, 256, 1024, 4096])))
@@ -230,18 +230,19 @@ def main():
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--sorted", type=int, default=0, help="seeds of the sorted_input (streaming Coverage) sweep")
     ap.add_argument("--ingest", type=int, default=0, help="seeds of the device-reader-against-host-reader sweep")
+    ap.add_argument("--seed-base", type=int, default=0, help="first seed of every sweep (a soak behind an earlier one takes up where that left off)")
     a = ap.parse_args()
     lib = ffi.load_library()
     if a.genome:
-        genome_sweep(lib, a.genome)
+        genome_sweep(lib, a.genome, a.seed_base)
     if a.sorted:
-        sorted_sweep(lib, a.sorted)
+        sorted_sweep(lib, a.sorted, a.seed_base)
     if a.extra:
-        extra_sweep(lib, a.extra)
+        extra_sweep(lib, a.extra, a.seed_base)
     if a.ingest:
-        ingest_sweep(lib, a.ingest)
+        ingest_sweep(lib, a.ingest, a.seed_base)
     td = tempfile.mkdtemp(prefix="ngsq_fuzz_")
-    for seed in range(a.seeds):
+    for seed in range(a.seed_base, a.seed_base + a.seeds):
         rng = np.random.default_rng(1000 + seed)
         n_refs = int(rng.integers(1, 5))
         ref_len = [int(rng.integers(200, 80_000)) for _ in range(n_refs)]
