@@ -210,3 +210,61 @@ def test_literal_model_on_the_hand_goldens():
     e.aggregate()
     assert sparse(e.one) == want["read_one_edits"] and sparse(e.two) == want["read_two_edits"] and sparse(e.vaf) == want["vaf_histogram"]
     assert e.summary["mean_edits_read_one"] == want["mean_edits_read_one"] and e.summary["mean_edits_read_two"] == want["mean_edits_read_two"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_record_by_record_the_same_records_stop_both(seed):
+    """Random CIGARs with Edits on (nearly every mapped read then fails somewhere in the walk): record by record, the model
+    stops at it <=> the oracle counts an error for it -- and for the others the two write the same Edits document."""
+    rng = np.random.default_rng(91_000 + seed)
+    n_refs = int(rng.integers(1, 4))
+    ref_len = [int(rng.integers(120, 900)) for _ in range(n_refs)]
+    names = [f"s{i}" for i in range(n_refs)]
+    primary = [1] * n_refs
+    fasta = random_fasta(rng, ref_len, refused=0.002)
+    hb = random_batch(rng, 260, ref_len, max_len=int(rng.choice([20, 60, 130])), min_len=0, weird=True)
+    c = hb.cols
+    # short operations so that some walks end well: spans stay inside the sequences now and then
+    c["cigar"][:] = (c["cigar"] & np.uint32(15)) | ((c["cigar"] >> np.uint32(4)) % np.uint32(23)) << np.uint32(4)
+    c["flag"] &= np.uint16(0xFFFF ^ 0x404) | np.uint16(0x404 if seed == 0 else 0)   # (seed 0 keeps unmapped / duplicate reads)
+    s = dict(ref_len=ref_len, primary=primary, names=names, fasta=fasta, bin_size=50, gc_seed=seed,
+             feat=(np.zeros(0, np.uint32),) * 4 + ((0, 1, 2, 3, 4),))
+    records = lm.records_of(hb)
+    bad = stops(records, s)
+    agree_ok = 0
+    category = {"general.rs:81-83": "missing_reference_id", "features.rs:133-141": "features_missing_reference_id",
+                "features.rs:171-174": "features_missing_position", "edits.rs:257-260": "edits_bad_reference", "edits.rs:263": "edits_bad_reference",
+                "edits.rs:283-285": "edits_bad_reference", "edits.rs:287-289": "edits_bad_reference", "alignment.rs:76-79": "edits_record_short",
+                "alignment.rs:100-101": "edits_not_consumed", "alignment.rs:102-103": "edits_not_consumed", "edits.rs:296-300": "edits_too_many"}
+    seen = set()
+    for i in range(hb.n):
+        one = take_records(hb, np.array([i]))
+        one.first_record_index = i
+        orc = oracle_of(s, one)
+        orc.finalize(allow_malformed=True)
+        errs = orc.error_counts()
+        assert any(errs.values()) == (i in bad), (i, errs, records[i].cigar, records[i].pos, records[i].ref_id, len(records[i].seq))
+        # facet by facet (the oracle counts in every facet, the reference would have stopped in the first): the same places
+        rec, mine = records[i], set()
+        trials = [lambda: lm.General().process(rec), lambda: lm.Features(names, primary, [], ("t0", "t1", "t2", "t3", "t4")).process(rec)]
+        if 0 <= rec.ref_id < n_refs and any(True for _ in lm.query([rec], rec.ref_id, ref_len[rec.ref_id])):
+            def edits_trial():
+                e = lm.Edits(dict(zip(names, fasta)))
+                e.setup(names[rec.ref_id], ref_len[rec.ref_id])
+                e.process(names[rec.ref_id], ref_len[rec.ref_id], rec)
+            trials.append(edits_trial)
+        for t in trials:
+            try:
+                t()
+            except lm.Abort as a:
+                mine.add(category[a.where])
+        assert mine == {k for k, v in errs.items() if v}, (i, mine, errs)
+        seen |= mine
+        if i not in bad:
+            rec = lm.records_of(one)
+            want = lm.run(rec, names, ref_len, primary, bin_size=50, gc_seed=seed, fasta=dict(zip(names, fasta)), intervals=[], role_names=("t0", "t1", "t2", "t3", "t4"))
+            json_equal(orc.results(names), want)
+            agree_ok += 1
+        orc.close()
+    assert 10 < agree_ok < hb.n - 10, (agree_ok, hb.n)
+    assert {"edits_bad_reference", "edits_record_short", "edits_not_consumed"} <= seen
