@@ -26,7 +26,9 @@
  *     4-bit BAM codes; any other byte is invalid, and, as in the reference, only a read that COVERS it (alignment start ..
  *     start + reference span, whatever the CIGAR operations) fails -- counted as edits_bad_reference;
  *   - a FASTA sequence shorter than its @SQ LN fails only the reads that run past its end (the reference's unwrap on
- *     `get`); a longer one, or records the BAM has no @SQ for, change nothing.
+ *     `get`); inside a LONGER one a read may end beyond LN and fails only if an `M` base lies there (edits.rs:283-291:
+ *     the per-position histograms have LN + 1 bins) or its slice holds an invalid byte; records the BAM has no @SQ
+ *     for change nothing.
  */
 #ifndef NGSQ_REFERENCE_H
 #define NGSQ_REFERENCE_H
@@ -79,7 +81,7 @@ typedef struct ngsq_reference_stats {
     uint64_t invalid_bytes;   /* bytes Base::try_from refuses (kept as positions: see above)   */
     uint32_t sequences;       /* sequences installed                                           */
     uint32_t shorter;         /* of them: shorter in the FASTA than their @SQ LN               */
-    uint32_t longer;          /* ... longer (the bases beyond LN are dropped)                   */
+    uint32_t longer;          /* ... longer (of the bases beyond LN only the count and the invalid positions are kept) */
     uint32_t reserved;
     double index_wait_s;      /* waiting for the definition-line index                         */
     double read_s;            /* first pread to last host-to-device copy queued                */

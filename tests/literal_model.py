@@ -175,8 +175,8 @@ def records_of(hb) -> List[Record]:
             codes += [int(b) >> 4, int(b) & 15]
         codes = codes[:l]
         q = [int(x) for x in c["qual"][int(c["qual_off"][i]):int(c["qual_off"][i + 1])]]
-        if q and all(x == 0xFF for x in q):
-            q = []                                                            # [N6]
+        # ([N6]: BAM's 0xFF-filled QUAL is an EMPTY score list -- in the offsets layout of include/ngsq.h that is zero bytes, the
+        # readers' job; a 0xFF that does reach a batch this way is a score of 255)
         if any(x > 93 for x in q):
             raise Abort("noodles-bam", "invalid quality score")               # [N6]
         out.append(Record(int(rid[i]) if rid is not None else hb.first_record_index + i, int(c["flag"][i]), int(c["mapq"][i]),

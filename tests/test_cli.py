@@ -285,6 +285,9 @@ def test_edits_with_reference_fasta(ngs, gpu_lib, oracle_mod, tmp_path):
     want = oracle_json(oracle_mod, hb, facets=ffi.FACETS_DEFAULT | ffi.FACET_EDITS, ref_bases=bases)
     json_equal(got, want)
     assert sum(got["edits"]["read_one_edits"]["values"][1:]) > 0 and sum(got["edits"]["vaf_histogram"]["values"]) > 0
+    from tests import literal_model as lm   # the second reading of the source, fed the FASTA's letters
+    json_equal(got, lm.run(lm.records_of(hb), NAMES, LENS, PRIMARY, gc_seed=0x4E4753,
+                           fasta={name: "".join(letters[x] for x in b).encode() for name, b in zip(NAMES, bases)}))
     # --vaf-file (edits.rs:134-151, :320-341): one line per covered position, in header order; binning the
     # written f32 values the way the facet does reproduces the VAF histogram; Rust's f32 Display
     vaf = tmp_path / "vafs.tsv"
@@ -324,13 +327,14 @@ def test_genomic_features_with_gff(ngs, gpu_lib, oracle_mod, tmp_path):
     hb = bamio.with_ids(hb, bamio.write_bam(bam, hb, NAMES, LENS))
     rng = np.random.default_rng(8)
     types = ["five_prime_UTR", "three_prime_UTR", "CDS", "exon", "gene", "transcript", "start_codon"]
-    rows, model = ["##gff-version 3", "#comment"], []
+    rows, model, every_row = ["##gff-version 3", "#comment"], [], []
     for _ in range(400):
         seq = int(rng.integers(0, 4))
         s = int(rng.integers(1, LENS[seq]))
         e = min(LENS[seq], s + int(rng.integers(0, 3000)))
         t = types[int(rng.integers(0, len(types)))]
         rows.append(f"{NAMES[seq]}\tHAVANA\t{t}\t{s}\t{e}\t.\t{'+-'[int(rng.integers(0, 2))]}\t.\tID=x")
+        every_row.append((seq, t, s, e))
         if t in types[:5] and PRIMARY[seq]:
             model.append((seq, types.index(t), s, e))
     rows += ["chr9\tHAVANA\tgene\t5\t900\t.\t+\t.\tID=primary_but_not_in_this_bam", "##FASTA", ">junk", "ACGT"]
@@ -346,6 +350,8 @@ def test_genomic_features_with_gff(ngs, gpu_lib, oracle_mod, tmp_path):
     o.finalize()
     json_equal(got, o.results(NAMES))
     assert got["features"]["records"]["processed"] > 1000 and got["features"]["gene_regions"]["exonic_count"] > 0
+    from tests import literal_model as lm   # the second reading sorts the GFF's rows into its stores itself (features.rs:288-341)
+    json_equal(got, lm.run(lm.records_of(hb), NAMES, LENS, PRIMARY, gc_seed=0x4E4753, intervals=every_row, role_names=tuple(types[:5])))
     # --only selects it by its display name, case-insensitively (qc.rs:101-123)
     r = run(ngs, "-q", "qc", bam, GENOME, "-f", gff, "-o", str(tmp_path), "--only", "genomic features")
     assert r.returncode == 0, r.stderr

@@ -268,3 +268,63 @@ def test_record_by_record_the_same_records_stop_both(seed):
         orc.close()
     assert 10 < agree_ok < hb.n - 10, (agree_ok, hb.n)
     assert {"edits_bad_reference", "edits_record_short", "edits_not_consumed"} <= seen
+
+
+def _both(recs_one, ref_len, facets, model_kw, oracle_kw):
+    """One record through both readings: ('same', document) or ('stop', the oracle's error counts, the model's place)."""
+    from tests.util import batch_from_records
+    hb = batch_from_records([dict(mapq=9, **recs_one)])
+    o = oracle_py.Oracle(ref_len, [1] * len(ref_len), facets=facets, **oracle_kw)
+    o.process_batch(hb)
+    o.finalize(allow_malformed=True)
+    errs = {k: v for k, v in o.error_counts().items() if v}
+    names = [f"s{i}" for i in range(len(ref_len))]
+    try:
+        want = lm.run(lm.records_of(hb), names, ref_len, [1] * len(ref_len), **model_kw)
+    except lm.Abort as a:
+        assert errs, (recs_one, a)
+        return "stop", errs, a.where
+    assert not errs, (recs_one, errs)
+    json_equal({k: v for k, v in o.results(names).items() if v is not None}, {k: v for k, v in want.items() if v is not None})
+    return "same", want, None
+
+
+def test_corner_records_in_both_readings():
+    """The corners of [N3]-[N6] and of the Edits walk, one record at a time: what each reading makes of it, and that they agree."""
+    d = dict
+    kw = (dict(bin_size=7), dict(bin_size=7))
+    L = [50]
+    out = [_both(r, L, ffi.FACETS_DEFAULT, *kw) for r in (
+        d(flag=0, ref_id=0, pos=3, cigar="4M", seq="ACGT", qual=[255] * 4),       # 0xFF in an offsets batch is a score of 255: a decode error
+        d(flag=0, ref_id=0, pos=3, cigar="4M", seq="ACGT", qual=[93, 0, 1, 2]),
+        d(flag=0, ref_id=0, pos=3, cigar="4M", seq="ACGT", qual=[94, 0, 1, 2]),
+        d(flag=0, ref_id=0, pos=3, cigar="4M", seq="ACGT", qual=None),
+        d(flag=0, ref_id=0, pos=0, cigar="2S", seq="AC", qual=[1, 2]),            # span 0 at start 1: alignment_end() is None, not yielded
+        d(flag=0, ref_id=0, pos=1, cigar="2S", seq="AC", qual=[1, 2]),            # span 0 at start 2: yielded, covers nothing
+        d(flag=0, ref_id=0, pos=49, cigar="5M", seq="ACGTA", qual=[1] * 5),       # crosses LN: four positions without a bin
+        d(flag=0, ref_id=0, pos=50, cigar="5M", seq="ACGTA", qual=[1] * 5))]      # starts beyond LN: not yielded
+    assert [o[0] for o in out] == ["stop", "same", "stop", "same", "same", "same", "same", "same"]
+    assert out[0][1] == {"bad_quality_score": 4} and out[2][1] == {"bad_quality_score": 1}
+    cov = [o[1]["coverage"] if o[0] == "same" else None for o in out]
+    assert cov[4]["mean_coverage"] == {} and list(cov[5]["mean_coverage"]) == ["s0"] and cov[5]["coverage_distribution"]["values"][0] == 51
+    assert cov[6]["ignored"]["nonsensical_records"] == 4 and cov[7]["mean_coverage"] == {}
+    fa = (b"ACGT" * 200)[:650]                                                    # LN 700, 650 bases in the FASTA
+    only = dict(general=False, template_length=False, gc_content=False, quality_scores=False, coverage=False, fasta={"s0": fa})
+    okw = dict(ref_bases=[oracle_py.fasta_codes(fa)], ref_bases_len=[len(fa)], max_read_len=700)
+    out = [_both(r, [700], ffi.FACET_EDITS, only, okw) for r in (
+        d(flag=0, ref_id=0, pos=1, cigar="4S", seq="ACGT", qual=[1] * 4),         # span 0, start 2: walked, no edit
+        d(flag=0, ref_id=0, pos=0, cigar="4S", seq="ACGT", qual=[1] * 4),         # span 0, start 1: not yielded
+        d(flag=0, ref_id=0, pos=5, cigar="*", seq="ACGT", qual=[1] * 4),          # no operation for four bases
+        d(flag=0, ref_id=0, pos=5, cigar="*", seq="", qual=None),
+        d(flag=0, ref_id=0, pos=650, cigar="3S", seq="ACG", qual=[1] * 3),        # get(651..651) of 650 bases: an empty slice
+        d(flag=0, ref_id=0, pos=651, cigar="3S", seq="ACG", qual=[1] * 3),        # get(652..652): None
+        d(flag=0x40, ref_id=0, pos=0, cigar="600M", seq="T" * 600, qual=[1] * 600),
+        d(flag=0x40, ref_id=0, pos=0, cigar="640M", seq="N" * 640, qual=[1] * 640),   # 640 edits: no such bin
+        d(flag=0, ref_id=0, pos=9, cigar="2M3I2M", seq="ACGTACG", qual=[1] * 7),
+        d(flag=0, ref_id=0, pos=9, cigar="3H2M1P2M3H", seq="GTAC", qual=[1] * 4),
+        d(flag=0, ref_id=0, pos=9, cigar="2=2X", seq="TTTT", qual=[1] * 4))]      # = and X are never compared
+    assert [o[0] for o in out] == ["same", "same", "stop", "same", "same", "stop", "same", "stop", "same", "same", "same"]
+    assert (out[2][1], out[5][1], out[7][1]) == ({"edits_not_consumed": 1}, {"edits_bad_reference": 1}, {"edits_too_many": 1})
+    e = [o[1]["edits"] if o[0] == "same" else None for o in out]
+    assert e[0]["read_two_edits"]["values"][0] == 1 and sum(e[1]["read_two_edits"]["values"]) == 0 and e[6]["read_one_edits"]["values"][450] == 1
+    assert e[8]["read_two_edits"]["values"][4] == 1 and e[9]["read_two_edits"]["values"][4] == 1 and e[10]["read_two_edits"]["values"][0] == 1
