@@ -548,8 +548,13 @@ static int check_batch(ngsq_ctx *c, const ngsq_batch *b, uint32_t facets) {
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Template Length needs tlen");
     if ((facets & (NGSQ_FACET_GC_CONTENT | NGSQ_FACET_EDITS)) && (!b->l_seq || !b->seq))
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "GC Content / Edits need l_seq and seq");
-    if ((facets & NGSQ_FACET_GC_CONTENT) && b->location == NGSQ_MEM_DEVICE && b->seq_off && !b->seq_bytes)
-        return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "device batch with seq_off needs seq_bytes");
+    if ((facets & NGSQ_FACET_GC_CONTENT) && b->location == NGSQ_MEM_DEVICE && b->seq_off && !b->seq_bytes) {
+        // 0 is also what a batch of reads without bases has (found by the parity sweep: a slice of records with l_seq 0, uploaded):
+        // the offsets say which -- eight bytes read back, on this path only
+        uint64_t end = 0;
+        if (hipMemcpy(&end, b->seq_off + b->n_records, sizeof end, hipMemcpyDeviceToHost) != hipSuccess || end != 0)
+            return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "device batch with seq_off needs seq_bytes");
+    }
     if ((facets & NGSQ_FACET_QUALITY_SCORE) && (!b->qual || (!b->qual_off && !b->l_seq)))
         return fail(c, NGSQ_ERR_INVALID_ARGUMENT, "Quality Score needs qual (+ l_seq or qual_off)");
     if ((facets & (NGSQ_FACET_COVERAGE | NGSQ_FACET_EDITS)) && (!b->ref_id || !b->pos || !b->n_cigar))

@@ -280,6 +280,22 @@ def test_no_records_gives_null_summaries(gpu_lib, oracle_mod):
     assert r["general"]["summary"]["mapped_pct"] is None and r["quality_scores"] == {"scores": {}}
 
 
+def test_device_batch_of_reads_without_bases(gpu_lib, oracle_mod):
+    """Every read of an uploaded offsets-layout batch has l_seq 0: seq_bytes is 0 because the column is empty, not because the
+    caller left it out (the parity sweep's seed 554 of round 6: refused as "needs seq_bytes" until then)."""
+    recs = [dict(flag=f, mapq=30, ref_id=0, pos=p, mate_ref_id=-1, tlen=0, cigar=c, seq="", qual=None)
+            for f, p, c in ((0, 5, "10M"), (0x10, 7, "*"), (0x4, -1, "*"), (0x400, 9, "3M2D3M"))]
+    hb = batch_from_records(recs)
+    orc = oracle_mod.Oracle([500], bin_size=100, max_read_len=320)
+    orc.process_batch(hb)
+    orc.finalize()
+    with host.QcContext([500], bin_size=100, max_read_len=320, lib=gpu_lib) as gpu:
+        gpu.process_batch(gpu.upload(hb))
+        gpu.finalize()
+        compare_contexts(gpu, orc, 1, ffi.FACETS_DEFAULT, 100, [500])
+        assert gpu.gc_content()["ignored_too_short"] == 3 and gpu.gc_content()["ignored_flags"] == 1
+
+
 def test_facet_subsets(gpu_lib, oracle_mod):
     """`--only FACET` (qc.rs:101-123): every other top-level key is null."""
     rng = np.random.default_rng(5)
