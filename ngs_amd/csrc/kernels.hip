@@ -75,6 +75,18 @@ __device__ __forceinline__ void gc_dword(uint32_t x, uint32_t mask, uint32_t &gc
     at += __popc((x ^ u) & ~(y | z) & mask); // nibble == 0001 or 1000
 }
 
+#ifndef NGSQ_GC_AHEAD
+#define NGSQ_GC_AHEAD 1 // measurement builds: 0 = every load when its turn comes
+#endif
+// Round 6: what says WHERE a record's window lies -- its flag, its length, its row's offset, its identity -- is requested an
+// iteration ahead, unconditionally and from a clamped index (a load under a branch gets a wait of its own from this compiler,
+// DESIGN 5.8; for the same reason OFFS / RID -- the batch has seq_off / record_id -- are compile-time).  An iteration used to
+// wait three or four times in a row: flag, then length, then offset / identity, then the window's bytes, each a round trip
+// to HBM behind the test that needs it; now once, for the window.  Same box, alternating builds: 1.40-1.41 -> 1.34-1.37 ms per
+// 100 M reads of 150 bases, 1.69-1.70 -> 1.62-1.64 on the 50-300 base reads of the offsets layout.  (The window's bytes an
+// iteration ahead as well -- a two-stage pipeline, 66-75 registers -- measured 1.62 on the offsets layout and 2.65 on
+// fixed-pitch rows: not kept.)
+template <bool OFFS, bool RID>
 __global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b, uint64_t seq_bytes) {
     NGSQ_FOREGROUND_WAVE();
     __shared__ uint32_t s_hist[NGSQ_GC_BINS];
@@ -87,20 +99,39 @@ __global__ __launch_bounds__(256) void k_gc(DeviceState st, DeviceBatch b, uint6
 
     uint64_t lo, hi;
     block_slice(b.n, lo, hi);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t f = b.flag[i];
-        if (f & 0x500u) { // duplicate | secondary  gc_content.rs:41-45
+    struct Info {
+        uint32_t f, l;
+        uint64_t row, rid;
+    };
+    auto fetch = [&](uint64_t j) -> Info { // (j < n)
+        Info r;
+        r.f = b.flag[j];
+        r.l = b.l_seq[j];
+        r.row = OFFS ? b.seq_off[j] : j * (uint64_t)b.seq_stride;
+        r.rid = RID ? b.record_id[j] : b.first_record_index + j;
+        return r;
+    };
+    const uint64_t step = blockDim.x, i0 = lo + threadIdx.x;
+    Info nx{0, 0, 0, 0};
+    if (NGSQ_GC_AHEAD && i0 < hi) nx = fetch(i0);
+    for (uint64_t i = i0; i < hi; i += step) {
+        Info r;
+        if (NGSQ_GC_AHEAD) {
+            r = nx;
+            nx = fetch(i + step < hi ? i + step : i); // (behind the slice: this record's columns again)
+        } else {
+            r = fetch(i);
+        }
+        if (r.f & 0x500u) { // duplicate | secondary  gc_content.rs:41-45
             c[4] += 1;
             continue;
         }
-        const uint32_t l = b.l_seq[i];
-        if (l < NGSQ_GC_WINDOW) { // :59-62
+        if (r.l < NGSQ_GC_WINDOW) { // :59-62
             c[5] += 1;
             continue;
         }
-        const uint32_t off = ngsq_gc_offset_fn(st.gc_seed, b.record_id ? b.record_id[i] : b.first_record_index + i, l); // :68-74
-        const uint64_t row = b.seq_off ? b.seq_off[i] : i * (uint64_t)b.seq_stride;
-        const uint64_t p = row + (off >> 1);
+        const uint32_t off = ngsq_gc_offset_fn(st.gc_seed, r.rid, r.l); // :68-74
+        const uint64_t p = r.row + (off >> 1);
         const uint32_t odd = off & 1u;
         uint32_t x[13];
         if (p + 52 <= seq_bytes) {
@@ -216,7 +247,10 @@ hipError_t launch_gc(const LaunchInfo &li, const DeviceState &st, const DeviceBa
                      hipStream_t s) {
     if (!b.n) return hipSuccess;
     const uint32_t grid = grid_for(b.n, 256 * 4, li.n_cu * 8);
-    hipLaunchKernelGGL(k_gc, dim3(grid), dim3(256), 0, s, st, b, seq_bytes);
+    if (b.seq_off && b.record_id) hipLaunchKernelGGL((k_gc<true, true>), dim3(grid), dim3(256), 0, s, st, b, seq_bytes);
+    else if (b.seq_off) hipLaunchKernelGGL((k_gc<true, false>), dim3(grid), dim3(256), 0, s, st, b, seq_bytes);
+    else if (b.record_id) hipLaunchKernelGGL((k_gc<false, true>), dim3(grid), dim3(256), 0, s, st, b, seq_bytes);
+    else hipLaunchKernelGGL((k_gc<false, false>), dim3(grid), dim3(256), 0, s, st, b, seq_bytes);
     return hipGetLastError();
 }
 
