@@ -549,7 +549,9 @@ int load_main(Loader *L) {
         S.longer += h_back[k] > Lr;
         lens[r] = (uint32_t)std::min<uint64_t>(h_back[k], 0xFFFFFFFFull); // the FASTA's own count: a read may end beyond LN inside a longer sequence
         std::sort(bad[r].begin(), bad[r].end());
-        lens[nr + r] = bad[r].empty() ? (uint32_t)have : 0u; // a sequence with listed positions: every record takes the walk, which looks them up
+        // a sequence with listed positions INSIDE what the window lanes may reach: every record takes the walk, which looks them up
+        // (positions beyond LN are only ever under reads that end beyond LN -- the walk's anyway)
+        lens[nr + r] = bad[r].empty() || bad[r].front() > have ? (uint32_t)have : 0u;
     }
     S.invalid_bytes = n_bad;
     if (nr) {
