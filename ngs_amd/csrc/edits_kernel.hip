@@ -468,6 +468,9 @@ constexpr uint32_t EDR_TILE = ED_THREADS * 4;    // records a block is launched 
 // waves per SIMD the register allocation is made for: four, what the block's LDS allows (the variant that also tallies GC Content
 // takes 143-148 registers when left alone -- three waves per SIMD: 3.9 ms per 100 M reads against 3.56 at four; the plain variant
 // fits by itself).  NGSQ_EDR_WAVES: measurement builds.
+#ifndef NGSQ_EDR_FAR
+#define NGSQ_EDR_FAR 1 // measurement builds: 0 = a read whose first M reaches beyond the wave's window is the walk kernel's
+#endif
 #ifndef NGSQ_EDR_WAVES
 #define NGSQ_EDR_WAVES 4
 #endif
@@ -837,7 +840,14 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                 // (P >= win_base: a mismatch's window entry is counted from P's)
                 // (RAGGED: the record's bytes hold its bases, at most EDG_MAXW windows of them, within 4 GiB of the pass's first byte)
                 const bool holds = RAGGED ? ((r.l + 1u) >> 1) <= r.sb && r.sb <= 16u * EDG_MAXW - 1u && r.so - so0 < 0xFFFF0000ull : r.l <= 2 * stride;
-                own = shape && m && (uint64_t)a + m + z == r.l && holds && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_E && i0 + m < WIN;
+                // Round 6: a read whose first M reaches beyond the wave's window (sparse data: at 5x the 64 sorted reads of a pass span
+                // 2 k positions, the window holds 1.4 k) stays on the fast path -- its cover goes straight to the difference array and
+                // its mismatches beyond the window's end to alts, as a second M beyond the window always did -- as long as its base 0
+                // lies within the 14 bits the descriptor has for it.  Until then such reads were the one-record walk's: 6.1 ms of
+                // walk + 7.3 ms here per 100 M reads spread over the 3.1 Gbp of a real header (bench.py whole_genome).
+                const bool far1 = i0 + m >= WIN; // (then far2 as well: i1 >= i0 + m)
+                own = shape && m && (uint64_t)a + m + z == r.l && holds && r.ref == win_ref && (uint32_t)r.pos >= a + win_base && e <= meta_E &&
+                      (!far1 || (NGSQ_EDR_FAR && i0 < (1u << 14) - 1024u));
                 if (own) {
                     // the record's descriptor for the window lanes: where its base 0 lies in the packed reference (a byte offset
                     // from ref_bases: the copy that starts at base P & 1), compared bases [v0, v1), window entry of base 0
@@ -845,8 +855,14 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                     vv = a | (a + m) << 9 | (P - win_base) << 18;
                     P = (uint32_t)(meta_boff + (P >> 1)) + (P & 1u ? odd_delta : 0u);
                     if (EDITS_EXP != 2 && EDITS_EXP != 4) {
-                        atomicAdd(&win[i0], 1u);
-                        atomicAdd(&win[i0 + m], 0xFFFFFFFFu);
+                        if (!far1) {
+                            atomicAdd(&win[i0], 1u);
+                            atomicAdd(&win[i0 + m], 0xFFFFFFFFu);
+                        } else {
+                            uint32_t *const diff = st.edits + meta_eoff + win_base;
+                            atomicAdd(&diff[i0], 1u);
+                            atomicAdd(&diff[i0 + m], 0xFFFFFFFFu);
+                        }
                         if (m2 && !far2) {
                             atomicAdd(&win[i0 + m + del], 1u);
                             atomicAdd(&win[i1], 0xFFFFFFFFu);
@@ -856,7 +872,7 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
                             atomicAdd(&diff[i1], 0xFFFFFFFFu);
                         }
                     }
-                    top = max(top, (uint32_t)(far2 ? WIN - 1 : i1)); // (far2: the second M's mismatches below the window's end are tallied in it)
+                    top = max(top, (uint32_t)(far2 || far1 ? WIN - 1 : i1)); // (far: the mismatches below the window's end are tallied in it)
                     // what step 2c needs of the record: first M's length, insertion, parity of P; the gap in an array of its own
                     if (m2) {
                         info = m | ins << 9 | ((uint32_t)r.pos & 1u) << 13; // (m >= 1: never 0; 14 bits, kept above the 10 bits of the edit count)
@@ -951,13 +967,13 @@ __global__ __launch_bounds__(ED_THREADS) EDR_WAVES_ATTR void k_edits_rows(Device
 #pragma unroll 1
             for (uint32_t k = 0; k < n_steps && EDITS_EXP != 3; k += 3) {
                 if (k + 2 < n_steps) wc = load_win();
-                compare_win(wa);
+                compare_win(wa, NGSQ_EDR_FAR != 0);
                 if (k + 1 >= n_steps) break;
                 if (k + 3 < n_steps) wa = load_win();
-                compare_win(wb);
+                compare_win(wb, NGSQ_EDR_FAR != 0);
                 if (k + 2 >= n_steps) break;
                 if (k + 4 < n_steps) wb = load_win();
-                compare_win(wc);
+                compare_win(wc, NGSQ_EDR_FAR != 0);
             }
             // ---- 2c. the second M of the records that have one: lane = window ww of the e-th such record (its row once more, the
             // reference del - ins bases further on -- the other packed copy when that is odd)
