@@ -465,6 +465,54 @@ def test_edits_positions_against_a_literal_walk(gpu_lib, oracle_mod, mode):
         assert r1[:50].sum() + r2[:50].sum() == 0
 
 
+@pytest.mark.parametrize("layout", ["rows", "rows_gc", "offsets"])
+@pytest.mark.parametrize("spacing", [12, 40, 300, 2000])
+def test_edits_on_sparse_sorted_reads(gpu_lib, oracle_mod, layout, spacing):
+    """Sorted reads further apart than a wave's LDS window holds 64 of (low-depth data: 64 x 40 positions against 1408 entries): the
+    reads of a pass beyond the window's end stay on the fast path -- their cover and their mismatches go straight to the arrays
+    (round 6) -- up to the 15 k positions the descriptor can say; at 300 and 2000 apart the later ones of a pass are the walk's.
+    Positions against the literal walk, histograms against the oracle; substitutions in every read, second M's, clips."""
+    rng = np.random.default_rng(1000 + spacing)
+    n = 3000
+    L = [n * spacing + 5000, 5000]
+    bases = random_ref_bases(rng, L)
+    letters = "=ACMGRSVTWYHKDBN"
+    recs = []
+    for i in range(n):
+        pos = i * spacing + int(rng.integers(0, max(1, spacing // 2)))
+        shape = rng.random()
+        l = 150 if layout != "offsets" else int(rng.integers(40, 300))
+        if shape < 0.6:
+            cig, ref_at = f"{l}M", [(pos, 0, l)]
+        elif shape < 0.75:
+            a = int(rng.integers(1, 20))
+            cig, ref_at = f"{a}S{l - a}M", [(pos, a, l)]
+        elif shape < 0.9:
+            a, g = int(rng.integers(5, l - 5)), int(rng.integers(1, 3000))
+            cig, ref_at = f"{a}M{g}{'DN'[int(rng.integers(0, 2))]}{l - a}M", [(pos, 0, a), (pos + a + g, a, l)]
+        else:
+            a, g = int(rng.integers(5, l - 12)), int(rng.integers(1, 9))
+            cig, ref_at = f"{a}M{g}I{l - a - g}M", [(pos, 0, a), (pos + a, a + g, l)]
+        codes = rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), l)
+        for p0, q0, q1 in ref_at:                              # the reference's bases under the M's ...
+            chunk = bases[0][p0:p0 + (q1 - q0)]
+            codes[q0:q0 + len(chunk)] = chunk
+        for k in rng.integers(0, l, int(rng.integers(0, 4))):  # ... with up to three substitutions
+            codes[k] = 15
+        recs.append(dict(flag=int(rng.choice([0, 0x10, 0x40, 0x80])), mapq=60, ref_id=0, pos=pos, mate_ref_id=-1, tlen=0, cigar=cig,
+                         seq="".join(letters[c] for c in codes), qual=[30] * l))
+    hb = batch_from_records(recs)
+    if layout != "offsets":
+        hb = to_fixed_stride(hb)
+    facets = ffi.FACET_EDITS | (ffi.FACET_GC_CONTENT if layout == "rows_gc" else 0)
+    gpu, orc = run_both(oracle_mod, gpu_lib, [hb], L, facets=facets, ref_bases=bases)
+    assert not any(orc.error_counts().values())
+    want_refs, want_alts = brute_force_refs_alts(batch_from_records(recs), L, bases)
+    refs, alts = gpu.edits_positions(0)
+    assert np.array_equal(alts, want_alts[0]) and np.array_equal(refs, want_refs[0])
+    assert int(alts.sum()) > n // 2
+
+
 @pytest.mark.parametrize("mode", ["fixed", "aligner", "subst25", "ragged_rows", "ids"])
 def test_gc_content_tallied_by_the_edits_kernel(gpu_lib, oracle_mod, mode):
     """With GC Content and Edits both enabled, fixed-pitch rows of up to 160 bases are scanned ONCE: k_edits_rows tallies the GC
